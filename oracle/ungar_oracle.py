@@ -1,0 +1,491 @@
+"""TEST INFRASTRUCTURE -- CPU oracle for the ungar_amd hot path.  NOT part of the product.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the
+product (ungar_amd/) never does and fails loudly if its HIP library is missing.
+
+What it is: an independent FP64 restatement (numpy/torch, written separately from the C++ node
+models in ungar_amd/csrc/models/nodes.hpp) of the per-shooting-node functions the reference inlines
+into its whole-horizon tapes, with Jacobians obtained from torch.autograd (an AD implementation that
+shares nothing with the product's tape engine):
+
+  quadrotor_node   /root/reference/example/mpc/quadrotor.example.cpp:126-190
+  rc_car_node      /root/reference/example/mpc/rc_car.example.cpp:131-185
+  srbd_node        /root/reference/example/mpc/quadruped.example.cpp:148-203
+  helpers          /root/reference/include/ungar/utils/utils.hpp:731-749 (ApproximateNorm / -ExponentialMap),
+                   Eigen 3.4.0 quaternion product and quaternion-times-vector formulas
+  aba              /root/reference/include/ungar/rbd/quantities/generalized_accelerations.hpp:42-43
+                   (= pinocchio::aba, Pinocchio v2.7.0 -- NOT in /root/reference, fetched by
+                   external/config/pinocchio/CMakeLists.txt.in:15; restated from the published
+                   Featherstone ABA in Pinocchio's conventions)
+  anymal_node      ABA + the Lie-group semi-implicit Euler step of quadruped.example.cpp:197-200
+                   (the full-body node function is defined by this project)
+
+PARITY STATUS: **derivative half parity unpinned** against the real reference -- CppAD,
+CppADCodeGen and Pinocchio are third-party, absent from /root/reference and not installable
+(SURVEY.md §8(c)).  What pins this oracle instead (tests/test_oracle.py):
+  * the reference's closed-form known answers (test/autodiff/function.test.cpp:70-89, 120-131);
+  * ApproximateExponentialMap vs the exact exponential map (function.test.cpp:40-58);
+  * second-order finite differences, the reference's own self-check (function.hpp:285-325);
+  * for ABA: M(q) ddq + h(q, v) = tau with M, h from an independent RNEA written here, free-fall
+    and total-mass checks, model dimensions nq=19 / nv=18 (test/rbd/robot.test.cpp:103-106).
+The layout half IS pinned: tests/golden/layout_*.txt come from the reference's own headers
+(oracle/ref_layout/build_ref.sh).
+"""
+from __future__ import annotations
+
+import math
+import os
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+torch.set_default_dtype(torch.float64)
+EPS = float(np.finfo(np.float64).eps)
+
+DIMS = {  # name: (nx, nu, nw, np)
+    "quadrotor": (13, 4, 0, 20),
+    "rc_car": (6, 2, 0, 15),
+    "srbd": (13, 24, 4, 6),
+    "anymal": (37, 12, 0, 1),
+}
+
+
+# ----------------------------------------------------------------------------- helpers
+def cross(a, b):
+    return torch.stack((a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]))
+
+
+def quat_rotate(q, v):
+    """Eigen QuaternionBase::_transformVector: v + w*t + u x t, t = 2 (u x v); q = (x, y, z, w)."""
+    u = q[:3]
+    t = 2.0 * cross(u, v)
+    return v + q[3] * t + cross(u, t)
+
+
+def quat_mul(a, b):
+    """Eigen quaternion product, xyzw storage."""
+    ax, ay, az, aw = a[0], a[1], a[2], a[3]
+    bx, by, bz, bw = b[0], b[1], b[2], b[3]
+    return torch.stack((aw * bx + ax * bw + ay * bz - az * by,
+                        aw * by + ay * bw + az * bx - ax * bz,
+                        aw * bz + az * bw + ax * by - ay * bx,
+                        aw * bw - ax * bx - ay * by - az * bz))
+
+
+def approximate_norm(v):
+    """utils.hpp:731-736."""
+    return torch.sqrt((v * v).sum() + EPS)
+
+
+def approximate_exponential_map(v):
+    """utils.hpp:738-749."""
+    n = approximate_norm(v)
+    return torch.cat((v * torch.sin(0.5 * n) / n, torch.cos(0.5 * n).reshape(1)))
+
+
+def exact_exponential_map(v):
+    """utils.hpp:700-729 (the branchy exact map; only used to pin the approximate one)."""
+    n = float(np.linalg.norm(v))
+    if n == 0.0:
+        return np.array([0.0, 0.0, 0.0, 1.0])
+    return np.concatenate((np.asarray(v) * math.sin(0.5 * n) / n, [math.cos(0.5 * n)]))
+
+
+# ----------------------------------------------------------------------------- node functions
+def quadrotor_node(x, u, w, p):
+    dt, m, moi = p[0], p[1], p[2:5]
+    g0, b, d = p[17], p[18], p[19]
+    pos, q, pdot, om = x[0:3], x[3:7], x[7:10], x[10:13]
+    ez = torch.tensor([0.0, 0.0, 1.0])
+    sum_f = torch.zeros(3)
+    sum_m = torch.zeros(3)
+    sum_d = torch.zeros(3)
+    for i in range(4):
+        thrust = b * u[i] ** 2 * ez
+        sum_f = sum_f + thrust
+        sum_m = sum_m + cross(p[5 + 3 * i:8 + 3 * i], thrust)
+        sum_d = sum_d + d * u[i] ** 2 * ez * (-1.0) ** i
+    pdotdot = (quat_rotate(q, sum_f) - m * g0 * ez) / m
+    omdot = (1.0 / moi) * (sum_m + sum_d - cross(om, moi * om))
+    pdot_n = pdot + dt * pdotdot
+    om_n = om + dt * omdot
+    pos_n = pos + dt * pdot_n
+    q_n = quat_mul(q, approximate_exponential_map(dt * om_n))
+    return torch.cat((pos_n, q_n, pdot_n, om_n))
+
+
+def rc_car_node(x, u, w, p):
+    dt, m, moi, lf, lr = p[0], p[1], p[2], p[3], p[4]
+    Bf, Cf, Df, Br, Cr, Dr = p[5], p[6], p[7], p[8], p[9], p[10]
+    Cm1, Cm2, Cr0, Cr2 = p[11], p[12], p[13], p[14]
+    px, py, phi, vx, vy, om = x[0], x[1], x[2], x[3], x[4], x[5]
+    d, delta = u[0], u[1]
+    alphaf = -torch.atan((om * lf + vy) / (vx + EPS)) + delta
+    alphar = torch.atan((om * lr - vy) / (vx + EPS))
+    Ffy = Df * torch.sin(Cf * torch.atan(Bf * alphaf))
+    Fry = Dr * torch.sin(Cr * torch.atan(Br * alphar))
+    Frx = (Cm1 - Cm2 * vx) * d - Cr0 - Cr2 * vx ** 2
+    vxdot = (Frx - Ffy * torch.sin(delta) + m * vy * om) / m
+    vydot = (Fry + Ffy * torch.cos(delta) - m * vx * om) / m
+    omdot = (Ffy * lf * torch.cos(delta) - Fry * lr) / moi
+    vx_n, vy_n, om_n = vx + dt * vxdot, vy + dt * vydot, om + dt * omdot
+    return torch.stack((px + dt * (vx_n * torch.cos(phi) - vy_n * torch.sin(phi)),
+                        py + dt * (vx_n * torch.sin(phi) + vy_n * torch.cos(phi)),
+                        phi + dt * om_n, vx_n, vy_n, om_n))
+
+
+def srbd_node(x, u, w, p):
+    dt, m, moi, g0 = p[0], p[1], p[2:5], p[5]
+    pos, q, pdot, om = x[0:3], x[3:7], x[7:10], x[10:13]
+    pdotdot = -g0 * torch.tensor([0.0, 0.0, 1.0])
+    omdot = -cross(om, moi * om)
+    for i in range(4):
+        f, r, s = u[6 * i:6 * i + 3], u[6 * i + 3:6 * i + 6], w[i]
+        pdotdot = pdotdot + s * f / m
+        omdot = omdot + s * cross(r, quat_rotate(q, f))
+    omdot = omdot / moi
+    pdot_n = pdot + dt * pdotdot
+    om_n = om + dt * omdot
+    pos_n = pos + dt * pdot_n
+    q_n = quat_mul(q, approximate_exponential_map(dt * om_n))
+    return torch.cat((pos_n, q_n, pdot_n, om_n))
+
+
+# ----------------------------------------------------------------------------- rigid-body model
+def _rpy(r, p, y):
+    cr, sr, cp, sp, cy, sy = math.cos(r), math.sin(r), math.cos(p), math.sin(p), math.cos(y), math.sin(y)
+    return np.array([[cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr],
+                     [sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr],
+                     [-sp, cp * sr, cp * cr]])
+
+
+def _skew(v):
+    return np.array([[0.0, -v[2], v[1]], [v[2], 0.0, -v[0]], [-v[1], v[0], 0.0]])
+
+
+def _spatial_inertia(mass, com, Ic):
+    """6x6, (linear, angular) ordering, about the frame origin."""
+    cx = _skew(com)
+    Y = np.zeros((6, 6))
+    Y[:3, :3] = mass * np.eye(3)
+    Y[:3, 3:] = -mass * cx
+    Y[3:, :3] = mass * cx
+    Y[3:, 3:] = Ic - mass * cx @ cx
+    return Y
+
+
+def _force_xform(R, p):
+    X = np.zeros((6, 6))
+    X[:3, :3] = R
+    X[3:, 3:] = R
+    X[3:, :3] = _skew(p) @ R
+    return X
+
+
+@dataclass
+class OJoint:
+    name: str
+    parent: int
+    R: np.ndarray
+    p: np.ndarray
+    axis: np.ndarray | None  # None => free flyer
+    Y: np.ndarray
+    iq: int = 0
+    iv: int = 0
+
+
+@dataclass
+class OModel:
+    joints: list = field(default_factory=list)
+    nq: int = 0
+    nv: int = 0
+    gravity: np.ndarray = field(default_factory=lambda: np.array([0.0, 0.0, -9.81]))
+
+
+def load_robot(path: str) -> OModel:
+    """Reads the flat '.robot' text (tools/urdf_to_robot.py) and builds the free-flyer model with
+    fixed joints lumped, children visited depth-first in joint-name order (Pinocchio/urdfdom)."""
+    links, joints = {}, {}
+    with open(path) as f:
+        for line in f:
+            t = line.split()
+            if not t or t[0].startswith("#"):
+                continue
+            if t[0] == "link":
+                v = [float(s) for s in t[3:]]
+                links[t[1]] = dict(has=int(t[2]), m=v[0], c=np.array(v[1:4]), rpy=v[4:7],
+                                   I=np.array([[v[7], v[8], v[9]], [v[8], v[10], v[11]], [v[9], v[11], v[12]]]))
+            elif t[0] == "joint":
+                v = [float(s) for s in t[5:]]
+                joints[t[1]] = dict(type=t[2], parent=t[3], child=t[4], xyz=np.array(v[0:3]), rpy=v[3:6], axis=np.array(v[6:9]))
+    children = {j["child"] for j in joints.values()}
+    (root,) = [l for l in links if l not in children]
+
+    def link_Y(name):
+        L = links[name]
+        if not L["has"]:
+            return np.zeros((6, 6))
+        R = _rpy(*L["rpy"])
+        return _spatial_inertia(L["m"], L["c"], R @ L["I"] @ R.T)
+
+    model = OModel()
+    model.joints.append(OJoint("universe", 0, np.eye(3), np.zeros(3), None, np.zeros((6, 6))))
+    model.joints.append(OJoint("root_joint", 0, np.eye(3), np.zeros(3), None, link_Y(root)))
+
+    def visit(link, support, R, p):
+        for name in sorted(joints):  # ASCII order, as std::map<std::string,...>
+            j = joints[name]
+            if j["parent"] != link:
+                continue
+            Rj = R @ _rpy(*j["rpy"])
+            pj = p + R @ j["xyz"]
+            if j["type"] == "fixed":
+                X = _force_xform(Rj, pj)
+                model.joints[support].Y = model.joints[support].Y + X @ link_Y(j["child"]) @ X.T
+                visit(j["child"], support, Rj, pj)
+            else:
+                model.joints.append(OJoint(name, support, Rj, pj, j["axis"], link_Y(j["child"])))
+                visit(j["child"], len(model.joints) - 1, np.eye(3), np.zeros(3))
+
+    visit(root, 1, np.eye(3), np.zeros(3))
+    iq = iv = 0
+    for k, j in enumerate(model.joints):
+        j.iq, j.iv = iq, iv
+        if k == 0:
+            continue
+        iq += 7 if j.axis is None else 1
+        iv += 6 if j.axis is None else 1
+    model.nq, model.nv = iq, iv
+    return model
+
+
+_ANYMAL = None
+
+
+def anymal_model() -> OModel:
+    global _ANYMAL
+    if _ANYMAL is None:
+        here = os.path.dirname(os.path.abspath(__file__))
+        _ANYMAL = load_robot(os.path.join(here, "..", "ungar_amd", "data", "anymal_b.robot"))
+    return _ANYMAL
+
+
+def _quat_to_rot(q):
+    """Eigen toRotationMatrix, q = (x, y, z, w), no normalisation."""
+    x, y, z, w = q[0], q[1], q[2], q[3]
+    tx, ty, tz = 2 * x, 2 * y, 2 * z
+    twx, twy, twz = tx * w, ty * w, tz * w
+    txx, txy, txz = tx * x, ty * x, tz * x
+    tyy, tyz, tzz = ty * y, tz * y, tz * z
+    return torch.stack((torch.stack((1 - (tyy + tzz), txy - twz, txz + twy)),
+                        torch.stack((txy + twz, 1 - (txx + tzz), tyz - twx)),
+                        torch.stack((txz - twy, tyz + twx, 1 - (txx + tyy)))))
+
+
+def _axis_rot(axis, angle):
+    a = torch.as_tensor(axis)
+    K = torch.as_tensor(_skew(axis))
+    return torch.eye(3) + torch.sin(angle) * K + (1 - torch.cos(angle)) * (K @ K) + 0.0 * a.sum()
+
+
+def _kinematics(model, q, v):
+    """liMi (R, p) and joint-local spatial velocity contributions for every joint."""
+    Rs, ps, vjs, Ss = [None], [None], [None], [None]
+    for j in model.joints[1:]:
+        if j.axis is None:
+            Rj = _quat_to_rot(q[j.iq + 3:j.iq + 7])
+            pj = q[j.iq:j.iq + 3]
+            vj = v[j.iv:j.iv + 6]
+            S = torch.eye(6)
+        else:
+            Rj = _axis_rot(j.axis, q[j.iq])
+            pj = torch.zeros(3)
+            S = torch.cat((torch.zeros(3), torch.as_tensor(j.axis))).reshape(6, 1)
+            vj = S[:, 0] * v[j.iv]
+        Rs.append(torch.as_tensor(j.R) @ Rj)
+        ps.append(torch.as_tensor(j.p) + torch.as_tensor(j.R) @ pj)
+        vjs.append(vj)
+        Ss.append(S)
+    return Rs, ps, vjs, Ss
+
+
+def _act_inv_motion(R, p, m):
+    return torch.cat((R.T @ (m[:3] - cross(p, m[3:])), R.T @ m[3:]))
+
+
+def _act_force(R, p, f):
+    l = R @ f[:3]
+    return torch.cat((l, R @ f[3:] + cross(p, l)))
+
+
+def _cross_motion(v, m):
+    return torch.cat((cross(v[3:], m[:3]) + cross(v[:3], m[3:]), cross(v[3:], m[3:])))
+
+
+def _cross_force(v, f):
+    return torch.cat((cross(v[3:], f[:3]), cross(v[3:], f[3:]) + cross(v[:3], f[:3])))
+
+
+def _force_xform_t(R, p):
+    px = torch.stack((torch.stack((torch.zeros(()), -p[2], p[1])),
+                      torch.stack((p[2], torch.zeros(()), -p[0])),
+                      torch.stack((-p[1], p[0], torch.zeros(())))))
+    top = torch.cat((R, torch.zeros(3, 3)), dim=1)
+    bot = torch.cat((px @ R, R), dim=1)
+    return torch.cat((top, bot), dim=0)
+
+
+def aba(model: OModel, q, v, tau):
+    """Featherstone's articulated-body algorithm in Pinocchio's formulation (three passes)."""
+    n = len(model.joints)
+    Rs, ps, vjs, Ss = _kinematics(model, q, v)
+    vel, acc, f, Y = [torch.zeros(6)] + [None] * (n - 1), [None] * n, [None] * n, [None] * n
+    for i in range(1, n):
+        j = model.joints[i]
+        vel[i] = vjs[i] + (_act_inv_motion(Rs[i], ps[i], vel[j.parent]) if j.parent > 0 else 0.0)
+        acc[i] = _cross_motion(vel[i], vjs[i])
+        Y[i] = torch.as_tensor(j.Y)
+        f[i] = _cross_force(vel[i], Y[i] @ vel[i])
+    u = [None] * n
+    U, Dinv, UDinv = [None] * n, [None] * n, [None] * n
+    for i in range(n - 1, 0, -1):
+        j = model.joints[i]
+        nv = 6 if j.axis is None else 1
+        S = Ss[i]
+        u[i] = tau[j.iv:j.iv + nv] - S.T @ f[i]
+        U[i] = Y[i] @ S
+        D = S.T @ U[i]
+        Dinv[i] = torch.linalg.inv(D)
+        UDinv[i] = U[i] @ Dinv[i]
+        if j.parent > 0:
+            Ia = Y[i] - UDinv[i] @ U[i].T
+            pa = f[i] + Ia @ acc[i] + UDinv[i] @ u[i]
+            X = _force_xform_t(Rs[i], ps[i])
+            Y[j.parent] = Y[j.parent] + X @ Ia @ X.T
+            f[j.parent] = f[j.parent] + _act_force(Rs[i], ps[i], pa)
+    acc[0] = torch.cat((-torch.as_tensor(model.gravity), torch.zeros(3)))
+    ddq = [None] * n
+    for i in range(1, n):
+        j = model.joints[i]
+        acc[i] = acc[i] + _act_inv_motion(Rs[i], ps[i], acc[j.parent])
+        ddq[i] = Dinv[i] @ u[i] - UDinv[i].T @ acc[i]
+        acc[i] = acc[i] + Ss[i] @ ddq[i]
+    return torch.cat(ddq[1:])
+
+
+def rnea(model: OModel, q, v, a, gravity=True):
+    """Recursive Newton-Euler inverse dynamics (independent cross-check of aba)."""
+    n = len(model.joints)
+    Rs, ps, vjs, Ss = _kinematics(model, q, v)
+    g = torch.as_tensor(model.gravity) if gravity else torch.zeros(3)
+    vel, acc, f = [torch.zeros(6)] + [None] * (n - 1), [torch.cat((-g, torch.zeros(3)))] + [None] * (n - 1), [None] * n
+    for i in range(1, n):
+        j = model.joints[i]
+        nv = 6 if j.axis is None else 1
+        vel[i] = vjs[i] + (_act_inv_motion(Rs[i], ps[i], vel[j.parent]) if j.parent > 0 else 0.0)
+        acc[i] = _act_inv_motion(Rs[i], ps[i], acc[j.parent]) + Ss[i] @ a[j.iv:j.iv + nv] + _cross_motion(vel[i], vjs[i])
+        Yi = torch.as_tensor(j.Y)
+        f[i] = Yi @ acc[i] + _cross_force(vel[i], Yi @ vel[i])
+    tau = [None] * n
+    for i in range(n - 1, 0, -1):
+        j = model.joints[i]
+        tau[i] = Ss[i].T @ f[i]
+        if j.parent > 0:
+            f[j.parent] = f[j.parent] + _act_force(Rs[i], ps[i], f[i])
+    return torch.cat(tau[1:])
+
+
+def anymal_node(x, u, w, p):
+    model = anymal_model()
+    nq, nv = model.nq, model.nv
+    dt = p[0]
+    q, v = x[:nq], x[nq:nq + nv]
+    tau = torch.cat((torch.zeros(6), u))
+    a = aba(model, q, v, tau)
+    v_n = v + dt * a
+    quat = q[3:7]
+    pos_n = q[0:3] + dt * quat_rotate(quat, v_n[0:3])
+    quat_n = quat_mul(quat, approximate_exponential_map(dt * v_n[3:6]))
+    qj_n = q[7:] + dt * v_n[6:]
+    return torch.cat((pos_n, quat_n, qj_n, v_n))
+
+
+NODES = {"quadrotor": quadrotor_node, "rc_car": rc_car_node, "srbd": srbd_node, "anymal": anymal_node}
+
+
+# ----------------------------------------------------------------------------- evaluation API
+def node_value(name: str, x, u, w, p) -> np.ndarray:
+    """f for a batch: x (B,nx), u (B,nu), w (B,nw), p (B,np) numpy -> (B,nx)."""
+    fn = NODES[name]
+    X, U, W, P = (torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64) for a in (x, u, w, p))
+    with torch.no_grad():
+        return torch.stack([fn(X[b], U[b], W[b], P[b]) for b in range(X.shape[0])]).numpy()
+
+
+def node_jacobian(name: str, x, u, w, p):
+    """(f, J) for a batch; J is the dense (B, nx, nx+nu) block [A | B] = d f / d (x, u)."""
+    fn = NODES[name]
+    nx = DIMS[name][0]
+    X, U, W, P = (torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64) for a in (x, u, w, p))
+    fs, js = [], []
+    for b in range(X.shape[0]):
+        z = torch.cat((X[b], U[b]))
+        g = lambda zz: fn(zz[:nx], zz[nx:], W[b], P[b])  # noqa: E731
+        js.append(torch.autograd.functional.jacobian(g, z, vectorize=False))
+        with torch.no_grad():
+            fs.append(g(z))
+    return torch.stack(fs).numpy(), torch.stack(js).numpy()
+
+
+# ----------------------------------------------------------------------------- synthetic inputs
+def default_params(name: str) -> np.ndarray:
+    """Per-instance parameter block p with the reference's values."""
+    if name == "quadrotor":  # quadrotor.example.cpp:326-343
+        props = [[0.2, 0.2, 0.0], [-0.2, 0.2, 0.0], [-0.2, -0.2, 0.0], [0.2, -0.2, 0.0]]
+        return np.array([1.0 / 30.0, 1.5, 3e-2, 3e-2, 3e-2] + [c for pp in props for c in pp] + [9.80665, 0.015, 0.1])
+    if name == "rc_car":  # rc_car.example.cpp:320-337
+        return np.array([1.0 / 30.0, 0.041, 27.8e-6, 0.029, 0.033, 2.579, 1.2, 0.192, 3.3852, 1.2691, 0.1737, 0.287, 0.0545,
+                         0.0518, 0.00035])
+    if name == "srbd":  # quadruped.example.cpp:378-392
+        return np.array([1.0 / 30.0, 25.0, 0.048125, 0.093125, 0.055625, 9.80665])
+    if name == "anymal":
+        return np.array([1.0 / 20.0])
+    raise KeyError(name)
+
+
+def synthetic_inputs(name: str, count: int, seed: int = 0):
+    """Deterministic random (x, u, w, p) in the ranges of SURVEY.md §8(d)."""
+    rng = np.random.default_rng(0x5EED0000 + seed)
+    nx, nu, nw, npar = DIMS[name]
+    p = np.tile(default_params(name), (count, 1))
+    w = np.zeros((count, nw))
+    if name == "quadrotor":
+        q = rng.normal(size=(count, 4))
+        q /= np.linalg.norm(q, axis=1, keepdims=True)
+        hover = math.sqrt(p[0, 1] * p[0, 17] / (4 * p[0, 18]))
+        x = np.concatenate((rng.uniform(-2, 2, (count, 3)), q, rng.uniform(-1, 1, (count, 3)), rng.uniform(-1, 1, (count, 3))), axis=1)
+        u = rng.uniform(0.5, 1.5, (count, 4)) * hover
+    elif name == "rc_car":
+        x = np.concatenate((rng.uniform(-1, 1, (count, 2)), rng.uniform(-math.pi, math.pi, (count, 1)), rng.uniform(0.5, 2.0, (count, 1)),
+                            rng.uniform(-0.3, 0.3, (count, 1)), rng.uniform(-2, 2, (count, 1))), axis=1)
+        u = np.concatenate((rng.uniform(-1, 1, (count, 1)), rng.uniform(-0.3, 0.3, (count, 1))), axis=1)
+    elif name == "srbd":
+        q = rng.normal(size=(count, 4))
+        q /= np.linalg.norm(q, axis=1, keepdims=True)
+        x = np.concatenate((rng.uniform(-2, 2, (count, 3)), q, rng.uniform(-1, 1, (count, 3)), rng.uniform(-1, 1, (count, 3))), axis=1)
+        mg4 = p[0, 1] * p[0, 5] / 4
+        hips = np.array([[0.2, 0.15, -0.1], [0.2, -0.15, -0.1], [-0.2, 0.15, -0.1], [-0.2, -0.15, -0.1]])
+        u = np.zeros((count, 24))
+        for i in range(4):
+            u[:, 6 * i:6 * i + 3] = mg4 * np.concatenate((rng.uniform(-0.2, 0.2, (count, 2)), rng.uniform(0.5, 1.5, (count, 1))), axis=1)
+            u[:, 6 * i + 3:6 * i + 6] = hips[i] + rng.uniform(-0.1, 0.1, (count, 3)) - np.array([0, 0, 0.3])
+        w = (rng.uniform(size=(count, 4)) < 0.5).astype(np.float64)
+    elif name == "anymal":
+        q = rng.normal(size=(count, 4))
+        q /= np.linalg.norm(q, axis=1, keepdims=True)
+        x = np.concatenate((rng.uniform(-1, 1, (count, 3)), q, rng.uniform(-1, 1, (count, 12)), rng.uniform(-1, 1, (count, 18))), axis=1)
+        u = rng.uniform(-20, 20, (count, 12))
+    else:
+        raise KeyError(name)
+    return x, u, w, p

@@ -1,0 +1,184 @@
+// ungar_amd :: the four built-in shooting-node functions  x+ = f(x, u; w, p).
+//
+// Each restates, operation for operation, the inner dynamics lambda the reference inlines N times
+// into its whole-horizon equality-constraint tape:
+//   quadrotor  example/mpc/quadrotor.example.cpp:126-190   nx=13 nu=4   np=20
+//   rc_car     example/mpc/rc_car.example.cpp:131-185      nx=6  nu=2   np=15
+//   srbd       example/mpc/quadruped.example.cpp:148-203   nx=13 nu=24  nw=4 (contact flags) np=6
+//   anymal     ABA of test/rbd/robot.test.cpp:109-135 (q19,v18) + the same Lie-group
+//              semi-implicit Euler step (quadruped.example.cpp:197-200); nx=37 nu=12 np=1.
+//              The reference has no MPC example for the full-body robot: this
+//              node function is DEFINED here and documented in DESIGN.md.
+// Argument blocks: x, u are differentiated; w = per-node parameters, p = per-instance parameters
+// (both are "parameters" in the sense of function.hpp:529-550 -- trimmed from the Jacobian).
+#pragma once
+
+#include <cmath>
+#include <limits>
+#include <vector>
+
+#include "../rbd/aba.hpp"
+#include "small_math.hpp"
+
+namespace ungar_amd::models {
+
+struct NodeDims {
+    const char* name;
+    int nx, nu, nw, np;
+};
+
+inline constexpr NodeDims kQuadrotorDims{"quadrotor", 13, 4, 0, 20};
+inline constexpr NodeDims kRcCarDims{"rc_car", 6, 2, 0, 15};
+inline constexpr NodeDims kSrbdDims{"srbd", 13, 24, 4, 6};
+inline constexpr NodeDims kAnymalDims{"anymal", 37, 12, 0, 1};
+
+/// p = parameters[0:20] of the example's `parameters` variable: step_size, mass,
+/// b_moi_diagonal(3), 4 x b_propeller_position(3), standard_gravity, thrust_constant,
+/// drag_constant  (quadrotor.example.cpp:103-116).
+template <class S>
+void QuadrotorNode(const S* x, const S* u, const S* /*w*/, const S* p, S* xn) {
+    const S dt = p[0], m = p[1];
+    const Vec3<S> moi{p[2], p[3], p[4]};
+    const S g0 = p[17], b = p[18], d = p[19];
+    const Vec3<S> pos{x[0], x[1], x[2]};
+    const Quat<S> q{x[3], x[4], x[5], x[6]};
+    const Vec3<S> pDot{x[7], x[8], x[9]};
+    const Vec3<S> om{x[10], x[11], x[12]};
+
+    // quadrotor.example.cpp:149-166 -- per-rotor thrust force/moment and drag moment, summed
+    // left to right from zero (std::accumulate).
+    Vec3<S> sumF{S{0.0}, S{0.0}, S{0.0}}, sumM{S{0.0}, S{0.0}, S{0.0}}, sumD{S{0.0}, S{0.0}, S{0.0}};
+    for (int i = 0; i < 4; ++i) {
+        const S r2 = u[i] * u[i];  // Utils::Pow(r, 2) = CppAD::pow(r, int 2)
+        const Vec3<S> thrust{S{0.0}, S{0.0}, b * r2};
+        const Vec3<S> pP{p[5 + 3 * i], p[6 + 3 * i], p[7 + 3 * i]};
+        sumF = Add(sumF, thrust);
+        sumM = Add(sumM, Cross(pP, thrust));
+        sumD = Add(sumD, Vec3<S>{S{0.0}, S{0.0}, d * r2 * ((i % 2) ? -1.0 : 1.0)});
+    }
+    // :167-170
+    const Vec3<S> qF = Rotate(q, sumF);
+    const Vec3<S> pDotDot{qF[0] / m, qF[1] / m, (qF[2] - m * g0) / m};
+    const Vec3<S> Iw{moi[0] * om[0], moi[1] * om[1], moi[2] * om[2]};
+    const Vec3<S> gyro = Cross(om, Iw);
+    Vec3<S> omDot;
+    for (std::size_t k = 0; k < 3; ++k) omDot[k] = (S{1.0} / moi[k]) * (sumM[k] + sumD[k] - gyro[k]);
+    // :184-187
+    Vec3<S> pDotN, omN, posN;
+    for (std::size_t k = 0; k < 3; ++k) {
+        pDotN[k] = pDot[k] + dt * pDotDot[k];
+        omN[k] = om[k] + dt * omDot[k];
+        posN[k] = pos[k] + dt * pDotN[k];
+    }
+    const Quat<S> qN = QuatMul(q, ApproximateExponentialMap(Scale(dt, omN)));
+    for (std::size_t k = 0; k < 3; ++k) {
+        xn[k] = posN[k];
+        xn[7 + k] = pDotN[k];
+        xn[10 + k] = omN[k];
+    }
+    for (std::size_t k = 0; k < 4; ++k) xn[3 + k] = qN[k];
+}
+
+/// p = parameters[0:15]: step_size, mass, b_moi, front_wheel_distance, rear_wheel_distance,
+/// ptm_front_{b,c,d}, ptm_rear_{b,c,d}, ptm_cm1, ptm_cm2, ptm_cr0, ptm_cr2
+/// (rc_car.example.cpp:105-121).
+template <class S>
+void RcCarNode(const S* x, const S* u, const S* /*w*/, const S* p, S* xn) {
+    using std::atan;
+    using std::cos;
+    using std::sin;
+    const S dt = p[0], m = p[1], moi = p[2], lf = p[3], lr = p[4];
+    const S Bf = p[5], Cf = p[6], Df = p[7], Br = p[8], Cr = p[9], Dr = p[10];
+    const S Cm1 = p[11], Cm2 = p[12], Cr0 = p[13], Cr2 = p[14];
+    const S px = x[0], py = x[1], phi = x[2], vx = x[3], vy = x[4], om = x[5];
+    const S d = u[0], delta = u[1];
+    const double eps = std::numeric_limits<double>::epsilon();
+    // rc_car.example.cpp:158-165
+    const S alphaf = -atan((om * lf + vy) / (vx + eps)) + delta;
+    const S alphar = atan((om * lr - vy) / (vx + eps));
+    const S Ffy = Df * sin(Cf * atan(Bf * alphaf));
+    const S Fry = Dr * sin(Cr * atan(Br * alphar));
+    const S Frx = (Cm1 - Cm2 * vx) * d - Cr0 - Cr2 * (vx * vx);
+    // :168-170
+    const S vxDot = (Frx - Ffy * sin(delta) + m * vy * om) / m;
+    const S vyDot = (Fry + Ffy * cos(delta) - m * vx * om) / m;
+    const S omDot = (Ffy * lf * cos(delta) - Fry * lr) / moi;
+    // :178-182
+    const S vxN = vx + dt * vxDot, vyN = vy + dt * vyDot, omN = om + dt * omDot;
+    xn[0] = px + dt * (vxN * cos(phi) - vyN * sin(phi));
+    xn[1] = py + dt * (vxN * sin(phi) + vyN * cos(phi));
+    xn[2] = phi + dt * omN;
+    xn[3] = vxN;
+    xn[4] = vyN;
+    xn[5] = omN;
+}
+
+/// w = the four reference_contact_state flags of knot k; p = [step_size, mass,
+/// b_moi_diagonal(3), standard_gravity]  (quadruped.example.cpp:160-176).
+template <class S>
+void SrbdNode(const S* x, const S* u, const S* w, const S* p, S* xn) {
+    const S dt = p[0], m = p[1];
+    const Vec3<S> moi{p[2], p[3], p[4]};
+    const S g0 = p[5];
+    const Vec3<S> pos{x[0], x[1], x[2]};
+    const Quat<S> q{x[3], x[4], x[5], x[6]};
+    const Vec3<S> pDot{x[7], x[8], x[9]};
+    const Vec3<S> om{x[10], x[11], x[12]};
+    // :166-176
+    Vec3<S> pDotDot{S{0.0}, S{0.0}, -g0};
+    const Vec3<S> Iw{moi[0] * om[0], moi[1] * om[1], moi[2] * om[2]};
+    const Vec3<S> gyro = Cross(om, Iw);
+    Vec3<S> omDot{-gyro[0], -gyro[1], -gyro[2]};
+    for (int i = 0; i < 4; ++i) {
+        const Vec3<S> f{u[6 * i], u[6 * i + 1], u[6 * i + 2]};
+        const Vec3<S> r{u[6 * i + 3], u[6 * i + 4], u[6 * i + 5]};
+        const S& s = w[i];
+        const Vec3<S> rxqf = Cross(r, Rotate(q, f));
+        for (std::size_t k = 0; k < 3; ++k) {
+            pDotDot[k] = pDotDot[k] + s * f[k] / m;
+            omDot[k] = omDot[k] + s * rxqf[k];
+        }
+    }
+    for (std::size_t k = 0; k < 3; ++k) omDot[k] = omDot[k] / moi[k];
+    // :197-200
+    Vec3<S> pDotN, omN, posN;
+    for (std::size_t k = 0; k < 3; ++k) {
+        pDotN[k] = pDot[k] + dt * pDotDot[k];
+        omN[k] = om[k] + dt * omDot[k];
+        posN[k] = pos[k] + dt * pDotN[k];
+    }
+    const Quat<S> qN = QuatMul(q, ApproximateExponentialMap(Scale(dt, omN)));
+    for (std::size_t k = 0; k < 3; ++k) {
+        xn[k] = posN[k];
+        xn[7 + k] = pDotN[k];
+        xn[10 + k] = omN[k];
+    }
+    for (std::size_t k = 0; k < 4; ++k) xn[3 + k] = qN[k];
+}
+
+/// Full-body floating-base node.  x = [q(nq); v(nv)], u = actuated joint torques (the base
+/// wrench of `tau` is zero), p = [step_size].
+///   a   = ABA(q, v, [0_6; u])
+///   v+  = v + dt a
+///   p+  = p + dt R(quat) v+_lin          (v_lin is body-frame, Pinocchio free-flyer convention)
+///   quat+ = quat * ApproximateExponentialMap(dt w+)
+///   qj+ = qj + dt vj+
+template <class S>
+void FloatingBaseNode(const rbd::Model& model, const S* x, const S* u, const S* /*w*/, const S* p, S* xn) {
+    const std::size_t nq = static_cast<std::size_t>(model.nq), nv = static_cast<std::size_t>(model.nv);
+    const S dt = p[0];
+    std::vector<S> q(x, x + nq), v(x + nq, x + nq + nv), tau(nv, S{0.0});
+    for (std::size_t k = 6; k < nv; ++k) tau[k] = u[k - 6];
+    const std::vector<S> a = rbd::Aba(model, q, v, tau);
+    std::vector<S> vN(nv);
+    for (std::size_t k = 0; k < nv; ++k) vN[k] = v[k] + dt * a[k];
+    const Quat<S> quat{q[3], q[4], q[5], q[6]};
+    const Vec3<S> lin = Rotate(quat, Vec3<S>{vN[0], vN[1], vN[2]});
+    for (std::size_t k = 0; k < 3; ++k) xn[k] = q[k] + dt * lin[k];
+    const Quat<S> qN = QuatMul(quat, ApproximateExponentialMap(Scale(dt, Vec3<S>{vN[3], vN[4], vN[5]})));
+    for (std::size_t k = 0; k < 4; ++k) xn[3 + k] = qN[k];
+    for (std::size_t k = 7; k < nq; ++k) xn[k] = q[k] + dt * vN[k - 1];
+    for (std::size_t k = 0; k < nv; ++k) xn[nq + k] = vN[k];
+}
+
+}  // namespace ungar_amd::models

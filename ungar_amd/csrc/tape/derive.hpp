@@ -1,0 +1,406 @@
+// ungar_amd :: derivative transforms on the expression tape (the CppADCodeGen "sparse Jacobian /
+// sparse Hessian model" half of the replacement).
+//
+// Reference behaviour reproduced:
+//   * sparse Jacobian restricted to the first n (decision-variable) columns, parameters trimmed
+//       include/ungar/autodiff/function.hpp:529-550
+//   * sparse *upper-triangular* Hessian of dependent variable 0 over decision variables only
+//       include/ungar/autodiff/function.hpp:552-574, 232-235
+//   * sparsity by dependency propagation through the operation sequence (CppAD's notion), CSR
+//     with rows ascending; columns ascending inside a row (canonical -- the reference's own
+//     within-row order is generator-defined and "cannot be used reliably", function.hpp:367-374)
+//
+// Both transforms are source-to-source: derivative expressions are appended to the same
+// hash-consed DAG, so partials shared between directions (cos(q), 1/m, R(q) ...) are emitted once.
+#pragma once
+
+#include <algorithm>
+#include <array>
+#include <cstdint>
+#include <utility>
+#include <vector>
+
+#include "graph.hpp"
+#include "scalar.hpp"
+
+namespace ungar_amd::tape {
+
+/// A recorded function y = f([x; p]) living in its own compact graph.
+struct Tape {
+    Graph graph;
+    std::vector<Id> inputs;   // size n + p, inputs[i] is the node of independent variable i
+    std::vector<Id> outputs;  // size m
+};
+
+/// Start recording: clears the thread's graph and returns n fresh independent variables
+/// (CppAD::Independent, function.hpp:456-458).
+inline std::vector<AD> Independent(int n) {
+    Graph& g = CurrentGraph();
+    g.Clear();
+    std::vector<AD> x;
+    x.reserve(static_cast<std::size_t>(n));
+    for (int i = 0; i < n; ++i) x.push_back(AD::FromId(g.Input()));
+    return x;
+}
+
+namespace detail {
+
+/// Copies the sub-DAG reachable from `roots` (plus every input) of `src` into `dst`, preserving
+/// relative order.  Returns old-id -> new-id.
+inline std::vector<Id> CopyReachable(const Graph& src, const std::vector<Id>& roots, Graph& dst) {
+    const std::size_t n = src.Size();
+    std::vector<std::uint8_t> live(n, 0);
+    for (Id r : roots) live[static_cast<std::size_t>(r)] = 1;
+    for (std::size_t i = n; i-- > 0;) {
+        if (!live[i]) continue;
+        const Node& nd = src.At(static_cast<Id>(i));
+        if (nd.op == Op::Input || nd.op == Op::Const) continue;
+        for (Id o : {nd.a, nd.b, nd.c, nd.d})
+            if (o != kNoId) live[static_cast<std::size_t>(o)] = 1;
+    }
+    std::vector<Id> map(n, kNoId);
+    for (std::size_t i = 0; i < n; ++i) {
+        const Node& nd = src.At(static_cast<Id>(i));
+        if (nd.op == Op::Input) {
+            map[i] = dst.Input();
+            continue;
+        }
+        if (!live[i]) continue;
+        switch (Arity(nd.op)) {
+            case 0: map[i] = dst.Constant(nd.value); break;
+            case 1: map[i] = dst.Unary(nd.op, map[static_cast<std::size_t>(nd.a)]); break;
+            case 2:
+                map[i] = dst.Binary(nd.op, map[static_cast<std::size_t>(nd.a)], map[static_cast<std::size_t>(nd.b)]);
+                break;
+            default:
+                map[i] = dst.Cond(nd.op,
+                                  map[static_cast<std::size_t>(nd.a)],
+                                  map[static_cast<std::size_t>(nd.b)],
+                                  map[static_cast<std::size_t>(nd.c)],
+                                  map[static_cast<std::size_t>(nd.d)]);
+        }
+    }
+    return map;
+}
+
+}  // namespace detail
+
+/// Stop recording (CppAD::ADFun(xp, y) + optimize, function.hpp:465-466): dead code is dropped,
+/// everything else was optimised while it was being recorded.
+inline Tape MakeTape(const std::vector<AD>& y) {
+    Graph& g = CurrentGraph();
+    std::vector<Id> roots;
+    roots.reserve(y.size());
+    for (const AD& v : y) roots.push_back(v.Node());
+    Tape t;
+    const std::vector<Id> map = detail::CopyReachable(g, roots, t.graph);
+    for (std::size_t i = 0; i < g.Size(); ++i)
+        if (g.At(static_cast<Id>(i)).op == Op::Input) t.inputs.push_back(map[i]);
+    for (Id r : roots) t.outputs.push_back(map[static_cast<std::size_t>(r)]);
+    return t;
+}
+
+/// Row-major coordinate list with ids of the value expressions.
+struct SparseEntries {
+    int rows = 0, cols = 0;
+    std::vector<int> row, col;
+    std::vector<Id> value;
+    std::size_t Nnz() const {
+        return value.size();
+    }
+    /// CSR row starts (size rows+1), the array Function's ctor derives at function.hpp:112-124.
+    std::vector<int> RowStarts() const {
+        std::vector<int> s(static_cast<std::size_t>(rows) + 1, 0);
+        for (int r : row) ++s[static_cast<std::size_t>(r) + 1];
+        for (int i = 0; i < rows; ++i) s[static_cast<std::size_t>(i) + 1] += s[static_cast<std::size_t>(i)];
+        return s;
+    }
+};
+
+class Differentiator {
+  public:
+    explicit Differentiator(Tape& tape) : t_{tape}, g_{tape.graph} {
+    }
+
+    /// Differentiable-dependency bitsets for nodes [0, limit): bit j of dep(node) is set iff the
+    /// node's value can vary with input j through differentiable operations.  Comparison
+    /// operands of CondExp and the argument of Sign carry no dependency (as in CppAD).
+    void ComputeDependencies(Id limit) {
+        const std::size_t nIn = t_.inputs.size();
+        words_ = (nIn + 63) / 64;
+        dep_.assign(static_cast<std::size_t>(limit) * words_, 0);
+        for (Id id = 0; id < limit; ++id) {
+            const Node& nd = g_.At(id);
+            std::uint64_t* d = Dep(id);
+            if (nd.op == Op::Input) {
+                d[static_cast<std::size_t>(nd.a) / 64] |= (1ULL << (static_cast<std::size_t>(nd.a) % 64));
+            } else if (nd.op == Op::Const || nd.op == Op::Sign) {
+            } else if (IsCond(nd.op)) {
+                Or(d, Dep(nd.c));
+                Or(d, Dep(nd.d));
+            } else {
+                Or(d, Dep(nd.a));
+                if (nd.b != kNoId) Or(d, Dep(nd.b));
+            }
+        }
+        depLimit_ = limit;
+    }
+
+    bool DependsOn(Id node, int input) const {
+        return (Dep(node)[static_cast<std::size_t>(input) / 64] >> (static_cast<std::size_t>(input) % 64)) & 1ULL;
+    }
+
+    /// Sparse Jacobian d outputs / d inputs[0, nCols).  Picks forward or reverse accumulation by
+    /// counting which creates fewer new nodes (both are exact; CppADCodeGen makes the same kind of
+    /// per-model choice).  mode: 0 = auto, 1 = forward, 2 = reverse.
+    SparseEntries Jacobian(int nCols, int mode = 0) {
+        const Id limit = static_cast<Id>(g_.Size());
+        ComputeDependencies(limit);
+        SparseEntries e;
+        e.rows = static_cast<int>(t_.outputs.size());
+        e.cols = nCols;
+        for (int i = 0; i < e.rows; ++i)
+            for (int j = 0; j < nCols; ++j)
+                if (DependsOn(t_.outputs[static_cast<std::size_t>(i)], j)) {
+                    e.row.push_back(i);
+                    e.col.push_back(j);
+                }
+        e.value.assign(e.row.size(), kNoId);
+        if (mode == 0) {
+            // Forward costs ~ sum over nodes of |dep(node) ∩ cols|; reverse ~ sum over nodes of
+            // #outputs reaching the node.  Estimate both from the bitsets, no graph growth.
+            mode = EstimateForwardCost(limit, nCols) <= EstimateReverseCost(limit) ? 1 : 2;
+        }
+        lastMode_ = mode;
+        if (mode == 1) {
+            std::vector<Id> d;
+            for (int j = 0; j < nCols; ++j) {
+                bool any = false;
+                for (std::size_t k = 0; k < e.col.size() && !any; ++k) any = e.col[k] == j;
+                if (!any) continue;
+                ForwardSweep(limit, j, d);
+                for (std::size_t k = 0; k < e.col.size(); ++k)
+                    if (e.col[k] == j)
+                        e.value[k] = d[static_cast<std::size_t>(t_.outputs[static_cast<std::size_t>(e.row[k])])];
+            }
+        } else {
+            std::vector<Id> adj;
+            std::size_t k = 0;
+            for (int i = 0; i < e.rows; ++i) {
+                if (k >= e.row.size() || e.row[k] != i) continue;
+                ReverseSweep(limit, t_.outputs[static_cast<std::size_t>(i)], adj);
+                for (; k < e.row.size() && e.row[k] == i; ++k)
+                    e.value[k] = adj[static_cast<std::size_t>(t_.inputs[static_cast<std::size_t>(e.col[k])])];
+            }
+        }
+        return e;
+    }
+
+    /// Sparse upper-triangular Hessian of outputs[outputIndex] over inputs[0, nCols):
+    /// reverse sweep for the gradient, then one forward sweep per column over the gradient DAG.
+    SparseEntries Hessian(int outputIndex, int nCols) {
+        const Id primalLimit = static_cast<Id>(g_.Size());
+        ComputeDependencies(primalLimit);
+        std::vector<Id> adj;
+        ReverseSweep(primalLimit, t_.outputs[static_cast<std::size_t>(outputIndex)], adj);
+        std::vector<Id> grad(static_cast<std::size_t>(nCols));
+        for (int j = 0; j < nCols; ++j) grad[static_cast<std::size_t>(j)] = adj[static_cast<std::size_t>(t_.inputs[static_cast<std::size_t>(j)])];
+        const Id limit = static_cast<Id>(g_.Size());
+        ComputeDependencies(limit);
+        SparseEntries e;
+        e.rows = e.cols = nCols;
+        for (int r = 0; r < nCols; ++r)
+            for (int c = r; c < nCols; ++c)
+                if (DependsOn(grad[static_cast<std::size_t>(r)], c)) {
+                    e.row.push_back(r);
+                    e.col.push_back(c);
+                }
+        e.value.assign(e.row.size(), kNoId);
+        std::vector<Id> d;
+        for (int c = 0; c < nCols; ++c) {
+            bool any = false;
+            for (std::size_t k = 0; k < e.col.size() && !any; ++k) any = e.col[k] == c;
+            if (!any) continue;
+            ForwardSweep(limit, c, d);
+            for (std::size_t k = 0; k < e.col.size(); ++k)
+                if (e.col[k] == c) e.value[k] = d[static_cast<std::size_t>(grad[static_cast<std::size_t>(e.row[k])])];
+        }
+        return e;
+    }
+
+    int LastMode() const {
+        return lastMode_;
+    }
+
+  private:
+    std::uint64_t* Dep(Id id) {
+        return dep_.data() + static_cast<std::size_t>(id) * words_;
+    }
+    const std::uint64_t* Dep(Id id) const {
+        return dep_.data() + static_cast<std::size_t>(id) * words_;
+    }
+    void Or(std::uint64_t* dst, const std::uint64_t* src) const {
+        for (std::size_t w = 0; w < words_; ++w) dst[w] |= src[w];
+    }
+
+    double EstimateForwardCost(Id limit, int nCols) const {
+        double c = 0;
+        for (Id id = 0; id < limit; ++id) {
+            if (Arity(g_.At(id).op) == 0) continue;
+            for (std::size_t w = 0; w < words_; ++w) {
+                std::uint64_t bits = Dep(id)[w];
+                if ((w + 1) * 64 > static_cast<std::size_t>(nCols)) {
+                    const std::size_t keep = static_cast<std::size_t>(nCols) > w * 64 ? static_cast<std::size_t>(nCols) - w * 64 : 0;
+                    bits &= keep >= 64 ? ~0ULL : ((1ULL << keep) - 1ULL);
+                }
+                c += static_cast<double>(__builtin_popcountll(bits));
+            }
+        }
+        return c;
+    }
+
+    double EstimateReverseCost(Id limit) const {
+        // #outputs reaching each node, by reverse propagation of output-membership bitsets.
+        const std::size_t m = t_.outputs.size();
+        const std::size_t w = (m + 63) / 64;
+        std::vector<std::uint64_t> reach(static_cast<std::size_t>(limit) * w, 0);
+        for (std::size_t i = 0; i < m; ++i)
+            reach[static_cast<std::size_t>(t_.outputs[i]) * w + i / 64] |= 1ULL << (i % 64);
+        double c = 0;
+        for (Id id = limit; id-- > 0;) {
+            const Node& nd = g_.At(id);
+            if (Arity(nd.op) == 0) continue;
+            const std::uint64_t* r = reach.data() + static_cast<std::size_t>(id) * w;
+            std::size_t cnt = 0;
+            for (std::size_t k = 0; k < w; ++k) cnt += static_cast<std::size_t>(__builtin_popcountll(r[k]));
+            if (!cnt) continue;
+            c += static_cast<double>(cnt);
+            auto push = [&](Id o) {
+                if (o == kNoId) return;
+                std::uint64_t* ro = reach.data() + static_cast<std::size_t>(o) * w;
+                for (std::size_t k = 0; k < w; ++k) ro[k] |= r[k];
+            };
+            if (IsCond(nd.op)) {
+                push(nd.c);
+                push(nd.d);
+            } else if (nd.op != Op::Sign) {
+                push(nd.a);
+                push(nd.b);
+            }
+        }
+        return c;
+    }
+
+    /// d(node)/d(operand) for unary/binary nodes, as expression ids (cached per node).
+    const std::array<Id, 2>& Partials(Id id) {
+        if (partials_.size() < g_.Size()) partials_.resize(g_.Size(), {kNoId, kNoId});
+        if (partials_[static_cast<std::size_t>(id)][0] != kNoId || partials_[static_cast<std::size_t>(id)][1] != kNoId)
+            return partials_[static_cast<std::size_t>(id)];
+        const Node nd = g_.At(id);
+        const Id one = g_.Constant(1.0);
+        Id pa = kNoId, pb = kNoId;
+        switch (nd.op) {
+            case Op::Add: pa = one; pb = one; break;
+            case Op::Sub: pa = one; pb = g_.Constant(-1.0); break;
+            case Op::Mul: pa = nd.b; pb = nd.a; break;
+            case Op::Div: {
+                const Id inv = g_.Div(one, nd.b);
+                pa = inv;
+                pb = g_.Neg(g_.Mul(id, inv));
+                break;
+            }
+            case Op::Neg: pa = g_.Constant(-1.0); break;
+            case Op::Sin: pa = g_.Unary(Op::Cos, nd.a); break;
+            case Op::Cos: pa = g_.Neg(g_.Unary(Op::Sin, nd.a)); break;
+            case Op::Tan: pa = g_.Add(one, g_.Mul(id, id)); break;
+            case Op::Asin: pa = g_.Div(one, g_.Unary(Op::Sqrt, g_.Sub(one, g_.Mul(nd.a, nd.a)))); break;
+            case Op::Acos: pa = g_.Neg(g_.Div(one, g_.Unary(Op::Sqrt, g_.Sub(one, g_.Mul(nd.a, nd.a))))); break;
+            case Op::Atan: pa = g_.Div(one, g_.Add(one, g_.Mul(nd.a, nd.a))); break;
+            case Op::Exp: pa = id; break;
+            case Op::Log: pa = g_.Div(one, nd.a); break;
+            case Op::Sqrt: pa = g_.Div(g_.Constant(0.5), id); break;
+            case Op::Abs: pa = g_.Unary(Op::Sign, nd.a); break;
+            case Op::Sign: break;
+            case Op::Pow: {
+                if (g_.IsConst(nd.b)) {
+                    const double e = g_.ConstValue(nd.b);
+                    pa = g_.Mul(nd.b, g_.Binary(Op::Pow, nd.a, g_.Constant(e - 1.0)));
+                } else {
+                    pa = g_.Mul(nd.b, g_.Binary(Op::Pow, nd.a, g_.Sub(nd.b, one)));
+                    pb = g_.Mul(id, g_.Unary(Op::Log, nd.a));
+                }
+                break;
+            }
+            case Op::Atan2: {
+                const Id den = g_.Add(g_.Mul(nd.a, nd.a), g_.Mul(nd.b, nd.b));
+                const Id inv = g_.Div(one, den);
+                pa = g_.Mul(nd.b, inv);
+                pb = g_.Neg(g_.Mul(nd.a, inv));
+                break;
+            }
+            default: break;
+        }
+        if (partials_.size() < g_.Size()) partials_.resize(g_.Size(), {kNoId, kNoId});
+        partials_[static_cast<std::size_t>(id)] = {pa, pb};
+        return partials_[static_cast<std::size_t>(id)];
+    }
+
+    /// Tangent of every node in [0, limit) along input `j`; d[node] is the id of the tangent
+    /// expression (constant 0 where the node does not depend on j).
+    void ForwardSweep(Id limit, int j, std::vector<Id>& d) {
+        const Id zero = g_.Constant(0.0);
+        d.assign(static_cast<std::size_t>(limit), zero);
+        for (Id id = 0; id < limit; ++id) {
+            if (id < depLimit_ && !DependsOn(id, j)) continue;
+            const Node nd = g_.At(id);
+            if (nd.op == Op::Input) {
+                if (nd.a == j) d[static_cast<std::size_t>(id)] = g_.Constant(1.0);
+                continue;
+            }
+            if (nd.op == Op::Const || nd.op == Op::Sign) continue;
+            if (IsCond(nd.op)) {
+                d[static_cast<std::size_t>(id)] =
+                    g_.Cond(nd.op, nd.a, nd.b, d[static_cast<std::size_t>(nd.c)], d[static_cast<std::size_t>(nd.d)]);
+                continue;
+            }
+            const std::array<Id, 2> p = Partials(id);
+            Id acc = zero;
+            if (p[0] != kNoId && d[static_cast<std::size_t>(nd.a)] != zero) acc = g_.Mul(p[0], d[static_cast<std::size_t>(nd.a)]);
+            if (nd.b != kNoId && p[1] != kNoId && d[static_cast<std::size_t>(nd.b)] != zero)
+                acc = g_.Add(acc, g_.Mul(p[1], d[static_cast<std::size_t>(nd.b)]));
+            d[static_cast<std::size_t>(id)] = acc;
+        }
+    }
+
+    /// Adjoint of every node in [0, limit) with respect to `output`.
+    void ReverseSweep(Id limit, Id output, std::vector<Id>& adj) {
+        const Id zero = g_.Constant(0.0);
+        adj.assign(static_cast<std::size_t>(limit), zero);
+        adj[static_cast<std::size_t>(output)] = g_.Constant(1.0);
+        for (Id id = output + 1; id-- > 0;) {
+            const Id w = adj[static_cast<std::size_t>(id)];
+            if (w == zero) continue;
+            const Node nd = g_.At(id);
+            if (Arity(nd.op) == 0 || nd.op == Op::Sign) continue;
+            if (IsCond(nd.op)) {
+                adj[static_cast<std::size_t>(nd.c)] = g_.Add(adj[static_cast<std::size_t>(nd.c)], g_.Cond(nd.op, nd.a, nd.b, w, zero));
+                adj[static_cast<std::size_t>(nd.d)] = g_.Add(adj[static_cast<std::size_t>(nd.d)], g_.Cond(nd.op, nd.a, nd.b, zero, w));
+                continue;
+            }
+            const std::array<Id, 2> p = Partials(id);
+            if (p[0] != kNoId) adj[static_cast<std::size_t>(nd.a)] = g_.Add(adj[static_cast<std::size_t>(nd.a)], g_.Mul(p[0], w));
+            if (nd.b != kNoId && p[1] != kNoId)
+                adj[static_cast<std::size_t>(nd.b)] = g_.Add(adj[static_cast<std::size_t>(nd.b)], g_.Mul(p[1], w));
+        }
+    }
+
+    Tape& t_;
+    Graph& g_;
+    std::vector<std::uint64_t> dep_;
+    std::size_t words_ = 1;
+    Id depLimit_ = 0;
+    std::vector<std::array<Id, 2>> partials_;
+    int lastMode_ = 0;
+};
+
+}  // namespace ungar_amd::tape
