@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/node_<model>.npz: seeded inputs and the oracle's (f, dense J) for each
+built-in shooting-node model.  The expected values come from oracle/ungar_oracle.py (torch.float64
+autograd over an independent restatement of the reference's node lambdas) -- nothing from
+/root/reference is read.  Run from the repo root:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import ungar_oracle as O  # noqa: E402
+
+COUNTS = {"quadrotor": 24, "rc_car": 32, "srbd": 16, "anymal": 8}
+
+for name, count in COUNTS.items():
+    x, u, w, p = O.synthetic_inputs(name, count, seed=7)
+    f, J = O.node_jacobian(name, x, u, w, p)
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", f"node_{name}.npz"), x=x, u=u, w=w, p=p, f=f, J=J)
+    print(name, count, "max|J|", np.abs(J).max())

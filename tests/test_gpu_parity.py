@@ -1,0 +1,204 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against
+  (a) the committed golden vectors (independent torch-autograd oracle, tests/golden/node_*.npz),
+  (b) the oracle evaluated live on the same seeded inputs,
+  (c) size-independent properties at BASELINE.json's full sizes.
+Tolerance for Jacobian entries: BASELINE.json north_star "<=1e-6 relative"; we assert a far tighter
+1e-9 relative to the block's max magnitude (FP64 end to end), and 1e-6 *entrywise* relative on every
+entry above 1e-6 of the block scale.
+"""
+import numpy as np
+import pytest
+
+from oracle import ungar_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+MODELS = ("quadrotor", "rc_car", "srbd", "anymal")
+
+
+def _assert_close(name, got_f, got_J, ref_f, ref_J):
+    assert np.isfinite(got_f).all() and np.isfinite(got_J).all(), f"{name}: non-finite output"
+    scale_f = max(1.0, np.abs(ref_f).max())
+    assert np.abs(got_f - ref_f).max() <= 1e-10 * scale_f, f"{name}: value mismatch {np.abs(got_f - ref_f).max()}"
+    scale = np.abs(ref_J).max(axis=(1, 2), keepdims=True)
+    err = np.abs(got_J - ref_J)
+    assert (err <= 1e-9 * scale).all(), f"{name}: Jacobian mismatch {err.max()} (scale {scale.max()})"
+    big = np.abs(ref_J) > 1e-6 * scale
+    rel = err[big] / np.abs(ref_J[big])
+    assert rel.max() <= 1e-6, f"{name}: entrywise relative error {rel.max()} > 1e-6"
+
+
+@pytest.fixture(scope="module")
+def ua():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import ungar_amd
+    ungar_amd.load_library()  # fails loudly if the HIP extension is missing
+    return ungar_amd
+
+
+@pytest.mark.parametrize("name", MODELS)
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+@pytest.mark.parametrize("mode", ["dense", "sparse"])
+def test_golden_vectors(ua, repo_root, name, layout, mode):
+    g = np.load(f"{repo_root}/tests/golden/node_{name}.npz")
+    m = ua.NodeModel(name)
+    f, J = m.evaluate_numpy(g["x"], g["u"], g["w"], g["p"], mode=mode, layout=layout)
+    _assert_close(name, f, J, g["f"], g["J"])
+
+
+@pytest.mark.parametrize("name", MODELS)
+def test_forward_zero_matches_golden(ua, repo_root, name):
+    g = np.load(f"{repo_root}/tests/golden/node_{name}.npz")
+    f, _ = ua.NodeModel(name).evaluate_numpy(g["x"], g["u"], g["w"], g["p"], mode="value")
+    assert np.abs(f - g["f"]).max() <= 1e-10 * max(1.0, np.abs(g["f"]).max())
+
+
+@pytest.mark.parametrize("name,count", [("quadrotor", 200), ("rc_car", 300), ("srbd", 100), ("anymal", 70)])
+def test_live_oracle_seeded(ua, name, count):
+    """Ragged count (not a multiple of the wavefront/block size) on fresh seeded inputs."""
+    x, u, w, p = O.synthetic_inputs(name, count, seed=123)
+    rf, rJ = O.node_jacobian(name, x, u, w, p)
+    f, J = ua.NodeModel(name).evaluate_numpy(x, u, w, p, mode="dense", layout="soa")
+    _assert_close(name, f, J, rf, rJ)
+
+
+def test_sparsity_matches_reference_probe_counts(ua):
+    """Structural nnz of the per-node [A|B] blocks (quadrotor 118, rc_car 32,
+    SRBD 238) and canonical CSR ordering."""
+    for name, nnz in (("quadrotor", 118), ("rc_car", 32), ("srbd", 238)):
+        m = ua.NodeModel(name)
+        assert m.jac_nnz == nnz
+        rows, cols = m.jacobian_sparsity()
+        key = rows.astype(np.int64) * (m.nx + m.nu) + cols
+        assert (np.diff(key) > 0).all()
+        starts, outer = m.jacobian_csr()
+        assert starts[0] == 0 and starts[-1] == nnz and len(starts) == m.ny + 1
+
+
+def test_empty_batch_and_errors(ua):
+    import torch
+    m = ua.NodeModel("rc_car")
+    z = torch.zeros(1, dtype=torch.float64, device="cuda")
+    op = ua.Operand.aos(z, 1)
+    m.dense_jacobian(0, op, op, None, op, op, op)  # count == 0 is a no-op
+    with pytest.raises(ua.UngarError):
+        ua.NodeModel("no_such_model")
+    with pytest.raises(ua.UngarError):
+        m.dense_jacobian(4, op, op, None, op, op, None)  # missing jac operand
+    with pytest.raises(ua.UngarError):
+        m.dense_jacobian(5, op, op, None, op, op, op, knots=2)  # count not a multiple of knots
+
+
+# ----------------------------------------------------------------------- full-size properties
+FULL = {  # BASELINE.json configs[1..3]
+    "quadrotor": (4096, 128),
+    "rc_car": (16384, 200),
+    "anymal": (4096, 20),
+}
+
+
+def _device_inputs(name, count, seed):
+    import torch
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(seed)
+    nx, nu, nw, npar = O.DIMS[name]
+    x = torch.rand((nx, count), generator=gen, device="cuda", dtype=torch.float64) * 2 - 1
+    u = torch.rand((nu, count), generator=gen, device="cuda", dtype=torch.float64) * 2 - 1
+    if name in ("quadrotor", "anymal"):
+        q = x[3:7]
+        x[3:7] = q / q.norm(dim=0, keepdim=True)
+    if name == "quadrotor":
+        u = (u * 0.5 + 1.0) * 15.0
+    if name == "rc_car":
+        x[3] = x[3] * 0.75 + 1.25
+        u[1] = u[1] * 0.3
+    if name == "anymal":
+        u = u * 20.0
+    p = torch.as_tensor(O.default_params(name), device="cuda")
+    return x, u, p
+
+
+@pytest.mark.parametrize("name", list(FULL))
+def test_full_size_properties(ua, name):
+    """At the BASELINE sizes: (1) unit-fastest (SoA) and node-major (AoS) device layouts agree
+    bit-for-bit; (2) sparse CSR values equal the dense block at the pattern and the dense block is
+    exactly zero elsewhere; (3) evaluating the batch in two halves reproduces the whole bit-for-bit;
+    (4) directional derivative J*delta matches a central difference of f (linearisation property);
+    (5) the exponential-map update keeps quaternions unit (where the state has one)."""
+    import torch
+    batch, N = FULL[name]
+    count = batch * N
+    m = ua.NodeModel(name)
+    nx, nu, ncols = m.nx, m.nu, m.nx + m.nu
+    x, u, p = _device_inputs(name, count, seed=11)
+    P = ua.Operand.per_instance(p, m.np, shared=True)
+    f = torch.empty((nx, count), dtype=torch.float64, device="cuda")
+    J = torch.empty((nx * ncols, count), dtype=torch.float64, device="cuda")
+    m.dense_jacobian(count, ua.Operand.soa(x, count), ua.Operand.soa(u, count), None, P, ua.Operand.soa(f, count), ua.Operand.soa(J, count))
+    torch.cuda.synchronize()
+    assert torch.isfinite(f).all() and torch.isfinite(J).all()
+
+    # (2) sparse vs dense
+    Js = torch.empty((m.jac_nnz, count), dtype=torch.float64, device="cuda")
+    f2 = torch.empty_like(f)
+    m.sparse_jacobian(count, ua.Operand.soa(x, count), ua.Operand.soa(u, count), None, P, ua.Operand.soa(f2, count), ua.Operand.soa(Js, count))
+    rows, cols = m.jacobian_sparsity()
+    idx = torch.as_tensor(rows.astype(np.int64) * ncols + cols, device="cuda")
+    assert torch.equal(J[idx], Js) and torch.equal(f, f2)
+    mask = torch.ones(nx * ncols, dtype=torch.bool, device="cuda")
+    mask[idx] = False
+    assert (J[mask] == 0).all()
+
+    # (1) AoS layout on a slice (keeps the transposed copies small)
+    sl = min(count, 64 * 1024)
+    xa, ua_ = x[:, :sl].t().contiguous(), u[:, :sl].t().contiguous()
+    fa = torch.empty((sl, nx), dtype=torch.float64, device="cuda")
+    Ja = torch.empty((sl, nx * ncols), dtype=torch.float64, device="cuda")
+    m.dense_jacobian(sl, ua.Operand.aos(xa, nx), ua.Operand.aos(ua_, nu), None, P, ua.Operand.aos(fa, nx), ua.Operand.aos(Ja, nx * ncols))
+    assert torch.equal(fa.t(), f[:, :sl]) and torch.equal(Ja.t(), J[:, :sl])
+
+    # (3) halves: second half evaluated alone, through offset views
+    h = count // 2
+    fh = torch.empty((nx, count - h), dtype=torch.float64, device="cuda")
+    Jh = torch.empty((nx * ncols, count - h), dtype=torch.float64, device="cuda")
+    xh, uh = x[:, h:].contiguous(), u[:, h:].contiguous()
+    m.dense_jacobian(count - h, ua.Operand.soa(xh, count - h), ua.Operand.soa(uh, count - h), None, P, ua.Operand.soa(fh, count - h),
+                     ua.Operand.soa(Jh, count - h))
+    assert torch.equal(fh, f[:, h:]) and torch.equal(Jh, J[:, h:])
+
+    # (4) linearisation: f(z + e d) - f(z - e d) = 2 e J d + O(e^3)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(5)
+    d = torch.rand((ncols, count), generator=gen, device="cuda", dtype=torch.float64) * 2 - 1
+    eps = 1e-6
+    fp, fm = torch.empty_like(f), torch.empty_like(f)
+    for sign, out in ((1.0, fp), (-1.0, fm)):
+        xx, uu = x + sign * eps * d[:nx], u + sign * eps * d[nx:]
+        m.forward_zero(count, ua.Operand.soa(xx, count), ua.Operand.soa(uu, count), None, P, ua.Operand.soa(out, count))
+    fd = (fp - fm) / (2 * eps)
+    Jd = torch.einsum("rcn,cn->rn", J.view(nx, ncols, count), d)
+    scale = Jd.abs().max().clamp(min=1.0)
+    assert ((fd - Jd).abs().max() / scale).item() < 1e-6
+
+    # (5) unit quaternion preserved by q+ = q * exp~(dt w+)
+    if name in ("quadrotor", "anymal"):
+        assert (f[3:7].norm(dim=0) - 1).abs().max().item() < 1e-12
+
+
+def test_gn_hessian_mfma(ua):
+    """J^T diag(d) J on the FP64 matrix cores vs torch (rows=37, cols=49 is the ANYmal block; also a
+    ragged small case and the identity-weight path)."""
+    import torch
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(3)
+    for rows, cols, count, weighted in ((37, 49, 1000, True), (13, 17, 257, True), (6, 8, 5, False), (37, 49, 3, False)):
+        J = torch.rand((count, rows, cols), generator=gen, device="cuda", dtype=torch.float64) * 2 - 1
+        d = torch.rand((count, rows), generator=gen, device="cuda", dtype=torch.float64) if weighted else None
+        G = torch.full((count, cols, cols), float("nan"), dtype=torch.float64, device="cuda")
+        ua.gn_hessian(J, d, G, rows, cols, count)
+        torch.cuda.synchronize()
+        ref = torch.einsum("nra,nr,nrb->nab", J, d if weighted else torch.ones((count, rows), device="cuda", dtype=torch.float64), J)
+        assert torch.isfinite(G).all()
+        assert (G - ref).abs().max().item() <= 1e-12 * ref.abs().max().item()
+        assert torch.equal(G, G.transpose(1, 2)) or (G - G.transpose(1, 2)).abs().max().item() < 1e-13

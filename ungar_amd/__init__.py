@@ -1,0 +1,257 @@
+"""ungar_amd -- MI355X-native batched derivative evaluation for Ungar's NMPC hot path.
+
+Python face of the C ABI in include/ungar_amd.h (ctypes; torch only supplies device memory and
+streams).  There is NO CPU fallback: importing works anywhere (so that host logic can be tested),
+but every evaluation goes through libungar_amd.so and raises if the library is missing.
+
+Reference interface mirrored here:
+  NodeModel.forward_zero / sparse_jacobian / dense_jacobian  <->  Ungar::Autodiff::Function::
+      operator() / Jacobian                       include/ungar/autodiff/function.hpp:206-230
+  NodeModel.independent_variable_size / parameter_size / dependent_variable_size
+                                                  include/ungar/autodiff/function.hpp:350-361
+  NodeModel.jacobian_sparsity (CSR inner starts / outer indices)
+                                                  include/ungar/autodiff/function.hpp:98-134
+  gn_hessian                                      include/ungar/optimization/soft_sqp.hpp:257-264
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+__all__ = ["NodeModel", "Operand", "gn_hessian", "library_path", "load_library", "UngarError", "MODELS"]
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+MODELS = ("quadrotor", "rc_car", "srbd", "anymal")
+
+
+class UngarError(RuntimeError):
+    """An ungar_amd C-ABI call failed (message from ungar_last_error())."""
+
+
+def library_path() -> str:
+    return os.path.join(_HERE, "lib", "libungar_amd.so")
+
+
+class _ModelInfo(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int64) for n in ("nx", "nu", "nw", "np", "ny", "jac_nnz", "hes_nnz")]
+
+
+class _Operand(ctypes.Structure):
+    _fields_ = [("base", ctypes.c_void_p), ("instance_stride", ctypes.c_int64), ("knot_stride", ctypes.c_int64),
+                ("element_stride", ctypes.c_int64)]
+
+
+class _NodeBatch(ctypes.Structure):
+    _fields_ = [("count", ctypes.c_int64), ("knots", ctypes.c_int64), ("x", _Operand), ("u", _Operand), ("w", _Operand),
+                ("p", _Operand), ("f", _Operand), ("jac", _Operand)]
+
+
+_LIB = None
+
+
+def load_library() -> ctypes.CDLL:
+    """dlopen libungar_amd.so and declare every symbol of include/ungar_amd.h.  Raises loudly if the
+    HIP library has not been built (no fallback path exists)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise UngarError(f"{path} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                         "(ungar_amd has no CPU fallback).")
+    lib = ctypes.CDLL(path)
+    vp, i64p = ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)
+    i32pp = ctypes.POINTER(ctypes.POINTER(ctypes.c_int32))
+    lib.ungar_model_open.argtypes = [ctypes.c_char_p, ctypes.POINTER(vp)]
+    lib.ungar_model_close.argtypes = [vp]
+    lib.ungar_model_close.restype = None
+    lib.ungar_model_name.argtypes = [vp]
+    lib.ungar_model_name.restype = ctypes.c_char_p
+    lib.ungar_model_get_info.argtypes = [vp, ctypes.POINTER(_ModelInfo)]
+    lib.ungar_model_jacobian_sparsity.argtypes = [vp, i32pp, i32pp, i64p]
+    lib.ungar_model_hessian_sparsity.argtypes = [vp, i32pp, i32pp, i64p]
+    for name in ("ungar_model_has_forward_zero", "ungar_model_has_sparse_jacobian", "ungar_model_has_sparse_hessian"):
+        getattr(lib, name).argtypes = [vp]
+    for name in ("ungar_model_forward_zero", "ungar_model_sparse_jacobian", "ungar_model_dense_jacobian"):
+        getattr(lib, name).argtypes = [vp, ctypes.POINTER(_NodeBatch), vp]
+    lib.ungar_gn_hessian.argtypes = [vp, ctypes.c_int64, ctypes.c_int64, vp, ctypes.c_int64, vp, ctypes.c_int64, ctypes.c_int64,
+                                     ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, vp]
+    lib.ungar_last_error.restype = ctypes.c_char_p
+    lib.ungar_version.restype = ctypes.c_char_p
+    _LIB = lib
+    return lib
+
+
+def _check(code: int):
+    if code != 0:
+        raise UngarError(f"ungar_amd error {code}: {load_library().ungar_last_error().decode()}")
+
+
+@dataclass
+class Operand:
+    """Strided device view of one operand (see `ungar_operand` in include/ungar_amd.h)."""
+    tensor: object  # torch.Tensor (cuda, float64) or None
+    instance_stride: int = 0
+    knot_stride: int = 0
+    element_stride: int = 1
+
+    def _c(self) -> _Operand:
+        if self.tensor is None:
+            return _Operand(None, 0, 0, 0)
+        t = self.tensor
+        if not t.is_cuda or str(t.dtype) != "torch.float64":
+            raise UngarError("operands must be float64 CUDA tensors (device memory; the engine has no host path)")
+        return _Operand(t.data_ptr(), self.instance_stride, self.knot_stride, self.element_stride)
+
+    # -- the two canonical layouts over a flat batch of `count` nodes --------------------------
+    @staticmethod
+    def soa(tensor, count: int, knots: int = 1) -> "Operand":
+        """tensor shape (elements, count): node index is the fastest axis (coalesced)."""
+        return Operand(tensor, instance_stride=knots, knot_stride=1, element_stride=count)
+
+    @staticmethod
+    def aos(tensor, elements: int, knots: int = 1, ld: int | None = None) -> "Operand":
+        """tensor shape (count, ld>=elements): node-major."""
+        ld = elements if ld is None else ld
+        return Operand(tensor, instance_stride=knots * ld, knot_stride=ld, element_stride=1)
+
+    @staticmethod
+    def per_instance(tensor, elements: int, shared: bool = False) -> "Operand":
+        """per-instance parameters, shape (instances, elements) or (elements,) when shared."""
+        return Operand(tensor, instance_stride=0 if shared else elements, knot_stride=0, element_stride=1)
+
+
+class NodeModel:
+    """A compiled shooting-node model  x+ = f(x, u; w, p)  with its sparse Jacobian."""
+
+    def __init__(self, name: str):
+        self._lib = load_library()
+        self._h = ctypes.c_void_p()
+        _check(self._lib.ungar_model_open(name.encode(), ctypes.byref(self._h)))
+        info = _ModelInfo()
+        _check(self._lib.ungar_model_get_info(self._h, ctypes.byref(info)))
+        self.name = name
+        self.nx, self.nu, self.nw, self.np, self.ny = info.nx, info.nu, info.nw, info.np, info.ny
+        self.jac_nnz, self.hes_nnz = info.jac_nnz, info.hes_nnz
+
+    def __del__(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.ungar_model_close(self._h)
+            self._h = ctypes.c_void_p()
+
+    # -- reference Function API names (function.hpp:340-361) ------------------------------------
+    def independent_variable_size(self) -> int:
+        return self.nx + self.nu
+
+    def parameter_size(self) -> int:
+        return self.nw + self.np
+
+    def dependent_variable_size(self) -> int:
+        return self.ny
+
+    def implements_function(self) -> bool:
+        return bool(self._lib.ungar_model_has_forward_zero(self._h))
+
+    def implements_jacobian(self) -> bool:
+        return bool(self._lib.ungar_model_has_sparse_jacobian(self._h))
+
+    def implements_hessian(self) -> bool:
+        return bool(self._lib.ungar_model_has_sparse_hessian(self._h))
+
+    def jacobian_sparsity(self):
+        """(rows, cols) int32 arrays, canonical row-major order."""
+        rows = ctypes.POINTER(ctypes.c_int32)()
+        cols = ctypes.POINTER(ctypes.c_int32)()
+        nnz = ctypes.c_int64()
+        _check(self._lib.ungar_model_jacobian_sparsity(self._h, ctypes.byref(rows), ctypes.byref(cols), ctypes.byref(nnz)))
+        n = nnz.value
+        return (np.ctypeslib.as_array(rows, shape=(n,)).copy(), np.ctypeslib.as_array(cols, shape=(n,)).copy())
+
+    def jacobian_csr(self):
+        """(inner_starts[ny+1], outer_indices[nnz]) -- the arrays Function's ctor builds
+        (function.hpp:106-124)."""
+        rows, cols = self.jacobian_sparsity()
+        starts = np.zeros(self.ny + 1, dtype=np.int32)
+        np.add.at(starts, rows + 1, 1)
+        return np.cumsum(starts, dtype=np.int32), cols
+
+    # -- batched evaluation -----------------------------------------------------------------------
+    def _batch(self, count, knots, x, u, w, p, f, jac) -> _NodeBatch:
+        none = Operand(None)
+        return _NodeBatch(count, knots, x._c(), u._c(), (w or none)._c(), p._c(), (f or none)._c(), (jac or none)._c())
+
+    @staticmethod
+    def _stream(stream):
+        if stream is not None:
+            return ctypes.c_void_p(stream)
+        import torch
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def forward_zero(self, count, x, u, w, p, f, knots=1, stream=None):
+        b = self._batch(count, knots, x, u, w, p, f, None)
+        _check(self._lib.ungar_model_forward_zero(self._h, ctypes.byref(b), self._stream(stream)))
+
+    def sparse_jacobian(self, count, x, u, w, p, f, jac, knots=1, stream=None):
+        b = self._batch(count, knots, x, u, w, p, f, jac)
+        _check(self._lib.ungar_model_sparse_jacobian(self._h, ctypes.byref(b), self._stream(stream)))
+
+    def dense_jacobian(self, count, x, u, w, p, f, jac, knots=1, stream=None):
+        b = self._batch(count, knots, x, u, w, p, f, jac)
+        _check(self._lib.ungar_model_dense_jacobian(self._h, ctypes.byref(b), self._stream(stream)))
+
+    # -- convenience: node-major numpy in, numpy out (tests, smoke) ---------------------------------
+    def evaluate_numpy(self, x, u, w, p, mode="dense", layout="soa"):
+        """Uploads (count, n) host arrays, evaluates on cuda:0, returns (f, J) as host arrays with
+        J dense (count, ny, nx+nu).  `layout` selects the DEVICE layout being exercised."""
+        import torch
+        count = x.shape[0]
+        dev = torch.device("cuda", 0)
+        ncols = self.nx + self.nu
+        nj = self.jac_nnz if mode == "sparse" else self.ny * ncols
+
+        def up(a, n):
+            if n == 0:
+                return None
+            t = torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64)
+            return (t.t().contiguous() if layout == "soa" else t.contiguous()).to(dev)
+
+        xt, ut, wt = up(x, self.nx), up(u, self.nu), up(w, self.nw)
+        pt = torch.as_tensor(np.ascontiguousarray(p), dtype=torch.float64).to(dev)
+        if layout == "soa":
+            ft = torch.full((self.ny, count), float("nan"), dtype=torch.float64, device=dev)
+            jt = torch.full((nj, count), float("nan"), dtype=torch.float64, device=dev)
+            mk = lambda t, n: None if t is None else Operand.soa(t, count)  # noqa: E731
+        else:
+            ft = torch.full((count, self.ny), float("nan"), dtype=torch.float64, device=dev)
+            jt = torch.full((count, nj), float("nan"), dtype=torch.float64, device=dev)
+            mk = lambda t, n: None if t is None else Operand.aos(t, n)  # noqa: E731
+        args = (count, mk(xt, self.nx), mk(ut, self.nu), mk(wt, self.nw), Operand.per_instance(pt, self.np), mk(ft, self.ny))
+        if mode == "value":
+            self.forward_zero(*args)
+            torch.cuda.synchronize()
+            f = ft.cpu().numpy()
+            return (f.T.copy() if layout == "soa" else f), None
+        (self.sparse_jacobian if mode == "sparse" else self.dense_jacobian)(*args, mk(jt, nj))
+        torch.cuda.synchronize()
+        f, j = ft.cpu().numpy(), jt.cpu().numpy()
+        if layout == "soa":
+            f, j = f.T.copy(), j.T.copy()
+        if mode == "sparse":
+            rows, cols = self.jacobian_sparsity()
+            dense = np.zeros((count, self.ny, ncols))
+            dense[:, rows, cols] = j
+            return f, dense
+        return f, j.reshape(count, self.ny, ncols)
+
+
+def gn_hessian(jac, d, g, rows: int, cols: int, count: int, ld_j=None, ld_g=None, stream=None):
+    """G = J^T diag(d) J per node on the FP64 matrix cores.  jac: (count, rows, ld_j) node-major,
+    d: (count, rows) or None, g: (count, cols, ld_g); all float64 CUDA tensors."""
+    lib = load_library()
+    ld_j = cols if ld_j is None else ld_j
+    ld_g = cols if ld_g is None else ld_g
+    _check(lib.ungar_gn_hessian(jac.data_ptr(), rows * ld_j, ld_j, d.data_ptr() if d is not None else None, rows, g.data_ptr(),
+                                cols * ld_g, ld_g, rows, cols, count, NodeModel._stream(stream)))

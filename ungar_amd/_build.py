@@ -1,0 +1,106 @@
+"""Build driver for the ungar_amd native pieces (used by __graft_entry__.build()).
+
+Steps (each skipped when its outputs are newer than its inputs):
+  1. g++   csrc/codegen/codegen_main.cpp                 -> build/ungar_codegen
+  2. run   ungar_codegen                                 -> csrc/gen/<model>_gen.hpp (+ oracle/_gen/<model>_cg.c)
+  3. hipcc csrc/kernels/*.hip, csrc/runtime/c_api.cpp    -> ungar_amd/lib/libungar_amd.so   (gfx950)
+The oracle's C checker / CPU baseline is built by oracle/build_oracle.py, not here.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "ungar_amd", "csrc")
+GEN = os.path.join(CSRC, "gen")
+BUILD = os.path.join(ROOT, "build")
+LIBDIR = os.path.join(ROOT, "ungar_amd", "lib")
+LIB = os.path.join(LIBDIR, "libungar_amd.so")
+ORACLE_GEN = os.path.join(ROOT, "oracle", "_gen")
+MODELS = ("quadrotor", "rc_car", "srbd", "anymal")
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-Wno-unused-result"]
+
+
+def _run(cmd, **kw):
+    print("[ungar_amd build]", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True, **kw)
+
+
+def _newer(outputs, inputs) -> bool:
+    """True when every output exists and is newer than every input."""
+    try:
+        out_t = min(os.path.getmtime(o) for o in outputs)
+    except OSError:
+        return False
+    return all(os.path.getmtime(i) <= out_t for i in inputs)
+
+
+def _tree(*dirs):
+    files = []
+    for d in dirs:
+        for base, _, names in os.walk(d):
+            if os.path.basename(base) == "gen":
+                continue
+            files += [os.path.join(base, n) for n in names if n.endswith((".hpp", ".cpp", ".hip", ".h"))]
+    return files
+
+
+def build_codegen() -> str:
+    exe = os.path.join(BUILD, "ungar_codegen")
+    srcs = _tree(os.path.join(CSRC, "tape"), os.path.join(CSRC, "models"), os.path.join(CSRC, "rbd"), os.path.join(CSRC, "codegen"))
+    if not _newer([exe], srcs):
+        os.makedirs(BUILD, exist_ok=True)
+        _run(["g++", "-std=c++20", "-O2", "-o", exe, os.path.join(CSRC, "codegen", "codegen_main.cpp")])
+    return exe
+
+
+def generate(exe: str):
+    outs = [os.path.join(GEN, f"{m}_gen.hpp") for m in MODELS] + [os.path.join(ORACLE_GEN, f"{m}_cg.c") for m in MODELS]
+    robot = os.path.join(ROOT, "ungar_amd", "data", "anymal_b.robot")
+    if not _newer(outs, [exe, robot]):
+        os.makedirs(GEN, exist_ok=True)
+        os.makedirs(ORACLE_GEN, exist_ok=True)
+        _run([exe, "--out", GEN, "--c-oracle", ORACLE_GEN, "--anymal-robot", robot])
+
+
+def build_library(jobs: int | None = None):
+    os.makedirs(LIBDIR, exist_ok=True)
+    os.makedirs(BUILD, exist_ok=True)
+    kernel_hdr = os.path.join(CSRC, "kernels", "node_kernel.hpp")
+    abi_hdr = os.path.join(ROOT, "include", "ungar_amd.h")
+    units = []  # (source, object, dependencies)
+    for m in MODELS:
+        src = os.path.join(CSRC, "kernels", f"model_{m}.hip")
+        units.append((src, os.path.join(BUILD, f"model_{m}.o"), [src, kernel_hdr, os.path.join(GEN, f"{m}_gen.hpp")]))
+    for name in sorted(os.listdir(os.path.join(CSRC, "kernels"))):
+        if name.endswith(".hip") and not name.startswith("model_"):
+            src = os.path.join(CSRC, "kernels", name)
+            units.append((src, os.path.join(BUILD, name[:-4] + ".o"), [src, kernel_hdr]))
+    src = os.path.join(CSRC, "runtime", "c_api.cpp")
+    units.append((src, os.path.join(BUILD, "c_api.o"), [src, kernel_hdr, abi_hdr]))
+
+    def compile_unit(u):
+        src, obj, deps = u
+        if not _newer([obj], deps):
+            _run(["hipcc", *HIPCC_FLAGS, "-c", src, "-o", obj])
+        return obj
+
+    with ThreadPoolExecutor(max_workers=jobs or min(8, os.cpu_count() or 1)) as pool:
+        objs = list(pool.map(compile_unit, units))
+    if not _newer([LIB], objs):
+        _run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
+    return LIB
+
+
+def build_all():
+    generate(build_codegen())
+    return build_library()
+
+
+if __name__ == "__main__":
+    build_all()
+    print(LIB)
+    sys.exit(0)

@@ -1,0 +1,154 @@
+// ungar_amd :: hand-written HIP kernel skeletons for batched shooting-node evaluation (gfx950).
+//
+// The hot loop of the reference is one generated C function per model, run single-threaded on one
+// problem instance per call (include/ungar/autodiff/function.hpp:186-257).  Here a
+// launch evaluates `count` independent nodes; the straight-line model bodies come from the tape
+// (csrc/gen/<model>_gen.hpp) and are generic over the I/O policy defined in this file, which is
+// where the mapping of lanes onto nodes and of operands onto HBM is decided.
+//
+// Mapping "lane per node" (this file): lane l of a wavefront owns node i = block*BLOCK + l and runs
+// the whole tape in registers.  With the unit-fastest layout (element_stride = count) every
+// load/store instruction of a wavefront touches 64 consecutive doubles = 512 contiguous bytes, so
+// HBM traffic equals the algorithmic bytes; other layouts go through the same code with their
+// strides (correct, but only coalesced when nodes are the fastest axis).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <utility>
+
+namespace ungar_amd::kernels {
+
+struct OperandView {
+    double* base;
+    long long bs, ks, es;  // instance, knot, element strides (doubles)
+};
+
+struct NodeLaunch {
+    long long count, knots;
+    OperandView x, u, w, p, f, jac;
+};
+
+enum : int { kModeValue = 0, kModeSparseJacobian = 1, kModeDenseJacobian = 2 };
+
+/// I/O policy: every lane addresses its own node through (base, element stride).
+template <int NCOLS, bool DENSE>
+struct StridedIO {
+    const double* __restrict__ xb;
+    const double* __restrict__ ub;
+    const double* __restrict__ wb;
+    const double* __restrict__ pb;
+    double* __restrict__ fb;
+    double* __restrict__ jb;
+    long long xe, ue, we, pe, fe, je;
+
+    __device__ __forceinline__ double x(int i) const { return xb[i * xe]; }
+    __device__ __forceinline__ double u(int i) const { return ub[i * ue]; }
+    __device__ __forceinline__ double w(int i) const { return wb[i * we]; }
+    __device__ __forceinline__ double p(int i) const { return pb[i * pe]; }
+    __device__ __forceinline__ void f(int i, double v) const {
+        if (fb) fb[i * fe] = v;
+    }
+    __device__ __forceinline__ void j(int k, int r, int c, double v) const {
+        jb[(DENSE ? r * NCOLS + c : k) * je] = v;
+    }
+};
+
+namespace detail {
+
+/// Dense offset (r * cols + c) of the z-th structural ZERO of the model's Jacobian pattern.
+template <class M>
+constexpr int ZeroOffset(int z) {
+    int seen = 0, k = 0;
+    for (int e = 0; e < M::kJacRows * M::kJacCols; ++e) {
+        const int r = e / M::kJacCols, c = e % M::kJacCols;
+        // pattern is sorted row-major: advance k to the first entry >= (r, c)
+        while (k < M::kJacNnz && (M::JacRow(k) < r || (M::JacRow(k) == r && M::JacCol(k) < c))) ++k;
+        const bool nz = k < M::kJacNnz && M::JacRow(k) == r && M::JacCol(k) == c;
+        if (!nz) {
+            if (seen == z) return e;
+            ++seen;
+        }
+    }
+    return -1;
+}
+
+template <class M, std::size_t... Z>
+__device__ __forceinline__ void StoreZeros(double* __restrict__ jb, long long je, std::index_sequence<Z...>) {
+    // offsets are compile-time constants; one plain store per structural zero
+    ((jb[static_cast<long long>(std::integral_constant<int, ZeroOffset<M>(static_cast<int>(Z))>::value) * je] = 0.0), ...);
+}
+
+}  // namespace detail
+
+/// One lane per shooting node.
+template <class M, int MODE, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void NodeKernel(const NodeLaunch a) {
+    const long long i = static_cast<long long>(blockIdx.x) * BLOCK + threadIdx.x;
+    if (i >= a.count) return;
+    long long b = i, k = 0;
+    if (a.knots > 1) {
+        b = i / a.knots;
+        k = i - b * a.knots;
+    }
+    StridedIO<M::kJacCols, MODE == kModeDenseJacobian> io{
+        a.x.base + b * a.x.bs + k * a.x.ks,
+        a.u.base + b * a.u.bs + k * a.u.ks,
+        a.w.base ? a.w.base + b * a.w.bs + k * a.w.ks : nullptr,
+        a.p.base + b * a.p.bs + k * a.p.ks,
+        a.f.base ? a.f.base + b * a.f.bs + k * a.f.ks : nullptr,
+        MODE == kModeValue ? nullptr : a.jac.base + b * a.jac.bs + k * a.jac.ks,
+        a.x.es, a.u.es, a.w.es, a.p.es, a.f.es, a.jac.es};
+    if constexpr (MODE == kModeValue) {
+        M::Value(io);
+    } else {
+        if constexpr (MODE == kModeDenseJacobian)
+            detail::StoreZeros<M>(io.jb, io.je, std::make_index_sequence<M::kJacRows * M::kJacCols - M::kJacNnz>{});
+        M::ValueJacobian(io);
+    }
+}
+
+template <class M, int BLOCK>
+inline hipError_t LaunchNodeModel(int mode, const NodeLaunch& a, hipStream_t stream) {
+    if (a.count <= 0) return hipSuccess;
+    const dim3 grid(static_cast<unsigned>((a.count + BLOCK - 1) / BLOCK)), block(BLOCK);
+    switch (mode) {
+        case kModeValue: hipLaunchKernelGGL((NodeKernel<M, kModeValue, BLOCK>), grid, block, 0, stream, a); break;
+        case kModeSparseJacobian: hipLaunchKernelGGL((NodeKernel<M, kModeSparseJacobian, BLOCK>), grid, block, 0, stream, a); break;
+        case kModeDenseJacobian: hipLaunchKernelGGL((NodeKernel<M, kModeDenseJacobian, BLOCK>), grid, block, 0, stream, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace ungar_amd::kernels
+
+/// Binds a generated model namespace to the traits the skeletons expect and defines its launcher.
+#define UNGAR_AMD_DEFINE_NODE_MODEL(ns, BLOCK)                                                                   \
+    namespace ungar_amd::kernels {                                                                               \
+    struct Model_##ns {                                                                                          \
+        static constexpr int kNx = gen::ns::kNx, kNu = gen::ns::kNu, kNw = gen::ns::kNw, kNp = gen::ns::kNp;     \
+        static constexpr int kJacRows = gen::ns::kJacRows, kJacCols = gen::ns::kJacCols, kJacNnz = gen::ns::kJacNnz; \
+        static constexpr int JacRow(int k) { return gen::ns::kJacRow[k]; }                                       \
+        static constexpr int JacCol(int k) { return gen::ns::kJacCol[k]; }                                       \
+        template <class IO>                                                                                      \
+        __device__ __forceinline__ static void Value(IO& io) { gen::ns::Value(io); }                             \
+        template <class IO>                                                                                      \
+        __device__ __forceinline__ static void ValueJacobian(IO& io) { gen::ns::ValueJacobian(io); }             \
+    };                                                                                                           \
+    }                                                                                                            \
+    extern "C" int ungar_amd_launch_##ns(int mode, const ungar_amd::kernels::NodeLaunch* a, void* stream) {      \
+        return static_cast<int>(ungar_amd::kernels::LaunchNodeModel<ungar_amd::kernels::Model_##ns, BLOCK>(      \
+            mode, *a, static_cast<hipStream_t>(stream)));                                                        \
+    }                                                                                                            \
+    extern "C" const int* ungar_amd_pattern_##ns(int which, int* nnz) {                                          \
+        *nnz = ungar_amd::gen::ns::kJacNnz;                                                                      \
+        return which == 0 ? ungar_amd::gen::ns::kJacRow : ungar_amd::gen::ns::kJacCol;                           \
+    }                                                                                                            \
+    extern "C" void ungar_amd_dims_##ns(int* d) {                                                                \
+        d[0] = ungar_amd::gen::ns::kNx;                                                                          \
+        d[1] = ungar_amd::gen::ns::kNu;                                                                          \
+        d[2] = ungar_amd::gen::ns::kNw;                                                                          \
+        d[3] = ungar_amd::gen::ns::kNp;                                                                          \
+    }

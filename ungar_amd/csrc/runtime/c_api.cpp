@@ -1,0 +1,188 @@
+// ungar_amd :: implementation of the C ABI declared in include/ungar_amd.h (compiled by hipcc).
+//
+// Thin by design: argument checking, the model registry, and launches.  No allocation and no
+// synchronisation on the batched entry points.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../../include/ungar_amd.h"
+#include "../kernels/node_kernel.hpp"
+
+using ungar_amd::kernels::NodeLaunch;
+using ungar_amd::kernels::OperandView;
+
+#define UNGAR_AMD_DECLARE_MODEL(ns)                                                           \
+    extern "C" int ungar_amd_launch_##ns(int mode, const NodeLaunch* a, void* stream);        \
+    extern "C" const int* ungar_amd_pattern_##ns(int which, int* nnz);                        \
+    extern "C" void ungar_amd_dims_##ns(int* d);
+
+UNGAR_AMD_DECLARE_MODEL(quadrotor)
+UNGAR_AMD_DECLARE_MODEL(rc_car)
+UNGAR_AMD_DECLARE_MODEL(srbd)
+UNGAR_AMD_DECLARE_MODEL(anymal)
+
+extern "C" int ungar_amd_launch_gn_hessian(const double* jac, long long js, long long ldj, const double* d, long long ds, double* g,
+                                            long long gs, long long ldg, int rows, int cols, long long count, void* stream);
+
+namespace {
+
+thread_local std::string g_lastError;
+
+int Fail(int code, const std::string& msg) {
+    g_lastError = msg;
+    return code;
+}
+
+struct BuiltinEntry {
+    const char* name;
+    int (*launch)(int, const NodeLaunch*, void*);
+    const int* (*pattern)(int, int*);
+    void (*dims)(int*);
+};
+
+const BuiltinEntry kBuiltins[] = {
+    {"quadrotor", ungar_amd_launch_quadrotor, ungar_amd_pattern_quadrotor, ungar_amd_dims_quadrotor},
+    {"rc_car", ungar_amd_launch_rc_car, ungar_amd_pattern_rc_car, ungar_amd_dims_rc_car},
+    {"srbd", ungar_amd_launch_srbd, ungar_amd_pattern_srbd, ungar_amd_dims_srbd},
+    {"anymal", ungar_amd_launch_anymal, ungar_amd_pattern_anymal, ungar_amd_dims_anymal},
+};
+
+OperandView View(const ungar_operand& o) {
+    return {o.base, o.instance_stride, o.knot_stride, o.element_stride};
+}
+
+}  // namespace
+
+struct ungar_model {
+    std::string name;
+    ungar_model_info info{};
+    std::vector<int32_t> jacRows, jacCols, hesRows, hesCols;
+    int (*launch)(int, const NodeLaunch*, void*) = nullptr;
+};
+
+namespace {
+
+int Evaluate(const ungar_model* model, const ungar_node_batch* batch, void* stream, int mode) {
+    if (!model || !batch) return Fail(UNGAR_E_INVALID, "null model or batch");
+    if (batch->count < 0 || batch->knots < 1) return Fail(UNGAR_E_INVALID, "batch.count must be >= 0 and batch.knots >= 1");
+    if (batch->count == 0) return UNGAR_OK;
+    if (batch->count % batch->knots != 0) return Fail(UNGAR_E_INVALID, "batch.count must be a multiple of batch.knots");
+    if (!batch->x.base || (model->info.nu > 0 && !batch->u.base) || (model->info.np > 0 && !batch->p.base) ||
+        (model->info.nw > 0 && !batch->w.base))
+        return Fail(UNGAR_E_INVALID, "null input operand for model '" + model->name + "'");
+    if (mode == ungar_amd::kernels::kModeValue && !batch->f.base) return Fail(UNGAR_E_INVALID, "forward_zero needs an output operand f");
+    if (mode != ungar_amd::kernels::kModeValue && !batch->jac.base) return Fail(UNGAR_E_INVALID, "Jacobian evaluation needs an output operand jac");
+    if (mode != ungar_amd::kernels::kModeValue && model->info.jac_nnz == 0)
+        return Fail(UNGAR_E_UNSUPPORTED, "model '" + model->name + "' was built without a Jacobian");
+    NodeLaunch a{batch->count, batch->knots, View(batch->x), View(batch->u), View(batch->w), View(batch->p), View(batch->f), View(batch->jac)};
+    const int err = model->launch(mode, &a, stream);
+    if (err != 0)
+        return Fail(UNGAR_E_HIP, std::string("kernel launch failed for model '") + model->name + "': " + hipGetErrorString(static_cast<hipError_t>(err)));
+    return UNGAR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ungar_model_open(const char* name, ungar_model** out) {
+    if (!name || !out) return Fail(UNGAR_E_INVALID, "ungar_model_open: null argument");
+    for (const BuiltinEntry& e : kBuiltins) {
+        if (std::strcmp(e.name, name) != 0) continue;
+        auto* m = new ungar_model;
+        m->name = name;
+        int d[4];
+        e.dims(d);
+        int nnz = 0;
+        const int* rows = e.pattern(0, &nnz);
+        const int* cols = e.pattern(1, &nnz);
+        m->jacRows.assign(rows, rows + nnz);
+        m->jacCols.assign(cols, cols + nnz);
+        m->info = {d[0], d[1], d[2], d[3], d[0], nnz, 0};
+        m->launch = e.launch;
+        *out = m;
+        return UNGAR_OK;
+    }
+    return Fail(UNGAR_E_INVALID, std::string("unknown model '") + name + "' (built-ins: quadrotor, rc_car, srbd, anymal)");
+}
+
+void ungar_model_close(ungar_model* model) {
+    delete model;
+}
+
+const char* ungar_model_name(const ungar_model* model) {
+    return model ? model->name.c_str() : "";
+}
+
+int ungar_model_get_info(const ungar_model* model, ungar_model_info* info) {
+    if (!model || !info) return Fail(UNGAR_E_INVALID, "ungar_model_get_info: null argument");
+    *info = model->info;
+    return UNGAR_OK;
+}
+
+int ungar_model_jacobian_sparsity(const ungar_model* model, const int32_t** rows, const int32_t** cols, int64_t* nnz) {
+    if (!model || !rows || !cols || !nnz) return Fail(UNGAR_E_INVALID, "ungar_model_jacobian_sparsity: null argument");
+    *rows = model->jacRows.data();
+    *cols = model->jacCols.data();
+    *nnz = static_cast<int64_t>(model->jacRows.size());
+    return UNGAR_OK;
+}
+
+int ungar_model_hessian_sparsity(const ungar_model* model, const int32_t** rows, const int32_t** cols, int64_t* nnz) {
+    if (!model || !rows || !cols || !nnz) return Fail(UNGAR_E_INVALID, "ungar_model_hessian_sparsity: null argument");
+    if (model->info.hes_nnz == 0) return Fail(UNGAR_E_UNSUPPORTED, "model '" + model->name + "' has no Hessian (vector-valued node model)");
+    *rows = model->hesRows.data();
+    *cols = model->hesCols.data();
+    *nnz = static_cast<int64_t>(model->hesRows.size());
+    return UNGAR_OK;
+}
+
+int ungar_model_has_forward_zero(const ungar_model* model) {
+    return model != nullptr;
+}
+int ungar_model_has_sparse_jacobian(const ungar_model* model) {
+    return model && model->info.jac_nnz > 0;
+}
+int ungar_model_has_sparse_hessian(const ungar_model* model) {
+    return model && model->info.hes_nnz > 0;
+}
+
+int ungar_model_forward_zero(const ungar_model* model, const ungar_node_batch* batch, void* stream) {
+    return Evaluate(model, batch, stream, ungar_amd::kernels::kModeValue);
+}
+int ungar_model_sparse_jacobian(const ungar_model* model, const ungar_node_batch* batch, void* stream) {
+    return Evaluate(model, batch, stream, ungar_amd::kernels::kModeSparseJacobian);
+}
+int ungar_model_dense_jacobian(const ungar_model* model, const ungar_node_batch* batch, void* stream) {
+    return Evaluate(model, batch, stream, ungar_amd::kernels::kModeDenseJacobian);
+}
+
+int ungar_gn_hessian(const double* jac, int64_t js, int64_t ld_j, const double* d, int64_t ds, double* g, int64_t gs, int64_t ld_g,
+                     int32_t rows, int32_t cols, int64_t count, void* stream) {
+    if (!jac || !g) return Fail(UNGAR_E_INVALID, "ungar_gn_hessian: null jac or g");
+    if (rows <= 0 || cols <= 0 || count < 0 || ld_j < cols || ld_g < cols) return Fail(UNGAR_E_INVALID, "ungar_gn_hessian: bad dimensions");
+    if (cols > 64) return Fail(UNGAR_E_UNSUPPORTED, "ungar_gn_hessian: cols > 64 not supported (one wavefront tile set per node)");
+    if (count == 0) return UNGAR_OK;
+    const int err = ungar_amd_launch_gn_hessian(jac, js, ld_j, d, ds, g, gs, ld_g, rows, cols, count, stream);
+    if (err != 0) return Fail(UNGAR_E_HIP, std::string("gn_hessian launch failed: ") + hipGetErrorString(static_cast<hipError_t>(err)));
+    return UNGAR_OK;
+}
+
+const char* ungar_last_error(void) {
+    return g_lastError.c_str();
+}
+
+const char* ungar_version(void) {
+    static std::string v = [] {
+        int rt = 0;
+        (void)hipRuntimeGetVersion(&rt);
+        return std::string("ungar_amd 0.1 gfx950 hip ") + std::to_string(rt);
+    }();
+    return v.c_str();
+}
+
+}  // extern "C"
