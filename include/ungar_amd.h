@@ -114,6 +114,63 @@ int ungar_model_dense_jacobian(const ungar_model* model, const ungar_node_batch*
 int ungar_gn_hessian(const double* jac, int64_t js, int64_t ld_j, const double* d, int64_t ds, double* g, int64_t gs, int64_t ld_g,
                      int32_t rows, int32_t cols, int64_t count, void* stream);
 
+/* ---- run-time function factory (any recorded function, not only the built-in node models) ----- */
+
+/* One node of a recorded expression tape, in topological order (operands refer to EARLIER nodes).
+ * `op` codes (ungar_amd/csrc/tape/graph.hpp): 0 const(value), 1 input(a = index into [x; p]),
+ * 2 add, 3 sub, 4 mul, 5 div, 6 neg, 7 sin, 8 cos, 9 tan, 10 asin, 11 acos, 12 atan, 13 exp,
+ * 14 log, 15 sqrt, 16 abs, 17 sign, 18 pow(a,b), 19 atan2(a,b), 20..24 CondExp{Lt,Le,Eq,Ge,Gt}:
+ * (a cmp b) ? c : d.   replaces the CppAD operation sequence recorded between CppAD::Independent
+ * and ADFun(xp, y) (function.hpp:456-466). */
+typedef struct ungar_tape_node {
+    int32_t op, a, b, c, d;
+    int32_t reserved;
+    double value;
+} ungar_tape_node;
+
+typedef struct ungar_function ungar_function;
+
+typedef struct ungar_function_info {
+    int64_t n;        /* independent (decision) variables   -- IndependentVariableSize() */
+    int64_t p;        /* parameters                         -- ParameterSize()            */
+    int64_t m;        /* dependent variables                -- DependentVariableSize()    */
+    int64_t jac_nnz;  /* nnz of the m x n sparse Jacobian (parameter columns trimmed)  */
+    int64_t hes_nnz;  /* nnz of the n x n UPPER-TRIANGULAR Hessian of y[0]              */
+    int64_t cache_hit; /* 1 if the code object was reused from the on-disk cache          */
+} ungar_function_info;
+
+#define UNGAR_ENABLE_NONE 1u      /* EnabledDerivatives::NONE     (autodiff/data_types.hpp:95-100) */
+#define UNGAR_ENABLE_JACOBIAN 2u  /* EnabledDerivatives::JACOBIAN */
+#define UNGAR_ENABLE_HESSIAN 4u   /* EnabledDerivatives::HESSIAN  */
+#define UNGAR_ENABLE_ALL 6u       /* EnabledDerivatives::ALL      */
+
+/* Derives the enabled sparse derivatives of the recorded y = f([x; p]), lowers value / Jacobian /
+ * Hessian to HIP kernels, compiles them with hipcc for gfx950 (or reuses the hashed on-disk code
+ * object under <folder>/<name>/ungar_amd/ unless `recompile`), and loads them.
+ * replaces Autodiff::MakeFunction / FunctionFactory::Make (function.hpp:589-613).
+ * `folder` null or "" -> $UNGAR_CODEGEN_FOLDER, else $TMPDIR/ungar_codegen (data_types.hpp:39-41). */
+int ungar_function_make(const ungar_tape_node* nodes, int64_t num_nodes, const int32_t* outputs, int64_t m, int64_t n, int64_t p,
+                        const char* name, uint32_t enabled_derivatives, const char* folder, int recompile, ungar_function** out);
+void ungar_function_free(ungar_function* fn);
+int ungar_function_get_info(const ungar_function* fn, ungar_function_info* info);
+const char* ungar_function_code_object(const ungar_function* fn);
+/* replaces GenericModel::JacobianSparsity / HessianSparsity(0, ...) (function.hpp:98-105, 135-145). */
+int ungar_function_jacobian_sparsity(const ungar_function* fn, const int32_t** rows, const int32_t** cols, int64_t* nnz);
+int ungar_function_hessian_sparsity(const ungar_function* fn, const int32_t** rows, const int32_t** cols, int64_t* nnz);
+
+/* Batched evaluation over `batch` independent instances (device pointers, stream-ordered).
+ * Element e of instance i: base[i * instance_stride + e * element_stride] (knot_stride unused).
+ * xp holds n+p elements per instance; outputs m / jac_nnz / hes_nnz values per instance.
+ * replaces GenericModel::ForwardZero / SparseJacobian / SparseHessian (function.hpp:186-257). */
+int ungar_function_forward_zero(const ungar_function* fn, const ungar_operand* xp, const ungar_operand* y, int64_t batch, void* stream);
+int ungar_function_sparse_jacobian(const ungar_function* fn, const ungar_operand* xp, const ungar_operand* jac, int64_t batch, void* stream);
+int ungar_function_sparse_hessian(const ungar_function* fn, const ungar_operand* xp, const ungar_operand* hes, int64_t batch, void* stream);
+
+/* Single-instance HOST call (what Ungar::Autodiff::Function::operator()/Jacobian/Hessian need):
+ * copies xp to the device, launches batch = 1, copies the result back, synchronously.
+ * what: 0 value (m doubles), 1 Jacobian values (jac_nnz), 2 Hessian values (hes_nnz). */
+int ungar_function_eval_host(ungar_function* fn, int32_t what, const double* xp_host, double* out_host);
+
 /* ---- diagnostics ------------------------------------------------------------------------------ */
 const char* ungar_last_error(void);
 /* "ungar_amd <version> gfx950 hip <runtime version>" */

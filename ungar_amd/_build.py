@@ -81,6 +81,8 @@ def build_library(jobs: int | None = None):
             units.append((src, os.path.join(BUILD, name[:-4] + ".o"), [src, kernel_hdr]))
     src = os.path.join(CSRC, "runtime", "c_api.cpp")
     units.append((src, os.path.join(BUILD, "c_api.o"), [src, kernel_hdr, abi_hdr]))
+    src = os.path.join(CSRC, "runtime", "function.cpp")
+    units.append((src, os.path.join(BUILD, "function.o"), [src, abi_hdr] + _tree(os.path.join(CSRC, "tape"))))
 
     def compile_unit(u):
         src, obj, deps = u

@@ -53,7 +53,8 @@ __global__ __launch_bounds__(256) void GnHessianKernel(const double* __restrict_
         }
     }
 
-    // D-fragment map of v_mfma_f64_16x16x4_f64: element reg of lane l is C[4 (l >> 4) + reg][l & 15].
+    // D-fragment map of v_mfma_f64_16x16x4_f64 (group size 1, 4 groups per block -- unlike the f32
+    // 16x16 family): element `reg` of lane l is C[4 reg + (l >> 4)][l & 15].
     double* __restrict__ G = g + node * gs;
 #pragma unroll
     for (int a = 0; a < T; ++a)
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(256) void GnHessianKernel(const double* __restrict_
         for (int b = 0; b < T; ++b)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
-                const int row = 16 * a + 4 * lk + reg, col = 16 * b + lc;
+                const int row = 16 * a + 4 * reg + lk, col = 16 * b + lc;
                 if (row < cols && col < cols) G[static_cast<long long>(row) * ldg + col] = acc[a][b][reg];
             }
 }

@@ -29,13 +29,19 @@ extern "C" int ungar_amd_launch_gn_hessian(const double* jac, long long js, long
                                             long long gs, long long ldg, int rows, int cols, long long count, void* stream);
 
 namespace {
-
 thread_local std::string g_lastError;
+}
 
+namespace ungar_amd::runtime {
 int Fail(int code, const std::string& msg) {
     g_lastError = msg;
     return code;
 }
+}  // namespace ungar_amd::runtime
+
+namespace {
+
+using ungar_amd::runtime::Fail;
 
 struct BuiltinEntry {
     const char* name;
