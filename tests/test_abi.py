@@ -1,0 +1,99 @@
+"""CPU checks of the drop-in boundary: libungar_amd.so loads, exports every symbol that
+include/ungar_amd.h declares, reports model metadata without a GPU, and FAILS LOUDLY (no fallback)
+when asked to compute without a device or without the library."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import ungar_amd
+
+
+def _declared_symbols(repo_root):
+    text = open(os.path.join(repo_root, "include", "ungar_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ungar_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported(repo_root):
+    lib = ungar_amd.load_library()
+    names = _declared_symbols(repo_root)
+    assert len(names) >= 25
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, f"declared in include/ungar_amd.h but not exported: {missing}"
+
+
+def test_header_cites_the_reference_interface(repo_root):
+    text = open(os.path.join(repo_root, "include", "ungar_amd.h")).read()
+    assert text.count("function.hpp:") >= 10 and "soft_sqp.hpp:257-264" in text
+
+
+def test_model_metadata_without_gpu():
+    dims = {"quadrotor": (13, 4, 0, 20, 118), "rc_car": (6, 2, 0, 15, 32), "srbd": (13, 24, 4, 6, 238), "anymal": (37, 12, 0, 1, None)}
+    for name, (nx, nu, nw, npar, nnz) in dims.items():
+        m = ungar_amd.NodeModel(name)
+        assert (m.nx, m.nu, m.nw, m.np, m.ny) == (nx, nu, nw, npar, nx)
+        assert m.independent_variable_size() == nx + nu and m.parameter_size() == nw + npar and m.dependent_variable_size() == nx
+        assert m.implements_function() and m.implements_jacobian() and not m.implements_hessian()
+        rows, cols = m.jacobian_sparsity()
+        if nnz is not None:
+            assert m.jac_nnz == nnz
+        assert len(rows) == m.jac_nnz and rows.max() < nx and cols.max() < nx + nu
+        key = rows.astype(np.int64) * (nx + nu) + cols
+        assert (np.diff(key) > 0).all(), "CSR pattern must be canonical (row-major, ascending)"
+        starts, outer = m.jacobian_csr()
+        assert starts[-1] == m.jac_nnz and (np.diff(starts) >= 0).all()
+
+
+def test_errors_are_reported_not_swallowed():
+    lib = ungar_amd.load_library()
+    with pytest.raises(ungar_amd.UngarError, match="unknown model"):
+        ungar_amd.NodeModel("pendulum")
+    h = ctypes.c_void_p()
+    assert lib.ungar_model_open(None, ctypes.byref(h)) == -1
+    assert b"null" in lib.ungar_last_error()
+    m = ungar_amd.NodeModel("rc_car")
+    rows = ctypes.POINTER(ctypes.c_int32)()
+    nnz = ctypes.c_int64()
+    assert lib.ungar_model_hessian_sparsity(m._h, ctypes.byref(rows), ctypes.byref(rows), ctypes.byref(nnz)) == -3  # UNSUPPORTED
+
+
+def test_no_cpu_fallback_operands_must_be_device_tensors():
+    import torch
+    m = ungar_amd.NodeModel("rc_car")
+    host = torch.zeros((4, 6), dtype=torch.float64)
+    with pytest.raises(ungar_amd.UngarError, match="CUDA"):
+        m.forward_zero(4, ungar_amd.Operand.aos(host, 6), ungar_amd.Operand.aos(host, 2), None, ungar_amd.Operand.aos(host, 15),
+                       ungar_amd.Operand.aos(host, 6))
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(ungar_amd, "_LIB", None)
+    monkeypatch.setattr(ungar_amd, "library_path", lambda: str(tmp_path / "libungar_amd.so"))
+    with pytest.raises(ungar_amd.UngarError, match="no CPU fallback"):
+        ungar_amd.load_library()
+
+
+def test_function_factory_rejects_bad_tapes():
+    """Host logic of ungar_function_make (argument validation happens before any device work)."""
+    lib = ungar_amd.load_library()
+
+    class Node(ctypes.Structure):
+        _fields_ = [("op", ctypes.c_int32), ("a", ctypes.c_int32), ("b", ctypes.c_int32), ("c", ctypes.c_int32), ("d", ctypes.c_int32),
+                    ("reserved", ctypes.c_int32), ("value", ctypes.c_double)]
+
+    fn = ctypes.c_void_p()
+    out = (ctypes.c_int32 * 1)(1)
+    # node 1 = add(node 0, node 5): forward reference -> invalid
+    nodes = (Node * 2)(Node(1, 0, -1, -1, -1, 0, 0.0), Node(2, 0, 5, -1, -1, 0, 0.0))
+    lib.ungar_function_make.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                        ctypes.c_char_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+    rc = lib.ungar_function_make(nodes, 2, out, 1, 1, 0, b"bad", 2, None, 0, ctypes.byref(fn))
+    assert rc == -1 and b"references" in lib.ungar_last_error()
+    # Hessian of a vector-valued function: reference asserts "implemented only for scalar functions"
+    nodes = (Node * 2)(Node(1, 0, -1, -1, -1, 0, 0.0), Node(7, 0, -1, -1, -1, 0, 0.0))
+    out2 = (ctypes.c_int32 * 2)(0, 1)
+    rc = lib.ungar_function_make(nodes, 2, out2, 2, 1, 0, b"bad", 6, None, 0, ctypes.byref(fn))
+    assert rc == -3 and b"scalar functions" in lib.ungar_last_error()

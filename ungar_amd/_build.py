@@ -97,9 +97,30 @@ def build_library(jobs: int | None = None):
     return LIB
 
 
+def build_cpp_tests():
+    """Host-side C++ programs exercising the facade headers (ungar_amd/include/ungar): run by
+    tests/test_layout.py (CPU) and tests/test_cpp_facade.py (GPU box, prebuilt binaries travel)."""
+    inc = os.path.join(ROOT, "ungar_amd", "include")
+    hdrs = _tree(inc, os.path.join(CSRC, "tape")) + [os.path.join(ROOT, "include", "ungar_amd.h")]
+    jobs = []
+    for name, link in (("layout_dump", False), ("function_test", True)):
+        src = os.path.join(ROOT, "tests", "cpp", f"{name}.cpp")
+        exe = os.path.join(BUILD, name)
+        if _newer([exe], [src, *hdrs] + ([LIB] if link else [])):
+            continue
+        cmd = ["g++", "-std=c++20", "-O1", "-I", inc, "-o", exe, src]
+        if link:
+            cmd += ["-L", LIBDIR, "-lungar_amd", "-Wl,-rpath,$ORIGIN/../ungar_amd/lib", "-Wl,-rpath,/opt/rocm/lib"]
+        jobs.append(cmd)
+    for cmd in jobs:
+        _run(cmd)
+
+
 def build_all():
     generate(build_codegen())
-    return build_library()
+    lib = build_library()
+    build_cpp_tests()
+    return lib
 
 
 if __name__ == "__main__":
