@@ -15,7 +15,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 GEN = os.path.join(HERE, "_gen")
-MODELS = ("quadrotor", "rc_car", "srbd", "anymal")
+MODELS = ("quadrotor", "rc_car", "srbd", "anymal", "anymal_ad")
 REFERENCE_FLAGS = ["-O3", "-g", "-march=native", "-mtune=native", "-ffast-math"]  # function.hpp:610-611
 PORTABLE_FLAGS = ["-O3", "-march=x86-64-v3", "-ffast-math"]
 

@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-MODELS = ("quadrotor", "rc_car", "srbd", "anymal")
+MODELS = ("quadrotor", "rc_car", "srbd", "anymal", "anymal_ad")
 
 
 @pytest.fixture(scope="module")
@@ -25,7 +25,7 @@ def clib(repo_root):
 
 @pytest.mark.parametrize("name", MODELS)
 def test_generated_c_matches_golden(repo_root, clib, name):
-    g = np.load(f"{repo_root}/tests/golden/node_{name}.npz")
+    g = np.load(f"{repo_root}/tests/golden/node_{name.replace('_ad', '')}.npz")
     dims = (ctypes.c_int * 4).in_dll(clib, f"{name}_dims")
     nx, nu, nw, _ = list(dims)
     nnz = ctypes.c_int.in_dll(clib, f"{name}_jac_nnz").value

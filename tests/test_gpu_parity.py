@@ -13,7 +13,12 @@ from oracle import ungar_oracle as O
 
 pytestmark = pytest.mark.gpu
 
-MODELS = ("quadrotor", "rc_car", "srbd", "anymal")
+MODELS = ("quadrotor", "rc_car", "srbd", "anymal", "anymal_ad")
+
+
+def _oracle_name(name):
+    """'anymal_ad' is the same function as 'anymal' with derivatives by taped ABA."""
+    return name.replace("_ad", "")
 
 
 def _assert_close(name, got_f, got_J, ref_f, ref_J):
@@ -41,7 +46,7 @@ def ua():
 @pytest.mark.parametrize("layout", ["soa", "aos"])
 @pytest.mark.parametrize("mode", ["dense", "sparse"])
 def test_golden_vectors(ua, repo_root, name, layout, mode):
-    g = np.load(f"{repo_root}/tests/golden/node_{name}.npz")
+    g = np.load(f"{repo_root}/tests/golden/node_{_oracle_name(name)}.npz")
     m = ua.NodeModel(name)
     f, J = m.evaluate_numpy(g["x"], g["u"], g["w"], g["p"], mode=mode, layout=layout)
     _assert_close(name, f, J, g["f"], g["J"])
@@ -49,16 +54,16 @@ def test_golden_vectors(ua, repo_root, name, layout, mode):
 
 @pytest.mark.parametrize("name", MODELS)
 def test_forward_zero_matches_golden(ua, repo_root, name):
-    g = np.load(f"{repo_root}/tests/golden/node_{name}.npz")
+    g = np.load(f"{repo_root}/tests/golden/node_{_oracle_name(name)}.npz")
     f, _ = ua.NodeModel(name).evaluate_numpy(g["x"], g["u"], g["w"], g["p"], mode="value")
     assert np.abs(f - g["f"]).max() <= 1e-10 * max(1.0, np.abs(g["f"]).max())
 
 
-@pytest.mark.parametrize("name,count", [("quadrotor", 200), ("rc_car", 300), ("srbd", 100), ("anymal", 70)])
+@pytest.mark.parametrize("name,count", [("quadrotor", 200), ("rc_car", 300), ("srbd", 100), ("anymal", 70), ("anymal_ad", 70)])
 def test_live_oracle_seeded(ua, name, count):
     """Ragged count (not a multiple of the wavefront/block size) on fresh seeded inputs."""
-    x, u, w, p = O.synthetic_inputs(name, count, seed=123)
-    rf, rJ = O.node_jacobian(name, x, u, w, p)
+    x, u, w, p = O.synthetic_inputs(_oracle_name(name), count, seed=123)
+    rf, rJ = O.node_jacobian(_oracle_name(name), x, u, w, p)
     f, J = ua.NodeModel(name).evaluate_numpy(x, u, w, p, mode="dense", layout="soa")
     _assert_close(name, f, J, rf, rJ)
 
@@ -95,6 +100,7 @@ FULL = {  # BASELINE.json configs[1..3]
     "quadrotor": (4096, 128),
     "rc_car": (16384, 200),
     "anymal": (4096, 20),
+    "anymal_ad": (4096, 20),
 }
 
 
@@ -102,6 +108,7 @@ def _device_inputs(name, count, seed):
     import torch
     gen = torch.Generator(device="cuda")
     gen.manual_seed(seed)
+    name = _oracle_name(name)
     nx, nu, nw, npar = O.DIMS[name]
     x = torch.rand((nx, count), generator=gen, device="cuda", dtype=torch.float64) * 2 - 1
     u = torch.rand((nu, count), generator=gen, device="cuda", dtype=torch.float64) * 2 - 1
@@ -182,8 +189,30 @@ def test_full_size_properties(ua, name):
     assert ((fd - Jd).abs().max() / scale).item() < 1e-6
 
     # (5) unit quaternion preserved by q+ = q * exp~(dt w+)
-    if name in ("quadrotor", "anymal"):
+    if name in ("quadrotor", "anymal", "anymal_ad"):
         assert (f[3:7].norm(dim=0) - 1).abs().max().item() < 1e-12
+
+
+def test_structured_and_taped_aba_kernels_agree_at_full_size(ua):
+    """'anymal' (implicit differentiation: CRBA + RNEA tangents + U D U^T solves) and 'anymal_ad'
+    (derivatives by taping ABA, the reference's route) are different algorithms for the same
+    Jacobian: they must agree to rounding on the whole BASELINE batch."""
+    import torch
+    count = 4096 * 20
+    x, u, p = _device_inputs("anymal", count, seed=21)
+    out = {}
+    for name in ("anymal", "anymal_ad"):
+        m = ua.NodeModel(name)
+        f = torch.empty((37, count), dtype=torch.float64, device="cuda")
+        J = torch.empty((37 * 49, count), dtype=torch.float64, device="cuda")
+        m.dense_jacobian(count, ua.Operand.soa(x, count), ua.Operand.soa(u, count), None, ua.Operand.per_instance(p, 1, shared=True),
+                         ua.Operand.soa(f, count), ua.Operand.soa(J, count))
+        out[name] = (f, J)
+    torch.cuda.synchronize()
+    (f0, J0), (f1, J1) = out["anymal"], out["anymal_ad"]
+    assert (f0 - f1).abs().max().item() < 1e-10
+    scale = J1.abs().amax(dim=0, keepdim=True)
+    assert ((J0 - J1).abs() / scale).max().item() < 1e-9
 
 
 def test_gn_hessian_mfma(ua):

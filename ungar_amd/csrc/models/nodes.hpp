@@ -163,22 +163,28 @@ void SrbdNode(const S* x, const S* u, const S* w, const S* p, S* xn) {
 ///   p+  = p + dt R(quat) v+_lin          (v_lin is body-frame, Pinocchio free-flyer convention)
 ///   quat+ = quat * ApproximateExponentialMap(dt w+)
 ///   qj+ = qj + dt vj+
+/// Integration half of the floating-base node: (x, a, dt) -> x+ (see FloatingBaseNode).
+template <class S>
+void IntegrateFloatingBase(const rbd::Model& model, const S* x, const S* a, const S& dt, S* xn) {
+    const std::size_t nq = static_cast<std::size_t>(model.nq), nv = static_cast<std::size_t>(model.nv);
+    std::vector<S> vN(nv);
+    for (std::size_t k = 0; k < nv; ++k) vN[k] = x[nq + k] + dt * a[k];
+    const Quat<S> quat{x[3], x[4], x[5], x[6]};
+    const Vec3<S> lin = Rotate(quat, Vec3<S>{vN[0], vN[1], vN[2]});
+    for (std::size_t k = 0; k < 3; ++k) xn[k] = x[k] + dt * lin[k];
+    const Quat<S> qN = QuatMul(quat, ApproximateExponentialMap(Scale(dt, Vec3<S>{vN[3], vN[4], vN[5]})));
+    for (std::size_t k = 0; k < 4; ++k) xn[3 + k] = qN[k];
+    for (std::size_t k = 7; k < nq; ++k) xn[k] = x[k] + dt * vN[k - 1];
+    for (std::size_t k = 0; k < nv; ++k) xn[nq + k] = vN[k];
+}
+
 template <class S>
 void FloatingBaseNode(const rbd::Model& model, const S* x, const S* u, const S* /*w*/, const S* p, S* xn) {
     const std::size_t nq = static_cast<std::size_t>(model.nq), nv = static_cast<std::size_t>(model.nv);
-    const S dt = p[0];
     std::vector<S> q(x, x + nq), v(x + nq, x + nq + nv), tau(nv, S{0.0});
     for (std::size_t k = 6; k < nv; ++k) tau[k] = u[k - 6];
     const std::vector<S> a = rbd::Aba(model, q, v, tau);
-    std::vector<S> vN(nv);
-    for (std::size_t k = 0; k < nv; ++k) vN[k] = v[k] + dt * a[k];
-    const Quat<S> quat{q[3], q[4], q[5], q[6]};
-    const Vec3<S> lin = Rotate(quat, Vec3<S>{vN[0], vN[1], vN[2]});
-    for (std::size_t k = 0; k < 3; ++k) xn[k] = q[k] + dt * lin[k];
-    const Quat<S> qN = QuatMul(quat, ApproximateExponentialMap(Scale(dt, Vec3<S>{vN[3], vN[4], vN[5]})));
-    for (std::size_t k = 0; k < 4; ++k) xn[3 + k] = qN[k];
-    for (std::size_t k = 7; k < nq; ++k) xn[k] = q[k] + dt * vN[k - 1];
-    for (std::size_t k = 0; k < nv; ++k) xn[nq + k] = vN[k];
+    IntegrateFloatingBase(model, x, a.data(), p[0], xn);
 }
 
 }  // namespace ungar_amd::models

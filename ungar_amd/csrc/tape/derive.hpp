@@ -119,7 +119,10 @@ struct SparseEntries {
 
 class Differentiator {
   public:
-    explicit Differentiator(Tape& tape) : t_{tape}, g_{tape.graph} {
+    explicit Differentiator(Tape& tape) : g_{tape.graph}, t_{tape.inputs, tape.outputs} {
+    }
+    /// Operate directly on a graph (e.g. the thread's recording graph) with the given input nodes.
+    Differentiator(Graph& graph, std::vector<Id> inputs, std::vector<Id> outputs = {}) : g_{graph}, t_{std::move(inputs), std::move(outputs)} {
     }
 
     /// Differentiable-dependency bitsets for nodes [0, limit): bit j of dep(node) is set iff the
@@ -154,46 +157,99 @@ class Differentiator {
     /// counting which creates fewer new nodes (both are exact; CppADCodeGen makes the same kind of
     /// per-model choice).  mode: 0 = auto, 1 = forward, 2 = reverse.
     SparseEntries Jacobian(int nCols, int mode = 0) {
+        std::vector<int> cols(static_cast<std::size_t>(nCols));
+        for (int j = 0; j < nCols; ++j) cols[static_cast<std::size_t>(j)] = j;
+        return Jacobian(t_.outputs, cols, mode);
+    }
+
+    /// General form: d outs[i] / d input(cols[j]); entry (i, j) indexes into `outs` / `cols`.
+    SparseEntries Jacobian(const std::vector<Id>& outs, const std::vector<int>& cols, int mode = 0) {
         const Id limit = static_cast<Id>(g_.Size());
         ComputeDependencies(limit);
         SparseEntries e;
-        e.rows = static_cast<int>(t_.outputs.size());
-        e.cols = nCols;
+        e.rows = static_cast<int>(outs.size());
+        e.cols = static_cast<int>(cols.size());
         for (int i = 0; i < e.rows; ++i)
-            for (int j = 0; j < nCols; ++j)
-                if (DependsOn(t_.outputs[static_cast<std::size_t>(i)], j)) {
+            for (int j = 0; j < e.cols; ++j)
+                if (DependsOn(outs[static_cast<std::size_t>(i)], cols[static_cast<std::size_t>(j)])) {
                     e.row.push_back(i);
                     e.col.push_back(j);
                 }
         e.value.assign(e.row.size(), kNoId);
-        if (mode == 0) {
-            // Forward costs ~ sum over nodes of |dep(node) ∩ cols|; reverse ~ sum over nodes of
-            // #outputs reaching the node.  Estimate both from the bitsets, no graph growth.
-            mode = EstimateForwardCost(limit, nCols) <= EstimateReverseCost(limit) ? 1 : 2;
+        // restrict all work to the sub-DAG the requested outputs can reach
+        active_.assign(static_cast<std::size_t>(limit), 0);
+        for (Id o : outs) active_[static_cast<std::size_t>(o)] = 1;
+        for (Id i = limit; i-- > 0;) {
+            if (!active_[static_cast<std::size_t>(i)]) continue;
+            const Node& nd = g_.At(i);
+            if (Arity(nd.op) == 0) continue;
+            for (Id o : {nd.a, nd.b, nd.c, nd.d})
+                if (o != kNoId) active_[static_cast<std::size_t>(o)] = 1;
         }
+        if (mode == 0) mode = EstimateForwardCost(limit, cols) <= EstimateReverseCost(limit, outs) ? 1 : 2;
         lastMode_ = mode;
         if (mode == 1) {
             std::vector<Id> d;
-            for (int j = 0; j < nCols; ++j) {
+            for (int j = 0; j < e.cols; ++j) {
                 bool any = false;
                 for (std::size_t k = 0; k < e.col.size() && !any; ++k) any = e.col[k] == j;
                 if (!any) continue;
-                ForwardSweep(limit, j, d);
+                ForwardSweep(limit, cols[static_cast<std::size_t>(j)], d);
                 for (std::size_t k = 0; k < e.col.size(); ++k)
-                    if (e.col[k] == j)
-                        e.value[k] = d[static_cast<std::size_t>(t_.outputs[static_cast<std::size_t>(e.row[k])])];
+                    if (e.col[k] == j) e.value[k] = d[static_cast<std::size_t>(outs[static_cast<std::size_t>(e.row[k])])];
             }
         } else {
             std::vector<Id> adj;
             std::size_t k = 0;
             for (int i = 0; i < e.rows; ++i) {
                 if (k >= e.row.size() || e.row[k] != i) continue;
-                ReverseSweep(limit, t_.outputs[static_cast<std::size_t>(i)], adj);
+                ReverseSweep(limit, outs[static_cast<std::size_t>(i)], adj);
                 for (; k < e.row.size() && e.row[k] == i; ++k)
-                    e.value[k] = adj[static_cast<std::size_t>(t_.inputs[static_cast<std::size_t>(e.col[k])])];
+                    e.value[k] = adj[static_cast<std::size_t>(t_.inputs[static_cast<std::size_t>(cols[static_cast<std::size_t>(e.col[k])])])];
             }
         }
+        active_.clear();
         return e;
+    }
+
+    /// Replaces input nodes by expressions (inputIndex -> expression id) in the sub-DAGs under
+    /// `roots`; returns the rewritten roots.  Used to compose separately differentiated stages.
+    std::vector<Id> Substitute(const std::vector<Id>& roots, const std::vector<std::pair<int, Id>>& inputToExpr) {
+        const Id limit = static_cast<Id>(g_.Size());
+        std::vector<char> live(static_cast<std::size_t>(limit), 0);
+        for (Id r : roots) live[static_cast<std::size_t>(r)] = 1;
+        for (Id i = limit; i-- > 0;) {
+            if (!live[static_cast<std::size_t>(i)]) continue;
+            const Node& nd = g_.At(i);
+            if (Arity(nd.op) == 0) continue;
+            for (Id o : {nd.a, nd.b, nd.c, nd.d})
+                if (o != kNoId) live[static_cast<std::size_t>(o)] = 1;
+        }
+        std::vector<Id> map(static_cast<std::size_t>(limit), kNoId);
+        for (Id i = 0; i < limit; ++i) {
+            if (!live[static_cast<std::size_t>(i)]) continue;
+            const Node nd = g_.At(i);
+            Id r = i;
+            if (nd.op == Op::Input) {
+                for (const auto& [idx, expr] : inputToExpr)
+                    if (idx == nd.a) r = expr;
+            } else if (nd.op != Op::Const) {
+                auto m = [&](Id o) { return o == kNoId ? kNoId : map[static_cast<std::size_t>(o)]; };
+                const Id a = m(nd.a), b = m(nd.b), c = m(nd.c), d = m(nd.d);
+                if (a != nd.a || b != nd.b || c != nd.c || d != nd.d) {
+                    switch (Arity(nd.op)) {
+                        case 1: r = g_.Unary(nd.op, a); break;
+                        case 2: r = g_.Binary(nd.op, a, b); break;
+                        default: r = g_.Cond(nd.op, a, b, c, d);
+                    }
+                }
+            }
+            map[static_cast<std::size_t>(i)] = r;
+        }
+        std::vector<Id> out;
+        out.reserve(roots.size());
+        for (Id r : roots) out.push_back(map[static_cast<std::size_t>(r)]);
+        return out;
     }
 
     /// Sparse upper-triangular Hessian of outputs[outputIndex] over inputs[0, nCols):
@@ -243,29 +299,25 @@ class Differentiator {
         for (std::size_t w = 0; w < words_; ++w) dst[w] |= src[w];
     }
 
-    double EstimateForwardCost(Id limit, int nCols) const {
+    double EstimateForwardCost(Id limit, const std::vector<int>& cols) const {
+        std::vector<std::uint64_t> mask(words_, 0);
+        for (int c : cols) mask[static_cast<std::size_t>(c) / 64] |= 1ULL << (static_cast<std::size_t>(c) % 64);
+        // only nodes that some requested output can reach matter; approximate with all nodes
         double c = 0;
         for (Id id = 0; id < limit; ++id) {
-            if (Arity(g_.At(id).op) == 0) continue;
-            for (std::size_t w = 0; w < words_; ++w) {
-                std::uint64_t bits = Dep(id)[w];
-                if ((w + 1) * 64 > static_cast<std::size_t>(nCols)) {
-                    const std::size_t keep = static_cast<std::size_t>(nCols) > w * 64 ? static_cast<std::size_t>(nCols) - w * 64 : 0;
-                    bits &= keep >= 64 ? ~0ULL : ((1ULL << keep) - 1ULL);
-                }
-                c += static_cast<double>(__builtin_popcountll(bits));
-            }
+            if (Arity(g_.At(id).op) == 0 || (!active_.empty() && !active_[static_cast<std::size_t>(id)])) continue;
+            for (std::size_t w = 0; w < words_; ++w) c += static_cast<double>(__builtin_popcountll(Dep(id)[w] & mask[w]));
         }
         return c;
     }
 
-    double EstimateReverseCost(Id limit) const {
+    double EstimateReverseCost(Id limit, const std::vector<Id>& outs) const {
         // #outputs reaching each node, by reverse propagation of output-membership bitsets.
-        const std::size_t m = t_.outputs.size();
+        const std::size_t m = outs.size();
         const std::size_t w = (m + 63) / 64;
         std::vector<std::uint64_t> reach(static_cast<std::size_t>(limit) * w, 0);
         for (std::size_t i = 0; i < m; ++i)
-            reach[static_cast<std::size_t>(t_.outputs[i]) * w + i / 64] |= 1ULL << (i % 64);
+            reach[static_cast<std::size_t>(outs[i]) * w + i / 64] |= 1ULL << (i % 64);
         double c = 0;
         for (Id id = limit; id-- > 0;) {
             const Node& nd = g_.At(id);
@@ -352,6 +404,7 @@ class Differentiator {
         d.assign(static_cast<std::size_t>(limit), zero);
         for (Id id = 0; id < limit; ++id) {
             if (id < depLimit_ && !DependsOn(id, j)) continue;
+            if (!active_.empty() && !active_[static_cast<std::size_t>(id)]) continue;
             const Node nd = g_.At(id);
             if (nd.op == Op::Input) {
                 if (nd.a == j) d[static_cast<std::size_t>(id)] = g_.Constant(1.0);
@@ -394,12 +447,16 @@ class Differentiator {
         }
     }
 
-    Tape& t_;
+    struct Io {
+        std::vector<Id> inputs, outputs;
+    };
     Graph& g_;
+    Io t_;
     std::vector<std::uint64_t> dep_;
     std::size_t words_ = 1;
     Id depLimit_ = 0;
     std::vector<std::array<Id, 2>> partials_;
+    std::vector<char> active_;  // when non-empty: nodes the current Jacobian request can reach
     int lastMode_ = 0;
 };
 
