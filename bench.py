@@ -112,6 +112,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="anymal", choices=sorted(WORKLOADS))
     ap.add_argument("--batch-per-gpu", type=int, default=None)
+    ap.add_argument("--model", default=None, help="kernel variant of the workload's model (e.g. anymal_ad, anymal_lds)")
     ap.add_argument("--layout", default="soa", choices=["soa"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -134,7 +135,8 @@ def main():
     model_name, N, default_batch = WORKLOADS[args.workload]
     batch = args.batch_per_gpu or default_batch
     count = batch * N  # nodes evaluated by THIS rank per step (batch axis sharded across ranks)
-    m = ungar_amd.NodeModel(model_name)
+    kernel_model = args.model or model_name
+    m = ungar_amd.NodeModel(kernel_model)
     nx, nu, ncols = m.nx, m.nu, m.nx + m.nu
     x, u, w, p = synth_device_inputs(model_name, count, seed=rank, torch=torch)
     f = torch.empty((nx, count), dtype=torch.float64, device="cuda")
@@ -200,7 +202,7 @@ def main():
                        "parallelism": f"batch-sharded x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel_ms": kernel_ms, "algorithmic_bytes_per_eval": bytes_per_eval,
-                         "kernel": f"NodeKernel<{model_name}, dense Jacobian>"},
+                         "kernel": f"NodeKernel<{kernel_model}, dense Jacobian>"},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(model_name, args.cpu_seconds)

@@ -20,7 +20,8 @@ BUILD = os.path.join(ROOT, "build")
 LIBDIR = os.path.join(ROOT, "ungar_amd", "lib")
 LIB = os.path.join(LIBDIR, "libungar_amd.so")
 ORACLE_GEN = os.path.join(ROOT, "oracle", "_gen")
-MODELS = ("quadrotor", "rc_car", "srbd", "anymal", "anymal_ad")
+MODELS = ("quadrotor", "rc_car", "srbd", "anymal", "anymal_ad", "anymal_lds")
+C_MODELS = ("quadrotor", "rc_car", "srbd", "anymal", "anymal_ad")
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-Wno-unused-result"]
 
 
@@ -58,12 +59,12 @@ def build_codegen() -> str:
 
 
 def generate(exe: str):
-    outs = [os.path.join(GEN, f"{m}_gen.hpp") for m in MODELS] + [os.path.join(ORACLE_GEN, f"{m}_cg.c") for m in MODELS]
+    outs = [os.path.join(GEN, f"{m}_gen.hpp") for m in MODELS] + [os.path.join(ORACLE_GEN, f"{m}_cg.c") for m in C_MODELS]
     robot = os.path.join(ROOT, "ungar_amd", "data", "anymal_b.robot")
     if not _newer(outs, [exe, robot]):
         os.makedirs(GEN, exist_ok=True)
         os.makedirs(ORACLE_GEN, exist_ok=True)
-        _run([exe, "--out", GEN, "--c-oracle", ORACLE_GEN, "--anymal-robot", robot])
+        _run([exe, "--out", GEN, "--c-oracle", ORACLE_GEN, "--anymal-robot", robot, "--lds-slots", "320"])
 
 
 def build_library(jobs: int | None = None):

@@ -213,7 +213,7 @@ std::string HipPrologue(const models::NodeDims& d, const std::vector<char>& used
     return os.str();
 }
 
-void EmitHip(const Generated& g, const std::string& dir, bool columnMajorEmission = false) {
+void EmitHip(const Generated& g, const std::string& dir, bool columnMajorEmission = false, int ldsSlots = 0, int rematConsumers = 2, int rematDepth = 3) {
     const auto& d = g.dims;
     const std::string name = d.name;
     std::ostringstream os;
@@ -277,6 +277,50 @@ void EmitHip(const Generated& g, const std::string& dir, bool columnMajorEmissio
                      g.jac.rows * g.jac.cols, g.jacMode == 1 ? "forward" : g.jacMode == 2 ? "reverse" : "implicit", em.Stats().statements, em.Stats().flops,
                      em.Stats().transcendentals, em.Stats().divisions);
     }
+    // Value + Jacobian, phased with an explicit per-lane LDS home for cross-phase values.
+    if (ldsSlots > 0) {
+        std::vector<std::string> names;
+        for (int i = 0; i < d.nx; ++i) names.push_back("io.x(" + std::to_string(i) + ")");
+        for (int i = 0; i < d.nu; ++i) names.push_back("io.u(" + std::to_string(i) + ")");
+        for (int i = 0; i < d.nw; ++i) names.push_back("io.w(" + std::to_string(i) + ")");
+        for (int i = 0; i < d.np; ++i) names.push_back("io.p(" + std::to_string(i) + ")");
+        for (int i = 0; i < 64; ++i) names.push_back("aux_unused");
+        std::vector<std::vector<tape::OutputSlot>> phases(1);
+        for (int i = 0; i < d.nx; ++i) phases[0].push_back({g.tape.outputs[static_cast<std::size_t>(i)], "io.f(" + std::to_string(i) + ", %s);"});
+        // Column order: columns that share sub-expressions are made neighbours so that the shared
+        // values die quickly: base twist, pose, then (q_j, v_j, u_j) joint by joint.
+        std::vector<int> colOrder;
+        if (d.nx == 37 && d.nu == 12) {
+            for (int c = 19; c < 25; ++c) colOrder.push_back(c);
+            for (int c = 0; c < 7; ++c) colOrder.push_back(c);
+            for (int j = 0; j < 12; ++j) {
+                colOrder.push_back(7 + j);
+                colOrder.push_back(25 + j);
+                colOrder.push_back(37 + j);
+            }
+        } else {
+            for (int c = 0; c < g.jac.cols; ++c) colOrder.push_back(c);
+        }
+        for (int c : colOrder) {
+            std::vector<tape::OutputSlot> ph;
+            for (std::size_t k = 0; k < g.jac.Nnz(); ++k)
+                if (g.jac.col[k] == c)
+                    ph.push_back({g.jac.value[k],
+                                  "io.j(" + std::to_string(k) + ", " + std::to_string(g.jac.row[k]) + ", " + std::to_string(g.jac.col[k]) + ", %s);"});
+            if (!ph.empty()) phases.push_back(std::move(ph));
+        }
+        tape::Emitter em{g.tape.graph, names};
+        int used = 0;
+        const std::string body = em.EmitPhased(phases, ldsSlots, used, rematConsumers, rematDepth);
+        os << "// phased: " << phases.size() << " phases, " << used << " LDS slots per lane, " << em.Stats().statements << " statements\n"
+           << "inline constexpr int kLdsSlots = " << used << ";\n"
+           << "template <class IO>\n__device__ __forceinline__ void ValueJacobianPhased(IO& io) {\n"
+           << body << "}\n\n";
+        std::fprintf(stderr, "[codegen] %-10s phased: %zu phases, %d LDS slots/lane (cap %d), %zu statements\n", d.name, phases.size(), used, ldsSlots,
+                     em.Stats().statements);
+    } else {
+        os << "inline constexpr int kLdsSlots = 0;\ntemplate <class IO>\n__device__ __forceinline__ void ValueJacobianPhased(IO&) {}\n";
+    }
     os << "}  // namespace ungar_amd::gen::" << name << "\n";
     std::ofstream f(dir + "/" + name + "_gen.hpp");
     f << os.str();
@@ -323,7 +367,8 @@ void EmitC(const Generated& g, const std::string& dir) {
 
 int main(int argc, char** argv) {
     std::string outDir, cDir, robot;
-    int jacMode = 0, structuredDMode = 0;
+    int jacMode = 0, structuredDMode = 1, ldsSlots = 0;
+    int rematConsumers = 2, rematDepth = 3;
     std::vector<std::string> only;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
@@ -332,6 +377,9 @@ int main(int argc, char** argv) {
         else if (a == "--anymal-robot" && i + 1 < argc) robot = argv[++i];
         else if (a == "--jac-mode" && i + 1 < argc) jacMode = std::atoi(argv[++i]);
         else if (a == "--structured-dmode" && i + 1 < argc) structuredDMode = std::atoi(argv[++i]);
+        else if (a == "--lds-slots" && i + 1 < argc) ldsSlots = std::atoi(argv[++i]);
+        else if (a == "--remat-consumers" && i + 1 < argc) rematConsumers = std::atoi(argv[++i]);
+        else if (a == "--remat-depth" && i + 1 < argc) rematDepth = std::atoi(argv[++i]);
         else if (a == "--model" && i + 1 < argc) only.push_back(argv[++i]);
         else {
             std::fprintf(stderr, "usage: %s --out DIR [--c-oracle DIR] [--anymal-robot FILE] [--jac-mode 0|1|2] [--model NAME]...\n", argv[0]);
@@ -369,15 +417,20 @@ int main(int argc, char** argv) {
         if (std::string(s.dims.name) == "anymal") {
             // "anymal_ad": derivatives by taping ABA (what the reference does, robot.test.cpp:124-135);
             // "anymal": the structured implicit-differentiation program with the same pattern.
-            if (!wanted("anymal") && !wanted("anymal_ad")) continue;
+            if (!wanted("anymal") && !wanted("anymal_ad") && !wanted("anymal_lds")) continue;
             Generated adv = Record(s, jacMode);
             const Generated st = RecordFloatingBaseStructured(anymal, adv, "anymal", structuredDMode);
             adv.dims.name = "anymal_ad";
             const Generated* both[2] = {&adv, &st};
             for (const Generated* gg : both) {
                 if (!wanted(gg->dims.name)) continue;
-                EmitHip(*gg, outDir, gg == &st);
+                EmitHip(*gg, outDir, gg == &st, 0);
                 if (!cDir.empty()) EmitC(*gg, cDir);
+            }
+            if (ldsSlots > 0 && wanted("anymal_lds")) {  // same structured program, phased body with an LDS home
+                Generated lds = st;
+                lds.dims.name = "anymal_lds";
+                EmitHip(lds, outDir, true, ldsSlots, rematConsumers, rematDepth);
             }
             continue;
         }

@@ -109,14 +109,54 @@ __global__ __launch_bounds__(BLOCK) void NodeKernel(const NodeLaunch a) {
     }
 }
 
+/// I/O policy of the phased bodies: StridedIO plus a per-lane LDS home for values that live across
+/// phases (slot s of lane l at lds[s * BLOCK + l]: a wavefront access is 64 consecutive doubles,
+/// conflict-free for ds_read_b64 / ds_write_b64) and a scheduling barrier between phases so that
+/// the compiler cannot stretch live ranges across them.
+template <int NCOLS, bool DENSE, int BLOCK>
+struct PhasedIO : StridedIO<NCOLS, DENSE> {
+    double* lds;  // already offset by the lane
+    __device__ __forceinline__ double ld(int slot) const { return lds[slot * BLOCK]; }
+    __device__ __forceinline__ void st(int slot, double v) const { lds[slot * BLOCK] = v; }
+    __device__ __forceinline__ void phase() const { __builtin_amdgcn_sched_barrier(0); }
+};
+
+/// One lane per shooting node, long-lived state in LDS (one workgroup of BLOCK lanes owns
+/// kLdsSlots * BLOCK doubles; with 320 slots and BLOCK = 64 that is the whole 160 KiB of a CU).
+template <class M, int MODE, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void NodeKernelPhased(const NodeLaunch a) {
+    __shared__ double lds[(M::kLdsSlots > 0 ? M::kLdsSlots : 1) * BLOCK];
+    const long long i = static_cast<long long>(blockIdx.x) * BLOCK + threadIdx.x;
+    if (i >= a.count) return;
+    long long b = i, k = 0;
+    if (a.knots > 1) {
+        b = i / a.knots;
+        k = i - b * a.knots;
+    }
+    PhasedIO<M::kJacCols, MODE == kModeDenseJacobian, BLOCK> io{
+        {a.x.base + b * a.x.bs + k * a.x.ks, a.u.base + b * a.u.bs + k * a.u.ks, a.w.base ? a.w.base + b * a.w.bs + k * a.w.ks : nullptr,
+         a.p.base + b * a.p.bs + k * a.p.ks, a.f.base ? a.f.base + b * a.f.bs + k * a.f.ks : nullptr,
+         a.jac.base + b * a.jac.bs + k * a.jac.ks, a.x.es, a.u.es, a.w.es, a.p.es, a.f.es, a.jac.es},
+        lds + threadIdx.x};
+    if constexpr (MODE == kModeDenseJacobian)
+        detail::StoreZeros<M>(io.jb, io.je, std::make_index_sequence<M::kJacRows * M::kJacCols - M::kJacNnz>{});
+    M::ValueJacobianPhased(io);
+}
+
 template <class M, int BLOCK>
 inline hipError_t LaunchNodeModel(int mode, const NodeLaunch& a, hipStream_t stream) {
     if (a.count <= 0) return hipSuccess;
     const dim3 grid(static_cast<unsigned>((a.count + BLOCK - 1) / BLOCK)), block(BLOCK);
     switch (mode) {
         case kModeValue: hipLaunchKernelGGL((NodeKernel<M, kModeValue, BLOCK>), grid, block, 0, stream, a); break;
-        case kModeSparseJacobian: hipLaunchKernelGGL((NodeKernel<M, kModeSparseJacobian, BLOCK>), grid, block, 0, stream, a); break;
-        case kModeDenseJacobian: hipLaunchKernelGGL((NodeKernel<M, kModeDenseJacobian, BLOCK>), grid, block, 0, stream, a); break;
+        case kModeSparseJacobian:
+            if constexpr (M::kLdsSlots > 0) hipLaunchKernelGGL((NodeKernelPhased<M, kModeSparseJacobian, BLOCK>), grid, block, 0, stream, a);
+            else hipLaunchKernelGGL((NodeKernel<M, kModeSparseJacobian, BLOCK>), grid, block, 0, stream, a);
+            break;
+        case kModeDenseJacobian:
+            if constexpr (M::kLdsSlots > 0) hipLaunchKernelGGL((NodeKernelPhased<M, kModeDenseJacobian, BLOCK>), grid, block, 0, stream, a);
+            else hipLaunchKernelGGL((NodeKernel<M, kModeDenseJacobian, BLOCK>), grid, block, 0, stream, a);
+            break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -130,12 +170,17 @@ inline hipError_t LaunchNodeModel(int mode, const NodeLaunch& a, hipStream_t str
     struct Model_##ns {                                                                                          \
         static constexpr int kNx = gen::ns::kNx, kNu = gen::ns::kNu, kNw = gen::ns::kNw, kNp = gen::ns::kNp;     \
         static constexpr int kJacRows = gen::ns::kJacRows, kJacCols = gen::ns::kJacCols, kJacNnz = gen::ns::kJacNnz; \
+        static constexpr int kLdsSlots = gen::ns::kLdsSlots;                                                     \
         static constexpr int JacRow(int k) { return gen::ns::kJacRow[k]; }                                       \
         static constexpr int JacCol(int k) { return gen::ns::kJacCol[k]; }                                       \
         template <class IO>                                                                                      \
         __device__ __forceinline__ static void Value(IO& io) { gen::ns::Value(io); }                             \
         template <class IO>                                                                                      \
         __device__ __forceinline__ static void ValueJacobian(IO& io) { gen::ns::ValueJacobian(io); }             \
+        template <class IO>                                                                                      \
+        __device__ __forceinline__ static void ValueJacobianPhased(IO& io) {                                     \
+            if constexpr (gen::ns::kLdsSlots > 0) gen::ns::ValueJacobianPhased(io);                              \
+        }                                                                                                        \
     };                                                                                                           \
     }                                                                                                            \
     extern "C" int ungar_amd_launch_##ns(int mode, const ungar_amd::kernels::NodeLaunch* a, void* stream) {      \

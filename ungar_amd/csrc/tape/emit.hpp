@@ -11,6 +11,7 @@
 // never linked into the product library.
 #pragma once
 
+#include <algorithm>
 #include <cstdio>
 #include <sstream>
 #include <string>
@@ -57,6 +58,225 @@ class Emitter {
             os << indent << line << "\n";
         }
         return os.str();
+    }
+
+    /// Phased emission with an explicit LDS home for long-lived values.
+    ///
+    /// The straight-line programs of the big models keep ~1000 values alive across the body
+    /// (factorisation, kinematic state, shared partials); that exceeds the 512-VGPR file several
+    /// times over and the compiler answers with scratch spills that turn an HBM-bound kernel into a
+    /// scratch-bound one.  Here the emitter does its own allocation:
+    ///   * the body is cut into PHASES (slot groups) separated by scheduling barriers;
+    ///   * a value defined in one phase and used in a later one is either STORED -- it gets a
+    ///     per-lane LDS slot (`io.st(slot, v)` at the definition, one `io.ld(slot)` per consuming
+    ///     phase), slots being recycled when their value dies -- or REMATERIALISED: cheap values
+    ///     with few consuming phases whose operands are stored/inputs/constants are simply
+    ///     recomputed where needed (bounded cone depth), which shrinks the stored set ~3x;
+    ///   * stored values beyond `ldsSlots` stay registers across phases.
+    /// Returns the code; `slotsUsed` = LDS slots actually needed.
+    std::string EmitPhased(const std::vector<std::vector<OutputSlot>>& phases, int ldsSlots, int& slotsUsed, int rematMaxConsumers = 2,
+                           int rematMaxDepth = 3, const char* indent = "    ") {
+        const std::size_t n = g_.Size();
+        // ---- analysis pass: first-definition phase, consumer phases -------------------------------------
+        std::vector<int> defPhase(n, -1);
+        std::vector<std::vector<Id>> order(phases.size());
+        for (std::size_t ph = 0; ph < phases.size(); ++ph)
+            for (const OutputSlot& s : phases[ph]) CollectOrder(s.value, static_cast<int>(ph), defPhase, order[ph]);
+        std::vector<int> consumers(n, 0);
+        for (std::size_t ph = 0; ph < phases.size(); ++ph) {
+            std::vector<char> seen(n, 0);
+            auto use = [&](Id o) {
+                if (o == kNoId) return;
+                const std::size_t so = static_cast<std::size_t>(o);
+                if (defPhase[so] >= 0 && defPhase[so] != static_cast<int>(ph) && !seen[so]) {
+                    seen[so] = 1;
+                    ++consumers[so];
+                }
+            };
+            for (Id id : order[ph]) {
+                const Node& nd = g_.At(id);
+                use(nd.a);
+                use(nd.b);
+                use(nd.c);
+                use(nd.d);
+            }
+            for (const OutputSlot& s : phases[ph]) use(s.value);
+        }
+        // ---- stored set: cross-phase values that are not worth recomputing ---------------------------------
+        std::vector<char> stored(n, 0);
+        std::vector<int> depth(n, 0);  // recompute-cone depth of non-stored cross values
+        std::size_t crossTotal = 0, storedTotal = 0;
+        for (std::size_t i = 0; i < n; ++i) {
+            if (defPhase[i] < 0 || consumers[i] == 0) continue;
+            ++crossTotal;
+            const Node& nd = g_.At(static_cast<Id>(i));
+            bool cheap = nd.op != Op::Input && nd.op != Op::Div && nd.op != Op::Sin && nd.op != Op::Cos && nd.op != Op::Sqrt && nd.op != Op::Tan &&
+                         nd.op != Op::Atan && nd.op != Op::Atan2 && nd.op != Op::Exp && nd.op != Op::Log && nd.op != Op::Pow && nd.op != Op::Asin &&
+                         nd.op != Op::Acos;
+            int dmax = 0;
+            if (cheap && consumers[i] <= rematMaxConsumers) {
+                for (Id o : {nd.a, nd.b, nd.c, nd.d}) {
+                    if (o == kNoId) continue;
+                    const std::size_t so = static_cast<std::size_t>(o);
+                    const Node& no = g_.At(o);
+                    if (no.op == Op::Const || no.op == Op::Input) continue;  // inputs are re-read from memory
+                    if (stored[so]) continue;
+                    if (consumers[so] > 0) {  // a rematerialised cross value: chain
+                        dmax = std::max(dmax, depth[so]);
+                    } else {
+                        cheap = false;  // operand is private to its defining phase: would have to be kept
+                    }
+                }
+            }
+            if (cheap && consumers[i] <= rematMaxConsumers && dmax + 1 <= rematMaxDepth) {
+                depth[i] = dmax + 1;
+            } else {
+                stored[i] = 1;
+                ++storedTotal;
+            }
+        }
+        // ---- generation (dry run first to learn the last phase that loads each stored value) ----------------
+        std::vector<int> slotOf(n, -1);
+        std::vector<int> lastLoad(n, -1);
+        std::string text;
+        for (int pass = 0; pass < 2; ++pass) {
+            const bool dry = pass == 0;
+            std::ostringstream os;
+            std::vector<int> availIn(n, -1);        // phase in which the value has a usable local
+            std::vector<std::string> local(n);
+            std::vector<char> defined(n, 0);
+            int counter = 0;
+            EmitStats stats;
+            for (std::size_t ph = 0; ph < phases.size(); ++ph) {
+                if (ph && !dry) os << indent << "io.phase();\n";
+                const int iph = static_cast<int>(ph);
+                // explicit stack DFS producing statements for `root` in this phase
+                auto produce = [&](Id root) {
+                    std::vector<std::pair<Id, int>> stack{{root, 0}};
+                    while (!stack.empty()) {
+                        auto& [id, state] = stack.back();
+                        const std::size_t si = static_cast<std::size_t>(id);
+                        const Node& nd = g_.At(id);
+                        if (nd.op == Op::Const || availIn[si] == iph) {
+                            stack.pop_back();
+                            continue;
+                        }
+                        const bool isStoredElsewhere = defined[si] && stored[si];
+                        const bool regResident = isStoredElsewhere && !dry && slotOf[si] < 0;
+                        if (isStoredElsewhere && (dry || slotOf[si] >= 0)) {
+                            lastLoad[si] = std::max(lastLoad[si], iph);
+                            availIn[si] = iph;
+                            local[si] = "v" + std::to_string(counter++);
+                            if (!dry) os << indent << "const double " << local[si] << " = io.ld(" << slotOf[si] << ");\n";
+                            stack.pop_back();
+                            continue;
+                        }
+                        if (regResident) {  // kept in a register across phases: original name stays valid
+                            availIn[si] = iph;
+                            stack.pop_back();
+                            continue;
+                        }
+                        // (re)compute here: operands first
+                        bool pushed = false;
+                        if (nd.op != Op::Input) {
+                            const Id ops[4] = {nd.a, nd.b, nd.c, nd.d};
+                            while (state < 4) {
+                                const Id o = ops[state++];
+                                if (o == kNoId) continue;
+                                if (g_.At(o).op != Op::Const && availIn[static_cast<std::size_t>(o)] != iph) {
+                                    stack.emplace_back(o, 0);
+                                    pushed = true;
+                                    break;
+                                }
+                            }
+                        }
+                        if (pushed) continue;
+                        const Id me = id;
+                        const std::size_t sm = static_cast<std::size_t>(me);
+                        const Node& nm = g_.At(me);
+                        stack.pop_back();
+                        auto nameOf = [&](Id o) -> std::string {
+                            if (o == kNoId) return "";
+                            const Node& no = g_.At(o);
+                            return no.op == Op::Const ? Lit(no.value) : local[static_cast<std::size_t>(o)];
+                        };
+                        std::string expr;
+                        if (nm.op == Op::Input) expr = inputExpr_[static_cast<std::size_t>(nm.a)];
+                        else {
+                            EmitStats& keep = stats_;
+                            (void)keep;
+                            expr = ExprWith(nm, nameOf(nm.a), nameOf(nm.b), nameOf(nm.c), nameOf(nm.d));
+                        }
+                        local[sm] = "v" + std::to_string(counter++);
+                        availIn[sm] = iph;
+                        ++stats.statements;
+                        if (!dry) os << indent << "const double " << local[sm] << " = " << expr << ";\n";
+                        if (!defined[sm]) {
+                            defined[sm] = 1;
+                            if (stored[sm] && !dry && slotOf[sm] >= 0) os << indent << "io.st(" << slotOf[sm] << ", " << local[sm] << ");\n";
+                        }
+                    }
+                };
+                for (const OutputSlot& s : phases[ph]) {
+                    produce(s.value);
+                    if (!dry) {
+                        std::string line = s.sink;
+                        const std::size_t pos = line.find("%s");
+                        const Node& nv = g_.At(s.value);
+                        if (pos != std::string::npos) line.replace(pos, 2, nv.op == Op::Const ? Lit(nv.value) : local[static_cast<std::size_t>(s.value)]);
+                        os << indent << line << "\n";
+                    }
+                }
+            }
+            if (dry) {
+                // slot allocation from (defPhase, lastLoad) intervals
+                std::vector<int> freeSlots;
+                std::vector<std::vector<int>> expiring(phases.size() + 2);
+                int next = 0;
+                std::size_t peak = 0, live = 0, inLds = 0;
+                std::vector<std::size_t> liveDelta(phases.size() + 2, 0);
+                for (std::size_t ph = 0; ph < phases.size(); ++ph) {
+                    for (int sl : expiring[ph]) freeSlots.push_back(sl);
+                    std::vector<Id> cross;
+                    for (Id id : order[ph])
+                        if (stored[static_cast<std::size_t>(id)] && lastLoad[static_cast<std::size_t>(id)] > static_cast<int>(ph)) cross.push_back(id);
+                    std::stable_sort(cross.begin(), cross.end(),
+                                     [&](Id x, Id y) { return lastLoad[static_cast<std::size_t>(x)] > lastLoad[static_cast<std::size_t>(y)]; });
+                    live += cross.size();
+                    peak = std::max(peak, live);
+                    std::fprintf(stderr, "%zu ", live);
+                    for (Id id : cross) {
+                        const std::size_t si = static_cast<std::size_t>(id);
+                        ++liveDelta[static_cast<std::size_t>(lastLoad[si]) + 1];
+                        int slot = -1;
+                        if (!freeSlots.empty()) {
+                            slot = freeSlots.back();
+                            freeSlots.pop_back();
+                        } else if (next < ldsSlots) {
+                            slot = next++;
+                        }
+                        if (slot < 0) continue;
+                        ++inLds;
+                        slotOf[si] = slot;
+                        expiring[static_cast<std::size_t>(lastLoad[si]) + 1].push_back(slot);
+                    }
+                    live -= liveDelta[ph + 1];
+                }
+                slotsUsed = next;
+                std::fprintf(stderr, "[emit] phased: %zu cross-phase values, %zu stored (%zu in LDS, peak live %zu), %zu rematerialised; %zu statements (+%zu recomputed)\n",
+                             crossTotal, storedTotal, inLds, peak, crossTotal - storedTotal, stats.statements, stats.statements - CountDefined(defPhase));
+            } else {
+                text = os.str();
+                stats_.statements = stats.statements;
+            }
+        }
+        return text;
+    }
+
+    static std::size_t CountDefined(const std::vector<int>& defPhase) {
+        std::size_t c = 0;
+        for (int d : defPhase) c += d >= 0;
+        return c;
     }
 
     const EmitStats& Stats() const {
@@ -111,6 +331,65 @@ class Emitter {
             name_[static_cast<std::size_t>(me)] = next_++;
             os << indent << "const double v" << name_[static_cast<std::size_t>(me)] << " = " << Expr(me) << ";\n";
             ++stats_.statements;
+        }
+    }
+
+    /// Post-order DFS that appends not-yet-ordered nodes (inputs included, constants excluded).
+    void CollectOrder(Id root, int phase, std::vector<int>& defPhase, std::vector<Id>& out) {
+        std::vector<std::pair<Id, int>> stack{{root, 0}};
+        while (!stack.empty()) {
+            auto& [id, state] = stack.back();
+            const Node& nd = g_.At(id);
+            if (nd.op == Op::Const || defPhase[static_cast<std::size_t>(id)] >= 0) {
+                stack.pop_back();
+                continue;
+            }
+            const Id ops[4] = {nd.a, nd.b, nd.c, nd.d};
+            bool pushed = false;
+            if (nd.op != Op::Input)
+                while (state < 4) {
+                    const Id o = ops[state++];
+                    if (o == kNoId) continue;
+                    if (g_.At(o).op != Op::Const && defPhase[static_cast<std::size_t>(o)] < 0) {
+                        stack.emplace_back(o, 0);
+                        pushed = true;
+                        break;
+                    }
+                }
+            if (pushed) continue;
+            const Id me = id;
+            stack.pop_back();
+            defPhase[static_cast<std::size_t>(me)] = phase;
+            out.push_back(me);
+        }
+    }
+
+    std::string ExprWith(const Node& nd, const std::string& a, const std::string& b, const std::string& c, const std::string& d) {
+        switch (nd.op) {
+            case Op::Add: ++stats_.flops; return a + " + " + b;
+            case Op::Sub: ++stats_.flops; return a + " - " + b;
+            case Op::Mul: ++stats_.flops; return a + " * " + b;
+            case Op::Div: ++stats_.flops; ++stats_.divisions; return a + " / " + b;
+            case Op::Neg: return "-" + a;
+            case Op::Sin: ++stats_.transcendentals; return "sin(" + a + ")";
+            case Op::Cos: ++stats_.transcendentals; return "cos(" + a + ")";
+            case Op::Tan: ++stats_.transcendentals; return "tan(" + a + ")";
+            case Op::Asin: ++stats_.transcendentals; return "asin(" + a + ")";
+            case Op::Acos: ++stats_.transcendentals; return "acos(" + a + ")";
+            case Op::Atan: ++stats_.transcendentals; return "atan(" + a + ")";
+            case Op::Exp: ++stats_.transcendentals; return "exp(" + a + ")";
+            case Op::Log: ++stats_.transcendentals; return "log(" + a + ")";
+            case Op::Sqrt: ++stats_.transcendentals; return "sqrt(" + a + ")";
+            case Op::Abs: return "fabs(" + a + ")";
+            case Op::Sign: return "(double)((" + a + " > 0.0) - (" + a + " < 0.0))";
+            case Op::Pow: ++stats_.transcendentals; return "pow(" + a + ", " + b + ")";
+            case Op::Atan2: ++stats_.transcendentals; return "atan2(" + a + ", " + b + ")";
+            case Op::CondLt: return "(" + a + " < " + b + " ? " + c + " : " + d + ")";
+            case Op::CondLe: return "(" + a + " <= " + b + " ? " + c + " : " + d + ")";
+            case Op::CondEq: return "(" + a + " == " + b + " ? " + c + " : " + d + ")";
+            case Op::CondGe: return "(" + a + " >= " + b + " ? " + c + " : " + d + ")";
+            case Op::CondGt: return "(" + a + " > " + b + " ? " + c + " : " + d + ")";
+            default: throw std::logic_error("Emitter: unexpected op");
         }
     }
 
