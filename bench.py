@@ -167,15 +167,12 @@ def main():
         ends[i].record()
     fence()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    from ungar_amd.sharding import reduce_timing
+    elapsed, total_evals = reduce_timing(elapsed, count * args.steps, dist, "cuda")  # MAX time, SUM evals over ranks
     kernel_ms = float(np.mean([s.elapsed_time(e) for s, e in zip(starts, ends)]))
     assert torch.isfinite(f).all() and torch.isfinite(J).all()
 
     if rank == 0:
-        total_evals = count * world * args.steps
         bytes_per_eval = algorithmic_bytes(nx, nu)
         achieved = count * bytes_per_eval / (kernel_ms * 1e-3) / 1e9
         traffic = None

@@ -73,7 +73,8 @@ typedef struct ungar_node_batch {
 /* ---- model lifetime ------------------------------------------------------------------------ */
 
 /* Opens one of the built-in node models: "quadrotor", "rc_car", "srbd", "anymal" (structured
- * implicit-differentiation kernel) or "anymal_ad" (same function, derivatives by taping ABA).
+ * implicit differentiation, phased body with an LDS home), "anymal_reg" (same program, plain
+ * straight-line body) or "anymal_ad" (same function, derivatives by taping ABA).
  * replaces FunctionFactory::Make -> DynamicLib::model(name)  (function.hpp:497, 589-604). */
 int ungar_model_open(const char* name, ungar_model** out);
 void ungar_model_close(ungar_model* model);

@@ -31,7 +31,7 @@ def test_header_cites_the_reference_interface(repo_root):
 
 
 def test_model_metadata_without_gpu():
-    dims = {"quadrotor": (13, 4, 0, 20, 118), "rc_car": (6, 2, 0, 15, 32), "srbd": (13, 24, 4, 6, 238), "anymal": (37, 12, 0, 1, 1691), "anymal_ad": (37, 12, 0, 1, 1691)}
+    dims = {"quadrotor": (13, 4, 0, 20, 118), "rc_car": (6, 2, 0, 15, 32), "srbd": (13, 24, 4, 6, 238), "anymal": (37, 12, 0, 1, 1691), "anymal_ad": (37, 12, 0, 1, 1691), "anymal_reg": (37, 12, 0, 1, 1691)}
     for name, (nx, nu, nw, npar, nnz) in dims.items():
         m = ungar_amd.NodeModel(name)
         assert (m.nx, m.nu, m.nw, m.np, m.ny) == (nx, nu, nw, npar, nx)

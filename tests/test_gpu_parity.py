@@ -13,12 +13,12 @@ from oracle import ungar_oracle as O
 
 pytestmark = pytest.mark.gpu
 
-MODELS = ("quadrotor", "rc_car", "srbd", "anymal", "anymal_ad", "anymal_lds")
+MODELS = ("quadrotor", "rc_car", "srbd", "anymal", "anymal_ad", "anymal_reg")
 
 
 def _oracle_name(name):
     """'anymal_ad' is the same function as 'anymal' with derivatives by taped ABA."""
-    return name.replace("_ad", "").replace("_lds", "")
+    return name.replace("_ad", "").replace("_reg", "")
 
 
 def _assert_close(name, got_f, got_J, ref_f, ref_J):
@@ -59,7 +59,7 @@ def test_forward_zero_matches_golden(ua, repo_root, name):
     assert np.abs(f - g["f"]).max() <= 1e-10 * max(1.0, np.abs(g["f"]).max())
 
 
-@pytest.mark.parametrize("name,count", [("quadrotor", 200), ("rc_car", 300), ("srbd", 100), ("anymal", 70), ("anymal_ad", 70), ("anymal_lds", 70)])
+@pytest.mark.parametrize("name,count", [("quadrotor", 200), ("rc_car", 300), ("srbd", 100), ("anymal", 70), ("anymal_ad", 70), ("anymal_reg", 70)])
 def test_live_oracle_seeded(ua, name, count):
     """Ragged count (not a multiple of the wavefront/block size) on fresh seeded inputs."""
     x, u, w, p = O.synthetic_inputs(_oracle_name(name), count, seed=123)
@@ -101,7 +101,7 @@ FULL = {  # BASELINE.json configs[1..3]
     "rc_car": (16384, 200),
     "anymal": (4096, 20),
     "anymal_ad": (4096, 20),
-    "anymal_lds": (4096, 20),
+    "anymal_reg": (4096, 20),
 }
 
 
@@ -190,7 +190,7 @@ def test_full_size_properties(ua, name):
     assert ((fd - Jd).abs().max() / scale).item() < 1e-6
 
     # (5) unit quaternion preserved by q+ = q * exp~(dt w+)
-    if name in ("quadrotor", "anymal", "anymal_ad", "anymal_lds"):
+    if name in ("quadrotor", "anymal", "anymal_ad", "anymal_reg"):
         assert (f[3:7].norm(dim=0) - 1).abs().max().item() < 1e-12
 
 
@@ -202,7 +202,7 @@ def test_structured_and_taped_aba_kernels_agree_at_full_size(ua):
     count = 4096 * 20
     x, u, p = _device_inputs("anymal", count, seed=21)
     out = {}
-    for name in ("anymal", "anymal_ad", "anymal_lds"):
+    for name in ("anymal", "anymal_ad", "anymal_reg"):
         m = ua.NodeModel(name)
         f = torch.empty((37, count), dtype=torch.float64, device="cuda")
         J = torch.empty((37 * 49, count), dtype=torch.float64, device="cuda")
@@ -212,7 +212,7 @@ def test_structured_and_taped_aba_kernels_agree_at_full_size(ua):
     torch.cuda.synchronize()
     f1, J1 = out["anymal_ad"]
     scale = J1.abs().amax(dim=0, keepdim=True)
-    for other in ("anymal", "anymal_lds"):
+    for other in ("anymal", "anymal_reg"):
         f0, J0 = out[other]
         assert (f0 - f1).abs().max().item() < 1e-10
         assert ((J0 - J1).abs() / scale).max().item() < 1e-9

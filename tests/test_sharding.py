@@ -1,0 +1,57 @@
+"""Multi-GPU path on CPU: gloo, world_size 2 (the GPU box runs the same code over RCCL)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from ungar_amd.sharding import reduce_timing, shard_range
+
+
+def test_shard_ranges_partition_the_batch():
+    for total in (0, 1, 7, 4096, 65536, 65537):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(total, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [e - b for b, e in spans]
+            assert max(sizes) - min(sizes) <= 1
+    assert shard_range(65536, 8, 3) == (24576, 32768)  # BASELINE config 5
+    with pytest.raises(ValueError):
+        shard_range(10, 2, 2)
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    b, e = shard_range(4097, world, rank)
+    # each rank "evaluates" its shard: a checksum over instance ids stands in for the outputs
+    local = torch.arange(b, e, dtype=torch.float64)
+    elapsed, evals = reduce_timing(0.010 * (rank + 1), (e - b) * 20, dist)
+    s = local.sum()
+    dist.all_reduce(s)
+    q.put((rank, elapsed, evals, float(s)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_timing_reduction_and_coverage():
+    world = 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, elapsed, evals, checksum in out:
+        assert elapsed == pytest.approx(0.020)        # MAX over ranks
+        assert evals == 4097 * 20                     # SUM over ranks: every instance exactly once
+        assert checksum == pytest.approx(4096 * 4097 / 2)

@@ -24,7 +24,7 @@ import numpy as np
 __all__ = ["NodeModel", "Operand", "gn_hessian", "library_path", "load_library", "UngarError", "MODELS"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-MODELS = ("quadrotor", "rc_car", "srbd", "anymal", "anymal_ad", "anymal_lds")
+MODELS = ("quadrotor", "rc_car", "srbd", "anymal", "anymal_ad", "anymal_reg")
 
 
 class UngarError(RuntimeError):

@@ -213,7 +213,7 @@ std::string HipPrologue(const models::NodeDims& d, const std::vector<char>& used
     return os.str();
 }
 
-void EmitHip(const Generated& g, const std::string& dir, bool columnMajorEmission = false, int ldsSlots = 0, int rematConsumers = 2, int rematDepth = 3) {
+void EmitHip(const Generated& g, const std::string& dir, bool columnMajorEmission = false, int ldsSlots = 0, int rematConsumers = 2, int rematDepth = 3, int prefetch = 48, int maxChunk = 0) {
     const auto& d = g.dims;
     const std::string name = d.name;
     std::ostringstream os;
@@ -311,7 +311,7 @@ void EmitHip(const Generated& g, const std::string& dir, bool columnMajorEmissio
         }
         tape::Emitter em{g.tape.graph, names};
         int used = 0;
-        const std::string body = em.EmitPhased(phases, ldsSlots, used, rematConsumers, rematDepth);
+        const std::string body = em.EmitPhased(phases, ldsSlots, used, rematConsumers, rematDepth, prefetch, maxChunk);
         os << "// phased: " << phases.size() << " phases, " << used << " LDS slots per lane, " << em.Stats().statements << " statements\n"
            << "inline constexpr int kLdsSlots = " << used << ";\n"
            << "template <class IO>\n__device__ __forceinline__ void ValueJacobianPhased(IO& io) {\n"
@@ -367,8 +367,8 @@ void EmitC(const Generated& g, const std::string& dir) {
 
 int main(int argc, char** argv) {
     std::string outDir, cDir, robot;
-    int jacMode = 0, structuredDMode = 1, ldsSlots = 0;
-    int rematConsumers = 2, rematDepth = 3;
+    int jacMode = 0, structuredDMode = 1, ldsSlots = 320;
+    int rematConsumers = 2, rematDepth = 3, prefetch = 48, maxChunk = 0;
     std::vector<std::string> only;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
@@ -380,6 +380,8 @@ int main(int argc, char** argv) {
         else if (a == "--lds-slots" && i + 1 < argc) ldsSlots = std::atoi(argv[++i]);
         else if (a == "--remat-consumers" && i + 1 < argc) rematConsumers = std::atoi(argv[++i]);
         else if (a == "--remat-depth" && i + 1 < argc) rematDepth = std::atoi(argv[++i]);
+        else if (a == "--prefetch" && i + 1 < argc) prefetch = std::atoi(argv[++i]);
+        else if (a == "--max-chunk" && i + 1 < argc) maxChunk = std::atoi(argv[++i]);
         else if (a == "--model" && i + 1 < argc) only.push_back(argv[++i]);
         else {
             std::fprintf(stderr, "usage: %s --out DIR [--c-oracle DIR] [--anymal-robot FILE] [--jac-mode 0|1|2] [--model NAME]...\n", argv[0]);
@@ -415,22 +417,25 @@ int main(int argc, char** argv) {
     };
     for (const NodeSpec& s : specs) {
         if (std::string(s.dims.name) == "anymal") {
-            // "anymal_ad": derivatives by taping ABA (what the reference does, robot.test.cpp:124-135);
-            // "anymal": the structured implicit-differentiation program with the same pattern.
-            if (!wanted("anymal") && !wanted("anymal_ad") && !wanted("anymal_lds")) continue;
+            // Three kernels for the same node function and the same sparsity pattern:
+            //   "anymal"     structured implicit differentiation, phased body with an LDS home (production)
+            //   "anymal_reg" the same structured program as one plain straight-line body
+            //   "anymal_ad"  derivatives by taping ABA (what the reference does, robot.test.cpp:124-135)
+            if (!wanted("anymal") && !wanted("anymal_ad") && !wanted("anymal_reg")) continue;
             Generated adv = Record(s, jacMode);
-            const Generated st = RecordFloatingBaseStructured(anymal, adv, "anymal", structuredDMode);
+            Generated st = RecordFloatingBaseStructured(anymal, adv, "anymal", structuredDMode);
             adv.dims.name = "anymal_ad";
-            const Generated* both[2] = {&adv, &st};
-            for (const Generated* gg : both) {
-                if (!wanted(gg->dims.name)) continue;
-                EmitHip(*gg, outDir, gg == &st, 0);
-                if (!cDir.empty()) EmitC(*gg, cDir);
+            if (wanted("anymal_ad")) {
+                EmitHip(adv, outDir, false, 0);
+                if (!cDir.empty()) EmitC(adv, cDir);
             }
-            if (ldsSlots > 0 && wanted("anymal_lds")) {  // same structured program, phased body with an LDS home
-                Generated lds = st;
-                lds.dims.name = "anymal_lds";
-                EmitHip(lds, outDir, true, ldsSlots, rematConsumers, rematDepth);
+            if (wanted("anymal")) {
+                EmitHip(st, outDir, true, ldsSlots, rematConsumers, rematDepth, prefetch, maxChunk);
+                if (!cDir.empty()) EmitC(st, cDir);
+            }
+            if (wanted("anymal_reg")) {
+                st.dims.name = "anymal_reg";
+                EmitHip(st, outDir, true, 0);
             }
             continue;
         }

@@ -25,7 +25,7 @@ UNGAR_AMD_DECLARE_MODEL(rc_car)
 UNGAR_AMD_DECLARE_MODEL(srbd)
 UNGAR_AMD_DECLARE_MODEL(anymal)
 UNGAR_AMD_DECLARE_MODEL(anymal_ad)
-UNGAR_AMD_DECLARE_MODEL(anymal_lds)
+UNGAR_AMD_DECLARE_MODEL(anymal_reg)
 
 extern "C" int ungar_amd_launch_gn_hessian(const double* jac, long long js, long long ldj, const double* d, long long ds, double* g,
                                             long long gs, long long ldg, int rows, int cols, long long count, void* stream);
@@ -58,7 +58,7 @@ const BuiltinEntry kBuiltins[] = {
     {"srbd", ungar_amd_launch_srbd, ungar_amd_pattern_srbd, ungar_amd_dims_srbd},
     {"anymal", ungar_amd_launch_anymal, ungar_amd_pattern_anymal, ungar_amd_dims_anymal},
     {"anymal_ad", ungar_amd_launch_anymal_ad, ungar_amd_pattern_anymal_ad, ungar_amd_dims_anymal_ad},
-    {"anymal_lds", ungar_amd_launch_anymal_lds, ungar_amd_pattern_anymal_lds, ungar_amd_dims_anymal_lds},
+    {"anymal_reg", ungar_amd_launch_anymal_reg, ungar_amd_pattern_anymal_reg, ungar_amd_dims_anymal_reg},
 };
 
 OperandView View(const ungar_operand& o) {
@@ -117,7 +117,7 @@ int ungar_model_open(const char* name, ungar_model** out) {
         *out = m;
         return UNGAR_OK;
     }
-    return Fail(UNGAR_E_INVALID, std::string("unknown model '") + name + "' (built-ins: quadrotor, rc_car, srbd, anymal, anymal_ad)");
+    return Fail(UNGAR_E_INVALID, std::string("unknown model '") + name + "' (built-ins: quadrotor, rc_car, srbd, anymal, anymal_ad, anymal_reg)");
 }
 
 void ungar_model_close(ungar_model* model) {

@@ -75,15 +75,43 @@ class Emitter {
     ///   * stored values beyond `ldsSlots` stay registers across phases.
     /// Returns the code; `slotsUsed` = LDS slots actually needed.
     std::string EmitPhased(const std::vector<std::vector<OutputSlot>>& phases, int ldsSlots, int& slotsUsed, int rematMaxConsumers = 2,
-                           int rematMaxDepth = 3, const char* indent = "    ") {
+                           int rematMaxDepth = 3, int prefetchDistance = 48, int maxChunk = 0, const char* indent = "    ") {
         const std::size_t n = g_.Size();
         // ---- analysis pass: first-definition phase, consumer phases -------------------------------------
         std::vector<int> defPhase(n, -1);
         std::vector<std::vector<Id>> order(phases.size());
         for (std::size_t ph = 0; ph < phases.size(); ++ph)
             for (const OutputSlot& s : phases[ph]) CollectOrder(s.value, static_cast<int>(ph), defPhase, order[ph]);
+        // Optional re-chunking: a phase whose statement list is longer than `maxChunk` is cut into
+        // pieces (bounding the register working set inside a piece); every output sink moves to the
+        // piece that first defines its value, so results leave for HBM as soon as they exist.
+        std::vector<std::vector<OutputSlot>> chunkSinks;
+        const std::vector<std::vector<OutputSlot>>* phasesPtr = &phases;
+        if (maxChunk > 0) {
+            std::vector<std::vector<Id>> newOrder;
+            for (std::size_t ph = 0; ph < phases.size(); ++ph) {
+                const std::size_t first = newOrder.size();
+                const std::size_t len = order[ph].size();
+                const std::size_t pieces = std::max<std::size_t>(1, (len + static_cast<std::size_t>(maxChunk) - 1) / static_cast<std::size_t>(maxChunk));
+                const std::size_t per = (len + pieces - 1) / pieces;
+                for (std::size_t c = 0; c < pieces; ++c) {
+                    const std::size_t lo = std::min(len, c * per), hi = std::min(len, (c + 1) * per);
+                    newOrder.emplace_back(order[ph].begin() + static_cast<std::ptrdiff_t>(lo), order[ph].begin() + static_cast<std::ptrdiff_t>(hi));
+                    for (Id id : newOrder.back()) defPhase[static_cast<std::size_t>(id)] = static_cast<int>(newOrder.size() - 1);
+                }
+                chunkSinks.resize(newOrder.size());
+                for (const OutputSlot& sl : phases[ph]) {
+                    const int dp = g_.At(sl.value).op == Op::Const ? -1 : defPhase[static_cast<std::size_t>(sl.value)];
+                    const std::size_t at = dp < static_cast<int>(first) ? newOrder.size() - 1 : static_cast<std::size_t>(dp);
+                    chunkSinks[at].push_back(sl);
+                }
+            }
+            order.swap(newOrder);
+            phasesPtr = &chunkSinks;
+        }
+        const std::vector<std::vector<OutputSlot>>& ph_ = *phasesPtr;
         std::vector<int> consumers(n, 0);
-        for (std::size_t ph = 0; ph < phases.size(); ++ph) {
+        for (std::size_t ph = 0; ph < ph_.size(); ++ph) {
             std::vector<char> seen(n, 0);
             auto use = [&](Id o) {
                 if (o == kNoId) return;
@@ -100,7 +128,7 @@ class Emitter {
                 use(nd.c);
                 use(nd.d);
             }
-            for (const OutputSlot& s : phases[ph]) use(s.value);
+            for (const OutputSlot& s : ph_[ph]) use(s.value);
         }
         // ---- stored set: cross-phase values that are not worth recomputing ---------------------------------
         std::vector<char> stored(n, 0);
@@ -147,9 +175,10 @@ class Emitter {
             std::vector<char> defined(n, 0);
             int counter = 0;
             EmitStats stats;
-            for (std::size_t ph = 0; ph < phases.size(); ++ph) {
+            for (std::size_t ph = 0; ph < ph_.size(); ++ph) {
                 if (ph && !dry) os << indent << "io.phase();\n";
                 const int iph = static_cast<int>(ph);
+                std::vector<std::pair<std::string, bool>> lines;  // (statement, is LDS load)
                 // explicit stack DFS producing statements for `root` in this phase
                 auto produce = [&](Id root) {
                     std::vector<std::pair<Id, int>> stack{{root, 0}};
@@ -167,7 +196,7 @@ class Emitter {
                             lastLoad[si] = std::max(lastLoad[si], iph);
                             availIn[si] = iph;
                             local[si] = "v" + std::to_string(counter++);
-                            if (!dry) os << indent << "const double " << local[si] << " = io.ld(" << slotOf[si] << ");\n";
+                            if (!dry) lines.emplace_back("const double " + local[si] + " = io.ld(" + std::to_string(slotOf[si]) + ");", true);
                             stack.pop_back();
                             continue;
                         }
@@ -210,32 +239,43 @@ class Emitter {
                         local[sm] = "v" + std::to_string(counter++);
                         availIn[sm] = iph;
                         ++stats.statements;
-                        if (!dry) os << indent << "const double " << local[sm] << " = " << expr << ";\n";
+                        if (!dry) lines.emplace_back("const double " + local[sm] + " = " + expr + ";", false);
                         if (!defined[sm]) {
                             defined[sm] = 1;
-                            if (stored[sm] && !dry && slotOf[sm] >= 0) os << indent << "io.st(" << slotOf[sm] << ", " << local[sm] << ");\n";
+                            if (stored[sm] && !dry && slotOf[sm] >= 0) lines.emplace_back("io.st(" + std::to_string(slotOf[sm]) + ", " + local[sm] + ");", false);
                         }
                     }
                 };
-                for (const OutputSlot& s : phases[ph]) {
+                for (Id id : order[ph]) produce(id);
+                for (const OutputSlot& s : ph_[ph]) {
                     produce(s.value);
                     if (!dry) {
                         std::string line = s.sink;
                         const std::size_t pos = line.find("%s");
                         const Node& nv = g_.At(s.value);
                         if (pos != std::string::npos) line.replace(pos, 2, nv.op == Op::Const ? Lit(nv.value) : local[static_cast<std::size_t>(s.value)]);
-                        os << indent << line << "\n";
+                        lines.emplace_back(line, false);
                     }
+                }
+                if (!dry) {
+                    // software prefetch: an LDS load has no intra-phase dependency, so it is hoisted
+                    // `prefetchDistance` statements ahead of its first use to hide the ~100+ cycle LDS
+                    // latency (one wavefront per SIMD: nothing else would cover it)
+                    std::vector<std::pair<double, std::size_t>> key(lines.size());
+                    for (std::size_t i = 0; i < lines.size(); ++i)
+                        key[i] = {lines[i].second ? std::max(-0.5, static_cast<double>(i) - prefetchDistance - 0.5) : static_cast<double>(i), i};
+                    std::stable_sort(key.begin(), key.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
+                    for (const auto& [k, i] : key) os << indent << lines[i].first << "\n";
                 }
             }
             if (dry) {
                 // slot allocation from (defPhase, lastLoad) intervals
                 std::vector<int> freeSlots;
-                std::vector<std::vector<int>> expiring(phases.size() + 2);
+                std::vector<std::vector<int>> expiring(ph_.size() + 2);
                 int next = 0;
                 std::size_t peak = 0, live = 0, inLds = 0;
-                std::vector<std::size_t> liveDelta(phases.size() + 2, 0);
-                for (std::size_t ph = 0; ph < phases.size(); ++ph) {
+                std::vector<std::size_t> liveDelta(ph_.size() + 2, 0);
+                for (std::size_t ph = 0; ph < ph_.size(); ++ph) {
                     for (int sl : expiring[ph]) freeSlots.push_back(sl);
                     std::vector<Id> cross;
                     for (Id id : order[ph])
@@ -244,7 +284,7 @@ class Emitter {
                                      [&](Id x, Id y) { return lastLoad[static_cast<std::size_t>(x)] > lastLoad[static_cast<std::size_t>(y)]; });
                     live += cross.size();
                     peak = std::max(peak, live);
-                    std::fprintf(stderr, "%zu ", live);
+
                     for (Id id : cross) {
                         const std::size_t si = static_cast<std::size_t>(id);
                         ++liveDelta[static_cast<std::size_t>(lastLoad[si]) + 1];
@@ -263,8 +303,8 @@ class Emitter {
                     live -= liveDelta[ph + 1];
                 }
                 slotsUsed = next;
-                std::fprintf(stderr, "[emit] phased: %zu cross-phase values, %zu stored (%zu in LDS, peak live %zu), %zu rematerialised; %zu statements (+%zu recomputed)\n",
-                             crossTotal, storedTotal, inLds, peak, crossTotal - storedTotal, stats.statements, stats.statements - CountDefined(defPhase));
+                std::fprintf(stderr, "[emit] phased (%zu pieces): %zu cross-phase values, %zu stored (%zu in LDS, peak live %zu), %zu rematerialised; %zu statements (+%zu recomputed)\n",
+                             ph_.size(), crossTotal, storedTotal, inLds, peak, crossTotal - storedTotal, stats.statements, stats.statements - CountDefined(defPhase));
             } else {
                 text = os.str();
                 stats_.statements = stats.statements;
