@@ -213,7 +213,7 @@ std::string HipPrologue(const models::NodeDims& d, const std::vector<char>& used
     return os.str();
 }
 
-void EmitHip(const Generated& g, const std::string& dir, bool columnMajorEmission = false, int ldsSlots = 0, int rematConsumers = 2, int rematDepth = 3, int prefetch = 48, int maxChunk = 0) {
+void EmitHip(const Generated& g, const std::string& dir, bool columnMajorEmission = false, int ldsSlots = 0, int rematConsumers = 2, int rematDepth = 3, int prefetch = 48, int maxChunk = 0, bool creationOrder = false) {
     const auto& d = g.dims;
     const std::string name = d.name;
     std::ostringstream os;
@@ -311,7 +311,7 @@ void EmitHip(const Generated& g, const std::string& dir, bool columnMajorEmissio
         }
         tape::Emitter em{g.tape.graph, names};
         int used = 0;
-        const std::string body = em.EmitPhased(phases, ldsSlots, used, rematConsumers, rematDepth, prefetch, maxChunk);
+        const std::string body = em.EmitPhased(phases, ldsSlots, used, rematConsumers, rematDepth, prefetch, maxChunk, creationOrder);
         os << "// phased: " << phases.size() << " phases, " << used << " LDS slots per lane, " << em.Stats().statements << " statements\n"
            << "inline constexpr int kLdsSlots = " << used << ";\n"
            << "template <class IO>\n__device__ __forceinline__ void ValueJacobianPhased(IO& io) {\n"
@@ -369,6 +369,7 @@ int main(int argc, char** argv) {
     std::string outDir, cDir, robot;
     int jacMode = 0, structuredDMode = 1, ldsSlots = 320;
     int rematConsumers = 2, rematDepth = 3, prefetch = 48, maxChunk = 0;
+    bool creationOrder = false;
     std::vector<std::string> only;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
@@ -382,6 +383,7 @@ int main(int argc, char** argv) {
         else if (a == "--remat-depth" && i + 1 < argc) rematDepth = std::atoi(argv[++i]);
         else if (a == "--prefetch" && i + 1 < argc) prefetch = std::atoi(argv[++i]);
         else if (a == "--max-chunk" && i + 1 < argc) maxChunk = std::atoi(argv[++i]);
+        else if (a == "--creation-order") creationOrder = true;
         else if (a == "--model" && i + 1 < argc) only.push_back(argv[++i]);
         else {
             std::fprintf(stderr, "usage: %s --out DIR [--c-oracle DIR] [--anymal-robot FILE] [--jac-mode 0|1|2] [--model NAME]...\n", argv[0]);
@@ -430,7 +432,7 @@ int main(int argc, char** argv) {
                 if (!cDir.empty()) EmitC(adv, cDir);
             }
             if (wanted("anymal")) {
-                EmitHip(st, outDir, true, ldsSlots, rematConsumers, rematDepth, prefetch, maxChunk);
+                EmitHip(st, outDir, true, ldsSlots, rematConsumers, rematDepth, prefetch, maxChunk, creationOrder);
                 if (!cDir.empty()) EmitC(st, cDir);
             }
             if (wanted("anymal_reg")) {
