@@ -1,0 +1,137 @@
+"""GPU test: the reference's whole-horizon quadrotor OCP (objective / equality / inequality tapes of
+example/mpc/quadrotor.example.cpp:196-316) built with ungar_amd's C++ facade and evaluated through
+Ungar::Autodiff::Function on the MI355X, checked BLOCK BY BLOCK against the per-shooting-node kernel
+(rows nx+k*nx.. are x_{k+1} - f(x_k,u_k): d/dx_{k+1} = I,
+d/dx_k = -A_k, d/du_k = -B_k) and against an independent torch model of the objective."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ungar_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+N, NX, NU = 30, 13, 4
+DEC, PAR = 523, 437
+
+
+def _parse(path):
+    out, lines, i = {}, open(path).read().split("\n"), 0
+    while i < len(lines):
+        t = lines[i].split()
+        if not t:
+            i += 1
+            continue
+        if len(t) == 2:  # vector
+            n = int(t[1])
+            out[t[0]] = np.array([float(v) for v in lines[i + 1:i + 1 + n]])
+            i += 1 + n
+        else:  # sparse: tag rows cols nnz
+            r, c, nnz = int(t[1]), int(t[2]), int(t[3])
+            M = np.zeros((r, c))
+            mask = np.zeros((r, c), dtype=bool)
+            for ln in lines[i + 1:i + 1 + nnz]:
+                a, b, v = ln.split()
+                M[int(a), int(b)] = float(v)
+                mask[int(a), int(b)] = True
+            out[t[0]], out[t[0] + "_MASK"] = M, mask
+            i += 1 + nnz
+    return out
+
+
+@pytest.fixture(scope="module")
+def dump(repo_root, tmp_path_factory):
+    exe = os.path.join(repo_root, "build", "quadrotor_ocp_test")
+    assert os.path.exists(exe), "build/quadrotor_ocp_test missing: run __graft_entry__.build()"
+    d = tmp_path_factory.mktemp("ocp")
+    r = subprocess.run([exe, str(d / "codegen"), str(d / "dump.txt")], capture_output=True, text=True, timeout=1500)
+    print(r.stdout[-2000:], r.stderr[-2000:])
+    assert r.returncode == 0 and "DUMPED" in r.stdout
+    return _parse(str(d / "dump.txt"))
+
+
+def test_equality_constraints_block_structure(dump):
+    import ungar_amd
+    v = dump["INPUT"]
+    assert v.size == DEC + PAR
+    X = v[:(N + 1) * NX].reshape(N + 1, NX)
+    U = v[(N + 1) * NX:DEC].reshape(N, NU)
+    par = v[DEC:]
+    p = np.tile(par[:20], (N, 1))            # node parameter block = parameters[0:20]
+    xm = par[-13:]                           # measured_state is the last parameter
+    f, J = ungar_amd.NodeModel("quadrotor").evaluate_numpy(X[:N], U, np.zeros((N, 0)), p, mode="dense", layout="aos")
+    fo, Jo = O.node_jacobian("quadrotor", X[:N], U, np.zeros((N, 0)), p)
+    assert np.abs(f - fo).max() < 1e-12 and np.abs(J - Jo).max() < 1e-10
+
+    eq, Jeq, mask = dump["EQ"], dump["EQ_JAC"], dump["EQ_JAC_MASK"]
+    assert eq.shape == (403,) and Jeq.shape == (403, DEC)  # m x n: parameter columns trimmed
+    assert np.abs(eq[:NX] - (X[0] - xm)).max() < 1e-14
+    expected = np.zeros((403, DEC))
+    expected[:NX, :NX] = np.eye(NX)
+    for k in range(N):
+        rows = slice(NX + k * NX, NX + (k + 1) * NX)
+        assert np.abs(eq[rows] - (X[k + 1] - f[k])).max() < 1e-12
+        expected[rows, k * NX:(k + 1) * NX] = -J[k][:, :NX]
+        expected[rows, (k + 1) * NX:(k + 2) * NX] += np.eye(NX)
+        expected[rows, (N + 1) * NX + k * NU:(N + 1) * NX + (k + 1) * NU] = -J[k][:, NX:]
+    assert np.abs(Jeq - expected).max() <= 1e-10 * np.abs(expected).max()
+    assert not (Jeq != 0)[~mask].any()
+    # structural pattern = identity blocks + the node pattern (118 nnz per knot),
+    # except where -A_k and +I overlap on no entry (A_k couples x_k, I couples x_{k+1})
+    assert mask.sum() == NX + N * (118 + NX)
+
+
+def test_inequality_constraints(dump):
+    v = dump["INPUT"]
+    U = v[(N + 1) * NX:DEC].reshape(N, NU)
+    rmax = v[DEC + 20]
+    h, Jh = dump["INEQ"], dump["INEQ_JAC"]
+    assert h.shape == (240,) and Jh.shape == (240, DEC) and dump["INEQ_JAC_MASK"].sum() == 240
+    want = np.stack((U - rmax, -U), axis=-1).reshape(-1)   # k-major, rotor-minor pairs [r - rmax, -r]
+    assert np.abs(h - want).max() < 1e-13
+    cols = (N + 1) * NX + np.repeat(np.arange(N * NU), 2)
+    expected = np.zeros((240, DEC))
+    expected[np.arange(240), cols] = np.tile([1.0, -1.0], N * NU)
+    assert np.array_equal(Jh, expected)
+
+
+def _objective_torch(z, par):
+    X = z[:(N + 1) * NX].reshape(N + 1, NX)
+    U = z[(N + 1) * NX:].reshape(N, NU)
+    o = 21
+    ref_p = par[o:o + 3 * (N + 1)].reshape(N + 1, 3)
+    o += 3 * (N + 1)
+    ref_q = par[o:o + 4 * (N + 1)].reshape(N + 1, 4)
+    o += 4 * (N + 1)
+    ref_v = par[o:o + 3 * (N + 1)].reshape(N + 1, 3)
+    o += 3 * (N + 1)
+    ref_w = par[o:o + 3 * (N + 1)].reshape(N + 1, 3)
+    val = torch.zeros((), dtype=torch.float64)
+    for k in range(N + 1):
+        q = X[k, 3:7]
+        val = val + ((X[k, 0:3] - ref_p[k]) ** 2).sum() + torch.minimum(((q - ref_q[k]) ** 2).sum(), ((q + ref_q[k]) ** 2).sum()) \
+            + ((X[k, 7:10] - ref_v[k]) ** 2).sum() + ((X[k, 10:13] - ref_w[k]) ** 2).sum()
+        if 0 < k < N:
+            val = val + 1e-6 * ((U[k] - U[k - 1]) ** 2).sum()
+        if k < N:
+            val = val + 1e-6 * (U[k] ** 2).sum()
+    return val
+
+
+def test_objective_value_gradient_and_upper_triangular_hessian(dump):
+    v = dump["INPUT"]
+    z = torch.tensor(v[:DEC], requires_grad=True)
+    par = torch.tensor(v[DEC:])
+    val = _objective_torch(z, par)
+    (grad,) = torch.autograd.grad(val, z, create_graph=False)
+    H = torch.autograd.functional.hessian(lambda zz: _objective_torch(zz, par), torch.tensor(v[:DEC])).numpy()
+    assert abs(dump["OBJ"][0] - val.item()) <= 1e-12 * abs(val.item())
+    g = dump["OBJ_JAC"]
+    assert g.shape == (1, DEC) and np.abs(g[0] - grad.numpy()).max() <= 1e-12 * np.abs(grad.numpy()).max()
+    Hd, Hm = dump["OBJ_HES"], dump["OBJ_HES_MASK"]
+    assert Hd.shape == (DEC, DEC)
+    assert not Hm[np.tril_indices(DEC, -1)].any(), "Hessian must be upper-triangular only (function.hpp:232-235)"
+    assert np.abs(Hd - np.triu(H)).max() <= 1e-12 * np.abs(H).max()

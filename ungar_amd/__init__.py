@@ -138,9 +138,12 @@ class NodeModel:
         self.jac_nnz, self.hes_nnz = info.jac_nnz, info.hes_nnz
 
     def __del__(self):
-        if getattr(self, "_h", None) and self._h.value:
-            self._lib.ungar_model_close(self._h)
-            self._h = ctypes.c_void_p()
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                self._lib.ungar_model_close(self._h)
+                self._h.value = None
+        except Exception:  # interpreter shutdown: module globals may already be gone
+            pass
 
     # -- reference Function API names (function.hpp:340-361) ------------------------------------
     def independent_variable_size(self) -> int:
