@@ -1,0 +1,78 @@
+// CPU 4-lane simulator of the lane-per-leg SPMD program (ungar_amd/csrc/gen/anymal_quad_gen.hpp).
+// The generated body is generic over the value type: here T = Quad (one value per lane of a quad),
+// quad_sum / quad_rot are plain loops, and the sinks scatter into node-level f[37] / J[37][49].
+// Built by tests/test_quad_program.py with g++ (no GPU needed): validates the SPMD MATH -- block-arrow
+// factorisation, ownership of rows/columns, rotations -- against the oracle's golden vectors before
+// the same text is compiled for gfx950.
+#include <cmath>
+#include <cstring>
+
+#include "anymal_quad_gen.hpp"
+
+namespace {
+
+struct Quad {
+    double v[4];
+    Quad() : v{0, 0, 0, 0} {}
+    Quad(double s) : v{s, s, s, s} {}  // NOLINT
+};
+#define QUAD_BIN(op)                                                   \
+    inline Quad operator op(const Quad& a, const Quad& b) {           \
+        Quad r;                                                        \
+        for (int l = 0; l < 4; ++l) r.v[l] = a.v[l] op b.v[l];         \
+        return r;                                                      \
+    }
+QUAD_BIN(+)
+QUAD_BIN(-)
+QUAD_BIN(*)
+QUAD_BIN(/)
+inline Quad operator-(const Quad& a) {
+    Quad r;
+    for (int l = 0; l < 4; ++l) r.v[l] = -a.v[l];
+    return r;
+}
+#define QUAD_FN(fn)                                          \
+    inline Quad fn(const Quad& a) {                          \
+        Quad r;                                              \
+        for (int l = 0; l < 4; ++l) r.v[l] = std::fn(a.v[l]); \
+        return r;                                            \
+    }
+QUAD_FN(sin)
+QUAD_FN(cos)
+QUAD_FN(sqrt)
+
+struct SimIO {
+    const double *x, *u, *p;
+    double *f, *J;
+    Quad qb(int i) const { return Quad{x[i]}; }
+    Quad vb(int i) const { return Quad{x[19 + i]}; }
+    Quad ql(int i) const { Quad r; for (int l = 0; l < 4; ++l) r.v[l] = x[7 + 3 * l + i]; return r; }
+    Quad vl(int i) const { Quad r; for (int l = 0; l < 4; ++l) r.v[l] = x[25 + 3 * l + i]; return r; }
+    Quad ul(int i) const { Quad r; for (int l = 0; l < 4; ++l) r.v[l] = u[3 * l + i]; return r; }
+    Quad dt() const { return Quad{p[0]}; }
+    void phase() const {}
+    Quad c(int k) const { Quad r; for (int l = 0; l < 4; ++l) r.v[l] = ungar_amd::gen::anymal_quad::kLegConstants[k][l]; return r; }
+    Quad quad_sum(const Quad& a) const { return Quad{a.v[0] + a.v[1] + a.v[2] + a.v[3]}; }
+    Quad rot(const Quad& a, int r) const { Quad o; for (int l = 0; l < 4; ++l) o.v[l] = a.v[(l + r) & 3]; return o; }
+    Quad quad_rot1(const Quad& a) const { return rot(a, 1); }
+    Quad quad_rot2(const Quad& a) const { return rot(a, 2); }
+    Quad quad_rot3(const Quad& a) const { return rot(a, 3); }
+    void f_base(int row, const Quad& v) const { f[row] = v.v[row & 3]; }
+    void f_leg(int rowBase, const Quad& v) const { for (int l = 0; l < 4; ++l) f[rowBase + 3 * l] = v.v[l]; }
+    void j_leg(int rowBase, int colBase, int legMul, int rot_, const Quad& v) const {
+        for (int l = 0; l < 4; ++l) J[(rowBase + 3 * l) * 49 + colBase + 3 * legMul * ((l + rot_) & 3)] = v.v[l];
+    }
+    void j_base_own(int row, int colBase, int legMul, int, const Quad& v) const {
+        for (int l = 0; l < 4; ++l) J[row * 49 + colBase + 3 * legMul * l] = v.v[l];
+    }
+    void j_base_shared(int row, int colBase, int, int, const Quad& v) const { J[row * 49 + colBase] = v.v[(row + colBase) & 3]; }
+};
+
+}  // namespace
+
+extern "C" void anymal_quad_sim(const double* x, const double* u, const double* p, double* f, double* J) {
+    for (int i = 0; i < 37; ++i) f[i] = NAN;
+    for (int i = 0; i < 37 * 49; ++i) J[i] = NAN;  // every entry must be written by the program
+    SimIO io{x, u, p, f, J};
+    ungar_amd::gen::anymal_quad::ValueJacobianQuad<Quad>(io);
+}

@@ -153,7 +153,11 @@ def test_full_size_properties(ua, name):
     m.sparse_jacobian(count, ua.Operand.soa(x, count), ua.Operand.soa(u, count), None, P, ua.Operand.soa(f2, count), ua.Operand.soa(Js, count))
     rows, cols = m.jacobian_sparsity()
     idx = torch.as_tensor(rows.astype(np.int64) * ncols + cols, device="cuda")
-    assert torch.equal(J[idx], Js) and torch.equal(f, f2)
+    if name == "anymal":  # dense block: lane-per-leg program; CSR values: phased lane-per-node program
+        assert (f - f2).abs().max().item() < 1e-10
+        assert ((J[idx] - Js).abs() / J.abs().amax(dim=0, keepdim=True)).max().item() < 1e-9
+    else:
+        assert torch.equal(J[idx], Js) and torch.equal(f, f2)
     mask = torch.ones(nx * ncols, dtype=torch.bool, device="cuda")
     mask[idx] = False
     assert (J[mask] == 0).all()

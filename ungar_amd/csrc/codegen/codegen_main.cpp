@@ -19,6 +19,7 @@
 #include "../models/nodes.hpp"
 #include "../rbd/rnea_crba.hpp"
 #include "../tape/emit.hpp"
+#include "quad_leg_program.hpp"
 
 using namespace ungar_amd;
 using tape::AD;
@@ -438,6 +439,37 @@ int main(int argc, char** argv) {
             if (wanted("anymal_reg")) {
                 st.dims.name = "anymal_reg";
                 EmitHip(st, outDir, true, 0);
+            }
+            if (wanted("anymal")) {  // lane-per-leg SPMD program (dense Jacobian path of the 'anymal' model)
+                const codegen::QuadProgram qp = codegen::RecordQuadLegProgram(anymal);
+                tape::EmitStats qs;
+                const std::string fn = codegen::EmitQuadProgram(qp, "ValueJacobianQuad", &qs);
+                std::ostringstream qo;
+                qo << "// GENERATED by ungar_amd/csrc/codegen (quad_leg_program.hpp) -- do not edit.\n"
+                   << "// ANYmal B shooting node, one lane per leg: " << qs.statements << " statements, " << qs.flops << " flops, "
+                   << qs.transcendentals << " transcendentals, " << qs.divisions << " divisions per lane.\n"
+                   << "#pragma once\n#ifndef __host__\n#define __host__\n#endif\n#ifndef __device__\n#define __device__\n#endif\n\n"
+                   << "namespace ungar_amd::gen::anymal_quad {\n\n"
+                   << "inline constexpr int kNumConstants = " << qp.constants.size() << ";\n"
+                   << "// leg constants that differ between legs, [k][leg]; legs in model order (LF, LH, RF, RH)\n"
+                   << "inline constexpr double kLegConstants[" << std::max<std::size_t>(1, qp.constants.size()) << "][4] = {\n";
+                for (const auto& c : qp.constants) {
+                    char buf[256];
+                    std::snprintf(buf, sizeof buf, "    {%.17g, %.17g, %.17g, %.17g},\n", c[0], c[1], c[2], c[3]);
+                    qo << buf;
+                }
+                qo << "};\n#ifdef __HIPCC__\n// device copy of the table (indexed by the lane's leg at run time)\n__device__ __constant__ double kLegConstantsDev["
+                   << std::max<std::size_t>(1, qp.constants.size()) << "][4] = {\n";
+                for (const auto& c : qp.constants) {
+                    char buf[256];
+                    std::snprintf(buf, sizeof buf, "    {%.17g, %.17g, %.17g, %.17g},\n", c[0], c[1], c[2], c[3]);
+                    qo << buf;
+                }
+                qo << "};\n#endif\n\n" << fn << "\n}  // namespace ungar_amd::gen::anymal_quad\n";
+                std::ofstream qf(outDir + "/anymal_quad_gen.hpp");
+                qf << qo.str();
+                std::fprintf(stderr, "[codegen] anymal_quad (lane per leg): %zu statements, %zu flops per lane, %zu table constants\n", qs.statements, qs.flops,
+                             qp.constants.size());
             }
             continue;
         }

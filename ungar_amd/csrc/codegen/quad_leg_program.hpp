@@ -1,0 +1,487 @@
+// ungar_amd :: SPMD "lane per leg" program for a floating-base quadruped shooting node.
+//
+// The structured derivative program of DESIGN.md §4.3 keeps ~600 doubles alive per node -- more than a
+// lane can hold on chip (128 ArchVGPR + 128 AGPR doubles, plus a share of the 160 KiB LDS).  The robot
+// is a floating base with four structurally identical 3-joint legs that only interact through the
+// base, so the node is split over the FOUR LANES OF A QUAD, one lane per leg (state per lane ~170
+// doubles: registers only, four wavefronts per CU).  All four lanes run the SAME straight-line
+// program; leg-specific numbers come from a constants table, and the lanes meet at a few points:
+//   quad_sum : composite inertia of the base, Schur complement of the block-arrow mass matrix, base
+//              bias force, shared right-hand sides;
+//   quad_rot : the base part y_b of M^-1 r for a column owned by another leg (so that every lane
+//              fills ITS OWN leg's rows of every Jacobian column).
+// The program is recorded on the tape like everything else (RNEA tangents come from the tape's own
+// differentiator, applied to the lane-local leg function with the solved accelerations held fixed
+// through auxiliary inputs), and is emitted generic over the value type so that the same text runs
+// on the GPU (T = double, DPP quad permutes) and in a 4-lane CPU simulator (T = Quad, tests).
+//
+// Math per lane (leg L), notation of csrc/rbd/*.hpp:
+//   M = [[Ybb, M_bL...], [M_bL^T, M_LL]]   block-arrow;  U D U^T from the bottom:
+//   M_LL = U_LL D_L U_LL^T,  U_bL = M_bL U_LL^-T D_L^-1,  S = Ybb - sum_L U_bL D_L U_bL^T  (quad_sum)
+//   solve(r_b, r_L):  z_L = U_LL^-1 r_L;  y_b = S^-1 (r_b - [sum_L] U_bL z_L);  y_L = U_LL^-T (D_L^-1 z_L - U_bL^T y_b)
+#pragma once
+
+#include <cmath>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../models/nodes.hpp"
+#include "../rbd/rnea_crba.hpp"
+#include "../tape/emit.hpp"
+
+namespace ungar_amd::codegen {
+
+using tape::AD;
+
+struct QuadProgram {
+    tape::Tape tape;                         // graph + inputs (outputs unused)
+    std::vector<tape::OutputSlot> slots;     // in emission order
+    std::vector<std::size_t> phaseStarts;    // slot indices where a new phase (Jacobian column) begins
+    std::vector<std::string> inputNames;     // spelling of every tape input in the generated code
+    std::vector<std::array<double, 4>> constants;  // constants[k][leg]
+};
+
+namespace detail {
+
+inline bool IsZeroLit(const AD& a) {
+    return a.IsLiteral() && a.Literal() == 0.0;
+}
+
+}  // namespace detail
+
+/// Records the leg-lane program for a free-flyer + 4 x (3 revolute) robot.
+inline QuadProgram RecordQuadLegProgram(const rbd::Model& model) {
+    using namespace rbd;
+    using namespace rbd::detail;
+    if (model.NumJoints() != 14 || model.nq != 19 || model.nv != 18) throw std::runtime_error("quad program: expected a free-flyer with 12 revolute joints");
+    for (int L = 0; L < 4; ++L)
+        for (int j = 0; j < 3; ++j) {
+            const Joint& J = model.joints[static_cast<std::size_t>(2 + 3 * L + j)];
+            const Joint& J0 = model.joints[static_cast<std::size_t>(2 + j)];
+            if (J.parent != (j == 0 ? 1 : 2 + 3 * L + j - 1)) throw std::runtime_error("quad program: legs must be 3-joint chains off the base");
+            if (J.axis != J0.axis) throw std::runtime_error("quad program: legs must share joint axes");
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c)
+                    if (std::fabs(J.placement.R[static_cast<std::size_t>(r)][static_cast<std::size_t>(c)] - (r == c ? 1.0 : 0.0)) > 1e-14)
+                        throw std::runtime_error("quad program: joint placements must be pure translations");
+        }
+
+    QuadProgram P;
+    // ---- inputs --------------------------------------------------------------------------------------------
+    // [0,7) q_b  [7,13) v_b  [13,16) q_L  [16,19) v_L  [19,22) u_L  [22] dt  [23, 23+K) constants  then 9 aux
+    constexpr int kQb = 0, kVb = 7, kQl = 13, kVl = 16, kUl = 19, kDt = 22, kConst = 23;
+    // leg constants: per joint t(3), mass, h(3), I(6 upper)  -> literal when identical in all four legs
+    struct CRef {
+        bool literal;
+        double value;
+        int index;
+    };
+    std::vector<CRef> cref;
+    auto addConst = [&](const std::array<double, 4>& v) {
+        if (v[0] == v[1] && v[1] == v[2] && v[2] == v[3]) {
+            cref.push_back({true, v[0], -1});
+        } else {
+            cref.push_back({false, 0.0, static_cast<int>(P.constants.size())});
+            P.constants.push_back(v);
+        }
+    };
+    for (int j = 0; j < 3; ++j) {
+        auto joint = [&](int L) -> const Joint& { return model.joints[static_cast<std::size_t>(2 + 3 * L + j)]; };
+        for (std::size_t k = 0; k < 3; ++k) addConst({joint(0).placement.p[k], joint(1).placement.p[k], joint(2).placement.p[k], joint(3).placement.p[k]});
+        addConst({joint(0).inertia.mass, joint(1).inertia.mass, joint(2).inertia.mass, joint(3).inertia.mass});
+        for (std::size_t k = 0; k < 3; ++k) addConst({joint(0).inertia.h[k], joint(1).inertia.h[k], joint(2).inertia.h[k], joint(3).inertia.h[k]});
+        for (std::size_t r = 0; r < 3; ++r)
+            for (std::size_t c = r; c < 3; ++c) addConst({joint(0).inertia.I[r][c], joint(1).inertia.I[r][c], joint(2).inertia.I[r][c], joint(3).inertia.I[r][c]});
+    }
+    const int K = static_cast<int>(P.constants.size());
+    const int kAux = kConst + K;  // aux: accb(6), aL(3)
+    const int nInputs = kAux + 9;
+    std::vector<AD> in = tape::Independent(nInputs);
+    tape::Graph& g = tape::CurrentGraph();
+    for (int i = 0; i < 7; ++i) P.inputNames.push_back("io.qb(" + std::to_string(i) + ")");
+    for (int i = 0; i < 6; ++i) P.inputNames.push_back("io.vb(" + std::to_string(i) + ")");
+    for (int i = 0; i < 3; ++i) P.inputNames.push_back("io.ql(" + std::to_string(i) + ")");
+    for (int i = 0; i < 3; ++i) P.inputNames.push_back("io.vl(" + std::to_string(i) + ")");
+    for (int i = 0; i < 3; ++i) P.inputNames.push_back("io.ul(" + std::to_string(i) + ")");
+    P.inputNames.push_back("io.dt()");
+    for (int i = 0; i < K; ++i) P.inputNames.push_back("io.c(" + std::to_string(i) + ")");
+    for (int i = 0; i < 9; ++i) P.inputNames.push_back("aux_unused");
+
+    std::size_t cnext = 0;
+    auto C = [&]() -> AD {
+        const CRef& r = cref[cnext++];
+        return r.literal ? AD{r.value} : in[static_cast<std::size_t>(kConst + r.index)];
+    };
+    const AD dt = in[kDt];
+    std::vector<AD> vb(in.begin() + kVb, in.begin() + kVb + 6);
+    std::array<AD, 3> ql{in[kQl], in[kQl + 1], in[kQl + 2]}, vl{in[kVl], in[kVl + 1], in[kVl + 2]}, ul{in[kUl], in[kUl + 1], in[kUl + 2]};
+
+    // ---- leg kinematics and inertias ---------------------------------------------------------------------------
+    std::array<Xform<AD>, 3> X;
+    std::array<Mat6<AD>, 3> Y;
+    std::array<V3, 3> axis;
+    for (std::size_t j = 0; j < 3; ++j) {
+        axis[j] = model.joints[2 + j].axis;
+        std::array<AD, 3> t{C(), C(), C()};
+        const AD m = C();
+        const std::array<AD, 3> h{C(), C(), C()};
+        AD I[3][3];
+        for (std::size_t r = 0; r < 3; ++r)
+            for (std::size_t c = r; c < 3; ++c) I[r][c] = I[c][r] = C();
+        using std::cos;
+        using std::sin;
+        X[j].R = AxisAngleRotation<AD>(axis[j], cos(ql[j]), sin(ql[j]));
+        X[j].p = t;
+        const AD hx[3][3] = {{AD{0.0}, -h[2], h[1]}, {h[2], AD{0.0}, -h[0]}, {-h[1], h[0], AD{0.0}}};
+        for (std::size_t r = 0; r < 3; ++r)
+            for (std::size_t c = 0; c < 3; ++c) {
+                Y[j][r][c] = r == c ? m : AD{0.0};
+                Y[j][r][3 + c] = -hx[r][c];
+                Y[j][3 + r][c] = hx[r][c];
+                Y[j][3 + r][3 + c] = I[r][c];
+            }
+    }
+    Mat6<AD> Yb;
+    {
+        const auto Yd = model.joints[1].inertia.Matrix();
+        for (std::size_t r = 0; r < 6; ++r)
+            for (std::size_t c = 0; c < 6; ++c) Yb[r][c] = AD{Yd[r][c]};
+    }
+    auto Sjoint = [&](std::size_t j) { return Vec6<AD>{AD{0.0}, AD{0.0}, AD{0.0}, AD{axis[j][0]}, AD{axis[j][1]}, AD{axis[j][2]}}; };
+    auto dotS = [&](std::size_t j, const Vec6<AD>& f) { return f[3] * axis[j][0] + f[4] * axis[j][1] + f[5] * axis[j][2]; };
+    auto add6 = [](const Vec6<AD>& a, const Vec6<AD>& b) {
+        Vec6<AD> r;
+        for (std::size_t k = 0; k < 6; ++k) r[k] = a[k] + b[k];
+        return r;
+    };
+    auto scaleS = [&](std::size_t j, const AD& s) { return Vec6<AD>{AD{0.0}, AD{0.0}, AD{0.0}, s * axis[j][0], s * axis[j][1], s * axis[j][2]}; };
+
+    const Rot<AD> Rb = QuaternionToRotation(in[kQb + 3], in[kQb + 4], in[kQb + 5], in[kQb + 6]);
+    std::array<AD, 3> gamma;
+    for (std::size_t k = 0; k < 3; ++k) {
+        AD acc{0.0};
+        for (std::size_t r = 0; r < 3; ++r) acc = acc + Rb[r][k] * (-model.gravity[r]);
+        gamma[k] = acc;
+    }
+    const Vec6<AD> velB{vb[0], vb[1], vb[2], vb[3], vb[4], vb[5]};
+
+    // ---- leg function: RNEA restricted to one leg, for given base acceleration and joint accelerations ---------
+    struct LegOut {
+        std::array<AD, 3> tau;
+        Vec6<AD> fb;
+    };
+    auto legRnea = [&](const Vec6<AD>& accB, const std::array<AD, 3>& aL) {
+        std::array<Vec6<AD>, 3> vel, acc, f;
+        for (std::size_t j = 0; j < 3; ++j) {
+            const Vec6<AD> vj = scaleS(j, vl[j]);
+            vel[j] = add6(ActInvMotion(X[j], j == 0 ? velB : vel[j - 1]), vj);
+            acc[j] = add6(add6(ActInvMotion(X[j], j == 0 ? accB : acc[j - 1]), scaleS(j, aL[j])), CrossMotion(vel[j], vj));
+            f[j] = add6(MatVec6(Y[j], acc[j]), CrossForce(vel[j], MatVec6(Y[j], vel[j])));
+        }
+        LegOut o;
+        for (std::size_t j = 3; j-- > 0;) {
+            o.tau[j] = dotS(j, f[j]);
+            const Vec6<AD> up = ActForce(X[j], f[j]);
+            if (j > 0) f[j - 1] = add6(f[j - 1], up);
+            else o.fb = up;
+        }
+        return o;
+    };
+    auto baseOwnForce = [&](const Vec6<AD>& accB) { return add6(MatVec6(Yb, accB), CrossForce(velB, MatVec6(Yb, velB))); };
+
+    // ---- CRBA: composite inertias, mass-matrix blocks -------------------------------------------------------------
+    std::array<Mat6<AD>, 3> Yc = Y;
+    for (std::size_t j = 2; j >= 1; --j) {
+        const Mat6<AD> T = TransportInertia(X[j], Yc[j]);
+        for (std::size_t r = 0; r < 6; ++r)
+            for (std::size_t c = 0; c < 6; ++c) Yc[j - 1][r][c] = Yc[j - 1][r][c] + T[r][c];
+    }
+    const Mat6<AD> YcbLeg = TransportInertia(X[0], Yc[0]);
+    Mat6<AD> Ybb;
+    for (std::size_t r = 0; r < 6; ++r)
+        for (std::size_t c = r; c < 6; ++c) Ybb[r][c] = Ybb[c][r] = Yb[r][c] + tape::QuadSum(YcbLeg[r][c]);
+    AD MLL[3][3], MbL[6][3];
+    for (std::size_t j = 0; j < 3; ++j) {
+        Vec6<AD> F = MatVec6(Yc[j], Sjoint(j));
+        MLL[j][j] = dotS(j, F);
+        for (std::size_t k = j; k-- > 0;) {
+            F = ActForce(X[k + 1], F);
+            MLL[k][j] = MLL[j][k] = dotS(k, F);
+        }
+        F = ActForce(X[0], F);
+        for (std::size_t r = 0; r < 6; ++r) MbL[r][j] = F[r];
+    }
+    // ---- block-arrow U D U^T ------------------------------------------------------------------------------------------
+    AD ULL[3][3], UbL[6][3], dL[3], dinvL[3];
+    for (std::size_t kk = 3; kk-- > 0;) {
+        AD dk = MLL[kk][kk];
+        for (std::size_t j = kk + 1; j < 3; ++j) dk = dk - ULL[kk][j] * ULL[kk][j] * dL[j];
+        dL[kk] = dk;
+        dinvL[kk] = AD{1.0} / dk;
+        for (std::size_t i = 0; i < kk; ++i) {
+            AD s = MLL[i][kk];
+            for (std::size_t j = kk + 1; j < 3; ++j) s = s - ULL[i][j] * ULL[kk][j] * dL[j];
+            ULL[i][kk] = s * dinvL[kk];
+        }
+        for (std::size_t r = 0; r < 6; ++r) {
+            AD s = MbL[r][kk];
+            for (std::size_t j = kk + 1; j < 3; ++j) s = s - UbL[r][j] * ULL[kk][j] * dL[j];
+            UbL[r][kk] = s * dinvL[kk];
+        }
+    }
+    std::vector<std::vector<AD>> Smat(6, std::vector<AD>(6));
+    for (std::size_t r = 0; r < 6; ++r)
+        for (std::size_t c = r; c < 6; ++c) {
+            AD acc{0.0};
+            for (std::size_t k = 0; k < 3; ++k) acc = acc + UbL[r][k] * UbL[c][k] * dL[k];
+            Smat[r][c] = Smat[c][r] = Ybb[r][c] - tape::QuadSum(acc);
+        }
+    const UdutFactor<AD> Fb = FactorUdut(Smat);
+
+    struct Sol {
+        std::vector<AD> yb;
+        std::array<AD, 3> yl;
+    };
+    /// shared = the right-hand side is non-zero in every leg (all lanes solve the SAME system).
+    auto solve = [&](const std::vector<AD>& rb, const std::array<AD, 3>& rl, bool shared) {
+        std::array<AD, 3> z = rl;
+        for (std::size_t k = 3; k-- > 0;)
+            for (std::size_t j = k + 1; j < 3; ++j) z[k] = z[k] - ULL[k][j] * z[j];
+        std::vector<AD> zb(6);
+        for (std::size_t r = 0; r < 6; ++r) {
+            AD c{0.0};
+            for (std::size_t k = 0; k < 3; ++k) c = c + UbL[r][k] * z[k];
+            zb[r] = rb[r] - (shared ? tape::QuadSum(c) : c);
+        }
+        Sol s;
+        s.yb = SolveUdut(Fb, zb);
+        for (std::size_t k = 0; k < 3; ++k) {
+            AD y = z[k] * dinvL[k];
+            for (std::size_t r = 0; r < 6; ++r) y = y - UbL[r][k] * s.yb[r];
+            for (std::size_t j = 0; j < k; ++j) y = y - ULL[j][k] * s.yl[j];
+            s.yl[k] = y;
+        }
+        return s;
+    };
+    /// rows of THIS leg for a column whose right-hand side lives entirely in another leg / the base.
+    auto foreignRows = [&](const std::vector<AD>& yb) {
+        std::array<AD, 3> y;
+        for (std::size_t k = 0; k < 3; ++k) {
+            AD v{0.0};
+            for (std::size_t r = 0; r < 6; ++r) v = v - UbL[r][k] * yb[r];
+            for (std::size_t j = 0; j < k; ++j) v = v - ULL[j][k] * y[j];
+            y[k] = v;
+        }
+        return y;
+    };
+
+    // ---- primal acceleration -------------------------------------------------------------------------------------------
+    const Vec6<AD> accB0{gamma[0], gamma[1], gamma[2], AD{0.0}, AD{0.0}, AD{0.0}};
+    const LegOut h = legRnea(accB0, {AD{0.0}, AD{0.0}, AD{0.0}});
+    const Vec6<AD> hbOwn = baseOwnForce(accB0);
+    std::vector<AD> rb0(6);
+    for (std::size_t r = 0; r < 6; ++r) rb0[r] = -(hbOwn[r] + tape::QuadSum(h.fb[r]));
+    const Sol acc = solve(rb0, {ul[0] - h.tau[0], ul[1] - h.tau[1], ul[2] - h.tau[2]}, true);
+
+    // ---- stage functions on auxiliary inputs: integrator and RNEA at fixed accelerations -----------------------------------
+    std::vector<AD> accbAux(in.begin() + kAux, in.begin() + kAux + 6);  // stands for a_b (integrator) / a_b + gamma (RNEA)
+    std::array<AD, 3> alAux{in[static_cast<std::size_t>(kAux + 6)], in[static_cast<std::size_t>(kAux + 7)], in[static_cast<std::size_t>(kAux + 8)]};
+    std::vector<tape::Id> inputIds;
+    for (const AD& i : in) inputIds.push_back(i.Node());
+    tape::Differentiator diff{g, inputIds};
+
+    // integrator rows: base (13) then leg (6)
+    using models::ApproximateExponentialMap;
+    using models::QuatMul;
+    using models::Rotate;
+    using models::Scale;
+    std::vector<AD> gOut;  // p+(3) quat+(4) v_b+(6) q_L+(3) v_L+(3)
+    {
+        std::array<AD, 6> vbN;
+        for (std::size_t k = 0; k < 6; ++k) vbN[k] = vb[k] + dt * accbAux[k];
+        const models::Quat<AD> quat{in[kQb + 3], in[kQb + 4], in[kQb + 5], in[kQb + 6]};
+        const models::Vec3<AD> lin = Rotate(quat, models::Vec3<AD>{vbN[0], vbN[1], vbN[2]});
+        for (std::size_t k = 0; k < 3; ++k) gOut.push_back(in[static_cast<std::size_t>(kQb) + k] + dt * lin[k]);
+        const models::Quat<AD> qN = QuatMul(quat, ApproximateExponentialMap(Scale(dt, models::Vec3<AD>{vbN[3], vbN[4], vbN[5]})));
+        for (std::size_t k = 0; k < 4; ++k) gOut.push_back(qN[k]);
+        for (std::size_t k = 0; k < 6; ++k) gOut.push_back(vbN[k]);
+        std::array<AD, 3> vlN;
+        for (std::size_t k = 0; k < 3; ++k) vlN[k] = vl[k] + dt * alAux[k];
+        for (std::size_t k = 0; k < 3; ++k) gOut.push_back(ql[k] + dt * vlN[k]);
+        for (std::size_t k = 0; k < 3; ++k) gOut.push_back(vlN[k]);
+    }
+    std::vector<tape::Id> gIds;
+    for (const AD& v : gOut) gIds.push_back(v.Node());
+    // integrator partials w.r.t. [q_b(7) v_b(6) q_L(3) v_L(3) | a_b(6) a_L(3)]
+    std::vector<int> gCols;
+    for (int k = 0; k < 19; ++k) gCols.push_back(k);
+    for (int k = 0; k < 9; ++k) gCols.push_back(kAux + k);
+    const tape::SparseEntries G = diff.Jacobian(gIds, gCols, 1);  // forward: each column's partials are born in its own phase
+    // RNEA stage
+    const Vec6<AD> accBAux{accbAux[0], accbAux[1], accbAux[2], accbAux[3], accbAux[4], accbAux[5]};
+    const LegOut tl = legRnea(accBAux, alAux);
+    const Vec6<AD> fbOwn = baseOwnForce(accBAux);
+    std::vector<tape::Id> tIds;  // tau_L(3) fb_leg(6) fb_own(6)
+    for (const AD& v : tl.tau) tIds.push_back(v.Node());
+    for (const AD& v : tl.fb) tIds.push_back(v.Node());
+    for (const AD& v : fbOwn) tIds.push_back(v.Node());
+    std::vector<int> dCols;  // q_L(3) v_L(3) v_b(6)
+    for (int k = 0; k < 3; ++k) dCols.push_back(kQl + k);
+    for (int k = 0; k < 3; ++k) dCols.push_back(kVl + k);
+    for (int k = 0; k < 6; ++k) dCols.push_back(kVb + k);
+    const tape::SparseEntries D = diff.Jacobian(tIds, dCols, 1);
+    const tape::SparseEntries dGamma = diff.Jacobian({gamma[0].Node(), gamma[1].Node(), gamma[2].Node()}, std::vector<int>{3, 4, 5, 6});
+
+    // substitutions: integrator sees a_b, RNEA sees a_b + gamma
+    std::vector<std::pair<int, tape::Id>> subG, subD;
+    for (std::size_t k = 0; k < 6; ++k) {
+        subG.emplace_back(kAux + static_cast<int>(k), acc.yb[k].Node());
+        subD.emplace_back(kAux + static_cast<int>(k), (acc.yb[k] + (k < 3 ? gamma[k] : AD{0.0})).Node());
+    }
+    for (std::size_t k = 0; k < 3; ++k) {
+        subG.emplace_back(kAux + 6 + static_cast<int>(k), acc.yl[k].Node());
+        subD.emplace_back(kAux + 6 + static_cast<int>(k), acc.yl[k].Node());
+    }
+    const std::vector<tape::Id> Gv = diff.Substitute(G.value, subG), fv = diff.Substitute(gIds, subG), Dv = diff.Substitute(D.value, subD);
+    // dense views of the small sparse blocks
+    AD Gm[19][28], Dm[15][12], dGam[3][4];
+    for (std::size_t e = 0; e < G.Nnz(); ++e) Gm[G.row[e]][G.col[e]] = AD::FromId(Gv[e]);
+    for (std::size_t e = 0; e < D.Nnz(); ++e) Dm[D.row[e]][D.col[e]] = AD::FromId(Dv[e]);
+    for (std::size_t e = 0; e < dGamma.Nnz(); ++e) dGam[dGamma.row[e]][dGamma.col[e]] = AD::FromId(dGamma.value[e]);
+
+    // ---- output helpers ---------------------------------------------------------------------------------------------------
+    // node-level indices: x = [p 0..2 | quat 3..6 | q_leg 7+3L+k | v_b 19..24 | v_leg 25+3L+k],  u column 37+3L+k
+    auto baseRowIndex = [](int i) { return i < 7 ? i : 19 + (i - 7); };  // i in [0,13): p,quat,v_b
+    auto sinkF = [&](const AD& v, const std::string& call) { P.slots.push_back({v.Node(), call}); };
+    for (int i = 0; i < 13; ++i) sinkF(AD::FromId(fv[static_cast<std::size_t>(i)]), "io.f_base(" + std::to_string(baseRowIndex(i)) + ", %s);");
+    for (int k = 0; k < 3; ++k) sinkF(AD::FromId(fv[static_cast<std::size_t>(13 + k)]), "io.f_leg(" + std::to_string(7 + k) + ", %s);");
+    for (int k = 0; k < 3; ++k) sinkF(AD::FromId(fv[static_cast<std::size_t>(16 + k)]), "io.f_leg(" + std::to_string(25 + k) + ", %s);");
+
+    /// Emits the Jacobian entries this lane is responsible for, for one column.
+    ///   gLocal: index of the column among the lane-local integrator inputs (0..18) or -1
+    ///   yb, yl: base / own-leg rows of da/dz for the column;  ownKind: this lane owns the column
+    ///   colExpr: how the column index is spelled; baseRows: emit the 13 base rows too
+    auto emitColumn = [&](int gLocal, const std::vector<AD>& yb, const std::array<AD, 3>& yl, const std::string& colArgs, bool baseRows,
+                          bool sharedColumn) {
+        if (baseRows) P.phaseStarts.push_back(P.slots.size());  // a column and its three rotated copies form one phase
+        auto entry = [&](int gr) {  // integrator row gr (0..18) of this column
+            AD v = gLocal >= 0 ? Gm[gr][gLocal] : AD{0.0};
+            for (int k = 0; k < 6; ++k) v = v + Gm[gr][19 + k] * yb[static_cast<std::size_t>(k)];
+            for (int k = 0; k < 3; ++k) v = v + Gm[gr][25 + k] * yl[static_cast<std::size_t>(k)];
+            return v;
+        };
+        if (baseRows)
+            for (int i = 0; i < 13; ++i)
+                P.slots.push_back({entry(i).Node(), std::string(sharedColumn ? "io.j_base_shared(" : "io.j_base_own(") + std::to_string(baseRowIndex(i)) + ", " +
+                                                        colArgs + ", %s);"});
+        for (int k = 0; k < 3; ++k) P.slots.push_back({entry(13 + k).Node(), "io.j_leg(" + std::to_string(7 + k) + ", " + colArgs + ", %s);"});
+        for (int k = 0; k < 3; ++k) P.slots.push_back({entry(16 + k).Node(), "io.j_leg(" + std::to_string(25 + k) + ", " + colArgs + ", %s);"});
+    };
+    const std::vector<AD> zero6(6, AD{0.0});
+    const std::array<AD, 3> zero3{AD{0.0}, AD{0.0}, AD{0.0}};
+
+    // ---- columns owned by this lane's leg: q_L, v_L (via D) and u_L ------------------------------------------------------------
+    for (int kind = 0; kind < 3; ++kind)      // 0: q_L, 1: v_L, 2: u_L
+        for (int k = 0; k < 3; ++k) {
+            std::vector<AD> rb(6, AD{0.0});
+            std::array<AD, 3> rl = zero3;
+            if (kind < 2) {
+                const int dc = 3 * kind + k;
+                for (int r = 0; r < 3; ++r) rl[static_cast<std::size_t>(r)] = -Dm[r][dc];
+                for (int r = 0; r < 6; ++r) rb[static_cast<std::size_t>(r)] = -Dm[3 + r][dc];  // fb_own does not depend on leg variables
+            } else {
+                rl[static_cast<std::size_t>(k)] = AD{1.0};
+            }
+            const Sol s = solve(rb, rl, false);
+            const int colBase = (kind == 0 ? 7 : kind == 1 ? 25 : 37) + k;
+            const int gLocal = kind == 0 ? 13 + k : kind == 1 ? 16 + k : -1;
+            emitColumn(gLocal, s.yb, s.yl, std::to_string(colBase) + ", 1, 0", true, false);
+            // the other three legs' versions of this column: their y_b arrives by rotation, only leg rows are ours
+            for (int rot = 1; rot < 4; ++rot) {
+                std::vector<AD> ybr(6);
+                for (std::size_t r = 0; r < 6; ++r) ybr[r] = tape::QuadRot(s.yb[r], rot);
+                emitColumn(-1, ybr, foreignRows(ybr), std::to_string(colBase) + ", 1, " + std::to_string(rot), false, false);
+            }
+        }
+    // ---- shared columns: base twist (via D, summed over legs), quaternion (closed form), position (none) -------------------------
+    for (int k = 0; k < 6; ++k) {
+        const int dc = 6 + k;
+        std::vector<AD> rb(6);
+        for (int r = 0; r < 6; ++r) rb[static_cast<std::size_t>(r)] = -(tape::QuadSum(Dm[3 + r][dc]) + Dm[9 + r][dc]);
+        const Sol s = solve(rb, {-Dm[0][dc], -Dm[1][dc], -Dm[2][dc]}, true);
+        emitColumn(7 + k, s.yb, s.yl, std::to_string(19 + k) + ", 0, 0", true, true);
+    }
+    for (int k = 0; k < 4; ++k) {
+        std::vector<AD> yb(6, AD{0.0});
+        for (int r = 0; r < 3; ++r) yb[static_cast<std::size_t>(r)] = -dGam[r][k];
+        emitColumn(3 + k, yb, zero3, std::to_string(3 + k) + ", 0, 0", true, true);
+    }
+    for (int k = 0; k < 3; ++k) emitColumn(k, zero6, zero3, std::to_string(k) + ", 0, 0", true, true);
+
+    // ---- package ---------------------------------------------------------------------------------------------------------------------
+    std::vector<AD> roots;
+    for (const auto& sl : P.slots) roots.push_back(AD::FromId(sl.value));
+    P.tape = tape::MakeTape(roots);
+    for (std::size_t i = 0; i < P.slots.size(); ++i) P.slots[i].value = P.tape.outputs[i];
+    return P;
+}
+
+/// Emits `template <class T, class IO> void <fn>(IO& io)` with all values of type T.
+inline std::string EmitQuadProgram(const QuadProgram& P, const std::string& fnName, tape::EmitStats* stats = nullptr, bool usePhases = true) {
+    // inputs are read ONCE into locals (an accessor call per use would be re-issued as a memory load
+    // after every store, since the compiler cannot prove the output buffers do not alias them)
+    std::vector<char> used(P.inputNames.size(), 0);
+    {
+        const tape::Graph& g = P.tape.graph;
+        std::vector<char> live(g.Size(), 0);
+        for (const auto& sl : P.slots) live[static_cast<std::size_t>(sl.value)] = 1;
+        for (std::size_t i = g.Size(); i-- > 0;) {
+            if (!live[i]) continue;
+            const tape::Node& nd = g.At(static_cast<tape::Id>(i));
+            if (nd.op == tape::Op::Input) used[static_cast<std::size_t>(nd.a)] = 1;
+            if (tape::Arity(nd.op) == 0) continue;
+            for (tape::Id o : {nd.a, nd.b, nd.c, nd.d})
+                if (o != tape::kNoId) live[static_cast<std::size_t>(o)] = 1;
+        }
+    }
+    std::vector<std::string> names(P.inputNames.size());
+    std::string prologue;
+    for (std::size_t i = 0; i < names.size(); ++i) {
+        names[i] = "in" + std::to_string(i);
+        if (used[i]) prologue += "    const T " + names[i] + " = " + P.inputNames[i] + ";\n";
+    }
+    tape::Emitter em{P.tape.graph, names};
+    // phases (primal + one per owned / shared column) separated by scheduling barriers, no LDS home:
+    // per-lane state fits the register file, the barriers only stop the scheduler from interleaving columns
+    std::vector<std::vector<tape::OutputSlot>> phases;
+    {
+        std::size_t next = 0;
+        std::vector<std::size_t> starts = P.phaseStarts;
+        starts.push_back(P.slots.size());
+        for (std::size_t st : starts) {
+            if (st > next) phases.emplace_back(P.slots.begin() + static_cast<std::ptrdiff_t>(next), P.slots.begin() + static_cast<std::ptrdiff_t>(st));
+            next = st;
+        }
+    }
+    int slotsUsed = 0;
+    std::string body = usePhases ? em.EmitPhased(phases, 0, slotsUsed, 0, 0, 0) : em.Emit(P.slots);
+    // the straight-line emitter declares `const double vN`; make the value type generic
+    std::string out;
+    out.reserve(body.size() + 256);
+    const std::string from = "const double v";
+    std::size_t pos = 0;
+    for (;;) {
+        const std::size_t hit = body.find(from, pos);
+        if (hit == std::string::npos) break;
+        out.append(body, pos, hit - pos);
+        out += "const T v";
+        pos = hit + from.size();
+    }
+    out.append(body, pos, std::string::npos);
+    if (stats) *stats = em.Stats();
+    return "template <class T, class IO>\n__host__ __device__ inline void " + fnName + "(IO& io) {\n" + prologue + out + "}\n";
+}
+
+}  // namespace ungar_amd::codegen

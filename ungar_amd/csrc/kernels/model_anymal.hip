@@ -1,8 +1,29 @@
-// ungar_amd :: kernels for the built-in 'anymal' (ANYmal B full-body) shooting-node model:
-// structured implicit differentiation (CRBA + RNEA tangents + U D U^T solves), phased body whose
-// cross-phase state lives in per-lane LDS slots.  One wavefront per workgroup,
-// one workgroup per CU (all 160 KiB of LDS).
+// ungar_amd :: kernels for the built-in 'anymal' (ANYmal B full-body) shooting-node model.
+//   dense [A|B] block  -> lane-per-leg SPMD program (quad_kernel.hpp), 4 wavefronts / CU
+//   sparse CSR values  -> structured implicit differentiation, phased body with an LDS home (§4.3-4.4)
+//   value only         -> plain lane-per-node body
 #include "../gen/anymal_gen.hpp"
-#include "node_kernel.hpp"
+#include "../gen/anymal_quad_gen.hpp"
+#include "quad_kernel.hpp"
 
-UNGAR_AMD_DEFINE_NODE_MODEL(anymal, 64)
+UNGAR_AMD_DEFINE_NODE_TRAITS(anymal)
+
+namespace ungar_amd::kernels {
+struct AnymalQuadBody {
+    __device__ __forceinline__ void operator()(QuadIO& io) const { gen::anymal_quad::ValueJacobianQuad<double>(io); }
+};
+}  // namespace ungar_amd::kernels
+
+extern "C" int ungar_amd_launch_anymal(int mode, const ungar_amd::kernels::NodeLaunch* a, void* stream) {
+    using namespace ungar_amd::kernels;
+    if (mode != kModeDenseJacobian) return static_cast<int>(LaunchNodeModel<Model_anymal, 64>(mode, *a, static_cast<hipStream_t>(stream)));
+    if (a->count <= 0) return 0;
+    constexpr int kBlock = 64;
+    void* sym = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&sym, HIP_SYMBOL(ungar_amd::gen::anymal_quad::kLegConstantsDev));
+    if (e != hipSuccess) return static_cast<int>(e);
+    const double(*ctab)[4] = static_cast<const double(*)[4]>(sym);
+    const dim3 grid(static_cast<unsigned>((a->count + kBlock / 4 - 1) / (kBlock / 4))), block(kBlock);
+    hipLaunchKernelGGL((QuadNodeKernel<kBlock, AnymalQuadBody>), grid, block, 0, static_cast<hipStream_t>(stream), *a, ctab, AnymalQuadBody{});
+    return static_cast<int>(hipGetLastError());
+}

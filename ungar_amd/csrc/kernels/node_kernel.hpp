@@ -164,6 +164,36 @@ inline hipError_t LaunchNodeModel(int mode, const NodeLaunch& a, hipStream_t str
 
 }  // namespace ungar_amd::kernels
 
+/// Binds a generated model namespace to the traits the skeletons expect (no launcher).
+#define UNGAR_AMD_DEFINE_NODE_TRAITS(ns)                                                                         \
+    namespace ungar_amd::kernels {                                                                               \
+    struct Model_##ns {                                                                                          \
+        static constexpr int kNx = gen::ns::kNx, kNu = gen::ns::kNu, kNw = gen::ns::kNw, kNp = gen::ns::kNp;     \
+        static constexpr int kJacRows = gen::ns::kJacRows, kJacCols = gen::ns::kJacCols, kJacNnz = gen::ns::kJacNnz; \
+        static constexpr int kLdsSlots = gen::ns::kLdsSlots;                                                     \
+        static constexpr int JacRow(int k) { return gen::ns::kJacRow[k]; }                                       \
+        static constexpr int JacCol(int k) { return gen::ns::kJacCol[k]; }                                       \
+        template <class IO>                                                                                      \
+        __device__ __forceinline__ static void Value(IO& io) { gen::ns::Value(io); }                             \
+        template <class IO>                                                                                      \
+        __device__ __forceinline__ static void ValueJacobian(IO& io) { gen::ns::ValueJacobian(io); }             \
+        template <class IO>                                                                                      \
+        __device__ __forceinline__ static void ValueJacobianPhased(IO& io) {                                     \
+            if constexpr (gen::ns::kLdsSlots > 0) gen::ns::ValueJacobianPhased(io);                              \
+        }                                                                                                        \
+    };                                                                                                           \
+    }                                                                                                            \
+    extern "C" const int* ungar_amd_pattern_##ns(int which, int* nnz) {                                          \
+        *nnz = ungar_amd::gen::ns::kJacNnz;                                                                      \
+        return which == 0 ? ungar_amd::gen::ns::kJacRow : ungar_amd::gen::ns::kJacCol;                           \
+    }                                                                                                            \
+    extern "C" void ungar_amd_dims_##ns(int* d) {                                                                \
+        d[0] = ungar_amd::gen::ns::kNx;                                                                          \
+        d[1] = ungar_amd::gen::ns::kNu;                                                                          \
+        d[2] = ungar_amd::gen::ns::kNw;                                                                          \
+        d[3] = ungar_amd::gen::ns::kNp;                                                                          \
+    }
+
 /// Binds a generated model namespace to the traits the skeletons expect and defines its launcher.
 #define UNGAR_AMD_DEFINE_NODE_MODEL(ns, BLOCK)                                                                   \
     namespace ungar_amd::kernels {                                                                               \

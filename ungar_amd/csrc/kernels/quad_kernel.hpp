@@ -1,0 +1,101 @@
+// ungar_amd :: kernel skeleton of the lane-per-leg SPMD node program.
+//
+// A quad of 4 adjacent lanes owns one shooting node of a floating-base quadruped, lane l & 3 = leg.
+// A 64-lane wavefront therefore evaluates 16 nodes; per-lane state (~170 doubles) lives in registers
+// only, so four wavefronts run per CU (one per SIMD) -- against ONE for the lane-per-node body whose
+// state had to be parked in 160 KiB of LDS.  The lanes of a quad meet through DPP quad permutes
+// (v_mov_b32 ... quad_perm: register-to-register, no LDS).
+// HBM access pattern (unit-fastest layout): the 16 nodes of a wavefront are consecutive, so every
+// load/store instruction touches, per leg, 16 consecutive doubles = one 128-byte segment.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "node_kernel.hpp"
+
+namespace ungar_amd::kernels {
+
+template <int CTRL>
+__device__ __forceinline__ double QuadPerm(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+
+/// I/O policy of gen::anymal_quad::ValueJacobianQuad<double>: node-level operands through strides,
+/// leg-dependent rows/columns through per-lane offsets computed once.
+struct QuadIO {
+    const double* __restrict__ xb;  // node's x (element stride xe)
+    const double* __restrict__ ub;
+    const double* __restrict__ pb;
+    double* __restrict__ fb;
+    double* __restrict__ jb;
+    long long xe, ue, fe, je;
+    int L;                       // this lane's leg
+    long long legRowJ;           // 3 L * 49 * je : offset of this leg's row block in the dense Jacobian
+    long long legColJ[4];        // 3 ((L + rot) & 3) * je : column offset of the leg owning a rotated column
+    const double (*ctab)[4];
+
+    __device__ __forceinline__ double qb(int i) const { return xb[i * xe]; }
+    __device__ __forceinline__ double vb(int i) const { return xb[(19 + i) * xe]; }
+    __device__ __forceinline__ double ql(int i) const { return xb[(7 + 3 * L + i) * xe]; }
+    __device__ __forceinline__ double vl(int i) const { return xb[(25 + 3 * L + i) * xe]; }
+    __device__ __forceinline__ double ul(int i) const { return ub[(3 * L + i) * ue]; }
+    __device__ __forceinline__ double dt() const { return pb[0]; }
+    __device__ __forceinline__ double c(int k) const { return ctab[k][L]; }
+    __device__ __forceinline__ void phase() const { __builtin_amdgcn_sched_barrier(0); }
+
+    // quad_perm control words: lane i of the quad reads lane p_i, ctrl = p0 | p1 << 2 | p2 << 4 | p3 << 6
+    __device__ __forceinline__ double quad_sum(double v) const {
+        const double t = v + QuadPerm<0xB1>(v);  // [1,0,3,2]
+        return t + QuadPerm<0x4E>(t);            // [2,3,0,1]
+    }
+    __device__ __forceinline__ double quad_rot1(double v) const { return QuadPerm<0x39>(v); }  // [1,2,3,0]
+    __device__ __forceinline__ double quad_rot2(double v) const { return QuadPerm<0x4E>(v); }  // [2,3,0,1]
+    __device__ __forceinline__ double quad_rot3(double v) const { return QuadPerm<0x93>(v); }  // [3,0,1,2]
+
+    // base rows / shared columns: all four lanes hold the same value and store it to the same address
+    // (merged inside the instruction) -- cheaper than masking three lanes off with exec-mask branches
+    __device__ __forceinline__ void f_base(int row, double v) const {
+        if (fb) fb[row * fe] = v;
+    }
+    __device__ __forceinline__ void f_leg(int rowBase, double v) const {
+        if (fb) fb[(rowBase + 3 * L) * fe] = v;
+    }
+    __device__ __forceinline__ void j_leg(int rowBase, int colBase, int legMul, int rot, double v) const {
+        jb[(rowBase * 49 + colBase) * je + legRowJ + (legMul ? legColJ[rot] : 0)] = v;
+    }
+    __device__ __forceinline__ void j_base_own(int row, int colBase, int /*legMul*/, int /*rot*/, double v) const {
+        jb[(row * 49 + colBase) * je + legColJ[0]] = v;
+    }
+    __device__ __forceinline__ void j_base_shared(int row, int colBase, int, int, double v) const {
+        jb[(row * 49 + colBase) * je] = v;
+    }
+};
+
+/// GEN is the generated namespace (ValueJacobianQuad, kLegConstantsDev).  BLOCK lanes = BLOCK/4 nodes.
+template <int BLOCK, class Body>
+__global__ __launch_bounds__(BLOCK) void QuadNodeKernel(const NodeLaunch a, const double (*ctab)[4], Body body) {
+    const int L = threadIdx.x & 3;
+    const long long i = static_cast<long long>(blockIdx.x) * (BLOCK / 4) + (threadIdx.x >> 2);
+    if (i >= a.count) return;  // whole quads leave together
+    long long b = i, k = 0;
+    if (a.knots > 1) {
+        b = i / a.knots;
+        k = i - b * a.knots;
+    }
+    QuadIO io{a.x.base + b * a.x.bs + k * a.x.ks,
+              a.u.base + b * a.u.bs + k * a.u.ks,
+              a.p.base + b * a.p.bs + k * a.p.ks,
+              a.f.base ? a.f.base + b * a.f.bs + k * a.f.ks : nullptr,
+              a.jac.base + b * a.jac.bs + k * a.jac.ks,
+              a.x.es, a.u.es, a.f.es, a.jac.es,
+              L,
+              3LL * L * 49 * a.jac.es,
+              {3LL * L * a.jac.es, 3LL * ((L + 1) & 3) * a.jac.es, 3LL * ((L + 2) & 3) * a.jac.es, 3LL * ((L + 3) & 3) * a.jac.es},
+              ctab};
+    body(io);
+}
+
+}  // namespace ungar_amd::kernels

@@ -373,6 +373,11 @@ class Differentiator {
             case Op::Sqrt: pa = g_.Div(g_.Constant(0.5), id); break;
             case Op::Abs: pa = g_.Unary(Op::Sign, nd.a); break;
             case Op::Sign: break;
+            case Op::QuadSum:
+            case Op::QuadRot1:
+            case Op::QuadRot2:
+            case Op::QuadRot3:
+                throw std::logic_error("tape: cannot differentiate through a quad communication op; differentiate the lane-local stage and substitute");
             case Op::Pow: {
                 if (g_.IsConst(nd.b)) {
                     const double e = g_.ConstValue(nd.b);

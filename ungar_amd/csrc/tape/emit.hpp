@@ -438,6 +438,10 @@ class Emitter {
             case Op::Sqrt: ++stats_.transcendentals; return "sqrt(" + a + ")";
             case Op::Abs: return "fabs(" + a + ")";
             case Op::Sign: return "(double)((" + a + " > 0.0) - (" + a + " < 0.0))";
+            case Op::QuadSum: return "io.quad_sum(" + a + ")";
+            case Op::QuadRot1: return "io.quad_rot1(" + a + ")";
+            case Op::QuadRot2: return "io.quad_rot2(" + a + ")";
+            case Op::QuadRot3: return "io.quad_rot3(" + a + ")";
             case Op::Pow: ++stats_.transcendentals; return "pow(" + a + ", " + b + ")";
             case Op::Atan2: ++stats_.transcendentals; return "atan2(" + a + ", " + b + ")";
             case Op::CondLt: return "(" + a + " < " + b + " ? " + c + " : " + d + ")";
@@ -470,6 +474,10 @@ class Emitter {
             case Op::Sqrt: ++stats_.transcendentals; return "sqrt(" + A() + ")";
             case Op::Abs: return "fabs(" + A() + ")";
             case Op::Sign: return "(double)((" + A() + " > 0.0) - (" + A() + " < 0.0))";
+            case Op::QuadSum: return "io.quad_sum(" + A() + ")";
+            case Op::QuadRot1: return "io.quad_rot1(" + A() + ")";
+            case Op::QuadRot2: return "io.quad_rot2(" + A() + ")";
+            case Op::QuadRot3: return "io.quad_rot3(" + A() + ")";
             case Op::Pow: ++stats_.transcendentals; return "pow(" + A() + ", " + B() + ")";
             case Op::Atan2: ++stats_.transcendentals; return "atan2(" + A() + ", " + B() + ")";
             case Op::CondLt: return "(" + A() + " < " + B() + " ? " + Ref(nd.c) + " : " + Ref(nd.d) + ")";

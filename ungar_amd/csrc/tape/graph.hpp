@@ -53,13 +53,22 @@ enum class Op : std::uint8_t {
     CondEq,
     CondGe,
     CondGt,
+    // SPMD communication inside a quad of 4 adjacent lanes (one lane per leg of a quadruped): opaque to
+    // the derivative transforms, emitted as io.quad_sum / io.quad_rotN (DPP quad_perm on the GPU).
+    QuadSum,   // every lane receives the sum over the 4 lanes of its quad
+    QuadRot1,  // lane l receives the value of lane (l + 1) & 3 of its quad
+    QuadRot2,
+    QuadRot3,
 };
 
+inline bool IsQuad(Op op) {
+    return op >= Op::QuadSum;
+}
 inline bool IsCond(Op op) {
-    return op >= Op::CondLt;
+    return op >= Op::CondLt && op <= Op::CondGt;
 }
 inline bool IsUnary(Op op) {
-    return op >= Op::Neg && op <= Op::Sign;
+    return (op >= Op::Neg && op <= Op::Sign) || IsQuad(op);
 }
 inline bool IsBinary(Op op) {
     return (op >= Op::Add && op <= Op::Div) || op == Op::Pow || op == Op::Atan2;
@@ -91,6 +100,10 @@ inline double EvalUnary(Op op, double a) {
         case Op::Sqrt: return std::sqrt(a);
         case Op::Abs: return std::fabs(a);
         case Op::Sign: return static_cast<double>(a > 0.0) - static_cast<double>(a < 0.0);
+        case Op::QuadSum: return 4.0 * a;  // a constant is the same in all four lanes
+        case Op::QuadRot1:
+        case Op::QuadRot2:
+        case Op::QuadRot3: return a;
         default: throw std::logic_error("EvalUnary: not a unary op");
     }
 }

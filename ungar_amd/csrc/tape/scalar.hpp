@@ -149,6 +149,9 @@ inline AD CondExpEq(const AD& a, const AD& b, const AD& t, const AD& f) { return
 inline AD CondExpGe(const AD& a, const AD& b, const AD& t, const AD& f) { return AD::Cond(Op::CondGe, a, b, t, f); }
 inline AD CondExpGt(const AD& a, const AD& b, const AD& t, const AD& f) { return AD::Cond(Op::CondGt, a, b, t, f); }
 
+inline AD QuadSum(const AD& a) { return AD::Un(Op::QuadSum, a); }
+inline AD QuadRot(const AD& a, int r) { return r == 0 ? a : AD::Un(r == 1 ? Op::QuadRot1 : r == 2 ? Op::QuadRot2 : Op::QuadRot3, a); }
+
 inline double Value(const AD& a) { return a.Literal(); }
 
 }  // namespace ungar_amd::tape
