@@ -51,6 +51,9 @@ struct SimIO {
     Quad ul(int i) const { Quad r; for (int l = 0; l < 4; ++l) r.v[l] = u[3 * l + i]; return r; }
     Quad dt() const { return Quad{p[0]}; }
     void phase() const {}
+    mutable Quad slots[512];
+    Quad ld(int s) const { return slots[s]; }
+    void st(int s, const Quad& v) const { slots[s] = v; }
     Quad c(int k) const { Quad r; for (int l = 0; l < 4; ++l) r.v[l] = ungar_amd::gen::anymal_quad::kLegConstants[k][l]; return r; }
     Quad quad_sum(const Quad& a) const { return Quad{a.v[0] + a.v[1] + a.v[2] + a.v[3]}; }
     Quad rot(const Quad& a, int r) const { Quad o; for (int l = 0; l < 4; ++l) o.v[l] = a.v[(l + r) & 3]; return o; }

@@ -371,6 +371,7 @@ int main(int argc, char** argv) {
     int jacMode = 0, structuredDMode = 1, ldsSlots = 320;
     int rematConsumers = 2, rematDepth = 3, prefetch = 48, maxChunk = 0;
     bool creationOrder = false;
+    int quadLdsSlots = 80;  // 64-lane workgroups, four per CU: 160 KiB / 4 / 64 lanes / 8 B
     std::vector<std::string> only;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
@@ -385,6 +386,7 @@ int main(int argc, char** argv) {
         else if (a == "--prefetch" && i + 1 < argc) prefetch = std::atoi(argv[++i]);
         else if (a == "--max-chunk" && i + 1 < argc) maxChunk = std::atoi(argv[++i]);
         else if (a == "--creation-order") creationOrder = true;
+        else if (a == "--quad-lds-slots" && i + 1 < argc) quadLdsSlots = std::atoi(argv[++i]);
         else if (a == "--model" && i + 1 < argc) only.push_back(argv[++i]);
         else {
             std::fprintf(stderr, "usage: %s --out DIR [--c-oracle DIR] [--anymal-robot FILE] [--jac-mode 0|1|2] [--model NAME]...\n", argv[0]);
@@ -443,7 +445,8 @@ int main(int argc, char** argv) {
             if (wanted("anymal")) {  // lane-per-leg SPMD program (dense Jacobian path of the 'anymal' model)
                 const codegen::QuadProgram qp = codegen::RecordQuadLegProgram(anymal);
                 tape::EmitStats qs;
-                const std::string fn = codegen::EmitQuadProgram(qp, "ValueJacobianQuad", &qs);
+                int quadLds = 0;
+                const std::string fn = codegen::EmitQuadProgram(qp, "ValueJacobianQuad", &qs, true, quadLdsSlots, &quadLds, rematConsumers, rematDepth, prefetch);
                 std::ostringstream qo;
                 qo << "// GENERATED by ungar_amd/csrc/codegen (quad_leg_program.hpp) -- do not edit.\n"
                    << "// ANYmal B shooting node, one lane per leg: " << qs.statements << " statements, " << qs.flops << " flops, "
@@ -451,6 +454,7 @@ int main(int argc, char** argv) {
                    << "#pragma once\n#ifndef __host__\n#define __host__\n#endif\n#ifndef __device__\n#define __device__\n#endif\n\n"
                    << "namespace ungar_amd::gen::anymal_quad {\n\n"
                    << "inline constexpr int kNumConstants = " << qp.constants.size() << ";\n"
+                   << "inline constexpr int kLdsSlots = " << quadLds << ";  // per-lane LDS slots of the phased body\n"
                    << "// leg constants that differ between legs, [k][leg]; legs in model order (LF, LH, RF, RH)\n"
                    << "inline constexpr double kLegConstants[" << std::max<std::size_t>(1, qp.constants.size()) << "][4] = {\n";
                 for (const auto& c : qp.constants) {

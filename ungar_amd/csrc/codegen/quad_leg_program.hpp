@@ -429,7 +429,8 @@ inline QuadProgram RecordQuadLegProgram(const rbd::Model& model) {
 }
 
 /// Emits `template <class T, class IO> void <fn>(IO& io)` with all values of type T.
-inline std::string EmitQuadProgram(const QuadProgram& P, const std::string& fnName, tape::EmitStats* stats = nullptr, bool usePhases = true) {
+inline std::string EmitQuadProgram(const QuadProgram& P, const std::string& fnName, tape::EmitStats* stats = nullptr, bool usePhases = true,
+                                   int ldsSlots = 0, int* ldsSlotsUsed = nullptr, int rematConsumers = 0, int rematDepth = 0, int prefetch = 0) {
     // inputs are read ONCE into locals (an accessor call per use would be re-issued as a memory load
     // after every store, since the compiler cannot prove the output buffers do not alias them)
     std::vector<char> used(P.inputNames.size(), 0);
@@ -466,7 +467,8 @@ inline std::string EmitQuadProgram(const QuadProgram& P, const std::string& fnNa
         }
     }
     int slotsUsed = 0;
-    std::string body = usePhases ? em.EmitPhased(phases, 0, slotsUsed, 0, 0, 0) : em.Emit(P.slots);
+    std::string body = usePhases ? em.EmitPhased(phases, ldsSlots, slotsUsed, rematConsumers, rematDepth, prefetch) : em.Emit(P.slots);
+    if (ldsSlotsUsed) *ldsSlotsUsed = slotsUsed;
     // the straight-line emitter declares `const double vN`; make the value type generic
     std::string out;
     out.reserve(body.size() + 256);

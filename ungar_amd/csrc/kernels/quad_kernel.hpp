@@ -36,6 +36,7 @@ struct QuadIO {
     long long legRowJ;           // 3 L * 49 * je : offset of this leg's row block in the dense Jacobian
     long long legColJ[4];        // 3 ((L + rot) & 3) * je : column offset of the leg owning a rotated column
     const double (*ctab)[4];
+    double* lds;  // per-lane LDS home of the phased body (slot s at lds[s * 64]); null when unused
 
     __device__ __forceinline__ double qb(int i) const { return xb[i * xe]; }
     __device__ __forceinline__ double vb(int i) const { return xb[(19 + i) * xe]; }
@@ -45,6 +46,8 @@ struct QuadIO {
     __device__ __forceinline__ double dt() const { return pb[0]; }
     __device__ __forceinline__ double c(int k) const { return ctab[k][L]; }
     __device__ __forceinline__ void phase() const { __builtin_amdgcn_sched_barrier(0); }
+    __device__ __forceinline__ double ld(int slot) const { return lds[slot * 64]; }
+    __device__ __forceinline__ void st(int slot, double v) const { lds[slot * 64] = v; }
 
     // quad_perm control words: lane i of the quad reads lane p_i, ctrl = p0 | p1 << 2 | p2 << 4 | p3 << 6
     __device__ __forceinline__ double quad_sum(double v) const {
@@ -75,8 +78,10 @@ struct QuadIO {
 };
 
 /// GEN is the generated namespace (ValueJacobianQuad, kLegConstantsDev).  BLOCK lanes = BLOCK/4 nodes.
-template <int BLOCK, class Body>
+template <int BLOCK, int LDS_SLOTS, class Body>
 __global__ __launch_bounds__(BLOCK) void QuadNodeKernel(const NodeLaunch a, const double (*ctab)[4], Body body) {
+    static_assert(BLOCK == 64, "the LDS home is laid out for one wavefront per workgroup");
+    __shared__ double lds[(LDS_SLOTS > 0 ? LDS_SLOTS : 1) * BLOCK];
     const int L = threadIdx.x & 3;
     const long long i = static_cast<long long>(blockIdx.x) * (BLOCK / 4) + (threadIdx.x >> 2);
     if (i >= a.count) return;  // whole quads leave together
@@ -94,7 +99,8 @@ __global__ __launch_bounds__(BLOCK) void QuadNodeKernel(const NodeLaunch a, cons
               L,
               3LL * L * 49 * a.jac.es,
               {3LL * L * a.jac.es, 3LL * ((L + 1) & 3) * a.jac.es, 3LL * ((L + 2) & 3) * a.jac.es, 3LL * ((L + 3) & 3) * a.jac.es},
-              ctab};
+              ctab,
+              lds + threadIdx.x};
     body(io);
 }
 
