@@ -113,8 +113,13 @@ def build_cpp_tests():
         if link:
             cmd += ["-L", LIBDIR, "-lungar_amd", "-Wl,-rpath,$ORIGIN/../ungar_amd/lib", "-Wl,-rpath,/opt/rocm/lib"]
         jobs.append(cmd)
-    for cmd in jobs:
-        _run(cmd)
+    # 4-lane CPU simulator of the lane-per-leg program (tests/test_quad_program.py)
+    sim_src, sim_lib = os.path.join(ROOT, "tests", "cpp", "quad_sim.cpp"), os.path.join(BUILD, "libquad_sim.so")
+    quad_gen = os.path.join(GEN, "anymal_quad_gen.hpp")
+    if os.path.exists(quad_gen) and not _newer([sim_lib], [sim_src, quad_gen]):
+        jobs.append(["g++", "-std=c++20", "-O0", "-shared", "-fPIC", "-I", GEN, "-o", sim_lib, sim_src])
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        list(pool.map(_run, jobs))
 
 
 def build_all():

@@ -371,6 +371,7 @@ int main(int argc, char** argv) {
     int jacMode = 0, structuredDMode = 1, ldsSlots = 320;
     int rematConsumers = 2, rematDepth = 3, prefetch = 48, maxChunk = 0;
     bool creationOrder = false;
+    int quadColumnsPerPhase = 1, quadRematConsumers = 4, quadRematDepth = 4;  // tools/sweep_quad.sh on MI355X
     int quadLdsSlots = 80;  // 64-lane workgroups, four per CU: 160 KiB / 4 / 64 lanes / 8 B
     std::vector<std::string> only;
     for (int i = 1; i < argc; ++i) {
@@ -387,6 +388,11 @@ int main(int argc, char** argv) {
         else if (a == "--max-chunk" && i + 1 < argc) maxChunk = std::atoi(argv[++i]);
         else if (a == "--creation-order") creationOrder = true;
         else if (a == "--quad-lds-slots" && i + 1 < argc) quadLdsSlots = std::atoi(argv[++i]);
+        else if (a == "--quad-columns-per-phase" && i + 1 < argc) quadColumnsPerPhase = std::atoi(argv[++i]);
+        else if (a == "--quad-remat" && i + 2 < argc) {
+            quadRematConsumers = std::atoi(argv[++i]);
+            quadRematDepth = std::atoi(argv[++i]);
+        }
         else if (a == "--model" && i + 1 < argc) only.push_back(argv[++i]);
         else {
             std::fprintf(stderr, "usage: %s --out DIR [--c-oracle DIR] [--anymal-robot FILE] [--jac-mode 0|1|2] [--model NAME]...\n", argv[0]);
@@ -443,10 +449,10 @@ int main(int argc, char** argv) {
                 EmitHip(st, outDir, true, 0);
             }
             if (wanted("anymal")) {  // lane-per-leg SPMD program (dense Jacobian path of the 'anymal' model)
-                const codegen::QuadProgram qp = codegen::RecordQuadLegProgram(anymal);
+                const codegen::QuadProgram qp = codegen::RecordQuadLegProgram(anymal, quadColumnsPerPhase);
                 tape::EmitStats qs;
                 int quadLds = 0;
-                const std::string fn = codegen::EmitQuadProgram(qp, "ValueJacobianQuad", &qs, true, quadLdsSlots, &quadLds, rematConsumers, rematDepth, prefetch);
+                const std::string fn = codegen::EmitQuadProgram(qp, "ValueJacobianQuad", &qs, true, quadLdsSlots, &quadLds, quadRematConsumers, quadRematDepth, prefetch);
                 std::ostringstream qo;
                 qo << "// GENERATED by ungar_amd/csrc/codegen (quad_leg_program.hpp) -- do not edit.\n"
                    << "// ANYmal B shooting node, one lane per leg: " << qs.statements << " statements, " << qs.flops << " flops, "

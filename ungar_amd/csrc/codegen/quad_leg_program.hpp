@@ -52,7 +52,7 @@ inline bool IsZeroLit(const AD& a) {
 }  // namespace detail
 
 /// Records the leg-lane program for a free-flyer + 4 x (3 revolute) robot.
-inline QuadProgram RecordQuadLegProgram(const rbd::Model& model) {
+inline QuadProgram RecordQuadLegProgram(const rbd::Model& model, int columnsPerPhase = 1) {
     using namespace rbd;
     using namespace rbd::detail;
     if (model.NumJoints() != 14 || model.nq != 19 || model.nv != 18) throw std::runtime_error("quad program: expected a free-flyer with 12 revolute joints");
@@ -363,9 +363,10 @@ inline QuadProgram RecordQuadLegProgram(const rbd::Model& model) {
     ///   gLocal: index of the column among the lane-local integrator inputs (0..18) or -1
     ///   yb, yl: base / own-leg rows of da/dz for the column;  ownKind: this lane owns the column
     ///   colExpr: how the column index is spelled; baseRows: emit the 13 base rows too
+    int columnCounter = 0;
     auto emitColumn = [&](int gLocal, const std::vector<AD>& yb, const std::array<AD, 3>& yl, const std::string& colArgs, bool baseRows,
                           bool sharedColumn) {
-        if (baseRows) P.phaseStarts.push_back(P.slots.size());  // a column and its three rotated copies form one phase
+        if (baseRows && (columnCounter++ % columnsPerPhase) == 0) P.phaseStarts.push_back(P.slots.size());  // a column + its rotated copies
         auto entry = [&](int gr) {  // integrator row gr (0..18) of this column
             AD v = gLocal >= 0 ? Gm[gr][gLocal] : AD{0.0};
             for (int k = 0; k < 6; ++k) v = v + Gm[gr][19 + k] * yb[static_cast<std::size_t>(k)];

@@ -16,7 +16,10 @@ struct AnymalQuadBody {
 
 extern "C" int ungar_amd_launch_anymal(int mode, const ungar_amd::kernels::NodeLaunch* a, void* stream) {
     using namespace ungar_amd::kernels;
-    if (mode != kModeDenseJacobian) return static_cast<int>(LaunchNodeModel<Model_anymal, 64>(mode, *a, static_cast<hipStream_t>(stream)));
+    // the quad kernel addresses the dense block with wave-uniform 32-bit element offsets (< 1813 * stride);
+    // operands too large for that go through the lane-per-node kernel (64-bit addressing)
+    const bool quadOk = mode == kModeDenseJacobian && a->jac.es >= 0 && a->jac.es * 1813LL < (1LL << 32);
+    if (!quadOk) return static_cast<int>(LaunchNodeModel<Model_anymal, 64>(mode, *a, static_cast<hipStream_t>(stream)));
     if (a->count <= 0) return 0;
     constexpr int kBlock = 64;
     void* sym = nullptr;

@@ -31,10 +31,14 @@ struct QuadIO {
     const double* __restrict__ pb;
     double* __restrict__ fb;
     double* __restrict__ jb;
-    long long xe, ue, fe, je;
+    long long xe, ue, fe;
+    unsigned je;  // element stride of the Jacobian operand; 1813 * je < 2^32 is checked by the launcher (uniform 32-bit offsets)
     int L;                       // this lane's leg
-    long long legRowJ;           // 3 L * 49 * je : offset of this leg's row block in the dense Jacobian
-    long long legColJ[4];        // 3 ((L + rot) & 3) * je : column offset of the leg owning a rotated column
+    // per-lane base pointers, so that every store address is (lane pointer) + (wave-uniform offset):
+    double* __restrict__ jLeg;        // jb + 3 L * 49 * je            : this leg's row block, leg-independent column
+    double* __restrict__ jLegCol[4];  // jLeg + 3 ((L + rot) & 3) * je : ... column owned by the leg `rot` lanes away
+    double* __restrict__ jOwnCol;     // jb + 3 L * je                  : base rows, column owned by this leg
+    double* __restrict__ fLeg;        // fb + 3 L * fe
     const double (*ctab)[4];
     double* lds;  // per-lane LDS home of the phased body (slot s at lds[s * 64]); null when unused
 
@@ -45,7 +49,11 @@ struct QuadIO {
     __device__ __forceinline__ double ul(int i) const { return ub[(3 * L + i) * ue]; }
     __device__ __forceinline__ double dt() const { return pb[0]; }
     __device__ __forceinline__ double c(int k) const { return ctab[k][L]; }
+#ifndef UNGAR_QUAD_NO_PHASE_BARRIER
     __device__ __forceinline__ void phase() const { __builtin_amdgcn_sched_barrier(0); }
+#else
+    __device__ __forceinline__ void phase() const {}
+#endif
     __device__ __forceinline__ double ld(int slot) const { return lds[slot * 64]; }
     __device__ __forceinline__ void st(int slot, double v) const { lds[slot * 64] = v; }
 
@@ -64,16 +72,16 @@ struct QuadIO {
         if (fb) fb[row * fe] = v;
     }
     __device__ __forceinline__ void f_leg(int rowBase, double v) const {
-        if (fb) fb[(rowBase + 3 * L) * fe] = v;
+        if (fb) fLeg[rowBase * fe] = v;
     }
     __device__ __forceinline__ void j_leg(int rowBase, int colBase, int legMul, int rot, double v) const {
-        jb[(rowBase * 49 + colBase) * je + legRowJ + (legMul ? legColJ[rot] : 0)] = v;
+        (legMul ? jLegCol[rot] : jLeg)[static_cast<unsigned>(rowBase * 49 + colBase) * je] = v;
     }
     __device__ __forceinline__ void j_base_own(int row, int colBase, int /*legMul*/, int /*rot*/, double v) const {
-        jb[(row * 49 + colBase) * je + legColJ[0]] = v;
+        jOwnCol[static_cast<unsigned>(row * 49 + colBase) * je] = v;
     }
     __device__ __forceinline__ void j_base_shared(int row, int colBase, int, int, double v) const {
-        jb[(row * 49 + colBase) * je] = v;
+        jb[static_cast<unsigned>(row * 49 + colBase) * je] = v;
     }
 };
 
@@ -90,15 +98,21 @@ __global__ __launch_bounds__(BLOCK) void QuadNodeKernel(const NodeLaunch a, cons
         b = i / a.knots;
         k = i - b * a.knots;
     }
+    double* const fb = a.f.base ? a.f.base + b * a.f.bs + k * a.f.ks : nullptr;
+    double* const jb = a.jac.base + b * a.jac.bs + k * a.jac.ks;
+    const long long je = a.jac.es;
+    double* const jLeg = jb + 3LL * L * 49 * je;
     QuadIO io{a.x.base + b * a.x.bs + k * a.x.ks,
               a.u.base + b * a.u.bs + k * a.u.ks,
               a.p.base + b * a.p.bs + k * a.p.ks,
-              a.f.base ? a.f.base + b * a.f.bs + k * a.f.ks : nullptr,
-              a.jac.base + b * a.jac.bs + k * a.jac.ks,
-              a.x.es, a.u.es, a.f.es, a.jac.es,
+              fb,
+              jb,
+              a.x.es, a.u.es, a.f.es, static_cast<unsigned>(je),
               L,
-              3LL * L * 49 * a.jac.es,
-              {3LL * L * a.jac.es, 3LL * ((L + 1) & 3) * a.jac.es, 3LL * ((L + 2) & 3) * a.jac.es, 3LL * ((L + 3) & 3) * a.jac.es},
+              jLeg,
+              {jLeg + 3LL * L * je, jLeg + 3LL * ((L + 1) & 3) * je, jLeg + 3LL * ((L + 2) & 3) * je, jLeg + 3LL * ((L + 3) & 3) * je},
+              jb + 3LL * L * je,
+              fb ? fb + 3LL * L * a.f.es : nullptr,
               ctab,
               lds + threadIdx.x};
     body(io);
