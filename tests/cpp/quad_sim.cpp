@@ -51,6 +51,7 @@ struct SimIO {
     Quad ul(int i) const { Quad r; for (int l = 0; l < 4; ++l) r.v[l] = u[3 * l + i]; return r; }
     Quad dt() const { return Quad{p[0]}; }
     void phase() const {}
+    void keep(const Quad&) const {}
     mutable Quad slots[512];
     Quad ld(int s) const { return slots[s]; }
     void st(int s, const Quad& v) const { slots[s] = v; }

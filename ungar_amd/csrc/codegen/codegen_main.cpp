@@ -214,7 +214,7 @@ std::string HipPrologue(const models::NodeDims& d, const std::vector<char>& used
     return os.str();
 }
 
-void EmitHip(const Generated& g, const std::string& dir, bool columnMajorEmission = false, int ldsSlots = 0, int rematConsumers = 2, int rematDepth = 3, int prefetch = 48, int maxChunk = 0, bool creationOrder = false) {
+void EmitHip(const Generated& g, const std::string& dir, bool columnMajorEmission = false, int ldsSlots = 0, int rematConsumers = 2, int rematDepth = 3, int prefetch = 48) {
     const auto& d = g.dims;
     const std::string name = d.name;
     std::ostringstream os;
@@ -312,7 +312,7 @@ void EmitHip(const Generated& g, const std::string& dir, bool columnMajorEmissio
         }
         tape::Emitter em{g.tape.graph, names};
         int used = 0;
-        const std::string body = em.EmitPhased(phases, ldsSlots, used, rematConsumers, rematDepth, prefetch, maxChunk, creationOrder);
+        const std::string body = em.EmitPhased(phases, ldsSlots, used, rematConsumers, rematDepth, prefetch);
         os << "// phased: " << phases.size() << " phases, " << used << " LDS slots per lane, " << em.Stats().statements << " statements\n"
            << "inline constexpr int kLdsSlots = " << used << ";\n"
            << "template <class IO>\n__device__ __forceinline__ void ValueJacobianPhased(IO& io) {\n"
@@ -369,8 +369,7 @@ void EmitC(const Generated& g, const std::string& dir) {
 int main(int argc, char** argv) {
     std::string outDir, cDir, robot;
     int jacMode = 0, structuredDMode = 1, ldsSlots = 320;
-    int rematConsumers = 2, rematDepth = 3, prefetch = 48, maxChunk = 0;
-    bool creationOrder = false;
+    int rematConsumers = 2, rematDepth = 3, prefetch = 48;
     int quadColumnsPerPhase = 1, quadRematConsumers = 4, quadRematDepth = 4;  // tools/sweep_quad.sh on MI355X
     int quadLdsSlots = 80;  // 64-lane workgroups, four per CU: 160 KiB / 4 / 64 lanes / 8 B
     std::vector<std::string> only;
@@ -385,8 +384,6 @@ int main(int argc, char** argv) {
         else if (a == "--remat-consumers" && i + 1 < argc) rematConsumers = std::atoi(argv[++i]);
         else if (a == "--remat-depth" && i + 1 < argc) rematDepth = std::atoi(argv[++i]);
         else if (a == "--prefetch" && i + 1 < argc) prefetch = std::atoi(argv[++i]);
-        else if (a == "--max-chunk" && i + 1 < argc) maxChunk = std::atoi(argv[++i]);
-        else if (a == "--creation-order") creationOrder = true;
         else if (a == "--quad-lds-slots" && i + 1 < argc) quadLdsSlots = std::atoi(argv[++i]);
         else if (a == "--quad-columns-per-phase" && i + 1 < argc) quadColumnsPerPhase = std::atoi(argv[++i]);
         else if (a == "--quad-remat" && i + 2 < argc) {
@@ -441,7 +438,7 @@ int main(int argc, char** argv) {
                 if (!cDir.empty()) EmitC(adv, cDir);
             }
             if (wanted("anymal")) {
-                EmitHip(st, outDir, true, ldsSlots, rematConsumers, rematDepth, prefetch, maxChunk, creationOrder);
+                EmitHip(st, outDir, true, ldsSlots, rematConsumers, rematDepth, prefetch);
                 if (!cDir.empty()) EmitC(st, cDir);
             }
             if (wanted("anymal_reg")) {

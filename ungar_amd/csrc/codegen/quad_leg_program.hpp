@@ -355,6 +355,22 @@ inline QuadProgram RecordQuadLegProgram(const rbd::Model& model, int columnsPerP
     // node-level indices: x = [p 0..2 | quat 3..6 | q_leg 7+3L+k | v_b 19..24 | v_leg 25+3L+k],  u column 37+3L+k
     auto baseRowIndex = [](int i) { return i < 7 ? i : 19 + (i - 7); };  // i in [0,13): p,quat,v_b
     auto sinkF = [&](const AD& v, const std::string& call) { P.slots.push_back({v.Node(), call}); };
+    // phase 0 = kinematics + CRBA + block-arrow factorisation (its results are pinned by no-op sinks so that the
+    // emitter can place them in LDS / rematerialise around them); phase 1 = bias forces, primal solve, f
+    auto keep = [&](const AD& v) {
+        if (!v.IsLiteral()) P.slots.push_back({v.Node(), "io.keep(%s);"});
+    };
+    for (std::size_t r = 0; r < 6; ++r)
+        for (std::size_t k = 0; k < 3; ++k) keep(UbL[r][k]);
+    for (std::size_t i = 0; i < 3; ++i) {
+        keep(dinvL[i]);
+        for (std::size_t j = i + 1; j < 3; ++j) keep(ULL[i][j]);
+    }
+    for (std::size_t i = 0; i < 6; ++i) {
+        keep(Fb.dinv[i]);
+        for (std::size_t j = i + 1; j < 6; ++j) keep(Fb.U[i][j]);
+    }
+    P.phaseStarts.push_back(P.slots.size());
     for (int i = 0; i < 13; ++i) sinkF(AD::FromId(fv[static_cast<std::size_t>(i)]), "io.f_base(" + std::to_string(baseRowIndex(i)) + ", %s);");
     for (int k = 0; k < 3; ++k) sinkF(AD::FromId(fv[static_cast<std::size_t>(13 + k)]), "io.f_leg(" + std::to_string(7 + k) + ", %s);");
     for (int k = 0; k < 3; ++k) sinkF(AD::FromId(fv[static_cast<std::size_t>(16 + k)]), "io.f_leg(" + std::to_string(25 + k) + ", %s);");

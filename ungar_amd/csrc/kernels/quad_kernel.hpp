@@ -54,6 +54,7 @@ struct QuadIO {
 #else
     __device__ __forceinline__ void phase() const {}
 #endif
+    __device__ __forceinline__ void keep(double) const {}
     __device__ __forceinline__ double ld(int slot) const { return lds[slot * 64]; }
     __device__ __forceinline__ void st(int slot, double v) const { lds[slot * 64] = v; }
 

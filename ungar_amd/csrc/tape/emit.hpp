@@ -75,57 +75,14 @@ class Emitter {
     ///   * stored values beyond `ldsSlots` stay registers across phases.
     /// Returns the code; `slotsUsed` = LDS slots actually needed.
     std::string EmitPhased(const std::vector<std::vector<OutputSlot>>& phases, int ldsSlots, int& slotsUsed, int rematMaxConsumers = 2,
-                           int rematMaxDepth = 3, int prefetchDistance = 48, int maxChunk = 0, bool creationOrder = false,
-                           const char* indent = "    ") {
+                           int rematMaxDepth = 3, int prefetchDistance = 48, const char* indent = "    ") {
         const std::size_t n = g_.Size();
         // ---- analysis pass: first-definition phase, consumer phases -------------------------------------
         std::vector<int> defPhase(n, -1);
         std::vector<std::vector<Id>> order(phases.size());
         for (std::size_t ph = 0; ph < phases.size(); ++ph)
             for (const OutputSlot& s : phases[ph]) CollectOrder(s.value, static_cast<int>(ph), defPhase, order[ph]);
-        if (creationOrder) {
-            // Schedule = the order in which the recording program created the values (node ids are
-            // creation-ordered and topological): the locality of the hand-written algorithm (leg by
-            // leg, column by column) is kept instead of a depth-first walk from the outputs.
-            std::vector<Id> all;
-            for (auto& o : order) all.insert(all.end(), o.begin(), o.end());
-            std::sort(all.begin(), all.end());
-            order.assign(phases.size(), {});
-            order[0] = std::move(all);
-            for (Id id : order[0]) defPhase[static_cast<std::size_t>(id)] = 0;
-        }
-        // Optional re-chunking: a phase whose statement list is longer than `maxChunk` is cut into
-        // pieces (bounding the register working set inside a piece); every output sink moves to the
-        // piece that first defines its value, so results leave for HBM as soon as they exist.
-        std::vector<std::vector<OutputSlot>> chunkSinks;
-        const std::vector<std::vector<OutputSlot>>* phasesPtr = &phases;
-        if (maxChunk > 0) {
-            std::vector<std::vector<Id>> newOrder;
-            for (std::size_t ph = 0; ph < phases.size(); ++ph) {
-                const std::size_t first = newOrder.size();
-                const std::size_t len = order[ph].size();
-                const std::size_t pieces = std::max<std::size_t>(1, (len + static_cast<std::size_t>(maxChunk) - 1) / static_cast<std::size_t>(maxChunk));
-                const std::size_t per = (len + pieces - 1) / pieces;
-                for (std::size_t c = 0; c < pieces; ++c) {
-                    const std::size_t lo = std::min(len, c * per), hi = std::min(len, (c + 1) * per);
-                    newOrder.emplace_back(order[ph].begin() + static_cast<std::ptrdiff_t>(lo), order[ph].begin() + static_cast<std::ptrdiff_t>(hi));
-                    for (Id id : newOrder.back()) defPhase[static_cast<std::size_t>(id)] = static_cast<int>(newOrder.size() - 1);
-                }
-                chunkSinks.resize(newOrder.size());
-                if (creationOrder && ph != 0) continue;
-                std::vector<OutputSlot> sinksHere;
-                if (creationOrder) for (const auto& pp : phases) sinksHere.insert(sinksHere.end(), pp.begin(), pp.end());
-                else sinksHere = phases[ph];
-                for (const OutputSlot& sl : sinksHere) {
-                    const int dp = g_.At(sl.value).op == Op::Const ? -1 : defPhase[static_cast<std::size_t>(sl.value)];
-                    const std::size_t at = dp < static_cast<int>(first) ? newOrder.size() - 1 : static_cast<std::size_t>(dp);
-                    chunkSinks[at].push_back(sl);
-                }
-            }
-            order.swap(newOrder);
-            phasesPtr = &chunkSinks;
-        }
-        const std::vector<std::vector<OutputSlot>>& ph_ = *phasesPtr;
+        const std::vector<std::vector<OutputSlot>>& ph_ = phases;
         std::vector<int> consumers(n, 0);
         for (std::size_t ph = 0; ph < ph_.size(); ++ph) {
             std::vector<char> seen(n, 0);
