@@ -116,6 +116,27 @@ int ungar_model_dense_jacobian(const ungar_model* model, const ungar_node_batch*
 int ungar_gn_hessian(const double* jac, int64_t js, int64_t ld_j, const double* d, int64_t ds, double* g, int64_t gs, int64_t ld_g,
                      int32_t rows, int32_t cols, int64_t count, void* stream);
 
+/* ---- whole-horizon assembly ------------------------------------------ */
+
+/* Sparsity of the equality-constraint Jacobian  d g / d [X | U]  of a horizon-N OCP built on `model`,
+ *     g = [x_0 - x_m ; x_{k+1} - f(x_k, u_k)]_{k<N}     (example/mpc/quadrotor.example.cpp:246-266),
+ * in canonical CSR: (N+1) nx rows, (N+1) nx + N nu columns, nnz = nx + N (jac_nnz + nx).
+ * Pass null arrays to query `nnz` only.  Host arrays; replaces the JacobianSparsity query that the
+ * reference makes on the whole-horizon model (function.hpp:98-105). */
+int ungar_ocp_equality_sparsity(const ungar_model* model, int64_t horizon, int32_t* row_starts, int32_t* cols, int64_t* nnz);
+
+/* Assembles, for `batch` instances, the constraint values g ((N+1) nx per instance) and the CSR value
+ * array of the block-bidiagonal Jacobian from the node kernels' outputs.
+ *   x    : states x_k, k = 0..N (instance/knot/element strides; a VariableMap buffer works directly)
+ *   xm   : measured state per instance (knot_stride ignored)
+ *   f    : node values, jac : node DENSE blocks, both over batch*N nodes as written by
+ *          ungar_model_dense_jacobian (node i = instance * N + knot)
+ *   g, values : outputs, instance-major (instance_stride = per-instance size or more).
+ * replaces, for this structure, the whole-horizon SparseJacobian evaluation (function.hpp:224-228). */
+int ungar_ocp_assemble_equality(const ungar_model* model, int64_t horizon, int64_t batch, const ungar_operand* x, const ungar_operand* xm,
+                                const ungar_operand* f, const ungar_operand* jac, const ungar_operand* g, const ungar_operand* values,
+                                void* stream);
+
 /* ---- run-time function factory (any recorded function, not only the built-in node models) ----- */
 
 /* One node of a recorded expression tape, in topological order (operands refer to EARLIER nodes).

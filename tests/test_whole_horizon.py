@@ -84,6 +84,62 @@ def test_equality_constraints_block_structure(dump):
     assert mask.sum() == NX + N * (118 + NX)
 
 
+def test_batched_assembly_from_node_blocks_matches_whole_horizon_function(dump):
+    """Row N1: the block-bidiagonal equality Jacobian of a BATCH of instances assembled on the GPU from the
+    node kernel's dense blocks (ungar_ocp_assemble_equality) -- instance 0 must reproduce, entry for entry
+    and in the same CSR order, what the whole-horizon Ungar::Autodiff::Function returned."""
+    import ungar_amd
+    v = dump["INPUT"]
+    m = ungar_amd.NodeModel("quadrotor")
+    starts, cols = m.ocp_equality_sparsity(N)
+    mask = dump["EQ_JAC_MASK"]
+    assert starts[-1] == mask.sum() == len(cols)
+    ref_rows, ref_cols = np.nonzero(mask)                      # row-major order = CSR order
+    assert np.array_equal(cols, ref_cols) and np.array_equal(np.diff(starts), mask.sum(axis=1))
+
+    batch, count = 5, 5 * N
+    rng = np.random.default_rng(0)
+    Xs = np.stack([v[:(N + 1) * NX].reshape(N + 1, NX)] + [v[:(N + 1) * NX].reshape(N + 1, NX) + 0.05 * rng.normal(size=(N + 1, NX)) for _ in range(batch - 1)])
+    Us = np.stack([v[(N + 1) * NX:DEC].reshape(N, NU)] + [v[(N + 1) * NX:DEC].reshape(N, NU) * (1 + 0.05 * rng.normal(size=(N, NU))) for _ in range(batch - 1)])
+    xm = np.tile(v[DEC:][-13:], (batch, 1))
+    dev = torch.device("cuda")
+    Xd = torch.as_tensor(Xs, device=dev).contiguous()           # (batch, N+1, nx): VariableMap-style state block
+    Ud = torch.as_tensor(Us, device=dev).contiguous()
+    pd = torch.as_tensor(v[DEC:DEC + 20], device=dev)
+    xmd = torch.as_tensor(xm, device=dev)
+    f = torch.empty((NX, count), dtype=torch.float64, device=dev)
+    J = torch.empty((NX * (NX + NU), count), dtype=torch.float64, device=dev)
+    Op = ungar_amd.Operand
+    m.dense_jacobian(count, Op(Xd, (N + 1) * NX, NX, 1), Op(Ud, N * NU, NU, 1), None, Op.per_instance(pd, 20, shared=True), Op.soa(f, count, N),
+                     Op.soa(J, count, N), knots=N)
+    nnz = len(cols)
+    g = torch.full((batch, (N + 1) * NX), float("nan"), dtype=torch.float64, device=dev)
+    vals = torch.full((batch, nnz), float("nan"), dtype=torch.float64, device=dev)
+    m.ocp_assemble_equality(N, batch, Op(Xd, (N + 1) * NX, NX, 1), Op(xmd, NX, 0, 1), Op.soa(f, count, N), Op.soa(J, count, N), Op(g, (N + 1) * NX, 0, 1),
+                            Op(vals, nnz, 0, 1))
+    torch.cuda.synchronize()
+    g, vals, fh, Jh = g.cpu().numpy(), vals.cpu().numpy(), f.cpu().numpy().T, J.cpu().numpy().T.reshape(count, NX, NX + NU)
+    assert np.isfinite(g).all() and np.isfinite(vals).all()
+    # instance 0 == the whole-horizon Function
+    assert np.abs(g[0] - dump["EQ"]).max() < 1e-12
+    assert np.abs(vals[0] - dump["EQ_JAC"][ref_rows, ref_cols]).max() <= 1e-10 * np.abs(dump["EQ_JAC"]).max()
+    # every instance == the block formula built on the host from the node outputs
+    for b in range(batch):
+        dense = np.zeros(((N + 1) * NX, DEC))
+        dense[ref_rows, ref_cols] = vals[b]
+        want = np.zeros_like(dense)
+        want[:NX, :NX] = np.eye(NX)
+        for k in range(N):
+            rows = slice(NX + k * NX, NX + (k + 1) * NX)
+            Jk = Jh[b * N + k]
+            want[rows, k * NX:(k + 1) * NX] = -Jk[:, :NX]
+            want[rows, (k + 1) * NX:(k + 2) * NX] += np.eye(NX)
+            want[rows, (N + 1) * NX + k * NU:(N + 1) * NX + (k + 1) * NU] = -Jk[:, NX:]
+            assert np.abs(g[b, rows] - (Xs[b, k + 1] - fh[b * N + k])).max() < 1e-13
+        assert np.array_equal(dense, want)
+        assert np.abs(g[b, :NX] - (Xs[b, 0] - xm[b])).max() < 1e-15
+
+
 def test_inequality_constraints(dump):
     v = dump["INPUT"]
     U = v[(N + 1) * NX:DEC].reshape(N, NU)

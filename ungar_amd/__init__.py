@@ -79,6 +79,8 @@ def load_library() -> ctypes.CDLL:
         getattr(lib, name).argtypes = [vp, ctypes.POINTER(_NodeBatch), vp]
     lib.ungar_gn_hessian.argtypes = [vp, ctypes.c_int64, ctypes.c_int64, vp, ctypes.c_int64, vp, ctypes.c_int64, ctypes.c_int64,
                                      ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, vp]
+    lib.ungar_ocp_equality_sparsity.argtypes = [vp, ctypes.c_int64, vp, vp, i64p]
+    lib.ungar_ocp_assemble_equality.argtypes = [vp, ctypes.c_int64, ctypes.c_int64] + [ctypes.POINTER(_Operand)] * 6 + [vp]
     lib.ungar_last_error.restype = ctypes.c_char_p
     lib.ungar_version.restype = ctypes.c_char_p
     _LIB = lib
@@ -204,6 +206,20 @@ class NodeModel:
     def dense_jacobian(self, count, x, u, w, p, f, jac, knots=1, stream=None):
         b = self._batch(count, knots, x, u, w, p, f, jac)
         _check(self._lib.ungar_model_dense_jacobian(self._h, ctypes.byref(b), self._stream(stream)))
+
+    # -- whole-horizon assembly --------------------------------------------
+    def ocp_equality_sparsity(self, horizon: int):
+        """(row_starts, cols) of d g / d [X | U], g = [x0 - xm; x_{k+1} - f(x_k, u_k)], canonical CSR."""
+        nnz = ctypes.c_int64()
+        _check(self._lib.ungar_ocp_equality_sparsity(self._h, horizon, None, None, ctypes.byref(nnz)))
+        starts = np.zeros((horizon + 1) * self.nx + 1, dtype=np.int32)
+        cols = np.zeros(nnz.value, dtype=np.int32)
+        _check(self._lib.ungar_ocp_equality_sparsity(self._h, horizon, starts.ctypes.data, cols.ctypes.data, ctypes.byref(nnz)))
+        return starts, cols
+
+    def ocp_assemble_equality(self, horizon, batch, x, xm, f, jac, g, values, stream=None):
+        ops = [o._c() for o in (x, xm, f, jac, g, values)]
+        _check(self._lib.ungar_ocp_assemble_equality(self._h, horizon, batch, *[ctypes.byref(o) for o in ops], self._stream(stream)))
 
     # -- convenience: node-major numpy in, numpy out (tests, smoke) ---------------------------------
     def evaluate_numpy(self, x, u, w, p, mode="dense", layout="soa"):

@@ -27,6 +27,29 @@ UNGAR_AMD_DECLARE_MODEL(anymal)
 UNGAR_AMD_DECLARE_MODEL(anymal_ad)
 UNGAR_AMD_DECLARE_MODEL(anymal_reg)
 
+namespace ungar_amd::kernels {
+struct OcpAssemblyArgs {
+    const double* X;
+    long long xbs, xks, xes;
+    const double* xm;
+    long long mbs, mes;
+    const double* f;
+    long long fus, fes;
+    const double* jac;
+    long long jus, jes;
+    double* g;
+    long long gbs;
+    double* values;
+    long long vbs;
+    const int* nodeRow;
+    const int* nodeCol;
+    const int* rowStart;
+    int nx, nu, N, nnzNode;
+    long long batch;
+};
+}  // namespace ungar_amd::kernels
+extern "C" int ungar_amd_launch_ocp_assemble(const ungar_amd::kernels::OcpAssemblyArgs* a, void* stream);
+
 extern "C" int ungar_amd_launch_gn_hessian(const double* jac, long long js, long long ldj, const double* d, long long ds, double* g,
                                             long long gs, long long ldg, int rows, int cols, long long count, void* stream);
 
@@ -72,6 +95,11 @@ struct ungar_model {
     ungar_model_info info{};
     std::vector<int32_t> jacRows, jacCols, hesRows, hesCols;
     int (*launch)(int, const NodeLaunch*, void*) = nullptr;
+    // device copy of the node pattern (rows, cols, row starts), created on first use by the assembly
+    mutable int* devPattern = nullptr;
+    ~ungar_model() {
+        if (devPattern) (void)hipFree(devPattern);
+    }
 };
 
 namespace {
@@ -179,6 +207,65 @@ int ungar_gn_hessian(const double* jac, int64_t js, int64_t ld_j, const double* 
     if (count == 0) return UNGAR_OK;
     const int err = ungar_amd_launch_gn_hessian(jac, js, ld_j, d, ds, g, gs, ld_g, rows, cols, count, stream);
     if (err != 0) return Fail(UNGAR_E_HIP, std::string("gn_hessian launch failed: ") + hipGetErrorString(static_cast<hipError_t>(err)));
+    return UNGAR_OK;
+}
+
+int ungar_ocp_equality_sparsity(const ungar_model* model, int64_t horizon, int32_t* row_starts, int32_t* cols, int64_t* nnz) {
+    if (!model || !nnz || horizon < 1) return Fail(UNGAR_E_INVALID, "ungar_ocp_equality_sparsity: bad argument");
+    const int64_t nx = model->info.nx, nu = model->info.nu, nn = model->info.jac_nnz;
+    *nnz = nx + horizon * (nn + nx);
+    if (!row_starts || !cols) return UNGAR_OK;
+    int64_t e = 0;
+    for (int64_t r = 0; r < nx; ++r) {
+        row_starts[r] = static_cast<int32_t>(e);
+        cols[e++] = static_cast<int32_t>(r);
+    }
+    for (int64_t k = 0; k < horizon; ++k) {
+        std::size_t p = 0;
+        for (int64_t r = 0; r < nx; ++r) {
+            row_starts[nx + k * nx + r] = static_cast<int32_t>(e);
+            for (; p < model->jacRows.size() && model->jacRows[p] == r && model->jacCols[p] < nx; ++p)
+                cols[e++] = static_cast<int32_t>(k * nx + model->jacCols[p]);
+            cols[e++] = static_cast<int32_t>((k + 1) * nx + r);
+            for (; p < model->jacRows.size() && model->jacRows[p] == r; ++p)
+                cols[e++] = static_cast<int32_t>((horizon + 1) * nx + k * nu + (model->jacCols[p] - nx));
+        }
+    }
+    row_starts[(horizon + 1) * nx] = static_cast<int32_t>(e);
+    return UNGAR_OK;
+}
+
+int ungar_ocp_assemble_equality(const ungar_model* model, int64_t horizon, int64_t batch, const ungar_operand* x, const ungar_operand* xm,
+                                const ungar_operand* f, const ungar_operand* jac, const ungar_operand* g, const ungar_operand* values,
+                                void* stream) {
+    if (!model || !x || !xm || !f || !jac || !g || !values || horizon < 1 || batch < 0)
+        return Fail(UNGAR_E_INVALID, "ungar_ocp_assemble_equality: bad argument");
+    if (batch == 0) return UNGAR_OK;
+    if (!x->base || !xm->base || !f->base || !jac->base || !g->base || !values->base)
+        return Fail(UNGAR_E_INVALID, "ungar_ocp_assemble_equality: null operand base");
+    const int nx = static_cast<int>(model->info.nx), nn = static_cast<int>(model->info.jac_nnz);
+    if (!model->devPattern) {  // one-time upload of the node pattern (cols + CSR row starts)
+        std::vector<int> host(static_cast<std::size_t>(2 * nn + nx + 1), 0);
+        for (int e = 0; e < nn; ++e) {
+            host[static_cast<std::size_t>(e)] = model->jacRows[static_cast<std::size_t>(e)];
+            host[static_cast<std::size_t>(nn + e)] = model->jacCols[static_cast<std::size_t>(e)];
+            ++host[static_cast<std::size_t>(2 * nn + model->jacRows[static_cast<std::size_t>(e)] + 1)];
+        }
+        for (int r = 0; r < nx; ++r) host[static_cast<std::size_t>(2 * nn + r + 1)] += host[static_cast<std::size_t>(2 * nn + r)];
+        hipError_t e = hipMalloc(&model->devPattern, host.size() * sizeof(int));
+        if (e == hipSuccess) e = hipMemcpy(model->devPattern, host.data(), host.size() * sizeof(int), hipMemcpyHostToDevice);
+        if (e != hipSuccess) return Fail(UNGAR_E_HIP, std::string("ungar_ocp_assemble_equality: ") + hipGetErrorString(e));
+    }
+    ungar_amd::kernels::OcpAssemblyArgs a{x->base, x->instance_stride, x->knot_stride, x->element_stride,
+                                          xm->base, xm->instance_stride, xm->element_stride,
+                                          f->base, f->knot_stride, f->element_stride,
+                                          jac->base, jac->knot_stride, jac->element_stride,
+                                          g->base, g->instance_stride,
+                                          values->base, values->instance_stride,
+                                          model->devPattern, model->devPattern + nn, model->devPattern + 2 * nn,
+                                          nx, static_cast<int>(model->info.nu), static_cast<int>(horizon), nn, batch};
+    const int err = ungar_amd_launch_ocp_assemble(&a, stream);
+    if (err != 0) return Fail(UNGAR_E_HIP, std::string("ocp assembly launch failed: ") + hipGetErrorString(static_cast<hipError_t>(err)));
     return UNGAR_OK;
 }
 
