@@ -195,7 +195,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.workload} shooting-node value + dense [A|B] Jacobian, nx={nx} nu={nu}, N={N}, batch={batch}/GPU "
                                    f"({count} nodes/GPU/step), unit-fastest (SoA) device layout",
-                       "model": None, "horizon": N, "batch_per_gpu": batch, "nodes_per_step": count * world,
+                       "horizon": N, "batch_per_gpu": batch, "nodes_per_step": count * world, "kernel_variant": kernel_model,
                        "parallelism": f"batch-sharded x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel_ms": kernel_ms, "algorithmic_bytes_per_eval": bytes_per_eval,

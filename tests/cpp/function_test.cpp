@@ -3,6 +3,7 @@
 // Hessian :111-142: closed-form ground truths at :81-89 and :131) and then records the quadrotor
 // shooting-node function through the variable-map API exactly the way a user model lambda does,
 // printing value and dense Jacobian for the Python side to compare with the oracle.
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <random>
@@ -187,6 +188,14 @@ static void QuadrotorNodeThroughFacade(const std::string& folder) {
     const auto real = Utils::ToRealFunction(dynamics);  // A13: the same lambda run on doubles
     const VectorXr yReal = real(VectorXr{in.head(13)}, VectorXr{in.segment(13, 4)}, VectorXr{in.tail(20)});
     for (index_t i = 0; i < 13; ++i) EXPECT_TRUE(std::fabs(yReal[i] - y[i]) < 1e-12);
+    {   // PCIe-inclusive latency of the single-instance host path (H2D + batch-1 launch + D2H + sync)
+        const auto t0 = std::chrono::steady_clock::now();
+        const int reps = 2000;
+        real_t acc = 0;
+        for (int i = 0; i < reps; ++i) acc += f.Jacobian(in).valuePtr()[0];
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / reps;
+        std::printf("HOST_CALL_LATENCY_US %.2f (Function::Jacobian, quadrotor node, 37 inputs -> 118 values; checksum %.3g)\n", us, acc);
+    }
     std::printf("QUADROTOR_IN");
     for (index_t i = 0; i < in.size(); ++i) std::printf(" %.17g", in[i]);
     std::printf("\nQUADROTOR_F");
