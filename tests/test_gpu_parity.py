@@ -222,6 +222,30 @@ def test_structured_and_taped_aba_kernels_agree_at_full_size(ua):
         assert ((J0 - J1).abs() / scale).max().item() < 1e-9
 
 
+def test_anymal_trajectory_layout_with_knots(ua):
+    """Per-instance VariableMap-style buffers [X | U] (instance / knot strides, knots > 1) through the
+    lane-per-leg kernel, against the oracle; ragged node count (not a multiple of 16 nodes per wavefront)."""
+    import torch
+    N, batch = 5, 7
+    count = N * batch
+    x, u, w, p = O.synthetic_inputs("anymal", count, seed=77)
+    rf, rJ = O.node_jacobian("anymal", x, u, w, p)
+    dev = torch.device("cuda")
+    # instance-major trajectory block: (N+1) states (the last one unused by the nodes) then N inputs
+    traj = torch.zeros((batch, (N + 1) * 37 + N * 12), dtype=torch.float64, device=dev)
+    traj[:, :N * 37] = torch.as_tensor(x, device=dev).reshape(batch, N * 37)
+    traj[:, (N + 1) * 37:] = torch.as_tensor(u, device=dev).reshape(batch, N * 12)
+    stride = traj.shape[1]
+    f = torch.full((count, 37), float("nan"), dtype=torch.float64, device=dev)
+    J = torch.full((count, 37 * 49), float("nan"), dtype=torch.float64, device=dev)
+    pd = torch.as_tensor(p[0], device=dev)
+    m = ua.NodeModel("anymal")
+    m.dense_jacobian(count, ua.Operand(traj, stride, 37, 1), ua.Operand(traj[:, (N + 1) * 37:], stride, 12, 1), None,
+                     ua.Operand.per_instance(pd, 1, shared=True), ua.Operand.aos(f, 37, N), ua.Operand.aos(J, 37 * 49, N), knots=N)
+    torch.cuda.synchronize()
+    _assert_close("anymal", f.cpu().numpy(), J.cpu().numpy().reshape(count, 37, 49), rf, rJ)
+
+
 def test_gn_hessian_mfma(ua):
     """J^T diag(d) J on the FP64 matrix cores vs torch (rows=37, cols=49 is the ANYmal block; also a
     ragged small case and the identity-weight path)."""

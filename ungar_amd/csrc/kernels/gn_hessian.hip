@@ -34,22 +34,32 @@ __global__ __launch_bounds__(256) void GnHessianKernel(const double* __restrict_
 #pragma unroll
         for (int b = 0; b < T; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
 
+    // The node's block is consumed in chunks of KC k-steps (KC * 4 rows): all loads of a chunk are issued
+    // before its first MFMA, so that up to KC * T independent 128-byte row segments are in flight per
+    // lane group instead of T (one wavefront per node has nothing else to hide HBM latency with).
+    constexpr int KC = 5;   // rows beyond `rows` are loaded as zeros: padded k-steps are harmless
     const int ksteps = (rows + 3) >> 2;
-    for (int ks = 0; ks < ksteps; ++ks) {
-        const int r = 4 * ks + lk;
-        const bool rowOk = r < rows;
-        const double w = rowOk ? (D ? D[r] : 1.0) : 0.0;
-        double jv[T];
+    for (int k0 = 0; k0 < ksteps; k0 += KC) {
+        double jv[KC][T], wv[KC];
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
-            const int c = 16 * t + lc;
-            jv[t] = (rowOk && c < cols) ? J[static_cast<long long>(r) * ldj + c] : 0.0;
+        for (int kk = 0; kk < KC; ++kk) {
+            const int r = 4 * (k0 + kk) + lk;
+            const bool rowOk = r < rows;
+            wv[kk] = rowOk ? (D ? D[r] : 1.0) : 0.0;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const int c = 16 * t + lc;
+                jv[kk][t] = (rowOk && c < cols) ? J[static_cast<long long>(r) * ldj + c] : 0.0;
+            }
         }
 #pragma unroll
-        for (int a = 0; a < T; ++a) {
-            const double av = jv[a] * w;
+        for (int kk = 0; kk < KC; ++kk) {
 #pragma unroll
-            for (int b = 0; b < T; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, jv[b], acc[a][b], 0, 0, 0);
+            for (int a = 0; a < T; ++a) {
+                const double av = jv[kk][a] * wv[kk];
+#pragma unroll
+                for (int b = 0; b < T; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, jv[kk][b], acc[a][b], 0, 0, 0);
+            }
         }
     }
 
