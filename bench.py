@@ -114,6 +114,8 @@ def main():
     ap.add_argument("--batch-per-gpu", type=int, default=None)
     ap.add_argument("--model", default=None, help="kernel variant of the workload's model (e.g. anymal_ad, anymal_lds)")
     ap.add_argument("--layout", default="soa", choices=["soa"])
+    ap.add_argument("--jacobian", default="dense", choices=["dense", "sparse"],
+                    help="dense [A|B] block (BASELINE metric, default) or the CSR value array of Function::Jacobian (function.hpp:216-230)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -140,14 +142,16 @@ def main():
     nx, nu, ncols = m.nx, m.nu, m.nx + m.nu
     x, u, w, p = synth_device_inputs(model_name, count, seed=rank, torch=torch)
     f = torch.empty((nx, count), dtype=torch.float64, device="cuda")
-    J = torch.empty((nx * ncols, count), dtype=torch.float64, device="cuda")
+    nnz = len(m.jacobian_sparsity()[0])
+    jac_len = nx * ncols if args.jacobian == "dense" else nnz
+    J = torch.empty((jac_len, count), dtype=torch.float64, device="cuda")
     Op = ungar_amd.Operand
     ops = (count, Op.soa(x, count, N), Op.soa(u, count, N), None if w is None else Op.soa(w, count, N), Op.per_instance(p, m.np, shared=True),
            Op.soa(f, count, N), Op.soa(J, count, N))
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
-        m.dense_jacobian(*ops, knots=N, stream=stream)
+        (m.dense_jacobian if args.jacobian == "dense" else m.sparse_jacobian)(*ops, knots=N, stream=stream)
 
     def fence():
         torch.cuda.synchronize()
@@ -173,13 +177,13 @@ def main():
     assert torch.isfinite(f).all() and torch.isfinite(J).all()
 
     if rank == 0:
-        bytes_per_eval = algorithmic_bytes(nx, nu)
+        bytes_per_eval = algorithmic_bytes(nx, nu) if args.jacobian == "dense" else 8 * ((nx + nu) + nx + nnz)
         achieved = count * bytes_per_eval / (kernel_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as fh:
-                traffic = json.load(fh).get(f"{args.workload}:{batch}")
+                traffic = json.load(fh).get(f"{args.workload}:{batch}") if args.jacobian == "dense" else None
         out = {
             "metric": "shooting-node Jacobian evals/sec",
             "value": total_evals / elapsed,
@@ -193,13 +197,13 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"{args.workload} shooting-node value + dense [A|B] Jacobian, nx={nx} nu={nu}, N={N}, batch={batch}/GPU "
+            "config": {"workload": f"{args.workload} shooting-node value + {'dense [A|B]' if args.jacobian == 'dense' else f'sparse (nnz={nnz})'} Jacobian, nx={nx} nu={nu}, N={N}, batch={batch}/GPU "
                                    f"({count} nodes/GPU/step), unit-fastest (SoA) device layout",
                        "horizon": N, "batch_per_gpu": batch, "nodes_per_step": count * world, "kernel_variant": kernel_model,
                        "parallelism": f"batch-sharded x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel_ms": kernel_ms, "algorithmic_bytes_per_eval": bytes_per_eval,
-                         "kernel": f"NodeKernel<{kernel_model}, dense Jacobian>"},
+                         "kernel": f"NodeKernel<{kernel_model}, {args.jacobian} Jacobian>"},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(model_name, args.cpu_seconds)

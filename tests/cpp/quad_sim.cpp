@@ -63,20 +63,36 @@ struct SimIO {
     Quad quad_rot3(const Quad& a) const { return rot(a, 3); }
     void f_base(int row, const Quad& v) const { f[row] = v.v[row & 3]; }
     void f_leg(int rowBase, const Quad& v) const { for (int l = 0; l < 4; ++l) f[rowBase + 3 * l] = v.v[l]; }
-    void j_leg(int rowBase, int colBase, int legMul, int rot_, const Quad& v) const {
-        for (int l = 0; l < 4; ++l) J[(rowBase + 3 * l) * 49 + colBase + 3 * legMul * ((l + rot_) & 3)] = v.v[l];
+    // every sink carries both addressings: dense (row, col) and the CSR index k per lane (-1 = structural zero)
+    double* Jsparse = nullptr;
+    void put(int l, int r, int c, int k, double v) const {
+        J[r * 49 + c] = v;
+        if (Jsparse && k >= 0) Jsparse[k] = v;
     }
-    void j_base_own(int row, int colBase, int legMul, int, const Quad& v) const {
-        for (int l = 0; l < 4; ++l) J[row * 49 + colBase + 3 * legMul * l] = v.v[l];
+    void j_leg(int rowBase, int colBase, int legMul, int rot_, int k0, int k1, int k2, int k3, const Quad& v) const {
+        const int ks[4] = {k0, k1, k2, k3};
+        for (int l = 0; l < 4; ++l) put(l, rowBase + 3 * l, colBase + 3 * legMul * ((l + rot_) & 3), ks[l], v.v[l]);
     }
-    void j_base_shared(int row, int colBase, int, int, const Quad& v) const { J[row * 49 + colBase] = v.v[(row + colBase) & 3]; }
+    void j_base_own(int row, int colBase, int legMul, int, int k0, int k1, int k2, int k3, const Quad& v) const {
+        const int ks[4] = {k0, k1, k2, k3};
+        for (int l = 0; l < 4; ++l) put(l, row, colBase + 3 * legMul * l, ks[l], v.v[l]);
+    }
+    void j_base_shared(int row, int colBase, int, int, int k0, int, int, int, const Quad& v) const { put(0, row, colBase, k0, v.v[(row + colBase) & 3]); }
 };
 
 }  // namespace
 
+extern "C" void anymal_quad_sim_sparse(const double* x, const double* u, const double* p, double* f, double* J, double* Jsparse, int nnz);
+
 extern "C" void anymal_quad_sim(const double* x, const double* u, const double* p, double* f, double* J) {
+    anymal_quad_sim_sparse(x, u, p, f, J, nullptr, 0);
+}
+
+extern "C" void anymal_quad_sim_sparse(const double* x, const double* u, const double* p, double* f, double* J, double* Jsparse, int nnz) {
     for (int i = 0; i < 37; ++i) f[i] = NAN;
     for (int i = 0; i < 37 * 49; ++i) J[i] = NAN;  // every entry must be written by the program
+    for (int i = 0; i < nnz; ++i) Jsparse[i] = NAN;
     SimIO io{x, u, p, f, J};
+    io.Jsparse = Jsparse;
     ungar_amd::gen::anymal_quad::ValueJacobianQuad<Quad>(io);
 }

@@ -34,3 +34,23 @@ def test_quad_program_matches_golden(repo_root, sim):
         assert not np.isnan(f).any() and not np.isnan(J).any(), "every entry of f and of the dense block must be written by some lane"
         assert np.abs(f - g["f"][b]).max() <= 1e-11 * max(1.0, np.abs(g["f"][b]).max())
         assert np.abs(J - g["J"][b]).max() <= 1e-10 * np.abs(g["J"][b]).max()
+
+
+def test_quad_program_sparse_addressing(repo_root, sim):
+    """Every Jacobian sink also carries its CSR index per lane; the values collected that way must be the
+    dense block gathered through the committed sparsity pattern, with every pattern entry written."""
+    import ungar_amd
+    g = np.load(f"{repo_root}/tests/golden/node_anymal.npz")
+    rows, cols = (a.astype(int) for a in ungar_amd.NodeModel("anymal").jacobian_sparsity())  # host-side table of the C ABI (no GPU needed)
+    nnz = cols.size
+    dp = ctypes.POINTER(ctypes.c_double)
+    for b in range(min(4, g["x"].shape[0])):
+        x, u, p = (np.ascontiguousarray(g[k][b]) for k in ("x", "u", "p"))
+        f, J, Js = np.zeros(37), np.zeros((37, 49)), np.zeros(nnz)
+        sim.anymal_quad_sim_sparse(x.ctypes.data_as(dp), u.ctypes.data_as(dp), p.ctypes.data_as(dp), f.ctypes.data_as(dp), J.ctypes.data_as(dp),
+                                   Js.ctypes.data_as(dp), ctypes.c_int(nnz))
+        assert not np.isnan(Js).any(), "a pattern entry was never written"
+        assert np.array_equal(Js, J[rows, cols])
+        mask = np.zeros((37, 49), dtype=bool)
+        mask[rows, cols] = True
+        assert np.all(J[~mask] == 0.0), "entries outside the pattern must be structural zeros"

@@ -72,14 +72,18 @@ def build_library(jobs: int | None = None):
     os.makedirs(BUILD, exist_ok=True)
     kernel_hdr = os.path.join(CSRC, "kernels", "node_kernel.hpp")
     abi_hdr = os.path.join(ROOT, "include", "ungar_amd.h")
+    quad_deps = [os.path.join(CSRC, "kernels", "quad_kernel.hpp"), os.path.join(GEN, "anymal_quad_gen.hpp")]
     units = []  # (source, object, dependencies)
     for m in MODELS:
         src = os.path.join(CSRC, "kernels", f"model_{m}.hip")
-        units.append((src, os.path.join(BUILD, f"model_{m}.o"), [src, kernel_hdr, os.path.join(GEN, f"{m}_gen.hpp")]))
+        deps = [src, kernel_hdr, os.path.join(GEN, f"{m}_gen.hpp")]
+        if m == "anymal":
+            deps += quad_deps
+        units.append((src, os.path.join(BUILD, f"model_{m}.o"), deps))
     for name in sorted(os.listdir(os.path.join(CSRC, "kernels"))):
         if name.endswith(".hip") and not name.startswith("model_"):
             src = os.path.join(CSRC, "kernels", name)
-            units.append((src, os.path.join(BUILD, name[:-4] + ".o"), [src, kernel_hdr]))
+            units.append((src, os.path.join(BUILD, name[:-4] + ".o"), [src, kernel_hdr] + (quad_deps if name.startswith("quad_") else [])))
     src = os.path.join(CSRC, "runtime", "c_api.cpp")
     units.append((src, os.path.join(BUILD, "c_api.o"), [src, kernel_hdr, abi_hdr]))
     src = os.path.join(CSRC, "runtime", "function.cpp")

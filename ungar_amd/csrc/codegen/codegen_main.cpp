@@ -446,7 +446,7 @@ int main(int argc, char** argv) {
                 EmitHip(st, outDir, true, 0);
             }
             if (wanted("anymal")) {  // lane-per-leg SPMD program (dense Jacobian path of the 'anymal' model)
-                const codegen::QuadProgram qp = codegen::RecordQuadLegProgram(anymal, quadColumnsPerPhase);
+                const codegen::QuadProgram qp = codegen::RecordQuadLegProgram(anymal, adv.jac, quadColumnsPerPhase);
                 tape::EmitStats qs;
                 int quadLds = 0;
                 const std::string fn = codegen::EmitQuadProgram(qp, "ValueJacobianQuad", &qs, true, quadLdsSlots, &quadLds, quadRematConsumers, quadRematDepth, prefetch);
@@ -465,7 +465,7 @@ int main(int argc, char** argv) {
                     std::snprintf(buf, sizeof buf, "    {%.17g, %.17g, %.17g, %.17g},\n", c[0], c[1], c[2], c[3]);
                     qo << buf;
                 }
-                qo << "};\n#ifdef __HIPCC__\n// device copy of the table (indexed by the lane's leg at run time)\n__device__ __constant__ double kLegConstantsDev["
+                qo << "};\n#ifdef __HIPCC__\n// device copy of the table (indexed by the lane's leg at run time; one per translation unit)\nstatic __device__ __constant__ double kLegConstantsDev["
                    << std::max<std::size_t>(1, qp.constants.size()) << "][4] = {\n";
                 for (const auto& c : qp.constants) {
                     char buf[256];

@@ -52,7 +52,7 @@ inline bool IsZeroLit(const AD& a) {
 }  // namespace detail
 
 /// Records the leg-lane program for a free-flyer + 4 x (3 revolute) robot.
-inline QuadProgram RecordQuadLegProgram(const rbd::Model& model, int columnsPerPhase = 1) {
+inline QuadProgram RecordQuadLegProgram(const rbd::Model& model, const tape::SparseEntries& pattern, int columnsPerPhase = 1) {
     using namespace rbd;
     using namespace rbd::detail;
     if (model.NumJoints() != 14 || model.nq != 19 || model.nv != 18) throw std::runtime_error("quad program: expected a free-flyer with 12 revolute joints");
@@ -69,6 +69,17 @@ inline QuadProgram RecordQuadLegProgram(const rbd::Model& model, int columnsPerP
         }
 
     QuadProgram P;
+    // CSR index of (row, col) in the node's sparse pattern, -1 for structural zeros (sparse output mode)
+    std::vector<int> kOf(static_cast<std::size_t>(37 * 49), -1);
+    for (std::size_t e = 0; e < pattern.Nnz(); ++e) kOf[static_cast<std::size_t>(pattern.row[e] * 49 + pattern.col[e])] = static_cast<int>(e);
+    auto kArgs = [&](int rowBase, int rowLegMul, int colBase, int colLegMul, int rot) {
+        std::string s;
+        for (int L = 0; L < 4; ++L) {
+            const int r = rowBase + 3 * rowLegMul * L, c = colBase + 3 * colLegMul * ((L + rot) & 3);
+            s += (L ? ", " : "") + std::to_string(kOf[static_cast<std::size_t>(r * 49 + c)]);
+        }
+        return s;
+    };
     // ---- inputs --------------------------------------------------------------------------------------------
     // [0,7) q_b  [7,13) v_b  [13,16) q_L  [16,19) v_L  [19,22) u_L  [22] dt  [23, 23+K) constants  then 9 aux
     constexpr int kQb = 0, kVb = 7, kQl = 13, kVl = 16, kUl = 19, kDt = 22, kConst = 23;
@@ -380,8 +391,16 @@ inline QuadProgram RecordQuadLegProgram(const rbd::Model& model, int columnsPerP
     ///   yb, yl: base / own-leg rows of da/dz for the column;  ownKind: this lane owns the column
     ///   colExpr: how the column index is spelled; baseRows: emit the 13 base rows too
     int columnCounter = 0;
-    auto emitColumn = [&](int gLocal, const std::vector<AD>& yb, const std::array<AD, 3>& yl, const std::string& colArgs, bool baseRows,
+    auto emitColumn = [&](int gLocal, const std::vector<AD>& yb, const std::array<AD, 3>& yl, int colBase, int colLegMul, int rot, bool baseRows,
                           bool sharedColumn) {
+        const std::string colArgs = std::to_string(colBase) + ", " + std::to_string(colLegMul) + ", " + std::to_string(rot);
+        auto checkZero = [&](const AD& v, int rowBase, int rowLegMul) {  // an entry outside the pattern must be a literal zero
+            for (int L = 0; L < 4; ++L) {
+                const int r = rowBase + 3 * rowLegMul * L, c = colBase + 3 * colLegMul * ((L + rot) & 3);
+                if (kOf[static_cast<std::size_t>(r * 49 + c)] < 0 && !(v.IsLiteral() && v.Literal() == 0.0))
+                    throw std::runtime_error("quad program: non-zero entry outside the sparsity pattern at (" + std::to_string(r) + "," + std::to_string(c) + ")");
+            }
+        };
         if (baseRows && (columnCounter++ % columnsPerPhase) == 0) P.phaseStarts.push_back(P.slots.size());  // a column + its rotated copies
         auto entry = [&](int gr) {  // integrator row gr (0..18) of this column
             AD v = gLocal >= 0 ? Gm[gr][gLocal] : AD{0.0};
@@ -390,11 +409,19 @@ inline QuadProgram RecordQuadLegProgram(const rbd::Model& model, int columnsPerP
             return v;
         };
         if (baseRows)
-            for (int i = 0; i < 13; ++i)
-                P.slots.push_back({entry(i).Node(), std::string(sharedColumn ? "io.j_base_shared(" : "io.j_base_own(") + std::to_string(baseRowIndex(i)) + ", " +
-                                                        colArgs + ", %s);"});
-        for (int k = 0; k < 3; ++k) P.slots.push_back({entry(13 + k).Node(), "io.j_leg(" + std::to_string(7 + k) + ", " + colArgs + ", %s);"});
-        for (int k = 0; k < 3; ++k) P.slots.push_back({entry(16 + k).Node(), "io.j_leg(" + std::to_string(25 + k) + ", " + colArgs + ", %s);"});
+            for (int i = 0; i < 13; ++i) {
+                const AD v = entry(i);
+                checkZero(v, baseRowIndex(i), 0);
+                P.slots.push_back({v.Node(), std::string(sharedColumn ? "io.j_base_shared(" : "io.j_base_own(") + std::to_string(baseRowIndex(i)) + ", " + colArgs +
+                                                 ", " + kArgs(baseRowIndex(i), 0, colBase, colLegMul, rot) + ", %s);"});
+            }
+        for (int half = 0; half < 2; ++half)
+            for (int k = 0; k < 3; ++k) {
+                const int rowBase = (half ? 25 : 7) + k;
+                const AD v = entry(13 + 3 * half + k);
+                checkZero(v, rowBase, 1);
+                P.slots.push_back({v.Node(), "io.j_leg(" + std::to_string(rowBase) + ", " + colArgs + ", " + kArgs(rowBase, 1, colBase, colLegMul, rot) + ", %s);"});
+            }
     };
     const std::vector<AD> zero6(6, AD{0.0});
     const std::array<AD, 3> zero3{AD{0.0}, AD{0.0}, AD{0.0}};
@@ -414,12 +441,12 @@ inline QuadProgram RecordQuadLegProgram(const rbd::Model& model, int columnsPerP
             const Sol s = solve(rb, rl, false);
             const int colBase = (kind == 0 ? 7 : kind == 1 ? 25 : 37) + k;
             const int gLocal = kind == 0 ? 13 + k : kind == 1 ? 16 + k : -1;
-            emitColumn(gLocal, s.yb, s.yl, std::to_string(colBase) + ", 1, 0", true, false);
+            emitColumn(gLocal, s.yb, s.yl, colBase, 1, 0, true, false);
             // the other three legs' versions of this column: their y_b arrives by rotation, only leg rows are ours
             for (int rot = 1; rot < 4; ++rot) {
                 std::vector<AD> ybr(6);
                 for (std::size_t r = 0; r < 6; ++r) ybr[r] = tape::QuadRot(s.yb[r], rot);
-                emitColumn(-1, ybr, foreignRows(ybr), std::to_string(colBase) + ", 1, " + std::to_string(rot), false, false);
+                emitColumn(-1, ybr, foreignRows(ybr), colBase, 1, rot, false, false);
             }
         }
     // ---- shared columns: base twist (via D, summed over legs), quaternion (closed form), position (none) -------------------------
@@ -428,14 +455,14 @@ inline QuadProgram RecordQuadLegProgram(const rbd::Model& model, int columnsPerP
         std::vector<AD> rb(6);
         for (int r = 0; r < 6; ++r) rb[static_cast<std::size_t>(r)] = -(tape::QuadSum(Dm[3 + r][dc]) + Dm[9 + r][dc]);
         const Sol s = solve(rb, {-Dm[0][dc], -Dm[1][dc], -Dm[2][dc]}, true);
-        emitColumn(7 + k, s.yb, s.yl, std::to_string(19 + k) + ", 0, 0", true, true);
+        emitColumn(7 + k, s.yb, s.yl, 19 + k, 0, 0, true, true);
     }
     for (int k = 0; k < 4; ++k) {
         std::vector<AD> yb(6, AD{0.0});
         for (int r = 0; r < 3; ++r) yb[static_cast<std::size_t>(r)] = -dGam[r][k];
-        emitColumn(3 + k, yb, zero3, std::to_string(3 + k) + ", 0, 0", true, true);
+        emitColumn(3 + k, yb, zero3, 3 + k, 0, 0, true, true);
     }
-    for (int k = 0; k < 3; ++k) emitColumn(k, zero6, zero3, std::to_string(k) + ", 0, 0", true, true);
+    for (int k = 0; k < 3; ++k) emitColumn(k, zero6, zero3, k, 0, 0, true, true);
 
     // ---- package ---------------------------------------------------------------------------------------------------------------------
     std::vector<AD> roots;

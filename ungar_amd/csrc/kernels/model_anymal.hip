@@ -1,7 +1,9 @@
 // ungar_amd :: kernels for the built-in 'anymal' (ANYmal B full-body) shooting-node model.
 //   dense [A|B] block  -> lane-per-leg SPMD program (quad_kernel.hpp), 4 wavefronts / CU
-//   sparse CSR values  -> structured implicit differentiation, phased body with an LDS home (§4.3-4.4)
+//   sparse CSR values  -> the same program, CSR addressing (quad_anymal_sparse.hip)
 //   value only         -> plain lane-per-node body
+//   operands beyond 32-bit element offsets -> structured implicit differentiation, lane-per-node phased
+//                         body with an LDS home (§4.3-4.4)
 #include "../gen/anymal_gen.hpp"
 #include "../gen/anymal_quad_gen.hpp"
 #include "quad_kernel.hpp"
@@ -10,15 +12,18 @@ UNGAR_AMD_DEFINE_NODE_TRAITS(anymal)
 
 namespace ungar_amd::kernels {
 struct AnymalQuadBody {
-    __device__ __forceinline__ void operator()(QuadIO& io) const { gen::anymal_quad::ValueJacobianQuad<double>(io); }
+    __device__ __forceinline__ void operator()(QuadIO<false>& io) const { gen::anymal_quad::ValueJacobianQuad<double>(io); }
 };
 }  // namespace ungar_amd::kernels
+
+extern "C" int ungar_amd_launch_anymal_quad_sparse(const ungar_amd::kernels::NodeLaunch* a, void* stream);  // quad_anymal_sparse.hip
 
 extern "C" int ungar_amd_launch_anymal(int mode, const ungar_amd::kernels::NodeLaunch* a, void* stream) {
     using namespace ungar_amd::kernels;
     // the quad kernel addresses the dense block with wave-uniform 32-bit element offsets (< 1813 * stride);
     // operands too large for that go through the lane-per-node kernel (64-bit addressing)
-    const bool quadOk = mode == kModeDenseJacobian && a->jac.es >= 0 && a->jac.es * 1813LL < (1LL << 32);
+    const bool quadOk = (mode == kModeDenseJacobian || mode == kModeSparseJacobian) && a->jac.es >= 0 && a->jac.es * 1813LL < (1LL << 32);
+    if (quadOk && mode == kModeSparseJacobian) return ungar_amd_launch_anymal_quad_sparse(a, stream);
     if (!quadOk) return static_cast<int>(LaunchNodeModel<Model_anymal, 64>(mode, *a, static_cast<hipStream_t>(stream)));
     if (a->count <= 0) return 0;
     constexpr int kBlock = 64;
@@ -27,7 +32,7 @@ extern "C" int ungar_amd_launch_anymal(int mode, const ungar_amd::kernels::NodeL
     if (e != hipSuccess) return static_cast<int>(e);
     const double(*ctab)[4] = static_cast<const double(*)[4]>(sym);
     const dim3 grid(static_cast<unsigned>((a->count + kBlock / 4 - 1) / (kBlock / 4))), block(kBlock);
-    hipLaunchKernelGGL((QuadNodeKernel<kBlock, ungar_amd::gen::anymal_quad::kLdsSlots, AnymalQuadBody>), grid, block, 0, static_cast<hipStream_t>(stream), *a, ctab,
+    hipLaunchKernelGGL((QuadNodeKernel<kBlock, ungar_amd::gen::anymal_quad::kLdsSlots, false, AnymalQuadBody>), grid, block, 0, static_cast<hipStream_t>(stream), *a, ctab,
                        AnymalQuadBody{});
     return static_cast<int>(hipGetLastError());
 }

@@ -24,7 +24,10 @@ __device__ __forceinline__ double QuadPerm(double v) {
 }
 
 /// I/O policy of gen::anymal_quad::ValueJacobianQuad<double>: node-level operands through strides,
-/// leg-dependent rows/columns through per-lane offsets computed once.
+/// leg-dependent rows/columns through per-lane offsets computed once.  Every Jacobian sink of the
+/// generated program carries both addressings -- (row, column) of the dense block and, per lane, the
+/// index k of the entry in the CSR value array (-1 = structural zero); SPARSE picks the second.
+template <bool SPARSE>
 struct QuadIO {
     const double* __restrict__ xb;  // node's x (element stride xe)
     const double* __restrict__ ub;
@@ -75,19 +78,37 @@ struct QuadIO {
     __device__ __forceinline__ void f_leg(int rowBase, double v) const {
         if (fb) fLeg[rowBase * fe] = v;
     }
-    __device__ __forceinline__ void j_leg(int rowBase, int colBase, int legMul, int rot, double v) const {
-        (legMul ? jLegCol[rot] : jLeg)[static_cast<unsigned>(rowBase * 49 + colBase) * je] = v;
+    __device__ __forceinline__ void j_sparse(int k0, int k1, int k2, int k3, double v) const {
+        if (k0 < 0 && k1 < 0 && k2 < 0 && k3 < 0) return;  // literal arguments: folds away at compile time
+        const int k = L == 0 ? k0 : L == 1 ? k1 : L == 2 ? k2 : k3;
+        if (k0 >= 0 && k1 >= 0 && k2 >= 0 && k3 >= 0)
+            jb[static_cast<unsigned>(k) * je] = v;
+        else if (k >= 0)
+            jb[static_cast<unsigned>(k) * je] = v;
     }
-    __device__ __forceinline__ void j_base_own(int row, int colBase, int /*legMul*/, int /*rot*/, double v) const {
-        jOwnCol[static_cast<unsigned>(row * 49 + colBase) * je] = v;
+    __device__ __forceinline__ void j_leg(int rowBase, int colBase, int legMul, int rot, int k0, int k1, int k2, int k3, double v) const {
+        if constexpr (SPARSE)
+            j_sparse(k0, k1, k2, k3, v);
+        else
+            (legMul ? jLegCol[rot] : jLeg)[static_cast<unsigned>(rowBase * 49 + colBase) * je] = v;
     }
-    __device__ __forceinline__ void j_base_shared(int row, int colBase, int, int, double v) const {
-        jb[static_cast<unsigned>(row * 49 + colBase) * je] = v;
+    __device__ __forceinline__ void j_base_own(int row, int colBase, int /*legMul*/, int /*rot*/, int k0, int k1, int k2, int k3, double v) const {
+        if constexpr (SPARSE)
+            j_sparse(k0, k1, k2, k3, v);
+        else
+            jOwnCol[static_cast<unsigned>(row * 49 + colBase) * je] = v;
+    }
+    __device__ __forceinline__ void j_base_shared(int row, int colBase, int, int, int k0, int, int, int, double v) const {
+        if constexpr (SPARSE) {
+            if (k0 >= 0) jb[static_cast<unsigned>(k0) * je] = v;
+        } else {
+            jb[static_cast<unsigned>(row * 49 + colBase) * je] = v;
+        }
     }
 };
 
 /// GEN is the generated namespace (ValueJacobianQuad, kLegConstantsDev).  BLOCK lanes = BLOCK/4 nodes.
-template <int BLOCK, int LDS_SLOTS, class Body>
+template <int BLOCK, int LDS_SLOTS, bool SPARSE, class Body>
 __global__ __launch_bounds__(BLOCK) void QuadNodeKernel(const NodeLaunch a, const double (*ctab)[4], Body body) {
     static_assert(BLOCK == 64, "the LDS home is laid out for one wavefront per workgroup");
     __shared__ double lds[(LDS_SLOTS > 0 ? LDS_SLOTS : 1) * BLOCK];
@@ -103,7 +124,7 @@ __global__ __launch_bounds__(BLOCK) void QuadNodeKernel(const NodeLaunch a, cons
     double* const jb = a.jac.base + b * a.jac.bs + k * a.jac.ks;
     const long long je = a.jac.es;
     double* const jLeg = jb + 3LL * L * 49 * je;
-    QuadIO io{a.x.base + b * a.x.bs + k * a.x.ks,
+    QuadIO<SPARSE> io{a.x.base + b * a.x.bs + k * a.x.ks,
               a.u.base + b * a.u.bs + k * a.u.ks,
               a.p.base + b * a.p.bs + k * a.p.ks,
               fb,
