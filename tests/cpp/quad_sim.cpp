@@ -55,6 +55,11 @@ struct SimIO {
     mutable Quad slots[512];
     Quad ld(int s) const { return slots[s]; }
     void st(int s, const Quad& v) const { slots[s] = v; }
+    // compact slots hold ONE copy per quad: only legal for values identical in the four lanes -- a value
+    // that is not poisons everything downstream, so the golden-vector test catches a wrong uniformity analysis
+    mutable double uslots[512];
+    Quad ldu(int s) const { return Quad{uslots[s]}; }
+    void stu(int s, const Quad& v) const { uslots[s] = (v.v[0] == v.v[1] && v.v[1] == v.v[2] && v.v[2] == v.v[3]) ? v.v[0] : NAN; }
     Quad c(int k) const { Quad r; for (int l = 0; l < 4; ++l) r.v[l] = ungar_amd::gen::anymal_quad::kLegConstants[k][l]; return r; }
     Quad quad_sum(const Quad& a) const { return Quad{a.v[0] + a.v[1] + a.v[2] + a.v[3]}; }
     Quad rot(const Quad& a, int r) const { Quad o; for (int l = 0; l < 4; ++l) o.v[l] = a.v[(l + r) & 3]; return o; }

@@ -371,7 +371,8 @@ int main(int argc, char** argv) {
     int jacMode = 0, structuredDMode = 1, ldsSlots = 320;
     int rematConsumers = 2, rematDepth = 3, prefetch = 48;
     int quadColumnsPerPhase = 1, quadRematConsumers = 4, quadRematDepth = 4;  // tools/sweep_quad.sh on MI355X
-    int quadLdsSlots = 80;  // 64-lane workgroups, four per CU: 160 KiB / 4 / 64 lanes / 8 B
+    int quadUniformSlots = 80;  // compact (one copy per quad) LDS slots; budget: quadLdsSlots + quadUniformSlots / 4 <= 80
+    int quadLdsSlots = 60;  // 64-lane workgroups, four per CU: 160 KiB / 4 / 64 lanes / 8 B
     std::vector<std::string> only;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
@@ -385,6 +386,7 @@ int main(int argc, char** argv) {
         else if (a == "--remat-depth" && i + 1 < argc) rematDepth = std::atoi(argv[++i]);
         else if (a == "--prefetch" && i + 1 < argc) prefetch = std::atoi(argv[++i]);
         else if (a == "--quad-lds-slots" && i + 1 < argc) quadLdsSlots = std::atoi(argv[++i]);
+        else if (a == "--quad-uniform-slots" && i + 1 < argc) quadUniformSlots = std::atoi(argv[++i]);
         else if (a == "--quad-columns-per-phase" && i + 1 < argc) quadColumnsPerPhase = std::atoi(argv[++i]);
         else if (a == "--quad-remat" && i + 2 < argc) {
             quadRematConsumers = std::atoi(argv[++i]);
@@ -448,8 +450,9 @@ int main(int argc, char** argv) {
             if (wanted("anymal")) {  // lane-per-leg SPMD program (dense Jacobian path of the 'anymal' model)
                 const codegen::QuadProgram qp = codegen::RecordQuadLegProgram(anymal, adv.jac, quadColumnsPerPhase);
                 tape::EmitStats qs;
-                int quadLds = 0;
-                const std::string fn = codegen::EmitQuadProgram(qp, "ValueJacobianQuad", &qs, true, quadLdsSlots, &quadLds, quadRematConsumers, quadRematDepth, prefetch);
+                int quadLds = 0, quadUniformUsed = 0;
+                const std::string fn = codegen::EmitQuadProgram(qp, "ValueJacobianQuad", &qs, true, quadLdsSlots, &quadLds, quadRematConsumers, quadRematDepth, prefetch,
+                                                                   quadUniformSlots, &quadUniformUsed);
                 std::ostringstream qo;
                 qo << "// GENERATED by ungar_amd/csrc/codegen (quad_leg_program.hpp) -- do not edit.\n"
                    << "// ANYmal B shooting node, one lane per leg: " << qs.statements << " statements, " << qs.flops << " flops, "
@@ -458,6 +461,7 @@ int main(int argc, char** argv) {
                    << "namespace ungar_amd::gen::anymal_quad {\n\n"
                    << "inline constexpr int kNumConstants = " << qp.constants.size() << ";\n"
                    << "inline constexpr int kLdsSlots = " << quadLds << ";  // per-lane LDS slots of the phased body\n"
+                   << "inline constexpr int kLdsUniformSlots = " << quadUniformUsed << ";  // per-quad (lane-uniform) LDS slots\n"
                    << "// leg constants that differ between legs, [k][leg]; legs in model order (LF, LH, RF, RH)\n"
                    << "inline constexpr double kLegConstants[" << std::max<std::size_t>(1, qp.constants.size()) << "][4] = {\n";
                 for (const auto& c : qp.constants) {

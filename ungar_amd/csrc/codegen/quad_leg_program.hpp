@@ -40,6 +40,7 @@ struct QuadProgram {
     std::vector<tape::OutputSlot> slots;     // in emission order
     std::vector<std::size_t> phaseStarts;    // slot indices where a new phase (Jacobian column) begins
     std::vector<std::string> inputNames;     // spelling of every tape input in the generated code
+    std::vector<char> inputUniform;          // 1: same value in the four lanes of a quad (base state, dt)
     std::vector<std::array<double, 4>> constants;  // constants[k][leg]
 };
 
@@ -119,6 +120,9 @@ inline QuadProgram RecordQuadLegProgram(const rbd::Model& model, const tape::Spa
     P.inputNames.push_back("io.dt()");
     for (int i = 0; i < K; ++i) P.inputNames.push_back("io.c(" + std::to_string(i) + ")");
     for (int i = 0; i < 9; ++i) P.inputNames.push_back("aux_unused");
+    P.inputUniform.assign(P.inputNames.size(), 0);
+    for (int i = 0; i < 13; ++i) P.inputUniform[static_cast<std::size_t>(i)] = 1;  // qb, vb
+    P.inputUniform[22] = 1;                                                        // dt
 
     std::size_t cnext = 0;
     auto C = [&]() -> AD {
@@ -474,7 +478,8 @@ inline QuadProgram RecordQuadLegProgram(const rbd::Model& model, const tape::Spa
 
 /// Emits `template <class T, class IO> void <fn>(IO& io)` with all values of type T.
 inline std::string EmitQuadProgram(const QuadProgram& P, const std::string& fnName, tape::EmitStats* stats = nullptr, bool usePhases = true,
-                                   int ldsSlots = 0, int* ldsSlotsUsed = nullptr, int rematConsumers = 0, int rematDepth = 0, int prefetch = 0) {
+                                   int ldsSlots = 0, int* ldsSlotsUsed = nullptr, int rematConsumers = 0, int rematDepth = 0, int prefetch = 0,
+                                   int uniformSlots = 0, int* uniformSlotsUsed = nullptr) {
     // inputs are read ONCE into locals (an accessor call per use would be re-issued as a memory load
     // after every store, since the compiler cannot prove the output buffers do not alias them)
     std::vector<char> used(P.inputNames.size(), 0);
@@ -511,7 +516,8 @@ inline std::string EmitQuadProgram(const QuadProgram& P, const std::string& fnNa
         }
     }
     int slotsUsed = 0;
-    std::string body = usePhases ? em.EmitPhased(phases, ldsSlots, slotsUsed, rematConsumers, rematDepth, prefetch) : em.Emit(P.slots);
+    std::string body = usePhases ? em.EmitPhased(phases, ldsSlots, slotsUsed, rematConsumers, rematDepth, prefetch, "    ", &P.inputUniform, uniformSlots, uniformSlotsUsed)
+                                 : em.Emit(P.slots);
     if (ldsSlotsUsed) *ldsSlotsUsed = slotsUsed;
     // the straight-line emitter declares `const double vN`; make the value type generic
     std::string out;

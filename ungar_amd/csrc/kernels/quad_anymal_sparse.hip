@@ -20,7 +20,7 @@ extern "C" int ungar_amd_launch_anymal_quad_sparse(const ungar_amd::kernels::Nod
     if (e != hipSuccess) return static_cast<int>(e);
     const double(*ctab)[4] = static_cast<const double(*)[4]>(sym);
     const dim3 grid(static_cast<unsigned>((a->count + kBlock / 4 - 1) / (kBlock / 4))), block(kBlock);
-    hipLaunchKernelGGL((QuadNodeKernel<kBlock, ungar_amd::gen::anymal_quad::kLdsSlots, true, AnymalQuadSparseBody>), grid, block, 0, static_cast<hipStream_t>(stream), *a,
+    hipLaunchKernelGGL((QuadNodeKernel<kBlock, ungar_amd::gen::anymal_quad::kLdsSlots, ungar_amd::gen::anymal_quad::kLdsUniformSlots, true, AnymalQuadSparseBody>), grid, block, 0, static_cast<hipStream_t>(stream), *a,
                        ctab, AnymalQuadSparseBody{});
     return static_cast<int>(hipGetLastError());
 }

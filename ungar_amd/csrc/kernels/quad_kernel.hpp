@@ -43,7 +43,8 @@ struct QuadIO {
     double* __restrict__ jOwnCol;     // jb + 3 L * je                  : base rows, column owned by this leg
     double* __restrict__ fLeg;        // fb + 3 L * fe
     const double (*ctab)[4];
-    double* lds;  // per-lane LDS home of the phased body (slot s at lds[s * 64]); null when unused
+    double* lds;   // per-lane LDS home of the phased body (slot s at lds[s * 64])
+    double* ldsu;  // per-quad home of lane-uniform values (slot s at ldsu[s * 16]): a quarter of the bytes
 
     __device__ __forceinline__ double qb(int i) const { return xb[i * xe]; }
     __device__ __forceinline__ double vb(int i) const { return xb[(19 + i) * xe]; }
@@ -60,6 +61,8 @@ struct QuadIO {
     __device__ __forceinline__ void keep(double) const {}
     __device__ __forceinline__ double ld(int slot) const { return lds[slot * 64]; }
     __device__ __forceinline__ void st(int slot, double v) const { lds[slot * 64] = v; }
+    __device__ __forceinline__ double ldu(int slot) const { return ldsu[slot * 16]; }  // same address in the 4 lanes: broadcast
+    __device__ __forceinline__ void stu(int slot, double v) const { ldsu[slot * 16] = v; }  // 4 lanes, same address, same value
 
     // quad_perm control words: lane i of the quad reads lane p_i, ctrl = p0 | p1 << 2 | p2 << 4 | p3 << 6
     __device__ __forceinline__ double quad_sum(double v) const {
@@ -108,10 +111,10 @@ struct QuadIO {
 };
 
 /// GEN is the generated namespace (ValueJacobianQuad, kLegConstantsDev).  BLOCK lanes = BLOCK/4 nodes.
-template <int BLOCK, int LDS_SLOTS, bool SPARSE, class Body>
+template <int BLOCK, int LDS_SLOTS, int LDS_USLOTS, bool SPARSE, class Body>
 __global__ __launch_bounds__(BLOCK) void QuadNodeKernel(const NodeLaunch a, const double (*ctab)[4], Body body) {
     static_assert(BLOCK == 64, "the LDS home is laid out for one wavefront per workgroup");
-    __shared__ double lds[(LDS_SLOTS > 0 ? LDS_SLOTS : 1) * BLOCK];
+    __shared__ double lds[(LDS_SLOTS > 0 ? LDS_SLOTS : 1) * BLOCK + LDS_USLOTS * (BLOCK / 4)];
     const int L = threadIdx.x & 3;
     const long long i = static_cast<long long>(blockIdx.x) * (BLOCK / 4) + (threadIdx.x >> 2);
     if (i >= a.count) return;  // whole quads leave together
@@ -136,7 +139,8 @@ __global__ __launch_bounds__(BLOCK) void QuadNodeKernel(const NodeLaunch a, cons
               jb + 3LL * L * je,
               fb ? fb + 3LL * L * a.f.es : nullptr,
               ctab,
-              lds + threadIdx.x};
+              lds + threadIdx.x,
+              lds + LDS_SLOTS * BLOCK + (threadIdx.x >> 2)};
     body(io);
 }
 

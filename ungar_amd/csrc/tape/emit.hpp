@@ -74,9 +74,26 @@ class Emitter {
     ///     recomputed where needed (bounded cone depth), which shrinks the stored set ~3x;
     ///   * stored values beyond `ldsSlots` stay registers across phases.
     /// Returns the code; `slotsUsed` = LDS slots actually needed.
+    /// `uniformInput` (optional, one flag per tape input) marks inputs whose value is the same in the four
+    /// lanes of a quad; values derived only from those (and every QuadSum) are quad-uniform and may live in
+    /// one of `uniformSlots` compact slots (io.ldu / io.stu: one copy per quad, a quarter of the LDS bytes).
     std::string EmitPhased(const std::vector<std::vector<OutputSlot>>& phases, int ldsSlots, int& slotsUsed, int rematMaxConsumers = 2,
-                           int rematMaxDepth = 3, int prefetchDistance = 48, const char* indent = "    ") {
+                           int rematMaxDepth = 3, int prefetchDistance = 48, const char* indent = "    ",
+                           const std::vector<char>* uniformInput = nullptr, int uniformSlots = 0, int* uniformSlotsUsed = nullptr) {
         const std::size_t n = g_.Size();
+        std::vector<char> uniform(n, 0);
+        if (uniformInput && uniformSlots > 0)
+            for (std::size_t i = 0; i < n; ++i) {  // operands precede their users in the graph
+                const Node& nd = g_.At(static_cast<Id>(i));
+                if (nd.op == Op::Const || nd.op == Op::QuadSum) uniform[i] = 1;
+                else if (nd.op == Op::Input) uniform[i] = (*uniformInput)[static_cast<std::size_t>(nd.a)];
+                else {
+                    bool u = true;
+                    for (Id o : {nd.a, nd.b, nd.c, nd.d})
+                        if (o != kNoId && !uniform[static_cast<std::size_t>(o)]) u = false;
+                    uniform[i] = u;
+                }
+            }
         // ---- analysis pass: first-definition phase, consumer phases -------------------------------------
         std::vector<int> defPhase(n, -1);
         std::vector<std::vector<Id>> order(phases.size());
@@ -137,8 +154,15 @@ class Emitter {
             }
         }
         // ---- generation (dry run first to learn the last phase that loads each stored value) ----------------
-        std::vector<int> slotOf(n, -1);
+        std::vector<int> slotOf(n, -1);  // varying slot s >= 0; uniform slot u encoded as -2 - u
         std::vector<int> lastLoad(n, -1);
+        auto hasSlot = [&](std::size_t i) { return slotOf[i] != -1; };
+        auto ldExpr = [&](std::size_t i) {
+            return slotOf[i] >= 0 ? "io.ld(" + std::to_string(slotOf[i]) + ")" : "io.ldu(" + std::to_string(-2 - slotOf[i]) + ")";
+        };
+        auto stStmt = [&](std::size_t i, const std::string& v) {
+            return slotOf[i] >= 0 ? "io.st(" + std::to_string(slotOf[i]) + ", " + v + ");" : "io.stu(" + std::to_string(-2 - slotOf[i]) + ", " + v + ");";
+        };
         std::string text;
         for (int pass = 0; pass < 2; ++pass) {
             const bool dry = pass == 0;
@@ -164,12 +188,12 @@ class Emitter {
                             continue;
                         }
                         const bool isStoredElsewhere = defined[si] && stored[si];
-                        const bool regResident = isStoredElsewhere && !dry && slotOf[si] < 0;
-                        if (isStoredElsewhere && (dry || slotOf[si] >= 0)) {
+                        const bool regResident = isStoredElsewhere && !dry && !hasSlot(si);
+                        if (isStoredElsewhere && (dry || hasSlot(si))) {
                             lastLoad[si] = std::max(lastLoad[si], iph);
                             availIn[si] = iph;
                             local[si] = "v" + std::to_string(counter++);
-                            if (!dry) lines.emplace_back("const double " + local[si] + " = io.ld(" + std::to_string(slotOf[si]) + ");", true);
+                            if (!dry) lines.emplace_back("const double " + local[si] + " = " + ldExpr(si) + ";", true);
                             stack.pop_back();
                             continue;
                         }
@@ -215,7 +239,7 @@ class Emitter {
                         if (!dry) lines.emplace_back("const double " + local[sm] + " = " + expr + ";", false);
                         if (!defined[sm]) {
                             defined[sm] = 1;
-                            if (stored[sm] && !dry && slotOf[sm] >= 0) lines.emplace_back("io.st(" + std::to_string(slotOf[sm]) + ", " + local[sm] + ");", false);
+                            if (stored[sm] && !dry && hasSlot(sm)) lines.emplace_back(stStmt(sm, local[sm]), false);
                         }
                     }
                 };
@@ -243,13 +267,13 @@ class Emitter {
             }
             if (dry) {
                 // slot allocation from (defPhase, lastLoad) intervals
-                std::vector<int> freeSlots;
+                std::vector<int> freeSlots, freeUniform;
                 std::vector<std::vector<int>> expiring(ph_.size() + 2);
-                int next = 0;
-                std::size_t peak = 0, live = 0, inLds = 0;
+                int next = 0, nextUniform = 0;
+                std::size_t peak = 0, live = 0, inLds = 0, inUniform = 0, uniformCross = 0;
                 std::vector<std::size_t> liveDelta(ph_.size() + 2, 0);
                 for (std::size_t ph = 0; ph < ph_.size(); ++ph) {
-                    for (int sl : expiring[ph]) freeSlots.push_back(sl);
+                    for (int sl : expiring[ph]) (sl >= 0 ? freeSlots : freeUniform).push_back(sl >= 0 ? sl : -2 - sl);
                     std::vector<Id> cross;
                     for (Id id : order[ph])
                         if (stored[static_cast<std::size_t>(id)] && lastLoad[static_cast<std::size_t>(id)] > static_cast<int>(ph)) cross.push_back(id);
@@ -262,6 +286,22 @@ class Emitter {
                         const std::size_t si = static_cast<std::size_t>(id);
                         ++liveDelta[static_cast<std::size_t>(lastLoad[si]) + 1];
                         int slot = -1;
+                        if (uniform[si]) {
+                            ++uniformCross;
+                            int us = -1;
+                            if (!freeUniform.empty()) {
+                                us = freeUniform.back();
+                                freeUniform.pop_back();
+                            } else if (nextUniform < uniformSlots) {
+                                us = nextUniform++;
+                            }
+                            if (us >= 0) {
+                                ++inUniform;
+                                slotOf[si] = -2 - us;
+                                expiring[static_cast<std::size_t>(lastLoad[si]) + 1].push_back(-2 - us);
+                                continue;
+                            }
+                        }
                         if (!freeSlots.empty()) {
                             slot = freeSlots.back();
                             freeSlots.pop_back();
@@ -276,8 +316,10 @@ class Emitter {
                     live -= liveDelta[ph + 1];
                 }
                 slotsUsed = next;
-                std::fprintf(stderr, "[emit] phased (%zu pieces): %zu cross-phase values, %zu stored (%zu in LDS, peak live %zu), %zu rematerialised; %zu statements (+%zu recomputed)\n",
-                             ph_.size(), crossTotal, storedTotal, inLds, peak, crossTotal - storedTotal, stats.statements, stats.statements - CountDefined(defPhase));
+                if (uniformSlotsUsed) *uniformSlotsUsed = nextUniform;
+                std::fprintf(stderr, "[emit] phased (%zu pieces): %zu cross-phase values, %zu stored (%zu in LDS + %zu of %zu quad-uniform in compact slots, peak live %zu), %zu rematerialised; %zu statements (+%zu recomputed)\n",
+                             ph_.size(), crossTotal, storedTotal, inLds, inUniform, uniformCross, peak, crossTotal - storedTotal, stats.statements,
+                             stats.statements - CountDefined(defPhase));
             } else {
                 text = os.str();
                 stats_.statements = stats.statements;
