@@ -371,6 +371,8 @@ int main(int argc, char** argv) {
     int jacMode = 0, structuredDMode = 1, ldsSlots = 320;
     int rematConsumers = 2, rematDepth = 3, prefetch = 48;
     int quadColumnsPerPhase = 1, quadRematConsumers = 4, quadRematDepth = 4;  // tools/sweep_quad.sh on MI355X
+    int quadPrefetch = 48;            // LDS loads are hoisted this many statements ahead of their first use ...
+    bool quadPrefetchAcross = false;  // ... and may cross into the tail of the previous phase
     int quadUniformSlots = 80;  // compact (one copy per quad) LDS slots; budget: quadLdsSlots + quadUniformSlots / 4 <= 80
     int quadLdsSlots = 60;  // 64-lane workgroups, four per CU: 160 KiB / 4 / 64 lanes / 8 B
     std::vector<std::string> only;
@@ -387,6 +389,10 @@ int main(int argc, char** argv) {
         else if (a == "--prefetch" && i + 1 < argc) prefetch = std::atoi(argv[++i]);
         else if (a == "--quad-lds-slots" && i + 1 < argc) quadLdsSlots = std::atoi(argv[++i]);
         else if (a == "--quad-uniform-slots" && i + 1 < argc) quadUniformSlots = std::atoi(argv[++i]);
+        else if (a == "--quad-prefetch" && i + 2 < argc) {
+            quadPrefetch = std::atoi(argv[++i]);
+            quadPrefetchAcross = std::atoi(argv[++i]) != 0;
+        }
         else if (a == "--quad-columns-per-phase" && i + 1 < argc) quadColumnsPerPhase = std::atoi(argv[++i]);
         else if (a == "--quad-remat" && i + 2 < argc) {
             quadRematConsumers = std::atoi(argv[++i]);
@@ -451,8 +457,8 @@ int main(int argc, char** argv) {
                 const codegen::QuadProgram qp = codegen::RecordQuadLegProgram(anymal, adv.jac, quadColumnsPerPhase);
                 tape::EmitStats qs;
                 int quadLds = 0, quadUniformUsed = 0;
-                const std::string fn = codegen::EmitQuadProgram(qp, "ValueJacobianQuad", &qs, true, quadLdsSlots, &quadLds, quadRematConsumers, quadRematDepth, prefetch,
-                                                                   quadUniformSlots, &quadUniformUsed);
+                const std::string fn = codegen::EmitQuadProgram(qp, "ValueJacobianQuad", &qs, true, quadLdsSlots, &quadLds, quadRematConsumers, quadRematDepth, quadPrefetch,
+                                                                   quadUniformSlots, &quadUniformUsed, quadPrefetchAcross);
                 std::ostringstream qo;
                 qo << "// GENERATED by ungar_amd/csrc/codegen (quad_leg_program.hpp) -- do not edit.\n"
                    << "// ANYmal B shooting node, one lane per leg: " << qs.statements << " statements, " << qs.flops << " flops, "

@@ -479,7 +479,7 @@ inline QuadProgram RecordQuadLegProgram(const rbd::Model& model, const tape::Spa
 /// Emits `template <class T, class IO> void <fn>(IO& io)` with all values of type T.
 inline std::string EmitQuadProgram(const QuadProgram& P, const std::string& fnName, tape::EmitStats* stats = nullptr, bool usePhases = true,
                                    int ldsSlots = 0, int* ldsSlotsUsed = nullptr, int rematConsumers = 0, int rematDepth = 0, int prefetch = 0,
-                                   int uniformSlots = 0, int* uniformSlotsUsed = nullptr) {
+                                   int uniformSlots = 0, int* uniformSlotsUsed = nullptr, bool prefetchAcrossPhases = false) {
     // inputs are read ONCE into locals (an accessor call per use would be re-issued as a memory load
     // after every store, since the compiler cannot prove the output buffers do not alias them)
     std::vector<char> used(P.inputNames.size(), 0);
@@ -516,7 +516,7 @@ inline std::string EmitQuadProgram(const QuadProgram& P, const std::string& fnNa
         }
     }
     int slotsUsed = 0;
-    std::string body = usePhases ? em.EmitPhased(phases, ldsSlots, slotsUsed, rematConsumers, rematDepth, prefetch, "    ", &P.inputUniform, uniformSlots, uniformSlotsUsed)
+    std::string body = usePhases ? em.EmitPhased(phases, ldsSlots, slotsUsed, rematConsumers, rematDepth, prefetch, "    ", &P.inputUniform, uniformSlots, uniformSlotsUsed, prefetchAcrossPhases)
                                  : em.Emit(P.slots);
     if (ldsSlotsUsed) *ldsSlotsUsed = slotsUsed;
     // the straight-line emitter declares `const double vN`; make the value type generic

@@ -1,12 +1,15 @@
 // ungar_amd :: kernel skeleton of the lane-per-leg SPMD node program.
 //
-// A quad of 4 adjacent lanes owns one shooting node of a floating-base quadruped, lane l & 3 = leg.
-// A 64-lane wavefront therefore evaluates 16 nodes; per-lane state (~170 doubles) lives in registers
-// only, so four wavefronts run per CU (one per SIMD) -- against ONE for the lane-per-node body whose
-// state had to be parked in 160 KiB of LDS.  The lanes of a quad meet through DPP quad permutes
-// (v_mov_b32 ... quad_perm: register-to-register, no LDS).
-// HBM access pattern (unit-fastest layout): the 16 nodes of a wavefront are consecutive, so every
-// load/store instruction touches, per leg, 16 consecutive doubles = one 128-byte segment.
+// Four lanes own one shooting node of a floating-base quadruped, one lane per leg.  A 64-lane wavefront
+// therefore evaluates 16 nodes; four wavefronts run per CU (one per SIMD) -- against ONE for the
+// lane-per-node body whose state had to be parked in 160 KiB of LDS.
+// Lane layout inside each 16-lane DPP row:  lane = 4 * leg + (node % 4),  row = node / 4.
+//   * the four legs of a node sit 4 lanes apart in one row, so they meet through DPP row rotations
+//     (v_mov_b32 ... row_ror:4/8/12: register-to-register, no LDS);
+//   * 4 ADJACENT lanes hold the same leg of 4 consecutive nodes, so in the unit-fastest layout every
+//     store instruction writes 32-byte contiguous runs (4 per 128-byte line).  With the legs of a node
+//     in adjacent lanes instead (quad_perm), adjacent lanes hit four different lines and the kernel
+//     was bound by the address path: 0.416 ms vs 0.335 ms measured with nothing else changed.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -64,14 +67,15 @@ struct QuadIO {
     __device__ __forceinline__ double ldu(int slot) const { return ldsu[slot * 16]; }  // same address in the 4 lanes: broadcast
     __device__ __forceinline__ void stu(int slot, double v) const { ldsu[slot * 16] = v; }  // 4 lanes, same address, same value
 
-    // quad_perm control words: lane i of the quad reads lane p_i, ctrl = p0 | p1 << 2 | p2 << 4 | p3 << 6
+    // DPP row_ror:n (ctrl 0x120 + n): lane i of a 16-lane row reads lane (i - n) mod 16.  Legs are 4 lanes
+    // apart, so leg L reads leg (L + k) & 3 of its own node with n = 16 - 4 k.
     __device__ __forceinline__ double quad_sum(double v) const {
-        const double t = v + QuadPerm<0xB1>(v);  // [1,0,3,2]
-        return t + QuadPerm<0x4E>(t);            // [2,3,0,1]
+        const double t = v + QuadPerm<0x124>(v);
+        return t + QuadPerm<0x128>(t);
     }
-    __device__ __forceinline__ double quad_rot1(double v) const { return QuadPerm<0x39>(v); }  // [1,2,3,0]
-    __device__ __forceinline__ double quad_rot2(double v) const { return QuadPerm<0x4E>(v); }  // [2,3,0,1]
-    __device__ __forceinline__ double quad_rot3(double v) const { return QuadPerm<0x93>(v); }  // [3,0,1,2]
+    __device__ __forceinline__ double quad_rot1(double v) const { return QuadPerm<0x12C>(v); }  // from leg L + 1
+    __device__ __forceinline__ double quad_rot2(double v) const { return QuadPerm<0x128>(v); }  // from leg L + 2
+    __device__ __forceinline__ double quad_rot3(double v) const { return QuadPerm<0x124>(v); }  // from leg L + 3
 
     // base rows / shared columns: all four lanes hold the same value and store it to the same address
     // (merged inside the instruction) -- cheaper than masking three lanes off with exec-mask branches
@@ -115,9 +119,10 @@ template <int BLOCK, int LDS_SLOTS, int LDS_USLOTS, bool SPARSE, class Body>
 __global__ __launch_bounds__(BLOCK) void QuadNodeKernel(const NodeLaunch a, const double (*ctab)[4], Body body) {
     static_assert(BLOCK == 64, "the LDS home is laid out for one wavefront per workgroup");
     __shared__ double lds[(LDS_SLOTS > 0 ? LDS_SLOTS : 1) * BLOCK + LDS_USLOTS * (BLOCK / 4)];
-    const int L = threadIdx.x & 3;
-    const long long i = static_cast<long long>(blockIdx.x) * (BLOCK / 4) + (threadIdx.x >> 2);
-    if (i >= a.count) return;  // whole quads leave together
+    const int L = (threadIdx.x >> 2) & 3;
+    const int nodeInWave = 4 * (threadIdx.x >> 4) + (threadIdx.x & 3);
+    const long long i = static_cast<long long>(blockIdx.x) * (BLOCK / 4) + nodeInWave;
+    if (i >= a.count) return;  // the four lanes of a node leave together
     long long b = i, k = 0;
     if (a.knots > 1) {
         b = i / a.knots;
@@ -140,7 +145,7 @@ __global__ __launch_bounds__(BLOCK) void QuadNodeKernel(const NodeLaunch a, cons
               fb ? fb + 3LL * L * a.f.es : nullptr,
               ctab,
               lds + threadIdx.x,
-              lds + LDS_SLOTS * BLOCK + (threadIdx.x >> 2)};
+              lds + LDS_SLOTS * BLOCK + nodeInWave};
     body(io);
 }
 

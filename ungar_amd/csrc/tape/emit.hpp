@@ -79,7 +79,8 @@ class Emitter {
     /// one of `uniformSlots` compact slots (io.ldu / io.stu: one copy per quad, a quarter of the LDS bytes).
     std::string EmitPhased(const std::vector<std::vector<OutputSlot>>& phases, int ldsSlots, int& slotsUsed, int rematMaxConsumers = 2,
                            int rematMaxDepth = 3, int prefetchDistance = 48, const char* indent = "    ",
-                           const std::vector<char>* uniformInput = nullptr, int uniformSlots = 0, int* uniformSlotsUsed = nullptr) {
+                           const std::vector<char>* uniformInput = nullptr, int uniformSlots = 0, int* uniformSlotsUsed = nullptr,
+                           bool prefetchAcrossPhases = false) {
         const std::size_t n = g_.Size();
         std::vector<char> uniform(n, 0);
         if (uniformInput && uniformSlots > 0)
@@ -172,10 +173,23 @@ class Emitter {
             std::vector<char> defined(n, 0);
             int counter = 0;
             EmitStats stats;
+            struct Line {
+                std::string text;
+                bool isLoad;
+                std::size_t value;  // LDS load: the value it brings back
+            };
+            std::vector<Line> all;                // statements of all phases, in recording order
+            std::vector<std::size_t> phaseBegin;  // index in `all` of the first statement of each phase (its marker)
+            std::vector<std::size_t> storeLine(n, 0);
+            struct LineSink {
+                std::vector<Line>& all;
+                std::size_t pendingValue = 0;
+                void emplace_back(std::string t, bool isLoad) { all.push_back({std::move(t), isLoad, isLoad ? pendingValue : 0}); }
+            } lines{all};
             for (std::size_t ph = 0; ph < ph_.size(); ++ph) {
-                if (ph && !dry) os << indent << "io.phase();\n";
+                phaseBegin.push_back(all.size());
+                if (ph && !dry) all.push_back({"io.phase();", false, 0});
                 const int iph = static_cast<int>(ph);
-                std::vector<std::pair<std::string, bool>> lines;  // (statement, is LDS load)
                 // explicit stack DFS producing statements for `root` in this phase
                 auto produce = [&](Id root) {
                     std::vector<std::pair<Id, int>> stack{{root, 0}};
@@ -193,6 +207,7 @@ class Emitter {
                             lastLoad[si] = std::max(lastLoad[si], iph);
                             availIn[si] = iph;
                             local[si] = "v" + std::to_string(counter++);
+                            lines.pendingValue = si;
                             if (!dry) lines.emplace_back("const double " + local[si] + " = " + ldExpr(si) + ";", true);
                             stack.pop_back();
                             continue;
@@ -239,7 +254,10 @@ class Emitter {
                         if (!dry) lines.emplace_back("const double " + local[sm] + " = " + expr + ";", false);
                         if (!defined[sm]) {
                             defined[sm] = 1;
-                            if (stored[sm] && !dry && hasSlot(sm)) lines.emplace_back(stStmt(sm, local[sm]), false);
+                            if (stored[sm] && !dry && hasSlot(sm)) {
+                                storeLine[sm] = all.size();
+                                lines.emplace_back(stStmt(sm, local[sm]), false);
+                            }
                         }
                     }
                 };
@@ -254,16 +272,28 @@ class Emitter {
                         lines.emplace_back(line, false);
                     }
                 }
-                if (!dry) {
-                    // software prefetch: an LDS load has no intra-phase dependency, so it is hoisted
-                    // `prefetchDistance` statements ahead of its first use to hide the ~100+ cycle LDS
-                    // latency (one wavefront per SIMD: nothing else would cover it)
-                    std::vector<std::pair<double, std::size_t>> key(lines.size());
-                    for (std::size_t i = 0; i < lines.size(); ++i)
-                        key[i] = {lines[i].second ? std::max(-0.5, static_cast<double>(i) - prefetchDistance - 0.5) : static_cast<double>(i), i};
-                    std::stable_sort(key.begin(), key.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
-                    for (const auto& [k, i] : key) os << indent << lines[i].first << "\n";
+            }
+            if (!dry) {
+                // software prefetch: an LDS load depends only on the store of its value, so it is hoisted
+                // `prefetchDistance` statements ahead of its first use to hide the ~100+ cycle LDS latency
+                // (one wavefront per SIMD: nothing else would cover it) -- up to the start of its phase, or,
+                // with prefetchAcrossPhases, into the tail of the previous phase (never above its store)
+                phaseBegin.push_back(all.size());
+                std::vector<std::pair<double, std::size_t>> key(all.size());
+                std::size_t ph = 0;
+                for (std::size_t i = 0; i < all.size(); ++i) {
+                    while (ph + 1 < phaseBegin.size() && phaseBegin[ph + 1] <= i) ++ph;
+                    double k = static_cast<double>(i);
+                    if (all[i].isLoad) {
+                        double lo = static_cast<double>(phaseBegin[ph]) + 0.25;  // after the phase marker
+                        if (prefetchAcrossPhases && ph > 0)
+                            lo = std::max(static_cast<double>(phaseBegin[ph - 1]), static_cast<double>(storeLine[all[i].value])) + 0.25;
+                        k = std::max(lo, static_cast<double>(i) - prefetchDistance - 0.5);
+                    }
+                    key[i] = {k, i};
                 }
+                std::stable_sort(key.begin(), key.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
+                for (const auto& [k, i] : key) os << indent << all[i].text << "\n";
             }
             if (dry) {
                 // slot allocation from (defPhase, lastLoad) intervals
