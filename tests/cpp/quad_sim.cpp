@@ -82,6 +82,12 @@ struct SimIO {
         const int ks[4] = {k0, k1, k2, k3};
         for (int l = 0; l < 4; ++l) put(l, row, colBase + 3 * legMul * l, ks[l], v.v[l]);
     }
+    void j_base_shared4(int r0, int r1, int r2, int r3, int col, int k0, int k1, int k2, int k3, const Quad& v0, const Quad& v1, const Quad& v2,
+                        const Quad& v3) const {
+        const int rs[4] = {r0, r1, r2, r3}, ks[4] = {k0, k1, k2, k3};
+        const Quad* vs[4] = {&v0, &v1, &v2, &v3};
+        for (int l = 0; l < 4; ++l) put(l, rs[l], col, ks[l], vs[l]->v[l]);  // the lane of leg l writes entry l
+    }
     void j_base_shared(int row, int colBase, int, int, int k0, int, int, int, const Quad& v) const { put(0, row, colBase, k0, v.v[(row + colBase) & 3]); }
 };
 

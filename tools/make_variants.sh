@@ -10,6 +10,6 @@ for spec in "$@"; do
   ( dir=/tmp/gen_v/$name; mkdir -p $dir
     ./build/ungar_codegen --out $dir --anymal-robot ungar_amd/data/anymal_b.robot --model anymal $flags > $dir/log 2>&1
     hipcc --offload-arch=gfx950 -O3 -std=c++20 -I $dir -Rpass-analysis=kernel-resource-usage -o build/variants/$name tools/quad_bench.hip > $dir/cc.log 2>&1
-    echo "$name: $(grep -E 'ScratchSize|VGPRs Spill' $dir/cc.log | sed 's/.*remark: *//; s/\[-R.*//' | tr '\n' ' ')" ) &
+    echo "$name: $(grep -E "ScratchSize" $dir/cc.log | head -1 | sed "s/.*remark: *//; s/\[-R.*//")" ) &
 done
 wait

@@ -88,14 +88,16 @@ __global__ __launch_bounds__(64) __attribute__((flatten)) void DiagKernel(const 
                                       : i;
     const long long o = wrap ? oi % wrap : oi;
     constexpr long long kMulA = VARIANT == 2 ? 2 : 1;
-    double* const fb = a.f.base + o * kMulA;
-    double* const jb = a.jac.base + o * kMulA;
-    const long long je = a.jac.es;
+    // REMAP 3: tiled output (array of [element][16 nodes] tiles): one wavefront's block is contiguous in HBM
+    double* const fb = REMAP == 3 ? a.f.base + (o / 16) * (37 * 16) + (o % 16) : a.f.base + o * kMulA;
+    double* const jb = REMAP == 3 ? a.jac.base + (o / 16) * (1813 * 16) + (o % 16) : a.jac.base + o * kMulA;
+    const long long je = REMAP == 3 ? 16 : a.jac.es;
+    const long long fe = REMAP == 3 ? 16 : a.f.es;
     double* const jLeg = jb + 3LL * L * 49 * je * kMulA;
     constexpr long long kMul = VARIANT == 2 ? 2 : 1;
-    StoreIO<VARIANT, TIMED> io{{{a.x.base + i, a.u.base + i, a.p.base, fb, jb, a.x.es, a.u.es, a.f.es, static_cast<unsigned>(je), Lreal, jLeg,
+    StoreIO<VARIANT, TIMED> io{{{a.x.base + i, a.u.base + i, a.p.base, fb, jb, a.x.es, a.u.es, fe, static_cast<unsigned>(je), Lreal, jLeg,
                 {jLeg + 3LL * L * je * kMul, jLeg + 3LL * ((L + 1) & 3) * je * kMul, jLeg + 3LL * ((L + 2) & 3) * je * kMul, jLeg + 3LL * ((L + 3) & 3) * je * kMul},
-                jb + 3LL * L * je * kMul, fb + 3LL * L * a.f.es * kMul, ctab, lds + threadIdx.x, lds + LDS_SLOTS * 64 + nodeInWave},
+                jb + 3LL * L * je * kMul, fb + 3LL * L * fe * kMul, ctab, lds + threadIdx.x, lds + LDS_SLOTS * 64 + nodeInWave},
                (stamps && threadIdx.x == 0 && blockIdx.x % 64 == 0) ? stamps + (blockIdx.x / 64) * 32 : nullptr}};
     if constexpr (TIMED) {
         if (io.ts) io.ts[io.k++] = clock64();
@@ -173,6 +175,7 @@ int main(int argc, char** argv) {
             if (mode == 4) hipLaunchKernelGGL((DiagKernel<Q::kLdsSlots, Q::kLdsUniformSlots, 0, 1>), grid, block, 0, 0, a, static_cast<const double(*)[4]>(sym), wrap, st);
             if (mode == 6) hipLaunchKernelGGL((DiagKernel<Q::kLdsSlots, Q::kLdsUniformSlots, 0, 2>), grid, block, 0, 0, a, static_cast<const double(*)[4]>(sym), wrap, st);
             if (mode == 7) hipLaunchKernelGGL((DiagKernel<Q::kLdsSlots, Q::kLdsUniformSlots, 1, 2>), grid, block, 0, 0, a, static_cast<const double(*)[4]>(sym), wrap, st);
+            if (mode == 8) hipLaunchKernelGGL((DiagKernel<Q::kLdsSlots, Q::kLdsUniformSlots, 0, 3>), grid, block, 0, 0, a, static_cast<const double(*)[4]>(sym), wrap, st);
             if (mode == 5) hipLaunchKernelGGL((DiagKernel<Q::kLdsSlots, Q::kLdsUniformSlots, 1, 1>), grid, block, 0, 0, a, static_cast<const double(*)[4]>(sym), wrap, st);
         };
         for (long long wrap : {0LL, 1024LL}) {

@@ -371,6 +371,7 @@ int main(int argc, char** argv) {
     int jacMode = 0, structuredDMode = 1, ldsSlots = 320;
     int rematConsumers = 2, rematDepth = 3, prefetch = 48;
     int quadColumnsPerPhase = 1, quadRematConsumers = 4, quadRematDepth = 4;  // tools/sweep_quad.sh on MI355X
+    bool quadMergeShared = false;     // four base-row entries of a shared column per store instruction (measured: no gain, 0.347 vs 0.343 ms)
     int quadPrefetch = 48;            // LDS loads are hoisted this many statements ahead of their first use ...
     bool quadPrefetchAcross = false;  // ... and may cross into the tail of the previous phase
     int quadUniformSlots = 80;  // compact (one copy per quad) LDS slots; budget: quadLdsSlots + quadUniformSlots / 4 <= 80
@@ -388,6 +389,7 @@ int main(int argc, char** argv) {
         else if (a == "--remat-depth" && i + 1 < argc) rematDepth = std::atoi(argv[++i]);
         else if (a == "--prefetch" && i + 1 < argc) prefetch = std::atoi(argv[++i]);
         else if (a == "--quad-lds-slots" && i + 1 < argc) quadLdsSlots = std::atoi(argv[++i]);
+        else if (a == "--quad-merge-shared" && i + 1 < argc) quadMergeShared = std::atoi(argv[++i]) != 0;
         else if (a == "--quad-uniform-slots" && i + 1 < argc) quadUniformSlots = std::atoi(argv[++i]);
         else if (a == "--quad-prefetch" && i + 2 < argc) {
             quadPrefetch = std::atoi(argv[++i]);
@@ -454,7 +456,7 @@ int main(int argc, char** argv) {
                 EmitHip(st, outDir, true, 0);
             }
             if (wanted("anymal")) {  // lane-per-leg SPMD program (dense Jacobian path of the 'anymal' model)
-                const codegen::QuadProgram qp = codegen::RecordQuadLegProgram(anymal, adv.jac, quadColumnsPerPhase);
+                const codegen::QuadProgram qp = codegen::RecordQuadLegProgram(anymal, adv.jac, quadColumnsPerPhase, quadMergeShared);
                 tape::EmitStats qs;
                 int quadLds = 0, quadUniformUsed = 0;
                 const std::string fn = codegen::EmitQuadProgram(qp, "ValueJacobianQuad", &qs, true, quadLdsSlots, &quadLds, quadRematConsumers, quadRematDepth, quadPrefetch,

@@ -53,7 +53,8 @@ inline bool IsZeroLit(const AD& a) {
 }  // namespace detail
 
 /// Records the leg-lane program for a free-flyer + 4 x (3 revolute) robot.
-inline QuadProgram RecordQuadLegProgram(const rbd::Model& model, const tape::SparseEntries& pattern, int columnsPerPhase = 1) {
+inline QuadProgram RecordQuadLegProgram(const rbd::Model& model, const tape::SparseEntries& pattern, int columnsPerPhase = 1,
+                                        bool mergeSharedStores = false) {
     using namespace rbd;
     using namespace rbd::detail;
     if (model.NumJoints() != 14 || model.nq != 19 || model.nv != 18) throw std::runtime_error("quad program: expected a free-flyer with 12 revolute joints");
@@ -395,6 +396,7 @@ inline QuadProgram RecordQuadLegProgram(const rbd::Model& model, const tape::Spa
     ///   yb, yl: base / own-leg rows of da/dz for the column;  ownKind: this lane owns the column
     ///   colExpr: how the column index is spelled; baseRows: emit the 13 base rows too
     int columnCounter = 0;
+    int sharedGroups = 0;  // merged base-row stores of shared columns emitted so far (unique names)
     auto emitColumn = [&](int gLocal, const std::vector<AD>& yb, const std::array<AD, 3>& yl, int colBase, int colLegMul, int rot, bool baseRows,
                           bool sharedColumn) {
         const std::string colArgs = std::to_string(colBase) + ", " + std::to_string(colLegMul) + ", " + std::to_string(rot);
@@ -416,9 +418,29 @@ inline QuadProgram RecordQuadLegProgram(const rbd::Model& model, const tape::Spa
             for (int i = 0; i < 13; ++i) {
                 const AD v = entry(i);
                 checkZero(v, baseRowIndex(i), 0);
+                // a shared column's base rows hold the same value in all four lanes of a node: four entries
+                // are merged into ONE store instruction, lane of leg g writing entry g (names sh<g>_<group>
+                // carry the first three values to the sink of the fourth)
+                if (mergeSharedStores && sharedColumn && i < 12) {
+                    const int g = i & 3, group = sharedGroups + (i >> 2);
+                    if (g < 3) {
+                        P.slots.push_back({v.Node(), "const T sh" + std::to_string(g) + "_" + std::to_string(group) + " = %s;"});
+                    } else {
+                        std::string rows, ks, vals;
+                        for (int j = 0; j < 4; ++j) {
+                            const int r = baseRowIndex(i - 3 + j);
+                            rows += std::to_string(r) + ", ";
+                            ks += std::to_string(kOf[static_cast<std::size_t>(r * 49 + colBase)]) + ", ";
+                            if (j < 3) vals += "sh" + std::to_string(j) + "_" + std::to_string(group) + ", ";
+                        }
+                        P.slots.push_back({v.Node(), "io.j_base_shared4(" + rows + std::to_string(colBase) + ", " + ks + vals + "%s);"});
+                    }
+                    continue;
+                }
                 P.slots.push_back({v.Node(), std::string(sharedColumn ? "io.j_base_shared(" : "io.j_base_own(") + std::to_string(baseRowIndex(i)) + ", " + colArgs +
                                                  ", " + kArgs(baseRowIndex(i), 0, colBase, colLegMul, rot) + ", %s);"});
             }
+        if (baseRows && sharedColumn) sharedGroups += 3;
         for (int half = 0; half < 2; ++half)
             for (int k = 0; k < 3; ++k) {
                 const int rowBase = (half ? 25 : 7) + k;

@@ -105,6 +105,18 @@ struct QuadIO {
         else
             jOwnCol[static_cast<unsigned>(row * 49 + colBase) * je] = v;
     }
+    /// Four entries of a shared column (same value in the four lanes of a node) in one store instruction:
+    /// the lane of leg g writes entry g.
+    __device__ __forceinline__ void j_base_shared4(int r0, int r1, int r2, int r3, int col, int k0, int k1, int k2, int k3, double v0, double v1, double v2,
+                                                   double v3) const {
+        const double v = L == 0 ? v0 : L == 1 ? v1 : L == 2 ? v2 : v3;
+        if constexpr (SPARSE) {
+            j_sparse(k0, k1, k2, k3, v);
+        } else {
+            const unsigned e = static_cast<unsigned>((L == 0 ? r0 : L == 1 ? r1 : L == 2 ? r2 : r3) * 49 + col);
+            jb[e * je] = v;
+        }
+    }
     __device__ __forceinline__ void j_base_shared(int row, int colBase, int, int, int k0, int, int, int, double v) const {
         if constexpr (SPARSE) {
             if (k0 >= 0) jb[static_cast<unsigned>(k0) * je] = v;
