@@ -9,6 +9,7 @@ echo "== pytest -m gpu"; timeout 1700 python -m pytest tests -m gpu -x -q 2>&1 |
 echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -4 | tee gpurun_out/smoke.log
 echo "== bench"; timeout 600 python bench.py 2>&1 | tail -1 | tee gpurun_out/bench.log
 for w in quadrotor rc_car srbd; do timeout 300 python bench.py --workload $w --steps 20 --warmup 3 --cpu-seconds 3 2>&1 | tail -1 > gpurun_out/bench_$w.log; done
+timeout 300 python bench.py --jacobian sparse --steps 20 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/bench_anymal_sparse.log
 for m in anymal_reg anymal_ad; do timeout 300 python bench.py --model $m --steps 20 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/bench_$m.log; done
 echo "== rocprofv3 kernel trace"
 rm -rf gpurun_out/prof gpurun_out/pmc1 gpurun_out/pmc2
