@@ -1,0 +1,17 @@
+#!/usr/bin/env bash
+# Compiles the reference's OWN example programs, from the sources where they lie under /root/reference,
+# against ungar_amd's headers and library -- nothing of the reference is copied, no reference header is
+# used (the include path holds only ungar_amd/include).  That they build UNCHANGED is the API-surface
+# check of BASELINE.json's north star ("the example/mpc problems link unchanged"); running them needs a
+# GPU (tests/test_reference_examples.py, -m gpu).  Outputs: oracle/_ref/<name>_example (git-ignored,
+# travels to the GPU box).
+set -euo pipefail
+here="$(cd "$(dirname "$0")" && pwd)"; root="$(cd "$here/../.." && pwd)"
+ref=${UNGAR_REFERENCE:-/root/reference}
+[ -d "$ref/example/mpc" ] || { echo "reference not present: nothing to build"; exit 0; }
+mkdir -p "$root/oracle/_ref"
+for name in "$@"; do
+  g++ -std=c++20 -O2 -I "$root/ungar_amd/include" -o "$root/oracle/_ref/${name}_example" "$ref/example/mpc/${name}.example.cpp" \
+      -L "$root/ungar_amd/lib" -lungar_amd -Wl,-rpath,'$ORIGIN/../../ungar_amd/lib' -Wl,-rpath,/opt/rocm/lib
+  echo "built oracle/_ref/${name}_example"
+done

@@ -124,6 +124,22 @@ def build_cpp_tests():
         jobs.append(["g++", "-std=c++20", "-O0", "-shared", "-fPIC", "-I", GEN, "-o", sim_lib, sim_src])
     with ThreadPoolExecutor(max_workers=4) as pool:
         list(pool.map(_run, jobs))
+    build_reference_examples()
+
+
+def build_reference_examples(names=("quadrotor", "rc_car")):
+    """The reference's own example/mpc programs against ungar_amd's headers (oracle/ref_examples):
+    only where the reference is present; the binaries land in oracle/_ref and travel to the GPU box."""
+    script = os.path.join(ROOT, "oracle", "ref_examples", "build_examples.sh")
+    ref = os.environ.get("UNGAR_REFERENCE", "/root/reference")
+    todo = []
+    for n in names:
+        src = os.path.join(ref, "example", "mpc", f"{n}.example.cpp")
+        exe = os.path.join(ROOT, "oracle", "_ref", f"{n}_example")
+        if os.path.exists(src) and not _newer([exe], [src, LIB] + _tree(os.path.join(ROOT, "ungar_amd", "include"))):
+            todo.append(n)
+    if todo:
+        _run(["bash", script, *todo])
 
 
 def build_all():

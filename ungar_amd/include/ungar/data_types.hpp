@@ -4,6 +4,8 @@
 #include <string>
 #include <string_view>
 
+#include "assert.hpp"
+#include "io/logging.hpp"
 #include "linalg.hpp"
 #include "variable.hpp"
 
@@ -35,6 +37,9 @@ using MapToVector3r = Eigen::Map<Vector3r>;
 using MapToConstVector3r = Eigen::Map<const Vector3r>;
 using MapToQuaternionr = Eigen::Map<Quaternionr>;
 using MapToConstQuaternionr = Eigen::Map<const Quaternionr>;
+
+template <class S>
+using SparseMatrix = Eigen::SparseMatrixCsr<S>;  // row-major compressed view (function.hpp:375-383)
 
 namespace Concepts {
 template <class T>

@@ -26,6 +26,7 @@ namespace Eigen {
 
 using Index = std::ptrdiff_t;
 inline constexpr Index Dynamic = -1;
+inline constexpr int Infinity = -1;  // lpNorm<Eigen::Infinity>()
 
 template <class S>
 struct NumTraits {
@@ -290,24 +291,72 @@ class MatrixBase {
         for (Index i = 1; i < size(); ++i) acc = acc + (*this)[i];
         return acc;
     }
+    S maxCoeff() const {
+        S best = (*this)[0];
+        for (Index i = 1; i < size(); ++i)
+            if ((*this)[i] > best) best = (*this)[i];
+        return best;
+    }
+    template <class I>
+    S maxCoeff(I* index) const {
+        *index = 0;
+        for (Index i = 1; i < size(); ++i)
+            if ((*this)[i] > (*this)[*index]) *index = static_cast<I>(i);
+        return (*this)[*index];
+    }
+    S minCoeff() const {
+        S best = (*this)[0];
+        for (Index i = 1; i < size(); ++i)
+            if ((*this)[i] < best) best = (*this)[i];
+        return best;
+    }
+    /// P = 1, 2 or Eigen::Infinity.
+    template <int P>
+    S lpNorm() const {
+        using std::abs;
+        if constexpr (P == 2) {
+            return norm();
+        } else {
+            S acc{0};
+            for (Index i = 0; i < size(); ++i) {
+                const S a = abs((*this)[i]);
+                if constexpr (P == 1) acc = acc + a;
+                else if (a > acc) acc = a;
+            }
+            return acc;
+        }
+    }
+    /// Forward iteration over the coefficients (range-for, fmt::join).
+    struct ConstIterator {
+        const MatrixBase* m;
+        Index i;
+        S operator*() const { return (*m)[i]; }
+        ConstIterator& operator++() {
+            ++i;
+            return *this;
+        }
+        bool operator!=(const ConstIterator& o) const { return i != o.i; }
+    };
+    ConstIterator begin() const { return {this, 0}; }
+    ConstIterator end() const { return {this, size()}; }
     template <class D2>
-    S dot(const MatrixBase<D2>& o) const {
-        S acc = (*this)[0] * o[0];
+    auto dot(const MatrixBase<D2>& o) const {
+        auto acc = (*this)[0] * o[0];
         for (Index i = 1; i < size(); ++i) acc = acc + (*this)[i] * o[i];
         return acc;
     }
     template <class D2>
-    PlainObject cross(const MatrixBase<D2>& b) const {
+    auto cross(const MatrixBase<D2>& b) const {
         const auto& a = *this;
-        PlainObject r(3);
+        Matrix<internal::remove_cvref_t<decltype((*this)[0] * b[0])>, RowsAtCompileTime> r(3);
         r[0] = a[1] * b[2] - a[2] * b[1];
         r[1] = a[2] * b[0] - a[0] * b[2];
         r[2] = a[0] * b[1] - a[1] * b[0];
         return r;
     }
     template <class D2>
-    PlainObject cwiseProduct(const MatrixBase<D2>& o) const {
-        PlainObject r(size());
+    auto cwiseProduct(const MatrixBase<D2>& o) const {
+        Matrix<internal::remove_cvref_t<decltype((*this)[0] * o[0])>, RowsAtCompileTime> r(size());
         for (Index i = 0; i < size(); ++i) r[i] = (*this)[i] * o[i];
         return r;
     }
@@ -381,33 +430,41 @@ class MatrixBase {
     }
 };
 
+namespace internal {
+template <class T>
+inline constexpr bool is_scalar_like_v = std::is_arithmetic_v<remove_cvref_t<T>> || requires(const remove_cvref_t<T>& t) { t.IsLiteral(); };
+/// Plain vector type of a binary operation between scalars SA and SB (double x tape scalar -> tape scalar).
+template <class A, class SB>
+using Promoted = Matrix<remove_cvref_t<decltype(std::declval<typename MatrixBase<A>::S>() * std::declval<SB>())>, MatrixBase<A>::RowsAtCompileTime>;
+}  // namespace internal
+
 template <class A, class B>
 auto operator+(const MatrixBase<A>& a, const MatrixBase<B>& b) {
-    typename MatrixBase<A>::PlainObject r(a.size());
+    internal::Promoted<A, typename MatrixBase<B>::S> r(a.size());
     for (Index i = 0; i < a.size(); ++i) r[i] = a[i] + b[i];
     return r;
 }
 template <class A, class B>
 auto operator-(const MatrixBase<A>& a, const MatrixBase<B>& b) {
-    typename MatrixBase<A>::PlainObject r(a.size());
+    internal::Promoted<A, typename MatrixBase<B>::S> r(a.size());
     for (Index i = 0; i < a.size(); ++i) r[i] = a[i] - b[i];
     return r;
 }
-template <class A, class T, std::enable_if_t<std::is_constructible_v<typename MatrixBase<A>::S, T> && !std::is_base_of_v<MatrixBase<internal::remove_cvref_t<T>>, internal::remove_cvref_t<T>>, int> = 0>
+template <class A, class T, std::enable_if_t<internal::is_scalar_like_v<T>, int> = 0>
 auto operator*(const MatrixBase<A>& a, const T& s) {
-    typename MatrixBase<A>::PlainObject r(a.size());
+    internal::Promoted<A, T> r(a.size());
     for (Index i = 0; i < a.size(); ++i) r[i] = a[i] * s;
     return r;
 }
-template <class A, class T, std::enable_if_t<std::is_constructible_v<typename MatrixBase<A>::S, T> && !std::is_base_of_v<MatrixBase<internal::remove_cvref_t<T>>, internal::remove_cvref_t<T>>, int> = 0>
+template <class A, class T, std::enable_if_t<internal::is_scalar_like_v<T>, int> = 0>
 auto operator*(const T& s, const MatrixBase<A>& a) {
-    typename MatrixBase<A>::PlainObject r(a.size());
+    internal::Promoted<A, T> r(a.size());
     for (Index i = 0; i < a.size(); ++i) r[i] = s * a[i];
     return r;
 }
-template <class A, class T, std::enable_if_t<std::is_constructible_v<typename MatrixBase<A>::S, T> && !std::is_base_of_v<MatrixBase<internal::remove_cvref_t<T>>, internal::remove_cvref_t<T>>, int> = 0>
+template <class A, class T, std::enable_if_t<internal::is_scalar_like_v<T>, int> = 0>
 auto operator/(const MatrixBase<A>& a, const T& s) {
-    typename MatrixBase<A>::PlainObject r(a.size());
+    internal::Promoted<A, T> r(a.size());
     for (Index i = 0; i < a.size(); ++i) r[i] = a[i] / s;
     return r;
 }
@@ -627,15 +684,19 @@ class QuaternionBase {
     }
     /// Rotate a 3-vector: v + w t + u x t with t = 2 (u x v)  (Eigen's _transformVector).
     template <class D2>
-    Matrix<S, 3> operator*(const MatrixBase<D2>& v) const {
+    auto operator*(const MatrixBase<D2>& v) const {
+        using R = internal::remove_cvref_t<decltype(x() * v[0])>;  // real rotation of a tape vector and vice versa
         const Matrix<S, 3> u{x(), y(), z()};
-        Matrix<S, 3> t = u.cross(v);
+        Matrix<R, 3> t = u.cross(v);
         t = t + t;
-        const Matrix<S, 3> ut = u.cross(t);
-        return Matrix<S, 3>{v[0] + w() * t[0] + ut[0], v[1] + w() * t[1] + ut[1], v[2] + w() * t[2] + ut[2]};
+        const Matrix<R, 3> ut = u.cross(t);
+        return Matrix<R, 3>{v[0] + w() * t[0] + ut[0], v[1] + w() * t[1] + ut[1], v[2] + w() * t[2] + ut[2]};
     }
     template <class T>
     auto cast() const;
+    auto conjugate() const;
+    /// Inverse rotation; like Eigen's, conjugate / squaredNorm (all-zero for the null quaternion).
+    auto inverse() const;
 };
 
 template <class S_>
@@ -744,6 +805,18 @@ auto operator*(const QuaternionBase<A>& a, const QuaternionBase<B>& b) {
                          a.w() * b.z() + a.z() * b.w() + a.x() * b.y() - a.y() * b.x()};
 }
 
+template <class Derived>
+auto QuaternionBase<Derived>::conjugate() const {
+    return Quaternion<S>{w(), -x(), -y(), -z()};
+}
+template <class Derived>
+auto QuaternionBase<Derived>::inverse() const {
+    const S n2 = squaredNorm();
+    if constexpr (std::is_arithmetic_v<S>) {
+        if (n2 == S{0}) return Quaternion<S>{S{0}, S{0}, S{0}, S{0}};
+    }
+    return Quaternion<S>{w() / n2, -x() / n2, -y() / n2, -z() / n2};
+}
 template <class Derived>
 template <class T>
 auto QuaternionBase<Derived>::cast() const {

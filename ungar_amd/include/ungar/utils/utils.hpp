@@ -9,10 +9,12 @@
 
 #include <cmath>
 #include <cstdio>
+#include <stdexcept>
 #include <string_view>
 #include <type_traits>
 
 #include "../autodiff/data_types.hpp"
+#include "../io/logging.hpp"
 
 namespace Ungar {
 namespace Utils {
@@ -89,6 +91,66 @@ inline S Abs(const S& a) {
 template <class S>
 inline S SmoothAbs(const S& a, const S& epsilon = S{std::numeric_limits<double>::epsilon()}) {
     return Sqrt(Pow(a, 2) + epsilon);
+}
+
+/// Rotations about the coordinate axes as unit quaternions (reference utils.hpp:906-925).
+template <class S>
+inline Quaternion<S> ElementaryXQuaternion(const S& angle) {
+    using std::cos;
+    using std::sin;
+    return Quaternion<S>{cos(angle / S{2.0}), sin(angle / S{2.0}), S{0.0}, S{0.0}};
+}
+template <class S>
+inline Quaternion<S> ElementaryYQuaternion(const S& angle) {
+    using std::cos;
+    using std::sin;
+    return Quaternion<S>{cos(angle / S{2.0}), S{0.0}, sin(angle / S{2.0}), S{0.0}};
+}
+template <class S>
+inline Quaternion<S> ElementaryZQuaternion(const S& angle) {
+    using std::cos;
+    using std::sin;
+    return Quaternion<S>{cos(angle / S{2.0}), S{0.0}, S{0.0}, sin(angle / S{2.0})};
+}
+
+/// [roll, pitch, yaw] of a unit quaternion (yaw = .z()).  Real scalars follow the reference's
+/// `toRotationMatrix().eulerAngles(2, 1, 0).reverse()` (utils.hpp:949-953), i.e. Eigen's convention
+/// with the yaw folded into [0, pi]; tape scalars use the branch-free atan2 form (utils.hpp:956-966).
+template <class Q>
+inline auto QuaternionToYawPitchRoll(const Eigen::QuaternionBase<Q>& q) {
+    using S = typename Eigen::QuaternionBase<Q>::S;
+    using std::atan2;
+    using std::cos;
+    using std::sin;
+    using std::sqrt;
+    const S x = q.x(), y = q.y(), z = q.z(), w = q.w();
+    const S r00 = 1.0 - 2.0 * (y * y + z * z), r01 = 2.0 * (x * y - w * z), r02 = 2.0 * (x * z + w * y);
+    const S r10 = 2.0 * (x * y + w * z), r11 = 1.0 - 2.0 * (x * x + z * z), r12 = 2.0 * (y * z - w * x);
+    const S r20 = 2.0 * (x * z - w * y), r21 = 2.0 * (y * z + w * x), r22 = 1.0 - 2.0 * (x * x + y * y);
+    if constexpr (is_ad_v<S>) {
+        (void)r01, (void)r02, (void)r11, (void)r12;
+        return Vector3<S>{atan2(r21, r22), atan2(-r20, sqrt(r21 * r21 + r22 * r22)), atan2(r10, r00)};
+    } else {
+        constexpr real_t pi = 3.14159265358979323846;
+        real_t yaw = std::atan2(r10, r00), pitch;
+        const real_t c2 = std::sqrt(r22 * r22 + r21 * r21);
+        if (yaw < 0.0) {
+            yaw += pi;
+            pitch = std::atan2(-r20, -c2);
+        } else {
+            pitch = std::atan2(-r20, c2);
+        }
+        const real_t s1 = std::sin(yaw), c1 = std::cos(yaw);
+        const real_t roll = std::atan2(s1 * r02 - c1 * r12, c1 * r11 - s1 * r01);
+        return Vector3<S>{roll, pitch, yaw};
+    }
+}
+
+/// The single coefficient of a 1-vector (reference utils.hpp:1026-1035).
+template <class V>
+inline auto Squeeze(const Eigen::MatrixBase<V>& m) {
+    if (m.size() != 1) throw std::invalid_argument("Utils::Squeeze: the argument must have exactly one coefficient");
+    return m[0];
 }
 
 /// Runs an AD lambda on doubles: arguments are cast to un-recorded AD literals and the result is
