@@ -33,3 +33,17 @@ def test_quadrotor_example_tracks_its_reference(repo_root, tmp_path):
     # height tracking: the MPC previews the reference, so the error stays a fraction of the 1 m amplitude
     assert max(abs(r[4] - r[5]) for r in late) < 0.15
     assert min(r[5] for r in late) < 3.4 and max(r[5] for r in late) > 4.6, "the quadrotor must actually follow the +-1 m sinusoid"
+
+
+RC_LINE = re.compile(r"t = ([\d.]+), obj = ([-\d.e+]+), eqs = ([-\d.e+]+), ineqs = ([-\d.e+]+), p ref = \[([-\d.]+), ([-\d.]+)\], p = \[([-\d.]+), ([-\d.]+)\]")
+
+
+@pytest.mark.gpu
+def test_rc_car_example_tracks_its_reference(repo_root, tmp_path):
+    """rc_car.example.cpp: the car must converge onto the reference path and stay on it."""
+    rows = [tuple(map(float, m.groups())) for m in map(RC_LINE.search, _run(repo_root, "rc_car", tmp_path, 600).splitlines()) if m]
+    assert len(rows) >= 290
+    late = [r for r in rows if r[0] > 2.0]
+    assert max(abs(r[2]) for r in late) < 1e-3
+    assert max(r[3] for r in late) < 1e-2
+    assert max(abs(r[4] - r[6]) + abs(r[5] - r[7]) for r in late) < 0.05

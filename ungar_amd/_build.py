@@ -106,9 +106,9 @@ def build_cpp_tests():
     """Host-side C++ programs exercising the facade headers (ungar_amd/include/ungar): run by
     tests/test_layout.py (CPU) and tests/test_cpp_facade.py (GPU box, prebuilt binaries travel)."""
     inc = os.path.join(ROOT, "ungar_amd", "include")
-    hdrs = _tree(inc, os.path.join(CSRC, "tape")) + [os.path.join(ROOT, "include", "ungar_amd.h")]
+    hdrs = _tree(inc, os.path.join(CSRC, "tape"), os.path.join(CSRC, "rbd")) + [os.path.join(ROOT, "include", "ungar_amd.h")]
     jobs = []
-    for name, link in (("layout_dump", False), ("function_test", True), ("quadrotor_ocp_test", True)):
+    for name, link in (("layout_dump", False), ("function_test", True), ("quadrotor_ocp_test", True), ("rbd_test", True)):
         src = os.path.join(ROOT, "tests", "cpp", f"{name}.cpp")
         exe = os.path.join(BUILD, name)
         if _newer([exe], [src, *hdrs] + ([LIB] if link else [])):

@@ -39,6 +39,9 @@ using MapToQuaternionr = Eigen::Map<Quaternionr>;
 using MapToConstQuaternionr = Eigen::Map<const Quaternionr>;
 
 template <class S>
+using MatrixX = Eigen::DenseMatrix<S>;
+using MatrixXr = MatrixX<real_t>;
+template <class S>
 using SparseMatrix = Eigen::SparseMatrixCsr<S>;  // row-major compressed view (function.hpp:375-383)
 
 namespace Concepts {

@@ -13,6 +13,7 @@
 #pragma once
 
 #include <array>
+#include <ostream>
 #include <cassert>
 #include <cmath>
 #include <cstddef>
@@ -430,6 +431,14 @@ class MatrixBase {
     }
 };
 
+/// Coefficients separated by blanks (Eigen prints column vectors one coefficient per line; one line reads
+/// better in a log message).
+template <class D>
+std::ostream& operator<<(std::ostream& os, const MatrixBase<D>& v) {
+    for (Index i = 0; i < v.size(); ++i) os << (i ? " " : "") << v[i];
+    return os;
+}
+
 namespace internal {
 template <class T>
 inline constexpr bool is_scalar_like_v = std::is_arithmetic_v<remove_cvref_t<T>> || requires(const remove_cvref_t<T>& t) { t.IsLiteral(); };
@@ -821,6 +830,59 @@ template <class Derived>
 template <class T>
 auto QuaternionBase<Derived>::cast() const {
     return Quaternion<T>{T{w()}, T{x()}, T{y()}, T{z()}};
+}
+
+/// Minimal dense matrix (column-major like Eigen's default): storage + element access + matrix-vector
+/// product; what the rigid-body quantities M(q) and M(q)^-1 are returned in.
+template <class S_>
+class DenseMatrix {
+  public:
+    using Scalar = S_;
+    DenseMatrix() = default;
+    DenseMatrix(Index rows, Index cols) : rows_{rows}, cols_{cols}, v_(static_cast<std::size_t>(rows * cols), S_{0.0}) {
+    }
+    Index rows() const { return rows_; }
+    Index cols() const { return cols_; }
+    Index size() const { return rows_ * cols_; }
+    S_& operator()(Index r, Index c) { return v_[static_cast<std::size_t>(c * rows_ + r)]; }
+    const S_& operator()(Index r, Index c) const { return v_[static_cast<std::size_t>(c * rows_ + r)]; }
+    S_* data() { return v_.data(); }
+    const S_* data() const { return v_.data(); }
+    void resize(Index rows, Index cols) {
+        rows_ = rows;
+        cols_ = cols;
+        v_.assign(static_cast<std::size_t>(rows * cols), S_{0.0});
+    }
+    template <class D>
+    auto operator*(const MatrixBase<D>& x) const {
+        Matrix<remove_cvref_helper<decltype(std::declval<S_>() * x[0])>, Dynamic> y(rows_);
+        for (Index r = 0; r < rows_; ++r) {
+            auto acc = (*this)(r, 0) * x[0];
+            for (Index c = 1; c < cols_; ++c) acc = acc + (*this)(r, c) * x[c];
+            y[r] = acc;
+        }
+        return y;
+    }
+    DenseMatrix transpose() const {
+        DenseMatrix t(cols_, rows_);
+        for (Index r = 0; r < rows_; ++r)
+            for (Index c = 0; c < cols_; ++c) t(c, r) = (*this)(r, c);
+        return t;
+    }
+
+  private:
+    template <class T>
+    using remove_cvref_helper = std::remove_cv_t<std::remove_reference_t<T>>;
+    Index rows_ = 0, cols_ = 0;
+    std::vector<S_> v_;
+};
+template <class S_>
+std::ostream& operator<<(std::ostream& os, const DenseMatrix<S_>& m) {
+    for (Index r = 0; r < m.rows(); ++r) {
+        for (Index c = 0; c < m.cols(); ++c) os << (c ? " " : "") << m(r, c);
+        if (r + 1 < m.rows()) os << "\n";
+    }
+    return os;
 }
 
 /// Minimal row-major compressed sparse matrix (what Function::Jacobian/Hessian return a view of,

@@ -1,0 +1,94 @@
+// ungar_amd :: Robot<Scalar> -- a kinematic tree loaded from a robot description plus the data its
+// rigid-body algorithms write to (reference include/ungar/rbd/robot.hpp:39-104).
+//
+// The description is a URDF file (read by ungar_amd's own XML reader: revolute / fixed joints, inertial
+// tags; fixed-joint links are lumped into their parents as Pinocchio does) or the `.robot` text form of
+// the same content shipped under ungar_amd/data; the root is a free-flyer, q = [p, quaternion xyzw,
+// joint angles], v = [body-frame linear, angular velocity, joint rates].
+#pragma once
+
+#include <memory>
+#include <random>
+#include <string>
+
+#include "quantities/quantities.hpp"
+
+namespace Ungar {
+
+template <Concepts::Scalar S = real_t>
+class Robot {
+  public:
+    explicit Robot(const std::string& descriptionFilename) : _data{std::make_unique<RBD::Data<S>>()} {
+        namespace rbd = ::ungar_amd::rbd;
+        _model.impl = rbd::BuildModel(rbd::ReadRobotDescription(descriptionFilename));
+        _model.name = _model.impl.name;
+        _model.nq = _model.impl.nq;
+        _model.nv = _model.impl.nv;
+        _model.njoints = _model.impl.NumJoints();
+        for (const auto& j : _model.impl.joints) _model.names.push_back(j.name);
+    }
+    Robot(const Robot& other) : _model{other._model}, _data{std::make_unique<RBD::Data<S>>()} {
+    }
+    Robot(Robot&&) = default;
+
+    constexpr auto Compute(auto quantity) {
+        return RBD::Evaluator<quantity, S>{_model, *_data};
+    }
+    decltype(auto) Get(auto quantity) const {
+        return std::as_const(*_data).*Member(quantity);
+    }
+    decltype(auto) Get(auto quantity) {
+        auto getter = RBD::Getter<quantity, S>{_model, *_data};
+        return getter.Get();
+    }
+
+    const RBD::ModelInfo& Model() const {
+        return _model;
+    }
+    const RBD::Data<S>& Data() const {
+        return *_data;
+    }
+    RBD::Data<S>& Data() {
+        return *_data;
+    }
+
+    /// Uniform position in [-1, 1]^3, uniform random unit quaternion, joint angles in [-pi, pi].
+    VectorX<S> RandomConfiguration() const {
+        static std::mt19937_64 rng{0x5EEDu};
+        std::uniform_real_distribution<double> U{-1.0, 1.0};
+        std::normal_distribution<double> G{0.0, 1.0};
+        VectorX<S> q{static_cast<index_t>(_model.nq)};
+        for (index_t i = 0; i < q.size(); ++i) q[i] = S{U(rng) * (i < 3 ? 1.0 : 3.14159265358979323846)};
+        double quat[4], n = 0;
+        for (double& c : quat) n += (c = G(rng)) * c;
+        for (int k = 0; k < 4; ++k) q[3 + k] = S{quat[k] / std::sqrt(n)};
+        return q;
+    }
+
+  private:
+    template <class Q>
+    static constexpr auto Member(Q quantity) {
+        // const access goes through the mutable getter's member: resolve which Data member it names
+        return MemberOf(quantity);
+    }
+    template <class Q>
+    static constexpr auto MemberOf(Q) {
+        namespace qs = RBD::Quantities;
+        if constexpr (std::is_same_v<Q, qs::generalized_accelerations_t>) return &RBD::Data<S>::ddq;
+        else if constexpr (std::is_same_v<Q, qs::joint_torques_t>) return &RBD::Data<S>::tau;
+        else if constexpr (std::is_same_v<Q, qs::nonlinear_effects_t>) return &RBD::Data<S>::nle;
+        else if constexpr (std::is_same_v<Q, qs::generalized_gravity_t>) return &RBD::Data<S>::g;
+        else if constexpr (std::is_same_v<Q, qs::joint_space_inertia_matrix_t>) return &RBD::Data<S>::M;
+        else if constexpr (std::is_same_v<Q, qs::joint_space_inertia_matrix_inverse_t>) return &RBD::Data<S>::Minv;
+        else if constexpr (std::is_same_v<Q, qs::com_position_t>) return &RBD::Data<S>::com;
+        else if constexpr (std::is_same_v<Q, qs::com_velocity_t>) return &RBD::Data<S>::vcom;
+        else if constexpr (std::is_same_v<Q, qs::com_acceleration_t>) return &RBD::Data<S>::acom;
+        else if constexpr (std::is_same_v<Q, qs::kinetic_energy_t>) return &RBD::Data<S>::kinetic_energy;
+        else return &RBD::Data<S>::potential_energy;
+    }
+
+    RBD::ModelInfo _model;
+    std::unique_ptr<RBD::Data<S>> _data;
+};
+
+}  // namespace Ungar

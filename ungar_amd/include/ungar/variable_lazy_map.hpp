@@ -6,6 +6,9 @@
 // dynamic-size Map.  No copies; works for Scalar in {real_t, ad_scalar_t}.
 #pragma once
 
+#include <algorithm>
+#include <map>
+#include <memory>
 #include <tuple>
 
 #include "data_types.hpp"
@@ -32,7 +35,7 @@ class VariableLazyMap {
         return _data;
     }
 
-  private:
+    /// View of an already resolved sub-variable (a result of Variable::operator()).
     template <class V>
     decltype(auto) View(const V& v) const {
         Ptr p = _data + (v.Index() - _var.Index());
@@ -46,6 +49,8 @@ class VariableLazyMap {
             return Eigen::Map<std::conditional_t<MUTABLE, VectorX<Scalar>, const VectorX<Scalar>>>{p, V::Size()};
         }
     }
+
+  private:
     Ptr _data;
     Var _var;
 };
@@ -64,35 +69,83 @@ auto MakeMVariableLazyMap(Underlying& underlying, const Var& var) {
     return MakeVariableLazyMap(underlying, var);
 }
 
-/// Owning map (reference variable_map.hpp:41-221).
+/// Owning map (reference variable_map.hpp:41-221).  Like the reference's, Get hands out REFERENCES to view
+/// objects owned by the map (`Eigen::Map<Vector3r>&`, `real_t&`, ...), so a view can be bound once and
+/// reused; the reference builds its table of views eagerly at construction, here a view is created the
+/// first time it is asked for and then kept (same observable types and lifetimes).
 template <class Scalar, Concepts::Variable Var>
 class VariableMap {
   public:
     explicit VariableMap(const Var& var) : _underlying(Var::Size()), _var{var} {
         _underlying.setZero();
     }
+    VariableMap(const VariableMap& o) : _underlying{o._underlying}, _var{o._var} {  // views are per-buffer: not copied
+    }
+    VariableMap(VariableMap&&) = default;  // the heap buffer moves along, cached views stay valid
+    VariableMap& operator=(const VariableMap& o) {
+        if (this != &o) {
+            if (_underlying.size() == o._underlying.size()) std::copy(o._underlying.data(), o._underlying.data() + o._underlying.size(), _underlying.data());
+            else {
+                _views.clear();
+                _underlying = o._underlying;
+            }
+        }
+        return *this;
+    }
+    VariableMap& operator=(VariableMap&&) = default;
+
     template <class... Args>
     decltype(auto) Get(const Args&... args) {
         if constexpr (sizeof...(Args) == 0) return (_underlying);
-        else return VariableLazyMap<Scalar, Var, true>{_underlying.data(), _var}.Get(args...);
+        else return Cached<true>(_var(args...));
     }
     template <class... Args>
     decltype(auto) Get(const Args&... args) const {
         if constexpr (sizeof...(Args) == 0) return (_underlying);
-        else return VariableLazyMap<Scalar, Var, false>{_underlying.data(), _var}.Get(args...);
+        else return Cached<false>(_var(args...));
     }
     template <class... Vars>
     auto GetTuple(const Vars&... vars) {
-        return VariableLazyMap<Scalar, Var, true>{_underlying.data(), _var}.GetTuple(vars...);
+        return std::tuple<decltype(Get(vars))...>{Get(vars)...};
     }
     template <class... Vars>
     auto GetTuple(const Vars&... vars) const {
-        return VariableLazyMap<Scalar, Var, false>{_underlying.data(), _var}.GetTuple(vars...);
+        return std::tuple<decltype(Get(vars))...>{Get(vars)...};
     }
 
   private:
+    struct Erased {
+        virtual ~Erased() = default;
+    };
+    template <class M>
+    struct Holder : Erased {
+        explicit Holder(M m) : view{std::move(m)} {
+        }
+        M view;
+    };
+    template <bool MUTABLE, class V>
+    decltype(auto) Cached(const V& v) const {
+        using P = std::conditional_t<MUTABLE, Scalar*, const Scalar*>;
+        P p = const_cast<P>(_underlying.data()) + (v.Index() - _var.Index());
+        if constexpr (V::IsScalar()) {
+            return (*p);
+        } else {
+            using M = std::remove_cvref_t<decltype(VariableLazyMap<Scalar, Var, MUTABLE>{p, _var}.View(v))>;
+            // key: offset, size, mutability, quaternion-ness (a 4-vector and a quaternion may share an offset)
+            const std::tuple<index_t, index_t, bool, bool> key{v.Index(), V::Size(), MUTABLE, V::IsQuaternion()};
+            auto it = _views.find(key);
+            if (it == _views.end()) {
+                VariableLazyMap<Scalar, Var, MUTABLE> lazy{const_cast<P>(_underlying.data()), _var};
+                it = _views.emplace(key, std::make_unique<Holder<M>>(lazy.View(v))).first;
+            }
+            if constexpr (MUTABLE) return (static_cast<Holder<M>&>(*it->second).view);
+            else return (static_cast<const Holder<M>&>(*it->second).view);
+        }
+    }
+
     VectorX<Scalar> _underlying;
     Var _var;
+    mutable std::map<std::tuple<index_t, index_t, bool, bool>, std::unique_ptr<Erased>> _views;
 };
 
 template <class Scalar, Concepts::Variable Var>
