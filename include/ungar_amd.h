@@ -116,6 +116,13 @@ int ungar_model_dense_jacobian(const ungar_model* model, const ungar_node_batch*
 int ungar_gn_hessian(const double* jac, int64_t js, int64_t ld_j, const double* d, int64_t ds, double* g, int64_t gs, int64_t ld_g,
                      int32_t rows, int32_t cols, int64_t count, void* stream);
 
+/* Same contraction, UPPER triangle only: entries with row <= col are written, the rest of `g` is left
+ * untouched.  The reference keeps Hessians upper-triangular (function.hpp:236-274) and its QP reads only
+ * the upper triangle of the objective matrix (soft_sqp.hpp:143-152), so this is what the SQP consumer
+ * needs: 10 of 16 tile products, half the bytes written. */
+int ungar_gn_hessian_upper(const double* jac, int64_t js, int64_t ld_j, const double* d, int64_t ds, double* g, int64_t gs, int64_t ld_g,
+                           int32_t rows, int32_t cols, int64_t count, void* stream);
+
 /* ---- whole-horizon assembly ------------------------------------------ */
 
 /* Sparsity of the equality-constraint Jacobian  d g / d [X | U]  of a horizon-N OCP built on `model`,

@@ -262,3 +262,10 @@ def test_gn_hessian_mfma(ua):
         assert torch.isfinite(G).all()
         assert (G - ref).abs().max().item() <= 1e-12 * ref.abs().max().item()
         assert torch.equal(G, G.transpose(1, 2)) or (G - G.transpose(1, 2)).abs().max().item() < 1e-13
+        # upper-triangular variant: identical values on and above the diagonal, nothing written below it
+        U = torch.full((count, cols, cols), float("nan"), dtype=torch.float64, device="cuda")
+        ua.gn_hessian(J, d, U, rows, cols, count, upper_only=True)
+        torch.cuda.synchronize()
+        upper = torch.triu(torch.ones((cols, cols), dtype=torch.bool, device="cuda"))
+        assert torch.equal(U[:, upper], G[:, upper])
+        assert torch.isnan(U[:, ~upper]).all()

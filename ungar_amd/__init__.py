@@ -77,8 +77,9 @@ def load_library() -> ctypes.CDLL:
         getattr(lib, name).argtypes = [vp]
     for name in ("ungar_model_forward_zero", "ungar_model_sparse_jacobian", "ungar_model_dense_jacobian"):
         getattr(lib, name).argtypes = [vp, ctypes.POINTER(_NodeBatch), vp]
-    lib.ungar_gn_hessian.argtypes = [vp, ctypes.c_int64, ctypes.c_int64, vp, ctypes.c_int64, vp, ctypes.c_int64, ctypes.c_int64,
-                                     ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, vp]
+    for name in ("ungar_gn_hessian", "ungar_gn_hessian_upper"):
+        getattr(lib, name).argtypes = [vp, ctypes.c_int64, ctypes.c_int64, vp, ctypes.c_int64, vp, ctypes.c_int64, ctypes.c_int64,
+                                       ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, vp]
     lib.ungar_ocp_equality_sparsity.argtypes = [vp, ctypes.c_int64, vp, vp, i64p]
     lib.ungar_ocp_assemble_equality.argtypes = [vp, ctypes.c_int64, ctypes.c_int64] + [ctypes.POINTER(_Operand)] * 6 + [vp]
     lib.ungar_last_error.restype = ctypes.c_char_p
@@ -266,11 +267,12 @@ class NodeModel:
         return f, j.reshape(count, self.ny, ncols)
 
 
-def gn_hessian(jac, d, g, rows: int, cols: int, count: int, ld_j=None, ld_g=None, stream=None):
+def gn_hessian(jac, d, g, rows: int, cols: int, count: int, ld_j=None, ld_g=None, stream=None, upper_only=False):
     """G = J^T diag(d) J per node on the FP64 matrix cores.  jac: (count, rows, ld_j) node-major,
-    d: (count, rows) or None, g: (count, cols, ld_g); all float64 CUDA tensors."""
+    d: (count, rows) or None, g: (count, cols, ld_g); all float64 CUDA tensors.  upper_only: write only
+    the entries with row <= col (the rest of g is left untouched)."""
     lib = load_library()
     ld_j = cols if ld_j is None else ld_j
     ld_g = cols if ld_g is None else ld_g
-    _check(lib.ungar_gn_hessian(jac.data_ptr(), rows * ld_j, ld_j, d.data_ptr() if d is not None else None, rows, g.data_ptr(),
+    _check((lib.ungar_gn_hessian_upper if upper_only else lib.ungar_gn_hessian)(jac.data_ptr(), rows * ld_j, ld_j, d.data_ptr() if d is not None else None, rows, g.data_ptr(),
                                 cols * ld_g, ld_g, rows, cols, count, NodeModel._stream(stream)))

@@ -9,15 +9,18 @@
 //     A-operand (16x4)  = (J^T D)[16 ta + (l & 15)][4 ks + (l >> 4)]
 //     B-operand (4x16)  =  J     [4 ks + (l >> 4)][16 tb + (l & 15)]
 // so both operands of every tile pair come from the SAME four loads per k-step (one per column
-// tile); no LDS is needed.  All T x T tiles are computed (not just the upper triangle) so that the
-// full symmetric block is written with coalesced 128-byte row segments.
+// tile); no LDS is needed.  UPPER = false computes all T x T tiles and writes the full symmetric block
+// with coalesced 128-byte row segments; UPPER = true computes only the T (T + 1) / 2 tiles on and above
+// the diagonal and writes only the entries with row <= col (what the QP's objective matrix uses:
+// Hessians are upper-triangular throughout the reference, function.hpp:236-274) -- 37 % fewer MFMAs,
+// half the bytes written, fewer accumulators and hence one more wavefront per SIMD.
 #include <hip/hip_runtime.h>
 
 namespace ungar_amd::kernels {
 
 using f64x4 = __attribute__((__vector_size__(4 * sizeof(double)))) double;
 
-template <int T>  // number of 16-wide column tiles, cols <= 16 T
+template <int T, bool UPPER>  // T = number of 16-wide column tiles, cols <= 16 T
 __global__ __launch_bounds__(256) void GnHessianKernel(const double* __restrict__ jac, long long js, long long ldj,
                                                        const double* __restrict__ d, long long ds, double* __restrict__ g,
                                                        long long gs, long long ldg, int rows, int cols, long long count) {
@@ -58,7 +61,7 @@ __global__ __launch_bounds__(256) void GnHessianKernel(const double* __restrict_
             for (int a = 0; a < T; ++a) {
                 const double av = jv[kk][a] * wv[kk];
 #pragma unroll
-                for (int b = 0; b < T; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, jv[kk][b], acc[a][b], 0, 0, 0);
+                for (int b = UPPER ? a : 0; b < T; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, jv[kk][b], acc[a][b], 0, 0, 0);
             }
         }
     }
@@ -69,27 +72,39 @@ __global__ __launch_bounds__(256) void GnHessianKernel(const double* __restrict_
 #pragma unroll
     for (int a = 0; a < T; ++a)
 #pragma unroll
-        for (int b = 0; b < T; ++b)
+        for (int b = UPPER ? a : 0; b < T; ++b)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int row = 16 * a + 4 * reg + lk, col = 16 * b + lc;
-                if (row < cols && col < cols) G[static_cast<long long>(row) * ldg + col] = acc[a][b][reg];
+                if (row < cols && col < cols && (!UPPER || row <= col)) G[static_cast<long long>(row) * ldg + col] = acc[a][b][reg];
             }
 }
 
 }  // namespace ungar_amd::kernels
 
 extern "C" int ungar_amd_launch_gn_hessian(const double* jac, long long js, long long ldj, const double* d, long long ds, double* g,
-                                            long long gs, long long ldg, int rows, int cols, long long count, void* stream) {
+                                            long long gs, long long ldg, int rows, int cols, long long count, int upperOnly, void* stream) {
     using namespace ungar_amd::kernels;
     const int wavesPerBlock = 4;
     const dim3 grid(static_cast<unsigned>((count + wavesPerBlock - 1) / wavesPerBlock)), block(64 * wavesPerBlock);
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch ((cols + 15) / 16) {
-        case 1: hipLaunchKernelGGL(GnHessianKernel<1>, grid, block, 0, s, jac, js, ldj, d, ds, g, gs, ldg, rows, cols, count); break;
-        case 2: hipLaunchKernelGGL(GnHessianKernel<2>, grid, block, 0, s, jac, js, ldj, d, ds, g, gs, ldg, rows, cols, count); break;
-        case 3: hipLaunchKernelGGL(GnHessianKernel<3>, grid, block, 0, s, jac, js, ldj, d, ds, g, gs, ldg, rows, cols, count); break;
-        case 4: hipLaunchKernelGGL(GnHessianKernel<4>, grid, block, 0, s, jac, js, ldj, d, ds, g, gs, ldg, rows, cols, count); break;
+        case 1:
+            if (upperOnly) hipLaunchKernelGGL((GnHessianKernel<1, true>), grid, block, 0, s, jac, js, ldj, d, ds, g, gs, ldg, rows, cols, count);
+            else hipLaunchKernelGGL((GnHessianKernel<1, false>), grid, block, 0, s, jac, js, ldj, d, ds, g, gs, ldg, rows, cols, count);
+            break;
+        case 2:
+            if (upperOnly) hipLaunchKernelGGL((GnHessianKernel<2, true>), grid, block, 0, s, jac, js, ldj, d, ds, g, gs, ldg, rows, cols, count);
+            else hipLaunchKernelGGL((GnHessianKernel<2, false>), grid, block, 0, s, jac, js, ldj, d, ds, g, gs, ldg, rows, cols, count);
+            break;
+        case 3:
+            if (upperOnly) hipLaunchKernelGGL((GnHessianKernel<3, true>), grid, block, 0, s, jac, js, ldj, d, ds, g, gs, ldg, rows, cols, count);
+            else hipLaunchKernelGGL((GnHessianKernel<3, false>), grid, block, 0, s, jac, js, ldj, d, ds, g, gs, ldg, rows, cols, count);
+            break;
+        case 4:
+            if (upperOnly) hipLaunchKernelGGL((GnHessianKernel<4, true>), grid, block, 0, s, jac, js, ldj, d, ds, g, gs, ldg, rows, cols, count);
+            else hipLaunchKernelGGL((GnHessianKernel<4, false>), grid, block, 0, s, jac, js, ldj, d, ds, g, gs, ldg, rows, cols, count);
+            break;
         default: return static_cast<int>(hipErrorInvalidValue);
     }
     return static_cast<int>(hipGetLastError());

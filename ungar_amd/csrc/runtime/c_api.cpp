@@ -51,7 +51,7 @@ struct OcpAssemblyArgs {
 extern "C" int ungar_amd_launch_ocp_assemble(const ungar_amd::kernels::OcpAssemblyArgs* a, void* stream);
 
 extern "C" int ungar_amd_launch_gn_hessian(const double* jac, long long js, long long ldj, const double* d, long long ds, double* g,
-                                            long long gs, long long ldg, int rows, int cols, long long count, void* stream);
+                                            long long gs, long long ldg, int rows, int cols, long long count, int upperOnly, void* stream);
 
 namespace {
 thread_local std::string g_lastError;
@@ -199,16 +199,30 @@ int ungar_model_dense_jacobian(const ungar_model* model, const ungar_node_batch*
     return Evaluate(model, batch, stream, ungar_amd::kernels::kModeDenseJacobian);
 }
 
+namespace {
+int GnHessian(const double* jac, int64_t js, int64_t ld_j, const double* d, int64_t ds, double* g, int64_t gs, int64_t ld_g, int32_t rows, int32_t cols,
+              int64_t count, int upperOnly, void* stream);
+}
 int ungar_gn_hessian(const double* jac, int64_t js, int64_t ld_j, const double* d, int64_t ds, double* g, int64_t gs, int64_t ld_g,
                      int32_t rows, int32_t cols, int64_t count, void* stream) {
+    return GnHessian(jac, js, ld_j, d, ds, g, gs, ld_g, rows, cols, count, 0, stream);
+}
+int ungar_gn_hessian_upper(const double* jac, int64_t js, int64_t ld_j, const double* d, int64_t ds, double* g, int64_t gs, int64_t ld_g,
+                           int32_t rows, int32_t cols, int64_t count, void* stream) {
+    return GnHessian(jac, js, ld_j, d, ds, g, gs, ld_g, rows, cols, count, 1, stream);
+}
+namespace {
+int GnHessian(const double* jac, int64_t js, int64_t ld_j, const double* d, int64_t ds, double* g, int64_t gs, int64_t ld_g, int32_t rows, int32_t cols,
+              int64_t count, int upperOnly, void* stream) {
     if (!jac || !g) return Fail(UNGAR_E_INVALID, "ungar_gn_hessian: null jac or g");
     if (rows <= 0 || cols <= 0 || count < 0 || ld_j < cols || ld_g < cols) return Fail(UNGAR_E_INVALID, "ungar_gn_hessian: bad dimensions");
     if (cols > 64) return Fail(UNGAR_E_UNSUPPORTED, "ungar_gn_hessian: cols > 64 not supported (one wavefront tile set per node)");
     if (count == 0) return UNGAR_OK;
-    const int err = ungar_amd_launch_gn_hessian(jac, js, ld_j, d, ds, g, gs, ld_g, rows, cols, count, stream);
+    const int err = ungar_amd_launch_gn_hessian(jac, js, ld_j, d, ds, g, gs, ld_g, rows, cols, count, upperOnly, stream);
     if (err != 0) return Fail(UNGAR_E_HIP, std::string("gn_hessian launch failed: ") + hipGetErrorString(static_cast<hipError_t>(err)));
     return UNGAR_OK;
 }
+}  // namespace
 
 int ungar_ocp_equality_sparsity(const ungar_model* model, int64_t horizon, int32_t* row_starts, int32_t* cols, int64_t* nnz) {
     if (!model || !nnz || horizon < 1) return Fail(UNGAR_E_INVALID, "ungar_ocp_equality_sparsity: bad argument");
