@@ -32,6 +32,16 @@ struct NodeLaunch {
 
 enum : int { kModeValue = 0, kModeSparseJacobian = 1, kModeDenseJacobian = 2 };
 
+/// Output store of the node kernels: non-temporal, the results are never re-read by the kernel
+/// (-DUNGAR_TEMPORAL_STORES restores plain stores for A/B runs).
+__device__ __forceinline__ void StoreResult(double* p, double v) {
+#ifndef UNGAR_TEMPORAL_STORES
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
 /// I/O policy: every lane addresses its own node through (base, element stride).
 template <int NCOLS, bool DENSE>
 struct StridedIO {
@@ -48,10 +58,10 @@ struct StridedIO {
     __device__ __forceinline__ double w(int i) const { return wb[i * we]; }
     __device__ __forceinline__ double p(int i) const { return pb[i * pe]; }
     __device__ __forceinline__ void f(int i, double v) const {
-        if (fb) fb[i * fe] = v;
+        if (fb) StoreResult(fb + i * fe, v);
     }
     __device__ __forceinline__ void j(int k, int r, int c, double v) const {
-        jb[(DENSE ? r * NCOLS + c : k) * je] = v;
+        StoreResult(jb + (DENSE ? r * NCOLS + c : k) * je, v);
     }
 };
 
@@ -77,7 +87,7 @@ constexpr int ZeroOffset(int z) {
 template <class M, std::size_t... Z>
 __device__ __forceinline__ void StoreZeros(double* __restrict__ jb, long long je, std::index_sequence<Z...>) {
     // offsets are compile-time constants; one plain store per structural zero
-    ((jb[static_cast<long long>(std::integral_constant<int, ZeroOffset<M>(static_cast<int>(Z))>::value) * je] = 0.0), ...);
+    (StoreResult(jb + static_cast<long long>(std::integral_constant<int, ZeroOffset<M>(static_cast<int>(Z))>::value) * je, 0.0), ...);
 }
 
 }  // namespace detail
