@@ -32,7 +32,8 @@ class UngarError(RuntimeError):
 
 
 def library_path() -> str:
-    return os.path.join(_HERE, "lib", "libungar_amd.so")
+    """In-tree library; UNGAR_AMD_LIBRARY overrides it (A/B builds of the same ABI)."""
+    return os.environ.get("UNGAR_AMD_LIBRARY") or os.path.join(_HERE, "lib", "libungar_amd.so")
 
 
 class _ModelInfo(ctypes.Structure):

@@ -470,6 +470,7 @@ int main(int argc, char** argv) {
                    << "inline constexpr int kNumConstants = " << qp.constants.size() << ";\n"
                    << "inline constexpr int kLdsSlots = " << quadLds << ";  // per-lane LDS slots of the phased body\n"
                    << "inline constexpr int kLdsUniformSlots = " << quadUniformUsed << ";  // per-quad (lane-uniform) LDS slots\n"
+                   << "inline constexpr int kJacNnz = " << adv.jac.Nnz() << ";  // entries of the sparse (CSR) output\n"
                    << "// leg constants that differ between legs, [k][leg]; legs in model order (LF, LH, RF, RH)\n"
                    << "inline constexpr double kLegConstants[" << std::max<std::size_t>(1, qp.constants.size()) << "][4] = {\n";
                 for (const auto& c : qp.constants) {

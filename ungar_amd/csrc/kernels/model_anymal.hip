@@ -12,7 +12,8 @@ UNGAR_AMD_DEFINE_NODE_TRAITS(anymal)
 
 namespace ungar_amd::kernels {
 struct AnymalQuadBody {
-    __device__ __forceinline__ void operator()(QuadIO<false>& io) const { gen::anymal_quad::ValueJacobianQuad<double>(io); }
+    template <class IO>
+    __device__ __forceinline__ void operator()(IO& io) const { gen::anymal_quad::ValueJacobianQuad<double>(io); }
 };
 }  // namespace ungar_amd::kernels
 
@@ -32,7 +33,12 @@ extern "C" int ungar_amd_launch_anymal(int mode, const ungar_amd::kernels::NodeL
     if (e != hipSuccess) return static_cast<int>(e);
     const double(*ctab)[4] = static_cast<const double(*)[4]>(sym);
     const dim3 grid(static_cast<unsigned>((a->count + kBlock / 4 - 1) / (kBlock / 4))), block(kBlock);
-    hipLaunchKernelGGL((QuadNodeKernel<kBlock, ungar_amd::gen::anymal_quad::kLdsSlots, ungar_amd::gen::anymal_quad::kLdsUniformSlots, false, AnymalQuadBody>), grid, block, 0, static_cast<hipStream_t>(stream), *a, ctab,
-                       AnymalQuadBody{});
+    namespace Q = ungar_amd::gen::anymal_quad;
+    if (UseStreamingStores(*a, mode, 37 * 49, 37))
+        hipLaunchKernelGGL((QuadNodeKernel<kBlock, Q::kLdsSlots, Q::kLdsUniformSlots, false, true, AnymalQuadBody>), grid, block, 0, static_cast<hipStream_t>(stream), *a, ctab,
+                           AnymalQuadBody{});
+    else
+        hipLaunchKernelGGL((QuadNodeKernel<kBlock, Q::kLdsSlots, Q::kLdsUniformSlots, false, false, AnymalQuadBody>), grid, block, 0, static_cast<hipStream_t>(stream), *a, ctab,
+                           AnymalQuadBody{});
     return static_cast<int>(hipGetLastError());
 }

@@ -7,7 +7,8 @@
 
 namespace ungar_amd::kernels {
 struct AnymalQuadSparseBody {
-    __device__ __forceinline__ void operator()(QuadIO<true>& io) const { gen::anymal_quad::ValueJacobianQuad<double>(io); }
+    template <class IO>
+    __device__ __forceinline__ void operator()(IO& io) const { gen::anymal_quad::ValueJacobianQuad<double>(io); }
 };
 }  // namespace ungar_amd::kernels
 
@@ -20,7 +21,12 @@ extern "C" int ungar_amd_launch_anymal_quad_sparse(const ungar_amd::kernels::Nod
     if (e != hipSuccess) return static_cast<int>(e);
     const double(*ctab)[4] = static_cast<const double(*)[4]>(sym);
     const dim3 grid(static_cast<unsigned>((a->count + kBlock / 4 - 1) / (kBlock / 4))), block(kBlock);
-    hipLaunchKernelGGL((QuadNodeKernel<kBlock, ungar_amd::gen::anymal_quad::kLdsSlots, ungar_amd::gen::anymal_quad::kLdsUniformSlots, true, AnymalQuadSparseBody>), grid, block, 0, static_cast<hipStream_t>(stream), *a,
-                       ctab, AnymalQuadSparseBody{});
+    namespace Q = ungar_amd::gen::anymal_quad;
+    if (UseStreamingStores(*a, kModeSparseJacobian, Q::kJacNnz, 37))
+        hipLaunchKernelGGL((QuadNodeKernel<kBlock, Q::kLdsSlots, Q::kLdsUniformSlots, true, true, AnymalQuadSparseBody>), grid, block, 0, static_cast<hipStream_t>(stream), *a,
+                           ctab, AnymalQuadSparseBody{});
+    else
+        hipLaunchKernelGGL((QuadNodeKernel<kBlock, Q::kLdsSlots, Q::kLdsUniformSlots, true, false, AnymalQuadSparseBody>), grid, block, 0, static_cast<hipStream_t>(stream), *a,
+                           ctab, AnymalQuadSparseBody{});
     return static_cast<int>(hipGetLastError());
 }

@@ -30,7 +30,7 @@ __device__ __forceinline__ double QuadPerm(double v) {
 /// leg-dependent rows/columns through per-lane offsets computed once.  Every Jacobian sink of the
 /// generated program carries both addressings -- (row, column) of the dense block and, per lane, the
 /// index k of the entry in the CSR value array (-1 = structural zero); SPARSE picks the second.
-template <bool SPARSE>
+template <bool SPARSE, bool STREAM = false>
 struct QuadIO {
     const double* __restrict__ xb;  // node's x (element stride xe)
     const double* __restrict__ ub;
@@ -77,14 +77,9 @@ struct QuadIO {
     __device__ __forceinline__ double quad_rot2(double v) const { return QuadPerm<0x128>(v); }  // from leg L + 2
     __device__ __forceinline__ double quad_rot3(double v) const { return QuadPerm<0x124>(v); }  // from leg L + 3
 
-    /// Output store: non-temporal (results are never re-read by the kernel; measured 0.340 -> 0.322 ms).
-    /// -DUNGAR_QUAD_TEMPORAL_STORES restores plain stores for A/B runs.
+    /// Output store; STREAM = non-temporal (node_kernel.hpp: StoreResult / UseStreamingStores).
     static __device__ __forceinline__ void Put(double* p, double v) {
-#ifndef UNGAR_QUAD_TEMPORAL_STORES
-        __builtin_nontemporal_store(v, p);
-#else
-        *p = v;
-#endif
+        StoreResult<STREAM>(p, v);
     }
     // base rows / shared columns: all four lanes hold the same value and store it to the same address
     // (merged inside the instruction) -- cheaper than masking three lanes off with exec-mask branches
@@ -136,7 +131,7 @@ struct QuadIO {
 };
 
 /// GEN is the generated namespace (ValueJacobianQuad, kLegConstantsDev).  BLOCK lanes = BLOCK/4 nodes.
-template <int BLOCK, int LDS_SLOTS, int LDS_USLOTS, bool SPARSE, class Body>
+template <int BLOCK, int LDS_SLOTS, int LDS_USLOTS, bool SPARSE, bool STREAM, class Body>
 __global__ __launch_bounds__(BLOCK) void QuadNodeKernel(const NodeLaunch a, const double (*ctab)[4], Body body) {
     static_assert(BLOCK == 64, "the LDS home is laid out for one wavefront per workgroup");
     __shared__ double lds[(LDS_SLOTS > 0 ? LDS_SLOTS : 1) * BLOCK + LDS_USLOTS * (BLOCK / 4)];
@@ -153,7 +148,7 @@ __global__ __launch_bounds__(BLOCK) void QuadNodeKernel(const NodeLaunch a, cons
     double* const jb = a.jac.base + b * a.jac.bs + k * a.jac.ks;
     const long long je = a.jac.es;
     double* const jLeg = jb + 3LL * L * 49 * je;
-    QuadIO<SPARSE> io{a.x.base + b * a.x.bs + k * a.x.ks,
+    QuadIO<SPARSE, STREAM> io{a.x.base + b * a.x.bs + k * a.x.ks,
               a.u.base + b * a.u.bs + k * a.u.ks,
               a.p.base + b * a.p.bs + k * a.p.ks,
               fb,
