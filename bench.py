@@ -183,7 +183,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as fh:
-                traffic = json.load(fh).get(f"{args.workload}:{batch}") if args.jacobian == "dense" else None
+                traffic = json.load(fh).get(f"{args.workload}:{batch}") if args.jacobian == "dense" and kernel_model == model_name else None
         out = {
             "metric": "shooting-node Jacobian evals/sec",
             "value": total_evals / elapsed,
