@@ -123,6 +123,13 @@ int ungar_gn_hessian(const double* jac, int64_t js, int64_t ld_j, const double* 
 int ungar_gn_hessian_upper(const double* jac, int64_t js, int64_t ld_j, const double* d, int64_t ds, double* g, int64_t gs, int64_t ld_g,
                            int32_t rows, int32_t cols, int64_t count, void* stream);
 
+/* The same upper-triangular contraction for a Jacobian in the UNIT-FASTEST layout, i.e. exactly what
+ * ungar_model_dense_jacobian writes fastest: entry (r, c) of node i at jac[(r * cols + c) * j_es + i]
+ * (nodes contiguous), weights at d[r * d_es + i] (or null).  The result is node-major as above.  Removes
+ * the transpose between the node kernel and the Gauss-Newton term (soft_sqp.hpp:257-264). */
+int ungar_gn_hessian_upper_unit_fastest(const double* jac, int64_t j_es, const double* d, int64_t d_es, double* g, int64_t gs, int64_t ld_g,
+                                        int32_t rows, int32_t cols, int64_t count, void* stream);
+
 /* ---- whole-horizon assembly ------------------------------------------ */
 
 /* Sparsity of the equality-constraint Jacobian  d g / d [X | U]  of a horizon-N OCP built on `model`,

@@ -269,3 +269,10 @@ def test_gn_hessian_mfma(ua):
         upper = torch.triu(torch.ones((cols, cols), dtype=torch.bool, device="cuda"))
         assert torch.equal(U[:, upper], G[:, upper])
         assert torch.isnan(U[:, ~upper]).all()
+        # the same contraction fed with the unit-fastest layout the node kernels write
+        S = torch.full((count, cols, cols), float("nan"), dtype=torch.float64, device="cuda")
+        Jt = J.reshape(count, rows * cols).t().contiguous()
+        ua.gn_hessian_unit_fastest(Jt, d.t().contiguous() if weighted else None, S, rows, cols, count)
+        torch.cuda.synchronize()
+        assert (S[:, upper] - ref[:, upper]).abs().max().item() <= 1e-12 * ref.abs().max().item()
+        assert torch.isnan(S[:, ~upper]).all()

@@ -17,6 +17,20 @@ ms = sum(s.elapsed_time(e) for s, e in evs) / len(evs)
 bytes_ = count * 8 * (rows * cols + rows + cols * cols)
 tiles = ((cols + 15) // 16) ** 2
 flops_issued = count * tiles * ((rows + 3) // 4) * 2048
+if "--unit-fastest" in sys.argv:
+    Jt = J.reshape(count, rows * cols).t().contiguous()
+    dt = d.t().contiguous()
+    for _ in range(3): ungar_amd.gn_hessian_unit_fastest(Jt, dt, G, rows, cols, count)
+    torch.cuda.synchronize()
+    for s, e in evs:
+        s.record(); ungar_amd.gn_hessian_unit_fastest(Jt, dt, G, rows, cols, count); e.record()
+    torch.cuda.synchronize()
+    ms = sum(s.elapsed_time(e) for s, e in evs) / len(evs)
+    bytes_ = count * 8 * (rows * cols + rows + cols * (cols + 1) // 2)
+    flops_issued = count * 10 * ((rows + 3) // 4) * 2048
+    print(json.dumps({"kernel": "GnHessianUpperSoaKernel<4>", "nodes": count, "ms": ms, "nodes_per_s": count / ms * 1e3, "hbm_GBs": bytes_ / ms / 1e6,
+                      "hbm_frac_of_8TBs": bytes_ / ms / 1e6 / 8000, "mfma_TFs_issued": flops_issued / ms / 1e9, "mfma_frac_of_78.6TF": flops_issued / ms / 1e9 / 78.6}))
+    sys.exit(0)
 upper = "--upper" in sys.argv
 if upper:
     for _ in range(3): ungar_amd.gn_hessian(J, d, G, rows, cols, count, upper_only=True)

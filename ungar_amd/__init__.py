@@ -81,6 +81,8 @@ def load_library() -> ctypes.CDLL:
     for name in ("ungar_gn_hessian", "ungar_gn_hessian_upper"):
         getattr(lib, name).argtypes = [vp, ctypes.c_int64, ctypes.c_int64, vp, ctypes.c_int64, vp, ctypes.c_int64, ctypes.c_int64,
                                        ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, vp]
+    lib.ungar_gn_hessian_upper_unit_fastest.argtypes = [vp, ctypes.c_int64, vp, ctypes.c_int64, vp, ctypes.c_int64, ctypes.c_int64,
+                                                        ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, vp]
     lib.ungar_ocp_equality_sparsity.argtypes = [vp, ctypes.c_int64, vp, vp, i64p]
     lib.ungar_ocp_assemble_equality.argtypes = [vp, ctypes.c_int64, ctypes.c_int64] + [ctypes.POINTER(_Operand)] * 6 + [vp]
     lib.ungar_last_error.restype = ctypes.c_char_p
@@ -266,6 +268,16 @@ class NodeModel:
             dense[:, rows, cols] = j
             return f, dense
         return f, j.reshape(count, self.ny, ncols)
+
+
+def gn_hessian_unit_fastest(jac, d, g, rows: int, cols: int, count: int, ld_g=None, stream=None):
+    """Upper triangle of G = J^T diag(d) J for a Jacobian in the unit-fastest layout of the node kernels:
+    jac (rows * cols, count), d (rows, count) or None; g (count, cols, ld_g) node-major."""
+    lib = load_library()
+    ld_g = cols if ld_g is None else ld_g
+    _check(lib.ungar_gn_hessian_upper_unit_fastest(jac.data_ptr(), jac.stride(0), d.data_ptr() if d is not None else None,
+                                                   d.stride(0) if d is not None else 0, g.data_ptr(), cols * ld_g, ld_g, rows, cols, count,
+                                                   NodeModel._stream(stream)))
 
 
 def gn_hessian(jac, d, g, rows: int, cols: int, count: int, ld_j=None, ld_g=None, stream=None, upper_only=False):
