@@ -347,6 +347,15 @@ class Emitter {
                 }
                 slotsUsed = next;
                 if (uniformSlotsUsed) *uniformSlotsUsed = nextUniform;
+                if (uniformInput && uniformSlots > 0) {
+                    std::size_t uniformStatements = 0, total = 0;
+                    for (std::size_t i = 0; i < n; ++i) {
+                        if (defPhase[i] < 0 || g_.At(static_cast<Id>(i)).op == Op::Input) continue;
+                        ++total;
+                        uniformStatements += uniform[i];
+                    }
+                    std::fprintf(stderr, "[emit] %zu of %zu statements are quad-uniform (computed identically by the four lanes of a node)\n", uniformStatements, total);
+                }
                 std::fprintf(stderr, "[emit] phased (%zu pieces): %zu cross-phase values, %zu stored (%zu in LDS + %zu of %zu quad-uniform in compact slots, peak live %zu), %zu rematerialised; %zu statements (+%zu recomputed)\n",
                              ph_.size(), crossTotal, storedTotal, inLds, inUniform, uniformCross, peak, crossTotal - storedTotal, stats.statements,
                              stats.statements - CountDefined(defPhase));
