@@ -15,6 +15,7 @@
 #include <sys/wait.h>
 #include <unistd.h>
 
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -39,7 +40,7 @@ struct ungar_function {
     int64_t n = 0, p = 0, m = 0;
     uint32_t enabled = 0;
     std::vector<int32_t> jacRows, jacCols, hesRows, hesCols;
-    hipModule_t module = nullptr;
+    hipModule_t modules[3] = {nullptr, nullptr, nullptr};  // value, Jacobian, Hessian: one code object each (compiled concurrently)
     hipFunction_t kValue = nullptr, kJac = nullptr, kHes = nullptr;
     std::string codeObjectPath;
     bool cacheHit = false;
@@ -49,7 +50,8 @@ struct ungar_function {
     ~ungar_function() {
         if (dIn) (void)hipFree(dIn);
         if (dOut) (void)hipFree(dOut);
-        if (module) (void)hipModuleUnload(module);
+        for (hipModule_t mod : modules)
+            if (mod) (void)hipModuleUnload(mod);
     }
 };
 
@@ -87,49 +89,31 @@ std::string DefaultFolder() {
 }
 
 /// Emits one `extern "C" __global__` kernel: lane = instance, strided operands.
-std::string EmitKernel(const std::string& kernelName, const tape::Graph& g, int64_t nIn, const std::vector<tape::Id>& values) {
+std::string EmitKernel(const std::string& kernelName, const tape::Graph& g, int64_t nIn, const std::vector<tape::Id>& values, std::size_t* statements) {
     std::vector<std::string> inNames;
     inNames.reserve(static_cast<std::size_t>(nIn));
-    for (int64_t i = 0; i < nIn; ++i) inNames.push_back("x" + std::to_string(i));
+    // inputs are spelled as loads at their uses (`in` derives from a __restrict__ parameter, so the compiler
+    // merges repeated loads and places them where they are needed): reading every input into a local up
+    // front keeps ~n values alive from the top of a whole-horizon kernel and made the register allocator
+    // the dominant compile cost (objective value kernel, 960 inputs: 21 s -> 2 s, 1 KB of scratch -> none)
+    for (int64_t i = 0; i < nIn; ++i) inNames.push_back("in[" + std::to_string(i) + " * xes]");
     std::vector<tape::OutputSlot> slots;
     for (std::size_t k = 0; k < values.size(); ++k) slots.push_back({values[k], "out[" + std::to_string(k) + " * oes] = %s;"});
-    // inputs actually read
-    std::vector<char> live(g.Size(), 0), used(static_cast<std::size_t>(nIn), 0);
-    for (tape::Id r : values) live[static_cast<std::size_t>(r)] = 1;
-    for (std::size_t i = g.Size(); i-- > 0;) {
-        if (!live[i]) continue;
-        const tape::Node& nd = g.At(static_cast<tape::Id>(i));
-        if (nd.op == tape::Op::Input) {
-            used[static_cast<std::size_t>(nd.a)] = 1;
-            continue;
-        }
-        if (nd.op == tape::Op::Const) continue;
-        for (tape::Id o : {nd.a, nd.b, nd.c, nd.d})
-            if (o != tape::kNoId) live[static_cast<std::size_t>(o)] = 1;
-    }
     std::ostringstream os;
-    os << "extern \"C\" __global__ void " << kernelName
+    // launched with 64-lane workgroups (LaunchFn): tell the compiler, so that it may use the full register file
+    os << "extern \"C\" __global__ __launch_bounds__(64) void " << kernelName
        << "(const double* __restrict__ xp, long long xbs, long long xes, double* __restrict__ outBase, long long obs, long long oes, long long "
           "batch) {\n"
        << "    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;\n"
        << "    if (i >= batch) return;\n"
        << "    const double* __restrict__ in = xp + i * xbs;\n"
        << "    double* __restrict__ out = outBase + i * obs;\n";
-    for (int64_t i = 0; i < nIn; ++i)
-        if (used[static_cast<std::size_t>(i)]) os << "    const double x" << i << " = in[" << i << " * xes];\n";
     tape::Emitter em{g, inNames};
     os << em.Emit(slots) << "}\n\n";
+    if (statements) *statements = em.Stats().statements;
     return os.str();
 }
 
-int RunCommand(const std::string& cmd, std::string& output) {
-    FILE* pipe = popen((cmd + " 2>&1").c_str(), "r");
-    if (!pipe) return -1;
-    char buf[512];
-    while (fgets(buf, sizeof buf, pipe)) output += buf;
-    const int st = pclose(pipe);
-    return WIFEXITED(st) ? WEXITSTATUS(st) : -1;
-}
 
 }  // namespace
 
@@ -195,47 +179,99 @@ int ungar_function_make(const ungar_tape_node* nodes, int64_t num_nodes, const i
         fn->hesCols.assign(hes.col.begin(), hes.col.end());
     }
 
-    // ---- HIP source --------------------------------------------------------------------------------
-    std::string src = "// generated by ungar_amd (runtime/function.cpp) for function '" + fn->name + "'\n#include <hip/hip_runtime.h>\n\n";
-    src += EmitKernel("ungar_fn_forward_zero", g, n + p, valueIds);
-    if (!jac.value.empty()) src += EmitKernel("ungar_fn_sparse_jacobian", g, n + p, jac.value);
-    if (!hes.value.empty()) src += EmitKernel("ungar_fn_sparse_hessian", g, n + p, hes.value);
-    const std::string flags = "--offload-arch=gfx950 -O3 -std=c++17";
+    // ---- HIP source: one translation unit per kernel so that the compiler runs on all of them at once ----
+    struct Unit {
+        const char* kernel;
+        const char* tag;
+        const std::vector<tape::Id>* values;
+        hipFunction_t* handle;
+        std::string src, object, tmp, log, flags;
+        FILE* pipe = nullptr;
+        std::size_t statements = 0;
+    };
+    std::vector<Unit> units;
+    units.push_back({"ungar_fn_forward_zero", "value", &valueIds, &fn->kValue, {}, {}, {}, {}});
+    if (!jac.value.empty()) units.push_back({"ungar_fn_sparse_jacobian", "jacobian", &jac.value, &fn->kJac, {}, {}, {}, {}});
+    if (!hes.value.empty()) units.push_back({"ungar_fn_sparse_hessian", "hessian", &hes.value, &fn->kHes, {}, {}, {}, {}});
+    // Compile flags.  The machine instruction schedulers (pre- and post-RA) account for > 95 % of the compile
+    // time of a large straight-line kernel (a whole-horizon constraint Jacobian of 23 k statements: 64 s -> 6 s
+    // without them) and the emitter already orders statements depth-first, so they are switched off above
+    // kBigKernel statements; node-sized functions -- the ones evaluated in large batches -- keep the full
+    // pipeline.  UNGAR_AMD_JIT_FLAGS replaces the optimisation flags altogether.
+    constexpr std::size_t kBigKernel = 3000;
+    const char* custom = std::getenv("UNGAR_AMD_JIT_FLAGS");
+    std::uint64_t hash = 1469598103934665603ULL;
+    for (Unit& u : units) {
+        u.src = "// generated by ungar_amd (runtime/function.cpp) for function '" + fn->name + "'\n#include <hip/hip_runtime.h>\n\n" +
+                EmitKernel(u.kernel, g, n + p, *u.values, &u.statements);
+        u.flags = std::string("--offload-arch=gfx950 -std=c++17 ") +
+                  (custom ? custom : u.statements > kBigKernel ? "-O3 -mllvm -enable-misched=false -mllvm -enable-post-misched=false" : "-O3");
+        hash = Fnv1a(u.flags, Fnv1a(u.src, hash));
+    }
     char hashHex[32];
-    std::snprintf(hashHex, sizeof hashHex, "%016llx", static_cast<unsigned long long>(Fnv1a(flags, Fnv1a(src))));
+    std::snprintf(hashHex, sizeof hashHex, "%016llx", static_cast<unsigned long long>(hash));
+    const bool verbose = std::getenv("UNGAR_AMD_VERBOSE") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
 
     // ---- compile or reuse (layout mirrors <folder>/<name>/cppad_cg/<name>_lib.so, function.hpp:433-435)
     const std::string dir = std::string(folder && *folder ? folder : DefaultFolder()) + "/" + fn->name + "/ungar_amd";
     const std::string base = dir + "/" + fn->name + "_" + hashHex;
-    fn->codeObjectPath = base + ".hsaco";
-    struct stat st {};
-    const bool have = stat(fn->codeObjectPath.c_str(), &st) == 0 && st.st_size > 0;
+    fn->codeObjectPath = base + "_value.hsaco";
+    bool have = true;
+    for (Unit& u : units) {
+        u.object = base + "_" + u.tag + ".hsaco";
+        struct stat st {};
+        have = have && stat(u.object.c_str(), &st) == 0 && st.st_size > 0;
+    }
     if (!have || recompile) {
         if (!MakeDirs(dir)) return Fail(UNGAR_E_IO, "cannot create code-generation folder '" + dir + "'");
-        {
-            std::ofstream f(base + ".hip");
-            f << src;
-            if (!f) return Fail(UNGAR_E_IO, "cannot write '" + base + ".hip'");
-        }
-        // temp name + rename = atomic publish (function.hpp:485-487, 501-502)
-        const std::string tmp = base + "." + std::to_string(getpid()) + ".tmp.hsaco";
         const char* hipcc = std::getenv("UNGAR_HIPCC");
-        std::string log;
-        const std::string cmd = std::string(hipcc ? hipcc : "hipcc") + " " + flags + " --genco -o '" + tmp + "' '" + base + ".hip'";
-        const int rc = RunCommand(cmd, log);
-        if (rc != 0) return Fail(UNGAR_E_COMPILE, "hipcc failed (" + std::to_string(rc) + ") for function '" + fn->name + "': " + cmd + "\n" + log);
-        if (std::rename(tmp.c_str(), fn->codeObjectPath.c_str()) != 0) return Fail(UNGAR_E_IO, "cannot publish '" + fn->codeObjectPath + "'");
+        for (Unit& u : units) {
+            const std::string hip = base + "_" + u.tag + ".hip";
+            {
+                std::ofstream f(hip);
+                f << u.src;
+                if (!f) return Fail(UNGAR_E_IO, "cannot write '" + hip + "'");
+            }
+            // temp name + rename = atomic publish (function.hpp:485-487, 501-502)
+            u.tmp = u.object + "." + std::to_string(getpid()) + ".tmp";
+            const std::string cmd = std::string(hipcc ? hipcc : "hipcc") + " " + u.flags + " --genco -o '" + u.tmp + "' '" + hip + "' 2>&1";
+            u.pipe = popen(cmd.c_str(), "r");  // all compilers start now and run concurrently
+            if (!u.pipe) return Fail(UNGAR_E_COMPILE, "cannot start hipcc for function '" + fn->name + "'");
+        }
+        std::string failure;
+        for (Unit& u : units) {
+            char buf[512];
+            while (fgets(buf, sizeof buf, u.pipe)) u.log += buf;
+            const int st = pclose(u.pipe);
+            const int rc = WIFEXITED(st) ? WEXITSTATUS(st) : -1;
+            if (rc != 0) failure += "hipcc failed (" + std::to_string(rc) + ") for the " + u.tag + " kernel of function '" + fn->name + "':\n" + u.log;
+        }
+        if (!failure.empty()) return Fail(UNGAR_E_COMPILE, failure);
+        for (Unit& u : units)
+            if (std::rename(u.tmp.c_str(), u.object.c_str()) != 0) return Fail(UNGAR_E_IO, "cannot publish '" + u.object + "'");
     } else {
         fn->cacheHit = true;
     }
+    if (verbose)
+        std::fprintf(stderr, "[ungar_amd] function '%s': %lld tape nodes, n=%lld p=%lld m=%lld, jac nnz %zu, hes nnz %zu, %s in %.1f s\n", fn->name.c_str(),
+                     static_cast<long long>(num_nodes), static_cast<long long>(n), static_cast<long long>(p), static_cast<long long>(m), jac.value.size(),
+                     hes.value.size(), fn->cacheHit ? "code objects reused" : "compiled",
+                     std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
 
     // ---- load ---------------------------------------------------------------------------------------
-    hipError_t e = hipModuleLoad(&fn->module, fn->codeObjectPath.c_str());
-    if (e != hipSuccess) return Fail(UNGAR_E_HIP, std::string("hipModuleLoad('") + fn->codeObjectPath + "'): " + hipGetErrorString(e));
-    e = hipModuleGetFunction(&fn->kValue, fn->module, "ungar_fn_forward_zero");
-    if (e == hipSuccess && !jac.value.empty()) e = hipModuleGetFunction(&fn->kJac, fn->module, "ungar_fn_sparse_jacobian");
-    if (e == hipSuccess && !hes.value.empty()) e = hipModuleGetFunction(&fn->kHes, fn->module, "ungar_fn_sparse_hessian");
-    if (e != hipSuccess) return Fail(UNGAR_E_HIP, std::string("hipModuleGetFunction: ") + hipGetErrorString(e));
+    // UNGAR_AMD_COMPILE_ONLY: stop after publishing the code objects (cache warm-up on a machine without a
+    // GPU, e.g. a build host); the returned function reports its sparsity but every evaluation fails.
+    if (std::getenv("UNGAR_AMD_COMPILE_ONLY")) {
+        *out = fn.release();
+        return UNGAR_OK;
+    }
+    for (std::size_t k = 0; k < units.size(); ++k) {
+        hipError_t e = hipModuleLoad(&fn->modules[k], units[k].object.c_str());
+        if (e != hipSuccess) return Fail(UNGAR_E_HIP, std::string("hipModuleLoad('") + units[k].object + "'): " + hipGetErrorString(e));
+        e = hipModuleGetFunction(units[k].handle, fn->modules[k], units[k].kernel);
+        if (e != hipSuccess) return Fail(UNGAR_E_HIP, std::string("hipModuleGetFunction: ") + hipGetErrorString(e));
+    }
     *out = fn.release();
     return UNGAR_OK;
 }
@@ -280,7 +316,7 @@ int ungar_function_hessian_sparsity(const ungar_function* fn, const int32_t** ro
 static int LaunchFn(const ungar_function* fn, hipFunction_t k, const char* what, const ungar_operand* xp, const ungar_operand* out,
                     int64_t batch, void* stream) {
     if (!fn || !xp || !out) return Fail(UNGAR_E_INVALID, std::string(what) + ": null argument");
-    if (!k) return Fail(UNGAR_E_UNSUPPORTED, std::string(what) + ": derivative not enabled for function '" + fn->name + "'");
+    if (!k) return Fail(UNGAR_E_UNSUPPORTED, std::string(what) + ": kernel not available for function '" + fn->name + "' (derivative not enabled, or made with UNGAR_AMD_COMPILE_ONLY)");
     if (batch < 0) return Fail(UNGAR_E_INVALID, std::string(what) + ": negative batch");
     if (batch == 0) return UNGAR_OK;
     if (!xp->base || !out->base) return Fail(UNGAR_E_INVALID, std::string(what) + ": null operand base");
@@ -312,7 +348,7 @@ int ungar_function_eval_host(ungar_function* fn, int32_t what, const double* xp_
     const int64_t nOut = what == 0 ? fn->m : what == 1 ? static_cast<int64_t>(fn->jacRows.size()) : static_cast<int64_t>(fn->hesRows.size());
     hipFunction_t k = what == 0 ? fn->kValue : what == 1 ? fn->kJac : fn->kHes;
     if (what < 0 || what > 2) return Fail(UNGAR_E_INVALID, "ungar_function_eval_host: what must be 0 (value), 1 (Jacobian) or 2 (Hessian)");
-    if (!k) return Fail(UNGAR_E_UNSUPPORTED, "ungar_function_eval_host: derivative not enabled for function '" + fn->name + "'");
+    if (!k) return Fail(UNGAR_E_UNSUPPORTED, "ungar_function_eval_host: kernel not available for function '" + fn->name + "' (derivative not enabled, or made with UNGAR_AMD_COMPILE_ONLY)");
     if (nOut == 0) return UNGAR_OK;
     hipError_t e = hipSuccess;
     if (!fn->dIn) e = hipMalloc(&fn->dIn, static_cast<std::size_t>(std::max<int64_t>(nIn, 1)) * sizeof(double));
