@@ -8,10 +8,13 @@
 set -euo pipefail
 here="$(cd "$(dirname "$0")" && pwd)"; root="$(cd "$here/../.." && pwd)"
 ref=${UNGAR_REFERENCE:-/root/reference}
-[ -d "$ref/example/mpc" ] || { echo "reference not present: nothing to build"; exit 0; }
+[ -d "$ref/example" ] || { echo "reference not present: nothing to build"; exit 0; }
 mkdir -p "$root/oracle/_ref"
 for name in "$@"; do
-  g++ -std=c++20 -O2 -I "$root/ungar_amd/include" -o "$root/oracle/_ref/${name}_example" "$ref/example/mpc/${name}.example.cpp" \
+  src="$ref/example/mpc/${name}.example.cpp"
+  [ -f "$src" ] || src="$ref/example/autodiff/${name}.example.cpp"
+  [ -f "$src" ] || src="$ref/example/${name}.example.cpp"
+  g++ -std=c++20 -O2 -I "$root/ungar_amd/include" -o "$root/oracle/_ref/${name}_example" "$src" \
       -L "$root/ungar_amd/lib" -lungar_amd -Wl,-rpath,'$ORIGIN/../../ungar_amd/lib' -Wl,-rpath,/opt/rocm/lib
   echo "built oracle/_ref/${name}_example"
 done

@@ -47,3 +47,16 @@ def test_rc_car_example_tracks_its_reference(repo_root, tmp_path):
     assert max(abs(r[2]) for r in late) < 1e-3
     assert max(r[3] for r in late) < 1e-2
     assert max(abs(r[4] - r[6]) + abs(r[5] - r[7]) for r in late) < 0.05
+
+
+def test_variable_map_example_runs_on_the_host(repo_root, tmp_path):
+    """example/variable_map.example.cpp is pure layout (compile-time static_asserts on indices and on the
+    view TYPES returned by VariableMap::Get, then setZero / setOnes / setLinSpaced through the views)."""
+    out = _run(repo_root, "variable_map", tmp_path, 60)
+    assert "u0 = 0 0 0 0" in out and "u1 = 1 1 1 1" in out and "uN-1 = 2 4 6 8" in out
+
+
+@pytest.mark.gpu
+def test_function_example_self_checks(repo_root, tmp_path):
+    """example/autodiff/function.example.cpp asserts TestJacobian / TestHessian (finite differences) itself."""
+    _run(repo_root, "function", tmp_path, 600)

@@ -127,14 +127,15 @@ def build_cpp_tests():
     build_reference_examples()
 
 
-def build_reference_examples(names=("quadrotor", "rc_car")):
+def build_reference_examples(names=("quadrotor", "rc_car", "quadruped", "function", "variable_map")):
     """The reference's own example/mpc programs against ungar_amd's headers (oracle/ref_examples):
     only where the reference is present; the binaries land in oracle/_ref and travel to the GPU box."""
     script = os.path.join(ROOT, "oracle", "ref_examples", "build_examples.sh")
     ref = os.environ.get("UNGAR_REFERENCE", "/root/reference")
     todo = []
     for n in names:
-        src = os.path.join(ref, "example", "mpc", f"{n}.example.cpp")
+        cands = [os.path.join(ref, "example", sub, f"{n}.example.cpp") for sub in ("mpc", "autodiff", "")]
+        src = next((c for c in cands if os.path.exists(c)), cands[0])
         exe = os.path.join(ROOT, "oracle", "_ref", f"{n}_example")
         if os.path.exists(src) and not _newer([exe], [src, LIB] + _tree(os.path.join(ROOT, "ungar_amd", "include"))):
             todo.append(n)
