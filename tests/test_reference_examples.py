@@ -60,3 +60,25 @@ def test_variable_map_example_runs_on_the_host(repo_root, tmp_path):
 def test_function_example_self_checks(repo_root, tmp_path):
     """example/autodiff/function.example.cpp asserts TestJacobian / TestHessian (finite differences) itself."""
     _run(repo_root, "function", tmp_path, 600)
+
+
+QP_LINE = re.compile(r"t = ([\d.]+), obj = ([-\d.e+]+), eqs = ([-\d.e+]+), ineqs = ([-\d.e+]+) \(\d+\), z ref = ([-\d.]+), z = ([-\d.]+), "
+                     r"yaw ref = ([-\d.]+), yaw = ([-\d.]+), grf z = ([-\d.]+), ([-\d.]+), ([-\d.]+), ([-\d.]+)")
+
+
+@pytest.mark.gpu
+def test_quadruped_example_trots_and_tracks(repo_root, tmp_path):
+    """quadruped.example.cpp (single-rigid-body quadruped, friction cones, contact schedule): the base must
+    keep its height and follow the yaw ramp while exactly one diagonal leg pair carries the weight."""
+    import math
+    rows = [tuple(map(float, m.groups())) for m in map(QP_LINE.search, _run(repo_root, "quadruped", tmp_path, 1500).splitlines()) if m]
+    assert len(rows) >= 290
+    late = [r for r in rows if r[0] > 5.0]
+    assert max(abs(r[2]) for r in late) < 0.1 and max(r[3] for r in late) < 1e-2
+    assert max(abs(r[4] - r[5]) for r in late) < 0.02
+    for r in late:
+        d = abs(r[6] - r[7]) % math.pi  # the logged yaw follows Eigen's eulerAngles convention (folded into [0, pi])
+        assert min(d, math.pi - d) < 0.05
+        swing = [f == 0.0 for f in r[8:12]]
+        assert swing in ([False, True, False, True], [True, False, True, False]), "trot: one diagonal pair in swing"
+        assert sum(r[8:12]) > 150.0  # the stance pair carries the ~25 kg body
