@@ -471,6 +471,12 @@ int main(int argc, char** argv) {
                    << "inline constexpr int kLdsSlots = " << quadLds << ";  // per-lane LDS slots of the phased body\n"
                    << "inline constexpr int kLdsUniformSlots = " << quadUniformUsed << ";  // per-quad (lane-uniform) LDS slots\n"
                    << "inline constexpr int kJacNnz = " << adv.jac.Nnz() << ";  // entries of the sparse (CSR) output\n"
+                   << "// per-leg CSR index patterns (k_L - k_0) of the per-lane Jacobian sinks: one per-lane base pointer each\n"
+                   << "struct SparsePlan {\n    static constexpr int kCount = " << qp.sparseDeltas.size() << ";\n    static constexpr int kDeltas["
+                   << std::max<std::size_t>(1, qp.sparseDeltas.size()) << "][4] = {";
+                for (const auto& dl : qp.sparseDeltas) qo << "{" << dl[0] << ", " << dl[1] << ", " << dl[2] << ", " << dl[3] << "}, ";
+                if (qp.sparseDeltas.empty()) qo << "{0, 0, 0, 0}";
+                qo << "};\n};\n"
                    << "// leg constants that differ between legs, [k][leg]; legs in model order (LF, LH, RF, RH)\n"
                    << "inline constexpr double kLegConstants[" << std::max<std::size_t>(1, qp.constants.size()) << "][4] = {\n";
                 for (const auto& c : qp.constants) {

@@ -41,6 +41,9 @@ struct QuadProgram {
     std::vector<std::size_t> phaseStarts;    // slot indices where a new phase (Jacobian column) begins
     std::vector<std::string> inputNames;     // spelling of every tape input in the generated code
     std::vector<char> inputUniform;          // 1: same value in the four lanes of a quad (base state, dt)
+    // distinct per-leg CSR index patterns (k_L - k_0, L = 0..3) of the per-lane sinks: the sparse kernel keeps
+    // one per-lane base pointer per pattern, so that a sparse store costs what a dense one does
+    std::vector<std::array<int, 4>> sparseDeltas;
     std::vector<std::array<double, 4>> constants;  // constants[k][leg]
 };
 
@@ -76,9 +79,15 @@ inline QuadProgram RecordQuadLegProgram(const rbd::Model& model, const tape::Spa
     for (std::size_t e = 0; e < pattern.Nnz(); ++e) kOf[static_cast<std::size_t>(pattern.row[e] * 49 + pattern.col[e])] = static_cast<int>(e);
     auto kArgs = [&](int rowBase, int rowLegMul, int colBase, int colLegMul, int rot) {
         std::string s;
+        std::array<int, 4> k{};
         for (int L = 0; L < 4; ++L) {
             const int r = rowBase + 3 * rowLegMul * L, c = colBase + 3 * colLegMul * ((L + rot) & 3);
-            s += (L ? ", " : "") + std::to_string(kOf[static_cast<std::size_t>(r * 49 + c)]);
+            k[static_cast<std::size_t>(L)] = kOf[static_cast<std::size_t>(r * 49 + c)];
+            s += (L ? ", " : "") + std::to_string(k[static_cast<std::size_t>(L)]);
+        }
+        if (*std::min_element(k.begin(), k.end()) >= 0) {
+            const std::array<int, 4> delta{0, k[1] - k[0], k[2] - k[0], k[3] - k[0]};
+            if (std::find(P.sparseDeltas.begin(), P.sparseDeltas.end(), delta) == P.sparseDeltas.end()) P.sparseDeltas.push_back(delta);
         }
         return s;
     };

@@ -23,10 +23,10 @@ extern "C" int ungar_amd_launch_anymal_quad_sparse(const ungar_amd::kernels::Nod
     const dim3 grid(static_cast<unsigned>((a->count + kBlock / 4 - 1) / (kBlock / 4))), block(kBlock);
     namespace Q = ungar_amd::gen::anymal_quad;
     if (UseStreamingStores(*a, kModeSparseJacobian, Q::kJacNnz, 37))
-        hipLaunchKernelGGL((QuadNodeKernel<kBlock, Q::kLdsSlots, Q::kLdsUniformSlots, true, true, AnymalQuadSparseBody>), grid, block, 0, static_cast<hipStream_t>(stream), *a,
+        hipLaunchKernelGGL((QuadNodeKernel<kBlock, Q::kLdsSlots, Q::kLdsUniformSlots, true, true, AnymalQuadSparseBody, Q::SparsePlan>), grid, block, 0, static_cast<hipStream_t>(stream), *a,
                            ctab, AnymalQuadSparseBody{});
     else
-        hipLaunchKernelGGL((QuadNodeKernel<kBlock, Q::kLdsSlots, Q::kLdsUniformSlots, true, false, AnymalQuadSparseBody>), grid, block, 0, static_cast<hipStream_t>(stream), *a,
+        hipLaunchKernelGGL((QuadNodeKernel<kBlock, Q::kLdsSlots, Q::kLdsUniformSlots, true, false, AnymalQuadSparseBody, Q::SparsePlan>), grid, block, 0, static_cast<hipStream_t>(stream), *a,
                            ctab, AnymalQuadSparseBody{});
     return static_cast<int>(hipGetLastError());
 }

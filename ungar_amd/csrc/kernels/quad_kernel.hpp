@@ -30,7 +30,16 @@ __device__ __forceinline__ double QuadPerm(double v) {
 /// leg-dependent rows/columns through per-lane offsets computed once.  Every Jacobian sink of the
 /// generated program carries both addressings -- (row, column) of the dense block and, per lane, the
 /// index k of the entry in the CSR value array (-1 = structural zero); SPARSE picks the second.
-template <bool SPARSE, bool STREAM = false>
+/// Default sparse-addressing plan: no precomputed patterns (every sparse store selects its index per lane).
+struct NoSparsePlan {
+    static constexpr int kCount = 0;
+    static constexpr int kDeltas[1][4] = {{0, 0, 0, 0}};
+};
+
+/// PLAN (generated: gen::anymal_quad::SparsePlan) lists the distinct per-leg index patterns k_L - k_0 of the
+/// sparse sinks; the kernel keeps one per-lane base pointer per pattern (jS[p] = jb + kDeltas[p][leg] * je),
+/// so a sparse store is (lane pointer) + (wave-uniform offset k_0 * je) like a dense one.
+template <bool SPARSE, bool STREAM = false, class PLAN = NoSparsePlan>
 struct QuadIO {
     const double* __restrict__ xb;  // node's x (element stride xe)
     const double* __restrict__ ub;
@@ -46,6 +55,7 @@ struct QuadIO {
     double* __restrict__ jOwnCol;     // jb + 3 L * je                  : base rows, column owned by this leg
     double* __restrict__ fLeg;        // fb + 3 L * fe
     const double (*ctab)[4];
+    double* jS[PLAN::kCount > 0 ? PLAN::kCount : 1];  // sparse mode: per-lane base pointer of every index pattern
     double* lds;   // per-lane LDS home of the phased body (slot s at lds[s * 64])
     double* ldsu;  // per-quad home of lane-uniform values (slot s at ldsu[s * 16]): a quarter of the bytes
 
@@ -91,6 +101,14 @@ struct QuadIO {
     }
     __device__ __forceinline__ void j_sparse(int k0, int k1, int k2, int k3, double v) const {
         if (k0 < 0 && k1 < 0 && k2 < 0 && k3 < 0) return;  // literal arguments: folds away at compile time
+        if (k0 >= 0 && k1 >= 0 && k2 >= 0 && k3 >= 0) {
+#pragma unroll
+            for (int p = 0; p < PLAN::kCount; ++p)  // literal arguments, constexpr table: exactly one branch survives
+                if (k1 - k0 == PLAN::kDeltas[p][1] && k2 - k0 == PLAN::kDeltas[p][2] && k3 - k0 == PLAN::kDeltas[p][3]) {
+                    Put(jS[p] + static_cast<unsigned>(k0) * je, v);
+                    return;
+                }
+        }
         const int k = L == 0 ? k0 : L == 1 ? k1 : L == 2 ? k2 : k3;
         if (k0 >= 0 && k1 >= 0 && k2 >= 0 && k3 >= 0)
             Put(jb + static_cast<unsigned>(k) * je, v);
@@ -131,7 +149,7 @@ struct QuadIO {
 };
 
 /// GEN is the generated namespace (ValueJacobianQuad, kLegConstantsDev).  BLOCK lanes = BLOCK/4 nodes.
-template <int BLOCK, int LDS_SLOTS, int LDS_USLOTS, bool SPARSE, bool STREAM, class Body>
+template <int BLOCK, int LDS_SLOTS, int LDS_USLOTS, bool SPARSE, bool STREAM, class Body, class PLAN = NoSparsePlan>
 __global__ __launch_bounds__(BLOCK) void QuadNodeKernel(const NodeLaunch a, const double (*ctab)[4], Body body) {
     static_assert(BLOCK == 64, "the LDS home is laid out for one wavefront per workgroup");
     __shared__ double lds[(LDS_SLOTS > 0 ? LDS_SLOTS : 1) * BLOCK + LDS_USLOTS * (BLOCK / 4)];
@@ -148,7 +166,7 @@ __global__ __launch_bounds__(BLOCK) void QuadNodeKernel(const NodeLaunch a, cons
     double* const jb = a.jac.base + b * a.jac.bs + k * a.jac.ks;
     const long long je = a.jac.es;
     double* const jLeg = jb + 3LL * L * 49 * je;
-    QuadIO<SPARSE, STREAM> io{a.x.base + b * a.x.bs + k * a.x.ks,
+    QuadIO<SPARSE, STREAM, PLAN> io{a.x.base + b * a.x.bs + k * a.x.ks,
               a.u.base + b * a.u.bs + k * a.u.ks,
               a.p.base + b * a.p.bs + k * a.p.ks,
               fb,
@@ -160,8 +178,13 @@ __global__ __launch_bounds__(BLOCK) void QuadNodeKernel(const NodeLaunch a, cons
               jb + 3LL * L * je,
               fb ? fb + 3LL * L * a.f.es : nullptr,
               ctab,
+              {},
               lds + threadIdx.x,
               lds + LDS_SLOTS * BLOCK + nodeInWave};
+    if constexpr (SPARSE) {
+#pragma unroll
+        for (int p = 0; p < PLAN::kCount; ++p) io.jS[p] = jb + static_cast<long long>(PLAN::kDeltas[p][L]) * je;
+    }
     body(io);
 }
 
