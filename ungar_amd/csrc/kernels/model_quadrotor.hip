@@ -2,4 +2,4 @@
 #include "../gen/quadrotor_gen.hpp"
 #include "node_kernel.hpp"
 
-UNGAR_AMD_DEFINE_NODE_MODEL(quadrotor, 256)
+UNGAR_AMD_DEFINE_NODE_MODEL(quadrotor, 128)

@@ -2,4 +2,4 @@
 #include "../gen/rc_car_gen.hpp"
 #include "node_kernel.hpp"
 
-UNGAR_AMD_DEFINE_NODE_MODEL(rc_car, 256)
+UNGAR_AMD_DEFINE_NODE_MODEL(rc_car, 128)

@@ -2,4 +2,4 @@
 #include "../gen/srbd_gen.hpp"
 #include "node_kernel.hpp"
 
-UNGAR_AMD_DEFINE_NODE_MODEL(srbd, 256)
+UNGAR_AMD_DEFINE_NODE_MODEL(srbd, 128)
