@@ -72,7 +72,8 @@ typedef struct ungar_node_batch {
 
 /* ---- model lifetime ------------------------------------------------------------------------ */
 
-/* Opens one of the built-in node models: "quadrotor", "rc_car", "srbd", "anymal" (structured
+/* Opens one of the built-in node models: "quadrotor_cost" (scalar stage cost of the quadrotor OCP: value,
+ * gradient, upper Hessian), "quadrotor", "rc_car", "srbd", "anymal" (structured
  * implicit differentiation, phased body with an LDS home), "anymal_reg" (same program, plain
  * straight-line body) or "anymal_ad" (same function, derivatives by taping ABA).
  * replaces FunctionFactory::Make -> DynamicLib::model(name)  (function.hpp:497, 589-604). */
@@ -106,6 +107,12 @@ int ungar_model_sparse_jacobian(const ungar_model* model, const ungar_node_batch
 /* y and the DENSE row-major ny x (nx+nu) block [A | B] (structural zeros written as 0.0) -- the
  * per-node block of the reference's block-bidiagonal equality Jacobian. */
 int ungar_model_dense_jacobian(const ungar_model* model, const ungar_node_batch* batch, void* stream);
+
+/* Scalar node models (one output, e.g. the stage cost "quadrotor_cost"): y, its gradient w.r.t. (x, u) into
+ * batch->jac when that operand is given (dense 1 x (nx+nu) row), and the UPPER triangle of the Hessian w.r.t.
+ * (x, u) into `hes`, hes_nnz values per node in the CSR order of ungar_model_hessian_sparsity.
+ * replaces GenericModel::SparseHessian (function.hpp:252-257).  UNGAR_E_UNSUPPORTED for vector-valued models. */
+int ungar_model_sparse_hessian(const ungar_model* model, const ungar_node_batch* batch, const ungar_operand* hes, void* stream);
 
 /* Gauss-Newton contraction  G = J^T diag(d) J  per node on the FP64 matrix cores
  * (v_mfma_f64_16x16x4_f64).  replaces the Eigen sparse triple product at

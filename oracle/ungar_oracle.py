@@ -415,6 +415,42 @@ NODES = {"quadrotor": quadrotor_node, "rc_car": rc_car_node, "srbd": srbd_node, 
 
 
 # ----------------------------------------------------------------------------- evaluation API
+# ----------------------------------------------------------------------------- scalar stage cost
+def quadrotor_cost(x, u, p):
+    """Per-knot stage cost of example/mpc/quadrotor.example.cpp:196-236 (input-rate term excluded: it couples
+    consecutive knots): p = [p_ref(3), q_ref(4), v_ref(3), omega_ref(3)]."""
+    track = ((x[0:3] - p[0:3]) ** 2).sum()
+    track = track + torch.minimum(((x[3:7] - p[3:7]) ** 2).sum(), ((x[3:7] + p[3:7]) ** 2).sum())
+    track = track + ((x[7:13] - p[7:13]) ** 2).sum()
+    return track + 1e-6 * (u ** 2).sum()
+
+
+def cost_value_gradient_hessian(x, u, p):
+    """(y, gradient, dense Hessian) w.r.t. z = (x, u) for a batch of numpy inputs."""
+    X, U, P = (torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64) for a in (x, u, p))
+    ys, gs, hs = [], [], []
+    for b in range(X.shape[0]):
+        z = torch.cat((X[b], U[b])).requires_grad_(True)
+        fn = lambda zz: quadrotor_cost(zz[:13], zz[13:], P[b])  # noqa: E731
+        y = fn(z)
+        (g,) = torch.autograd.grad(y, z, create_graph=False)
+        ys.append(y.detach())
+        gs.append(g)
+        hs.append(torch.autograd.functional.hessian(fn, z.detach()))
+    return torch.stack(ys).numpy(), torch.stack(gs).numpy(), torch.stack(hs).numpy()
+
+
+def synthetic_cost_inputs(count: int, seed: int = 0):
+    """States/inputs as for the quadrotor node, references = perturbed states (some with flipped quaternion
+    sign, so that both branches of the min are exercised)."""
+    x, u, _, _ = synthetic_inputs("quadrotor", count, seed)
+    rng = np.random.default_rng(0xC057 + seed)
+    ref = x + rng.normal(scale=0.3, size=x.shape)
+    ref[:, 3:7] /= np.linalg.norm(ref[:, 3:7], axis=1, keepdims=True)
+    ref[::2, 3:7] *= -1.0
+    return x, u, ref
+
+
 def node_value(name: str, x, u, w, p) -> np.ndarray:
     """f for a batch: x (B,nx), u (B,nu), w (B,nw), p (B,np) numpy -> (B,nx)."""
     fn = NODES[name]

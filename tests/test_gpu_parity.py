@@ -276,3 +276,46 @@ def test_gn_hessian_mfma(ua):
         torch.cuda.synchronize()
         assert (S[:, upper] - ref[:, upper]).abs().max().item() <= 1e-12 * ref.abs().max().item()
         assert torch.isnan(S[:, ~upper]).all()
+
+
+def test_quadrotor_stage_cost_value_gradient_hessian(ua, repo_root):
+    """Scalar node model 'quadrotor_cost' (SURVEY.md section 8(f) N2): value, gradient and upper-triangular
+    Hessian w.r.t. (x, u) against torch.autograd on the oracle's restatement of the reference's stage cost,
+    in both operand layouts; inputs exercise both branches of the quaternion min."""
+    import torch
+    g = np.load(f"{repo_root}/tests/golden/cost_quadrotor.npz")
+    m = ua.NodeModel("quadrotor_cost")
+    assert (m.nx, m.nu, m.np, m.ny, m.jac_nnz) == (13, 4, 13, 1, 17) and m.implements_hessian()
+    rows, cols = m.hessian_sparsity()
+    assert (rows <= cols).all(), "upper triangle only (function.hpp:236-274)"
+    count = g["x"].shape[0]
+    dev = "cuda"
+    for layout in ("soa", "aos"):
+        t = (lambda a: torch.as_tensor(a.T.copy(), device=dev)) if layout == "soa" else (lambda a: torch.as_tensor(a.copy(), device=dev))
+        shape = (lambda n: (n, count)) if layout == "soa" else (lambda n: (count, n))
+        mk = (lambda ten, n: ua.Operand.soa(ten, count)) if layout == "soa" else (lambda ten, n: ua.Operand.aos(ten, n))
+        x, u, p = t(g["x"]), t(g["u"]), t(g["p"])
+        y = torch.full(shape(1), float("nan"), dtype=torch.float64, device=dev)
+        grad = torch.full(shape(17), float("nan"), dtype=torch.float64, device=dev)
+        hes = torch.full(shape(len(rows)), float("nan"), dtype=torch.float64, device=dev)
+        m.sparse_hessian(count, mk(x, 13), mk(u, 4), None, mk(p, 13), mk(y, 1), mk(grad, 17), mk(hes, len(rows)))
+        torch.cuda.synchronize()
+        Y, G, H = (a.cpu().numpy().T if layout == "soa" else a.cpu().numpy() for a in (y, grad, hes))
+        assert np.abs(Y[:, 0] - g["y"]).max() <= 1e-12 * np.abs(g["y"]).max()
+        assert np.abs(G - g["g"]).max() <= 1e-12 * np.abs(g["g"]).max()
+        assert np.abs(H - g["H"][:, rows, cols]).max() <= 1e-12
+        dense = np.zeros_like(g["H"])
+        dense[:, rows, cols] = H
+        assert np.abs(np.triu(g["H"]) - dense).max() <= 1e-12, "entries outside the pattern must be structural zeros"
+    # value-only and gradient-only entry points of the same model
+    x, u, p = (torch.as_tensor(g[k].T.copy(), device=dev) for k in ("x", "u", "p"))
+    y2 = torch.empty((1, count), dtype=torch.float64, device=dev)
+    m.forward_zero(count, ua.Operand.soa(x, count), ua.Operand.soa(u, count), None, ua.Operand.soa(p, count), ua.Operand.soa(y2, count))
+    g2 = torch.empty((17, count), dtype=torch.float64, device=dev)
+    m.dense_jacobian(count, ua.Operand.soa(x, count), ua.Operand.soa(u, count), None, ua.Operand.soa(p, count), ua.Operand.soa(y2, count), ua.Operand.soa(g2, count))
+    torch.cuda.synchronize()
+    assert np.abs(y2.cpu().numpy()[0] - g["y"]).max() <= 1e-12 * np.abs(g["y"]).max()
+    assert np.abs(g2.cpu().numpy().T - g["g"]).max() <= 1e-12 * np.abs(g["g"]).max()
+    # vector-valued models refuse the Hessian entry point
+    with pytest.raises(ua.UngarError):
+        ua.NodeModel("quadrotor").hessian_sparsity()

@@ -78,6 +78,7 @@ def load_library() -> ctypes.CDLL:
         getattr(lib, name).argtypes = [vp]
     for name in ("ungar_model_forward_zero", "ungar_model_sparse_jacobian", "ungar_model_dense_jacobian"):
         getattr(lib, name).argtypes = [vp, ctypes.POINTER(_NodeBatch), vp]
+    lib.ungar_model_sparse_hessian.argtypes = [vp, ctypes.POINTER(_NodeBatch), ctypes.POINTER(_Operand), vp]
     for name in ("ungar_gn_hessian", "ungar_gn_hessian_upper"):
         getattr(lib, name).argtypes = [vp, ctypes.c_int64, ctypes.c_int64, vp, ctypes.c_int64, vp, ctypes.c_int64, ctypes.c_int64,
                                        ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, vp]
@@ -210,6 +211,22 @@ class NodeModel:
     def dense_jacobian(self, count, x, u, w, p, f, jac, knots=1, stream=None):
         b = self._batch(count, knots, x, u, w, p, f, jac)
         _check(self._lib.ungar_model_dense_jacobian(self._h, ctypes.byref(b), self._stream(stream)))
+
+    def sparse_hessian(self, count, x, u, w, p, f, grad, hes, knots=1, stream=None):
+        """Scalar (cost) models: value into f, gradient w.r.t. (x, u) into grad (may be None), upper-triangular
+        Hessian values (hessian_sparsity order) into hes."""
+        b = self._batch(count, knots, x, u, w, p, f, grad)
+        h = hes._c()
+        _check(self._lib.ungar_model_sparse_hessian(self._h, ctypes.byref(b), ctypes.byref(h), self._stream(stream)))
+
+    def hessian_sparsity(self):
+        """(rows, cols) int32 arrays of the upper-triangular Hessian w.r.t. (x, u), canonical row-major order."""
+        rows = ctypes.POINTER(ctypes.c_int32)()
+        cols = ctypes.POINTER(ctypes.c_int32)()
+        nnz = ctypes.c_int64()
+        _check(self._lib.ungar_model_hessian_sparsity(self._h, ctypes.byref(rows), ctypes.byref(cols), ctypes.byref(nnz)))
+        n = nnz.value
+        return (np.ctypeslib.as_array(rows, shape=(n,)).copy(), np.ctypeslib.as_array(cols, shape=(n,)).copy())
 
     # -- whole-horizon assembly (SURVEY.md section 8(f) N1) --------------------------------------------
     def ocp_equality_sparsity(self, horizon: int):

@@ -327,6 +327,57 @@ void EmitHip(const Generated& g, const std::string& dir, bool columnMajorEmissio
     f << os.str();
 }
 
+/// Scalar stage-cost node: value, gradient w.r.t. (x, u) and the UPPER triangle of
+/// the Hessian w.r.t. (x, u) (what Function::Hessian delivers, function.hpp:236-274) in one body.  Sinks:
+/// io.f(0, v); io.j(k, 0, c, v) for the gradient (a 1 x (nx+nu) Jacobian); io.h(k, row, col, v) for the Hessian.
+void EmitCostHip(const models::NodeDims& d, const std::function<void(const AD*, const AD*, const AD*, const AD*, AD*)>& fn, const std::string& dir) {
+    const int nIn = d.nx + d.nu + d.nw + d.np, ncols = d.nx + d.nu;
+    std::vector<AD> in = tape::Independent(nIn);
+    AD y{0.0};
+    fn(in.data(), in.data() + d.nx, in.data() + d.nx + d.nu, in.data() + d.nx + d.nu + d.nw, &y);
+    tape::Tape t = tape::MakeTape(std::vector<AD>{y});
+    tape::Differentiator diff{t};
+    const tape::SparseEntries grad = diff.Jacobian(ncols, 0);
+    const tape::SparseEntries hes = diff.Hessian(0, ncols);
+    const std::string name = d.name;
+    std::ostringstream os;
+    os << "// GENERATED by ungar_amd/csrc/codegen/codegen_main.cpp -- do not edit.\n"
+       << "// Scalar stage-cost node '" << name << "': value, gradient and upper-triangular Hessian w.r.t. (x, u).\n"
+       << "#pragma once\n#include <hip/hip_runtime.h>\n\n"
+       << "namespace ungar_amd::gen::" << name << " {\n\n"
+       << "inline constexpr int kNx = " << d.nx << ", kNu = " << d.nu << ", kNw = " << d.nw << ", kNp = " << d.np << ";\n"
+       << "inline constexpr int kJacRows = 1, kJacCols = " << ncols << ", kJacNnz = " << grad.Nnz() << ", kHesNnz = " << hes.Nnz() << ";\n";
+    auto table = [&](const char* nm, const std::vector<int>& v, const char* size) {
+        os << "inline constexpr int " << nm << "[" << size << "] = {";
+        for (std::size_t k = 0; k < v.size(); ++k) os << (k ? "," : "") << v[k];
+        os << "};\n";
+    };
+    table("kJacRow", grad.row, "kJacNnz");
+    table("kJacCol", grad.col, "kJacNnz");
+    table("kHesRow", hes.row, "kHesNnz");
+    table("kHesCol", hes.col, "kHesNnz");
+    std::vector<tape::OutputSlot> slots{{t.outputs[0], "io.f(0, %s);"}};
+    std::vector<tape::Id> roots{t.outputs[0]};
+    for (std::size_t k = 0; k < grad.Nnz(); ++k) {
+        slots.push_back({grad.value[k], "io.j(" + std::to_string(k) + ", 0, " + std::to_string(grad.col[k]) + ", %s);"});
+        roots.push_back(grad.value[k]);
+    }
+    for (std::size_t k = 0; k < hes.Nnz(); ++k) {
+        slots.push_back({hes.value[k], "io.h(" + std::to_string(k) + ", " + std::to_string(hes.row[k]) + ", " + std::to_string(hes.col[k]) + ", %s);"});
+        roots.push_back(hes.value[k]);
+    }
+    tape::Emitter em{t.graph, InputNames(d, false)};
+    const std::string body = em.Emit(slots);
+    os << "// " << em.Stats().statements << " statements, " << em.Stats().flops << " flops\n"
+       << "template <class IO>\n__device__ __forceinline__ void ValueGradientHessian(IO& io) {\n"
+       << HipPrologue(d, UsedInputs(t.graph, roots)) << body << "}\n\n"
+       << "}  // namespace ungar_amd::gen::" << name << "\n";
+    std::ofstream f(dir + "/" + name + "_gen.hpp");
+    f << os.str();
+    std::fprintf(stderr, "[codegen] %-14s scalar cost: grad nnz %zu/%d, upper Hessian nnz %zu, statements=%zu\n", d.name, grad.Nnz(), ncols, hes.Nnz(),
+                 em.Stats().statements);
+}
+
 void EmitC(const Generated& g, const std::string& dir) {
     const auto& d = g.dims;
     const std::string name = d.name;
@@ -507,6 +558,12 @@ int main(int argc, char** argv) {
         const Generated g = Record(s, jacMode);
         EmitHip(g, outDir);
         if (!cDir.empty()) EmitC(g, cDir);
+    }
+    // scalar stage-cost nodes (value + gradient + upper Hessian)
+    {
+        bool keep = only.empty();
+        for (const auto& o : only) keep = keep || o == models::kQuadrotorCostDims.name;
+        if (keep) EmitCostHip(models::kQuadrotorCostDims, models::QuadrotorCostNode<AD>, outDir);
     }
     return 0;
 }

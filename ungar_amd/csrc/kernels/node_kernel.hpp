@@ -28,9 +28,10 @@ struct OperandView {
 struct NodeLaunch {
     long long count, knots;
     OperandView x, u, w, p, f, jac;
+    OperandView hes{};  // Hessian values of scalar (cost) node models; unused by the dynamics models
 };
 
-enum : int { kModeValue = 0, kModeSparseJacobian = 1, kModeDenseJacobian = 2 };
+enum : int { kModeValue = 0, kModeSparseJacobian = 1, kModeDenseJacobian = 2, kModeHessian = 3 };
 
 /// Output store of the node kernels.  STREAM = true: non-temporal (the results are written once and not
 /// re-read by the kernel).  Measured on MI355X: +5..25 % for unit-fastest operands whose output exceeds

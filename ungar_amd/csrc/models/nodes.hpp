@@ -29,6 +29,8 @@ struct NodeDims {
 
 inline constexpr NodeDims kQuadrotorDims{"quadrotor", 13, 4, 0, 20};
 inline constexpr NodeDims kRcCarDims{"rc_car", 6, 2, 0, 15};
+/// Scalar stage cost of the quadrotor OCP (one output): p = [p_ref(3), q_ref(4), v_ref(3), omega_ref(3)].
+inline constexpr NodeDims kQuadrotorCostDims{"quadrotor_cost", 13, 4, 0, 13};
 inline constexpr NodeDims kSrbdDims{"srbd", 13, 24, 4, 6};
 inline constexpr NodeDims kAnymalDims{"anymal", 37, 12, 0, 1};
 
@@ -185,6 +187,26 @@ void FloatingBaseNode(const rbd::Model& model, const S* x, const S* u, const S* 
     for (std::size_t k = 6; k < nv; ++k) tau[k] = u[k - 6];
     const std::vector<S> a = rbd::Aba(model, q, v, tau);
     IntegrateFloatingBase(model, x, a.data(), p[0], xn);
+}
+
+/// Stage cost of example/mpc/quadrotor.example.cpp:196-236 for one knot: reference tracking with the
+/// sign-invariant quaternion term  min(|q - q_ref|^2, |q + q_ref|^2)  (:215-218) plus the input
+/// regularisation 1e-6 |u|^2 (:229-231).  The input-RATE term (:223-227) couples u_k with u_{k-1} and
+/// therefore lives in the whole-horizon function, not in the per-knot block.
+template <class S>
+void QuadrotorCostNode(const S* x, const S* u, const S* /*w*/, const S* p, S* y) {
+    S track{0.0};
+    for (int i = 0; i < 3; ++i) track = track + (x[i] - p[i]) * (x[i] - p[i]);
+    S minus{0.0}, plus{0.0};
+    for (int i = 0; i < 4; ++i) {
+        minus = minus + (x[3 + i] - p[3 + i]) * (x[3 + i] - p[3 + i]);
+        plus = plus + (x[3 + i] + p[3 + i]) * (x[3 + i] + p[3 + i]);
+    }
+    track = track + Min(minus, plus);
+    for (int i = 0; i < 6; ++i) track = track + (x[7 + i] - p[7 + i]) * (x[7 + i] - p[7 + i]);
+    S reg{0.0};
+    for (int i = 0; i < 4; ++i) reg = reg + u[i] * u[i];
+    y[0] = track + 1e-6 * reg;
 }
 
 }  // namespace ungar_amd::models

@@ -9,6 +9,7 @@
 
 #include <array>
 #include <cmath>
+#include <type_traits>
 #include <limits>
 
 namespace ungar_amd::models {
@@ -35,6 +36,13 @@ template <class S, class T>
 inline Vec3<S> Scale(const T& s, const Vec3<S>& a) {
     return {s * a[0], s * a[1], s * a[2]};
 }
+/// min(a, b); on the tape a conditional expression, as Utils::Min (reference utils.hpp:969-982).
+template <class S>
+inline S Min(const S& a, const S& b) {
+    if constexpr (std::is_arithmetic_v<S>) return a < b ? a : b;
+    else return CondExpGt(a, b, b, a);  // found by ADL in ungar_amd::tape
+}
+
 template <class S>
 inline S SquaredNorm(const Vec3<S>& a) {
     return a[0] * a[0] + a[1] * a[1] + a[2] * a[2];

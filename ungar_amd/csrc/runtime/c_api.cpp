@@ -26,6 +26,7 @@ UNGAR_AMD_DECLARE_MODEL(srbd)
 UNGAR_AMD_DECLARE_MODEL(anymal)
 UNGAR_AMD_DECLARE_MODEL(anymal_ad)
 UNGAR_AMD_DECLARE_MODEL(anymal_reg)
+UNGAR_AMD_DECLARE_MODEL(quadrotor_cost)
 
 namespace ungar_amd::kernels {
 struct OcpAssemblyArgs {
@@ -71,8 +72,9 @@ using ungar_amd::runtime::Fail;
 struct BuiltinEntry {
     const char* name;
     int (*launch)(int, const NodeLaunch*, void*);
-    const int* (*pattern)(int, int*);
+    const int* (*pattern)(int, int*);  // which = 0 / 1: Jacobian rows / cols; 2 / 3: Hessian rows / cols (scalar models)
     void (*dims)(int*);
+    bool scalar = false;  // one output (a stage cost) with gradient and upper-triangular Hessian
 };
 
 const BuiltinEntry kBuiltins[] = {
@@ -82,6 +84,7 @@ const BuiltinEntry kBuiltins[] = {
     {"anymal", ungar_amd_launch_anymal, ungar_amd_pattern_anymal, ungar_amd_dims_anymal},
     {"anymal_ad", ungar_amd_launch_anymal_ad, ungar_amd_pattern_anymal_ad, ungar_amd_dims_anymal_ad},
     {"anymal_reg", ungar_amd_launch_anymal_reg, ungar_amd_pattern_anymal_reg, ungar_amd_dims_anymal_reg},
+    {"quadrotor_cost", ungar_amd_launch_quadrotor_cost, ungar_amd_pattern_quadrotor_cost, ungar_amd_dims_quadrotor_cost, true},
 };
 
 OperandView View(const ungar_operand& o) {
@@ -104,7 +107,7 @@ struct ungar_model {
 
 namespace {
 
-int Evaluate(const ungar_model* model, const ungar_node_batch* batch, void* stream, int mode) {
+int Evaluate(const ungar_model* model, const ungar_node_batch* batch, void* stream, int mode, const ungar_operand* hes = nullptr) {
     if (!model || !batch) return Fail(UNGAR_E_INVALID, "null model or batch");
     if (batch->count < 0 || batch->knots < 1) return Fail(UNGAR_E_INVALID, "batch.count must be >= 0 and batch.knots >= 1");
     if (batch->count == 0) return UNGAR_OK;
@@ -113,10 +116,16 @@ int Evaluate(const ungar_model* model, const ungar_node_batch* batch, void* stre
         (model->info.nw > 0 && !batch->w.base))
         return Fail(UNGAR_E_INVALID, "null input operand for model '" + model->name + "'");
     if (mode == ungar_amd::kernels::kModeValue && !batch->f.base) return Fail(UNGAR_E_INVALID, "forward_zero needs an output operand f");
-    if (mode != ungar_amd::kernels::kModeValue && !batch->jac.base) return Fail(UNGAR_E_INVALID, "Jacobian evaluation needs an output operand jac");
+    if (mode == ungar_amd::kernels::kModeHessian) {
+        if (model->info.hes_nnz == 0) return Fail(UNGAR_E_UNSUPPORTED, "model '" + model->name + "' has no Hessian (vector-valued node model)");
+        if (!hes || !hes->base) return Fail(UNGAR_E_INVALID, "Hessian evaluation needs an output operand hes");
+    } else if (mode != ungar_amd::kernels::kModeValue && !batch->jac.base) {
+        return Fail(UNGAR_E_INVALID, "Jacobian evaluation needs an output operand jac");
+    }
     if (mode != ungar_amd::kernels::kModeValue && model->info.jac_nnz == 0)
         return Fail(UNGAR_E_UNSUPPORTED, "model '" + model->name + "' was built without a Jacobian");
     NodeLaunch a{batch->count, batch->knots, View(batch->x), View(batch->u), View(batch->w), View(batch->p), View(batch->f), View(batch->jac)};
+    if (hes) a.hes = View(*hes);
     const int err = model->launch(mode, &a, stream);
     if (err != 0)
         return Fail(UNGAR_E_HIP, std::string("kernel launch failed for model '") + model->name + "': " + hipGetErrorString(static_cast<hipError_t>(err)));
@@ -140,12 +149,20 @@ int ungar_model_open(const char* name, ungar_model** out) {
         const int* cols = e.pattern(1, &nnz);
         m->jacRows.assign(rows, rows + nnz);
         m->jacCols.assign(cols, cols + nnz);
-        m->info = {d[0], d[1], d[2], d[3], d[0], nnz, 0};
+        m->info = {d[0], d[1], d[2], d[3], e.scalar ? 1 : d[0], nnz, 0};
+        if (e.scalar) {
+            int hnnz = 0;
+            const int* hr = e.pattern(2, &hnnz);
+            const int* hc = e.pattern(3, &hnnz);
+            m->hesRows.assign(hr, hr + hnnz);
+            m->hesCols.assign(hc, hc + hnnz);
+            m->info.hes_nnz = hnnz;
+        }
         m->launch = e.launch;
         *out = m;
         return UNGAR_OK;
     }
-    return Fail(UNGAR_E_INVALID, std::string("unknown model '") + name + "' (built-ins: quadrotor, rc_car, srbd, anymal, anymal_ad, anymal_reg)");
+    return Fail(UNGAR_E_INVALID, std::string("unknown model '") + name + "' (built-ins: quadrotor, rc_car, srbd, anymal, anymal_ad, anymal_reg, quadrotor_cost)");
 }
 
 void ungar_model_close(ungar_model* model) {
@@ -197,6 +214,10 @@ int ungar_model_sparse_jacobian(const ungar_model* model, const ungar_node_batch
 }
 int ungar_model_dense_jacobian(const ungar_model* model, const ungar_node_batch* batch, void* stream) {
     return Evaluate(model, batch, stream, ungar_amd::kernels::kModeDenseJacobian);
+}
+
+int ungar_model_sparse_hessian(const ungar_model* model, const ungar_node_batch* batch, const ungar_operand* hes, void* stream) {
+    return Evaluate(model, batch, stream, ungar_amd::kernels::kModeHessian, hes);
 }
 
 extern "C" int ungar_amd_launch_gn_hessian_upper_soa(const double* jac, long long jes, const double* d, long long des, double* g, long long gs,
