@@ -319,3 +319,28 @@ def test_quadrotor_stage_cost_value_gradient_hessian(ua, repo_root):
     # vector-valued models refuse the Hessian entry point
     with pytest.raises(ua.UngarError):
         ua.NodeModel("quadrotor").hessian_sparsity()
+
+
+def test_pipeline_node_jacobian_to_gn_term(ua):
+    """BASELINE config 3 chain: ANYmal node Jacobians written by the lane-per-leg kernel in the unit-fastest
+    layout are consumed by the unit-fastest Gauss-Newton kernel with no transpose in between; the upper
+    triangle of J^T diag(d) J must equal the contraction of the very same device Jacobians done by torch."""
+    import torch
+    m = ua.NodeModel("anymal")
+    nx, ncols, count = m.nx, m.nx + m.nu, 1000  # ragged: not a multiple of 16
+    x, u, p = _device_inputs("anymal", count, seed=21)
+    f = torch.empty((nx, count), dtype=torch.float64, device="cuda")
+    J = torch.empty((nx * ncols, count), dtype=torch.float64, device="cuda")
+    m.dense_jacobian(count, ua.Operand.soa(x, count), ua.Operand.soa(u, count), None, ua.Operand.per_instance(p, m.np, shared=True),
+                     ua.Operand.soa(f, count), ua.Operand.soa(J, count))
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(9)
+    d = torch.rand((nx, count), generator=gen, device="cuda", dtype=torch.float64)
+    G = torch.full((count, ncols, ncols), float("nan"), dtype=torch.float64, device="cuda")
+    ua.gn_hessian_unit_fastest(J, d, G, nx, ncols, count)
+    torch.cuda.synchronize()
+    Jn = J.view(nx, ncols, count)
+    ref = torch.einsum("ran,rn,rbn->nab", Jn, d, Jn)
+    upper = torch.triu(torch.ones((ncols, ncols), dtype=torch.bool, device="cuda"))
+    assert (G[:, upper] - ref[:, upper]).abs().max().item() <= 1e-12 * ref.abs().max().item()
+    assert torch.isnan(G[:, ~upper]).all()
