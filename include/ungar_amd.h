@@ -73,7 +73,8 @@ typedef struct ungar_node_batch {
 /* ---- model lifetime ------------------------------------------------------------------------ */
 
 /* Opens one of the built-in node models: "quadrotor_cost" (scalar stage cost of the quadrotor OCP: value,
- * gradient, upper Hessian), "quadrotor", "rc_car", "srbd", "anymal" (structured
+ * gradient, upper Hessian), "srbd_ineq" (12 inequality rows per knot of the quadruped OCP and their Jacobian),
+ * "quadrotor", "rc_car", "srbd", "anymal" (structured
  * implicit differentiation, phased body with an LDS home), "anymal_reg" (same program, plain
  * straight-line body) or "anymal_ad" (same function, derivatives by taping ABA).
  * replaces FunctionFactory::Make -> DynamicLib::model(name)  (function.hpp:497, 589-604). */

@@ -48,6 +48,7 @@ DIMS = {  # name: (nx, nu, nw, np)
     "rc_car": (6, 2, 0, 15),
     "srbd": (13, 24, 4, 6),
     "anymal": (37, 12, 0, 1),
+    "srbd_ineq": (13, 24, 4, 14),  # 12 outputs per knot (inequality rows), not a dynamics node
 }
 
 
@@ -411,7 +412,19 @@ def anymal_node(x, u, w, p):
     return torch.cat((pos_n, quat_n, qj_n, v_n))
 
 
-NODES = {"quadrotor": quadrotor_node, "rc_car": rc_car_node, "srbd": srbd_node, "anymal": anymal_node}
+def srbd_ineq_node(x, u, w, p):
+    """Inequality rows h <= 0 of one knot of the quadruped OCP (quadruped.example.cpp:321-335): per leg
+    -s f_z, s |f_xy|~ - mu f_z, s |r - hip|~ - leg_length; p = [mu, 4 x hip(3), leg_length]."""
+    rows = []
+    for i in range(4):
+        f, r = u[6 * i:6 * i + 3], u[6 * i + 3:6 * i + 6]
+        hip = p[1 + 3 * i:4 + 3 * i]
+        s = w[i]
+        rows += [-s * f[2], s * approximate_norm(f[:2]) - p[0] * f[2], s * approximate_norm(r - hip) - p[13]]
+    return torch.stack(rows)
+
+
+NODES = {"quadrotor": quadrotor_node, "rc_car": rc_car_node, "srbd": srbd_node, "anymal": anymal_node, "srbd_ineq": srbd_ineq_node}
 
 
 # ----------------------------------------------------------------------------- evaluation API
@@ -487,6 +500,8 @@ def default_params(name: str) -> np.ndarray:
         return np.array([1.0 / 30.0, 25.0, 0.048125, 0.093125, 0.055625, 9.80665])
     if name == "anymal":
         return np.array([1.0 / 20.0])
+    if name == "srbd_ineq":  # quadruped.example.cpp:384-392
+        return np.array([0.7, 0.2, 0.15, -0.1, 0.2, -0.15, -0.1, -0.2, 0.15, -0.1, -0.2, -0.15, -0.1, 0.42])
     raise KeyError(name)
 
 
@@ -522,6 +537,9 @@ def synthetic_inputs(name: str, count: int, seed: int = 0):
         q /= np.linalg.norm(q, axis=1, keepdims=True)
         x = np.concatenate((rng.uniform(-1, 1, (count, 3)), q, rng.uniform(-1, 1, (count, 12)), rng.uniform(-1, 1, (count, 18))), axis=1)
         u = rng.uniform(-20, 20, (count, 12))
+    elif name == "srbd_ineq":  # states/forces/footholds as for the srbd dynamics node; some constraints violated
+        x, u, w, _ = synthetic_inputs("srbd", count, seed)
+        u[::3, 2::6] *= -0.1  # pulling contact forces: unilateral and friction rows active
     else:
         raise KeyError(name)
     return x, u, w, p

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 from oracle import ungar_oracle as O  # noqa: E402
 
-COUNTS = {"quadrotor": 24, "rc_car": 32, "srbd": 16, "anymal": 8}
+COUNTS = {"quadrotor": 24, "rc_car": 32, "srbd": 16, "anymal": 8, "srbd_ineq": 24}
 
 for name, count in COUNTS.items():
     x, u, w, p = O.synthetic_inputs(name, count, seed=7)

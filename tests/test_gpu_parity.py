@@ -344,3 +344,54 @@ def test_pipeline_node_jacobian_to_gn_term(ua):
     upper = torch.triu(torch.ones((ncols, ncols), dtype=torch.bool, device="cuda"))
     assert (G[:, upper] - ref[:, upper]).abs().max().item() <= 1e-12 * ref.abs().max().item()
     assert torch.isnan(G[:, ~upper]).all()
+
+
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+@pytest.mark.parametrize("mode", ["dense", "sparse"])
+def test_srbd_inequality_node_golden(ua, repo_root, layout, mode):
+    """'srbd_ineq': 12 inequality rows per knot (unilateral force, friction cone, leg reach) of the quadruped
+    OCP and their Jacobian; an output count different from nx (ny = 12)."""
+    g = np.load(f"{repo_root}/tests/golden/node_srbd_ineq.npz")
+    m = ua.NodeModel("srbd_ineq")
+    assert (m.nx, m.nu, m.nw, m.np, m.ny) == (13, 24, 4, 14, 12)
+    f, J = m.evaluate_numpy(g["x"], g["u"], g["w"], g["p"], mode=mode, layout=layout)
+    assert f.shape == g["f"].shape and J.shape == g["J"].shape
+    assert np.abs(f - g["f"]).max() <= 1e-12 * max(1.0, np.abs(g["f"]).max())
+    assert np.abs(J - g["J"]).max() <= 1e-12 * np.abs(g["J"]).max()
+    assert (g["f"] > 0).any() and (g["f"] < 0).any(), "the fixture must contain violated and satisfied rows"
+
+
+def test_barrier_gauss_newton_term_on_device(ua, repo_root):
+    """The Gauss-Newton barrier term of the soft SQP, J_h^T diag(b''(-h)) J_h (soft_sqp.hpp:257-264), per knot and
+    entirely on the device: inequality values and Jacobians from the 'srbd_ineq' node kernel, second derivatives
+    of the relaxed POLY barrier (soft_inequality_constraint.hpp:135-205) applied elementwise, contraction on the
+    FP64 matrix cores; checked against numpy on the oracle's h and J."""
+    import torch
+    count = 1000
+    x, u, w, p = O.synthetic_inputs("srbd_ineq", count, seed=3)
+    rh, rJ = O.node_jacobian("srbd_ineq", x[:64], u[:64], w[:64], p[:64])  # oracle on a slice (autograd is slow)
+    m = ua.NodeModel("srbd_ineq")
+    ny, ncols = m.ny, m.nx + m.nu
+    dev = "cuda"
+    tx, tu, tw = (torch.as_tensor(a.T.copy(), device=dev) for a in (x, u, w))
+    tp = torch.as_tensor(p[0].copy(), device=dev)
+    h = torch.empty((ny, count), dtype=torch.float64, device=dev)
+    J = torch.empty((ny * ncols, count), dtype=torch.float64, device=dev)
+    Op = ua.Operand
+    m.dense_jacobian(count, Op.soa(tx, count), Op.soa(tu, count), Op.soa(tw, count), Op.per_instance(tp, m.np, shared=True), Op.soa(h, count), Op.soa(J, count))
+    # b''(z) of RelaxedPolyBarrierFunction{rhs 0, stiffness k, epsilon e} at z = -h (the SQP's defaults: 100, 2e-5)
+    k, e = 100.0, 2e-5
+    a1, b1 = k, -0.5 * k * e
+    a2 = (-b1 - a1 * e) / e ** 2
+    z = -h
+    d2 = torch.where(z < 0.0, torch.full_like(z, a1), torch.where(z < e, 2.0 * a2 * z + a1, torch.zeros_like(z)))
+    G = torch.full((count, ncols, ncols), float("nan"), dtype=torch.float64, device=dev)
+    ua.gn_hessian_unit_fastest(J, d2, G, ny, ncols, count)
+    torch.cuda.synchronize()
+    Gh = G[:64].cpu().numpy()
+    zr = -rh
+    d2r = np.where(zr < 0.0, a1, np.where(zr < e, 2.0 * a2 * zr + a1, 0.0))
+    ref = np.einsum("nra,nr,nrb->nab", rJ, d2r, rJ)
+    iu = np.triu_indices(ncols)
+    assert np.abs(Gh[:, iu[0], iu[1]] - ref[:, iu[0], iu[1]]).max() <= 1e-10 * np.abs(ref).max()
+    assert np.abs(ref).max() > 1.0, "active barrier rows expected in the fixture"

@@ -20,7 +20,7 @@ BUILD = os.path.join(ROOT, "build")
 LIBDIR = os.path.join(ROOT, "ungar_amd", "lib")
 LIB = os.path.join(LIBDIR, "libungar_amd.so")
 ORACLE_GEN = os.path.join(ROOT, "oracle", "_gen")
-MODELS = ("quadrotor", "rc_car", "srbd", "anymal", "anymal_ad", "anymal_reg")
+MODELS = ("quadrotor", "rc_car", "srbd", "srbd_ineq", "anymal", "anymal_ad", "anymal_reg")
 C_MODELS = ("quadrotor", "rc_car", "srbd", "anymal", "anymal_ad")
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-Wno-unused-result"]
 

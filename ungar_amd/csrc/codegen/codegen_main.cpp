@@ -42,7 +42,7 @@ Generated Record(const NodeSpec& spec, int jacMode) {
     const auto& d = spec.dims;
     const int nIn = d.nx + d.nu + d.nw + d.np;
     std::vector<AD> in = tape::Independent(nIn);
-    std::vector<AD> out(static_cast<std::size_t>(d.nx));
+    std::vector<AD> out(static_cast<std::size_t>(d.Ny()));
     spec.fn(in.data(), in.data() + d.nx, in.data() + d.nx + d.nu, in.data() + d.nx + d.nu + d.nw, out.data());
     Generated g{d, tape::MakeTape(out), {}, 0};
     tape::Differentiator diff{g.tape};
@@ -235,7 +235,7 @@ void EmitHip(const Generated& g, const std::string& dir, bool columnMajorEmissio
     // Value only.
     {
         std::vector<tape::OutputSlot> slots;
-        for (int i = 0; i < d.nx; ++i) slots.push_back({g.tape.outputs[static_cast<std::size_t>(i)], "io.f(" + std::to_string(i) + ", %s);"});
+        for (int i = 0; i < d.Ny(); ++i) slots.push_back({g.tape.outputs[static_cast<std::size_t>(i)], "io.f(" + std::to_string(i) + ", %s);"});
         tape::Emitter em{g.tape.graph, InputNames(d, false)};
         const std::string body = em.Emit(slots);
         os << "// " << em.Stats().statements << " statements, " << em.Stats().flops << " flops, " << em.Stats().transcendentals
@@ -256,13 +256,13 @@ void EmitHip(const Generated& g, const std::string& dir, bool columnMajorEmissio
         if (columnMajorEmission) {
             // values first (they need the primal solve), then one Jacobian column after the other: each
             // column is an independent solve + chain rule, so its temporaries die before the next starts
-            for (int i = 0; i < d.nx; ++i) slots.push_back({g.tape.outputs[static_cast<std::size_t>(i)], "io.f(" + std::to_string(i) + ", %s);"});
+            for (int i = 0; i < d.Ny(); ++i) slots.push_back({g.tape.outputs[static_cast<std::size_t>(i)], "io.f(" + std::to_string(i) + ", %s);"});
             for (int c = 0; c < g.jac.cols; ++c)
                 for (std::size_t k = 0; k < g.jac.Nnz(); ++k)
                     if (g.jac.col[k] == c) jslot(k);
         } else {
             std::size_t k = 0;
-            for (int i = 0; i < d.nx; ++i) {
+            for (int i = 0; i < d.Ny(); ++i) {
                 slots.push_back({g.tape.outputs[static_cast<std::size_t>(i)], "io.f(" + std::to_string(i) + ", %s);"});
                 for (; k < g.jac.Nnz() && g.jac.row[k] == i; ++k) jslot(k);
             }
@@ -287,7 +287,7 @@ void EmitHip(const Generated& g, const std::string& dir, bool columnMajorEmissio
         for (int i = 0; i < d.np; ++i) names.push_back("io.p(" + std::to_string(i) + ")");
         for (int i = 0; i < 64; ++i) names.push_back("aux_unused");
         std::vector<std::vector<tape::OutputSlot>> phases(1);
-        for (int i = 0; i < d.nx; ++i) phases[0].push_back({g.tape.outputs[static_cast<std::size_t>(i)], "io.f(" + std::to_string(i) + ", %s);"});
+        for (int i = 0; i < d.Ny(); ++i) phases[0].push_back({g.tape.outputs[static_cast<std::size_t>(i)], "io.f(" + std::to_string(i) + ", %s);"});
         // Column order: columns that share sub-expressions are made neighbours so that the shared
         // values die quickly: base twist, pose, then (q_j, v_j, u_j) joint by joint.
         std::vector<int> colOrder;
@@ -395,7 +395,7 @@ void EmitC(const Generated& g, const std::string& dir) {
     os << "};\n\n";
     {
         std::vector<tape::OutputSlot> slots;
-        for (int i = 0; i < d.nx; ++i) slots.push_back({g.tape.outputs[static_cast<std::size_t>(i)], "f[" + std::to_string(i) + "] = %s;"});
+        for (int i = 0; i < d.Ny(); ++i) slots.push_back({g.tape.outputs[static_cast<std::size_t>(i)], "f[" + std::to_string(i) + "] = %s;"});
         tape::Emitter em{g.tape.graph, InputNames(d, true)};
         os << "void " << name << "_forward_zero(const double* x, const double* u, const double* w, const double* p, double* f) {\n"
            << "    (void)x; (void)u; (void)w; (void)p;\n"
@@ -403,7 +403,7 @@ void EmitC(const Generated& g, const std::string& dir) {
     }
     {
         std::vector<tape::OutputSlot> slots;
-        for (int i = 0; i < d.nx; ++i) slots.push_back({g.tape.outputs[static_cast<std::size_t>(i)], "f[" + std::to_string(i) + "] = %s;"});
+        for (int i = 0; i < d.Ny(); ++i) slots.push_back({g.tape.outputs[static_cast<std::size_t>(i)], "f[" + std::to_string(i) + "] = %s;"});
         for (std::size_t k = 0; k < g.jac.Nnz(); ++k) slots.push_back({g.jac.value[k], "jac[" + std::to_string(k) + "] = %s;"});
         tape::Emitter em{g.tape.graph, InputNames(d, true)};
         os << "void " << name
@@ -465,6 +465,7 @@ int main(int argc, char** argv) {
     specs.push_back({models::kQuadrotorDims, [](auto... a) { models::QuadrotorNode<AD>(a...); }});
     specs.push_back({models::kRcCarDims, [](auto... a) { models::RcCarNode<AD>(a...); }});
     specs.push_back({models::kSrbdDims, [](auto... a) { models::SrbdNode<AD>(a...); }});
+    specs.push_back({models::kSrbdIneqDims, [](auto... a) { models::SrbdIneqNode<AD>(a...); }});
     rbd::Model anymal;
     if (!robot.empty()) {
         anymal = rbd::BuildModel(rbd::ReadRobotDescription(robot));

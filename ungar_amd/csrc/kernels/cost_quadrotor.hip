@@ -66,4 +66,5 @@ extern "C" void ungar_amd_dims_quadrotor_cost(int* d) {
     d[1] = G::kNu;
     d[2] = G::kNw;
     d[3] = G::kNp;
+    d[4] = 1;
 }

@@ -223,6 +223,7 @@ inline hipError_t LaunchNodeModel(int mode, const NodeLaunch& a, hipStream_t str
         d[1] = ungar_amd::gen::ns::kNu;                                                                          \
         d[2] = ungar_amd::gen::ns::kNw;                                                                          \
         d[3] = ungar_amd::gen::ns::kNp;                                                                          \
+        d[4] = ungar_amd::gen::ns::kJacRows; /* outputs per node */                                              \
     }
 
 /// Binds a generated model namespace to the traits the skeletons expect and defines its launcher.
@@ -257,4 +258,5 @@ inline hipError_t LaunchNodeModel(int mode, const NodeLaunch& a, hipStream_t str
         d[1] = ungar_amd::gen::ns::kNu;                                                                          \
         d[2] = ungar_amd::gen::ns::kNw;                                                                          \
         d[3] = ungar_amd::gen::ns::kNp;                                                                          \
+        d[4] = ungar_amd::gen::ns::kJacRows; /* outputs per node */                                              \
     }

@@ -25,10 +25,17 @@ namespace ungar_amd::models {
 struct NodeDims {
     const char* name;
     int nx, nu, nw, np;
+    int ny = -1;  // outputs per node; -1: nx (a dynamics node x+ = f(x, u))
+    constexpr int Ny() const {
+        return ny < 0 ? nx : ny;
+    }
 };
 
 inline constexpr NodeDims kQuadrotorDims{"quadrotor", 13, 4, 0, 20};
 inline constexpr NodeDims kRcCarDims{"rc_car", 6, 2, 0, 15};
+/// Inequality rows of one knot of the single-rigid-body quadruped OCP, h(u; w, p) <= 0, three per leg
+/// (12 outputs): p = [friction_coefficient, 4 x b_hip_position(3), leg_length].
+inline constexpr NodeDims kSrbdIneqDims{"srbd_ineq", 13, 24, 4, 14, 12};
 /// Scalar stage cost of the quadrotor OCP (one output): p = [p_ref(3), q_ref(4), v_ref(3), omega_ref(3)].
 inline constexpr NodeDims kQuadrotorCostDims{"quadrotor_cost", 13, 4, 0, 13};
 inline constexpr NodeDims kSrbdDims{"srbd", 13, 24, 4, 6};
@@ -187,6 +194,27 @@ void FloatingBaseNode(const rbd::Model& model, const S* x, const S* u, const S* 
     for (std::size_t k = 6; k < nv; ++k) tau[k] = u[k - 6];
     const std::vector<S> a = rbd::Aba(model, q, v, tau);
     IntegrateFloatingBase(model, x, a.data(), p[0], xn);
+}
+
+/// Inequality constraints of example/mpc/quadruped.example.cpp:321-335 for one knot, per leg i:
+///   -s f_z <= 0                                   (unilateral contact force)
+///   s |f_xy|~ - mu f_z <= 0                       (friction cone, smoothed norm)
+///   s |r - hip_i|~ - leg_length <= 0              (kinematic reach)
+/// with u = 4 x [f(3), r(3)] as in SrbdNode, w = contact flags s; the state does not enter.
+template <class S>
+void SrbdIneqNode(const S* /*x*/, const S* u, const S* w, const S* p, S* h) {
+    const S mu = p[0], legLength = p[13];
+    for (int i = 0; i < 4; ++i) {
+        const Vec3<S> f{u[6 * i], u[6 * i + 1], u[6 * i + 2]};
+        const Vec3<S> r{u[6 * i + 3], u[6 * i + 4], u[6 * i + 5]};
+        const Vec3<S> hip{p[1 + 3 * i], p[2 + 3 * i], p[3 + 3 * i]};
+        const S& s = w[i];
+        using std::sqrt;
+        const S fxy = sqrt(f[0] * f[0] + f[1] * f[1] + S{std::numeric_limits<double>::epsilon()});  // Utils::ApproximateNorm
+        h[3 * i] = -s * f[2];
+        h[3 * i + 1] = s * fxy - mu * f[2];
+        h[3 * i + 2] = s * ApproximateNorm(Sub(r, hip)) - legLength;
+    }
 }
 
 /// Stage cost of example/mpc/quadrotor.example.cpp:196-236 for one knot: reference tracking with the

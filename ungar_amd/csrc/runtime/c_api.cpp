@@ -27,6 +27,7 @@ UNGAR_AMD_DECLARE_MODEL(anymal)
 UNGAR_AMD_DECLARE_MODEL(anymal_ad)
 UNGAR_AMD_DECLARE_MODEL(anymal_reg)
 UNGAR_AMD_DECLARE_MODEL(quadrotor_cost)
+UNGAR_AMD_DECLARE_MODEL(srbd_ineq)
 
 namespace ungar_amd::kernels {
 struct OcpAssemblyArgs {
@@ -84,6 +85,7 @@ const BuiltinEntry kBuiltins[] = {
     {"anymal", ungar_amd_launch_anymal, ungar_amd_pattern_anymal, ungar_amd_dims_anymal},
     {"anymal_ad", ungar_amd_launch_anymal_ad, ungar_amd_pattern_anymal_ad, ungar_amd_dims_anymal_ad},
     {"anymal_reg", ungar_amd_launch_anymal_reg, ungar_amd_pattern_anymal_reg, ungar_amd_dims_anymal_reg},
+    {"srbd_ineq", ungar_amd_launch_srbd_ineq, ungar_amd_pattern_srbd_ineq, ungar_amd_dims_srbd_ineq},
     {"quadrotor_cost", ungar_amd_launch_quadrotor_cost, ungar_amd_pattern_quadrotor_cost, ungar_amd_dims_quadrotor_cost, true},
 };
 
@@ -142,14 +144,14 @@ int ungar_model_open(const char* name, ungar_model** out) {
         if (std::strcmp(e.name, name) != 0) continue;
         auto* m = new ungar_model;
         m->name = name;
-        int d[4];
+        int d[5];
         e.dims(d);
         int nnz = 0;
         const int* rows = e.pattern(0, &nnz);
         const int* cols = e.pattern(1, &nnz);
         m->jacRows.assign(rows, rows + nnz);
         m->jacCols.assign(cols, cols + nnz);
-        m->info = {d[0], d[1], d[2], d[3], e.scalar ? 1 : d[0], nnz, 0};
+        m->info = {d[0], d[1], d[2], d[3], d[4], nnz, 0};
         if (e.scalar) {
             int hnnz = 0;
             const int* hr = e.pattern(2, &hnnz);
@@ -162,7 +164,7 @@ int ungar_model_open(const char* name, ungar_model** out) {
         *out = m;
         return UNGAR_OK;
     }
-    return Fail(UNGAR_E_INVALID, std::string("unknown model '") + name + "' (built-ins: quadrotor, rc_car, srbd, anymal, anymal_ad, anymal_reg, quadrotor_cost)");
+    return Fail(UNGAR_E_INVALID, std::string("unknown model '") + name + "' (built-ins: quadrotor, rc_car, srbd, anymal, anymal_ad, anymal_reg, srbd_ineq, quadrotor_cost)");
 }
 
 void ungar_model_close(ungar_model* model) {
@@ -259,6 +261,7 @@ int GnHessian(const double* jac, int64_t js, int64_t ld_j, const double* d, int6
 
 int ungar_ocp_equality_sparsity(const ungar_model* model, int64_t horizon, int32_t* row_starts, int32_t* cols, int64_t* nnz) {
     if (!model || !nnz || horizon < 1) return Fail(UNGAR_E_INVALID, "ungar_ocp_equality_sparsity: bad argument");
+    if (model->info.ny != model->info.nx) return Fail(UNGAR_E_UNSUPPORTED, "whole-horizon assembly needs a dynamics node model (ny == nx)");
     const int64_t nx = model->info.nx, nu = model->info.nu, nn = model->info.jac_nnz;
     *nnz = nx + horizon * (nn + nx);
     if (!row_starts || !cols) return UNGAR_OK;
@@ -290,6 +293,7 @@ int ungar_ocp_assemble_equality(const ungar_model* model, int64_t horizon, int64
     if (batch == 0) return UNGAR_OK;
     if (!x->base || !xm->base || !f->base || !jac->base || !g->base || !values->base)
         return Fail(UNGAR_E_INVALID, "ungar_ocp_assemble_equality: null operand base");
+    if (model->info.ny != model->info.nx) return Fail(UNGAR_E_UNSUPPORTED, "whole-horizon assembly needs a dynamics node model (ny == nx)");
     const int nx = static_cast<int>(model->info.nx), nn = static_cast<int>(model->info.jac_nnz);
     if (!model->devPattern) {  // one-time upload of the node pattern (cols + CSR row starts)
         std::vector<int> host(static_cast<std::size_t>(2 * nn + nx + 1), 0);
