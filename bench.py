@@ -75,7 +75,7 @@ def cpu_baseline(name, seconds=12.0):
     from oracle import build_oracle
     from oracle import ungar_oracle as O
     tag, flags = "portable", build_oracle.PORTABLE_FLAGS
-    lib = ctypes.CDLL(build_oracle.build(tag, models=(name,)) if not os.path.exists(build_oracle.lib_path(tag)) else build_oracle.lib_path(tag))
+    lib = ctypes.CDLL(build_oracle.build(tag))  # rebuilt only when its generated sources are newer
     nx, nu, nw, npar = O.DIMS[name]
     sample = 2048
     x, u, w, p = O.synthetic_inputs(name, sample, seed=99)
@@ -100,9 +100,29 @@ def cpu_baseline(name, seconds=12.0):
         dt = time.perf_counter() - t0
         if dt >= seconds:
             break
-    return {"value": evals / dt, "unit": "node Jacobian evals/s", "cores": 1, "kind": "port",
+    single = evals / dt
+    # (b) the whole sample spread over all host cores: one thread per core, each evaluating its contiguous share
+    # in ONE foreign call (C loop of oracle/_gen/batch_loops.c; ctypes releases the GIL) -- SURVEY.md section 8(d)
+    import threading
+    cores = os.cpu_count() or 1
+    loop = getattr(lib, f"{name}_sparse_jacobian_batch")
+    loop.argtypes = [dp] * 6 + [ctypes.c_long, ctypes.c_long, ctypes.c_long]
+    loop.restype = None
+    fo, jo = np.zeros((sample, nx)), np.zeros((sample, nnz))
+    share = sample // cores  # nodes per thread; every thread sweeps its share `reps` times
+    reps = max(1, int(single * max(2.0, seconds / 3) / max(1, share)))
+    threads = [threading.Thread(target=loop, args=(ptr(x), ptr(u), ptr(w), ptr(p), ptr(fo), ptr(jo), t * share, (t + 1) * share, reps)) for t in range(cores)]
+    t1 = time.perf_counter()
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    dt_all = time.perf_counter() - t1
+    counts = [share * cores * reps]
+    return {"value": single, "unit": "node Jacobian evals/s", "cores": 1, "kind": "port",
             "sample": f"{evals} single-instance calls of the tape-generated C Jacobian ({name}, sparse nnz={nnz}) over {sample} seeded nodes, "
-                      f"gcc {' '.join(flags)}, 1 thread, {dt:.1f} s, via ctypes"}
+                      f"gcc {' '.join(flags)}, 1 thread, {dt:.1f} s, via ctypes",
+            "all_cores": {"value": sum(counts) / dt_all, "cores": cores, "seconds": dt_all}}
 
 
 def main():
