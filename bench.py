@@ -104,13 +104,13 @@ def cpu_baseline(name, seconds=12.0):
     # (b) the whole sample spread over all host cores: one thread per core, each evaluating its contiguous share
     # in ONE foreign call (C loop of oracle/_gen/batch_loops.c; ctypes releases the GIL) -- SURVEY.md section 8(d)
     import threading
-    cores = os.cpu_count() or 1
+    cores = min(64, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))  # bounded: the box may be CPU-throttled
     loop = getattr(lib, f"{name}_sparse_jacobian_batch")
     loop.argtypes = [dp] * 6 + [ctypes.c_long, ctypes.c_long, ctypes.c_long]
     loop.restype = None
     fo, jo = np.zeros((sample, nx)), np.zeros((sample, nnz))
     share = sample // cores  # nodes per thread; every thread sweeps its share `reps` times
-    reps = max(1, int(single * max(2.0, seconds / 3) / max(1, share)))
+    reps = max(1, int(single * 1.5 / max(1, share)))  # ~1.5 s of single-thread work per thread
     threads = [threading.Thread(target=loop, args=(ptr(x), ptr(u), ptr(w), ptr(p), ptr(fo), ptr(jo), t * share, (t + 1) * share, reps)) for t in range(cores)]
     t1 = time.perf_counter()
     for th in threads:
