@@ -133,6 +133,100 @@ __global__ __launch_bounds__(BLOCK) void NodeKernel(const NodeLaunch a) {
     }
 }
 
+/// I/O policy for INSTANCE-MAJOR dense Jacobians (element stride 1: what a VariableMap-style buffer per
+/// instance looks like).  A lane storing its own node's entries one by one touches a different cache line
+/// in every lane of the wavefront (8 bytes per line per instruction: 3-4x slower than the unit-fastest
+/// layout).  Here every wavefront collects one Jacobian ROW of its 64 nodes in LDS and writes it out
+/// cooperatively: consecutive lanes store consecutive doubles of the node-major array, i.e. runs of NCOLS
+/// contiguous doubles per node.  The generated body emits the non-zeros row by row with literal (row, col)
+/// arguments, so `row != current` folds at compile time; rows are zero-filled in LDS, which also replaces the
+/// separate structural-zero stores.  No workgroup barrier: the buffer is per wavefront and LDS is in-order.
+template <int NROWS, int NCOLS>
+struct RowBufferedIO {
+    static constexpr int kPitch = NCOLS | 1;  // odd pitch: lane-strided writes hit distinct banks
+    const double* __restrict__ xb;
+    const double* __restrict__ ub;
+    const double* __restrict__ wb;
+    const double* __restrict__ pb;
+    double* __restrict__ fb;
+    long long xe, ue, we, pe, fe;
+    double* rowbuf;          // this wavefront's [64][kPitch] buffer
+    double* __restrict__ jw;  // Jacobian of the wavefront's first node
+    long long nodeStride;    // doubles between the Jacobians of consecutive nodes
+    int lane, nodesInWave;   // nodes of this wavefront that exist (tail)
+    int current = 0;
+
+    __device__ __forceinline__ double x(int i) const { return xb[i * xe]; }
+    __device__ __forceinline__ double u(int i) const { return ub[i * ue]; }
+    __device__ __forceinline__ double w(int i) const { return wb[i * we]; }
+    __device__ __forceinline__ double p(int i) const { return pb[i * pe]; }
+    __device__ __forceinline__ void f(int i, double v) const {
+        if (fb) fb[i * fe] = v;
+    }
+    __device__ __forceinline__ void clear() const {
+#pragma unroll
+        for (int c = 0; c < NCOLS; ++c) rowbuf[lane * kPitch + c] = 0.0;
+    }
+    __device__ __forceinline__ void flush(int row) const {
+        // flat index q over [node][col] of this row: lane l takes q = t * 64 + l
+        for (int q = lane; q < nodesInWave * NCOLS; q += 64) {
+            const int node = q / NCOLS, col = q - node * NCOLS;
+            jw[node * nodeStride + row * NCOLS + col] = rowbuf[node * kPitch + col];
+        }
+    }
+    __device__ __forceinline__ void j(int /*k*/, int r, int c, double v) {
+        while (current < r) {  // literal rows: unrolled and folded at compile time
+            flush(current);
+            clear();
+            ++current;
+        }
+        rowbuf[lane * kPitch + c] = v;
+    }
+    __device__ __forceinline__ void finish() {
+        while (current < NROWS) {
+            flush(current);
+            if (current + 1 < NROWS) clear();
+            ++current;
+        }
+    }
+};
+
+/// Dense Jacobians into node-major (element stride 1) operands, row-buffered through LDS (RowBufferedIO).
+/// Requires the Jacobians of consecutive nodes to be equally spaced (knots == 1, or contiguous trajectories).
+template <class M, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void NodeKernelAosDense(const NodeLaunch a, long long jacNodeStride) {
+    using IO = RowBufferedIO<M::kJacRows, M::kJacCols>;
+    __shared__ double lds[(BLOCK / 64) * 64 * IO::kPitch];
+    const long long first = static_cast<long long>(blockIdx.x) * BLOCK + (threadIdx.x & ~63);  // first node of the wavefront
+    if (first >= a.count) return;  // whole wavefront
+    const long long i = min(static_cast<long long>(blockIdx.x) * BLOCK + threadIdx.x, a.count - 1);  // tail lanes recompute the last node, store nothing
+    const bool exists = static_cast<long long>(blockIdx.x) * BLOCK + threadIdx.x < a.count;
+    long long b = i, k = 0;
+    if (a.knots > 1) {
+        b = i / a.knots;
+        k = i - b * a.knots;
+    }
+    long long fbq = first, fkq = 0;
+    if (a.knots > 1) {
+        fbq = first / a.knots;
+        fkq = first - fbq * a.knots;
+    }
+    IO io{a.x.base + b * a.x.bs + k * a.x.ks,
+          a.u.base + b * a.u.bs + k * a.u.ks,
+          a.w.base ? a.w.base + b * a.w.bs + k * a.w.ks : nullptr,
+          a.p.base + b * a.p.bs + k * a.p.ks,
+          (a.f.base && exists) ? a.f.base + b * a.f.bs + k * a.f.ks : nullptr,
+          a.x.es, a.u.es, a.w.es, a.p.es, a.f.es,
+          lds + (threadIdx.x >> 6) * 64 * IO::kPitch,
+          a.jac.base + fbq * a.jac.bs + fkq * a.jac.ks,
+          jacNodeStride,
+          static_cast<int>(threadIdx.x & 63),
+          static_cast<int>(min(64LL, a.count - first))};
+    io.clear();
+    M::ValueJacobian(io);
+    io.finish();
+}
+
 /// I/O policy of the phased bodies: StridedIO plus a per-lane LDS home for values that live across
 /// phases (slot s of lane l at lds[s * BLOCK + l]: a wavefront access is 64 consecutive doubles,
 /// conflict-free for ds_read_b64 / ds_write_b64) and a scheduling barrier between phases so that
@@ -185,6 +279,8 @@ inline hipError_t LaunchNodeModel(int mode, const NodeLaunch& a, hipStream_t str
             break;
         case kModeDenseJacobian:
             if constexpr (M::kLdsSlots > 0) hipLaunchKernelGGL((NodeKernelPhased<M, kModeDenseJacobian, BLOCK>), grid, block, 0, stream, a);
+            else if (M::kRowMajorEmission && a.jac.es == 1 && (a.knots == 1 || a.jac.bs == a.knots * a.jac.ks) && M::kJacCols <= 64)  // node-major: row-buffered stores
+                hipLaunchKernelGGL((NodeKernelAosDense<M, BLOCK>), grid, block, 0, stream, a, a.knots == 1 ? a.jac.bs : a.jac.ks);
             else if (streaming) hipLaunchKernelGGL((NodeKernel<M, kModeDenseJacobian, BLOCK, true>), grid, block, 0, stream, a);
             else hipLaunchKernelGGL((NodeKernel<M, kModeDenseJacobian, BLOCK, false>), grid, block, 0, stream, a);
             break;
@@ -202,6 +298,7 @@ inline hipError_t LaunchNodeModel(int mode, const NodeLaunch& a, hipStream_t str
         static constexpr int kNx = gen::ns::kNx, kNu = gen::ns::kNu, kNw = gen::ns::kNw, kNp = gen::ns::kNp;     \
         static constexpr int kJacRows = gen::ns::kJacRows, kJacCols = gen::ns::kJacCols, kJacNnz = gen::ns::kJacNnz; \
         static constexpr int kLdsSlots = gen::ns::kLdsSlots;                                                     \
+        static constexpr bool kRowMajorEmission = gen::ns::kJacMode < 10; /* structured bodies emit column by column */ \
         static constexpr int JacRow(int k) { return gen::ns::kJacRow[k]; }                                       \
         static constexpr int JacCol(int k) { return gen::ns::kJacCol[k]; }                                       \
         template <class IO>                                                                                      \
@@ -233,6 +330,7 @@ inline hipError_t LaunchNodeModel(int mode, const NodeLaunch& a, hipStream_t str
         static constexpr int kNx = gen::ns::kNx, kNu = gen::ns::kNu, kNw = gen::ns::kNw, kNp = gen::ns::kNp;     \
         static constexpr int kJacRows = gen::ns::kJacRows, kJacCols = gen::ns::kJacCols, kJacNnz = gen::ns::kJacNnz; \
         static constexpr int kLdsSlots = gen::ns::kLdsSlots;                                                     \
+        static constexpr bool kRowMajorEmission = gen::ns::kJacMode < 10; /* structured bodies emit column by column */ \
         static constexpr int JacRow(int k) { return gen::ns::kJacRow[k]; }                                       \
         static constexpr int JacCol(int k) { return gen::ns::kJacCol[k]; }                                       \
         template <class IO>                                                                                      \
