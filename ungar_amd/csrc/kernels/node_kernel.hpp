@@ -141,38 +141,46 @@ __global__ __launch_bounds__(BLOCK) void NodeKernel(const NodeLaunch a) {
 /// contiguous doubles per node.  The generated body emits the non-zeros row by row with literal (row, col)
 /// arguments, so `row != current` folds at compile time; rows are zero-filled in LDS, which also replaces the
 /// separate structural-zero stores.  No workgroup barrier: the buffer is per wavefront and LDS is in-order.
-template <int NROWS, int NCOLS>
+template <int NROWS, int NCOLS, int NX, int NU>
 struct RowBufferedIO {
-    static constexpr int kPitch = NCOLS | 1;  // odd pitch: lane-strided writes hit distinct banks
-    const double* __restrict__ xb;
-    const double* __restrict__ ub;
+    static constexpr int kPitch = NCOLS | 1;  // odd pitches: lane-strided LDS accesses hit distinct banks
+    static constexpr int kPitchX = NX | 1, kPitchU = NU | 1, kPitchF = NROWS | 1;
+    static constexpr int kDoublesPerWave = 64 * (kPitch + kPitchX + kPitchU + kPitchF);
     const double* __restrict__ wb;
     const double* __restrict__ pb;
-    double* __restrict__ fb;
-    long long xe, ue, we, pe, fe;
-    double* rowbuf;          // this wavefront's [64][kPitch] buffer
-    double* __restrict__ jw;  // Jacobian of the wavefront's first node
-    long long nodeStride;    // doubles between the Jacobians of consecutive nodes
-    int lane, nodesInWave;   // nodes of this wavefront that exist (tail)
+    long long we, pe;
+    double* rowbuf;  // this wavefront's [64][kPitch] Jacobian row
+    double* xl;      // [64][kPitchX] staged states
+    double* ul;      // [64][kPitchU] staged inputs
+    double* fl;      // [64][kPitchF] values, written out at the end
+    double* __restrict__ jw;  // Jacobian / value of the wavefront's first node
+    double* __restrict__ fw;
+    long long jacNodeStride, fNodeStride;  // doubles between consecutive nodes
+    int lane, nodesInWave;                 // nodes of this wavefront that exist (tail)
     int current = 0;
 
-    __device__ __forceinline__ double x(int i) const { return xb[i * xe]; }
-    __device__ __forceinline__ double u(int i) const { return ub[i * ue]; }
+    __device__ __forceinline__ double x(int i) const { return xl[lane * kPitchX + i]; }
+    __device__ __forceinline__ double u(int i) const { return ul[lane * kPitchU + i]; }
     __device__ __forceinline__ double w(int i) const { return wb[i * we]; }
     __device__ __forceinline__ double p(int i) const { return pb[i * pe]; }
-    __device__ __forceinline__ void f(int i, double v) const {
-        if (fb) fb[i * fe] = v;
+    __device__ __forceinline__ void f(int i, double v) const { fl[lane * kPitchF + i] = v; }
+
+    /// Cooperative copy between a node-major global array (n doubles per node, `stride` apart) and an LDS
+    /// tile [64][pitch]: lane l takes flat index q = t * 64 + l over [node][element].
+    template <int N, bool TO_LDS>
+    __device__ __forceinline__ void copy(double* tile, int pitch, double* __restrict__ global, long long stride) const {
+        for (int q = lane; q < nodesInWave * N; q += 64) {
+            const int node = q / N, e = q - node * N;
+            if constexpr (TO_LDS) tile[node * pitch + e] = global[node * stride + e];
+            else global[node * stride + e] = tile[node * pitch + e];
+        }
     }
     __device__ __forceinline__ void clear() const {
 #pragma unroll
         for (int c = 0; c < NCOLS; ++c) rowbuf[lane * kPitch + c] = 0.0;
     }
     __device__ __forceinline__ void flush(int row) const {
-        // flat index q over [node][col] of this row: lane l takes q = t * 64 + l
-        for (int q = lane; q < nodesInWave * NCOLS; q += 64) {
-            const int node = q / NCOLS, col = q - node * NCOLS;
-            jw[node * nodeStride + row * NCOLS + col] = rowbuf[node * kPitch + col];
-        }
+        copy<NCOLS, false>(rowbuf, kPitch, jw + row * NCOLS, jacNodeStride);
     }
     __device__ __forceinline__ void j(int /*k*/, int r, int c, double v) {
         while (current < r) {  // literal rows: unrolled and folded at compile time
@@ -188,40 +196,49 @@ struct RowBufferedIO {
             if (current + 1 < NROWS) clear();
             ++current;
         }
+        if (fw) copy<NROWS, false>(fl, kPitchF, fw, fNodeStride);
     }
 };
 
-/// Dense Jacobians into node-major (element stride 1) operands, row-buffered through LDS (RowBufferedIO).
-/// Requires the Jacobians of consecutive nodes to be equally spaced (knots == 1, or contiguous trajectories).
+/// Dense Jacobians for node-major (element stride 1) x, u, f and jac operands whose nodes are equally spaced
+/// (knots == 1, or contiguous trajectories): states and inputs are staged, values and Jacobian rows written
+/// out, through LDS with consecutive lanes on consecutive doubles (RowBufferedIO).
 template <class M, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void NodeKernelAosDense(const NodeLaunch a, long long jacNodeStride) {
-    using IO = RowBufferedIO<M::kJacRows, M::kJacCols>;
-    __shared__ double lds[(BLOCK / 64) * 64 * IO::kPitch];
+__global__ __launch_bounds__(BLOCK) void NodeKernelAosDense(const NodeLaunch a, long long xStride, long long uStride, long long fStride, long long jacStride) {
+    using IO = RowBufferedIO<M::kJacRows, M::kJacCols, M::kNx, M::kNu>;
+    __shared__ double lds[(BLOCK / 64) * IO::kDoublesPerWave];
     const long long first = static_cast<long long>(blockIdx.x) * BLOCK + (threadIdx.x & ~63);  // first node of the wavefront
     if (first >= a.count) return;  // whole wavefront
-    const long long i = min(static_cast<long long>(blockIdx.x) * BLOCK + threadIdx.x, a.count - 1);  // tail lanes recompute the last node, store nothing
-    const bool exists = static_cast<long long>(blockIdx.x) * BLOCK + threadIdx.x < a.count;
-    long long b = i, k = 0;
+    const long long i = min(static_cast<long long>(blockIdx.x) * BLOCK + threadIdx.x, a.count - 1);  // tail lanes recompute the last node
+    long long b = i, k = 0, fb = first, fk = 0;
     if (a.knots > 1) {
         b = i / a.knots;
         k = i - b * a.knots;
+        fb = first / a.knots;
+        fk = first - fb * a.knots;
     }
-    long long fbq = first, fkq = 0;
-    if (a.knots > 1) {
-        fbq = first / a.knots;
-        fkq = first - fbq * a.knots;
-    }
-    IO io{a.x.base + b * a.x.bs + k * a.x.ks,
-          a.u.base + b * a.u.bs + k * a.u.ks,
-          a.w.base ? a.w.base + b * a.w.bs + k * a.w.ks : nullptr,
+    double* const tile = lds + (threadIdx.x >> 6) * IO::kDoublesPerWave;
+    IO io{a.w.base ? a.w.base + b * a.w.bs + k * a.w.ks : nullptr,
           a.p.base + b * a.p.bs + k * a.p.ks,
-          (a.f.base && exists) ? a.f.base + b * a.f.bs + k * a.f.ks : nullptr,
-          a.x.es, a.u.es, a.w.es, a.p.es, a.f.es,
-          lds + (threadIdx.x >> 6) * 64 * IO::kPitch,
-          a.jac.base + fbq * a.jac.bs + fkq * a.jac.ks,
-          jacNodeStride,
+          a.w.es,
+          a.p.es,
+          tile,
+          tile + 64 * IO::kPitch,
+          tile + 64 * (IO::kPitch + IO::kPitchX),
+          tile + 64 * (IO::kPitch + IO::kPitchX + IO::kPitchU),
+          a.jac.base + fb * a.jac.bs + fk * a.jac.ks,
+          a.f.base ? a.f.base + fb * a.f.bs + fk * a.f.ks : nullptr,
+          jacStride,
+          fStride,
           static_cast<int>(threadIdx.x & 63),
           static_cast<int>(min(64LL, a.count - first))};
+    io.template copy<M::kNx, true>(io.xl, IO::kPitchX, const_cast<double*>(a.x.base + fb * a.x.bs + fk * a.x.ks), xStride);
+    if constexpr (M::kNu > 0) io.template copy<M::kNu, true>(io.ul, IO::kPitchU, const_cast<double*>(a.u.base + fb * a.u.bs + fk * a.u.ks), uStride);
+    // tail lanes (no node of their own) read the staged state of the last existing node
+    if (io.lane >= io.nodesInWave) {
+        for (int e = 0; e < M::kNx; ++e) io.xl[io.lane * IO::kPitchX + e] = io.xl[(io.nodesInWave - 1) * IO::kPitchX + e];
+        for (int e = 0; e < M::kNu; ++e) io.ul[io.lane * IO::kPitchU + e] = io.ul[(io.nodesInWave - 1) * IO::kPitchU + e];
+    }
     io.clear();
     M::ValueJacobian(io);
     io.finish();
@@ -261,6 +278,33 @@ __global__ __launch_bounds__(BLOCK) void NodeKernelPhased(const NodeLaunch a) {
     M::ValueJacobianPhased(io);
 }
 
+/// Node-major operand (element stride 1) whose nodes are equally spaced in memory.
+inline bool NodeMajorEquallySpaced(const NodeLaunch& a, const OperandView& o) {
+    return o.base && o.es == 1 && (a.knots == 1 || o.bs == a.knots * o.ks);
+}
+inline long long NodeStride(const NodeLaunch& a, const OperandView& o) {
+    return a.knots == 1 ? o.bs : o.ks;
+}
+
+/// The row-buffered node-major kernel needs a row-major body, equally spaced node-major x, u, f, jac and
+/// its LDS tiles to fit a workgroup's static allocation (the taped-ABA ANYmal comparison kernel does not).
+template <class M, int BLOCK>
+inline constexpr bool kAosDenseFits =
+    M::kRowMajorEmission && M::kLdsSlots == 0 &&
+    sizeof(double) * (BLOCK / 64) * RowBufferedIO<M::kJacRows, M::kJacCols, M::kNx, M::kNu>::kDoublesPerWave <= 64 * 1024;
+template <class M, int BLOCK>
+inline bool AosDenseApplies(const NodeLaunch& a) {
+    if constexpr (!kAosDenseFits<M, BLOCK>) return false;
+    else
+        return NodeMajorEquallySpaced(a, a.jac) && NodeMajorEquallySpaced(a, a.x) && (M::kNu == 0 || NodeMajorEquallySpaced(a, a.u)) &&
+               (!a.f.base || NodeMajorEquallySpaced(a, a.f));
+}
+template <class M, int BLOCK>
+inline void LaunchAosDense(const NodeLaunch& a, dim3 grid, dim3 block, hipStream_t stream) {
+    if constexpr (kAosDenseFits<M, BLOCK>)
+        hipLaunchKernelGGL((NodeKernelAosDense<M, BLOCK>), grid, block, 0, stream, a, NodeStride(a, a.x), NodeStride(a, a.u), NodeStride(a, a.f), NodeStride(a, a.jac));
+}
+
 template <class M, int BLOCK>
 inline hipError_t LaunchNodeModel(int mode, const NodeLaunch& a, hipStream_t stream) {
     if (a.count <= 0) return hipSuccess;
@@ -279,8 +323,7 @@ inline hipError_t LaunchNodeModel(int mode, const NodeLaunch& a, hipStream_t str
             break;
         case kModeDenseJacobian:
             if constexpr (M::kLdsSlots > 0) hipLaunchKernelGGL((NodeKernelPhased<M, kModeDenseJacobian, BLOCK>), grid, block, 0, stream, a);
-            else if (M::kRowMajorEmission && a.jac.es == 1 && (a.knots == 1 || a.jac.bs == a.knots * a.jac.ks) && M::kJacCols <= 64)  // node-major: row-buffered stores
-                hipLaunchKernelGGL((NodeKernelAosDense<M, BLOCK>), grid, block, 0, stream, a, a.knots == 1 ? a.jac.bs : a.jac.ks);
+            else if (AosDenseApplies<M, BLOCK>(a)) LaunchAosDense<M, BLOCK>(a, grid, block, stream);
             else if (streaming) hipLaunchKernelGGL((NodeKernel<M, kModeDenseJacobian, BLOCK, true>), grid, block, 0, stream, a);
             else hipLaunchKernelGGL((NodeKernel<M, kModeDenseJacobian, BLOCK, false>), grid, block, 0, stream, a);
             break;
