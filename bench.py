@@ -132,7 +132,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="anymal", choices=sorted(WORKLOADS))
     ap.add_argument("--batch-per-gpu", type=int, default=None)
-    ap.add_argument("--model", default=None, help="kernel variant of the workload's model (e.g. anymal_ad, anymal_lds)")
+    ap.add_argument("--model", default=None, help="kernel variant of the workload's model (e.g. anymal_ad, anymal_reg)")
     ap.add_argument("--layout", default="soa", choices=["soa"])
     ap.add_argument("--jacobian", default="dense", choices=["dense", "sparse"],
                     help="dense [A|B] block (BASELINE metric, default) or the CSR value array of Function::Jacobian (function.hpp:216-230)")
