@@ -97,3 +97,16 @@ def test_function_factory_rejects_bad_tapes():
     out2 = (ctypes.c_int32 * 2)(0, 1)
     rc = lib.ungar_function_make(nodes, 2, out2, 2, 1, 0, b"bad", 6, None, 0, ctypes.byref(fn))
     assert rc == -3 and b"scalar functions" in lib.ungar_last_error()
+
+
+def test_header_is_plain_c(repo_root, tmp_path):
+    """include/ungar_amd.h compiled as C99 (-pedantic -Werror) and linked against the library: no C++ leaks into
+    the boundary; the host-only entry points (open / info / version) work without a GPU."""
+    import subprocess
+    exe = str(tmp_path / "abi_smoke")
+    lib = os.path.join(repo_root, "ungar_amd", "lib")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(repo_root, "include"),
+                    os.path.join(repo_root, "tests", "c", "abi_smoke.c"), "-o", exe, "-L", lib, "-lungar_amd", f"-Wl,-rpath,{lib}", "-Wl,-rpath,/opt/rocm/lib"],
+                   check=True)
+    out = subprocess.run([exe], capture_output=True, text=True, check=True).stdout
+    assert "quadrotor_cost nx=13 ny=1 hes_nnz=17" in out
