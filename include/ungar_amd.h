@@ -72,8 +72,8 @@ typedef struct ungar_node_batch {
 
 /* ---- model lifetime ------------------------------------------------------------------------ */
 
-/* Opens one of the built-in node models: "quadrotor_cost" (scalar stage cost of the quadrotor OCP: value,
- * gradient, upper Hessian), "srbd_ineq" (12 inequality rows per knot of the quadruped OCP and their Jacobian),
+/* Opens one of the built-in node models: "quadrotor_cost" / "srbd_cost" (scalar stage costs of the quadrotor and
+ * quadruped OCPs: value, gradient, upper Hessian), "srbd_ineq" (12 inequality rows per knot of the quadruped OCP and their Jacobian),
  * "quadrotor", "rc_car", "srbd", "anymal" (structured
  * implicit differentiation, phased body with an LDS home), "anymal_reg" (same program, plain
  * straight-line body) or "anymal_ad" (same function, derivatives by taping ABA).

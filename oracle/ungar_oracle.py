@@ -438,13 +438,30 @@ def quadrotor_cost(x, u, p):
     return track + 1e-6 * (u ** 2).sum()
 
 
-def cost_value_gradient_hessian(x, u, p):
+def srbd_cost(x, u, p):
+    """Per-knot stage cost of example/mpc/quadruped.example.cpp:215-245:
+    p = [p_ref(3), q_ref(4), v_ref(3), omega_ref(3), 4 x b_reference_foot_position(3)], u = 4 x [f(3), r(3)]."""
+    weight = torch.tensor([0.1, 0.1, 10.0], dtype=torch.float64)
+    value = ((weight * (x[0:3] - p[0:3])) ** 2).sum()
+    value = value + torch.minimum(((x[3:7] - p[3:7]) ** 2).sum(), ((x[3:7] + p[3:7]) ** 2).sum())
+    value = value + ((x[7:13] - p[7:13]) ** 2).sum()
+    for leg in range(4):
+        f, r = u[6 * leg:6 * leg + 3], u[6 * leg + 3:6 * leg + 6]
+        value = value + ((r - p[13 + 3 * leg:16 + 3 * leg]) ** 2).sum() + 1e-8 * (f ** 2).sum()
+    return value
+
+
+COSTS = {"quadrotor_cost": (quadrotor_cost, 13, 4, 13), "srbd_cost": (srbd_cost, 13, 24, 25)}  # fn, nx, nu, np
+
+
+def cost_value_gradient_hessian(x, u, p, name="quadrotor_cost"):
     """(y, gradient, dense Hessian) w.r.t. z = (x, u) for a batch of numpy inputs."""
+    cost, nx = COSTS[name][0], COSTS[name][1]
     X, U, P = (torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64) for a in (x, u, p))
     ys, gs, hs = [], [], []
     for b in range(X.shape[0]):
         z = torch.cat((X[b], U[b])).requires_grad_(True)
-        fn = lambda zz: quadrotor_cost(zz[:13], zz[13:], P[b])  # noqa: E731
+        fn = lambda zz: cost(zz[:nx], zz[nx:], P[b])  # noqa: E731
         y = fn(z)
         (g,) = torch.autograd.grad(y, z, create_graph=False)
         ys.append(y.detach())
@@ -453,14 +470,17 @@ def cost_value_gradient_hessian(x, u, p):
     return torch.stack(ys).numpy(), torch.stack(gs).numpy(), torch.stack(hs).numpy()
 
 
-def synthetic_cost_inputs(count: int, seed: int = 0):
-    """States/inputs as for the quadrotor node, references = perturbed states (some with flipped quaternion
-    sign, so that both branches of the min are exercised)."""
-    x, u, _, _ = synthetic_inputs("quadrotor", count, seed)
+def synthetic_cost_inputs(count: int, seed: int = 0, name: str = "quadrotor_cost"):
+    """States/inputs as for the dynamics node, references = perturbed states (some with flipped quaternion
+    sign, so that both branches of the min are exercised); srbd_cost: plus perturbed footholds."""
+    x, u, _, _ = synthetic_inputs("quadrotor" if name == "quadrotor_cost" else "srbd", count, seed)
     rng = np.random.default_rng(0xC057 + seed)
     ref = x + rng.normal(scale=0.3, size=x.shape)
     ref[:, 3:7] /= np.linalg.norm(ref[:, 3:7], axis=1, keepdims=True)
     ref[::2, 3:7] *= -1.0
+    if name == "srbd_cost":
+        feet = np.concatenate([u[:, 6 * leg + 3:6 * leg + 6] for leg in range(4)], axis=1)
+        ref = np.concatenate((ref, feet + rng.normal(scale=0.05, size=feet.shape)), axis=1)
     return x, u, ref
 
 

@@ -21,7 +21,8 @@ for name, count in COUNTS.items():
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", f"node_{name}.npz"), x=x, u=u, w=w, p=p, f=f, J=J)
     print(name, count, "max|J|", np.abs(J).max())
 
-x, u, ref = O.synthetic_cost_inputs(32, seed=7)
-y, g, H = O.cost_value_gradient_hessian(x, u, ref)
-np.savez_compressed(os.path.join(ROOT, "tests", "golden", "cost_quadrotor.npz"), x=x, u=u, p=ref, y=y, g=g, H=H)
-print("quadrotor_cost", 32, "max|H|", np.abs(H).max())
+for cost, fname in (("quadrotor_cost", "cost_quadrotor.npz"), ("srbd_cost", "cost_srbd.npz")):
+    x, u, ref = O.synthetic_cost_inputs(32, seed=7, name=cost)
+    y, g, H = O.cost_value_gradient_hessian(x, u, ref, name=cost)
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", fname), x=x, u=u, p=ref, y=y, g=g, H=H)
+    print(cost, 32, "max|H|", np.abs(H).max())

@@ -278,14 +278,16 @@ def test_gn_hessian_mfma(ua):
         assert torch.isnan(S[:, ~upper]).all()
 
 
-def test_quadrotor_stage_cost_value_gradient_hessian(ua, repo_root):
-    """Scalar node model 'quadrotor_cost' (SURVEY.md section 8(f) N2): value, gradient and upper-triangular
-    Hessian w.r.t. (x, u) against torch.autograd on the oracle's restatement of the reference's stage cost,
-    in both operand layouts; inputs exercise both branches of the quaternion min."""
+@pytest.mark.parametrize("name,fixture,nu,npar", [("quadrotor_cost", "cost_quadrotor.npz", 4, 13), ("srbd_cost", "cost_srbd.npz", 24, 25)])
+def test_stage_cost_value_gradient_hessian(ua, repo_root, name, fixture, nu, npar):
+    """Scalar node models 'quadrotor_cost' / 'srbd_cost' (SURVEY.md section 8(f) N2): value, gradient and
+    upper-triangular Hessian w.r.t. (x, u) against torch.autograd on the oracle's restatement of the
+    reference's stage costs, in both operand layouts; inputs exercise both branches of the quaternion min."""
     import torch
-    g = np.load(f"{repo_root}/tests/golden/cost_quadrotor.npz")
-    m = ua.NodeModel("quadrotor_cost")
-    assert (m.nx, m.nu, m.np, m.ny, m.jac_nnz) == (13, 4, 13, 1, 17) and m.implements_hessian()
+    g = np.load(f"{repo_root}/tests/golden/{fixture}")
+    m = ua.NodeModel(name)
+    ncols = 13 + nu
+    assert (m.nx, m.nu, m.np, m.ny, m.jac_nnz) == (13, nu, npar, 1, ncols) and m.implements_hessian()
     rows, cols = m.hessian_sparsity()
     assert (rows <= cols).all(), "upper triangle only (function.hpp:236-274)"
     count = g["x"].shape[0]
@@ -296,9 +298,9 @@ def test_quadrotor_stage_cost_value_gradient_hessian(ua, repo_root):
         mk = (lambda ten, n: ua.Operand.soa(ten, count)) if layout == "soa" else (lambda ten, n: ua.Operand.aos(ten, n))
         x, u, p = t(g["x"]), t(g["u"]), t(g["p"])
         y = torch.full(shape(1), float("nan"), dtype=torch.float64, device=dev)
-        grad = torch.full(shape(17), float("nan"), dtype=torch.float64, device=dev)
+        grad = torch.full(shape(ncols), float("nan"), dtype=torch.float64, device=dev)
         hes = torch.full(shape(len(rows)), float("nan"), dtype=torch.float64, device=dev)
-        m.sparse_hessian(count, mk(x, 13), mk(u, 4), None, mk(p, 13), mk(y, 1), mk(grad, 17), mk(hes, len(rows)))
+        m.sparse_hessian(count, mk(x, 13), mk(u, nu), None, mk(p, npar), mk(y, 1), mk(grad, ncols), mk(hes, len(rows)))
         torch.cuda.synchronize()
         Y, G, H = (a.cpu().numpy().T if layout == "soa" else a.cpu().numpy() for a in (y, grad, hes))
         assert np.abs(Y[:, 0] - g["y"]).max() <= 1e-12 * np.abs(g["y"]).max()
@@ -311,7 +313,7 @@ def test_quadrotor_stage_cost_value_gradient_hessian(ua, repo_root):
     x, u, p = (torch.as_tensor(g[k].T.copy(), device=dev) for k in ("x", "u", "p"))
     y2 = torch.empty((1, count), dtype=torch.float64, device=dev)
     m.forward_zero(count, ua.Operand.soa(x, count), ua.Operand.soa(u, count), None, ua.Operand.soa(p, count), ua.Operand.soa(y2, count))
-    g2 = torch.empty((17, count), dtype=torch.float64, device=dev)
+    g2 = torch.empty((ncols, count), dtype=torch.float64, device=dev)
     m.dense_jacobian(count, ua.Operand.soa(x, count), ua.Operand.soa(u, count), None, ua.Operand.soa(p, count), ua.Operand.soa(y2, count), ua.Operand.soa(g2, count))
     torch.cuda.synchronize()
     assert np.abs(y2.cpu().numpy()[0] - g["y"]).max() <= 1e-12 * np.abs(g["y"]).max()

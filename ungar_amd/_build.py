@@ -59,7 +59,7 @@ def build_codegen() -> str:
 
 
 def generate(exe: str):
-    outs = [os.path.join(GEN, f"{m}_gen.hpp") for m in MODELS + ("quadrotor_cost",)] + [os.path.join(ORACLE_GEN, f"{m}_cg.c") for m in C_MODELS]
+    outs = [os.path.join(GEN, f"{m}_gen.hpp") for m in MODELS + ("quadrotor_cost", "srbd_cost")] + [os.path.join(ORACLE_GEN, f"{m}_cg.c") for m in C_MODELS]
     robot = os.path.join(ROOT, "ungar_amd", "data", "anymal_b.robot")
     if not _newer(outs, [exe, robot]):
         os.makedirs(GEN, exist_ok=True)
@@ -83,7 +83,8 @@ def build_library(jobs: int | None = None):
     for name in sorted(os.listdir(os.path.join(CSRC, "kernels"))):
         if name.endswith(".hip") and not name.startswith("model_"):
             src = os.path.join(CSRC, "kernels", name)
-            extra = quad_deps if name.startswith("quad_") else [os.path.join(GEN, f"quadrotor_cost_gen.hpp")] if name.startswith("cost_") else []
+            extra = (quad_deps if name.startswith("quad_") else
+                     [os.path.join(GEN, f"{name[5:-4]}_cost_gen.hpp"), os.path.join(CSRC, "kernels", "cost_kernel.hpp")] if name.startswith("cost_") else [])
             units.append((src, os.path.join(BUILD, name[:-4] + ".o"), [src, kernel_hdr] + extra))
     src = os.path.join(CSRC, "runtime", "c_api.cpp")
     units.append((src, os.path.join(BUILD, "c_api.o"), [src, kernel_hdr, abi_hdr]))

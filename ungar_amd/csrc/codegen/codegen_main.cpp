@@ -565,6 +565,9 @@ int main(int argc, char** argv) {
         bool keep = only.empty();
         for (const auto& o : only) keep = keep || o == models::kQuadrotorCostDims.name;
         if (keep) EmitCostHip(models::kQuadrotorCostDims, models::QuadrotorCostNode<AD>, outDir);
+        keep = only.empty();
+        for (const auto& o : only) keep = keep || o == models::kSrbdCostDims.name;
+        if (keep) EmitCostHip(models::kSrbdCostDims, models::SrbdCostNode<AD>, outDir);
     }
     return 0;
 }

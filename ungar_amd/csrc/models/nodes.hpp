@@ -36,6 +36,8 @@ inline constexpr NodeDims kRcCarDims{"rc_car", 6, 2, 0, 15};
 /// Inequality rows of one knot of the single-rigid-body quadruped OCP, h(u; w, p) <= 0, three per leg
 /// (12 outputs): p = [friction_coefficient, 4 x b_hip_position(3), leg_length].
 inline constexpr NodeDims kSrbdIneqDims{"srbd_ineq", 13, 24, 4, 14, 12};
+/// Scalar stage cost of the quadruped OCP: p = [p_ref(3), q_ref(4), v_ref(3), omega_ref(3), 4 x b_reference_foot_position(3)].
+inline constexpr NodeDims kSrbdCostDims{"srbd_cost", 13, 24, 0, 25};
 /// Scalar stage cost of the quadrotor OCP (one output): p = [p_ref(3), q_ref(4), v_ref(3), omega_ref(3)].
 inline constexpr NodeDims kQuadrotorCostDims{"quadrotor_cost", 13, 4, 0, 13};
 inline constexpr NodeDims kSrbdDims{"srbd", 13, 24, 4, 6};
@@ -235,6 +237,36 @@ void QuadrotorCostNode(const S* x, const S* u, const S* /*w*/, const S* p, S* y)
     S reg{0.0};
     for (int i = 0; i < 4; ++i) reg = reg + u[i] * u[i];
     y[0] = track + 1e-6 * reg;
+}
+
+/// Stage cost of example/mpc/quadruped.example.cpp:215-245 for one knot: weighted position tracking
+/// |diag(0.1, 0.1, 10) (p - p_ref)|^2, sign-invariant quaternion term, velocity tracking, foothold tracking
+/// |r_i - r_ref_i|^2 and force regularisation 1e-8 |f_i|^2; u = 4 x [f(3), r(3)] as in SrbdNode.
+template <class S>
+void SrbdCostNode(const S* x, const S* u, const S* /*w*/, const S* p, S* y) {
+    const double weight[3] = {0.1, 0.1, 10.0};
+    S value{0.0};
+    for (int i = 0; i < 3; ++i) {
+        const S e = weight[i] * (x[i] - p[i]);
+        value = value + e * e;
+    }
+    S minus{0.0}, plus{0.0};
+    for (int i = 0; i < 4; ++i) {
+        minus = minus + (x[3 + i] - p[3 + i]) * (x[3 + i] - p[3 + i]);
+        plus = plus + (x[3 + i] + p[3 + i]) * (x[3 + i] + p[3 + i]);
+    }
+    value = value + Min(minus, plus);
+    for (int i = 0; i < 6; ++i) value = value + (x[7 + i] - p[7 + i]) * (x[7 + i] - p[7 + i]);
+    for (int leg = 0; leg < 4; ++leg) {
+        S foothold{0.0}, force{0.0};
+        for (int k = 0; k < 3; ++k) {
+            const S e = u[6 * leg + 3 + k] - p[13 + 3 * leg + k];
+            foothold = foothold + e * e;
+            force = force + u[6 * leg + k] * u[6 * leg + k];
+        }
+        value = value + foothold + 1e-8 * force;
+    }
+    y[0] = value;
 }
 
 }  // namespace ungar_amd::models

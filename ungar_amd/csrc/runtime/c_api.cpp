@@ -27,6 +27,7 @@ UNGAR_AMD_DECLARE_MODEL(anymal)
 UNGAR_AMD_DECLARE_MODEL(anymal_ad)
 UNGAR_AMD_DECLARE_MODEL(anymal_reg)
 UNGAR_AMD_DECLARE_MODEL(quadrotor_cost)
+UNGAR_AMD_DECLARE_MODEL(srbd_cost)
 UNGAR_AMD_DECLARE_MODEL(srbd_ineq)
 
 namespace ungar_amd::kernels {
@@ -87,6 +88,7 @@ const BuiltinEntry kBuiltins[] = {
     {"anymal_reg", ungar_amd_launch_anymal_reg, ungar_amd_pattern_anymal_reg, ungar_amd_dims_anymal_reg},
     {"srbd_ineq", ungar_amd_launch_srbd_ineq, ungar_amd_pattern_srbd_ineq, ungar_amd_dims_srbd_ineq},
     {"quadrotor_cost", ungar_amd_launch_quadrotor_cost, ungar_amd_pattern_quadrotor_cost, ungar_amd_dims_quadrotor_cost, true},
+    {"srbd_cost", ungar_amd_launch_srbd_cost, ungar_amd_pattern_srbd_cost, ungar_amd_dims_srbd_cost, true},
 };
 
 OperandView View(const ungar_operand& o) {
@@ -164,7 +166,7 @@ int ungar_model_open(const char* name, ungar_model** out) {
         *out = m;
         return UNGAR_OK;
     }
-    return Fail(UNGAR_E_INVALID, std::string("unknown model '") + name + "' (built-ins: quadrotor, rc_car, srbd, anymal, anymal_ad, anymal_reg, srbd_ineq, quadrotor_cost)");
+    return Fail(UNGAR_E_INVALID, std::string("unknown model '") + name + "' (built-ins: quadrotor, rc_car, srbd, anymal, anymal_ad, anymal_reg, srbd_ineq, quadrotor_cost, srbd_cost)");
 }
 
 void ungar_model_close(ungar_model* model) {
