@@ -233,6 +233,7 @@ def load_robot(path: str) -> OModel:
     model = OModel()
     model.joints.append(OJoint("universe", 0, np.eye(3), np.zeros(3), None, np.zeros((6, 6))))
     model.joints.append(OJoint("root_joint", 0, np.eye(3), np.zeros(3), None, link_Y(root)))
+    model.frames = [(root, 1, np.eye(3), np.zeros(3))]  # (link name, supporting joint, R, p in that joint's frame)
 
     def visit(link, support, R, p):
         for name in sorted(joints):  # ASCII order, as std::map<std::string,...>
@@ -244,9 +245,11 @@ def load_robot(path: str) -> OModel:
             if j["type"] == "fixed":
                 X = _force_xform(Rj, pj)
                 model.joints[support].Y = model.joints[support].Y + X @ link_Y(j["child"]) @ X.T
+                model.frames.append((j["child"], support, Rj, pj))
                 visit(j["child"], support, Rj, pj)
             else:
                 model.joints.append(OJoint(name, support, Rj, pj, j["axis"], link_Y(j["child"])))
+                model.frames.append((j["child"], len(model.joints) - 1, np.eye(3), np.zeros(3)))
                 visit(j["child"], len(model.joints) - 1, np.eye(3), np.zeros(3))
 
     visit(root, 1, np.eye(3), np.zeros(3))
@@ -335,6 +338,22 @@ def _force_xform_t(R, p):
     top = torch.cat((R, torch.zeros(3, 3)), dim=1)
     bot = torch.cat((px @ R, R), dim=1)
     return torch.cat((top, bot), dim=0)
+
+
+def frame_placements(model: OModel, q):
+    """World placement (R, p) of every frame of the model for configuration q (forward kinematics)."""
+    Rs, ps, _, _ = _kinematics(model, q, torch.zeros(model.nv, dtype=torch.float64))
+    oR, op = [None] * len(model.joints), [None] * len(model.joints)
+    for i in range(1, len(model.joints)):
+        par = model.joints[i].parent
+        if par == 0:
+            oR[i], op[i] = Rs[i], ps[i]
+        else:
+            oR[i], op[i] = oR[par] @ Rs[i], op[par] + oR[par] @ ps[i]
+    out = {}
+    for name, joint, R, p in model.frames:
+        out[name] = (oR[joint] @ torch.as_tensor(R), op[joint] + oR[joint] @ torch.as_tensor(p))
+    return out
 
 
 def aba(model: OModel, q, v, tau):

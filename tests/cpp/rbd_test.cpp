@@ -11,6 +11,7 @@
 #include <random>
 
 #include "ungar/autodiff/function.hpp"
+#include "ungar/rbd/quantities/frames.hpp"
 #include "ungar/rbd/quantities/generalized_accelerations.hpp"
 #include "ungar/rbd/robot.hpp"
 
@@ -106,6 +107,24 @@ int main(int argc, char** argv) {
     robot.Compute(qs::potential_energy).At(q);
     robot.Compute(qs::com_position).At(q);
     EXPECT_TRUE(std::fabs(robot.Get(qs::potential_energy) - 9.81 * robot.Model().impl.TotalMass() * robot.Get(qs::com_position)[2]) < 1e-9);
+
+    // forward kinematics of the frames (one per link; the feet are links lumped through fixed joints)
+    robot.Compute(qs::frames).At(q);
+    EXPECT_TRUE(robot.Model().nframes == static_cast<int>(robot.Get(qs::frames).size()) && robot.Model().existFrame("LF_FOOT") && !robot.Model().existFrame("no_such_frame"));
+    {
+        const auto& base = robot.Get(qs::frames)[0];  // the root link sits in the free-flyer joint frame
+        EXPECT_TRUE(std::fabs(base.translation()[0] - q[0]) + std::fabs(base.translation()[1] - q[1]) + std::fabs(base.translation()[2] - q[2]) < 1e-15);
+    }
+    for (const char* name : {"base", "LF_FOOT", "LH_FOOT", "RF_FOOT", "RH_FOOT", "LF_SHANK"}) {
+        const int id = robot.Model().getFrameId(name);
+        if (id >= robot.Model().nframes) continue;
+        const auto& pose = robot.Get(qs::frames)[static_cast<std::size_t>(id)];
+        std::printf("frame %s", name);
+        for (int k = 0; k < 3; ++k) std::printf(" %.17g", pose.translation()[k]);
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) std::printf(" %.17g", pose.rotation()[static_cast<std::size_t>(r)][static_cast<std::size_t>(c)]);
+        std::printf("\n");
+    }
 
     std::printf("q");
     for (index_t i = 0; i < nq; ++i) std::printf(" %.17g", q[i]);

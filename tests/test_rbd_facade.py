@@ -22,6 +22,7 @@ def _run(repo_root, mode, tmp_path):
     print(r.stdout[-3000:], r.stderr[-2000:])
     assert r.returncode == 0 and "PASSED" in r.stdout
     vals = {line.split()[0]: np.array([float(t) for t in line.split()[1:]]) for line in r.stdout.splitlines() if line.split()[0] in ("q", "v", "tau", "ddq")}
+    vals["frames"] = {line.split()[1]: np.array([float(t) for t in line.split()[2:]]) for line in r.stdout.splitlines() if line.startswith("frame ")}
     return vals, r.stdout
 
 
@@ -34,6 +35,13 @@ def test_robot_quantities_against_the_oracle(repo_root, tmp_path):
     assert np.abs(vals["ddq"] - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max())
     tau_back = O.rnea(model, t("q"), t("v"), t("ddq")).numpy()
     assert np.abs(tau_back - vals["tau"]).max() < 1e-8
+    # frames (forward kinematics of every link, incl. the feet lumped through fixed joints) vs the oracle's own
+    # description reader and kinematics
+    ref = O.frame_placements(model, t("q"))
+    assert {"LF_FOOT", "LH_FOOT", "RF_FOOT", "RH_FOOT"} <= set(vals["frames"]) and len(model.frames) >= 17
+    for name, flat in vals["frames"].items():
+        R, p = ref[name]
+        assert np.abs(flat[:3] - p.numpy()).max() < 1e-12 and np.abs(flat[3:].reshape(3, 3) - R.numpy()).max() < 1e-12, name
 
 
 @pytest.mark.gpu

@@ -143,9 +143,18 @@ struct Joint {
     int idxQ = 0, idxV = 0, nq = 0, nv = 0;
 };
 
+/// A named frame rigidly attached to a moving joint: every link of the description (including the links
+/// lumped into their parents through fixed joints, e.g. the feet) gives one.
+struct Frame {
+    std::string name;
+    int joint = 0;        // index into Model::joints of the supporting joint
+    Placement placement;  // of the frame in that joint's frame
+};
+
 struct Model {
     std::string name;
     std::vector<Joint> joints;  // joints[0] is the universe
+    std::vector<Frame> frames;  // one per link, in visiting order (root link first)
     V3 gravity{0.0, 0.0, -9.81};
     int nq = 0, nv = 0;
     int NumJoints() const {
@@ -413,6 +422,7 @@ inline Model BuildModel(const RobotDescription& d) {
     rootJoint.nv = 6;
     rootJoint.inertia = linkInertia(*links.at(root));
     m.joints.push_back(rootJoint);
+    m.frames.push_back({root, 1, Placement{}});
 
     // Depth-first over links in joint-name order; `support` = index of the moving joint carrying
     // the link, `toSupport` = placement of the link frame in that joint's frame.  A moving joint
@@ -432,6 +442,7 @@ inline Model BuildModel(const RobotDescription& d) {
                 const RobotDescription::Link& child = *links.at(j->child);
                 if (j->type == "fixed") {
                     m.joints[static_cast<std::size_t>(support)].inertia += inertiaOf(child).Transported(inSupport);
+                    m.frames.push_back({j->child, support, inSupport});
                     Visit(j->child, support, inSupport);
                 } else if (j->type == "revolute" || j->type == "continuous") {
                     Joint nj;
@@ -443,6 +454,7 @@ inline Model BuildModel(const RobotDescription& d) {
                     nj.nq = nj.nv = 1;
                     nj.inertia = inertiaOf(child);
                     m.joints.push_back(nj);
+                    m.frames.push_back({j->child, static_cast<int>(m.joints.size()) - 1, Placement{}});
                     Visit(j->child, static_cast<int>(m.joints.size()) - 1, Placement{});
                 } else {
                     throw std::runtime_error("robot description: unsupported joint type '" + j->type + "'");

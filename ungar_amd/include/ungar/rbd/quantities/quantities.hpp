@@ -10,8 +10,9 @@
 //   com_position / _velocity / _acceleration  q[, v[, a]]  pinocchio::centerOfMass         -> com / vcom / acom (world frame)
 //   kinetic_energy                        q, v         pinocchio::computeKineticEnergy     -> kinetic_energy
 //   potential_energy                      q            pinocchio::computePotentialEnergy   -> potential_energy
-// Not provided: frames, centroidal_momentum(_matrix), composite_rigid_body_inertia (they return Pinocchio
-// spatial-algebra objects).
+//   frames                                q            pinocchio::framesForwardKinematics  -> oMf (one RBD::Pose per link, Model().frameNames)
+// Not provided: centroidal_momentum(_matrix), composite_rigid_body_inertia (they return Pinocchio spatial-algebra
+// objects).
 #pragma once
 
 #include "../quantity.hpp"
@@ -30,6 +31,7 @@ UNGAR_MAKE_QUANTITY(com_velocity);
 UNGAR_MAKE_QUANTITY(com_acceleration);
 UNGAR_MAKE_QUANTITY(kinetic_energy);
 UNGAR_MAKE_QUANTITY(potential_energy);
+UNGAR_MAKE_QUANTITY(frames);
 }  // namespace Quantities
 
 UNGAR_MAKE_GETTER(generalized_accelerations, ddq);
@@ -43,6 +45,7 @@ UNGAR_MAKE_GETTER(com_velocity, vcom);
 UNGAR_MAKE_GETTER(com_acceleration, acom);
 UNGAR_MAKE_GETTER(kinetic_energy, kinetic_energy);
 UNGAR_MAKE_GETTER(potential_energy, potential_energy);
+UNGAR_MAKE_GETTER(frames, oMf);
 
 #define UNGAR_RBD_EVALUATOR_MEMBERS      \
     const ::Ungar::RBD::ModelInfo& model; \
@@ -201,6 +204,52 @@ struct Evaluator<Quantities::com_acceleration, S> {
     void At(const auto& q, const auto& v, const auto& a) {
         const std::vector<S> vs = Internal::ToStd<S>(v), as = Internal::ToStd<S>(a);
         Internal::CenterOfMass<S>(model, data, Internal::ToStd<S>(q), &vs, &as);
+    }
+    UNGAR_RBD_EVALUATOR_MEMBERS;
+};
+
+template <class S>
+struct Evaluator<Quantities::frames, S> {
+    /// Forward kinematics of every frame: oMf = oMi(supporting joint) * placement of the frame in that joint.
+    void At(const auto& q) {
+        namespace rbd = ::ungar_amd::rbd;
+        const rbd::Model& m = model.impl;
+        const auto liMi = rbd::JointPlacements(m, Internal::ToStd<S>(q));
+        const int n = m.NumJoints();
+        std::vector<rbd::Xform<S>> oMi(static_cast<std::size_t>(n));
+        for (int i = 1; i < n; ++i) {
+            const std::size_t si = static_cast<std::size_t>(i), sp = static_cast<std::size_t>(m.joints[si].parent);
+            if (m.joints[si].parent == 0) {
+                oMi[si] = liMi[si];
+                continue;
+            }
+            for (std::size_t r = 0; r < 3; ++r) {
+                for (std::size_t c = 0; c < 3; ++c) {
+                    S acc{0.0};
+                    for (std::size_t k = 0; k < 3; ++k) acc = acc + oMi[sp].R[r][k] * liMi[si].R[k][c];
+                    oMi[si].R[r][c] = acc;
+                }
+                S acc = oMi[sp].p[r];
+                for (std::size_t k = 0; k < 3; ++k) acc = acc + oMi[sp].R[r][k] * liMi[si].p[k];
+                oMi[si].p[r] = acc;
+            }
+        }
+        data.oMf.resize(m.frames.size());
+        for (std::size_t f = 0; f < m.frames.size(); ++f) {
+            const rbd::Frame& fr = m.frames[f];
+            const rbd::Xform<S>& W = oMi[static_cast<std::size_t>(fr.joint)];
+            Pose<S>& out = data.oMf[f];
+            for (std::size_t r = 0; r < 3; ++r) {
+                for (std::size_t c = 0; c < 3; ++c) {
+                    S acc{0.0};
+                    for (std::size_t k = 0; k < 3; ++k) acc = acc + W.R[r][k] * fr.placement.R[k][c];
+                    out.rotationMatrix[r][c] = acc;
+                }
+                S acc = W.p[r];
+                for (std::size_t k = 0; k < 3; ++k) acc = acc + W.R[r][k] * fr.placement.p[k];
+                out.position[static_cast<index_t>(r)] = acc;
+            }
+        }
     }
     UNGAR_RBD_EVALUATOR_MEMBERS;
 };

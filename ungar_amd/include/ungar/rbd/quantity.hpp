@@ -9,6 +9,7 @@
 // reference records pinocchio::aba (test/rbd/robot.test.cpp:124-135) -- and then runs batched on the GPU.
 #pragma once
 
+#include <array>
 #include <string>
 #include <vector>
 
@@ -21,14 +22,37 @@ namespace RBD {
 /// What Robot::Model() exposes (field names follow pinocchio::Model).
 struct ModelInfo {
     std::string name;
-    int nq = 0, nv = 0, njoints = 0;
-    std::vector<std::string> names;  // joint names, universe first
+    int nq = 0, nv = 0, njoints = 0, nframes = 0;
+    std::vector<std::string> names;       // joint names, universe first
+    std::vector<std::string> frameNames;  // one per link of the description
+    int getFrameId(const std::string& name) const {
+        for (int i = 0; i < nframes; ++i)
+            if (frameNames[static_cast<std::size_t>(i)] == name) return i;
+        return nframes;  // as pinocchio: "not found" = nframes
+    }
+    bool existFrame(const std::string& name) const {
+        return getFrameId(name) < nframes;
+    }
     ::ungar_amd::rbd::Model impl;
+};
+
+/// Placement of a frame in the world: x_world = rotation * x_frame + translation (cf. pinocchio::SE3).
+template <class S>
+struct Pose {
+    std::array<std::array<S, 3>, 3> rotationMatrix;
+    Vector3<S> position;
+    const Vector3<S>& translation() const {
+        return position;
+    }
+    const std::array<std::array<S, 3>, 3>& rotation() const {
+        return rotationMatrix;
+    }
 };
 
 /// Results of the algorithms (field names follow pinocchio::Data).
 template <class S>
 struct Data {
+    std::vector<Pose<S>> oMf;  // world placements of Model().frames
     VectorX<S> ddq, tau, nle, g;
     MatrixX<S> M, Minv;
     Vector3<S> com, vcom, acom;

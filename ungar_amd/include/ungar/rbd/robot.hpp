@@ -26,6 +26,8 @@ class Robot {
         _model.nv = _model.impl.nv;
         _model.njoints = _model.impl.NumJoints();
         for (const auto& j : _model.impl.joints) _model.names.push_back(j.name);
+        for (const auto& f : _model.impl.frames) _model.frameNames.push_back(f.name);
+        _model.nframes = static_cast<int>(_model.frameNames.size());
     }
     Robot(const Robot& other) : _model{other._model}, _data{std::make_unique<RBD::Data<S>>()} {
     }
@@ -84,6 +86,7 @@ class Robot {
         else if constexpr (std::is_same_v<Q, qs::com_velocity_t>) return &RBD::Data<S>::vcom;
         else if constexpr (std::is_same_v<Q, qs::com_acceleration_t>) return &RBD::Data<S>::acom;
         else if constexpr (std::is_same_v<Q, qs::kinetic_energy_t>) return &RBD::Data<S>::kinetic_energy;
+        else if constexpr (std::is_same_v<Q, qs::frames_t>) return &RBD::Data<S>::oMf;
         else return &RBD::Data<S>::potential_energy;
     }
 
