@@ -356,6 +356,29 @@ def frame_placements(model: OModel, q):
     return out
 
 
+def centroidal_momentum(model: OModel, q, v):
+    """[linear; angular] momentum about the centre of mass, world axes, by spatial algebra: every body's
+    momentum Y_i v_i is carried to the world origin with the force transform of its world placement, summed,
+    and shifted to the centre of mass (angular_G = angular_O - com x linear)."""
+    Rs, ps, vjs, _ = _kinematics(model, q, v)
+    n = len(model.joints)
+    oR, op, vel = [None] * n, [None] * n, [torch.zeros(6, dtype=torch.float64)] + [None] * (n - 1)
+    h = torch.zeros(6, dtype=torch.float64)
+    mass, first = 0.0, torch.zeros(3, dtype=torch.float64)
+    for i in range(1, n):
+        j = model.joints[i]
+        vel[i] = vjs[i] + (_act_inv_motion(Rs[i], ps[i], vel[j.parent]) if j.parent > 0 else 0.0)
+        oR[i], op[i] = (Rs[i], ps[i]) if j.parent == 0 else (oR[j.parent] @ Rs[i], op[j.parent] + oR[j.parent] @ ps[i])
+        Y = torch.as_tensor(j.Y)
+        h = h + _act_force(oR[i], op[i], Y @ vel[i])
+        m_i = Y[0, 0]
+        c_i = torch.stack((Y[5, 1], Y[3, 2], Y[4, 0])) / m_i if m_i > 0 else torch.zeros(3, dtype=torch.float64)  # m c from the m c^ block
+        mass = mass + m_i
+        first = first + m_i * (op[i] + oR[i] @ c_i)
+    com = first / mass
+    return torch.cat((h[:3], h[3:] - torch.linalg.cross(com, h[:3])))
+
+
 def aba(model: OModel, q, v, tau):
     """Featherstone's articulated-body algorithm in Pinocchio's formulation (three passes)."""
     n = len(model.joints)

@@ -11,6 +11,7 @@
 #include <random>
 
 #include "ungar/autodiff/function.hpp"
+#include "ungar/rbd/quantities/centroidal_momentum.hpp"
 #include "ungar/rbd/quantities/frames.hpp"
 #include "ungar/rbd/quantities/generalized_accelerations.hpp"
 #include "ungar/rbd/robot.hpp"
@@ -125,6 +126,15 @@ int main(int argc, char** argv) {
             for (int c = 0; c < 3; ++c) std::printf(" %.17g", pose.rotation()[static_cast<std::size_t>(r)][static_cast<std::size_t>(c)]);
         std::printf("\n");
     }
+
+    // centroidal momentum: linear part = total mass * com velocity; printed for the oracle comparison
+    robot.Compute(qs::centroidal_momentum).At(q, v);
+    const VectorXr hg = robot.Get(qs::centroidal_momentum);
+    robot.Compute(qs::com_velocity).At(q, v);
+    for (index_t k = 0; k < 3; ++k) EXPECT_TRUE(std::fabs(hg[k] - robot.Model().impl.TotalMass() * robot.Get(qs::com_velocity)[k]) < 1e-10);
+    std::printf("hg");
+    for (index_t i = 0; i < 6; ++i) std::printf(" %.17g", hg[i]);
+    std::printf("\n");
 
     std::printf("q");
     for (index_t i = 0; i < nq; ++i) std::printf(" %.17g", q[i]);

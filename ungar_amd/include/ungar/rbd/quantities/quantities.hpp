@@ -11,7 +11,8 @@
 //   kinetic_energy                        q, v         pinocchio::computeKineticEnergy     -> kinetic_energy
 //   potential_energy                      q            pinocchio::computePotentialEnergy   -> potential_energy
 //   frames                                q            pinocchio::framesForwardKinematics  -> oMf (one RBD::Pose per link, Model().frameNames)
-// Not provided: centroidal_momentum(_matrix), composite_rigid_body_inertia (they return Pinocchio spatial-algebra
+//   centroidal_momentum                   q, v         pinocchio::ccrba                    -> hg (6-vector [linear; angular] at the CoM)
+// Not provided: centroidal_momentum_matrix, composite_rigid_body_inertia (they return Pinocchio spatial-algebra
 // objects).
 #pragma once
 
@@ -32,6 +33,7 @@ UNGAR_MAKE_QUANTITY(com_acceleration);
 UNGAR_MAKE_QUANTITY(kinetic_energy);
 UNGAR_MAKE_QUANTITY(potential_energy);
 UNGAR_MAKE_QUANTITY(frames);
+UNGAR_MAKE_QUANTITY(centroidal_momentum);
 }  // namespace Quantities
 
 UNGAR_MAKE_GETTER(generalized_accelerations, ddq);
@@ -46,6 +48,7 @@ UNGAR_MAKE_GETTER(com_acceleration, acom);
 UNGAR_MAKE_GETTER(kinetic_energy, kinetic_energy);
 UNGAR_MAKE_GETTER(potential_energy, potential_energy);
 UNGAR_MAKE_GETTER(frames, oMf);
+UNGAR_MAKE_GETTER(centroidal_momentum, hg);
 
 #define UNGAR_RBD_EVALUATOR_MEMBERS      \
     const ::Ungar::RBD::ModelInfo& model; \
@@ -120,7 +123,7 @@ namespace Internal {
 /// World-frame position / velocity / acceleration of the centre of mass (accelerations WITHOUT gravity,
 /// as pinocchio::centerOfMass): classical point kinematics of every body's centre of mass.
 template <class S>
-void CenterOfMass(const ModelInfo& model, Data<S>& data, const std::vector<S>& q, const std::vector<S>* v, const std::vector<S>* a) {
+void CenterOfMass(const ModelInfo& model, Data<S>& data, const std::vector<S>& q, const std::vector<S>* v, const std::vector<S>* a, bool momentum = false) {
     namespace rbd = ::ungar_amd::rbd;
     using V3s = std::array<S, 3>;
     const rbd::Model& m = model.impl;
@@ -131,6 +134,7 @@ void CenterOfMass(const ModelInfo& model, Data<S>& data, const std::vector<S>& q
     for (auto& e : vel[0]) e = S{0.0};
     for (auto& e : acc[0]) e = S{0.0};
     V3s com{S{0.0}, S{0.0}, S{0.0}}, vcom = com, acom = com;
+    V3s angularAtOrigin{S{0.0}, S{0.0}, S{0.0}};  // sum_i [ c_i x m_i v_ci + R_i I_ci omega_i ], world frame, about the world origin
     const double total = m.TotalMass();
     auto cross = [](const V3s& x, const V3s& y) { return V3s{x[1] * y[2] - x[2] * y[1], x[2] * y[0] - x[0] * y[2], x[0] * y[1] - x[1] * y[0]}; };
     for (int i = 1; i < n; ++i) {
@@ -164,6 +168,20 @@ void CenterOfMass(const ModelInfo& model, Data<S>& data, const std::vector<S>& q
             const V3s wxc = cross(ang, c);
             const V3s vc = rbd::detail::RotMul(W.R, V3s{lin[0] + wxc[0], lin[1] + wxc[1], lin[2] + wxc[2]});
             for (std::size_t k = 0; k < 3; ++k) vcom[k] = vcom[k] + (mass / total) * vc[k];
+            if (momentum && mass > 0.0) {
+                // rotational inertia about the body's centre of mass, joint frame: I_c = I_origin - m (|c|^2 1 - c c^T)
+                const auto& I = J.inertia.I;
+                const double cd[3] = {J.inertia.h[0] / mass, J.inertia.h[1] / mass, J.inertia.h[2] / mass};
+                const double cc = cd[0] * cd[0] + cd[1] * cd[1] + cd[2] * cd[2];
+                V3s Iw{S{0.0}, S{0.0}, S{0.0}};
+                for (std::size_t r = 0; r < 3; ++r)
+                    for (std::size_t cidx = 0; cidx < 3; ++cidx)
+                        Iw[r] = Iw[r] + (I[r][cidx] - mass * ((r == cidx ? cc : 0.0) - cd[r] * cd[cidx])) * ang[cidx];
+                const V3s spin = rbd::detail::RotMul(W.R, Iw);
+                const V3s cw{W.p[0] + wc[0], W.p[1] + wc[1], W.p[2] + wc[2]};
+                const V3s orbital = cross(cw, V3s{mass * vc[0], mass * vc[1], mass * vc[2]});
+                for (std::size_t k = 0; k < 3; ++k) angularAtOrigin[k] = angularAtOrigin[k] + spin[k] + orbital[k];
+            }
             if (a) {
                 const rbd::Vec6<S> aJ = rbd::JointMotion(J, *a);
                 acc[si] = rbd::detail::ActInvMotion(liMi[si], acc[sp]);
@@ -180,6 +198,15 @@ void CenterOfMass(const ModelInfo& model, Data<S>& data, const std::vector<S>& q
     }
     data.com = Vector3<S>{com[0], com[1], com[2]};
     if (v) data.vcom = Vector3<S>{vcom[0], vcom[1], vcom[2]};
+    if (momentum) {  // h_G = [m v_com ; L_origin - com x m v_com]: expressed at the centre of mass, world-aligned axes
+        const V3s lin{total * vcom[0], total * vcom[1], total * vcom[2]};
+        const V3s shift = cross(com, lin);
+        data.hg.resize(6);
+        for (std::size_t k = 0; k < 3; ++k) {
+            data.hg[static_cast<index_t>(k)] = lin[k];
+            data.hg[static_cast<index_t>(3 + k)] = angularAtOrigin[k] - shift[k];
+        }
+    }
     if (a) data.acom = Vector3<S>{acom[0], acom[1], acom[2]};
 }
 }  // namespace Internal
@@ -196,6 +223,15 @@ struct Evaluator<Quantities::com_velocity, S> {
     void At(const auto& q, const auto& v) {
         const std::vector<S> vs = Internal::ToStd<S>(v);
         Internal::CenterOfMass<S>(model, data, Internal::ToStd<S>(q), &vs, nullptr);
+    }
+    UNGAR_RBD_EVALUATOR_MEMBERS;
+};
+template <class S>
+struct Evaluator<Quantities::centroidal_momentum, S> {
+    /// [linear; angular] momentum about the centre of mass, world-aligned axes (pinocchio::ccrba -> data.hg).
+    void At(const auto& q, const auto& v) {
+        const std::vector<S> vs = Internal::ToStd<S>(v);
+        Internal::CenterOfMass<S>(model, data, Internal::ToStd<S>(q), &vs, nullptr, true);
     }
     UNGAR_RBD_EVALUATOR_MEMBERS;
 };

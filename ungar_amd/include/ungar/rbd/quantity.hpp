@@ -53,7 +53,7 @@ struct Pose {
 template <class S>
 struct Data {
     std::vector<Pose<S>> oMf;  // world placements of Model().frames
-    VectorX<S> ddq, tau, nle, g;
+    VectorX<S> ddq, tau, nle, g, hg;
     MatrixX<S> M, Minv;
     Vector3<S> com, vcom, acom;
     S kinetic_energy{0.0}, potential_energy{0.0};

@@ -87,6 +87,7 @@ class Robot {
         else if constexpr (std::is_same_v<Q, qs::com_acceleration_t>) return &RBD::Data<S>::acom;
         else if constexpr (std::is_same_v<Q, qs::kinetic_energy_t>) return &RBD::Data<S>::kinetic_energy;
         else if constexpr (std::is_same_v<Q, qs::frames_t>) return &RBD::Data<S>::oMf;
+        else if constexpr (std::is_same_v<Q, qs::centroidal_momentum_t>) return &RBD::Data<S>::hg;
         else return &RBD::Data<S>::potential_energy;
     }
 
