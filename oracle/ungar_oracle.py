@@ -379,6 +379,24 @@ def centroidal_momentum(model: OModel, q, v):
     return torch.cat((h[:3], h[3:] - torch.linalg.cross(com, h[:3])))
 
 
+def composite_inertia_about_com(model: OModel, q):
+    """Rotational inertia (3 x 3, world axes) of the robot frozen at q about its centre of mass: every body's
+    spatial inertia is carried to the world origin (X Y X^T with the force transform of its world placement),
+    summed, and the parallel-axis term of the total mass at the centre of mass is removed."""
+    Rs, ps, _, _ = _kinematics(model, q, torch.zeros(model.nv, dtype=torch.float64))
+    n = len(model.joints)
+    oR, op = [None] * n, [None] * n
+    total = torch.zeros((6, 6), dtype=torch.float64)
+    for i in range(1, n):
+        par = model.joints[i].parent
+        oR[i], op[i] = (Rs[i], ps[i]) if par == 0 else (oR[par] @ Rs[i], op[par] + oR[par] @ ps[i])
+        X = torch.as_tensor(_force_xform(oR[i].numpy(), op[i].numpy()))
+        total = total + X @ torch.as_tensor(model.joints[i].Y) @ X.T
+    mass = total[0, 0]
+    com = torch.stack((total[5, 1], total[3, 2], total[4, 0])) / mass
+    return total[3:, 3:] - mass * (com.dot(com) * torch.eye(3, dtype=torch.float64) - torch.outer(com, com))
+
+
 def aba(model: OModel, q, v, tau):
     """Featherstone's articulated-body algorithm in Pinocchio's formulation (three passes)."""
     n = len(model.joints)

@@ -12,6 +12,8 @@
 
 #include "ungar/autodiff/function.hpp"
 #include "ungar/rbd/quantities/centroidal_momentum.hpp"
+#include "ungar/rbd/quantities/centroidal_momentum_matrix.hpp"
+#include "ungar/rbd/quantities/composite_rigid_body_inertia.hpp"
 #include "ungar/rbd/quantities/frames.hpp"
 #include "ungar/rbd/quantities/generalized_accelerations.hpp"
 #include "ungar/rbd/robot.hpp"
@@ -132,6 +134,23 @@ int main(int argc, char** argv) {
     const VectorXr hg = robot.Get(qs::centroidal_momentum);
     robot.Compute(qs::com_velocity).At(q, v);
     for (index_t k = 0; k < 3; ++k) EXPECT_TRUE(std::fabs(hg[k] - robot.Model().impl.TotalMass() * robot.Get(qs::com_velocity)[k]) < 1e-10);
+    // centroidal map: h_G = A_G v; composite inertia: symmetric, positive, and consistent with A_G for a rigid rotation
+    robot.Compute(qs::centroidal_momentum_matrix).At(q);
+    EXPECT_TRUE(MaxAbsDiff(VectorXr{robot.Get(qs::centroidal_momentum_matrix) * v}, hg) < 1e-10);
+    robot.Compute(qs::composite_rigid_body_inertia).At(q, v);
+    {
+        const MatrixXr Ig = robot.Get(qs::composite_rigid_body_inertia);
+        real_t asym = 0, minDiag = 1e9;
+        for (index_t r = 3; r < 6; ++r) {
+            minDiag = std::min(minDiag, Ig(r, r));
+            for (index_t c = 3; c < 6; ++c) asym = std::max(asym, std::fabs(Ig(r, c) - Ig(c, r)));
+        }
+        EXPECT_TRUE(asym < 1e-10 && minDiag > 0.1 && std::fabs(Ig(0, 0) - robot.Model().impl.TotalMass()) < 1e-12);
+        std::printf("Ig");
+        for (index_t r = 3; r < 6; ++r)
+            for (index_t c = 3; c < 6; ++c) std::printf(" %.17g", Ig(r, c));
+        std::printf("\n");
+    }
     std::printf("hg");
     for (index_t i = 0; i < 6; ++i) std::printf(" %.17g", hg[i]);
     std::printf("\n");

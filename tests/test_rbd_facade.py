@@ -21,7 +21,7 @@ def _run(repo_root, mode, tmp_path):
     r = subprocess.run([exe, mode, robot, str(tmp_path / "codegen")], capture_output=True, text=True, timeout=1200)
     print(r.stdout[-3000:], r.stderr[-2000:])
     assert r.returncode == 0 and "PASSED" in r.stdout
-    vals = {line.split()[0]: np.array([float(t) for t in line.split()[1:]]) for line in r.stdout.splitlines() if line.split()[0] in ("q", "v", "tau", "ddq", "hg")}
+    vals = {line.split()[0]: np.array([float(t) for t in line.split()[1:]]) for line in r.stdout.splitlines() if line.split()[0] in ("q", "v", "tau", "ddq", "hg", "Ig")}
     vals["frames"] = {line.split()[1]: np.array([float(t) for t in line.split()[2:]]) for line in r.stdout.splitlines() if line.startswith("frame ")}
     return vals, r.stdout
 
@@ -38,6 +38,8 @@ def test_robot_quantities_against_the_oracle(repo_root, tmp_path):
     # centroidal momentum: point-mass formulation in C++ vs spatial algebra in the oracle
     hg = O.centroidal_momentum(model, t("q"), t("v")).numpy()
     assert np.abs(vals["hg"] - hg).max() <= 1e-10 * max(1.0, np.abs(hg).max())
+    Ig = O.composite_inertia_about_com(model, t("q")).numpy()
+    assert np.abs(vals["Ig"].reshape(3, 3) - Ig).max() <= 1e-10 * np.abs(Ig).max()
     # frames (forward kinematics of every link, incl. the feet lumped through fixed joints) vs the oracle's own
     # description reader and kinematics
     ref = O.frame_placements(model, t("q"))

@@ -12,7 +12,10 @@
 //   potential_energy                      q            pinocchio::computePotentialEnergy   -> potential_energy
 //   frames                                q            pinocchio::framesForwardKinematics  -> oMf (one RBD::Pose per link, Model().frameNames)
 //   centroidal_momentum                   q, v         pinocchio::ccrba                    -> hg (6-vector [linear; angular] at the CoM)
-// Not provided: centroidal_momentum_matrix, composite_rigid_body_inertia (they return Pinocchio spatial-algebra
+//   centroidal_momentum_matrix            q            pinocchio::crbaMinimal              -> Ag (6 x nv, h_G = A_G v)
+//   composite_rigid_body_inertia          q[, v]       pinocchio::ccrba                    -> Ig (6 x 6 [m 1, 0; 0, I_G], a matrix
+//                                                                                                instead of a pinocchio::Inertia)
+// Return types differ where the reference hands out Pinocchio spatial-algebra objects (they return Pinocchio spatial-algebra
 // objects).
 #pragma once
 
@@ -34,6 +37,8 @@ UNGAR_MAKE_QUANTITY(kinetic_energy);
 UNGAR_MAKE_QUANTITY(potential_energy);
 UNGAR_MAKE_QUANTITY(frames);
 UNGAR_MAKE_QUANTITY(centroidal_momentum);
+UNGAR_MAKE_QUANTITY(centroidal_momentum_matrix);
+UNGAR_MAKE_QUANTITY(composite_rigid_body_inertia);
 }  // namespace Quantities
 
 UNGAR_MAKE_GETTER(generalized_accelerations, ddq);
@@ -49,6 +54,8 @@ UNGAR_MAKE_GETTER(kinetic_energy, kinetic_energy);
 UNGAR_MAKE_GETTER(potential_energy, potential_energy);
 UNGAR_MAKE_GETTER(frames, oMf);
 UNGAR_MAKE_GETTER(centroidal_momentum, hg);
+UNGAR_MAKE_GETTER(centroidal_momentum_matrix, Ag);
+UNGAR_MAKE_GETTER(composite_rigid_body_inertia, Ig);
 
 #define UNGAR_RBD_EVALUATOR_MEMBERS      \
     const ::Ungar::RBD::ModelInfo& model; \
@@ -232,6 +239,45 @@ struct Evaluator<Quantities::centroidal_momentum, S> {
     void At(const auto& q, const auto& v) {
         const std::vector<S> vs = Internal::ToStd<S>(v);
         Internal::CenterOfMass<S>(model, data, Internal::ToStd<S>(q), &vs, nullptr, true);
+    }
+    UNGAR_RBD_EVALUATOR_MEMBERS;
+};
+template <class S>
+struct Evaluator<Quantities::centroidal_momentum_matrix, S> {
+    /// A_G(q), 6 x nv with h_G = A_G v (pinocchio::computeCentroidalMap / crbaMinimal -> data.Ag): the momentum is
+    /// linear in v, so column j is the centroidal momentum of the unit velocity e_j.
+    void At(const auto& q) {
+        const std::vector<S> qs = Internal::ToStd<S>(q);
+        data.Ag.resize(6, model.nv);
+        for (int j = 0; j < model.nv; ++j) {
+            std::vector<S> e(static_cast<std::size_t>(model.nv), S{0.0});
+            e[static_cast<std::size_t>(j)] = S{1.0};
+            Internal::CenterOfMass<S>(model, data, qs, &e, nullptr, true);
+            for (int r = 0; r < 6; ++r) data.Ag(r, j) = data.hg[r];
+        }
+    }
+    UNGAR_RBD_EVALUATOR_MEMBERS;
+};
+template <class S>
+struct Evaluator<Quantities::composite_rigid_body_inertia, S> {
+    /// Inertia of the whole robot frozen in configuration q, about its centre of mass, world axes, as a 6 x 6
+    /// spatial inertia [m 1, 0; 0, I_G] (pinocchio::ccrba -> data.Ig; the velocity argument is accepted and unused):
+    /// its angular block maps a rigid angular velocity of the frozen robot to the angular centroidal momentum,
+    /// i.e. it is the block of A_G that multiplies the base angular velocity, rotated to world axes.
+    void At(const auto& q, const auto&... /*v*/) {
+        const std::vector<S> qs = Internal::ToStd<S>(q);
+        const auto R = ::ungar_amd::rbd::detail::QuaternionToRotation(qs[3], qs[4], qs[5], qs[6]);  // base orientation
+        data.Ig.resize(6, 6);
+        for (int j = 0; j < 3; ++j) {  // base angular velocity = R^T e_j (body frame) <=> world angular velocity e_j
+            std::vector<S> v(static_cast<std::size_t>(model.nv), S{0.0});
+            for (int k = 0; k < 3; ++k) v[static_cast<std::size_t>(3 + k)] = R[static_cast<std::size_t>(j)][static_cast<std::size_t>(k)];
+            Internal::CenterOfMass<S>(model, data, qs, &v, nullptr, true);
+            // a rotation about the world origin also translates the centre of mass; the angular momentum ABOUT the
+            // centre of mass of a rigid rotation is I_G omega regardless of the pivot
+            for (int r = 0; r < 3; ++r) data.Ig(3 + r, 3 + j) = data.hg[3 + r];
+        }
+        const double mass = model.impl.TotalMass();
+        for (int r = 0; r < 3; ++r) data.Ig(r, r) = S{mass};
     }
     UNGAR_RBD_EVALUATOR_MEMBERS;
 };

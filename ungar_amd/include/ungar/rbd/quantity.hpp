@@ -54,7 +54,7 @@ template <class S>
 struct Data {
     std::vector<Pose<S>> oMf;  // world placements of Model().frames
     VectorX<S> ddq, tau, nle, g, hg;
-    MatrixX<S> M, Minv;
+    MatrixX<S> M, Minv, Ag, Ig;
     Vector3<S> com, vcom, acom;
     S kinetic_energy{0.0}, potential_energy{0.0};
 };

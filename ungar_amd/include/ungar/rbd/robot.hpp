@@ -88,6 +88,8 @@ class Robot {
         else if constexpr (std::is_same_v<Q, qs::kinetic_energy_t>) return &RBD::Data<S>::kinetic_energy;
         else if constexpr (std::is_same_v<Q, qs::frames_t>) return &RBD::Data<S>::oMf;
         else if constexpr (std::is_same_v<Q, qs::centroidal_momentum_t>) return &RBD::Data<S>::hg;
+        else if constexpr (std::is_same_v<Q, qs::centroidal_momentum_matrix_t>) return &RBD::Data<S>::Ag;
+        else if constexpr (std::is_same_v<Q, qs::composite_rigid_body_inertia_t>) return &RBD::Data<S>::Ig;
         else return &RBD::Data<S>::potential_energy;
     }
 
