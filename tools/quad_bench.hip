@@ -128,7 +128,10 @@ int main(int argc, char** argv) {
     std::vector<double> x(37 * count), u(12 * count), p(1, 0.01);
     for (long long i = 0; i < count; ++i) {
         double q[4], n = 0;
-        for (double& v : q) n += (v = U(rng)) * v;
+        for (double& v : q) {
+            v = U(rng);
+            n += v * v;
+        }
         for (int e = 0; e < 37; ++e) x[e * count + i] = U(rng);
         for (int k = 0; k < 4; ++k) x[(3 + k) * count + i] = q[k] / std::sqrt(n);
         for (int e = 0; e < 12; ++e) u[e * count + i] = 20 * U(rng);

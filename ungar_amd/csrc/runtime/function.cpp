@@ -181,18 +181,26 @@ int ungar_function_make(const ungar_tape_node* nodes, int64_t num_nodes, const i
 
     // ---- HIP source: one translation unit per kernel so that the compiler runs on all of them at once ----
     struct Unit {
-        const char* kernel;
-        const char* tag;
-        const std::vector<tape::Id>* values;
-        hipFunction_t* handle;
+        const char* kernel = nullptr;
+        const char* tag = nullptr;
+        const std::vector<tape::Id>* values = nullptr;
+        hipFunction_t* handle = nullptr;
         std::string src, object, tmp, log, flags;
         FILE* pipe = nullptr;
         std::size_t statements = 0;
     };
     std::vector<Unit> units;
-    units.push_back({"ungar_fn_forward_zero", "value", &valueIds, &fn->kValue, {}, {}, {}, {}});
-    if (!jac.value.empty()) units.push_back({"ungar_fn_sparse_jacobian", "jacobian", &jac.value, &fn->kJac, {}, {}, {}, {}});
-    if (!hes.value.empty()) units.push_back({"ungar_fn_sparse_hessian", "hessian", &hes.value, &fn->kHes, {}, {}, {}, {}});
+    auto unit = [](const char* kernel, const char* tag, const std::vector<tape::Id>* values, hipFunction_t* handle) {
+        Unit u;
+        u.kernel = kernel;
+        u.tag = tag;
+        u.values = values;
+        u.handle = handle;
+        return u;
+    };
+    units.push_back(unit("ungar_fn_forward_zero", "value", &valueIds, &fn->kValue));
+    if (!jac.value.empty()) units.push_back(unit("ungar_fn_sparse_jacobian", "jacobian", &jac.value, &fn->kJac));
+    if (!hes.value.empty()) units.push_back(unit("ungar_fn_sparse_hessian", "hessian", &hes.value, &fn->kHes));
     // Compile flags.  The machine instruction schedulers (pre- and post-RA) account for > 95 % of the compile
     // time of a large straight-line kernel (a whole-horizon constraint Jacobian of 23 k statements: 64 s -> 6 s
     // without them) and the emitter already orders statements depth-first, so they are switched off above

@@ -35,8 +35,8 @@ class BacktrackingLineSearch {
     template <class Gradient, class Direction, class Cost, class Violation, class W>
     [[nodiscard]] bool Do(const Gradient& costFunctionGradient, const Direction& dw, const Cost& costFunction, const Violation& constraintViolation,
                           W&& w) const {
-        const index_t n = dw.size();
-        if (costFunctionGradient.size() != n || w.size() != n) throw std::invalid_argument("BacktrackingLineSearch: size mismatch");
+        const index_t n = static_cast<index_t>(dw.size());
+        if (static_cast<index_t>(costFunctionGradient.size()) != n || static_cast<index_t>(w.size()) != n) throw std::invalid_argument("BacktrackingLineSearch: size mismatch");
         real_t slope = 0.0;
         for (index_t i = 0; i < n; ++i) slope += costFunctionGradient[i] * dw[i];
 

@@ -62,7 +62,10 @@ class Robot {
         VectorX<S> q{static_cast<index_t>(_model.nq)};
         for (index_t i = 0; i < q.size(); ++i) q[i] = S{U(rng) * (i < 3 ? 1.0 : 3.14159265358979323846)};
         double quat[4], n = 0;
-        for (double& c : quat) n += (c = G(rng)) * c;
+        for (double& c : quat) {
+            c = G(rng);
+            n += c * c;
+        }
         for (int k = 0; k < 4; ++k) q[3 + k] = S{quat[k] / std::sqrt(n)};
         return q;
     }
