@@ -148,11 +148,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    torch.cuda.set_device(local_rank)
+    device_index = local_rank % max(1, torch.cuda.device_count())  # one rank per GPU on a real node; the modulo only matters in the
+    torch.cuda.set_device(device_index)                           # single-GPU dry run of the multi-rank control flow (gloo) below
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
+        backend = os.environ.get("UNGAR_BENCH_BACKEND", "nccl")  # nccl == RCCL on ROCm; "gloo" only for dry runs
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend)
 
     model_name, N, default_batch = WORKLOADS[args.workload]
     batch = args.batch_per_gpu or default_batch
@@ -192,7 +197,8 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     from ungar_amd.sharding import reduce_timing
-    elapsed, total_evals = reduce_timing(elapsed, count * args.steps, dist, "cuda")  # MAX time, SUM evals over ranks
+    reduce_device = "cuda" if dist is None or dist.get_backend() == "nccl" else "cpu"
+    elapsed, total_evals = reduce_timing(elapsed, count * args.steps, dist, reduce_device)  # MAX time, SUM evals over ranks
     kernel_ms = float(np.mean([s.elapsed_time(e) for s, e in zip(starts, ends)]))
     assert torch.isfinite(f).all() and torch.isfinite(J).all()
 
