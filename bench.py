@@ -1,14 +1,19 @@
 #!/usr/bin/env python3
 """bench.py -- shooting-node Jacobian evaluations per second on MI355X (BASELINE.json metric).
 
-A "step" is one pass of the hot path over one batch of synthetic input: for every (instance, knot)
-of `batch` independent NMPC instances with horizon N, evaluate x+ = f(x,u) and the dense
-[A|B] = df/d(x,u) block.  Default workload = BASELINE.json configs[3]: ANYmal-class quadruped
-(nx=37, nu=12), N=20, batch=4096 per GPU.  Inputs are generated on the device before the timed
-region; outputs stay resident.  N>1: one process per GPU (torch.distributed / RCCL), the batch axis
-is sharded, no data-path collective; only the timing is reduced (MAX over ranks).
+A "step" is one pass of the hot path over one batch of synthetic input: for every (instance, knot) of a batch of
+independent NMPC instances with horizon N, evaluate x+ = f(x,u) and the dense [A|B] = df/d(x,u) block.
 
-Prints ONE JSON line on rank 0.
+  --gpus 1 (default)  BASELINE.json configs[3]: ANYmal-class quadruped (nx=37, nu=12), N=20, batch=4096.
+  --gpus G > 1        BASELINE.json configs[4]: the FIXED batch of 65 536 instances partitioned over the G ranks
+                      (contiguous split of the instance axis, ungar_amd.sharding.shard_range; "scaling": "strong").
+                      --batch-per-gpu B keeps B instances on every rank instead ("scaling": "weak").
+One process per GPU (torch.distributed; backend nccl == RCCL).  The path has no exchange step: the
+only collectives are MAX of the elapsed time and SUM of the evaluation count and of the output checksum.
+
+Inputs are generated on the device before the timed region; outputs stay resident.  Rank 0 prints ONE JSON line with
+`roofline` (dominant kernel, HIP events on the launch stream), `sub_results` (configs[1] quadrotor N=128 x 4096 and
+configs[2] rc_car N=200 x 16384, 1 GPU) and `cpu_baseline` (the oracle's tape-generated C on the host cores).
 """
 from __future__ import annotations
 
@@ -16,7 +21,9 @@ import argparse
 import ctypes
 import json
 import os
+import statistics
 import sys
+import threading
 import time
 
 import numpy as np
@@ -24,130 +31,185 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-WORKLOADS = {  # name -> (model, N, default batch per GPU)
-    "anymal": ("anymal", 20, 4096),        # configs[3] / [4]
-    "quadrotor": ("quadrotor", 128, 4096),  # configs[1]
-    "rc_car": ("rc_car", 200, 16384),       # configs[2]
-    "srbd": ("srbd", 30, 4096),
-}
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def algorithmic_bytes(nx, nu):
-    """read (x,u), write f and the dense nx x (nx+nu) block, FP64."""
-    return 8 * ((nx + nu) + nx + nx * (nx + nu))
+# ------------------------------------------------------------------------------------------------ CPU baseline
+class NativeOracleBuild:
+    """Compiles the oracle's generated C with the reference's JIT flags (-O3 -g -march=native -mtune=native -ffast-math,
+    function.hpp:610-611) ON THIS BOX, in a background thread started before the GPU measurement; falls back to the
+    prebuilt -march=x86-64-v3 library if the compiler is missing or does not finish within `patience` seconds."""
+
+    def __init__(self, models):
+        self.models, self.path, self.error = tuple(models), None, None
+        self.thread = threading.Thread(target=self._run, daemon=True)
+        self.thread.start()
+
+    def _run(self):
+        try:
+            from oracle import build_oracle
+            self.path = build_oracle.build("native", models=self.models)
+        except Exception as exc:  # noqa: BLE001 -- any failure means "use the portable build"
+            self.error = repr(exc)
+
+    def library(self, patience: float):
+        from oracle import build_oracle
+        self.thread.join(timeout=patience)
+        if self.path:
+            return self.path, "native", build_oracle.REFERENCE_FLAGS
+        return build_oracle.build("portable"), "portable", build_oracle.PORTABLE_FLAGS
 
 
-def synth_device_inputs(name, count, seed, torch):
-    """Deterministic synthetic node inputs in the unit-fastest device layout (elements, count),
-    ranges per SURVEY.md §8(d)."""
-    from oracle import ungar_oracle as O  # only for the parameter VALUES of the reference examples
-    nx, nu, nw, npar = O.DIMS[name]
-    gen = torch.Generator(device="cuda")
-    gen.manual_seed(0x5EED0000 + seed)
-    r = lambda n, lo, hi: torch.rand((n, count), generator=gen, device="cuda", dtype=torch.float64) * (hi - lo) + lo  # noqa: E731
-    quat = torch.randn((4, count), generator=gen, device="cuda", dtype=torch.float64)
-    quat = quat / quat.norm(dim=0, keepdim=True)
-    p = torch.as_tensor(O.default_params(name), device="cuda")
-    w = None
-    if name == "anymal":
-        x = torch.cat((r(3, -1, 1), quat, r(12, -1, 1), r(18, -1, 1)))
-        u = r(12, -20, 20)
-    elif name == "quadrotor":
-        hover = float(np.sqrt(1.5 * 9.80665 / (4 * 0.015)))
-        x = torch.cat((r(3, -2, 2), quat, r(3, -1, 1), r(3, -1, 1)))
-        u = r(4, 0.5, 1.5) * hover
-    elif name == "rc_car":
-        x = torch.cat((r(2, -1, 1), r(1, -np.pi, np.pi), r(1, 0.5, 2.0), r(1, -0.3, 0.3), r(1, -2, 2)))
-        u = torch.cat((r(1, -1, 1), r(1, -0.3, 0.3)))
-    else:  # srbd
-        x = torch.cat((r(3, -2, 2), quat, r(3, -1, 1), r(3, -1, 1)))
-        u = r(24, -1, 1)
-        u[2::6] = 25.0 * 9.80665 / 4 * (u[2::6] * 0.5 + 1.0)
-        w = (r(4, 0, 1) < 0.5).to(torch.float64)
-    return x.contiguous(), u.contiguous(), w, p
-
-
-def cpu_baseline(name, seconds=12.0):
-    """Times the oracle's generated-C Jacobian (stand-in for the reference's CppADCodeGen C; see
-    oracle/build_oracle.py) single-threaded, one instance per call -- the reference's execution
-    model (function.hpp:216-230) -- on a bounded sample of the same workload."""
+def cpu_baseline(name, native: NativeOracleBuild | None, seconds=10.0, patience=240.0):
+    """Times the oracle's generated-C Jacobian (stand-in for the reference's CppADCodeGen C; oracle/build_oracle.py):
+    (a) single-threaded, one instance per call -- the reference's execution model (function.hpp:216-230) -- median of 5
+    sweeps over a bounded sample, for the structured program AND for the taped-ABA program (the route the reference
+    itself takes: record ABA, let the AD tool differentiate it); (b) the same sample over all host cores."""
     from oracle import build_oracle
     from oracle import ungar_oracle as O
-    tag, flags = "portable", build_oracle.PORTABLE_FLAGS
-    lib = ctypes.CDLL(build_oracle.build(tag))  # rebuilt only when its generated sources are newer
+    if native is not None:
+        path, tag, flags = native.library(patience)
+    else:
+        path, tag, flags = build_oracle.build("portable"), "portable", build_oracle.PORTABLE_FLAGS
+    lib = ctypes.CDLL(path)
     nx, nu, nw, npar = O.DIMS[name]
     sample = 2048
     x, u, w, p = O.synthetic_inputs(name, sample, seed=99)
     w = w if nw else np.zeros((sample, 1))
-    nnz = ctypes.c_int.in_dll(lib, f"{name}_jac_nnz").value
-    fn = getattr(lib, f"{name}_sparse_jacobian")
     dp = ctypes.POINTER(ctypes.c_double)
-    fn.argtypes = [dp] * 6
-    fn.restype = None
-    f, jac = np.zeros(nx), np.zeros(nnz)
     ptr = lambda a: a.ctypes.data_as(dp)  # noqa: E731
-    args = [(ptr(x[i]), ptr(u[i]), ptr(w[i]), ptr(p[i]), ptr(f), ptr(jac)) for i in range(sample)]
-    for a in args[:64]:
-        fn(*a)
-    # ctypes call overhead (~1 us) is included; it is small against an ANYmal evaluation and is
-    # stated in the sample description for the small models.
-    evals, t0 = 0, time.perf_counter()
-    while True:
-        for a in args:
-            fn(*a)
-        evals += sample
-        dt = time.perf_counter() - t0
-        if dt >= seconds:
-            break
-    single = evals / dt
-    # (b) the whole sample spread over all host cores: one thread per core, each evaluating its contiguous share
-    # in ONE foreign call (C loop of oracle/_gen/batch_loops.c; ctypes releases the GIL) -- SURVEY.md section 8(d)
-    import threading
+
+    def single_thread(model):
+        """median over 5 sweeps of evals/s; every sweep runs whole passes over the sample for ~seconds/5."""
+        if not hasattr(lib, f"{model}_sparse_jacobian_batch"):
+            return None
+        nnz = ctypes.c_int.in_dll(lib, f"{model}_jac_nnz").value
+        loop = getattr(lib, f"{model}_sparse_jacobian_batch")  # C loop around the single-instance function: no per-call Python overhead
+        loop.argtypes = [dp] * 6 + [ctypes.c_long, ctypes.c_long, ctypes.c_long]
+        loop.restype = None
+        fo, jo = np.zeros((sample, nx)), np.zeros((sample, nnz))
+        t0 = time.perf_counter()
+        loop(ptr(x), ptr(u), ptr(w), ptr(p), ptr(fo), ptr(jo), 0, sample, 1)  # warm-up sweep, also sizes the repetitions
+        per_pass = max(time.perf_counter() - t0, 1e-6)
+        reps = max(1, int(seconds / 5 / per_pass))
+        rates = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            loop(ptr(x), ptr(u), ptr(w), ptr(p), ptr(fo), ptr(jo), 0, sample, reps)
+            rates.append(sample * reps / (time.perf_counter() - t0))
+        return {"value": statistics.median(rates), "sweeps": rates, "evals_per_sweep": sample * reps, "nnz": nnz}
+
+    structured = single_thread(name)
+    taped = single_thread(name + "_ad") if name == "anymal" else None
+    # (b) all host cores: one thread per core, each sweeping its contiguous share in ONE foreign call (ctypes releases the GIL)
     cores = min(64, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))  # bounded: the box may be CPU-throttled
+    nnz = structured["nnz"]
     loop = getattr(lib, f"{name}_sparse_jacobian_batch")
-    loop.argtypes = [dp] * 6 + [ctypes.c_long, ctypes.c_long, ctypes.c_long]
-    loop.restype = None
     fo, jo = np.zeros((sample, nx)), np.zeros((sample, nnz))
-    share = sample // cores  # nodes per thread; every thread sweeps its share `reps` times
-    reps = max(1, int(single * 1.5 / max(1, share)))  # ~1.5 s of single-thread work per thread
-    threads = [threading.Thread(target=loop, args=(ptr(x), ptr(u), ptr(w), ptr(p), ptr(fo), ptr(jo), t * share, (t + 1) * share, reps)) for t in range(cores)]
+    share = max(1, sample // cores)
+    reps = max(1, int(structured["value"] * 1.5 / share))  # ~1.5 s of single-thread work per thread
+    threads = [threading.Thread(target=loop, args=(ptr(x), ptr(u), ptr(w), ptr(p), ptr(fo), ptr(jo), t * share, (t + 1) * share, reps))
+               for t in range(min(cores, sample))]
     t1 = time.perf_counter()
     for th in threads:
         th.start()
     for th in threads:
         th.join()
     dt_all = time.perf_counter() - t1
-    counts = [share * cores * reps]
-    return {"value": single, "unit": "node Jacobian evals/s", "cores": 1, "kind": "port",
-            "sample": f"{evals} single-instance calls of the tape-generated C Jacobian ({name}, sparse nnz={nnz}) over {sample} seeded nodes, "
-                      f"gcc {' '.join(flags)}, 1 thread, {dt:.1f} s, via ctypes",
-            "all_cores": {"value": sum(counts) / dt_all, "cores": cores, "seconds": dt_all}}
+    out = {"value": structured["value"], "unit": "node Jacobian evals/s", "cores": 1, "kind": "port",
+           "sample": f"median of 5 sweeps x {structured['evals_per_sweep']} single-instance evaluations of the tape-generated C Jacobian "
+                     f"({name}, structured program, sparse nnz={nnz}) over {sample} seeded nodes, gcc {' '.join(flags)} "
+                     f"({'compiled on this box' if tag == 'native' else 'prebuilt portable library: native build unavailable'}), 1 thread",
+           "sweeps": structured["sweeps"],
+           "all_cores": {"value": share * len(threads) * reps / dt_all, "cores": len(threads), "seconds": dt_all}}
+    if taped:
+        out["taped_aba"] = {"value": taped["value"], "sweeps": taped["sweeps"], "nnz": taped["nnz"],
+                            "note": "same node function, derivatives by taping ABA (test/rbd/robot.test.cpp:124-135) -- the reference's own route"}
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ GPU measurement
+def measure(torch, ungar_amd, workload, instances, total_instances, begin, steps, warmup, jacobian="dense", kernel_model=None, fence=None,
+            seed=0):
+    """Times `steps` passes over the node range of instances [begin, begin + instances) of a `total_instances` batch.
+    Returns per-rank figures (elapsed seconds on the host clock, mean kernel time from HIP events on the launch
+    stream, nodes per step, output checksum)."""
+    from ungar_amd import workloads as W
+    model_name, N, _ = W.WORKLOADS[workload]
+    m = ungar_amd.NodeModel(kernel_model or model_name)
+    nx, nu, ncols = m.nx, m.nu, m.nx + m.nu
+    count = instances * N
+    x, u, w, p = W.synth_device_inputs(model_name, total_instances * N, seed, torch, begin=begin * N, end=(begin + instances) * N)
+    f = torch.empty((nx, count), dtype=torch.float64, device="cuda")
+    nnz = m.jac_nnz
+    jac_len = nx * ncols if jacobian == "dense" else nnz
+    J = torch.empty((jac_len, count), dtype=torch.float64, device="cuda")
+    Op = ungar_amd.Operand
+    ops = (count, Op.soa(x, count, N), Op.soa(u, count, N), None if w is None else Op.soa(w, count, N), Op.per_instance(p, m.np, shared=True),
+           Op.soa(f, count, N), Op.soa(J, count, N))
+    stream = torch.cuda.current_stream().cuda_stream
+    call = m.dense_jacobian if jacobian == "dense" else m.sparse_jacobian
+    fence = fence or torch.cuda.synchronize
+    for _ in range(warmup):
+        call(*ops, knots=N, stream=stream)
+    fence()
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+    ends = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for i in range(steps):
+        starts[i].record()  # same stream the kernel is launched on
+        call(*ops, knots=N, stream=stream)
+        ends[i].record()
+    fence()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = float(np.mean([s.elapsed_time(e) for s, e in zip(starts, ends)]))
+    assert torch.isfinite(f).all() and torch.isfinite(J).all()
+    checksum = float(f.sum().item() + J.sum().item())  # summed over ranks afterwards: independent of the partition (up to rounding)
+    bytes_per_eval = W.algorithmic_bytes(nx, nu, None if jacobian == "dense" else nnz)
+    return {"elapsed": elapsed, "kernel_ms": kernel_ms, "count": count, "checksum": checksum, "bytes_per_eval": bytes_per_eval,
+            "nx": nx, "nu": nu, "nnz": nnz, "N": N, "kernel_model": kernel_model or model_name}
+
+
+def roofline(r, jacobian, traffic=None, traffic_source=None):
+    achieved = r["count"] * r["bytes_per_eval"] / (r["kernel_ms"] * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "traffic_source": traffic_source, "kernel_ms": r["kernel_ms"], "algorithmic_bytes_per_eval": r["bytes_per_eval"],
+            "kernel": f"NodeKernel<{r['kernel_model']}, {jacobian} Jacobian>"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="anymal", choices=sorted(WORKLOADS))
-    ap.add_argument("--batch-per-gpu", type=int, default=None)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="anymal", choices=["anymal", "quadrotor", "rc_car", "srbd"])
+    ap.add_argument("--total-batch", type=int, default=None,
+                    help="instances of the whole job, partitioned over the ranks (default: the workload's single-GPU batch for --gpus 1, "
+                         "65536 = BASELINE config 5 for the anymal workload on --gpus > 1)")
+    ap.add_argument("--batch-per-gpu", type=int, default=None, help="weak-scaling variant: this many instances on EVERY rank")
     ap.add_argument("--model", default=None, help="kernel variant of the workload's model (e.g. anymal_ad, anymal_reg)")
     ap.add_argument("--layout", default="soa", choices=["soa"])
     ap.add_argument("--jacobian", default="dense", choices=["dense", "sparse"],
                     help="dense [A|B] block (BASELINE metric, default) or the CSR value array of Function::Jacobian (function.hpp:216-230)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-sub-results", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
     args = ap.parse_args()
-
-    import torch
-    import ungar_amd
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    want_cpu = not args.no_cpu_baseline and world == 1 and rank == 0
+    from ungar_amd import workloads as W
+    model_name = W.WORKLOADS[args.workload][0]
+    native = NativeOracleBuild((model_name, "anymal_ad") if model_name == "anymal" else (model_name,)) if want_cpu else None  # compiles while the GPU runs
+
+    import torch
+    import ungar_amd
+    from ungar_amd.sharding import reduce_sums, reduce_timing, shard_range
+
     device_index = local_rank % max(1, torch.cuda.device_count())  # one rank per GPU on a real node; the modulo only matters in the
     torch.cuda.set_device(device_index)                           # single-GPU dry run of the multi-rank control flow (gloo) below
     dist = None
@@ -159,24 +221,14 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    model_name, N, default_batch = WORKLOADS[args.workload]
-    batch = args.batch_per_gpu or default_batch
-    count = batch * N  # nodes evaluated by THIS rank per step (batch axis sharded across ranks)
-    kernel_model = args.model or model_name
-    m = ungar_amd.NodeModel(kernel_model)
-    nx, nu, ncols = m.nx, m.nu, m.nx + m.nu
-    x, u, w, p = synth_device_inputs(model_name, count, seed=rank, torch=torch)
-    f = torch.empty((nx, count), dtype=torch.float64, device="cuda")
-    nnz = len(m.jacobian_sparsity()[0])
-    jac_len = nx * ncols if args.jacobian == "dense" else nnz
-    J = torch.empty((jac_len, count), dtype=torch.float64, device="cuda")
-    Op = ungar_amd.Operand
-    ops = (count, Op.soa(x, count, N), Op.soa(u, count, N), None if w is None else Op.soa(w, count, N), Op.per_instance(p, m.np, shared=True),
-           Op.soa(f, count, N), Op.soa(J, count, N))
-    stream = torch.cuda.current_stream().cuda_stream
-
-    def step():
-        (m.dense_jacobian if args.jacobian == "dense" else m.sparse_jacobian)(*ops, knots=N, stream=stream)
+    _, N, default_batch = W.WORKLOADS[args.workload]
+    if args.batch_per_gpu is not None:  # weak scaling: fixed work per rank
+        total, scaling = args.batch_per_gpu * world, "weak"
+        begin, end = rank * args.batch_per_gpu, (rank + 1) * args.batch_per_gpu
+    else:  # strong scaling: a fixed batch partitioned over the ranks
+        total = args.total_batch or (default_batch if world == 1 else (W.CONFIG5_TOTAL_BATCH if args.workload == "anymal" else default_batch * 8))
+        scaling = "strong"
+        begin, end = shard_range(total, world, rank)
 
     def fence():
         torch.cuda.synchronize()
@@ -184,32 +236,19 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    ends = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        starts[i].record()  # same stream the kernel is launched on
-        step()
-        ends[i].record()
-    fence()
-    elapsed = time.perf_counter() - t0
-    from ungar_amd.sharding import reduce_timing
+    r = measure(torch, ungar_amd, args.workload, end - begin, total, begin, args.steps, args.warmup, args.jacobian, args.model, fence)
     reduce_device = "cuda" if dist is None or dist.get_backend() == "nccl" else "cpu"
-    elapsed, total_evals = reduce_timing(elapsed, count * args.steps, dist, reduce_device)  # MAX time, SUM evals over ranks
-    kernel_ms = float(np.mean([s.elapsed_time(e) for s, e in zip(starts, ends)]))
-    assert torch.isfinite(f).all() and torch.isfinite(J).all()
+    elapsed, total_evals = reduce_timing(r["elapsed"], r["count"] * args.steps, dist, reduce_device)  # MAX time, SUM evals over ranks
+    checksum, nodes_per_step = reduce_sums([r["checksum"], float(r["count"])], dist, reduce_device)  # SUM over ranks
 
     if rank == 0:
-        bytes_per_eval = algorithmic_bytes(nx, nu) if args.jacobian == "dense" else 8 * ((nx + nu) + nx + nnz)
-        achieved = count * bytes_per_eval / (kernel_ms * 1e-3) / 1e9
-        traffic = None
+        traffic = traffic_source = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and args.jacobian == "dense" and r["kernel_model"] == model_name:
             with open(tpath) as fh:
-                traffic = json.load(fh).get(f"{args.workload}:{batch}") if args.jacobian == "dense" and kernel_model == model_name else None
+                table = json.load(fh)
+            traffic = table.get(f"{args.workload}:{end - begin}")
+            traffic_source = table.get("_source") if traffic is not None else None  # NOT measured in this run: see profiles/
         out = {
             "metric": "shooting-node Jacobian evals/sec",
             "value": total_evals / elapsed,
@@ -219,20 +258,30 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"{args.workload} shooting-node value + {'dense [A|B]' if args.jacobian == 'dense' else f'sparse (nnz={nnz})'} Jacobian, nx={nx} nu={nu}, N={N}, batch={batch}/GPU "
-                                   f"({count} nodes/GPU/step), unit-fastest (SoA) device layout",
-                       "horizon": N, "batch_per_gpu": batch, "nodes_per_step": count * world, "kernel_variant": kernel_model,
-                       "parallelism": f"batch-sharded x{world}, no data-path collective"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel_ms": kernel_ms, "algorithmic_bytes_per_eval": bytes_per_eval,
-                         "kernel": f"NodeKernel<{kernel_model}, {args.jacobian} Jacobian>"},
+            "config": {"workload": f"{args.workload} shooting-node value + {'dense [A|B]' if args.jacobian == 'dense' else 'sparse (nnz=%d)' % r['nnz']} Jacobian, "
+                                   f"nx={r['nx']} nu={r['nu']}, N={N}, batch={total} instances over {world} GPU(s) "
+                                   f"({end - begin} instances = {r['count']} nodes on rank 0 per step), unit-fastest (SoA) device layout",
+                       "horizon": N, "total_batch": total, "batch_rank0": end - begin, "nodes_per_step": int(nodes_per_step), "kernel_variant": r["kernel_model"],
+                       "parallelism": f"instance axis partitioned x{world} (shard_range), no data-path collective"},
+            "checksum": checksum,
+            "roofline": roofline(r, args.jacobian, traffic, traffic_source),
         }
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(model_name, args.cpu_seconds)
+        if world == 1 and not args.no_sub_results and args.workload == "anymal":
+            subs = []
+            for wl in ("quadrotor", "rc_car"):  # BASELINE.json configs[1], configs[2]
+                _, n_sub, b_sub = W.WORKLOADS[wl]
+                s = measure(torch, ungar_amd, wl, b_sub, b_sub, 0, max(20, args.steps // 2), max(2, args.warmup // 2))
+                rl = roofline(s, "dense")
+                subs.append({"workload": f"{wl} N={n_sub} batch={b_sub} dense [A|B]", "value": s["count"] * max(20, args.steps // 2) / s["elapsed"],
+                             "unit": "evals/s", "kernel_ms": s["kernel_ms"], "roofline_frac": rl["frac"], "achieved_GBps": rl["achieved"],
+                             "algorithmic_bytes_per_eval": s["bytes_per_eval"]})
+            out["sub_results"] = subs
+        if want_cpu:
+            out["cpu_baseline"] = cpu_baseline(model_name, native, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

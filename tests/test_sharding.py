@@ -7,7 +7,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from ungar_amd.sharding import reduce_timing, shard_range
+from ungar_amd.sharding import reduce_sums, reduce_timing, shard_range
 
 
 def test_shard_ranges_partition_the_batch():
@@ -30,9 +30,8 @@ def _worker(rank, world, port, q):
     # each rank "evaluates" its shard: a checksum over instance ids stands in for the outputs
     local = torch.arange(b, e, dtype=torch.float64)
     elapsed, evals = reduce_timing(0.010 * (rank + 1), (e - b) * 20, dist)
-    s = local.sum()
-    dist.all_reduce(s)
-    q.put((rank, elapsed, evals, float(s)))
+    s, nodes = reduce_sums([float(local.sum()), (e - b) * 20], dist)  # checksum-of-checksums and node count: SUM over ranks
+    q.put((rank, elapsed, evals, s, nodes))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -51,7 +50,13 @@ def test_two_rank_timing_reduction_and_coverage():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, elapsed, evals, checksum in out:
+    for rank, elapsed, evals, checksum, nodes in out:
         assert elapsed == pytest.approx(0.020)        # MAX over ranks
         assert evals == 4097 * 20                     # SUM over ranks: every instance exactly once
         assert checksum == pytest.approx(4096 * 4097 / 2)
+        assert nodes == 4097 * 20
+
+
+def test_reductions_are_identities_on_one_rank():
+    assert reduce_timing(0.5, 7) == (0.5, 7)
+    assert reduce_sums([1.5, 2]) == [1.5, 2.0]

@@ -18,12 +18,16 @@ struct AnymalQuadBody {
 }  // namespace ungar_amd::kernels
 
 extern "C" int ungar_amd_launch_anymal_quad_sparse(const ungar_amd::kernels::NodeLaunch* a, void* stream);  // quad_anymal_sparse.hip
+extern "C" int ungar_amd_launch_anymal_quad_wide(int mode, const ungar_amd::kernels::NodeLaunch* a, void* stream);  // quad_anymal_wide.hip
 
 extern "C" int ungar_amd_launch_anymal(int mode, const ungar_amd::kernels::NodeLaunch* a, void* stream) {
     using namespace ungar_amd::kernels;
-    // the quad kernel addresses the dense block with wave-uniform 32-bit element offsets (< 1813 * stride);
-    // operands too large for that go through the lane-per-node kernel (64-bit addressing)
-    const bool quadOk = (mode == kModeDenseJacobian || mode == kModeSparseJacobian) && a->jac.es >= 0 && a->jac.es * 1813LL < (1LL << 32);
+    // the quad kernel addresses the block with wave-uniform element offsets (< 1813 * element stride): 32-bit ones up
+    // to 2.37 M nodes per unit-fastest operand, 64-bit ones (quad_anymal_wide.hip, same program) beyond; only operands
+    // with a negative element stride are left to the lane-per-node kernel
+    const bool jacobian = mode == kModeDenseJacobian || mode == kModeSparseJacobian;
+    if (jacobian && !QuadOffsetsFit32(*a) && a->jac.es >= 0) return ungar_amd_launch_anymal_quad_wide(mode, a, stream);
+    const bool quadOk = jacobian && QuadOffsetsFit32(*a);
     if (quadOk && mode == kModeSparseJacobian) return ungar_amd_launch_anymal_quad_sparse(a, stream);
     if (!quadOk) return static_cast<int>(LaunchNodeModel<Model_anymal, 64>(mode, *a, static_cast<hipStream_t>(stream)));
     if (a->count <= 0) return 0;

@@ -39,7 +39,9 @@ struct NoSparsePlan {
 /// PLAN (generated: gen::anymal_quad::SparsePlan) lists the distinct per-leg index patterns k_L - k_0 of the
 /// sparse sinks; the kernel keeps one per-lane base pointer per pattern (jS[p] = jb + kDeltas[p][leg] * je),
 /// so a sparse store is (lane pointer) + (wave-uniform offset k_0 * je) like a dense one.
-template <bool SPARSE, bool STREAM = false, class PLAN = NoSparsePlan>
+/// OFF is the type of the wave-uniform element offsets: 32-bit when 1813 * (element stride) < 2^32 (checked by the
+/// launcher), 64-bit for larger unit-fastest operands (> 2.37 M nodes per launch: one more scalar multiply per store).
+template <bool SPARSE, bool STREAM = false, class PLAN = NoSparsePlan, class OFF = unsigned>
 struct QuadIO {
     const double* __restrict__ xb;  // node's x (element stride xe)
     const double* __restrict__ ub;
@@ -47,7 +49,7 @@ struct QuadIO {
     double* __restrict__ fb;
     double* __restrict__ jb;
     long long xe, ue, fe;
-    unsigned je;  // element stride of the Jacobian operand; 1813 * je < 2^32 is checked by the launcher (uniform 32-bit offsets)
+    OFF je;  // element stride of the Jacobian operand (OFF = unsigned: 1813 * je < 2^32 is checked by the launcher)
     int L;                       // this lane's leg
     // per-lane base pointers, so that every store address is (lane pointer) + (wave-uniform offset):
     double* __restrict__ jLeg;        // jb + 3 L * 49 * je            : this leg's row block, leg-independent column
@@ -149,7 +151,7 @@ struct QuadIO {
 };
 
 /// GEN is the generated namespace (ValueJacobianQuad, kLegConstantsDev).  BLOCK lanes = BLOCK/4 nodes.
-template <int BLOCK, int LDS_SLOTS, int LDS_USLOTS, bool SPARSE, bool STREAM, class Body, class PLAN = NoSparsePlan>
+template <int BLOCK, int LDS_SLOTS, int LDS_USLOTS, bool SPARSE, bool STREAM, class Body, class PLAN = NoSparsePlan, class OFF = unsigned>
 __global__ __launch_bounds__(BLOCK) void QuadNodeKernel(const NodeLaunch a, const double (*ctab)[4], Body body) {
     static_assert(BLOCK == 64, "the LDS home is laid out for one wavefront per workgroup");
     __shared__ double lds[(LDS_SLOTS > 0 ? LDS_SLOTS : 1) * BLOCK + LDS_USLOTS * (BLOCK / 4)];
@@ -166,12 +168,12 @@ __global__ __launch_bounds__(BLOCK) void QuadNodeKernel(const NodeLaunch a, cons
     double* const jb = a.jac.base + b * a.jac.bs + k * a.jac.ks;
     const long long je = a.jac.es;
     double* const jLeg = jb + 3LL * L * 49 * je;
-    QuadIO<SPARSE, STREAM, PLAN> io{a.x.base + b * a.x.bs + k * a.x.ks,
+    QuadIO<SPARSE, STREAM, PLAN, OFF> io{a.x.base + b * a.x.bs + k * a.x.ks,
               a.u.base + b * a.u.bs + k * a.u.ks,
               a.p.base + b * a.p.bs + k * a.p.ks,
               fb,
               jb,
-              a.x.es, a.u.es, a.f.es, static_cast<unsigned>(je),
+              a.x.es, a.u.es, a.f.es, static_cast<OFF>(je),
               L,
               jLeg,
               {jLeg + 3LL * L * je, jLeg + 3LL * ((L + 1) & 3) * je, jLeg + 3LL * ((L + 2) & 3) * je, jLeg + 3LL * ((L + 3) & 3) * je},
@@ -186,6 +188,11 @@ __global__ __launch_bounds__(BLOCK) void QuadNodeKernel(const NodeLaunch a, cons
         for (int p = 0; p < PLAN::kCount; ++p) io.jS[p] = jb + static_cast<long long>(PLAN::kDeltas[p][L]) * je;
     }
     body(io);
+}
+
+/// True when the wave-uniform element offsets of the 37 x 49 block (or of its CSR value array) fit 32 bits.
+inline bool QuadOffsetsFit32(const NodeLaunch& a) {
+    return a.jac.es >= 0 && a.jac.es * 1813LL < (1LL << 32);
 }
 
 }  // namespace ungar_amd::kernels

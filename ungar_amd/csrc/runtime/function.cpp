@@ -342,10 +342,15 @@ static int LaunchFn(const ungar_function* fn, hipFunction_t k, const char* what,
 int ungar_function_forward_zero(const ungar_function* fn, const ungar_operand* xp, const ungar_operand* y, int64_t batch, void* stream) {
     return LaunchFn(fn, fn ? fn->kValue : nullptr, "ungar_function_forward_zero", xp, y, batch, stream);
 }
+// A derivative that is enabled but structurally empty (Jacobian of a function of the parameters only, Hessian of a
+// linear objective) has no kernel and nothing to write: the reference returns an empty sparse matrix there
+// (function.hpp:216-230, 236-259), so the batched calls succeed without a launch.
 int ungar_function_sparse_jacobian(const ungar_function* fn, const ungar_operand* xp, const ungar_operand* jac, int64_t batch, void* stream) {
+    if (fn && xp && jac && batch >= 0 && (fn->enabled & kEnableJacobian) && fn->jacRows.empty()) return UNGAR_OK;
     return LaunchFn(fn, fn ? fn->kJac : nullptr, "ungar_function_sparse_jacobian", xp, jac, batch, stream);
 }
 int ungar_function_sparse_hessian(const ungar_function* fn, const ungar_operand* xp, const ungar_operand* hes, int64_t batch, void* stream) {
+    if (fn && xp && hes && batch >= 0 && (fn->enabled & kEnableHessian) && fn->hesRows.empty()) return UNGAR_OK;
     return LaunchFn(fn, fn ? fn->kHes : nullptr, "ungar_function_sparse_hessian", xp, hes, batch, stream);
 }
 
@@ -356,6 +361,7 @@ int ungar_function_eval_host(ungar_function* fn, int32_t what, const double* xp_
     const int64_t nOut = what == 0 ? fn->m : what == 1 ? static_cast<int64_t>(fn->jacRows.size()) : static_cast<int64_t>(fn->hesRows.size());
     hipFunction_t k = what == 0 ? fn->kValue : what == 1 ? fn->kJac : fn->kHes;
     if (what < 0 || what > 2) return Fail(UNGAR_E_INVALID, "ungar_function_eval_host: what must be 0 (value), 1 (Jacobian) or 2 (Hessian)");
+    if (nOut == 0 && what != 0 && (fn->enabled & (what == 1 ? kEnableJacobian : kEnableHessian))) return UNGAR_OK;  // enabled but structurally empty
     if (!k) return Fail(UNGAR_E_UNSUPPORTED, "ungar_function_eval_host: kernel not available for function '" + fn->name + "' (derivative not enabled, or made with UNGAR_AMD_COMPILE_ONLY)");
     if (nOut == 0) return UNGAR_OK;
     hipError_t e = hipSuccess;

@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <array>
 #include <cstdint>
+#include <unordered_set>
 #include <utility>
 #include <vector>
 
@@ -430,10 +431,40 @@ class Differentiator {
         }
     }
 
+    /// w * p with CppAD's "absolute zero" semantics for the adjoint w (azmul in CppAD's reverse sweeps): when w is
+    /// exactly zero the product is zero whatever p is.  Needed only below a conditional: the adjoint of the
+    /// branch that was NOT selected is an exact zero, while that branch's partials may be NaN/Inf at the guarded
+    /// point (y = x / CondExpGt(z, 0, sqrt(z), 1) at z <= 0 -- the guard pattern of
+    /// autodiff/support/quaternion.hpp:38-60 and utils.hpp:731-736).  guardedExpr_ holds the adjoint expressions
+    /// that can be such a zero; the result is registered there too.
+    Id AdjointTimesPartial(Id p, Id w) {
+        if (!guardedExpr_.count(w) || g_.IsConst(p)) {
+            const Id r = g_.Mul(p, w);
+            if (guardedExpr_.count(w) && !g_.IsConst(r)) guardedExpr_.insert(r);
+            return r;
+        }
+        const Id zero = g_.Constant(0.0);
+        const Node nw = g_.At(w);
+        Id r;
+        if (IsCond(nw.op) && (nw.c == zero || nw.d == zero))  // w = (a cmp b) ? c : 0: multiply inside the selection (no extra compare)
+            r = g_.Cond(nw.op, nw.a, nw.b, nw.c == zero ? zero : AdjointTimesPartial(p, nw.c), nw.d == zero ? zero : AdjointTimesPartial(p, nw.d));
+        else
+            r = g_.Cond(Op::CondEq, w, zero, zero, g_.Mul(p, w));
+        if (!g_.IsConst(r)) guardedExpr_.insert(r);
+        return r;
+    }
+    void Accumulate(std::vector<Id>& adj, Id operand, Id contribution) {
+        Id& slot = adj[static_cast<std::size_t>(operand)];
+        const bool g = guardedExpr_.count(slot) || guardedExpr_.count(contribution);
+        slot = g_.Add(slot, contribution);
+        if (g && !g_.IsConst(slot)) guardedExpr_.insert(slot);
+    }
+
     /// Adjoint of every node in [0, limit) with respect to `output`.
     void ReverseSweep(Id limit, Id output, std::vector<Id>& adj) {
         const Id zero = g_.Constant(0.0);
         adj.assign(static_cast<std::size_t>(limit), zero);
+        guardedExpr_.clear();
         adj[static_cast<std::size_t>(output)] = g_.Constant(1.0);
         for (Id id = output + 1; id-- > 0;) {
             const Id w = adj[static_cast<std::size_t>(id)];
@@ -441,14 +472,16 @@ class Differentiator {
             const Node nd = g_.At(id);
             if (Arity(nd.op) == 0 || nd.op == Op::Sign) continue;
             if (IsCond(nd.op)) {
-                adj[static_cast<std::size_t>(nd.c)] = g_.Add(adj[static_cast<std::size_t>(nd.c)], g_.Cond(nd.op, nd.a, nd.b, w, zero));
-                adj[static_cast<std::size_t>(nd.d)] = g_.Add(adj[static_cast<std::size_t>(nd.d)], g_.Cond(nd.op, nd.a, nd.b, zero, w));
+                const Id wc = g_.Cond(nd.op, nd.a, nd.b, w, zero), wd = g_.Cond(nd.op, nd.a, nd.b, zero, w);
+                if (!g_.IsConst(wc)) guardedExpr_.insert(wc);
+                if (!g_.IsConst(wd)) guardedExpr_.insert(wd);
+                Accumulate(adj, nd.c, wc);
+                Accumulate(adj, nd.d, wd);
                 continue;
             }
             const std::array<Id, 2> p = Partials(id);
-            if (p[0] != kNoId) adj[static_cast<std::size_t>(nd.a)] = g_.Add(adj[static_cast<std::size_t>(nd.a)], g_.Mul(p[0], w));
-            if (nd.b != kNoId && p[1] != kNoId)
-                adj[static_cast<std::size_t>(nd.b)] = g_.Add(adj[static_cast<std::size_t>(nd.b)], g_.Mul(p[1], w));
+            if (p[0] != kNoId) Accumulate(adj, nd.a, AdjointTimesPartial(p[0], w));
+            if (nd.b != kNoId && p[1] != kNoId) Accumulate(adj, nd.b, AdjointTimesPartial(p[1], w));
         }
     }
 
@@ -461,6 +494,7 @@ class Differentiator {
     std::size_t words_ = 1;
     Id depLimit_ = 0;
     std::vector<std::array<Id, 2>> partials_;
+    std::unordered_set<Id> guardedExpr_;  // reverse sweep: adjoint expressions that may be the exact zero of a non-selected branch
     std::vector<char> active_;  // when non-empty: nodes the current Jacobian request can reach
     int lastMode_ = 0;
 };

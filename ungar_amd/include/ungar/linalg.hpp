@@ -79,6 +79,24 @@ struct Storage<S, Dynamic> {
 template <class T>
 using remove_cvref_t = std::remove_cv_t<std::remove_reference_t<T>>;
 
+// Conditional expressions on REAL scalars.  Recorded scalars bring their own CondExp* overloads (found by
+// argument-dependent lookup, tape/scalar.hpp), which is how the guarded formulas below stay on the tape as
+// selections instead of host branches (reference autodiff/support/quaternion.hpp:34-192).
+template <class S, std::enable_if_t<std::is_arithmetic_v<S>, int> = 0>
+inline S CondExpGt(S a, S b, S c, S d) { return a > b ? c : d; }
+template <class S, std::enable_if_t<std::is_arithmetic_v<S>, int> = 0>
+inline S CondExpGe(S a, S b, S c, S d) { return a >= b ? c : d; }
+template <class S, std::enable_if_t<std::is_arithmetic_v<S>, int> = 0>
+inline S CondExpLt(S a, S b, S c, S d) { return a < b ? c : d; }
+
+/// sqrt(z) where z > 0, else 1: the divisor of a normalisation that leaves the null vector untouched (Eigen 3.4's
+/// `if (z > 0) derived() /= sqrt(z)`, and the reference's AD specialisations, support/quaternion.hpp:56-116).
+template <class S>
+inline S GuardedNorm(const S& squaredNorm) {
+    using std::sqrt;
+    return CondExpGt(squaredNorm, S{0.0}, sqrt(squaredNorm), S{1.0});
+}
+
 }  // namespace internal
 
 template <class S, Index N>
@@ -366,8 +384,13 @@ class MatrixBase {
         for (Index i = 0; i < size(); ++i) r[i] = S{1.0} / (*this)[i];
         return r;
     }
+    /// Guarded like Eigen 3.4 (null vector unchanged); on recorded scalars the guard is a CondExpGt on the tape
+    /// (reference autodiff/support/quaternion.hpp:56-116).
     PlainObject normalized() const {
-        return *this / norm();
+        return *this / internal::GuardedNorm(squaredNorm());
+    }
+    void normalize() {
+        derived() /= internal::GuardedNorm(squaredNorm());
     }
     ArrayWrap<S, RowsAtCompileTime> array() const {
         return {eval()};
@@ -701,11 +724,90 @@ class QuaternionBase {
         const Matrix<R, 3> ut = u.cross(t);
         return Matrix<R, 3>{v[0] + w() * t[0] + ut[0], v[1] + w() * t[1] + ut[1], v[2] + w() * t[2] + ut[2]};
     }
+    template <class D2>
+    S dot(const QuaternionBase<D2>& o) const {
+        return x() * o.x() + y() * o.y() + z() * o.z() + w() * o.w();
+    }
+    void normalize() {
+        const S n = internal::GuardedNorm(squaredNorm());
+        x() = x() / n;
+        y() = y() / n;
+        z() = z() / n;
+        w() = w() / n;
+    }
     template <class T>
     auto cast() const;
     auto conjugate() const;
-    /// Inverse rotation; like Eigen's, conjugate / squaredNorm (all-zero for the null quaternion).
+    /// Inverse rotation: conjugate / squaredNorm, the null quaternion mapping to itself -- on every scalar type through
+    /// a conditional expression (reference autodiff/support/quaternion.hpp:34-54; Eigen 3.4 branches on n2 > 0).
     auto inverse() const;
+    auto normalized() const;
+    /// Spherical linear interpolation, Eigen 3.4's formula with its two branches (|d| >= 1 - eps: linear; d < 0: the
+    /// shorter arc) expressed as conditional expressions so that it can be recorded
+    /// (reference autodiff/support/quaternion.hpp:133-192).
+    template <class D2>
+    auto slerp(const S& t, const QuaternionBase<D2>& other) const;
+    /// Rotation taking a to b.  Real scalars only: the reference static_asserts on recorded scalars
+    /// (autodiff/support/quaternion.hpp:194-222).
+    template <class D1, class D2>
+    Derived& setFromTwoVectors(const MatrixBase<D1>& a, const MatrixBase<D2>& b) {
+        static_assert(std::is_arithmetic_v<S> && sizeof(D1) != 0 && sizeof(D2) != 0,
+                      "The construction of unit quaternions with scalar type 'ad_scalar_t' from two vectors is not implemented.");
+        Matrix<S, 3> v0{a[0], a[1], a[2]}, v1{b[0], b[1], b[2]};
+        v0.normalize();
+        v1.normalize();
+        const S c = v0.dot(v1);
+        if (c < S{-1.0} + NumTraits<S>::epsilon()) {  // opposite vectors: any axis orthogonal to a
+            Matrix<S, 3> axis = std::abs(v0[0]) < S{0.9} ? Matrix<S, 3>{S{0}, -v0[2], v0[1]} : Matrix<S, 3>{-v0[2], S{0}, v0[0]};
+            axis.normalize();
+            x() = axis[0];
+            y() = axis[1];
+            z() = axis[2];
+            w() = S{0};
+            return derived();
+        }
+        const Matrix<S, 3> axis = v0.cross(v1);
+        const S s2 = std::sqrt((S{1} + c) * S{2});
+        x() = axis[0] / s2;
+        y() = axis[1] / s2;
+        z() = axis[2] / s2;
+        w() = s2 * S{0.5};
+        return derived();
+    }
+    /// Assignment from a 3 x 3 rotation matrix (Shepperd's method, as Eigen).  Real scalars only: the reference
+    /// static_asserts on recorded scalars (autodiff/support/quaternion.hpp:120-129).
+    template <class M, std::enable_if_t<std::is_same_v<decltype(std::declval<const M&>().rows()), Index> && !std::is_base_of_v<MatrixBase<M>, M>, int> = 0>
+    Derived& operator=(const M& m) {
+        static_assert(std::is_arithmetic_v<S> && sizeof(M) != 0,
+                      "The construction of unit quaternions from rotation matrices with scalar type 'ad_scalar_t' is not implemented.");
+        assert(m.rows() == 3 && m.cols() == 3);
+        S t = m(0, 0) + m(1, 1) + m(2, 2);
+        S q[4];  // x, y, z, w
+        if (t > S{0}) {
+            t = std::sqrt(t + S{1.0});
+            q[3] = S{0.5} * t;
+            t = S{0.5} / t;
+            q[0] = (m(2, 1) - m(1, 2)) * t;
+            q[1] = (m(0, 2) - m(2, 0)) * t;
+            q[2] = (m(1, 0) - m(0, 1)) * t;
+        } else {
+            Index i = 0;
+            if (m(1, 1) > m(0, 0)) i = 1;
+            if (m(2, 2) > m(i, i)) i = 2;
+            const Index j = (i + 1) % 3, k = (j + 1) % 3;
+            t = std::sqrt(m(i, i) - m(j, j) - m(k, k) + S{1.0});
+            q[i] = S{0.5} * t;
+            t = S{0.5} / t;
+            q[3] = (m(k, j) - m(j, k)) * t;
+            q[j] = (m(j, i) + m(i, j)) * t;
+            q[k] = (m(k, i) + m(i, k)) * t;
+        }
+        x() = q[0];
+        y() = q[1];
+        z() = q[2];
+        w() = q[3];
+        return derived();
+    }
 };
 
 template <class S_>
@@ -754,10 +856,7 @@ class Quaternion : public QuaternionBase<Quaternion<S_>> {
     Quaternion conjugate() const {
         return Quaternion{this->w(), -this->x(), -this->y(), -this->z()};
     }
-    Quaternion normalized() const {
-        const S_ n = this->norm();
-        return Quaternion{this->w() / n, this->x() / n, this->y() / n, this->z() / n};
-    }
+    using QuaternionBase<Quaternion<S_>>::operator=;
 
   private:
     std::array<S_, 4> c_{};
@@ -820,11 +919,33 @@ auto QuaternionBase<Derived>::conjugate() const {
 }
 template <class Derived>
 auto QuaternionBase<Derived>::inverse() const {
+    using internal::CondExpGt;
     const S n2 = squaredNorm();
-    if constexpr (std::is_arithmetic_v<S>) {
-        if (n2 == S{0}) return Quaternion<S>{S{0}, S{0}, S{0}, S{0}};
-    }
-    return Quaternion<S>{w() / n2, -x() / n2, -y() / n2, -z() / n2};
+    const S den = CondExpGt(n2, S{0.0}, n2, S{1.0});
+    return Quaternion<S>{w() / den, -x() / den, -y() / den, -z() / den};
+}
+template <class Derived>
+auto QuaternionBase<Derived>::normalized() const {
+    const S n = internal::GuardedNorm(squaredNorm());
+    return Quaternion<S>{w() / n, x() / n, y() / n, z() / n};
+}
+template <class Derived>
+template <class D2>
+auto QuaternionBase<Derived>::slerp(const S& t, const QuaternionBase<D2>& other) const {
+    using internal::CondExpGe;
+    using internal::CondExpLt;
+    using std::abs;
+    using std::acos;
+    using std::sin;
+    const S one = S{1.0} - NumTraits<S>::epsilon();
+    const S d = dot(other);
+    const S absD = abs(d);
+    const S theta = acos(absD), sinTheta = sin(theta);
+    const S scale0 = CondExpGe(absD, one, S{1.0} - t, sin((S{1.0} - t) * theta) / sinTheta);
+    S scale1 = CondExpGe(absD, one, t, sin(t * theta) / sinTheta);
+    scale1 = CondExpLt(d, S{0.0}, -scale1, scale1);
+    return Quaternion<S>{scale0 * w() + scale1 * other.w(), scale0 * x() + scale1 * other.x(), scale0 * y() + scale1 * other.y(),
+                         scale0 * z() + scale1 * other.z()};
 }
 template <class Derived>
 template <class T>

@@ -24,3 +24,13 @@ def reduce_timing(elapsed_s: float, evals: int, dist=None, device=None) -> tuple
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.all_reduce(n, op=dist.ReduceOp.SUM)
     return float(t.item()), int(n.item())
+
+
+def reduce_sums(values, dist=None, device=None) -> list[float]:
+    """Element-wise SUM over ranks of a short list of floats (evaluation counts, output checksums: SURVEY.md §8(e))."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return [float(v) for v in values]
+    import torch
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [float(v) for v in t.tolist()]
