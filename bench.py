@@ -130,50 +130,66 @@ def cpu_baseline(name, native: NativeOracleBuild | None, seconds=10.0, patience=
 
 # ------------------------------------------------------------------------------------------------ GPU measurement
 def measure(torch, ungar_amd, workload, instances, total_instances, begin, steps, warmup, jacobian="dense", kernel_model=None, fence=None,
-            seed=0):
-    """Times `steps` passes over the node range of instances [begin, begin + instances) of a `total_instances` batch.
-    Returns per-rank figures (elapsed seconds on the host clock, mean kernel time from HIP events on the launch
-    stream, nodes per step, output checksum)."""
+            seed=0, tile=None):
+    """Times `steps` passes over the node range of instances [begin, begin + instances) of a `total_instances` batch.  The shard
+    is stored as [tile][element][node of tile] (ungar_amd.sharding.tile_ranges) and a pass is one launch per tile on one stream.
+    Returns per-rank figures (elapsed seconds on the host clock, mean launch duration from HIP events on the launch stream,
+    nodes per step, output checksum)."""
     from ungar_amd import workloads as W
+    from ungar_amd.sharding import DEFAULT_TILE_INSTANCES, tile_ranges
     model_name, N, _ = W.WORKLOADS[workload]
     m = ungar_amd.NodeModel(kernel_model or model_name)
     nx, nu, ncols = m.nx, m.nu, m.nx + m.nu
     count = instances * N
     x, u, w, p = W.synth_device_inputs(model_name, total_instances * N, seed, torch, begin=begin * N, end=(begin + instances) * N)
-    f = torch.empty((nx, count), dtype=torch.float64, device="cuda")
     nnz = m.jac_nnz
     jac_len = nx * ncols if jacobian == "dense" else nnz
-    J = torch.empty((jac_len, count), dtype=torch.float64, device="cuda")
     Op = ungar_amd.Operand
-    ops = (count, Op.soa(x, count, N), Op.soa(u, count, N), None if w is None else Op.soa(w, count, N), Op.per_instance(p, m.np, shared=True),
-           Op.soa(f, count, N), Op.soa(J, count, N))
+    launches, outputs = [], []
+    for b, e in tile_ranges(instances, tile or DEFAULT_TILE_INSTANCES):
+        tn = (e - b) * N
+        sl = slice(b * N, e * N)
+        xt, ut, wt = x[:, sl].contiguous(), u[:, sl].contiguous(), None if w is None else w[:, sl].contiguous()
+        f = torch.empty((nx, tn), dtype=torch.float64, device="cuda")
+        J = torch.empty((jac_len, tn), dtype=torch.float64, device="cuda")
+        outputs.append((f, J))
+        launches.append((tn, Op.soa(xt, tn, N), Op.soa(ut, tn, N), None if wt is None else Op.soa(wt, tn, N), Op.per_instance(p, m.np, shared=True),
+                         Op.soa(f, tn, N), Op.soa(J, tn, N)))
+    del x, u, w
     stream = torch.cuda.current_stream().cuda_stream
     call = m.dense_jacobian if jacobian == "dense" else m.sparse_jacobian
+
+    def step():
+        for ops in launches:
+            call(*ops, knots=N, stream=stream)
+
     fence = fence or torch.cuda.synchronize
     for _ in range(warmup):
-        call(*ops, knots=N, stream=stream)
+        step()
     fence()
     starts = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
     ends = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
     t0 = time.perf_counter()
     for i in range(steps):
-        starts[i].record()  # same stream the kernel is launched on
-        call(*ops, knots=N, stream=stream)
+        starts[i].record()  # same stream the kernels are launched on
+        step()
         ends[i].record()
     fence()
     elapsed = time.perf_counter() - t0
-    kernel_ms = float(np.mean([s.elapsed_time(e) for s, e in zip(starts, ends)]))
-    assert torch.isfinite(f).all() and torch.isfinite(J).all()
-    checksum = float(f.sum().item() + J.sum().item())  # summed over ranks afterwards: independent of the partition (up to rounding)
+    step_ms = float(np.mean([s.elapsed_time(e) for s, e in zip(starts, ends)]))
+    assert all(bool(torch.isfinite(f).all()) and bool(torch.isfinite(J).all()) for f, J in outputs)
+    checksum = float(sum(f.sum().item() + J.sum().item() for f, J in outputs))  # summed over ranks afterwards: independent of the partition (up to rounding)
     bytes_per_eval = W.algorithmic_bytes(nx, nu, None if jacobian == "dense" else nnz)
-    return {"elapsed": elapsed, "kernel_ms": kernel_ms, "count": count, "checksum": checksum, "bytes_per_eval": bytes_per_eval,
-            "nx": nx, "nu": nu, "nnz": nnz, "N": N, "kernel_model": kernel_model or model_name}
+    return {"elapsed": elapsed, "kernel_ms": step_ms / len(launches), "step_kernel_ms": step_ms, "launches_per_step": len(launches), "count": count,
+            "nodes_per_launch": count / len(launches), "checksum": checksum, "bytes_per_eval": bytes_per_eval, "nx": nx, "nu": nu, "nnz": nnz, "N": N,
+            "kernel_model": kernel_model or model_name}
 
 
 def roofline(r, jacobian, traffic=None, traffic_source=None):
-    achieved = r["count"] * r["bytes_per_eval"] / (r["kernel_ms"] * 1e-3) / 1e9
+    achieved = r["nodes_per_launch"] * r["bytes_per_eval"] / (r["kernel_ms"] * 1e-3) / 1e9  # algorithmic bytes per launch / launch duration
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "traffic_source": traffic_source, "kernel_ms": r["kernel_ms"], "algorithmic_bytes_per_eval": r["bytes_per_eval"],
+            "traffic_source": traffic_source, "kernel_ms": r["kernel_ms"], "launches_per_step": r["launches_per_step"], "nodes_per_launch": r["nodes_per_launch"],
+            "algorithmic_bytes_per_eval": r["bytes_per_eval"],
             "kernel": f"NodeKernel<{r['kernel_model']}, {jacobian} Jacobian>"}
 
 
@@ -187,6 +203,8 @@ def main():
                     help="instances of the whole job, partitioned over the ranks (default: the workload's single-GPU batch for --gpus 1, "
                          "65536 = BASELINE config 5 for the anymal workload on --gpus > 1)")
     ap.add_argument("--batch-per-gpu", type=int, default=None, help="weak-scaling variant: this many instances on EVERY rank")
+    ap.add_argument("--tile-instances", type=int, default=None,
+                    help="instances per tile of the [tile][element][node] device layout (default ungar_amd.sharding.DEFAULT_TILE_INSTANCES = 8192)")
     ap.add_argument("--model", default=None, help="kernel variant of the workload's model (e.g. anymal_ad, anymal_reg)")
     ap.add_argument("--layout", default="soa", choices=["soa"])
     ap.add_argument("--jacobian", default="dense", choices=["dense", "sparse"],
@@ -236,7 +254,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    r = measure(torch, ungar_amd, args.workload, end - begin, total, begin, args.steps, args.warmup, args.jacobian, args.model, fence)
+    r = measure(torch, ungar_amd, args.workload, end - begin, total, begin, args.steps, args.warmup, args.jacobian, args.model, fence, tile=args.tile_instances)
     reduce_device = "cuda" if dist is None or dist.get_backend() == "nccl" else "cpu"
     elapsed, total_evals = reduce_timing(r["elapsed"], r["count"] * args.steps, dist, reduce_device)  # MAX time, SUM evals over ranks
     checksum, nodes_per_step = reduce_sums([r["checksum"], float(r["count"])], dist, reduce_device)  # SUM over ranks
@@ -247,7 +265,7 @@ def main():
         if os.path.exists(tpath) and args.jacobian == "dense" and r["kernel_model"] == model_name:
             with open(tpath) as fh:
                 table = json.load(fh)
-            traffic = table.get(f"{args.workload}:{end - begin}")
+            traffic = table.get(f"{args.workload}:{int(r['nodes_per_launch']) // N}")  # keyed by the instances of one launch
             traffic_source = table.get("_source") if traffic is not None else None  # NOT measured in this run: see profiles/
         out = {
             "metric": "shooting-node Jacobian evals/sec",
@@ -264,7 +282,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.workload} shooting-node value + {'dense [A|B]' if args.jacobian == 'dense' else 'sparse (nnz=%d)' % r['nnz']} Jacobian, "
                                    f"nx={r['nx']} nu={r['nu']}, N={N}, batch={total} instances over {world} GPU(s) "
-                                   f"({end - begin} instances = {r['count']} nodes on rank 0 per step), unit-fastest (SoA) device layout",
+                                   f"({end - begin} instances = {r['count']} nodes on rank 0 per step), unit-fastest (SoA) device layout in tiles of <= {args.tile_instances or 8192} instances",
                        "horizon": N, "total_batch": total, "batch_rank0": end - begin, "nodes_per_step": int(nodes_per_step), "kernel_variant": r["kernel_model"],
                        "parallelism": f"instance axis partitioned x{world} (shard_range), no data-path collective"},
             "checksum": checksum,

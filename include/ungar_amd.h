@@ -147,12 +147,18 @@ int ungar_gn_hessian_upper_unit_fastest(const double* jac, int64_t j_es, const d
  * reference makes on the whole-horizon model (function.hpp:98-105). */
 int ungar_ocp_equality_sparsity(const ungar_model* model, int64_t horizon, int32_t* row_starts, int32_t* cols, int64_t* nnz);
 
+/* Uploads the model's node pattern (a few KB) to the CURRENT device so that ungar_ocp_assemble_equality allocates
+ * nothing and does not synchronise; optional (the first assembly call on a device does it otherwise), thread-safe,
+ * once per device.  No reference counterpart: the reference's sparsity lives in host arrays (function.hpp:98-134). */
+int ungar_model_prepare(const ungar_model* model);
+
 /* Assembles, for `batch` instances, the constraint values g ((N+1) nx per instance) and the CSR value
  * array of the block-bidiagonal Jacobian from the node kernels' outputs.
  *   x    : states x_k, k = 0..N (instance/knot/element strides; a VariableMap buffer works directly)
  *   xm   : measured state per instance (knot_stride ignored)
  *   f    : node values, jac : node DENSE blocks, both over batch*N nodes as written by
- *          ungar_model_dense_jacobian (node i = instance * N + knot)
+ *          ungar_model_dense_jacobian (node (b, k) at b * instance_stride + k * knot_stride;
+ *          the unit-fastest layout of the node kernels is instance_stride = N, knot_stride = 1)
  *   g, values : outputs, instance-major (instance_stride = per-instance size or more).
  * replaces, for this structure, the whole-horizon SparseJacobian evaluation (function.hpp:224-228). */
 int ungar_ocp_assemble_equality(const ungar_model* model, int64_t horizon, int64_t batch, const ungar_operand* x, const ungar_operand* xm,

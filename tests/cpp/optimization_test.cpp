@@ -61,6 +61,24 @@ int main() {
     three[0] = 0.45, three[1] = 0.5, three[2] = 0.7;
     EXPECT_TRUE(std::fabs(poly.Evaluate(three) - (poly.Evaluate(0.45) + poly.Evaluate(0.5) + poly.Evaluate(0.7))) < 1e-15);
     EXPECT_TRUE(LogisticFunction::SmoothGreaterThan(5.0, 0.0, 10.0) > 0.999 && LogisticFunction::SmoothLessThan(5.0, 0.0, 10.0) < 1e-3);
+    // reference defaults (soft_inequality_constraint.hpp:36-59): midpoint 0, steepness 1 (constructor) / 1024 (smooth comparisons)
+    EXPECT_TRUE(std::fabs(LogisticFunction{}.Evaluate(0.3) - 1.0 / (1.0 + std::exp(-0.3))) < 1e-15);
+    EXPECT_TRUE(std::fabs(LogisticFunction::SmoothGreaterThan(1e-3, 0.0) - 1.0 / (1.0 + std::exp(-1.024))) < 1e-15);
+    EXPECT_TRUE(std::fabs(LogisticFunction::SmoothLessThan(1e-3, 0.0) - (1.0 - 1.0 / (1.0 + std::exp(-1.024)))) < 1e-15);
+    {  // the reference's explicit-scalar vector form, barrier.Evaluate<Scalar>(vector) (:90-95, :157-168, :225-228)
+        VectorXr v{3};
+        v << 0.5, -0.25, 1e-5;
+        const RelaxedPolyBarrierFunction poly{0.0, 10.0, 1e-2};
+        const RelaxedLogBarrierFunction logb{0.0, 1e-2, 0.1};
+        const SoftBoundConstraint bound{-1.0, 1.0, 5.0};
+        EXPECT_TRUE(poly.Evaluate<real_t>(v) == poly.Evaluate(v[0]) + poly.Evaluate(v[1]) + poly.Evaluate(v[2]));
+        EXPECT_TRUE((poly.Evaluate<real_t, true>(v)) == (poly.Evaluate<real_t, true>(v[0]) + poly.Evaluate<real_t, true>(v[1]) + poly.Evaluate<real_t, true>(v[2])));
+        EXPECT_TRUE(logb.Evaluate<real_t>(v) == logb.Evaluate(v[0]) + logb.Evaluate(v[1]) + logb.Evaluate(v[2]));
+        EXPECT_TRUE(bound.Evaluate<real_t>(v) == bound.Evaluate(v[0]) + bound.Evaluate(v[1]) + bound.Evaluate(v[2]));
+        VectorXad va = v.cast<ad_scalar_t>();
+        EXPECT_TRUE(std::fabs(::ungar_amd::tape::Value(poly.Evaluate<ad_scalar_t>(va)) - poly.Evaluate<real_t>(v)) < 1e-15);
+        EXPECT_TRUE(std::fabs(::ungar_amd::tape::Value(bound.Evaluate<ad_scalar_t>(va)) - bound.Evaluate<real_t>(v)) < 1e-15);
+    }
 
     // ---- KKT solver -------------------------------------------------------------------------------
     std::mt19937 gen{7};

@@ -12,7 +12,7 @@
 #include <random>
 #include <vector>
 
-#include "../../ungar_amd/csrc/tape/derive.hpp"
+#include "tape_interpreter.hpp"
 
 using namespace ungar_amd::tape;
 
@@ -24,23 +24,6 @@ static int g_failures = 0;
             std::printf("FAIL %s:%d  %s\n", __FILE__, __LINE__, #cond); \
         }                                                               \
     } while (0)
-
-/// Evaluates every node of `g` for the input vector `in` (test infrastructure, not a product path).
-static std::vector<double> Interpret(const Graph& g, const std::vector<double>& in) {
-    std::vector<double> v(g.Size(), 0.0);
-    for (std::size_t i = 0; i < g.Size(); ++i) {
-        const Node& n = g.At(static_cast<Id>(i));
-        switch (Arity(n.op)) {
-            case 0: v[i] = n.op == Op::Const ? n.value : in[static_cast<std::size_t>(n.a)]; break;
-            case 1: v[i] = EvalUnary(n.op, v[static_cast<std::size_t>(n.a)]); break;
-            case 2: v[i] = EvalBinary(n.op, v[static_cast<std::size_t>(n.a)], v[static_cast<std::size_t>(n.b)]); break;
-            default:
-                v[i] = EvalCompare(n.op, v[static_cast<std::size_t>(n.a)], v[static_cast<std::size_t>(n.b)]) ? v[static_cast<std::size_t>(n.c)]
-                                                                                                            : v[static_cast<std::size_t>(n.d)];
-        }
-    }
-    return v;
-}
 
 template <class F>
 static Tape Record(int n, F&& f) {

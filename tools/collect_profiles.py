@@ -48,5 +48,8 @@ traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
 dense = [v for k, v in out.items() if ", 2, " in k or "Jacobian" in k or True]
 if dense:
     traffic[key] = max(v["hbm_bytes_fetch_x2"] for v in dense)
+    traffic["_source"] = (f"profiles/{tag}_pmc.json: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of `bench.py --no-cpu-baseline "
+                          f"--no-sub-results`, run {tag}; bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch (gfx950 correction of MI355X_MICROARCH.md); "
+                          "NOT measured in the run that printed this line")
 json.dump(traffic, open(tpath, "w"), indent=1)
 print(json.dumps(out, indent=1)[:600])

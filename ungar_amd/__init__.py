@@ -84,6 +84,7 @@ def load_library() -> ctypes.CDLL:
                                        ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, vp]
     lib.ungar_gn_hessian_upper_unit_fastest.argtypes = [vp, ctypes.c_int64, vp, ctypes.c_int64, vp, ctypes.c_int64, ctypes.c_int64,
                                                         ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, vp]
+    lib.ungar_model_prepare.argtypes = [vp]
     lib.ungar_ocp_equality_sparsity.argtypes = [vp, ctypes.c_int64, vp, vp, i64p]
     lib.ungar_ocp_assemble_equality.argtypes = [vp, ctypes.c_int64, ctypes.c_int64] + [ctypes.POINTER(_Operand)] * 6 + [vp]
     lib.ungar_last_error.restype = ctypes.c_char_p
@@ -237,6 +238,10 @@ class NodeModel:
         cols = np.zeros(nnz.value, dtype=np.int32)
         _check(self._lib.ungar_ocp_equality_sparsity(self._h, horizon, starts.ctypes.data, cols.ctypes.data, ctypes.byref(nnz)))
         return starts, cols
+
+    def prepare(self):
+        """Uploads the node pattern to the current device (keeps the first assembly call allocation-free)."""
+        _check(self._lib.ungar_model_prepare(self._h))
 
     def ocp_assemble_equality(self, horizon, batch, x, xm, f, jac, g, values, stream=None):
         ops = [o._c() for o in (x, xm, f, jac, g, values)]

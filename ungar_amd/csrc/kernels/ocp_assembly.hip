@@ -12,27 +12,9 @@
 // block (coalesced in the unit-fastest layout) and writes its nx rows.
 #include <hip/hip_runtime.h>
 
-namespace ungar_amd::kernels {
+#include "ocp_assembly.hpp"
 
-struct OcpAssemblyArgs {
-    const double* X;        // states x_k of every instance: element e of (b, k) at X[b * xbs + k * xks + e * xes], k = 0..N
-    long long xbs, xks, xes;
-    const double* xm;       // measured state per instance (nx), instance stride mbs, element stride mes
-    long long mbs, mes;
-    const double* f;        // node values f_k:   element e of node i = b N + k at f[i * fus + e * fes]
-    long long fus, fes;
-    const double* jac;      // node dense blocks: element d = r * ncols + c of node i at jac[i * jus + d * jes]
-    long long jus, jes;
-    double* g;              // out: constraint values, (N+1) nx per instance, instance stride gbs
-    long long gbs;
-    double* values;         // out: CSR values, nnz per instance, instance stride vbs
-    long long vbs;
-    const int* nodeRow;     // node pattern (device), nnzNode entries, row-major
-    const int* nodeCol;
-    const int* rowStart;    // node pattern CSR starts (nx + 1)
-    int nx, nu, N, nnzNode;
-    long long batch;
-};
+namespace ungar_amd::kernels {
 
 __global__ __launch_bounds__(256) void OcpAssembleEqualityKernel(const OcpAssemblyArgs a) {
     const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -43,7 +25,8 @@ __global__ __launch_bounds__(256) void OcpAssembleEqualityKernel(const OcpAssemb
     const long long perKnot = a.nnzNode + a.nx;
     double* __restrict__ val = a.values + b * a.vbs + a.nx + static_cast<long long>(k) * perKnot;
     double* __restrict__ g = a.g + b * a.gbs;
-    const double* __restrict__ jac = a.jac + i * a.jus;
+    const double* __restrict__ jac = a.jac + b * a.jbs + k * a.jks;
+    const double* __restrict__ f = a.f + b * a.fbs + k * a.fks;
     const double* __restrict__ xn = a.X + b * a.xbs + static_cast<long long>(k + 1) * a.xks;
     if (k == 0) {  // initial-state rows: x_0 - x_m, Jacobian = I
         const double* __restrict__ x0 = a.X + b * a.xbs;
@@ -54,7 +37,7 @@ __global__ __launch_bounds__(256) void OcpAssembleEqualityKernel(const OcpAssemb
     }
     long long out = 0;
     for (int r = 0; r < a.nx; ++r) {
-        g[a.nx + k * a.nx + r] = xn[r * a.xes] - a.f[i * a.fus + r * a.fes];
+        g[a.nx + k * a.nx + r] = xn[r * a.xes] - f[r * a.fes];
         int e = a.rowStart[r];
         const int end = a.rowStart[r + 1];
         for (; e < end && a.nodeCol[e] < a.nx; ++e) val[out++] = -jac[static_cast<long long>(r * ncols + a.nodeCol[e]) * a.jes];  // -A_k

@@ -6,11 +6,14 @@
 
 #include <cstdio>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
 #include "../../../include/ungar_amd.h"
 #include "../kernels/node_kernel.hpp"
+#include "../kernels/ocp_assembly.hpp"
 
 using ungar_amd::kernels::NodeLaunch;
 using ungar_amd::kernels::OperandView;
@@ -30,27 +33,6 @@ UNGAR_AMD_DECLARE_MODEL(quadrotor_cost)
 UNGAR_AMD_DECLARE_MODEL(srbd_cost)
 UNGAR_AMD_DECLARE_MODEL(srbd_ineq)
 
-namespace ungar_amd::kernels {
-struct OcpAssemblyArgs {
-    const double* X;
-    long long xbs, xks, xes;
-    const double* xm;
-    long long mbs, mes;
-    const double* f;
-    long long fus, fes;
-    const double* jac;
-    long long jus, jes;
-    double* g;
-    long long gbs;
-    double* values;
-    long long vbs;
-    const int* nodeRow;
-    const int* nodeCol;
-    const int* rowStart;
-    int nx, nu, N, nnzNode;
-    long long batch;
-};
-}  // namespace ungar_amd::kernels
 extern "C" int ungar_amd_launch_ocp_assemble(const ungar_amd::kernels::OcpAssemblyArgs* a, void* stream);
 
 extern "C" int ungar_amd_launch_gn_hessian(const double* jac, long long js, long long ldj, const double* d, long long ds, double* g,
@@ -102,12 +84,49 @@ struct ungar_model {
     ungar_model_info info{};
     std::vector<int32_t> jacRows, jacCols, hesRows, hesCols;
     int (*launch)(int, const NodeLaunch*, void*) = nullptr;
-    // device copy of the node pattern (rows, cols, row starts), created on first use by the assembly
-    mutable int* devPattern = nullptr;
+    // device copies of the node pattern (rows, cols, row starts) for the whole-horizon assembly, one per device,
+    // uploaded by ungar_model_prepare (or by the first assembly call on that device)
+    mutable std::mutex patternMutex;
+    mutable std::map<int, int*> devPattern;
     ~ungar_model() {
-        if (devPattern) (void)hipFree(devPattern);
+        for (auto& [dev, ptr] : devPattern)
+            if (ptr) (void)hipFree(ptr);
     }
 };
+
+namespace {
+/// Device pointer of the node pattern on the CURRENT device; uploads it on first use (thread-safe; a failed upload
+/// leaves nothing behind).
+int DevicePattern(const ungar_model* model, const int** out) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return Fail(UNGAR_E_HIP, std::string("hipGetDevice: ") + hipGetErrorString(e));
+    std::lock_guard<std::mutex> lock(model->patternMutex);
+    auto it = model->devPattern.find(dev);
+    if (it != model->devPattern.end()) {
+        *out = it->second;
+        return UNGAR_OK;
+    }
+    const int nx = static_cast<int>(model->info.ny), nn = static_cast<int>(model->info.jac_nnz);
+    std::vector<int> host(static_cast<std::size_t>(2 * nn + nx + 1), 0);
+    for (int k = 0; k < nn; ++k) {
+        host[static_cast<std::size_t>(k)] = model->jacRows[static_cast<std::size_t>(k)];
+        host[static_cast<std::size_t>(nn + k)] = model->jacCols[static_cast<std::size_t>(k)];
+        ++host[static_cast<std::size_t>(2 * nn + model->jacRows[static_cast<std::size_t>(k)] + 1)];
+    }
+    for (int r = 0; r < nx; ++r) host[static_cast<std::size_t>(2 * nn + r + 1)] += host[static_cast<std::size_t>(2 * nn + r)];
+    int* ptr = nullptr;
+    e = hipMalloc(&ptr, host.size() * sizeof(int));
+    if (e == hipSuccess) {
+        e = hipMemcpy(ptr, host.data(), host.size() * sizeof(int), hipMemcpyHostToDevice);
+        if (e != hipSuccess) (void)hipFree(ptr);
+    }
+    if (e != hipSuccess) return Fail(UNGAR_E_HIP, std::string("node pattern upload: ") + hipGetErrorString(e));
+    model->devPattern[dev] = ptr;
+    *out = ptr;
+    return UNGAR_OK;
+}
+}  // namespace
 
 namespace {
 
@@ -261,6 +280,13 @@ int GnHessian(const double* jac, int64_t js, int64_t ld_j, const double* d, int6
 }
 }  // namespace
 
+int ungar_model_prepare(const ungar_model* model) {
+    if (!model) return Fail(UNGAR_E_INVALID, "ungar_model_prepare: null model");
+    if (model->info.ny != model->info.nx) return UNGAR_OK;  // only dynamics nodes take part in the whole-horizon assembly
+    const int* pattern = nullptr;
+    return DevicePattern(model, &pattern);
+}
+
 int ungar_ocp_equality_sparsity(const ungar_model* model, int64_t horizon, int32_t* row_starts, int32_t* cols, int64_t* nnz) {
     if (!model || !nnz || horizon < 1) return Fail(UNGAR_E_INVALID, "ungar_ocp_equality_sparsity: bad argument");
     if (model->info.ny != model->info.nx) return Fail(UNGAR_E_UNSUPPORTED, "whole-horizon assembly needs a dynamics node model (ny == nx)");
@@ -297,25 +323,15 @@ int ungar_ocp_assemble_equality(const ungar_model* model, int64_t horizon, int64
         return Fail(UNGAR_E_INVALID, "ungar_ocp_assemble_equality: null operand base");
     if (model->info.ny != model->info.nx) return Fail(UNGAR_E_UNSUPPORTED, "whole-horizon assembly needs a dynamics node model (ny == nx)");
     const int nx = static_cast<int>(model->info.nx), nn = static_cast<int>(model->info.jac_nnz);
-    if (!model->devPattern) {  // one-time upload of the node pattern (cols + CSR row starts)
-        std::vector<int> host(static_cast<std::size_t>(2 * nn + nx + 1), 0);
-        for (int e = 0; e < nn; ++e) {
-            host[static_cast<std::size_t>(e)] = model->jacRows[static_cast<std::size_t>(e)];
-            host[static_cast<std::size_t>(nn + e)] = model->jacCols[static_cast<std::size_t>(e)];
-            ++host[static_cast<std::size_t>(2 * nn + model->jacRows[static_cast<std::size_t>(e)] + 1)];
-        }
-        for (int r = 0; r < nx; ++r) host[static_cast<std::size_t>(2 * nn + r + 1)] += host[static_cast<std::size_t>(2 * nn + r)];
-        hipError_t e = hipMalloc(&model->devPattern, host.size() * sizeof(int));
-        if (e == hipSuccess) e = hipMemcpy(model->devPattern, host.data(), host.size() * sizeof(int), hipMemcpyHostToDevice);
-        if (e != hipSuccess) return Fail(UNGAR_E_HIP, std::string("ungar_ocp_assemble_equality: ") + hipGetErrorString(e));
-    }
+    const int* pattern = nullptr;  // allocation-free after ungar_model_prepare (or after the first call on this device)
+    if (const int rc = DevicePattern(model, &pattern); rc != UNGAR_OK) return rc;
     ungar_amd::kernels::OcpAssemblyArgs a{x->base, x->instance_stride, x->knot_stride, x->element_stride,
                                           xm->base, xm->instance_stride, xm->element_stride,
-                                          f->base, f->knot_stride, f->element_stride,
-                                          jac->base, jac->knot_stride, jac->element_stride,
+                                          f->base, f->instance_stride, f->knot_stride, f->element_stride,
+                                          jac->base, jac->instance_stride, jac->knot_stride, jac->element_stride,
                                           g->base, g->instance_stride,
                                           values->base, values->instance_stride,
-                                          model->devPattern, model->devPattern + nn, model->devPattern + 2 * nn,
+                                          pattern, pattern + nn, pattern + 2 * nn,
                                           nx, static_cast<int>(model->info.nu), static_cast<int>(horizon), nn, batch};
     const int err = ungar_amd_launch_ocp_assemble(&a, stream);
     if (err != 0) return Fail(UNGAR_E_HIP, std::string("ocp assembly launch failed: ") + hipGetErrorString(static_cast<hipError_t>(err)));

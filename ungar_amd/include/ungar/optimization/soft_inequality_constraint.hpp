@@ -19,7 +19,7 @@ namespace Ungar {
 
 class LogisticFunction {
   public:
-    constexpr LogisticFunction(const real_t midpoint, const real_t steepness = 1.0, const real_t maximumValue = 1.0)
+    constexpr LogisticFunction(const real_t midpoint = 0.0, const real_t steepness = 1.0, const real_t maximumValue = 1.0)
         : _midpoint{midpoint}, _steepness{steepness}, _maximumValue{maximumValue} {
     }
 
@@ -29,14 +29,15 @@ class LogisticFunction {
         return _maximumValue / (1.0 + exp(-_steepness * (x - _midpoint)));
     }
 
-    /// 1 where lhs is (smoothly) greater / less than rhs, 0 elsewhere.
+    /// 1 where x is (smoothly) greater / less than lhs, 0 elsewhere; default steepness and the `1 - ...` form of the
+    /// reference (soft_inequality_constraint.hpp:47-59).
     template <Concepts::Scalar S>
-    static S SmoothGreaterThan(const S& lhs, const real_t rhs, const real_t steepness = 1.0) {
-        return LogisticFunction{rhs, steepness}.Evaluate(lhs);
+    static S SmoothGreaterThan(const S& x, const real_t lhs, const real_t steepness = 1024.0) {
+        return LogisticFunction{lhs, steepness}.Evaluate(x);
     }
     template <Concepts::Scalar S>
-    static S SmoothLessThan(const S& lhs, const real_t rhs, const real_t steepness = 1.0) {
-        return LogisticFunction{rhs, -steepness}.Evaluate(lhs);
+    static S SmoothLessThan(const S& x, const real_t lhs, const real_t steepness = 1024.0) {
+        return 1.0 - SmoothGreaterThan(x, lhs, steepness);
     }
 
   private:
@@ -59,6 +60,14 @@ class RelaxedLogBarrierFunction {
         requires requires(const V& v) { v.size(); v[0]; }
     auto Evaluate(const V& lhs) const {
         using S = std::remove_cvref_t<decltype(lhs[0] + lhs[0])>;
+        S acc{0.0};
+        for (index_t i = 0; i < lhs.size(); ++i) acc += Piece(S{lhs[i] - _rhs});
+        return acc;
+    }
+    /// The reference's spelling with the scalar named explicitly, `barrier.Evaluate<ad_scalar_t>(vector)` (:90-95).
+    template <Concepts::Scalar S, class V>
+        requires(!Concepts::Scalar<V>) && requires(const V& v) { v.size(); v[0]; }
+    S Evaluate(const V& lhs) const {
         S acc{0.0};
         for (index_t i = 0; i < lhs.size(); ++i) acc += Piece(S{lhs[i] - _rhs});
         return acc;
@@ -118,6 +127,12 @@ class RelaxedPolyBarrierFunction {
             else acc += Piece(S{lhs[i] - _rhs});
         }
         return acc;
+    }
+    /// `barrier.Evaluate<ad_scalar_t>(vector)` / `Evaluate<ad_scalar_t, true>(vector)` as in the reference (:157-168).
+    template <Concepts::Scalar S, bool NO_CONDITIONAL_APPROXIMATION = false, class V>
+        requires(!Concepts::Scalar<V>) && requires(const V& v) { v.size(); v[0]; }
+    S Evaluate(const V& lhs) const {
+        return S{this->template Evaluate<V, NO_CONDITIONAL_APPROXIMATION>(lhs)};
     }
 
     real_t FirstDerivative(const real_t lhs) const {
@@ -180,6 +195,11 @@ class SoftBoundConstraint {
         S acc{0.0};
         for (index_t i = 0; i < x.size(); ++i) acc += Evaluate<S, NO_CONDITIONAL_APPROXIMATION>(S{x[i]});
         return acc;
+    }
+    template <Concepts::Scalar S, bool NO_CONDITIONAL_APPROXIMATION = false, class V>
+        requires(!Concepts::Scalar<V>) && requires(const V& v) { v.size(); v[0]; }
+    S Evaluate(const V& x) const {
+        return S{this->template Evaluate<V, NO_CONDITIONAL_APPROXIMATION>(x)};
     }
 
   private:

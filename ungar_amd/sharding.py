@@ -14,6 +14,25 @@ def shard_range(total_instances: int, world: int, rank: int) -> tuple[int, int]:
     return begin, begin + base + (1 if rank < extra else 0)
 
 
+# Tile size of the unit-fastest device layout.  Within one operand the element stride is (nodes of the operand) x 8 bytes, and
+# a wavefront of the ANYmal kernel keeps 1813 store streams open, one per Jacobian entry: at 65 536 instances x 20 knots in ONE
+# operand the streams are 10.5 MB apart (1813 distinct pages per wavefront) and the kernel drops from 3.2 to 4.1 ns per node;
+# tiles of 4096-8192 instances (element stride <= 1.3 MB) keep the full rate, smaller tiles lose it again to launch tails
+# (tools/bench_tiles.py, profiles/r02b_tile_sweep.json).  A rank therefore stores its shard as [tile][element][node of tile].
+DEFAULT_TILE_INSTANCES = 8192
+
+
+def tile_ranges(instances: int, tile: int = DEFAULT_TILE_INSTANCES) -> list[tuple[int, int]]:
+    """[begin, end) instance ranges of the tiles of a shard: as many equal tiles of at most `tile` instances as needed
+    (sizes differ by at most one), so that no launch is much smaller than the others."""
+    if instances < 0 or tile < 1:
+        raise ValueError("bad tiling request")
+    if instances == 0:
+        return []
+    n = -(-instances // tile)
+    return [shard_range(instances, n, t) for t in range(n)]
+
+
 def reduce_timing(elapsed_s: float, evals: int, dist=None, device=None) -> tuple[float, int]:
     """(max elapsed over ranks, total evals over ranks).  `dist` = torch.distributed or None."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
