@@ -76,7 +76,11 @@ typedef struct ungar_node_batch {
  * quadruped OCPs: value, gradient, upper Hessian), "srbd_ineq" (12 inequality rows per knot of the quadruped OCP and their Jacobian),
  * "quadrotor", "rc_car", "srbd", "anymal" (structured
  * implicit differentiation, phased body with an LDS home), "anymal_reg" (same program, plain
- * straight-line body) or "anymal_ad" (same function, derivatives by taping ABA).
+ * straight-line body) or "anymal_ad" (same function, derivatives by taping ABA); and the rigid-body quantities of
+ * ANYmal B as batched node models y = f(x, u) (rbd/quantities/<name>.hpp:42-43 in the reference): "anymal_rnea"
+ * (x = [q; v], u = a, y = joint torques), "anymal_crba" (x = q, y = M(q) 18 x 18 row-major), "anymal_minv" (x = q,
+ * y = M(q)^-1, value only), "anymal_feet" (x = q, y = 4 x [position(3); rotation(9)] of LF/LH/RF/RH_FOOT),
+ * "anymal_centroidal" (x = [q; v], y = centroidal momentum [linear; angular]).
  * replaces FunctionFactory::Make -> DynamicLib::model(name)  (function.hpp:497, 589-604). */
 int ungar_model_open(const char* name, ungar_model** out);
 void ungar_model_close(ungar_model* model);

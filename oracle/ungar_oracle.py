@@ -457,6 +457,59 @@ def rnea(model: OModel, q, v, a, gravity=True):
     return torch.cat(tau[1:])
 
 
+# ----------------------------------------------------------------------------- rigid-body quantities as node functions
+RBD_DIMS = {  # name: (nx, nu, ny) of the batched quantity models of SURVEY.md section 8(f) N4
+    "anymal_rnea": (37, 18, 18), "anymal_crba": (19, 0, 324), "anymal_minv": (19, 0, 324), "anymal_feet": (19, 0, 48), "anymal_centroidal": (37, 0, 6),
+}
+FOOT_FRAMES = ("LF_FOOT", "LH_FOOT", "RF_FOOT", "RH_FOOT")  # test/rbd/robot.test.cpp:49-52
+
+
+def inertia_matrix(model: OModel, q):
+    """M(q) column by column from inverse dynamics: M e_j = RNEA(q, 0, e_j) without gravity (an identity of the
+    equations of motion, not the composite-rigid-body recursion the product uses)."""
+    zero = torch.zeros(model.nv, dtype=torch.float64)
+    eye = torch.eye(model.nv, dtype=torch.float64)
+    return torch.stack([rnea(model, q, zero, eye[j], gravity=False) for j in range(model.nv)], dim=1)
+
+
+def rbd_quantity(name: str, x, u=None):
+    """y = f(x, u) of the quantity model `name` for ONE configuration (torch vectors in, torch vector out)."""
+    model = anymal_model()
+    if name == "anymal_rnea":  # rbd/quantities/joint_torques.hpp:42-43
+        return rnea(model, x[:19], x[19:], u)
+    if name == "anymal_crba":  # joint_space_inertia_matrix.hpp:42-43
+        return inertia_matrix(model, x).reshape(-1)
+    if name == "anymal_minv":  # joint_space_inertia_matrix_inverse.hpp:42-43
+        return torch.linalg.inv(inertia_matrix(model, x)).reshape(-1)
+    if name == "anymal_feet":  # frames.hpp:42-43
+        placements = frame_placements(model, x)
+        return torch.cat([torch.cat((placements[f][1], placements[f][0].reshape(-1))) for f in FOOT_FRAMES])
+    if name == "anymal_centroidal":  # centroidal_momentum.hpp:42-43
+        return centroidal_momentum(model, x[:19], x[19:])
+    raise KeyError(name)
+
+
+def rbd_quantity_jacobian(name: str, x, u=None):
+    """(y, d y / d (x, u)) with torch.autograd."""
+    nx = RBD_DIMS[name][0]
+    z = torch.cat((x, u)) if u is not None else x
+    g = lambda zz: rbd_quantity(name, zz[:nx], zz[nx:] if u is not None else None)  # noqa: E731
+    J = torch.autograd.functional.jacobian(g, z, vectorize=False)
+    with torch.no_grad():
+        return g(z), J
+
+
+def synthetic_rbd_inputs(name: str, count: int, seed: int = 0):
+    """Seeded (x, u) rows for the quantity models: q = [p, unit quaternion, joints], v, a ~ U(-1, 1)."""
+    rng = np.random.default_rng(0x5EED0000 + seed)
+    nx, nu, _ = RBD_DIMS[name]
+    quat = rng.normal(size=(count, 4))
+    quat /= np.linalg.norm(quat, axis=1, keepdims=True)
+    q = np.concatenate((rng.uniform(-1, 1, (count, 3)), quat, rng.uniform(-1, 1, (count, 12))), axis=1)
+    x = q if nx == 19 else np.concatenate((q, rng.uniform(-1, 1, (count, 18))), axis=1)
+    return x, rng.uniform(-1, 1, (count, nu))
+
+
 def anymal_node(x, u, w, p):
     model = anymal_model()
     nq, nv = model.nq, model.nv

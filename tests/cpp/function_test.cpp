@@ -205,9 +205,77 @@ static void QuadrotorNodeThroughFacade(const std::string& folder) {
     std::printf("\n");
 }
 
+/// a function loaded from a cache hit (derive / emit / compile skipped, sparsity read from the
+/// entry's meta file) evaluates exactly like the freshly compiled one; an EDITED function of the same name never picks up
+/// the stale entry (the reference's existence-only cache would, function.hpp:420-451); a linear objective has an enabled but
+/// structurally empty Hessian that evaluates to an empty matrix instead of failing.
+static void TestCacheAndEmptyDerivatives(const std::string& folder) {
+    const auto make = [&](real_t gain, bool recompile) {
+        const auto impl = [gain](const VectorXad& xp, VectorXad& y) {
+            y.resize(1);
+            using std::sin;
+            y[0] = gain * xp[3] * (xp[0] * xp[0] + xp[1] * xp[1] * xp[2]) + sin(xp[0] * xp[2]);
+        };
+        return Autodiff::MakeFunction(Autodiff::Function::Blueprint{impl, 3, 1, "function_test_cache_probe", EnabledDerivatives::ALL, folder}, recompile);
+    };
+    Autodiff::Function fresh = make(1.5, true);
+    EXPECT_TRUE(!fresh.LoadedFromCache());
+    Autodiff::Function cached = make(1.5, false);
+    EXPECT_TRUE(cached.LoadedFromCache());
+    Autodiff::Function edited = make(2.5, false);  // same name, different tape
+    EXPECT_TRUE(!edited.LoadedFromCache());
+    std::mt19937 gen{5U};
+    for (int k = 0; k < 16; ++k) {
+        const VectorXr xp = RandomVector(4, gen);
+        EXPECT_TRUE(fresh(xp)[0] == cached(xp)[0]);
+        const std::vector<real_t> j0 = fresh.Jacobian(xp).toDense(), j1 = cached.Jacobian(xp).toDense();
+        const std::vector<real_t> h0 = fresh.Hessian(xp).toDense(), h1 = cached.Hessian(xp).toDense();
+        EXPECT_TRUE(j0 == j1 && h0 == h1 && j0.size() == 3 && h0.size() == 9);
+        EXPECT_TRUE(std::fabs(edited(xp)[0] - (fresh(xp)[0] + 1.0 * xp[3] * (xp[0] * xp[0] + xp[1] * xp[1] * xp[2]))) < 1e-12);
+        EXPECT_TRUE(std::fabs(h0[0] - (2.0 * 1.5 * xp[3] - xp[2] * xp[2] * std::sin(xp[0] * xp[2]))) < 1e-12);
+        EXPECT_TRUE(cached.TestJacobian(xp) && cached.TestHessian(xp));
+    }
+    // linear objective: Hessian enabled, structurally empty
+    const auto linear = [](const VectorXad& xp, VectorXad& y) {
+        y.resize(1);
+        y[0] = 2.0 * xp[0] - xp[1] + xp[2] * 0.5;
+    };
+    Autodiff::Function lin = Autodiff::MakeFunction(Autodiff::Function::Blueprint{linear, 3, 0, "function_test_linear_objective", EnabledDerivatives::ALL, folder}, true);
+    const VectorXr x = RandomVector(3, gen);
+    EXPECT_TRUE(lin.ImplementsHessian() && lin.Hessian(x).nonZeros() == 0 && lin.Hessian(x).rows() == 3);
+    const std::vector<real_t> jl = lin.Jacobian(x).toDense();
+    EXPECT_TRUE(jl.size() == 3 && jl[0] == 2.0 && jl[1] == -1.0 && jl[2] == 0.5);
+    // a function of the parameters only: Jacobian enabled, structurally empty
+    const auto paramOnly = [](const VectorXad& xp, VectorXad& y) {
+        y.resize(2);
+        y[0] = xp[2] * xp[2];
+        y[1] = xp[2] + 1.0;
+    };
+    Autodiff::Function par = Autodiff::MakeFunction(Autodiff::Function::Blueprint{paramOnly, 2, 1, "function_test_parameters_only", EnabledDerivatives::JACOBIAN, folder}, true);
+    VectorXr xp3{3};
+    xp3 << 0.1, 0.2, 3.0;
+    EXPECT_TRUE(par.Jacobian(xp3).nonZeros() == 0 && par(xp3)[0] == 9.0 && par(xp3)[1] == 4.0);
+    // the guard pattern of the reference's AD-safe quaternion layer, differentiated in reverse mode on the device
+    const auto guarded = [](const VectorXad& xp, VectorXad& y) {
+        y.resize(1);
+        using std::sqrt;
+        y[0] = xp[0] / ::ungar_amd::tape::CondExpGt(xp[1], ad_scalar_t{0.0}, sqrt(xp[1]), ad_scalar_t{1.0});
+    };
+    Autodiff::Function grd = Autodiff::MakeFunction(Autodiff::Function::Blueprint{guarded, 2, 0, "function_test_guarded_sqrt", EnabledDerivatives::ALL, folder}, true);
+    for (const real_t z : {-2.0, 0.0, 4.0}) {
+        VectorXr in{2};
+        in << 3.0, z;
+        const std::vector<real_t> jg = grd.Jacobian(in).toDense(), hg = grd.Hessian(in).toDense();
+        EXPECT_TRUE(std::fabs(jg[0] - (z > 0 ? 0.5 : 1.0)) < 1e-15 && std::fabs(jg[1] - (z > 0 ? -0.5 * 3.0 / 8.0 : 0.0)) < 1e-15);
+        for (const real_t e : hg) EXPECT_TRUE(std::isfinite(e));
+    }
+    std::printf("cache probe ok\n");
+}
+
 int main(int argc, char** argv) {
     const std::string folder = argc > 1 ? argv[1] : "/tmp/ungar_amd_cpp_test";
     try {
+        TestCacheAndEmptyDerivatives(folder);
         TestExponentialMap(folder);
         TestJacobianClosedForm(folder);
         TestHessianClosedForm(folder);

@@ -1,0 +1,159 @@
+"""Run-time function cache (reference function.hpp:420-451, 485-503 keeps an existence-only
+`.so` cache).  A cache entry here is {meta: sparsity patterns + kernel table, one gfx950 code object per kernel}, keyed by a
+hash of (optimised tape, enabled derivatives, arch, ROCm version, emitter build id, JIT flags).  hipcc cross-compiles without a
+GPU, so the whole life cycle is checked on the CPU with UNGAR_AMD_COMPILE_ONLY=1: miss -> publish, hit (derive / emit / compile
+skipped, same sparsity), an edited function never hits the stale entry, damaged entries are rebuilt, publishing is atomic
+under concurrent builders, odd characters in the folder name survive the shell.  The GPU half (a function loaded from a hit
+evaluates exactly like a freshly compiled one) is tests/cpp/function_test.cpp, run by tests/test_cpp_facade.py."""
+import ctypes
+import multiprocessing as mp
+import os
+import time
+
+import pytest
+
+import ungar_amd
+
+
+class Node(ctypes.Structure):
+    _fields_ = [("op", ctypes.c_int32), ("a", ctypes.c_int32), ("b", ctypes.c_int32), ("c", ctypes.c_int32), ("d", ctypes.c_int32),
+                ("reserved", ctypes.c_int32), ("value", ctypes.c_double)]
+
+
+class Info(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int64) for n in ("n", "p", "m", "jac_nnz", "hes_nnz", "cache_hit")]
+
+
+CONST, INPUT, ADD, MUL, SIN = 0, 1, 2, 4, 7
+
+
+def _tape(scale):
+    """y = scale * (x0^2 + x1^2 + x2^2) * p0 + sin(x0): n = 3, p = 1, m = 1."""
+    nodes = [Node(INPUT, i, -1, -1, -1, 0, 0.0) for i in range(4)]               # 0..3: x0 x1 x2 p0
+    nodes += [Node(MUL, i, i, -1, -1, 0, 0.0) for i in range(3)]                 # 4..6: squares
+    nodes += [Node(ADD, 4, 5, -1, -1, 0, 0.0), Node(ADD, 7, 6, -1, -1, 0, 0.0)]  # 7, 8: sum
+    nodes += [Node(CONST, -1, -1, -1, -1, 0, scale), Node(MUL, 8, 9, -1, -1, 0, 0.0), Node(MUL, 10, 3, -1, -1, 0, 0.0)]  # 9, 10, 11
+    nodes += [Node(SIN, 0, -1, -1, -1, 0, 0.0), Node(ADD, 11, 12, -1, -1, 0, 0.0)]  # 12, 13
+    return (Node * len(nodes))(*nodes), len(nodes), (ctypes.c_int32 * 1)(13)
+
+
+def _make(folder, scale=1.0, enabled=6, recompile=0, name="cache_probe"):
+    lib = ungar_amd.load_library()
+    lib.ungar_function_make.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                        ctypes.c_char_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+    lib.ungar_function_free.argtypes = [ctypes.c_void_p]
+    lib.ungar_function_free.restype = None
+    lib.ungar_function_get_info.argtypes = [ctypes.c_void_p, ctypes.POINTER(Info)]
+    i32pp = ctypes.POINTER(ctypes.POINTER(ctypes.c_int32))
+    lib.ungar_function_jacobian_sparsity.argtypes = [ctypes.c_void_p, i32pp, i32pp, ctypes.POINTER(ctypes.c_int64)]
+    lib.ungar_function_hessian_sparsity.argtypes = [ctypes.c_void_p, i32pp, i32pp, ctypes.POINTER(ctypes.c_int64)]
+    nodes, count, outs = _tape(scale)
+    fn = ctypes.c_void_p()
+    t0 = time.perf_counter()
+    rc = lib.ungar_function_make(nodes, count, outs, 1, 3, 1, name.encode(), enabled, str(folder).encode(), recompile, ctypes.byref(fn))
+    dt = time.perf_counter() - t0
+    assert rc == 0, lib.ungar_last_error().decode()
+    info = Info()
+    assert lib.ungar_function_get_info(fn, ctypes.byref(info)) == 0
+
+    def pattern(query):
+        rows, cols, nnz = ctypes.POINTER(ctypes.c_int32)(), ctypes.POINTER(ctypes.c_int32)(), ctypes.c_int64()
+        if query(fn, ctypes.byref(rows), ctypes.byref(cols), ctypes.byref(nnz)) != 0:
+            return None
+        return [(rows[k], cols[k]) for k in range(nnz.value)]
+
+    out = {"hit": bool(info.cache_hit), "jac": pattern(lib.ungar_function_jacobian_sparsity), "hes": pattern(lib.ungar_function_hessian_sparsity),
+           "jac_nnz": info.jac_nnz, "hes_nnz": info.hes_nnz, "seconds": dt}
+    lib.ungar_function_free(fn)
+    return out
+
+
+@pytest.fixture(autouse=True)
+def compile_only(monkeypatch):
+    monkeypatch.setenv("UNGAR_AMD_COMPILE_ONLY", "1")
+
+
+def _entry_files(folder, name="cache_probe"):
+    d = os.path.join(str(folder), name, "ungar_amd")
+    return sorted(os.listdir(d)) if os.path.isdir(d) else []
+
+
+def test_miss_publish_hit_and_edit_invalidates(tmp_path):
+    first = _make(tmp_path)
+    assert not first["hit"] and first["jac"] == [(0, 0), (0, 1), (0, 2)] and first["hes"] == [(0, 0), (1, 1), (2, 2)]
+    files = _entry_files(tmp_path)
+    assert len([f for f in files if f.endswith(".meta")]) == 1 and len([f for f in files if f.endswith(".hsaco")]) == 3
+    assert not [f for f in files if f.endswith(".tmp") or f.endswith(".hip")], files  # nothing half-published, sources removed
+    second = _make(tmp_path)
+    assert second["hit"] and second["jac"] == first["jac"] and second["hes"] == first["hes"]
+    assert second["seconds"] < 0.25 * first["seconds"]  # derive / emit / compile skipped
+    # an EDITED function of the same name must not pick up the stale entry (the reference's existence-only cache does)
+    edited = _make(tmp_path, scale=2.0)
+    assert not edited["hit"]
+    assert len([f for f in _entry_files(tmp_path) if f.endswith(".meta")]) == 2
+    assert _make(tmp_path, scale=2.0)["hit"] and _make(tmp_path)["hit"]  # both entries stay valid side by side
+    # a different set of enabled derivatives is a different entry; recompile = true never hits
+    jac_only = _make(tmp_path, enabled=2)
+    assert not jac_only["hit"] and jac_only["hes"] is None and jac_only["jac_nnz"] == 3
+    assert not _make(tmp_path, recompile=1)["hit"]
+    assert _make(tmp_path)["hit"]
+
+
+def test_damaged_entries_are_rebuilt(tmp_path):
+    assert not _make(tmp_path)["hit"]
+    d = os.path.join(str(tmp_path), "cache_probe", "ungar_amd")
+    meta = [f for f in os.listdir(d) if f.endswith(".meta")][0]
+    text = open(os.path.join(d, meta)).read()
+    with open(os.path.join(d, meta), "w") as fh:  # flip one sparsity index: the trailing checksum no longer matches
+        fh.write(text.replace("jac 3 0 0 0 1", "jac 3 0 0 0 2"))
+    again = _make(tmp_path)
+    assert not again["hit"] and again["jac"] == [(0, 0), (0, 1), (0, 2)]
+    assert _make(tmp_path)["hit"]
+    with open(os.path.join(d, meta), "w") as fh:  # truncated meta
+        fh.write(text[: len(text) // 2])
+    assert not _make(tmp_path)["hit"]
+    obj = [f for f in os.listdir(d) if f.endswith("_jacobian.hsaco")][0]
+    os.remove(os.path.join(d, obj))  # missing code object
+    assert not _make(tmp_path)["hit"]
+    with open(os.path.join(d, obj), "ab") as fh:  # size differs from the recorded one
+        fh.write(b"junk")
+    assert not _make(tmp_path)["hit"]
+    assert _make(tmp_path)["hit"]
+
+
+def test_folder_names_survive_the_shell(tmp_path):
+    folder = tmp_path / "it's a (dir) & more; #1"
+    assert not _make(folder)["hit"]
+    assert _make(folder)["hit"]
+    lib = ungar_amd.load_library()
+    nodes, count, outs = _tape(1.0)
+    fn = ctypes.c_void_p()
+    for bad_name, bad_folder in ((b"probe", str(tmp_path / "a $HOME dir").encode()), (b"probe", str(tmp_path / "a `dir`").encode()), (b"pro'be", str(tmp_path).encode()),
+                                 (b"pro/be", str(tmp_path).encode())):
+        assert lib.ungar_function_make(nodes, count, outs, 1, 3, 1, bad_name, 6, bad_folder, 0, ctypes.byref(fn)) == -1  # the hipcc driver re-expands these
+        assert b"unsupported character" in lib.ungar_last_error()
+
+
+def _concurrent_builder(folder, q):
+    os.environ["UNGAR_AMD_COMPILE_ONLY"] = "1"
+    try:
+        q.put(_make(folder, scale=3.0, name="cache_race"))
+    except Exception as exc:  # noqa: BLE001
+        q.put(repr(exc))
+
+
+def test_concurrent_builders_of_the_same_function(tmp_path):
+    """One process per GPU: every rank builds the same functions at start-up (a shared in-place source file
+    let one rank truncate what another rank's compiler was reading)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_concurrent_builder, args=(str(tmp_path), q)) for _ in range(4)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(isinstance(r, dict) and r["jac_nnz"] == 3 for r in results), results
+    files = _entry_files(tmp_path, "cache_race")
+    assert not [f for f in files if f.endswith(".tmp") or f.endswith(".hip")], files
+    assert _make(tmp_path, scale=3.0, name="cache_race")["hit"]

@@ -1,0 +1,151 @@
+"""Rigid-body quantities as batched node models (reference
+include/ungar/rbd/quantities/{joint_torques, joint_space_inertia_matrix, joint_space_inertia_matrix_inverse, frames,
+centroidal_momentum}.hpp:42-43): anymal_rnea / anymal_crba / anymal_minv / anymal_feet / anymal_centroidal.
+
+  CPU   the product's tapes lowered to C (oracle/_gen/<model>_cg.c) against the committed oracle fixtures
+        tests/golden/rbd_<model>.npz (values and Jacobians from RNEA, RNEA-column mass matrix, forward kinematics and a
+        spatial-momentum sum with torch.autograd -- made by tests/golden/make_rbd_golden.py), plus identities between the
+        quantities (M symmetric positive definite, M M^-1 = 1, tau = M a + tau(a = 0), orthonormal foot rotations) and the
+        mass matrix of the formulation-independent Lagrangian oracle;
+  GPU   the HIP kernels through the C ABI against the same fixtures, both device layouts, dense and sparse Jacobians.
+"""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from oracle import ungar_oracle as O
+
+MODELS = ("anymal_rnea", "anymal_crba", "anymal_minv", "anymal_feet", "anymal_centroidal")
+
+
+def _golden(repo_root, name):
+    return np.load(os.path.join(repo_root, "tests", "golden", f"rbd_{name}.npz"))
+
+
+@pytest.fixture(scope="module")
+def clib(repo_root):
+    from oracle import build_oracle
+    if not all(os.path.exists(os.path.join(repo_root, "oracle", "_gen", f"{m}_cg.c")) for m in MODELS):
+        pytest.skip("oracle/_gen/*.c not generated: run __graft_entry__.build()")
+    return ctypes.CDLL(build_oracle.build("portable", models=build_oracle.RBD_MODELS))
+
+
+def _eval_c(clib, name, x, u):
+    nx, nu, ny = O.RBD_DIMS[name]
+    nnz = ctypes.c_int.in_dll(clib, f"{name}_jac_nnz").value
+    assert ctypes.c_int.in_dll(clib, f"{name}_ny").value == ny and list((ctypes.c_int * 4).in_dll(clib, f"{name}_dims")) == [nx, nu, 0, 0]
+    rows = np.ctypeslib.as_array((ctypes.c_int * max(nnz, 1)).in_dll(clib, f"{name}_jac_row"))[:nnz]
+    cols = np.ctypeslib.as_array((ctypes.c_int * max(nnz, 1)).in_dll(clib, f"{name}_jac_col"))[:nnz]
+    dp = ctypes.POINTER(ctypes.c_double)
+    ptr = lambda a: a.ctypes.data_as(dp)  # noqa: E731
+    y, y0, jac, dummy = np.zeros(ny), np.zeros(ny), np.zeros(max(nnz, 1)), np.zeros(1)
+    xx, uu = np.ascontiguousarray(x), (np.ascontiguousarray(u) if nu else dummy)
+    getattr(clib, f"{name}_sparse_jacobian")(ptr(xx), ptr(uu), ptr(dummy), ptr(dummy), ptr(y), ptr(jac))
+    getattr(clib, f"{name}_forward_zero")(ptr(xx), ptr(uu), ptr(dummy), ptr(dummy), ptr(y0))
+    assert np.array_equal(y, y0)
+    J = np.zeros((ny, nx + nu))
+    J[rows, cols] = jac[:nnz]
+    return y, J, nnz
+
+
+@pytest.mark.parametrize("name", MODELS)
+def test_generated_c_matches_the_oracle_fixture(repo_root, clib, name):
+    g = _golden(repo_root, name)
+    for i in range(g["x"].shape[0]):
+        y, J, nnz = _eval_c(clib, name, g["x"][i], g["u"][i])
+        assert np.abs(y - g["y"][i]).max() <= 1e-11 * max(1.0, np.abs(g["y"][i]).max())
+        if name == "anymal_minv":
+            assert nnz == 0  # value-only model
+            continue
+        assert np.abs(J - g["J"][i]).max() <= 1e-10 * max(1.0, np.abs(g["J"][i]).max())
+        assert not ((J == 0) & (np.abs(g["J"][i]) > 1e-11)).any()  # the structural pattern misses nothing
+
+
+def test_identities_between_the_quantities(repo_root, clib):
+    import torch
+    from oracle import lagrange_oracle as L
+    g = _golden(repo_root, "anymal_rnea")
+    lag = L.LagrangeModel(L.load_fixture())
+    for i in range(3):
+        x, a = g["x"][i], g["u"][i]
+        q = x[:19]
+        M = _eval_c(clib, "anymal_crba", q, None)[0].reshape(18, 18)
+        Minv = _eval_c(clib, "anymal_minv", q, None)[0].reshape(18, 18)
+        assert np.abs(M - M.T).max() < 1e-13 and np.linalg.eigvalsh(M).min() > 0
+        assert np.abs(M @ Minv - np.eye(18)).max() < 1e-10
+        tau = _eval_c(clib, "anymal_rnea", x, a)[0]
+        tau0 = _eval_c(clib, "anymal_rnea", x, np.zeros(18))[0]
+        assert np.abs(tau - tau0 - M @ a).max() < 1e-10  # tau = M a + h(q, v)
+        # the mass matrix of the energy-based oracle (no spatial algebra, un-lumped links read by the second URDF reader)
+        M_lag = lag.mass_matrix(torch.zeros(18, dtype=torch.float64), torch.zeros(3, dtype=torch.float64), torch.eye(3, dtype=torch.float64), torch.as_tensor(q[7:])).numpy()
+        assert np.abs(M - M_lag).max() < 1e-11
+        feet = _eval_c(clib, "anymal_feet", q, None)[0].reshape(4, 12)
+        for f in range(4):
+            R = feet[f, 3:].reshape(3, 3)
+            assert np.abs(R @ R.T - np.eye(3)).max() < 1e-12 and abs(np.linalg.det(R) - 1) < 1e-12
+        local = lag.frame_positions(np.concatenate((np.zeros(3), [0, 0, 0, 1], q[7:])), [f"{leg}_FOOT" for leg in L.LEGS])
+        world = torch.as_tensor(q[:3]) + (L.quat_to_rot(torch.as_tensor(q[3:7])) @ local.T).T
+        assert np.abs(feet[:, :3] - world.numpy()).max() < 1e-12
+        h = _eval_c(clib, "anymal_centroidal", x, None)[0]
+        Mlin = M[:3, :] @ x[19:]  # base-frame linear momentum = first three rows of M v; rotate to the world
+        assert np.abs(L.quat_to_rot(torch.as_tensor(q[3:7])).numpy() @ Mlin - h[:3]).max() < 1e-10
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", MODELS)
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+def test_hip_kernels_match_the_oracle_fixture(repo_root, name, layout):
+    import ungar_amd
+    g = _golden(repo_root, name)
+    m = ungar_amd.NodeModel(name)
+    nx, nu, ny = O.RBD_DIMS[name]
+    assert (m.nx, m.nu, m.nw, m.np, m.ny) == (nx, nu, 0, 0, ny)
+    count = g["x"].shape[0]
+    none = np.zeros((count, 0))
+    y, _ = m.evaluate_numpy(g["x"], g["u"], none, none, mode="value", layout=layout)
+    assert np.abs(y - g["y"]).max() <= 1e-11 * max(1.0, np.abs(g["y"]).max())
+    if name == "anymal_minv":
+        assert not m.implements_jacobian()
+        with pytest.raises(ungar_amd.UngarError, match="without a Jacobian"):
+            m.evaluate_numpy(g["x"], g["u"], none, none, mode="dense", layout=layout)
+        return
+    for mode in ("dense", "sparse"):
+        y, J = m.evaluate_numpy(g["x"], g["u"], none, none, mode=mode, layout=layout)
+        assert np.isfinite(J).all()
+        assert np.abs(y - g["y"]).max() <= 1e-11 * max(1.0, np.abs(g["y"]).max())
+        assert np.abs(J - g["J"]).max() <= 1e-10 * max(1.0, np.abs(g["J"]).max())
+
+
+@pytest.mark.gpu
+def test_batched_quantities_at_scale():
+    """65 536 configurations in one launch per quantity: identities that need no oracle (M M^-1 = 1, tau linear in a,
+    orthonormal foot rotations), i.e. every lane of a large launch computes what the small launches compute."""
+    import torch
+    import ungar_amd
+    count = 65536
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(9)
+    r = lambda n: torch.rand((n, count), generator=gen, device="cuda", dtype=torch.float64) * 2 - 1  # noqa: E731
+    quat = torch.randn((4, count), generator=gen, device="cuda", dtype=torch.float64)
+    q = torch.cat((r(3), quat / quat.norm(dim=0, keepdim=True), r(12)))
+    Op = ungar_amd.Operand
+
+    def run(name, x, u=None):
+        m = ungar_amd.NodeModel(name)
+        y = torch.full((m.ny, count), float("nan"), dtype=torch.float64, device="cuda")
+        m.forward_zero(count, Op.soa(x, count), None if u is None else Op.soa(u, count), None, None, Op.soa(y, count))
+        torch.cuda.synchronize()
+        return y
+
+    M = run("anymal_crba", q).t().reshape(count, 18, 18)
+    Minv = run("anymal_minv", q).t().reshape(count, 18, 18)
+    assert (torch.bmm(M, Minv) - torch.eye(18, dtype=torch.float64, device="cuda")).abs().max().item() < 1e-9
+    v, a = r(18), r(18)
+    x = torch.cat((q, v))
+    tau, tau0 = run("anymal_rnea", x, a), run("anymal_rnea", x, torch.zeros_like(a))
+    assert ((tau - tau0).t() - torch.bmm(M, a.t().unsqueeze(2)).squeeze(2)).abs().max().item() < 1e-9
+    feet = run("anymal_feet", q).t().reshape(count, 4, 12)
+    R = feet[:, :, 3:].reshape(count * 4, 3, 3)
+    assert (torch.bmm(R, R.transpose(1, 2)) - torch.eye(3, dtype=torch.float64, device="cuda")).abs().max().item() < 1e-12

@@ -25,6 +25,7 @@ __all__ = ["NodeModel", "Operand", "gn_hessian", "library_path", "load_library",
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 MODELS = ("quadrotor", "rc_car", "srbd", "anymal", "anymal_ad", "anymal_reg")
+RBD_MODELS = ("anymal_rnea", "anymal_crba", "anymal_minv", "anymal_feet", "anymal_centroidal")  # rigid-body quantities as node models
 
 
 class UngarError(RuntimeError):
@@ -192,7 +193,7 @@ class NodeModel:
     # -- batched evaluation -----------------------------------------------------------------------
     def _batch(self, count, knots, x, u, w, p, f, jac) -> _NodeBatch:
         none = Operand(None)
-        return _NodeBatch(count, knots, x._c(), u._c(), (w or none)._c(), p._c(), (f or none)._c(), (jac or none)._c())
+        return _NodeBatch(count, knots, x._c(), (u or none)._c(), (w or none)._c(), (p or none)._c(), (f or none)._c(), (jac or none)._c())
 
     @staticmethod
     def _stream(stream):
@@ -264,7 +265,7 @@ class NodeModel:
             return (t.t().contiguous() if layout == "soa" else t.contiguous()).to(dev)
 
         xt, ut, wt = up(x, self.nx), up(u, self.nu), up(w, self.nw)
-        pt = torch.as_tensor(np.ascontiguousarray(p), dtype=torch.float64).to(dev)
+        pt = torch.as_tensor(np.ascontiguousarray(p), dtype=torch.float64).to(dev) if self.np else None
         if layout == "soa":
             ft = torch.full((self.ny, count), float("nan"), dtype=torch.float64, device=dev)
             jt = torch.full((nj, count), float("nan"), dtype=torch.float64, device=dev)
@@ -273,7 +274,7 @@ class NodeModel:
             ft = torch.full((count, self.ny), float("nan"), dtype=torch.float64, device=dev)
             jt = torch.full((count, nj), float("nan"), dtype=torch.float64, device=dev)
             mk = lambda t, n: None if t is None else Operand.aos(t, n)  # noqa: E731
-        args = (count, mk(xt, self.nx), mk(ut, self.nu), mk(wt, self.nw), Operand.per_instance(pt, self.np), mk(ft, self.ny))
+        args = (count, mk(xt, self.nx), mk(ut, self.nu), mk(wt, self.nw), Operand.per_instance(pt, self.np) if self.np else None, mk(ft, self.ny))
         if mode == "value":
             self.forward_zero(*args)
             torch.cuda.synchronize()

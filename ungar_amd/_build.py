@@ -20,8 +20,9 @@ BUILD = os.path.join(ROOT, "build")
 LIBDIR = os.path.join(ROOT, "ungar_amd", "lib")
 LIB = os.path.join(LIBDIR, "libungar_amd.so")
 ORACLE_GEN = os.path.join(ROOT, "oracle", "_gen")
-MODELS = ("quadrotor", "rc_car", "srbd", "srbd_ineq", "anymal", "anymal_ad", "anymal_reg")
-C_MODELS = ("quadrotor", "rc_car", "srbd", "anymal", "anymal_ad")
+RBD_MODELS = ("anymal_rnea", "anymal_crba", "anymal_minv", "anymal_feet", "anymal_centroidal")
+MODELS = ("quadrotor", "rc_car", "srbd", "srbd_ineq", "anymal", "anymal_ad", "anymal_reg") + RBD_MODELS
+C_MODELS = ("quadrotor", "rc_car", "srbd", "anymal", "anymal_ad") + RBD_MODELS
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-Wno-unused-result"]
 
 
@@ -112,13 +113,22 @@ def build_library(jobs: int | None = None):
     # the two comparison kernels (taped ABA / structured, lane per node: 40-60 k statements in one basic block)
     # spend > 90 % of their compile time in the machine schedulers; without them the from-scratch build drops
     # from 12.7 to ~6 minutes.  The product kernels keep the full pipeline.
-    fast = ("model_anymal_ad.hip", "model_anymal_reg.hip")
+    fast = ("model_anymal_ad.hip", "model_anymal_reg.hip", "model_anymal_rnea.hip", "model_anymal_centroidal.hip")  # the last two: 12-23 k statements, not hot
     no_sched = ["-mllvm", "-enable-misched=false", "-mllvm", "-enable-post-misched=false"]
+
+    # identity of the tape engine (recorder, derivative transforms, emitters, run-time factory): part of the key of
+    # every run-time cache entry, so that editing any of these sources invalidates the entries they produced
+    import hashlib
+    h = hashlib.sha1()
+    for f in sorted(_tree(os.path.join(CSRC, "tape")) + [os.path.join(CSRC, "runtime", "function.cpp")]):
+        h.update(open(f, "rb").read())
+    emitter_id = h.hexdigest()[:16]
 
     def compile_unit(u):
         src, obj, deps = u
         if not _newer([obj], deps):
-            _run(["hipcc", *HIPCC_FLAGS, *(no_sched if os.path.basename(src) in fast else []), "-c", src, "-o", obj])
+            extra = [f'-DUNGAR_AMD_EMITTER_ID="{emitter_id}"'] if os.path.basename(src) == "function.cpp" else []
+            _run(["hipcc", *HIPCC_FLAGS, *extra, *(no_sched if os.path.basename(src) in fast else []), "-c", src, "-o", obj])
         return obj
 
     with ThreadPoolExecutor(max_workers=jobs or min(8, os.cpu_count() or 1)) as pool:

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "../models/nodes.hpp"
+#include "../models/rbd_nodes.hpp"
 #include "../rbd/rnea_crba.hpp"
 #include "../tape/emit.hpp"
 #include "quad_leg_program.hpp"
@@ -29,6 +30,7 @@ namespace {
 struct NodeSpec {
     models::NodeDims dims;
     std::function<void(const AD*, const AD*, const AD*, const AD*, AD*)> fn;
+    bool valueOnly = false;  // no Jacobian program (ungar_model_has_sparse_jacobian() == 0)
 };
 
 struct Generated {
@@ -45,6 +47,11 @@ Generated Record(const NodeSpec& spec, int jacMode) {
     std::vector<AD> out(static_cast<std::size_t>(d.Ny()));
     spec.fn(in.data(), in.data() + d.nx, in.data() + d.nx + d.nu, in.data() + d.nx + d.nu + d.nw, out.data());
     Generated g{d, tape::MakeTape(out), {}, 0};
+    if (spec.valueOnly) {
+        g.jac.rows = d.Ny();
+        g.jac.cols = d.nx + d.nu;
+        return g;
+    }
     tape::Differentiator diff{g.tape};
     g.jac = diff.Jacobian(d.nx + d.nu, jacMode);
     g.jacMode = diff.LastMode();
@@ -226,11 +233,11 @@ void EmitHip(const Generated& g, const std::string& dir, bool columnMajorEmissio
        << "inline constexpr int kNx = " << d.nx << ", kNu = " << d.nu << ", kNw = " << d.nw << ", kNp = " << d.np << ";\n"
        << "inline constexpr int kJacRows = " << g.jac.rows << ", kJacCols = " << g.jac.cols << ", kJacNnz = " << g.jac.Nnz() << ";\n"
        << "inline constexpr int kJacMode = " << g.jacMode << ";  // 1 = forward, 2 = reverse accumulation\n";
-    os << "inline constexpr int kJacRow[kJacNnz] = {";
+    os << "inline constexpr int kJacRow[kJacNnz > 0 ? kJacNnz : 1] = {";
     for (std::size_t k = 0; k < g.jac.Nnz(); ++k) os << (k ? "," : "") << g.jac.row[k];
-    os << "};\ninline constexpr int kJacCol[kJacNnz] = {";
+    os << (g.jac.Nnz() ? "" : "0") << "};\ninline constexpr int kJacCol[kJacNnz > 0 ? kJacNnz : 1] = {";
     for (std::size_t k = 0; k < g.jac.Nnz(); ++k) os << (k ? "," : "") << g.jac.col[k];
-    os << "};\n\n";
+    os << (g.jac.Nnz() ? "" : "0") << "};\n\n";
 
     // Value only.
     {
@@ -390,9 +397,9 @@ void EmitC(const Generated& g, const std::string& dir) {
        << "const int " << name << "_jac_nnz = " << g.jac.Nnz() << ";\n"
        << "const int " << name << "_jac_row[] = {";
     for (std::size_t k = 0; k < g.jac.Nnz(); ++k) os << (k ? "," : "") << g.jac.row[k];
-    os << "};\nconst int " << name << "_jac_col[] = {";
+    os << (g.jac.Nnz() ? "" : "0") << "};\nconst int " << name << "_jac_col[] = {";
     for (std::size_t k = 0; k < g.jac.Nnz(); ++k) os << (k ? "," : "") << g.jac.col[k];
-    os << "};\n\n";
+    os << (g.jac.Nnz() ? "" : "0") << "};\nconst int " << name << "_ny = " << d.Ny() << ";\n\n";
     {
         std::vector<tape::OutputSlot> slots;
         for (int i = 0; i < d.Ny(); ++i) slots.push_back({g.tape.outputs[static_cast<std::size_t>(i)], "f[" + std::to_string(i) + "] = %s;"});
@@ -478,6 +485,12 @@ int main(int argc, char** argv) {
         specs.push_back({models::kAnymalDims, [&anymal](const AD* x, const AD* u, const AD* w, const AD* p, AD* xn) {
                              models::FloatingBaseNode<AD>(anymal, x, u, w, p, xn);
                          }});
+        // rigid-body quantities as node models
+        specs.push_back({models::kAnymalRneaDims, [&anymal](const AD* x, const AD* u, const AD*, const AD*, AD* y) { models::JointTorquesNode<AD>(anymal, x, u, y); }});
+        specs.push_back({models::kAnymalCrbaDims, [&anymal](const AD* x, const AD*, const AD*, const AD*, AD* y) { models::InertiaMatrixNode<AD>(anymal, x, y); }});
+        specs.push_back({models::kAnymalMinvDims, [&anymal](const AD* x, const AD*, const AD*, const AD*, AD* y) { models::InertiaInverseNode<AD>(anymal, x, y); }, true});
+        specs.push_back({models::kAnymalFeetDims, [&anymal](const AD* x, const AD*, const AD*, const AD*, AD* y) { models::FootFramesNode<AD>(anymal, x, y); }});
+        specs.push_back({models::kAnymalCentroidalDims, [&anymal](const AD* x, const AD*, const AD*, const AD*, AD* y) { models::CentroidalMomentumNode<AD>(anymal, x, y); }});
     }
     auto wanted = [&](const char* nm) {
         if (only.empty()) return true;

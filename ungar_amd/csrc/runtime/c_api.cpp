@@ -32,6 +32,11 @@ UNGAR_AMD_DECLARE_MODEL(anymal_reg)
 UNGAR_AMD_DECLARE_MODEL(quadrotor_cost)
 UNGAR_AMD_DECLARE_MODEL(srbd_cost)
 UNGAR_AMD_DECLARE_MODEL(srbd_ineq)
+UNGAR_AMD_DECLARE_MODEL(anymal_rnea)
+UNGAR_AMD_DECLARE_MODEL(anymal_crba)
+UNGAR_AMD_DECLARE_MODEL(anymal_minv)
+UNGAR_AMD_DECLARE_MODEL(anymal_feet)
+UNGAR_AMD_DECLARE_MODEL(anymal_centroidal)
 
 extern "C" int ungar_amd_launch_ocp_assemble(const ungar_amd::kernels::OcpAssemblyArgs* a, void* stream);
 
@@ -69,6 +74,11 @@ const BuiltinEntry kBuiltins[] = {
     {"anymal_ad", ungar_amd_launch_anymal_ad, ungar_amd_pattern_anymal_ad, ungar_amd_dims_anymal_ad},
     {"anymal_reg", ungar_amd_launch_anymal_reg, ungar_amd_pattern_anymal_reg, ungar_amd_dims_anymal_reg},
     {"srbd_ineq", ungar_amd_launch_srbd_ineq, ungar_amd_pattern_srbd_ineq, ungar_amd_dims_srbd_ineq},
+    {"anymal_rnea", ungar_amd_launch_anymal_rnea, ungar_amd_pattern_anymal_rnea, ungar_amd_dims_anymal_rnea},
+    {"anymal_crba", ungar_amd_launch_anymal_crba, ungar_amd_pattern_anymal_crba, ungar_amd_dims_anymal_crba},
+    {"anymal_minv", ungar_amd_launch_anymal_minv, ungar_amd_pattern_anymal_minv, ungar_amd_dims_anymal_minv},
+    {"anymal_feet", ungar_amd_launch_anymal_feet, ungar_amd_pattern_anymal_feet, ungar_amd_dims_anymal_feet},
+    {"anymal_centroidal", ungar_amd_launch_anymal_centroidal, ungar_amd_pattern_anymal_centroidal, ungar_amd_dims_anymal_centroidal},
     {"quadrotor_cost", ungar_amd_launch_quadrotor_cost, ungar_amd_pattern_quadrotor_cost, ungar_amd_dims_quadrotor_cost, true},
     {"srbd_cost", ungar_amd_launch_srbd_cost, ungar_amd_pattern_srbd_cost, ungar_amd_dims_srbd_cost, true},
 };
@@ -185,7 +195,7 @@ int ungar_model_open(const char* name, ungar_model** out) {
         *out = m;
         return UNGAR_OK;
     }
-    return Fail(UNGAR_E_INVALID, std::string("unknown model '") + name + "' (built-ins: quadrotor, rc_car, srbd, anymal, anymal_ad, anymal_reg, srbd_ineq, quadrotor_cost, srbd_cost)");
+    return Fail(UNGAR_E_INVALID, std::string("unknown model '") + name + "' (built-ins: quadrotor, rc_car, srbd, anymal, anymal_ad, anymal_reg, srbd_ineq, quadrotor_cost, srbd_cost, anymal_rnea, anymal_crba, anymal_minv, anymal_feet, anymal_centroidal)");
 }
 
 void ungar_model_close(ungar_model* model) {

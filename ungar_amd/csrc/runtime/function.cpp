@@ -7,7 +7,9 @@
 //   GccCompiler / createDynamicLibrary -> `hipcc --offload-arch=gfx950 --genco`  (process boundary)
 //   LinuxDynamicLib / dlopen         -> hipModuleLoad / hipModuleGetFunction
 //   existence-only .so cache (function.hpp:420-451, stale-cache hazard)
-//                                    -> cache keyed by a hash of (generated source, arch, flags)
+//                                    -> versioned cache entry {meta (sparsity, kernel table), code objects} keyed by a hash of
+//                                       (optimised tape, enabled derivatives, arch, ROCm version, emitter build id, JIT flags):
+//                                       a hit skips derive / emit / compile altogether
 // Kernels map one lane to one problem instance and address operands through strides, so the same
 // code object serves batch = 1 host calls (what Ungar::Autodiff::Function needs) and large batches.
 #include <hip/hip_runtime.h>
@@ -18,6 +20,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstdint>
 #include <cstring>
 #include <algorithm>
 #include <fstream>
@@ -62,13 +65,122 @@ using runtime::Fail;
 constexpr uint32_t kEnableJacobian = 1U << 1;  // EnabledDerivatives::JACOBIAN, autodiff/data_types.hpp:95-100
 constexpr uint32_t kEnableHessian = 1U << 2;   // EnabledDerivatives::HESSIAN
 
-std::uint64_t Fnv1a(const std::string& s, std::uint64_t h = 1469598103934665603ULL) {
-    for (unsigned char c : s) {
-        h ^= c;
+std::uint64_t Fnv1a(const void* data, std::size_t n, std::uint64_t h) {
+    const unsigned char* p = static_cast<const unsigned char*>(data);
+    for (std::size_t i = 0; i < n; ++i) {
+        h ^= p[i];
         h *= 1099511628211ULL;
     }
     return h;
 }
+
+/// 128-bit content key: two FNV-1a lanes with different offsets (the second lane also sees the running first lane).
+struct KeyHasher {
+    std::uint64_t a = 1469598103934665603ULL, b = 0x9E3779B97F4A7C15ULL;
+    void Bytes(const void* data, std::size_t n) {
+        a = Fnv1a(data, n, a);
+        b = Fnv1a(data, n, b ^ (a >> 7));
+    }
+    void Str(const std::string& s) {
+        Bytes(s.data(), s.size());
+        Int(static_cast<long long>(s.size()));
+    }
+    void Int(long long v) {
+        Bytes(&v, sizeof v);
+    }
+    std::string Hex() const {
+        char buf[40];
+        std::snprintf(buf, sizeof buf, "%016llx%016llx", static_cast<unsigned long long>(a), static_cast<unsigned long long>(b));
+        return buf;
+    }
+};
+
+// Everything that decides what a cache entry contains, besides the tape itself.  UNGAR_AMD_EMITTER_ID is a hash of the
+// tape engine's sources (csrc/tape/*.hpp, this file) injected by the build (ungar_amd/_build.py): editing the derivative
+// transforms or the emitter invalidates every entry without anyone remembering to bump a version.
+#ifndef UNGAR_AMD_EMITTER_ID
+#define UNGAR_AMD_EMITTER_ID "unversioned"
+#endif
+constexpr const char* kCacheFormat = "ungar_amd-cache-2";
+constexpr const char* kArch = "gfx950";
+constexpr std::size_t kBigKernel = 3000;  // statements above which the machine schedulers are switched off (see below)
+
+std::string ShellQuote(const std::string& s) {
+    std::string q = "'";
+    for (char c : s) {
+        if (c == '\'') q += "'\\''";
+        else q += c;
+    }
+    return q + "'";
+}
+
+bool FileSize(const std::string& path, long long* size) {
+    struct stat st {};
+    if (stat(path.c_str(), &st) != 0) return false;
+    *size = static_cast<long long>(st.st_size);
+    return true;
+}
+
+/// What a cache entry records besides the code objects: enough to serve every query and launch without the tape.
+struct CacheMeta {
+    std::string key;
+    long long n = 0, p = 0, m = 0, enabled = 0;
+    std::vector<int32_t> jacRows, jacCols, hesRows, hesCols;
+    struct Unit {
+        std::string tag, kernel;
+        long long objectSize = 0, statements = 0;
+    };
+    std::vector<Unit> units;
+
+    std::string Serialise() const {
+        std::ostringstream os;
+        os << kCacheFormat << "\nkey " << key << "\ndims " << n << ' ' << p << ' ' << m << ' ' << enabled << "\n";
+        auto pattern = [&](const char* tag, const std::vector<int32_t>& r, const std::vector<int32_t>& c) {
+            os << tag << ' ' << r.size();
+            for (std::size_t k = 0; k < r.size(); ++k) os << ' ' << r[k] << ' ' << c[k];
+            os << "\n";
+        };
+        pattern("jac", jacRows, jacCols);
+        pattern("hes", hesRows, hesCols);
+        os << "units " << units.size() << "\n";
+        for (const Unit& u : units) os << "unit " << u.tag << ' ' << u.kernel << ' ' << u.objectSize << ' ' << u.statements << "\n";
+        const std::string body = os.str();
+        char sum[24];
+        std::snprintf(sum, sizeof sum, "%016llx", static_cast<unsigned long long>(Fnv1a(body.data(), body.size(), 1469598103934665603ULL)));
+        return body + "end " + sum + "\n";
+    }
+
+    /// Parses and validates (format line, key, trailing checksum); false = treat the entry as absent.
+    bool Parse(const std::string& text, const std::string& expectKey) {
+        const std::size_t endPos = text.rfind("end ");
+        if (endPos == std::string::npos) return false;
+        const std::string body = text.substr(0, endPos);
+        char sum[24];
+        std::snprintf(sum, sizeof sum, "%016llx", static_cast<unsigned long long>(Fnv1a(body.data(), body.size(), 1469598103934665603ULL)));
+        if (text.compare(endPos + 4, 16, sum) != 0) return false;
+        std::istringstream is(body);
+        std::string word;
+        if (!std::getline(is, word) || word != kCacheFormat) return false;
+        if (!(is >> word >> key) || word != "key" || key != expectKey) return false;
+        if (!(is >> word >> n >> p >> m >> enabled) || word != "dims") return false;
+        auto pattern = [&](const char* tag, std::vector<int32_t>& r, std::vector<int32_t>& c) {
+            std::size_t nnz = 0;
+            if (!(is >> word >> nnz) || word != tag) return false;
+            r.resize(nnz);
+            c.resize(nnz);
+            for (std::size_t k = 0; k < nnz; ++k)
+                if (!(is >> r[k] >> c[k])) return false;
+            return true;
+        };
+        if (!pattern("jac", jacRows, jacCols) || !pattern("hes", hesRows, hesCols)) return false;
+        std::size_t count = 0;
+        if (!(is >> word >> count) || word != "units" || count > 3) return false;
+        units.resize(count);
+        for (Unit& u : units)
+            if (!(is >> word >> u.tag >> u.kernel >> u.objectSize >> u.statements) || word != "unit") return false;
+        return true;
+    }
+};
 
 bool MakeDirs(const std::string& path) {
     std::string cur;
@@ -158,126 +270,219 @@ int ungar_function_make(const ungar_tape_node* nodes, int64_t num_nodes, const i
     if ((enabled_derivatives & kEnableHessian) && m != 1)
         return Fail(UNGAR_E_UNSUPPORTED, "The Hessian is implemented only for scalar functions.");  // function.hpp:136-137
 
-    // ---- derivatives (parameters trimmed: columns [0, n) only; function.hpp:529-574) -------------
+    // names become file names and travel through the hipcc driver script, which re-expands $, ` and " in its arguments
+    for (const char* text : {name, folder ? folder : ""})
+        for (const char* c = text; *c; ++c)
+            if (*c == '$' || *c == '`' || *c == '"' || *c == '\\' || *c == '\n' || (text == name && (*c == '/' || *c == '\'')))
+                return Fail(UNGAR_E_INVALID, std::string("ungar_function_make: unsupported character '") + *c + "' in the function name or code-generation folder");
+
+    // ---- cache key: the optimised tape and everything that decides what is generated from it --------------------
+    const char* custom = std::getenv("UNGAR_AMD_JIT_FLAGS");
+    KeyHasher key;
+    key.Str(kCacheFormat);
+    key.Str(UNGAR_AMD_EMITTER_ID);
+    key.Str(kArch);
+    {
+        int rocm = 0;
+        (void)hipRuntimeGetVersion(&rocm);  // ROCm / HIP runtime the code objects are built for
+        key.Int(rocm);
+    }
+    key.Str(custom ? custom : "");
+    key.Int(n);
+    key.Int(p);
+    key.Int(m);
+    key.Int(enabled_derivatives);
+    key.Int(static_cast<long long>(g.Size()));
+    for (const tape::Node& nd : g.Nodes()) {
+        const std::int32_t head[5] = {static_cast<std::int32_t>(nd.op), nd.a, nd.b, nd.c, nd.d};
+        key.Bytes(head, sizeof head);
+        key.Bytes(&nd.value, sizeof nd.value);
+    }
+    for (tape::Id o : t.outputs) key.Int(o);
+    const std::string keyHex = key.Hex();
+
     auto fn = std::make_unique<ungar_function>();
     fn->name = name;
     fn->n = n;
     fn->p = p;
     fn->m = m;
     fn->enabled = enabled_derivatives;
-    const std::vector<tape::Id> valueIds = t.outputs;
-    tape::SparseEntries jac, hes;
-    tape::Differentiator diff{t};
-    if (enabled_derivatives & kEnableJacobian) {
-        jac = diff.Jacobian(static_cast<int>(n));
-        fn->jacRows.assign(jac.row.begin(), jac.row.end());
-        fn->jacCols.assign(jac.col.begin(), jac.col.end());
-    }
-    if (enabled_derivatives & kEnableHessian) {
-        hes = diff.Hessian(0, static_cast<int>(n));
-        fn->hesRows.assign(hes.row.begin(), hes.row.end());
-        fn->hesCols.assign(hes.col.begin(), hes.col.end());
-    }
-
-    // ---- HIP source: one translation unit per kernel so that the compiler runs on all of them at once ----
-    struct Unit {
-        const char* kernel = nullptr;
-        const char* tag = nullptr;
-        const std::vector<tape::Id>* values = nullptr;
-        hipFunction_t* handle = nullptr;
-        std::string src, object, tmp, log, flags;
-        FILE* pipe = nullptr;
-        std::size_t statements = 0;
-    };
-    std::vector<Unit> units;
-    auto unit = [](const char* kernel, const char* tag, const std::vector<tape::Id>* values, hipFunction_t* handle) {
-        Unit u;
-        u.kernel = kernel;
-        u.tag = tag;
-        u.values = values;
-        u.handle = handle;
-        return u;
-    };
-    units.push_back(unit("ungar_fn_forward_zero", "value", &valueIds, &fn->kValue));
-    if (!jac.value.empty()) units.push_back(unit("ungar_fn_sparse_jacobian", "jacobian", &jac.value, &fn->kJac));
-    if (!hes.value.empty()) units.push_back(unit("ungar_fn_sparse_hessian", "hessian", &hes.value, &fn->kHes));
-    // Compile flags.  The machine instruction schedulers (pre- and post-RA) account for > 95 % of the compile
-    // time of a large straight-line kernel (a whole-horizon constraint Jacobian of 23 k statements: 64 s -> 6 s
-    // without them) and the emitter already orders statements depth-first, so they are switched off above
-    // kBigKernel statements; node-sized functions -- the ones evaluated in large batches -- keep the full
-    // pipeline.  UNGAR_AMD_JIT_FLAGS replaces the optimisation flags altogether.
-    constexpr std::size_t kBigKernel = 3000;
-    const char* custom = std::getenv("UNGAR_AMD_JIT_FLAGS");
-    std::uint64_t hash = 1469598103934665603ULL;
-    for (Unit& u : units) {
-        u.src = "// generated by ungar_amd (runtime/function.cpp) for function '" + fn->name + "'\n#include <hip/hip_runtime.h>\n\n" +
-                EmitKernel(u.kernel, g, n + p, *u.values, &u.statements);
-        u.flags = std::string("--offload-arch=gfx950 -std=c++17 ") +
-                  (custom ? custom : u.statements > kBigKernel ? "-O3 -mllvm -enable-misched=false -mllvm -enable-post-misched=false" : "-O3");
-        hash = Fnv1a(u.flags, Fnv1a(u.src, hash));
-    }
-    char hashHex[32];
-    std::snprintf(hashHex, sizeof hashHex, "%016llx", static_cast<unsigned long long>(hash));
     const bool verbose = std::getenv("UNGAR_AMD_VERBOSE") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
 
-    // ---- compile or reuse (layout mirrors <folder>/<name>/cppad_cg/<name>_lib.so, function.hpp:433-435)
+    // ---- cache entry (layout mirrors <folder>/<name>/cppad_cg/<name>_lib.so, function.hpp:433-435) ------------------
+    //   <dir>/<name>_<key>.meta           sparsity patterns + kernel table, written LAST (commit marker)
+    //   <dir>/<name>_<key>_<tag>.hsaco    one code object per kernel (value / jacobian / hessian)
     const std::string dir = std::string(folder && *folder ? folder : DefaultFolder()) + "/" + fn->name + "/ungar_amd";
-    const std::string base = dir + "/" + fn->name + "_" + hashHex;
+    const std::string base = dir + "/" + fn->name + "_" + keyHex;
+    const std::string metaPath = base + ".meta";
     fn->codeObjectPath = base + "_value.hsaco";
-    bool have = true;
-    for (Unit& u : units) {
-        u.object = base + "_" + u.tag + ".hsaco";
-        struct stat st {};
-        have = have && stat(u.object.c_str(), &st) == 0 && st.st_size > 0;
-    }
-    if (!have || recompile) {
-        if (!MakeDirs(dir)) return Fail(UNGAR_E_IO, "cannot create code-generation folder '" + dir + "'");
-        const char* hipcc = std::getenv("UNGAR_HIPCC");
-        for (Unit& u : units) {
-            const std::string hip = base + "_" + u.tag + ".hip";
-            {
-                std::ofstream f(hip);
-                f << u.src;
-                if (!f) return Fail(UNGAR_E_IO, "cannot write '" + hip + "'");
+    CacheMeta meta;
+    bool hit = false;
+    if (!recompile) {
+        std::ifstream in(metaPath);
+        if (in) {
+            std::stringstream ss;
+            ss << in.rdbuf();
+            hit = meta.Parse(ss.str(), keyHex) && meta.n == n && meta.p == p && meta.m == m && meta.enabled == static_cast<long long>(enabled_derivatives) &&
+                  !meta.units.empty();
+            for (std::size_t k = 0; hit && k < meta.units.size(); ++k) {
+                long long size = 0;
+                hit = FileSize(base + "_" + meta.units[k].tag + ".hsaco", &size) && size == meta.units[k].objectSize && size > 0;
             }
-            // temp name + rename = atomic publish (function.hpp:485-487, 501-502)
-            u.tmp = u.object + "." + std::to_string(getpid()) + ".tmp";
-            const std::string cmd = std::string(hipcc ? hipcc : "hipcc") + " " + u.flags + " --genco -o '" + u.tmp + "' '" + hip + "' 2>&1";
+        }
+    }
+
+    if (!hit) {
+        // ---- derivatives (parameters trimmed: columns [0, n) only; function.hpp:529-574) -------------
+        meta = CacheMeta{};
+        meta.key = keyHex;
+        meta.n = n;
+        meta.p = p;
+        meta.m = m;
+        meta.enabled = enabled_derivatives;
+        const std::vector<tape::Id> valueIds = t.outputs;
+        tape::SparseEntries jac, hes;
+        tape::Differentiator diff{t};
+        if (enabled_derivatives & kEnableJacobian) {
+            jac = diff.Jacobian(static_cast<int>(n));
+            meta.jacRows.assign(jac.row.begin(), jac.row.end());
+            meta.jacCols.assign(jac.col.begin(), jac.col.end());
+        }
+        if (enabled_derivatives & kEnableHessian) {
+            hes = diff.Hessian(0, static_cast<int>(n));
+            meta.hesRows.assign(hes.row.begin(), hes.row.end());
+            meta.hesCols.assign(hes.col.begin(), hes.col.end());
+        }
+
+        // ---- HIP source: one translation unit per kernel so that the compiler runs on all of them at once ----
+        struct Unit {
+            const char* kernel = nullptr;
+            const char* tag = nullptr;
+            const std::vector<tape::Id>* values = nullptr;
+            std::string source, object, tmpObject, log, flags;
+            FILE* pipe = nullptr;
+            std::size_t statements = 0;
+        };
+        std::vector<Unit> units;
+        auto unit = [](const char* kernel, const char* tag, const std::vector<tape::Id>* values) {
+            Unit u;
+            u.kernel = kernel;
+            u.tag = tag;
+            u.values = values;
+            return u;
+        };
+        units.push_back(unit("ungar_fn_forward_zero", "value", &valueIds));
+        if (!jac.value.empty()) units.push_back(unit("ungar_fn_sparse_jacobian", "jacobian", &jac.value));
+        if (!hes.value.empty()) units.push_back(unit("ungar_fn_sparse_hessian", "hessian", &hes.value));
+        if (!MakeDirs(dir)) return Fail(UNGAR_E_IO, "cannot create code-generation folder '" + dir + "'");
+        // Compile flags.  The machine instruction schedulers (pre- and post-RA) account for > 95 % of the compile
+        // time of a large straight-line kernel (a whole-horizon constraint Jacobian of 23 k statements: 64 s -> 6 s
+        // without them) and the emitter already orders statements depth-first, so they are switched off above
+        // kBigKernel statements; node-sized functions -- the ones evaluated in large batches -- keep the full
+        // pipeline.  UNGAR_AMD_JIT_FLAGS replaces the optimisation flags altogether.
+        const char* hipcc = std::getenv("UNGAR_HIPCC");
+        const std::string unique = "." + std::to_string(getpid()) + "." + std::to_string(reinterpret_cast<std::uintptr_t>(fn.get()) & 0xFFFFFF) + ".tmp";
+        auto cleanup = [&units] {  // every error path: reap the compilers that were started, remove what they wrote
+            for (Unit& u : units) {
+                if (u.pipe) {
+                    char buf[512];
+                    while (fgets(buf, sizeof buf, u.pipe)) {
+                    }
+                    (void)pclose(u.pipe);
+                    u.pipe = nullptr;
+                }
+                if (!u.source.empty()) (void)std::remove(u.source.c_str());
+                if (!u.tmpObject.empty()) (void)std::remove(u.tmpObject.c_str());
+            }
+        };
+        for (Unit& u : units) {
+            const std::string src = "// generated by ungar_amd (runtime/function.cpp) for function '" + fn->name + "'\n#include <hip/hip_runtime.h>\n\n" +
+                                    EmitKernel(u.kernel, g, n + p, *u.values, &u.statements);
+            u.flags = std::string("--offload-arch=") + kArch + " -std=c++17 " +
+                      (custom ? custom : u.statements > kBigKernel ? "-O3 -mllvm -enable-misched=false -mllvm -enable-post-misched=false" : "-O3");
+            u.object = base + "_" + u.tag + ".hsaco";
+            // process-unique names for BOTH the source and the object: ranks that build the same function at start-up
+            // never read or truncate each other's files; the rename below is the atomic publish (function.hpp:485-487, 501-502)
+            u.source = base + "_" + u.tag + unique + ".hip";
+            u.tmpObject = u.object + unique;
+            {
+                std::ofstream f(u.source);
+                f << src;
+                if (!f) {
+                    cleanup();
+                    return Fail(UNGAR_E_IO, "cannot write '" + u.source + "'");
+                }
+            }
+            const std::string cmd = std::string(hipcc ? hipcc : "hipcc") + " " + u.flags + " --genco -o " + ShellQuote(u.tmpObject) + " " + ShellQuote(u.source) + " 2>&1";
             u.pipe = popen(cmd.c_str(), "r");  // all compilers start now and run concurrently
-            if (!u.pipe) return Fail(UNGAR_E_COMPILE, "cannot start hipcc for function '" + fn->name + "'");
+            if (!u.pipe) {
+                cleanup();
+                return Fail(UNGAR_E_COMPILE, "cannot start hipcc for function '" + fn->name + "'");
+            }
         }
         std::string failure;
         for (Unit& u : units) {
             char buf[512];
             while (fgets(buf, sizeof buf, u.pipe)) u.log += buf;
             const int st = pclose(u.pipe);
+            u.pipe = nullptr;
             const int rc = WIFEXITED(st) ? WEXITSTATUS(st) : -1;
             if (rc != 0) failure += "hipcc failed (" + std::to_string(rc) + ") for the " + u.tag + " kernel of function '" + fn->name + "':\n" + u.log;
         }
-        if (!failure.empty()) return Fail(UNGAR_E_COMPILE, failure);
-        for (Unit& u : units)
-            if (std::rename(u.tmp.c_str(), u.object.c_str()) != 0) return Fail(UNGAR_E_IO, "cannot publish '" + u.object + "'");
-    } else {
-        fn->cacheHit = true;
+        if (!failure.empty()) {
+            cleanup();
+            return Fail(UNGAR_E_COMPILE, failure);
+        }
+        const bool keepSource = std::getenv("UNGAR_AMD_KEEP_SOURCE") != nullptr;
+        for (Unit& u : units) {
+            long long size = 0;
+            if (!FileSize(u.tmpObject, &size) || size <= 0 || std::rename(u.tmpObject.c_str(), u.object.c_str()) != 0) {
+                cleanup();
+                return Fail(UNGAR_E_IO, "cannot publish '" + u.object + "'");
+            }
+            u.tmpObject.clear();
+            if (keepSource) (void)std::rename(u.source.c_str(), (base + "_" + u.tag + ".hip").c_str());
+            else (void)std::remove(u.source.c_str());
+            u.source.clear();
+            meta.units.push_back({u.tag, u.kernel, size, static_cast<long long>(u.statements)});
+        }
+        {  // the meta file commits the entry: temp + rename, after every code object is in place
+            const std::string tmpMeta = metaPath + unique;
+            std::ofstream f(tmpMeta);
+            f << meta.Serialise();
+            f.close();
+            if (!f || std::rename(tmpMeta.c_str(), metaPath.c_str()) != 0) {
+                (void)std::remove(tmpMeta.c_str());
+                return Fail(UNGAR_E_IO, "cannot publish '" + metaPath + "'");
+            }
+        }
     }
+    fn->cacheHit = hit;
+    fn->jacRows = meta.jacRows;
+    fn->jacCols = meta.jacCols;
+    fn->hesRows = meta.hesRows;
+    fn->hesCols = meta.hesCols;
     if (verbose)
-        std::fprintf(stderr, "[ungar_amd] function '%s': %lld tape nodes, n=%lld p=%lld m=%lld, jac nnz %zu, hes nnz %zu, %s in %.1f s\n", fn->name.c_str(),
-                     static_cast<long long>(num_nodes), static_cast<long long>(n), static_cast<long long>(p), static_cast<long long>(m), jac.value.size(),
-                     hes.value.size(), fn->cacheHit ? "code objects reused" : "compiled",
-                     std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+        std::fprintf(stderr, "[ungar_amd] function '%s': %lld tape nodes, n=%lld p=%lld m=%lld, jac nnz %zu, hes nnz %zu, %s in %.2f s (key %s)\n",
+                     fn->name.c_str(), static_cast<long long>(num_nodes), static_cast<long long>(n), static_cast<long long>(p), static_cast<long long>(m),
+                     fn->jacRows.size(), fn->hesRows.size(), hit ? "cache hit: derive / emit / compile skipped" : "derived, emitted and compiled",
+                     std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), keyHex.c_str());
 
     // ---- load ---------------------------------------------------------------------------------------
-    // UNGAR_AMD_COMPILE_ONLY: stop after publishing the code objects (cache warm-up on a machine without a
+    // UNGAR_AMD_COMPILE_ONLY: stop after publishing the cache entry (cache warm-up on a machine without a
     // GPU, e.g. a build host); the returned function reports its sparsity but every evaluation fails.
     if (std::getenv("UNGAR_AMD_COMPILE_ONLY")) {
         *out = fn.release();
         return UNGAR_OK;
     }
-    for (std::size_t k = 0; k < units.size(); ++k) {
-        hipError_t e = hipModuleLoad(&fn->modules[k], units[k].object.c_str());
-        if (e != hipSuccess) return Fail(UNGAR_E_HIP, std::string("hipModuleLoad('") + units[k].object + "'): " + hipGetErrorString(e));
-        e = hipModuleGetFunction(units[k].handle, fn->modules[k], units[k].kernel);
+    for (std::size_t k = 0; k < meta.units.size(); ++k) {
+        const CacheMeta::Unit& u = meta.units[k];
+        const std::string object = base + "_" + u.tag + ".hsaco";
+        hipFunction_t* handle = u.tag == "value" ? &fn->kValue : u.tag == "jacobian" ? &fn->kJac : &fn->kHes;
+        hipError_t e = hipModuleLoad(&fn->modules[k], object.c_str());
+        if (e != hipSuccess) return Fail(UNGAR_E_HIP, std::string("hipModuleLoad('") + object + "'): " + hipGetErrorString(e));
+        e = hipModuleGetFunction(handle, fn->modules[k], u.kernel.c_str());
         if (e != hipSuccess) return Fail(UNGAR_E_HIP, std::string("hipModuleGetFunction: ") + hipGetErrorString(e));
     }
     *out = fn.release();
