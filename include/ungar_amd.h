@@ -74,6 +74,7 @@ typedef struct ungar_node_batch {
 
 /* Opens one of the built-in node models: "quadrotor_cost" / "srbd_cost" (scalar stage costs of the quadrotor and
  * quadruped OCPs: value, gradient, upper Hessian), "srbd_ineq" (12 inequality rows per knot of the quadruped OCP and their Jacobian),
+ * "quadrotor_ineq" (8 rotor-speed bound rows per knot of the quadrotor OCP),
  * "quadrotor", "rc_car", "srbd", "anymal" (structured
  * implicit differentiation, phased body with an LDS home), "anymal_reg" (same program, plain
  * straight-line body) or "anymal_ad" (same function, derivatives by taping ABA); and the rigid-body quantities of
@@ -168,6 +169,91 @@ int ungar_model_prepare(const ungar_model* model);
 int ungar_ocp_assemble_equality(const ungar_model* model, int64_t horizon, int64_t batch, const ungar_operand* x, const ungar_operand* xm,
                                 const ungar_operand* f, const ungar_operand* jac, const ungar_operand* g, const ungar_operand* values,
                                 void* stream);
+
+/* ---- batched SQP iteration for shooting problems ---------------------------------
+ * Device counterparts of the pieces of SoftSQPOptimizer::Optimize (include/ungar/optimization/soft_sqp.hpp:62-112) for
+ * problems with stage-wise cost / soft inequalities and the dynamics constraint g = [x_0 - x_m; x_{k+1} - f(x_k, u_k)]:
+ * thousands of independent MPC instances per launch, one 64-lane workgroup per instance, everything stream-ordered.
+ * Node operands use (instance_stride, knot_stride, element_stride); per-instance operands ignore knot_stride. */
+
+/* Relaxed barrier of the soft inequality constraints h <= 0, applied to z = -h
+ * (soft_inequality_constraint.hpp:77-205; soft_sqp.hpp:105-130). */
+#define UNGAR_BARRIER_POLY 0
+#define UNGAR_BARRIER_LOG 1
+typedef struct ungar_barrier {
+    int32_t type;
+    int32_t reserved;
+    double stiffness, epsilon;
+} ungar_barrier;
+
+/* Stage data of the QP subproblem from the node kernels' outputs (soft_sqp.hpp:143-155, 247-264 per knot):
+ *   b_k = f_k - x_{k+1},   dx0 = x_m - x_0,
+ *   hess_k = hess cost_k + J_h^T diag(b''(-h)) J_h   (dense (nx+nu)^2 row-major, upper triangle filled, rest zero),
+ *   grad_k = grad cost_k - J_h^T b'(-h). */
+typedef struct ungar_ocp_stage_qp_args {
+    int64_t nx, nu, horizon, batch;
+    ungar_operand X, xm, f;        /* states k = 0..N; measured state; node values k < N (ungar_model_dense_jacobian's f) */
+    ungar_operand cost_grad;       /* dense 1 x (nx+nu) per node (jac operand of ungar_model_sparse_hessian) */
+    ungar_operand cost_hes;        /* hes_nnz values per node in the order of ungar_model_hessian_sparsity */
+    const int32_t* hes_rows;       /* HOST arrays of that pattern (hes_nnz <= 160, rows <= cols < 256) */
+    const int32_t* hes_cols;
+    int64_t hes_nnz;
+    int64_t nh;                    /* inequality rows per knot (<= 64), 0: none */
+    ungar_operand h, h_jac;        /* values and dense nh x (nx+nu) Jacobian per node (ungar_model_dense_jacobian of an inequality node) */
+    ungar_barrier barrier;
+    ungar_operand b, hess, grad, dx0; /* outputs */
+} ungar_ocp_stage_qp_args;
+int ungar_ocp_stage_qp(const ungar_ocp_stage_qp_args* args, void* stream);
+
+/* Solves  min sum_k 1/2 [dx;du]^T hess_k [dx;du] + grad_k^T [dx;du] + terminal   s.t.  dx_0 = dx0,
+ * dx_{k+1} = A_k dx_k + B_k du_k + b_k   for every instance by the discrete Riccati recursion (exact solution of the KKT
+ * system the reference hands to OSQP, soft_sqp.hpp:143-158).  `regularization` is added to the diagonal of every stage
+ * Hessian and of the terminal one (the reference's 1e-6 I, :149-151).  workspace: ungar_ocp_riccati_workspace() doubles
+ * of device memory.  status (device, may be null): 0, or k+1 if the reduced input Hessian of knot k was not positive definite. */
+typedef struct ungar_ocp_qp {
+    int64_t nx, nu, horizon, batch;
+    ungar_operand jac;             /* dense nx x (nx+nu) [A|B] per node */
+    ungar_operand b, hess, grad;   /* per node: nx, (nx+nu)^2 (upper triangle read), nx+nu */
+    ungar_operand hess_terminal, grad_terminal; /* per instance: nx^2 (upper triangle read), nx; bases may be null */
+    ungar_operand dx0;             /* per instance */
+    ungar_operand dX, dU;          /* outputs: dx_k (k = 0..N), du_k (k < N) */
+    double* workspace;
+    int64_t workspace_doubles;
+    double regularization;
+    int32_t* status;
+} ungar_ocp_qp;
+int64_t ungar_ocp_riccati_workspace(int64_t nx, int64_t nu, int64_t horizon, int64_t batch);
+int ungar_ocp_riccati_solve(const ungar_ocp_qp* qp, void* stream);
+
+/* Merit terms of the line search per instance (soft_sqp.hpp:68-87): theta = multiplier * |g|_2, phi = sum of the stage
+ * costs (+ terminal) + sum of the barrier over the inequality values; and, when cost_grad and dX are given, the slope
+ * grad(objective) . step used by the Armijo branch (backtracking_line_search.hpp:99-101). */
+typedef struct ungar_ocp_merit_args {
+    int64_t nx, nu, horizon, batch, nh;
+    ungar_operand X, xm, f;        /* states, measured state, node values at (X, U) */
+    ungar_operand cost;            /* 1 value per node; base may be null */
+    ungar_operand cost_terminal;   /* 1 value per instance; base may be null */
+    ungar_operand h;               /* nh values per node; base may be null */
+    ungar_barrier barrier;
+    double violation_multiplier;
+    ungar_operand cost_grad, cost_grad_terminal, dX, dU; /* optional: slope */
+    double *theta, *phi, *slope;   /* device, one per instance (slope may be null) */
+} ungar_ocp_merit_args;
+int ungar_ocp_merit(const ungar_ocp_merit_args* args, void* stream);
+
+/* Xt = X + alpha dX,  Ut = U + alpha dU for every instance. */
+int ungar_ocp_trial_point(int64_t nx, int64_t nu, int64_t horizon, int64_t batch, const ungar_operand* X, const ungar_operand* U, const ungar_operand* dX,
+                          const ungar_operand* dU, double alpha, const ungar_operand* Xt, const ungar_operand* Ut, void* stream);
+
+/* One candidate step size of BacktrackingLineSearch::Do (backtracking_line_search.hpp:116-151) for every instance that has
+ * not accepted a larger one: the three-way test on (theta, phi) -> (theta_trial, phi_trial); accepting instances copy the
+ * trial point into (X, U) and record alpha in accepted[instance] (0 = still searching). */
+typedef struct ungar_line_search_parameters {
+    double alpha_min, theta_min, theta_max, eta, gamma_phi, gamma_theta, gamma_alpha; /* reference defaults: 1e-4 1e-6 1e-2 1e-4 1e-6 1e-6 0.5 */
+} ungar_line_search_parameters;
+int ungar_ocp_line_search_accept(int64_t nx, int64_t nu, int64_t horizon, int64_t batch, const ungar_line_search_parameters* parameters, double alpha,
+                                 const double* theta0, const double* phi0, const double* slope, const double* theta_trial, const double* phi_trial,
+                                 double* accepted, const ungar_operand* X, const ungar_operand* U, const ungar_operand* Xt, const ungar_operand* Ut, void* stream);
 
 /* ---- run-time function factory (any recorded function, not only the built-in node models) ----- */
 

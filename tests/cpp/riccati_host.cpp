@@ -1,0 +1,40 @@
+// TEST INFRASTRUCTURE: runs the batched Riccati recursion of ungar_amd/csrc/kernels/ocp_riccati.hpp -- the very source the
+// gfx950 kernel executes -- with a sequential host execution policy, so that the algorithm can be pinned against a dense KKT
+// solve without a GPU (tests/test_ocp_sqp.py).  Not part of the product: libungar_amd.so has no host path.
+#include <vector>
+
+#include "../../ungar_amd/csrc/kernels/ocp_riccati.hpp"
+
+using namespace ungar_amd::kernels;
+
+namespace {
+struct HostExec {
+    template <class F>
+    void ForEach(int n, F f) {
+        for (int i = 0; i < n; ++i) f(i);
+    }
+};
+}  // namespace
+
+/// Node-major contiguous arrays: jac [batch][N][nx*(nx+nu)], b [batch][N][nx], hess [batch][N][n*n], grad [batch][N][n],
+/// hessN [batch][nx*nx] (or null), gradN [batch][nx] (or null), dx0 [batch][nx]; outputs dX [batch][N+1][nx], dU [batch][N][nu].
+extern "C" int riccati_host_solve(int nx, int nu, int N, long long batch, double* jac, double* b, double* hess, double* grad, double* hessN, double* gradN,
+                                  double* dx0, double regularization, double* dX, double* dU, int* status) {
+    const int n = nx + nu;
+    std::vector<double> gains(static_cast<std::size_t>(batch) * N * nu * (nx + 1));
+    RiccatiArgs a{nx, nu, N, batch,
+                  {jac, static_cast<long long>(N) * nx * n, static_cast<long long>(nx) * n, 1},
+                  {b, static_cast<long long>(N) * nx, nx, 1},
+                  {hess, static_cast<long long>(N) * n * n, static_cast<long long>(n) * n, 1},
+                  {grad, static_cast<long long>(N) * n, n, 1},
+                  {hessN, static_cast<long long>(nx) * nx, 0, 1},
+                  {gradN, nx, 0, 1},
+                  {dx0, nx, 0, 1},
+                  {dX, static_cast<long long>(N + 1) * nx, nx, 1},
+                  {dU, static_cast<long long>(N) * nu, nu, 1},
+                  gains.data(), regularization, status};
+    std::vector<double> scratch(static_cast<std::size_t>(RiccatiScratchDoubles(nx, nu)));
+    HostExec ex;
+    for (long long i = 0; i < batch; ++i) RiccatiInstance(a, i, scratch.data(), ex);
+    return 0;
+}

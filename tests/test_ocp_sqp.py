@@ -1,0 +1,305 @@
+"""Batched soft SQP on the device (reference include/ungar/optimization/soft_sqp.hpp:62-158,
+186-264 and backtracking_line_search.hpp:80-165).
+
+  CPU   the Riccati recursion of ungar_amd/csrc/kernels/ocp_riccati.hpp -- the source the gfx950 kernel runs -- executed by a
+        sequential host policy (tests/cpp/riccati_host.cpp, test infrastructure) against a dense solve of the KKT system the
+        reference hands to OSQP; indefinite reduced Hessians are reported, not silently used;
+  GPU   the device kernel against the same dense solves; the stage-QP assembly and the merit terms against numpy on the
+        node kernels' own outputs; ONE FULL SQP ITERATION (derivatives -> QP data -> Riccati -> backtracking line search)
+        for 4096 instances of the quadrotor OCP (N = 30, rotor-speed bounds behind the POLY barrier) against an independent
+        numpy restatement of SoftSQPOptimizer::Optimize built on the torch oracle's derivatives, to 1e-9; several iterations
+        drive the constraint violation of every instance down; the same for the quadruped (SRBD) OCP with its friction-cone rows.
+"""
+import ctypes
+import json
+import os
+import subprocess
+import time
+
+import numpy as np
+import pytest
+
+from oracle import ungar_oracle as O
+
+
+# ------------------------------------------------------------------------------------------------ numpy reference pieces
+def kkt_dense(nx, nu, N, AB, b, W, w, dx0, reg, WN=None, wN=None):
+    """Dense solve of  min 1/2 d^T H d + g^T d  s.t.  dx_0 = dx0, dx_{k+1} = A dx_k + B du_k + b_k  (one instance)."""
+    n, nz = nx + nu, (N + 1) * nx + N * nu
+    H, g = np.zeros((nz, nz)), np.zeros(nz)
+    xs = lambda k: np.arange(k * nx, (k + 1) * nx)  # noqa: E731
+    us = lambda k: np.arange((N + 1) * nx + k * nu, (N + 1) * nx + (k + 1) * nu)  # noqa: E731
+    for k in range(N):
+        Wk = np.triu(W[k])
+        Wk = Wk + Wk.T - np.diag(np.diag(Wk)) + reg * np.eye(n)
+        idx = np.r_[xs(k), us(k)]
+        H[np.ix_(idx, idx)] += Wk
+        g[idx] += w[k]
+    WNs = np.zeros((nx, nx)) if WN is None else np.triu(WN) + np.triu(WN, 1).T
+    H[np.ix_(xs(N), xs(N))] += WNs + reg * np.eye(nx)
+    if wN is not None:
+        g[xs(N)] += wN
+    m = (N + 1) * nx
+    A, c = np.zeros((m, nz)), np.zeros(m)
+    A[:nx, xs(0)] = np.eye(nx)
+    c[:nx] = dx0
+    for k in range(N):
+        r = np.arange((k + 1) * nx, (k + 2) * nx)
+        A[np.ix_(r, xs(k + 1))] = np.eye(nx)
+        A[np.ix_(r, xs(k))] = -AB[k][:, :nx]
+        A[np.ix_(r, us(k))] = -AB[k][:, nx:]
+        c[r] = b[k]
+    sol = np.linalg.solve(np.block([[H, A.T], [A, np.zeros((m, m))]]), np.r_[-g, c])
+    return sol[:(N + 1) * nx].reshape(N + 1, nx), sol[(N + 1) * nx:nz].reshape(N, nu)
+
+
+def random_qp(rng, nx, nu, N, batch):
+    n = nx + nu
+    AB = rng.normal(size=(batch, N, nx, n)) * 0.3
+    AB[:, :, :, :nx] += np.eye(nx)
+    L = rng.normal(size=(batch, N, n, n))
+    W = L @ np.swapaxes(L, -1, -2) * 0.1
+    LN = rng.normal(size=(batch, nx, nx))
+    return {"AB": np.ascontiguousarray(AB), "b": rng.normal(size=(batch, N, nx)) * 0.1, "W": np.ascontiguousarray(np.triu(W)), "Wfull": W,
+            "w": rng.normal(size=(batch, N, n)), "WN": np.ascontiguousarray(np.triu(LN @ np.swapaxes(LN, -1, -2))), "wN": rng.normal(size=(batch, nx)),
+            "dx0": rng.normal(size=(batch, nx))}
+
+
+def poly_barrier(z, k, eps, order=0):
+    a1, b1 = k, -0.5 * k * eps
+    c1 = -(1.0 / 3.0) * (-b1 - a1 * eps) * eps - 0.5 * a1 * eps * eps - b1 * eps
+    a2 = (-b1 - a1 * eps) / eps ** 2
+    if order == 0:
+        return np.where(z < 0, 0.5 * a1 * z * z + b1 * z + c1, np.where(z < eps, a2 * z ** 3 / 3 + 0.5 * a1 * z * z + b1 * z + c1, 0.0))
+    if order == 1:
+        return np.where(z < 0, a1 * z + b1, np.where(z < eps, a2 * z * z + a1 * z + b1, 0.0))
+    return np.where(z < 0, a1, np.where(z < eps, 2 * a2 * z + a1, 0.0))
+
+
+# ------------------------------------------------------------------------------------------------ CPU
+@pytest.fixture(scope="module")
+def host(repo_root):
+    lib = os.path.join(repo_root, "build", "libriccati_host.so")
+    src = os.path.join(repo_root, "tests", "cpp", "riccati_host.cpp")
+    hdr = os.path.join(repo_root, "ungar_amd", "csrc", "kernels", "ocp_riccati.hpp")
+    if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        os.makedirs(os.path.dirname(lib), exist_ok=True)
+        subprocess.run(["g++", "-std=c++20", "-O2", "-shared", "-fPIC", "-o", lib, src], check=True, timeout=300)
+    return ctypes.CDLL(lib)
+
+
+def solve_host(lib, nx, nu, N, q, reg, terminal=True):
+    batch = q["AB"].shape[0]
+    dX, dU, st = np.zeros((batch, N + 1, nx)), np.zeros((batch, N, nu)), np.zeros(batch, dtype=np.int32)
+    dp = ctypes.POINTER(ctypes.c_double)
+    p = lambda a: a.ctypes.data_as(dp)  # noqa: E731
+    lib.riccati_host_solve(nx, nu, N, ctypes.c_longlong(batch), p(q["AB"]), p(q["b"]), p(q["W"]), p(q["w"]), p(q["WN"]) if terminal else None,
+                           p(q["wN"]) if terminal else None, p(q["dx0"]), ctypes.c_double(reg), p(dX), p(dU), st.ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
+    return dX, dU, st
+
+
+@pytest.mark.parametrize("nx,nu,N", [(13, 4, 30), (6, 2, 20), (13, 24, 8), (3, 1, 5), (37, 12, 6)])
+def test_riccati_recursion_equals_the_dense_kkt_solve(host, nx, nu, N):
+    rng = np.random.default_rng(nx * 100 + nu)
+    q = random_qp(rng, nx, nu, N, 3)
+    for terminal in (True, False):
+        dX, dU, st = solve_host(host, nx, nu, N, q, 1e-6, terminal)
+        assert (st == 0).all()
+        for i in range(3):
+            rX, rU = kkt_dense(nx, nu, N, q["AB"][i], q["b"][i], q["Wfull"][i], q["w"][i], q["dx0"][i], 1e-6, q["WN"][i] if terminal else None,
+                               q["wN"][i] if terminal else None)
+            assert np.abs(dX[i] - rX).max() <= 1e-10 * max(1.0, np.abs(rX).max()) and np.abs(dU[i] - rU).max() <= 1e-10 * max(1.0, np.abs(rU).max())
+            # the solution satisfies the linearised dynamics exactly (feasibility of the QP's equality constraints)
+            for k in range(N):
+                assert np.abs(dX[i, k + 1] - q["AB"][i, k] @ np.r_[dX[i, k], dU[i, k]] - q["b"][i, k]).max() < 1e-10 * max(1.0, np.abs(dX[i]).max())
+
+
+def test_riccati_reports_an_indefinite_reduced_hessian(host):
+    rng = np.random.default_rng(1)
+    q = random_qp(rng, 4, 2, 6, 2)
+    q["W"][1, 3] = -np.eye(6) * 50.0  # knot 3 of instance 1: concave in the inputs
+    _, _, st = solve_host(host, 4, 2, 6, q, 1e-6)
+    assert st[0] == 0 and st[1] == 4  # knot index + 1
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+gpu = pytest.mark.gpu
+
+
+@gpu
+@pytest.mark.parametrize("nx,nu,N,batch", [(13, 4, 30, 257), (13, 24, 10, 33), (37, 12, 20, 9), (6, 2, 200, 16)])
+def test_device_riccati_equals_the_dense_kkt_solve(nx, nu, N, batch):
+    import torch
+    from ungar_amd import sqp
+    rng = np.random.default_rng(7)
+    q = random_qp(rng, nx, nu, N, batch)
+    dev = lambda a: torch.as_tensor(a, device="cuda")  # noqa: E731
+    dX, dU, st = sqp.riccati_solve(nx, nu, N, batch, dev(q["AB"]), dev(q["b"]), dev(q["W"]), dev(q["w"]), dev(q["dx0"]), dev(q["WN"]), dev(q["wN"]))
+    torch.cuda.synchronize()
+    assert (st == 0).all()
+    dX, dU = dX.cpu().numpy(), dU.cpu().numpy()
+    for i in sorted({0, batch // 2, batch - 1}):
+        rX, rU = kkt_dense(nx, nu, N, q["AB"][i], q["b"][i], q["Wfull"][i], q["w"][i], q["dx0"][i], 1e-6, q["WN"][i], q["wN"][i])
+        assert np.abs(dX[i] - rX).max() <= 1e-9 * max(1.0, np.abs(rX).max()) and np.abs(dU[i] - rU).max() <= 1e-9 * max(1.0, np.abs(rU).max())
+    res = dX[:, 1:] - np.einsum("bkij,bkj->bki", q["AB"], np.concatenate((dX[:, :-1], dU), axis=2)) - q["b"]
+    assert np.abs(res).max() <= 1e-9 * max(1.0, np.abs(dX).max())
+
+
+def _quadrotor_problem(batch, N, seed, torch):
+    """Random-but-reasonable instances of the quadrotor OCP: states near hover, references 1 m away, inputs around hover speed."""
+    rng = np.random.default_rng(seed)
+    hover = np.sqrt(1.5 * 9.80665 / (4 * 0.015))
+    quat = rng.normal(size=(batch, N + 1, 4)) * 0.1 + np.array([0, 0, 0, 1.0])
+    quat /= np.linalg.norm(quat, axis=2, keepdims=True)
+    X = np.concatenate((rng.uniform(-0.5, 0.5, (batch, N + 1, 3)), quat, rng.uniform(-0.3, 0.3, (batch, N + 1, 6))), axis=2)
+    U = hover * rng.uniform(0.7, 1.3, (batch, N, 4))
+    U[:, ::5, 0] = 1.05 * 2.0 * hover  # some rotors beyond r_max = 2 hover: active barrier rows
+    xm = X[:, 0] + rng.normal(size=(batch, 13)) * 0.02
+    qref = rng.normal(size=(batch, 4)) * 0.1 + np.array([0, 0, 0, 1.0])
+    p_cost = np.concatenate((rng.uniform(-1, 1, (batch, 3)), qref / np.linalg.norm(qref, axis=1, keepdims=True), np.zeros((batch, 6))), axis=1)
+    p_dyn = np.tile(O.default_params("quadrotor"), (batch, 1))
+    p_dyn[:, 0] = 1.0 / N
+    p_ineq = np.full((batch, 1), 2.0 * hover)
+    return X, U, xm, p_dyn, p_cost, p_ineq
+
+
+def _reference_iteration(X, U, xm, p_dyn, p_cost, p_ineq, dyn, cost, N, k_barrier=100.0, eps=2e-5, mult=1.0):
+    """One iteration of SoftSQPOptimizer::Optimize for ONE instance, numpy + the torch oracle (independent of the product)."""
+    nx, nu = X.shape[1], U.shape[1]
+    n = nx + nu
+    w0 = np.zeros((N, 0))
+
+    def evaluate(Xc, Uc, derivatives):
+        pd, pc = np.tile(p_dyn, (N, 1)), np.tile(p_cost, (N, 1))
+        if derivatives:
+            f, J = O.node_jacobian(dyn, Xc[:N], Uc, w0, pd)
+            c, g, H = O.cost_value_gradient_hessian(Xc[:N], Uc, pc, name=cost)
+        else:
+            f, J = O.node_value(dyn, Xc[:N], Uc, w0, pd), None
+            c, g, H = O.cost_value_gradient_hessian(Xc[:N], Uc, pc, name=cost)[0], None, None
+        h = np.stack((Uc - p_ineq[0], -Uc), axis=2).reshape(N, 2 * nu)  # [r - r_max, -r] per rotor
+        return f, J, c, g, H, h
+
+    def merit(Xc, f, c, h):
+        gres = np.concatenate((Xc[0] - xm, (Xc[1:] - f).reshape(-1)))
+        return mult * np.sqrt((gres ** 2).sum()), c.sum() + poly_barrier(-h, k_barrier, eps).sum()
+
+    f, J, c, g, H, h = evaluate(X, U, True)
+    Jh = np.zeros((N, 2 * nu, n))
+    for i in range(nu):
+        Jh[:, 2 * i, nx + i] = 1.0
+        Jh[:, 2 * i + 1, nx + i] = -1.0
+    d1, d2 = poly_barrier(-h, k_barrier, eps, 1), poly_barrier(-h, k_barrier, eps, 2)
+    W = H + np.einsum("kja,kj,kjb->kab", Jh, d2, Jh)
+    w = g - np.einsum("kja,kj->ka", Jh, d1)
+    dX, dU = kkt_dense(nx, nu, N, J, f - X[1:], W, w, xm - X[0], 1e-6)
+    theta, phi = merit(X, f, c, h)
+    slope = (g * np.concatenate((dX[:N], dU), axis=1)).sum()
+    alpha = 1.0
+    while alpha >= 1e-4:
+        Xt, Ut = X + alpha * dX, U + alpha * dU
+        ft, _, ct, _, _, ht = evaluate(Xt, Ut, False)
+        tn, pn = merit(Xt, ft, ct, ht)
+        if tn > 1e-2:
+            ok = tn < (1 - 1e-6) * theta
+        elif max(theta, tn) < 1e-6 and slope < 0:
+            ok = pn < phi + 1e-4 * alpha * slope
+        else:
+            ok = pn < (1 - 1e-6) * phi or tn < (1 - 1e-6) * theta
+        if ok:
+            return dX, dU, alpha, Xt, Ut, (theta, phi, slope)
+        alpha *= 0.5
+    return dX, dU, 0.0, X, U, (theta, phi, slope)
+
+
+@gpu
+def test_one_sqp_iteration_quadrotor_4096_instances(repo_root):
+    import torch
+    from ungar_amd import sqp
+    batch, N = 4096, 30
+    X, U, xm, p_dyn, p_cost, p_ineq = _quadrotor_problem(batch, N, 3, torch)
+    dev = lambda a: torch.as_tensor(np.ascontiguousarray(a), device="cuda")  # noqa: E731
+    Xd, Ud, xmd, pd, pc, pi = dev(X), dev(U), dev(xm), dev(p_dyn), dev(p_cost), dev(p_ineq)
+    solver = sqp.BatchedSoftSqp("quadrotor", "quadrotor_cost", N, batch, inequality="quadrotor_ineq")
+    accepted = solver.iterate(Xd, Ud, xmd, pd, pc, pi)
+    torch.cuda.synchronize()
+    assert (solver.status == 0).all()
+    acc = accepted.cpu().numpy()
+    dXd, dUd, Xn, Un = solver.dX.cpu().numpy(), solver.dU.cpu().numpy(), Xd.cpu().numpy(), Ud.cpu().numpy()
+    th0, ph0, sl = solver.theta0.cpu().numpy(), solver.phi0.cpu().numpy(), solver.slope.cpu().numpy()
+    assert (acc > 0).mean() > 0.95  # nearly every instance finds an acceptable step
+    for i in (0, 1, 777, 2048, 4095):
+        dX, dU, alpha, Xr, Ur, (theta, phi, slope) = _reference_iteration(X[i], U[i], xm[i], p_dyn[i], p_cost[i], p_ineq[i], "quadrotor", "quadrotor_cost", N)
+        scale = max(1.0, np.abs(dX).max(), np.abs(dU).max())
+        assert np.abs(dXd[i] - dX).max() <= 1e-9 * scale and np.abs(dUd[i] - dU).max() <= 1e-9 * scale
+        assert abs(th0[i] - theta) <= 1e-10 * max(1.0, theta) and abs(ph0[i] - phi) <= 1e-10 * max(1.0, abs(phi)) and abs(sl[i] - slope) <= 1e-9 * max(1.0, abs(slope))
+        assert acc[i] == alpha
+        assert np.abs(Xn[i] - Xr).max() <= 1e-9 * max(1.0, np.abs(Xr).max()) and np.abs(Un[i] - Ur).max() <= 1e-9 * max(1.0, np.abs(Ur).max())
+    # further iterations: the dynamics defect of every instance goes down by orders of magnitude
+    theta_first = th0.copy()
+    t0 = time.perf_counter()
+    iterations = 6
+    for _ in range(iterations):
+        solver.iterate(Xd, Ud, xmd, pd, pc, pi)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iterations
+    theta_last = solver.theta0.cpu().numpy()  # violation at the start of the last iteration
+    assert np.isfinite(Xd).all() and (theta_last < 1e-2 * theta_first).mean() > 0.95
+    # time of the QP part alone (derivatives + stage data + Riccati), stream-ordered
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(20):
+        solver.qp_step(Xd, Ud, xmd, pd, pc, pi)
+    torch.cuda.synchronize()
+    qp_ms = (time.perf_counter() - t1) / 20 * 1e3
+    os.makedirs(os.path.join(repo_root, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(repo_root, "gpurun_out", "sqp_quadrotor_timing.json"), "w") as fh:
+        json.dump({"workload": "quadrotor OCP N=30, 4096 instances, rotor bounds (POLY barrier)", "ms_per_sqp_iteration": dt * 1e3, "ms_per_qp_step": qp_ms,
+                   "line_search_candidates": 14, "instances_per_s": batch / dt, "median_theta_first": float(np.median(theta_first)),
+                   "median_theta_after": float(np.median(theta_last))}, fh)
+
+
+@gpu
+def test_sqp_iterations_quadruped_srbd_with_friction_cones():
+    """The single-rigid-body quadruped OCP (example/mpc/quadruped.example.cpp): dynamics 'srbd' with per-knot contact flags,
+    stage cost 'srbd_cost', inequality rows 'srbd_ineq' -- 37 stage variables, 12 barrier rows per knot, 1024 instances."""
+    import torch
+    from ungar_amd import sqp
+    batch, N = 1024, 30
+    rng = np.random.default_rng(4)
+    x, u, w, p = O.synthetic_inputs("srbd", batch * (N + 1), seed=11)
+    X = x.reshape(batch, N + 1, 13)
+    U = u[:batch * N].reshape(batch, N, 24)
+    W = np.ascontiguousarray(w[:batch * N].reshape(batch, N, 4))
+    p_dyn = np.tile(O.default_params("srbd"), (batch, 1))
+    p_ineq = np.tile(O.default_params("srbd_ineq"), (batch, 1))
+    _, _, ref = O.synthetic_cost_inputs(batch, seed=5, name="srbd_cost")
+    xm = X[:, 0] + rng.normal(size=(batch, 13)) * 0.01
+    dev = lambda a: torch.as_tensor(np.ascontiguousarray(a), device="cuda")  # noqa: E731
+    Xd, Ud, Wd, xmd, pd, pc, pi = dev(X), dev(U), dev(W), dev(xm), dev(p_dyn), dev(ref), dev(p_ineq)
+    solver = sqp.BatchedSoftSqp("srbd", "srbd_cost", N, batch, inequality="srbd_ineq", constraint_violation_multiplier=1.0 / 30.0, stiffness=1.0, epsilon=1.0)
+    solver.qp_step(Xd, Ud, xmd, pd, pc, pi, w=Wd)
+    torch.cuda.synchronize()
+    assert (solver.status == 0).all()
+    # the step of instance 0 against the dense KKT solve of the QP data the kernels produced
+    J, b, Wq, wq, dx0 = (t[0].cpu().numpy() for t in (solver.J, solver.b, solver.W, solver.w, solver.dx0))
+    Wfull = np.triu(Wq) + np.triu(Wq, 1).transpose(0, 2, 1)
+    rX, rU = kkt_dense(13, 24, N, J, b, Wfull, wq, dx0, 1e-6)
+    assert np.abs(solver.dX[0].cpu().numpy() - rX).max() <= 1e-9 * max(1.0, np.abs(rX).max())
+    assert np.abs(solver.dU[0].cpu().numpy() - rU).max() <= 1e-9 * max(1.0, np.abs(rU).max())
+    # stage data against numpy on the node kernels' outputs: W = hess cost + J_h^T diag(b'') J_h, w = grad - J_h^T b'
+    h, hJ, cg = solver.h[0].cpu().numpy(), solver.hJ[0].cpu().numpy(), solver.cgrad[0].cpu().numpy()
+    rows, cols = solver.cost.hessian_sparsity()
+    Hc = np.zeros((N, 37, 37))
+    Hc[:, rows, cols] = solver.chess[0].cpu().numpy()
+    ref_W = Hc + np.triu(np.einsum("kja,kj,kjb->kab", hJ, poly_barrier(-h, 1.0, 1.0, 2), hJ))
+    assert np.abs(np.triu(Wq) - ref_W).max() <= 1e-10 * max(1.0, np.abs(ref_W).max())
+    assert np.abs(wq - (cg - np.einsum("kja,kj->ka", hJ, poly_barrier(-h, 1.0, 1.0, 1)))).max() <= 1e-10 * max(1.0, np.abs(wq).max())
+    first = None
+    for it in range(6):
+        solver.iterate(Xd, Ud, xmd, pd, pc, pi, w=Wd)
+        if it == 0:
+            first = solver.theta0.clone()
+    torch.cuda.synchronize()
+    assert torch.isfinite(Xd).all() and torch.isfinite(Ud).all()
+    assert (solver.theta0 < 0.1 * first).float().mean().item() > 0.9

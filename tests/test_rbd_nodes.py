@@ -44,7 +44,7 @@ def _eval_c(clib, name, x, u):
     xx, uu = np.ascontiguousarray(x), (np.ascontiguousarray(u) if nu else dummy)
     getattr(clib, f"{name}_sparse_jacobian")(ptr(xx), ptr(uu), ptr(dummy), ptr(dummy), ptr(y), ptr(jac))
     getattr(clib, f"{name}_forward_zero")(ptr(xx), ptr(uu), ptr(dummy), ptr(dummy), ptr(y0))
-    assert np.array_equal(y, y0)
+    assert np.abs(y - y0).max() <= 1e-13 * max(1.0, np.abs(y).max())  # two separately compiled bodies (-ffast-math)
     J = np.zeros((ny, nx + nu))
     J[rows, cols] = jac[:nnz]
     return y, J, nnz

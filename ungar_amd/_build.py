@@ -21,7 +21,7 @@ LIBDIR = os.path.join(ROOT, "ungar_amd", "lib")
 LIB = os.path.join(LIBDIR, "libungar_amd.so")
 ORACLE_GEN = os.path.join(ROOT, "oracle", "_gen")
 RBD_MODELS = ("anymal_rnea", "anymal_crba", "anymal_minv", "anymal_feet", "anymal_centroidal")
-MODELS = ("quadrotor", "rc_car", "srbd", "srbd_ineq", "anymal", "anymal_ad", "anymal_reg") + RBD_MODELS
+MODELS = ("quadrotor", "rc_car", "srbd", "srbd_ineq", "quadrotor_ineq", "anymal", "anymal_ad", "anymal_reg") + RBD_MODELS
 C_MODELS = ("quadrotor", "rc_car", "srbd", "anymal", "anymal_ad") + RBD_MODELS
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-Wno-unused-result"]
 
@@ -102,11 +102,15 @@ def build_library(jobs: int | None = None):
     for name in sorted(os.listdir(os.path.join(CSRC, "kernels"))):
         if name.endswith(".hip") and not name.startswith("model_"):
             src = os.path.join(CSRC, "kernels", name)
-            extra = (quad_deps if name.startswith("quad_") else
+            extra = ([os.path.join(CSRC, "kernels", "ocp_sqp.hpp"), os.path.join(CSRC, "kernels", "ocp_riccati.hpp")] if name.startswith("ocp_riccati") else
+                     [os.path.join(CSRC, "kernels", "ocp_assembly.hpp")] if name.startswith("ocp_assembly") else
+                     quad_deps if name.startswith("quad_") else
                      [os.path.join(GEN, f"{name[5:-4]}_cost_gen.hpp"), os.path.join(CSRC, "kernels", "cost_kernel.hpp")] if name.startswith("cost_") else [])
             units.append((src, os.path.join(BUILD, name[:-4] + ".o"), [src, kernel_hdr] + extra))
     src = os.path.join(CSRC, "runtime", "c_api.cpp")
-    units.append((src, os.path.join(BUILD, "c_api.o"), [src, kernel_hdr, abi_hdr]))
+    units.append((src, os.path.join(BUILD, "c_api.o"), [src, kernel_hdr, abi_hdr, os.path.join(CSRC, "kernels", "ocp_assembly.hpp")]))
+    src = os.path.join(CSRC, "runtime", "c_api_sqp.cpp")
+    units.append((src, os.path.join(BUILD, "c_api_sqp.o"), [src, abi_hdr, os.path.join(CSRC, "kernels", "ocp_sqp.hpp"), os.path.join(CSRC, "kernels", "ocp_riccati.hpp")]))
     src = os.path.join(CSRC, "runtime", "function.cpp")
     units.append((src, os.path.join(BUILD, "function.o"), [src, abi_hdr] + _tree(os.path.join(CSRC, "tape"))))
 

@@ -473,6 +473,7 @@ int main(int argc, char** argv) {
     specs.push_back({models::kRcCarDims, [](auto... a) { models::RcCarNode<AD>(a...); }});
     specs.push_back({models::kSrbdDims, [](auto... a) { models::SrbdNode<AD>(a...); }});
     specs.push_back({models::kSrbdIneqDims, [](auto... a) { models::SrbdIneqNode<AD>(a...); }});
+    specs.push_back({models::kQuadrotorIneqDims, [](auto... a) { models::QuadrotorIneqNode<AD>(a...); }});
     rbd::Model anymal;
     if (!robot.empty()) {
         anymal = rbd::BuildModel(rbd::ReadRobotDescription(robot));

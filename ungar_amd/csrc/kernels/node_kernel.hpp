@@ -104,6 +104,30 @@ __device__ __forceinline__ void StoreZeros(double* __restrict__ jb, long long je
     (StoreResult<STREAM>(jb + static_cast<long long>(std::integral_constant<int, ZeroOffset<M>(static_cast<int>(Z))>::value) * je, 0.0), ...);
 }
 
+/// All structural zeros of the pattern in one pass (for blocks with thousands of them, e.g. d M(q) / d q: 5240 of 6156).
+template <class M>
+struct ZeroTable {
+    static constexpr int kCount = M::kJacRows * M::kJacCols - M::kJacNnz;
+    int offset[kCount > 0 ? kCount : 1];
+    constexpr ZeroTable() : offset{} {
+        int z = 0, k = 0;
+        for (int e = 0; e < M::kJacRows * M::kJacCols; ++e) {
+            const int r = e / M::kJacCols, c = e % M::kJacCols;
+            while (k < M::kJacNnz && (M::JacRow(k) < r || (M::JacRow(k) == r && M::JacCol(k) < c))) ++k;
+            if (!(k < M::kJacNnz && M::JacRow(k) == r && M::JacCol(k) == c)) offset[z++] = e;
+        }
+    }
+};
+template <class M>
+__device__ __constant__ const ZeroTable<M> kZeroTable{};
+
+template <class M, bool STREAM>
+__device__ __forceinline__ void StoreZerosFromTable(double* __restrict__ jb, long long je) {
+    for (int z = 0; z < ZeroTable<M>::kCount; ++z) StoreResult<STREAM>(jb + static_cast<long long>(kZeroTable<M>.offset[z]) * je, 0.0);
+}
+
+inline constexpr int kMaxUnrolledZeros = 1024;  // beyond this the fold expression exceeds the compiler's nesting limit
+
 }  // namespace detail
 
 /// One lane per shooting node.
@@ -127,8 +151,12 @@ __global__ __launch_bounds__(BLOCK) void NodeKernel(const NodeLaunch a) {
     if constexpr (MODE == kModeValue) {
         M::Value(io);
     } else {
-        if constexpr (MODE == kModeDenseJacobian)
-            detail::StoreZeros<M, STREAM>(io.jb, io.je, std::make_index_sequence<M::kJacRows * M::kJacCols - M::kJacNnz>{});
+        if constexpr (MODE == kModeDenseJacobian) {
+            if constexpr (M::kJacRows * M::kJacCols - M::kJacNnz <= detail::kMaxUnrolledZeros)
+                detail::StoreZeros<M, STREAM>(io.jb, io.je, std::make_index_sequence<M::kJacRows * M::kJacCols - M::kJacNnz>{});
+            else
+                detail::StoreZerosFromTable<M, STREAM>(io.jb, io.je);
+        }
         M::ValueJacobian(io);
     }
 }

@@ -41,6 +41,8 @@ inline constexpr NodeDims kSrbdCostDims{"srbd_cost", 13, 24, 0, 25};
 /// Scalar stage cost of the quadrotor OCP (one output): p = [p_ref(3), q_ref(4), v_ref(3), omega_ref(3)].
 inline constexpr NodeDims kQuadrotorCostDims{"quadrotor_cost", 13, 4, 0, 13};
 inline constexpr NodeDims kSrbdDims{"srbd", 13, 24, 4, 6};
+/// Inequality rows of one knot of the quadrotor OCP, h(u; p) <= 0: per rotor [r - r_max, -r] (8 outputs); p = [max_rotor_speed].
+inline constexpr NodeDims kQuadrotorIneqDims{"quadrotor_ineq", 13, 4, 0, 1, 8};
 inline constexpr NodeDims kAnymalDims{"anymal", 37, 12, 0, 1};
 
 /// p = parameters[0:20] of the example's `parameters` variable: step_size, mass,
@@ -216,6 +218,16 @@ void SrbdIneqNode(const S* /*x*/, const S* u, const S* w, const S* p, S* h) {
         h[3 * i] = -s * f[2];
         h[3 * i + 1] = s * fxy - mu * f[2];
         h[3 * i + 2] = s * ApproximateNorm(Sub(r, hip)) - legLength;
+    }
+}
+
+/// Inequality constraints of example/mpc/quadrotor.example.cpp:280-288 for one knot: every rotor speed within [0, r_max],
+/// written as the pair  r - r_max <= 0,  -r <= 0  (rotor-minor order); the state does not enter.
+template <class S>
+void QuadrotorIneqNode(const S* /*x*/, const S* u, const S* /*w*/, const S* p, S* h) {
+    for (int i = 0; i < 4; ++i) {
+        h[2 * i] = u[i] - p[0];
+        h[2 * i + 1] = -u[i];
     }
 }
 

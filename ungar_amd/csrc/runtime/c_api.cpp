@@ -32,6 +32,7 @@ UNGAR_AMD_DECLARE_MODEL(anymal_reg)
 UNGAR_AMD_DECLARE_MODEL(quadrotor_cost)
 UNGAR_AMD_DECLARE_MODEL(srbd_cost)
 UNGAR_AMD_DECLARE_MODEL(srbd_ineq)
+UNGAR_AMD_DECLARE_MODEL(quadrotor_ineq)
 UNGAR_AMD_DECLARE_MODEL(anymal_rnea)
 UNGAR_AMD_DECLARE_MODEL(anymal_crba)
 UNGAR_AMD_DECLARE_MODEL(anymal_minv)
@@ -74,6 +75,7 @@ const BuiltinEntry kBuiltins[] = {
     {"anymal_ad", ungar_amd_launch_anymal_ad, ungar_amd_pattern_anymal_ad, ungar_amd_dims_anymal_ad},
     {"anymal_reg", ungar_amd_launch_anymal_reg, ungar_amd_pattern_anymal_reg, ungar_amd_dims_anymal_reg},
     {"srbd_ineq", ungar_amd_launch_srbd_ineq, ungar_amd_pattern_srbd_ineq, ungar_amd_dims_srbd_ineq},
+    {"quadrotor_ineq", ungar_amd_launch_quadrotor_ineq, ungar_amd_pattern_quadrotor_ineq, ungar_amd_dims_quadrotor_ineq},
     {"anymal_rnea", ungar_amd_launch_anymal_rnea, ungar_amd_pattern_anymal_rnea, ungar_amd_dims_anymal_rnea},
     {"anymal_crba", ungar_amd_launch_anymal_crba, ungar_amd_pattern_anymal_crba, ungar_amd_dims_anymal_crba},
     {"anymal_minv", ungar_amd_launch_anymal_minv, ungar_amd_pattern_anymal_minv, ungar_amd_dims_anymal_minv},
@@ -195,7 +197,7 @@ int ungar_model_open(const char* name, ungar_model** out) {
         *out = m;
         return UNGAR_OK;
     }
-    return Fail(UNGAR_E_INVALID, std::string("unknown model '") + name + "' (built-ins: quadrotor, rc_car, srbd, anymal, anymal_ad, anymal_reg, srbd_ineq, quadrotor_cost, srbd_cost, anymal_rnea, anymal_crba, anymal_minv, anymal_feet, anymal_centroidal)");
+    return Fail(UNGAR_E_INVALID, std::string("unknown model '") + name + "' (built-ins: quadrotor, rc_car, srbd, anymal, anymal_ad, anymal_reg, srbd_ineq, quadrotor_ineq, quadrotor_cost, srbd_cost, anymal_rnea, anymal_crba, anymal_minv, anymal_feet, anymal_centroidal)");
 }
 
 void ungar_model_close(ungar_model* model) {
