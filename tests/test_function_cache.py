@@ -82,7 +82,7 @@ def test_miss_publish_hit_and_edit_invalidates(tmp_path):
     first = _make(tmp_path)
     assert not first["hit"] and first["jac"] == [(0, 0), (0, 1), (0, 2)] and first["hes"] == [(0, 0), (1, 1), (2, 2)]
     files = _entry_files(tmp_path)
-    assert len([f for f in files if f.endswith(".meta")]) == 1 and len([f for f in files if f.endswith(".hsaco")]) == 3
+    assert len([f for f in files if f.endswith(".meta")]) == 1 and len([f for f in files if f.endswith(".hsaco")]) == 3 and len([f for f in files if f.endswith(".lock")]) == 1
     assert not [f for f in files if f.endswith(".tmp") or f.endswith(".hip")], files  # nothing half-published, sources removed
     second = _make(tmp_path)
     assert second["hit"] and second["jac"] == first["jac"] and second["hes"] == first["hes"]
@@ -154,6 +154,7 @@ def test_concurrent_builders_of_the_same_function(tmp_path):
     for p in procs:
         p.join(timeout=60)
     assert all(isinstance(r, dict) and r["jac_nnz"] == 3 for r in results), results
+    assert sum(1 for r in results if not r["hit"]) == 1, results  # one builder compiles, the others wait on the entry lock and hit
     files = _entry_files(tmp_path, "cache_race")
     assert not [f for f in files if f.endswith(".tmp") or f.endswith(".hip")], files
     assert _make(tmp_path, scale=3.0, name="cache_race")["hit"]

@@ -13,6 +13,8 @@
 // Kernels map one lane to one problem instance and address operands through strides, so the same
 // code object serves batch = 1 host calls (what Ungar::Autodiff::Function needs) and large batches.
 #include <hip/hip_runtime.h>
+#include <fcntl.h>
+#include <sys/file.h>
 #include <sys/stat.h>
 #include <sys/wait.h>
 #include <unistd.h>
@@ -318,19 +320,37 @@ int ungar_function_make(const ungar_tape_node* nodes, int64_t num_nodes, const i
     const std::string metaPath = base + ".meta";
     fn->codeObjectPath = base + "_value.hsaco";
     CacheMeta meta;
-    bool hit = false;
-    if (!recompile) {
+    auto lookup = [&] {  // a complete, self-consistent entry for this key?
         std::ifstream in(metaPath);
-        if (in) {
-            std::stringstream ss;
-            ss << in.rdbuf();
-            hit = meta.Parse(ss.str(), keyHex) && meta.n == n && meta.p == p && meta.m == m && meta.enabled == static_cast<long long>(enabled_derivatives) &&
+        if (!in) return false;
+        std::stringstream ss;
+        ss << in.rdbuf();
+        bool ok = meta.Parse(ss.str(), keyHex) && meta.n == n && meta.p == p && meta.m == m && meta.enabled == static_cast<long long>(enabled_derivatives) &&
                   !meta.units.empty();
-            for (std::size_t k = 0; hit && k < meta.units.size(); ++k) {
-                long long size = 0;
-                hit = FileSize(base + "_" + meta.units[k].tag + ".hsaco", &size) && size == meta.units[k].objectSize && size > 0;
+        for (std::size_t k = 0; ok && k < meta.units.size(); ++k) {
+            long long size = 0;
+            ok = FileSize(base + "_" + meta.units[k].tag + ".hsaco", &size) && size == meta.units[k].objectSize && size > 0;
+        }
+        return ok;
+    };
+    bool hit = !recompile && lookup();
+    // Builders of the same entry are serialised by an advisory lock (released by the kernel if the holder dies): with one
+    // process per GPU every rank asks for the same functions at start-up; the first one compiles, the others wait and
+    // then hit -- no duplicated compile work, and never a meta file that describes another process's code objects.
+    struct EntryLock {
+        int fd = -1;
+        ~EntryLock() {
+            if (fd >= 0) {
+                (void)flock(fd, LOCK_UN);
+                (void)close(fd);
             }
         }
+    } lock;
+    if (!hit) {
+        if (!MakeDirs(dir)) return Fail(UNGAR_E_IO, "cannot create code-generation folder '" + dir + "'");
+        lock.fd = open((base + ".lock").c_str(), O_CREAT | O_RDWR, 0666);
+        if (lock.fd >= 0) (void)flock(lock.fd, LOCK_EX);
+        if (!recompile) hit = lookup();  // published by another builder while this one waited
     }
 
     if (!hit) {
