@@ -123,6 +123,26 @@ bool FileSize(const std::string& path, long long* size) {
     return true;
 }
 
+/// Identity of the toolchain that compiles the kernels: the ROCm release file, else the compiler's own banner.  (NOT
+/// hipRuntimeGetVersion: a process that has PyTorch loaded resolves the HIP runtime to torch's bundled copy, so two
+/// processes on one machine would disagree about the key of the same function.)
+const std::string& ToolchainVersion() {
+    static const std::string version = [] {
+        const char* root = std::getenv("ROCM_PATH");
+        std::ifstream f(std::string(root && *root ? root : "/opt/rocm") + "/.info/version");
+        std::string v;
+        if (f && std::getline(f, v) && !v.empty()) return "rocm-" + v;
+        const char* hipcc = std::getenv("UNGAR_HIPCC");
+        if (FILE* p = popen((std::string(hipcc ? hipcc : "hipcc") + " --version 2>/dev/null").c_str(), "r")) {
+            char buf[256];
+            while (fgets(buf, sizeof buf, p)) v += buf;
+            (void)pclose(p);
+        }
+        return v.empty() ? std::string("unknown-toolchain") : v;
+    }();
+    return version;
+}
+
 /// What a cache entry records besides the code objects: enough to serve every query and launch without the tape.
 struct CacheMeta {
     std::string key;
@@ -284,11 +304,7 @@ int ungar_function_make(const ungar_tape_node* nodes, int64_t num_nodes, const i
     key.Str(kCacheFormat);
     key.Str(UNGAR_AMD_EMITTER_ID);
     key.Str(kArch);
-    {
-        int rocm = 0;
-        (void)hipRuntimeGetVersion(&rocm);  // ROCm / HIP runtime the code objects are built for
-        key.Int(rocm);
-    }
+    key.Str(ToolchainVersion());  // the ROCm release whose compiler produces the code objects
     key.Str(custom ? custom : "");
     key.Int(n);
     key.Int(p);
