@@ -143,6 +143,14 @@ int ungar_gn_hessian_upper(const double* jac, int64_t js, int64_t ld_j, const do
 int ungar_gn_hessian_upper_unit_fastest(const double* jac, int64_t j_es, const double* d, int64_t d_es, double* g, int64_t gs, int64_t ld_g,
                                         int32_t rows, int32_t cols, int64_t count, void* stream);
 
+/* The same upper-triangular contraction for unit-fastest Jacobians with ONE LANE PER NODE on the FP64 vector ALU (which has
+ * the matrix instruction's FP64 rate on gfx950 and needs no transposition of this layout): every operand a coalesced load
+ * of 64 consecutive nodes.  Output strides are the caller's: G(a, b) of node i at g[(a * ld_g + b) * g_es + i * g_ns] --
+ * unit-fastest (g_es >= count, g_ns = 1: coalesced, what ungar_ocp_riccati_solve reads through its operand strides) or
+ * node-major blocks (g_es = 1, g_ns = block stride).  Entries with row > col are not written.  Any cols; (soft_sqp.hpp:257-264). */
+int ungar_gn_hessian_upper_lanes(const double* jac, int64_t j_es, const double* d, int64_t d_es, double* g, int64_t g_es, int64_t g_ns, int64_t ld_g,
+                                 int32_t rows, int32_t cols, int64_t count, void* stream);
+
 /* ---- whole-horizon assembly ------------------------------------------ */
 
 /* Sparsity of the equality-constraint Jacobian  d g / d [X | U]  of a horizon-N OCP built on `model`,

@@ -278,6 +278,64 @@ def test_gn_hessian_mfma(ua):
         assert torch.isnan(S[:, ~upper]).all()
 
 
+def test_gn_hessian_lane_per_node(ua):
+    """The lane-per-node contraction for unit-fastest Jacobians (gn_hessian_lanes.hip): ragged node counts (not a multiple of
+    64), column counts that are not a multiple of the 7 x 7 tile, weighted and unweighted, both output layouts; entries below
+    the diagonal are never written."""
+    import torch
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(5)
+    for rows, cols, count, weighted in ((37, 49, 1000, True), (12, 37, 130, True), (13, 17, 257, False), (6, 8, 5, True), (8, 17, 64, True)):
+        J = torch.rand((rows * cols, count), generator=gen, device="cuda", dtype=torch.float64) * 2 - 1
+        d = torch.rand((rows, count), generator=gen, device="cuda", dtype=torch.float64) if weighted else None
+        Jv = J.view(rows, cols, count)
+        ref = torch.einsum("ran,rn,rbn->nab", Jv, d if weighted else torch.ones((rows, count), device="cuda", dtype=torch.float64), Jv)
+        upper = torch.triu(torch.ones((cols, cols), dtype=torch.bool, device="cuda"))
+        Guf = torch.full((cols * cols, count), float("nan"), dtype=torch.float64, device="cuda")
+        ua.gn_hessian_lanes(J, d, Guf, rows, cols, count, True)
+        Gnm = torch.full((count, cols, cols), float("nan"), dtype=torch.float64, device="cuda")
+        ua.gn_hessian_lanes(J, d, Gnm, rows, cols, count, False)
+        torch.cuda.synchronize()
+        got = Guf.view(cols, cols, count).permute(2, 0, 1)
+        assert (got[:, upper] - ref[:, upper]).abs().max().item() <= 1e-12 * ref.abs().max().item()
+        assert torch.isnan(got[:, ~upper]).all()
+        assert torch.equal(Gnm[:, upper], got[:, upper]) and torch.isnan(Gnm[:, ~upper]).all()
+
+
+def test_full_size_chain_node_jacobians_to_gauss_newton_term(ua):
+    """BASELINE config 4 at full size (4096 instances x 20 knots = 81 920 nodes): ANYmal node Jacobians (unit-fastest) ->
+    G = J^T diag(d) J with no transposition, by BOTH contractions (FP64 vector lanes and LDS-staged MFMA); they agree with each
+    other on every node and with torch on a slice; trace(G) = sum_r d_r |J_r|^2 on every node."""
+    import torch
+    from ungar_amd import workloads as W
+    N, batch = 20, 4096
+    count = N * batch
+    m = ua.NodeModel("anymal")
+    rows, cols = m.nx, m.nx + m.nu
+    x, u, _, p = W.synth_device_inputs("anymal", count, 2, torch)
+    f = torch.empty((rows, count), dtype=torch.float64, device="cuda")
+    J = torch.empty((rows * cols, count), dtype=torch.float64, device="cuda")
+    Op = ua.Operand
+    m.dense_jacobian(count, Op.soa(x, count, N), Op.soa(u, count, N), None, Op.per_instance(p, 1, shared=True), Op.soa(f, count, N), Op.soa(J, count, N), knots=N)
+    d = torch.rand((rows, count), device="cuda", dtype=torch.float64) + 0.1
+    Guf = torch.zeros((cols * cols, count), dtype=torch.float64, device="cuda")
+    ua.gn_hessian_lanes(J, d, Guf, rows, cols, count, True)
+    Gnm = torch.zeros((count, cols, cols), dtype=torch.float64, device="cuda")
+    ua.gn_hessian_unit_fastest(J, d, Gnm, rows, cols, count)
+    torch.cuda.synchronize()
+    upper = torch.triu(torch.ones((cols, cols), dtype=torch.bool, device="cuda"))
+    got = Guf.view(cols, cols, count).permute(2, 0, 1)
+    scale = got.abs().amax(dim=(1, 2), keepdim=True)
+    assert ((got - Gnm)[:, upper].abs() <= 1e-11 * scale.expand(-1, cols, cols)[:, upper]).all()  # vector lanes == matrix cores
+    Jv = J.view(rows, cols, count)
+    sl = slice(count - 2048, count)
+    ref = torch.einsum("ran,rn,rbn->nab", Jv[:, :, sl], d[:, sl], Jv[:, :, sl])
+    assert ((got[sl] - ref)[:, upper].abs().max() <= 1e-12 * ref.abs().max()).item()
+    trace = torch.einsum("naa->n", got)
+    assert torch.allclose(trace, (d.unsqueeze(1) * Jv * Jv).sum(dim=(0, 1)), rtol=1e-12, atol=0)
+    assert (torch.diagonal(got, dim1=1, dim2=2) >= 0).all()
+
+
 @pytest.mark.parametrize("name,fixture,nu,npar", [("quadrotor_cost", "cost_quadrotor.npz", 4, 13), ("srbd_cost", "cost_srbd.npz", 24, 25)])
 def test_stage_cost_value_gradient_hessian(ua, repo_root, name, fixture, nu, npar):
     """Scalar node models 'quadrotor_cost' / 'srbd_cost' (SURVEY.md section 8(f) N2): value, gradient and

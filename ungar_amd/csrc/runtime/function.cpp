@@ -597,12 +597,13 @@ int ungar_function_sparse_hessian(const ungar_function* fn, const ungar_operand*
 
 /// Single-instance host call: H2D, batch-1 launch, D2H, on the null stream, synchronous.
 int ungar_function_eval_host(ungar_function* fn, int32_t what, const double* xp_host, double* out_host) {
-    if (!fn || !xp_host || !out_host) return Fail(UNGAR_E_INVALID, "ungar_function_eval_host: null argument");
+    if (!fn || !xp_host) return Fail(UNGAR_E_INVALID, "ungar_function_eval_host: null argument");
     const int64_t nIn = fn->n + fn->p;
     const int64_t nOut = what == 0 ? fn->m : what == 1 ? static_cast<int64_t>(fn->jacRows.size()) : static_cast<int64_t>(fn->hesRows.size());
     hipFunction_t k = what == 0 ? fn->kValue : what == 1 ? fn->kJac : fn->kHes;
     if (what < 0 || what > 2) return Fail(UNGAR_E_INVALID, "ungar_function_eval_host: what must be 0 (value), 1 (Jacobian) or 2 (Hessian)");
-    if (nOut == 0 && what != 0 && (fn->enabled & (what == 1 ? kEnableJacobian : kEnableHessian))) return UNGAR_OK;  // enabled but structurally empty
+    if (nOut == 0 && what != 0 && (fn->enabled & (what == 1 ? kEnableJacobian : kEnableHessian))) return UNGAR_OK;  // enabled but structurally empty (out_host may be null)
+    if (!out_host) return Fail(UNGAR_E_INVALID, "ungar_function_eval_host: null output");
     if (!k) return Fail(UNGAR_E_UNSUPPORTED, "ungar_function_eval_host: kernel not available for function '" + fn->name + "' (derivative not enabled, or made with UNGAR_AMD_COMPILE_ONLY)");
     if (nOut == 0) return UNGAR_OK;
     hipError_t e = hipSuccess;
