@@ -199,6 +199,8 @@ class NodeModel:
 
     @staticmethod
     def _stream(stream):
+        if isinstance(stream, ctypes.c_void_p):
+            return stream
         if stream is not None:
             return ctypes.c_void_p(stream)
         import torch

@@ -11,7 +11,12 @@
 // The (cols / TILE)(cols / TILE + 1) / 2 block pairs on or above the diagonal are spread over the wavefronts of consecutive
 // workgroups, so the rows of a node group are shared through the L1 / L2 caches while they are hot.  The result is written
 // with caller-chosen strides: unit-fastest (coalesced; what the batched Riccati solve and a second contraction read) or
-// node-major blocks (the layout of ungar_gn_hessian_upper).  Reference analogue: soft_sqp.hpp:257-264.
+// node-major blocks (the layout of ungar_gn_hessian_upper; lane-strided stores, 5x slower -- kept for completeness).
+// Measured (MI355X, 37 x 49, 81 920 nodes): 0.90 ms with the XCD renumbering (0.95 without) against 0.78-0.82 ms of the
+// LDS-staged matrix-core kernel: the 8x re-fetch of every Jacobian entry through L1 / L2 (9.5 GB per launch) is the limit,
+// not the arithmetic (8.2 of 78.6 TFLOP/s).  A variant staging each row through LDS (one barrier per row, four passes of 8
+// wavefronts) exposed the HBM latency of every row and took 2.5 ms; it was not kept.  This kernel is the one that writes a
+// unit-fastest G, which is what a lane-per-instance consumer wants.  Reference analogue: soft_sqp.hpp:257-264.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -22,8 +27,12 @@ template <int TILE, bool WEIGHTED, int UNROLL>
 __global__ __launch_bounds__(256) void GnHessianLanesKernel(const double* __restrict__ jac, long long jes, const double* __restrict__ d, long long des,
                                                             double* __restrict__ g, long long ges, long long gns, long long ldg, int rows, int cols, long long count,
                                                             int blocksPerSide, int pairs) {
+    // Consecutive workgroups are dealt round-robin to the 8 XCDs, each with its own L2: renumber them so that workgroups
+    // with consecutive LOGICAL ids -- the block pairs of one node group, which read the same Jacobian rows -- share an XCD.
+    const long long perXcd = (static_cast<long long>(gridDim.x) + 7) / 8;
+    const long long logical = (static_cast<long long>(blockIdx.x) & 7) * perXcd + (static_cast<long long>(blockIdx.x) >> 3);
     // wavefront w of the launch: node group w / pairs (64 nodes), block pair w % pairs
-    const long long wave = (static_cast<long long>(blockIdx.x) * 256 + threadIdx.x) >> 6;
+    const long long wave = logical * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const long long group = wave / pairs;
     int pair = static_cast<int>(wave - group * pairs);
@@ -85,11 +94,11 @@ extern "C" int ungar_amd_launch_gn_hessian_lanes(const double* jac, long long je
     constexpr int kTile = 7;
     const int side = (cols + kTile - 1) / kTile, pairs = side * (side + 1) / 2;
     const long long groups = (count + 63) / 64, waves = groups * pairs;
-    const dim3 grid(static_cast<unsigned>((waves + 3) / 4)), block(256);
+    const dim3 grid(static_cast<unsigned>((((waves + 3) / 4 + 7) / 8) * 8)), block(256);  // a multiple of 8: the XCD renumbering is a bijection
     hipStream_t s = static_cast<hipStream_t>(stream);
     static const int unroll = [] {  // tuning knob (tools/bench_gn_hessian.py sweeps it); default = the measured best
         const char* e = getenv("UNGAR_GN_LANES_UNROLL");
-        return e ? atoi(e) : 2;
+        return e ? atoi(e) : 1;  // measured on MI355X (ANYmal block, 81 920 nodes): 0.90 / 1.13 / 1.24 ms for 1 / 2 / 4 -- occupancy beats unrolling
     }();
 #define UNGAR_GN_LANES_LAUNCH(W, U) \
     hipLaunchKernelGGL((GnHessianLanesKernel<kTile, W, U>), grid, block, 0, s, jac, jes, d, des, g, ges, gns, ldg, rows, cols, count, side, pairs)

@@ -6,6 +6,8 @@
 //                         body with an LDS home (§4.3-4.4)
 #include "../gen/anymal_gen.hpp"
 #include "../gen/anymal_quad_gen.hpp"
+#include <cstdlib>
+
 #include "quad_kernel.hpp"
 
 UNGAR_AMD_DEFINE_NODE_TRAITS(anymal)
@@ -38,7 +40,11 @@ extern "C" int ungar_amd_launch_anymal(int mode, const ungar_amd::kernels::NodeL
     const double(*ctab)[4] = static_cast<const double(*)[4]>(sym);
     const dim3 grid(static_cast<unsigned>((a->count + kBlock / 4 - 1) / (kBlock / 4))), block(kBlock);
     namespace Q = ungar_amd::gen::anymal_quad;
-    if (UseStreamingStores(*a, mode, 37 * 49, 37))
+    static const bool noBuffer = getenv("UNGAR_AMD_NO_BUFFER_STORES") != nullptr;  // A/B switch for the store path (tools/)
+    if (UseStreamingStores(*a, mode, 37 * 49, 37) && QuadBufferStoresApply(*a) && !noBuffer)
+        hipLaunchKernelGGL((QuadNodeKernel<kBlock, Q::kLdsSlots, Q::kLdsUniformSlots, false, true, AnymalQuadBody, NoSparsePlan, unsigned, true>), grid, block, 0,
+                           static_cast<hipStream_t>(stream), *a, ctab, AnymalQuadBody{});
+    else if (UseStreamingStores(*a, mode, 37 * 49, 37))
         hipLaunchKernelGGL((QuadNodeKernel<kBlock, Q::kLdsSlots, Q::kLdsUniformSlots, false, true, AnymalQuadBody>), grid, block, 0, static_cast<hipStream_t>(stream), *a, ctab,
                            AnymalQuadBody{});
     else

@@ -41,7 +41,13 @@ struct NoSparsePlan {
 /// so a sparse store is (lane pointer) + (wave-uniform offset k_0 * je) like a dense one.
 /// OFF is the type of the wave-uniform element offsets: 32-bit when 1813 * (element stride) < 2^32 (checked by the
 /// launcher), 64-bit for larger unit-fastest operands (> 2.37 M nodes per launch: one more scalar multiply per store).
-template <bool SPARSE, bool STREAM = false, class PLAN = NoSparsePlan, class OFF = unsigned>
+///
+/// BUF (dense output only): the Jacobian is stored with MUBUF instructions, buffer_store_dwordx2 v_data, v_lane_offset,
+/// s[resource], s_entry_offset -- the lane-dependent part of the address is a 32-bit VGPR byte offset computed once, the
+/// entry-dependent part a scalar register, so a store costs one s_mul_i32 and NO vector-ALU address arithmetic (the
+/// pointer form needs a 64-bit v_lshl_add_u64 per store: 635 of the 14.2 k instructions a lane issues).  Requires the whole
+/// operand to span less than 4 GiB from the first node of the launch (checked by the launcher: 1813 * stride * 8 < 2^32).
+template <bool SPARSE, bool STREAM = false, class PLAN = NoSparsePlan, class OFF = unsigned, bool BUF = false>
 struct QuadIO {
     const double* __restrict__ xb;  // node's x (element stride xe)
     const double* __restrict__ ub;
@@ -60,6 +66,15 @@ struct QuadIO {
     double* jS[PLAN::kCount > 0 ? PLAN::kCount : 1];  // sparse mode: per-lane base pointer of every index pattern
     double* lds;   // per-lane LDS home of the phased body (slot s at lds[s * 64])
     double* ldsu;  // per-quad home of lane-uniform values (slot s at ldsu[s * 16]): a quarter of the bytes
+    // BUF: buffer resource over the Jacobian operand and the per-lane byte offsets that replace the pointers above
+    struct BufferState {
+#if defined(__HIP_DEVICE_COMPILE__)
+        __amdgpu_buffer_rsrc_t jr;
+#endif
+        int vNode, vLeg, vLegCol[4], vOwnCol;
+        unsigned je8;  // element stride in bytes (wave-uniform)
+        __host__ __device__ BufferState() {}  // filled in by the kernel when BUF
+    } buf;
 
     __device__ __forceinline__ double qb(int i) const { return xb[i * xe]; }
     __device__ __forceinline__ double vb(int i) const { return xb[(19 + i) * xe]; }
@@ -93,6 +108,15 @@ struct QuadIO {
     static __device__ __forceinline__ void Put(double* p, double v) {
         StoreResult<STREAM>(p, v);
     }
+    /// Buffer store of entry `e` (wave-uniform) at the lane offset `voff`.
+    __device__ __forceinline__ void BufPut(int voff, unsigned e, double v) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        typedef int v2i __attribute__((ext_vector_type(2)));
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, v), buf.jr, voff, static_cast<int>(e * buf.je8), STREAM ? 2 : 0);  // aux 2 = nt
+#else
+        (void)voff, (void)e, (void)v;
+#endif
+    }
     // base rows / shared columns: all four lanes hold the same value and store it to the same address
     // (merged inside the instruction) -- cheaper than masking three lanes off with exec-mask branches
     __device__ __forceinline__ void f_base(int row, double v) const {
@@ -120,12 +144,16 @@ struct QuadIO {
     __device__ __forceinline__ void j_leg(int rowBase, int colBase, int legMul, int rot, int k0, int k1, int k2, int k3, double v) const {
         if constexpr (SPARSE)
             j_sparse(k0, k1, k2, k3, v);
+        else if constexpr (BUF)
+            BufPut(legMul ? buf.vLegCol[rot] : buf.vLeg, static_cast<unsigned>(rowBase * 49 + colBase), v);
         else
             Put((legMul ? jLegCol[rot] : jLeg) + static_cast<unsigned>(rowBase * 49 + colBase) * je, v);
     }
     __device__ __forceinline__ void j_base_own(int row, int colBase, int /*legMul*/, int /*rot*/, int k0, int k1, int k2, int k3, double v) const {
         if constexpr (SPARSE)
             j_sparse(k0, k1, k2, k3, v);
+        else if constexpr (BUF)
+            BufPut(buf.vOwnCol, static_cast<unsigned>(row * 49 + colBase), v);
         else
             Put(jOwnCol + static_cast<unsigned>(row * 49 + colBase) * je, v);
     }
@@ -138,12 +166,14 @@ struct QuadIO {
             j_sparse(k0, k1, k2, k3, v);
         } else {
             const unsigned e = static_cast<unsigned>((L == 0 ? r0 : L == 1 ? r1 : L == 2 ? r2 : r3) * 49 + col);
-            Put(jb + e * je, v);
+            Put(jb + e * je, v);  // per-lane entry: pointer form in both variants (only with --quad-merge-shared)
         }
     }
     __device__ __forceinline__ void j_base_shared(int row, int colBase, int, int, int k0, int, int, int, double v) const {
         if constexpr (SPARSE) {
             if (k0 >= 0) Put(jb + static_cast<unsigned>(k0) * je, v);
+        } else if constexpr (BUF) {
+            BufPut(buf.vNode, static_cast<unsigned>(row * 49 + colBase), v);
         } else {
             Put(jb + static_cast<unsigned>(row * 49 + colBase) * je, v);
         }
@@ -151,7 +181,7 @@ struct QuadIO {
 };
 
 /// GEN is the generated namespace (ValueJacobianQuad, kLegConstantsDev).  BLOCK lanes = BLOCK/4 nodes.
-template <int BLOCK, int LDS_SLOTS, int LDS_USLOTS, bool SPARSE, bool STREAM, class Body, class PLAN = NoSparsePlan, class OFF = unsigned>
+template <int BLOCK, int LDS_SLOTS, int LDS_USLOTS, bool SPARSE, bool STREAM, class Body, class PLAN = NoSparsePlan, class OFF = unsigned, bool BUF = false>
 __global__ __launch_bounds__(BLOCK) void QuadNodeKernel(const NodeLaunch a, const double (*ctab)[4], Body body) {
     static_assert(BLOCK == 64, "the LDS home is laid out for one wavefront per workgroup");
     __shared__ double lds[(LDS_SLOTS > 0 ? LDS_SLOTS : 1) * BLOCK + LDS_USLOTS * (BLOCK / 4)];
@@ -168,7 +198,7 @@ __global__ __launch_bounds__(BLOCK) void QuadNodeKernel(const NodeLaunch a, cons
     double* const jb = a.jac.base + b * a.jac.bs + k * a.jac.ks;
     const long long je = a.jac.es;
     double* const jLeg = jb + 3LL * L * 49 * je;
-    QuadIO<SPARSE, STREAM, PLAN, OFF> io{a.x.base + b * a.x.bs + k * a.x.ks,
+    QuadIO<SPARSE, STREAM, PLAN, OFF, BUF> io{a.x.base + b * a.x.bs + k * a.x.ks,
               a.u.base + b * a.u.bs + k * a.u.ks,
               a.p.base + b * a.p.bs + k * a.p.ks,
               fb,
@@ -182,12 +212,34 @@ __global__ __launch_bounds__(BLOCK) void QuadNodeKernel(const NodeLaunch a, cons
               ctab,
               {},
               lds + threadIdx.x,
-              lds + LDS_SLOTS * BLOCK + nodeInWave};
+              lds + LDS_SLOTS * BLOCK + nodeInWave,
+              {}};
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (BUF) {
+        // resource over the operand from the FIRST node of the launch (node 0 of instance 0): every lane offset is >= 0
+        io.buf.jr = __builtin_amdgcn_make_buffer_rsrc(a.jac.base, 0, 0xFFFFFFFF, 0x00020000);  // raw buffer, 32-bit data format
+        const long long nodeOff = b * a.jac.bs + k * a.jac.ks;  // elements
+        io.buf.je8 = static_cast<unsigned>(je) * 8u;
+        io.buf.vNode = static_cast<int>(static_cast<unsigned>(nodeOff) * 8u);
+        io.buf.vLeg = static_cast<int>(static_cast<unsigned>(nodeOff + 3LL * L * 49 * je) * 8u);
+        for (int r = 0; r < 4; ++r) io.buf.vLegCol[r] = static_cast<int>(static_cast<unsigned>(nodeOff + 3LL * L * 49 * je + 3LL * ((L + r) & 3) * je) * 8u);
+        io.buf.vOwnCol = static_cast<int>(static_cast<unsigned>(nodeOff + 3LL * L * je) * 8u);
+    }
+#endif
     if constexpr (SPARSE) {
 #pragma unroll
         for (int p = 0; p < PLAN::kCount; ++p) io.jS[p] = jb + static_cast<long long>(PLAN::kDeltas[p][L]) * je;
     }
     body(io);
+}
+
+/// True when every byte offset of the dense 37 x 49 block, measured from the operand's base, fits the 32-bit offsets of
+/// buffer instructions: non-negative strides and the last entry of the last node below 4 GiB.
+inline bool QuadBufferStoresApply(const NodeLaunch& a) {
+    if (a.jac.es < 0 || a.jac.bs < 0 || a.jac.ks < 0) return false;
+    const long long instances = a.count / (a.knots > 0 ? a.knots : 1);
+    const long long lastNode = (instances - 1) * a.jac.bs + (a.knots - 1) * a.jac.ks;
+    return (lastNode + 1813LL * a.jac.es) * 8 < (1LL << 32);
 }
 
 /// True when the wave-uniform element offsets of the 37 x 49 block (or of its CSR value array) fit 32 bits.

@@ -16,7 +16,11 @@
 #include <string_view>
 #include <vector>
 
+#if __has_include(<ungar_amd.h>)  // installed layout: the C ABI header is on the include path
+#include <ungar_amd.h>
+#else  // in-tree layout: <repo>/include/ungar_amd.h next to <repo>/ungar_amd/include/ungar/
 #include "../../../../include/ungar_amd.h"
+#endif
 #include "../utils/utils.hpp"
 #include "data_types.hpp"
 
@@ -198,8 +202,18 @@ class Function {
 
 class FunctionFactory {
   public:
-    static Function Make(const Function::Blueprint& bp, const bool recompileLibraries, const std::vector<std::string>& /*compilerFlags*/) {
+    static Function Make(const Function::Blueprint& bp, const bool recompileLibraries, const std::vector<std::string>& compilerFlags) {
         namespace tape = ::ungar_amd::tape;
+        // The reference forwards `compilerFlags` to gcc (function.hpp:475-480); kernels here are built by hipcc for gfx950
+        // and gcc options such as -march=native do not apply.  Anything other than the reference's default set is reported
+        // once instead of being dropped silently; UNGAR_AMD_JIT_FLAGS replaces the device compiler's optimisation flags.
+        static bool warned = false;
+        static const std::vector<std::string> kReferenceDefaults{"-O3", "-g", "-march=native", "-mtune=native", "-ffast-math"};
+        if (!warned && compilerFlags != kReferenceDefaults) {
+            warned = true;
+            UNGAR_LOG(warn, "Autodiff::MakeFunction: compilerFlags are host-compiler (gcc) options and do not apply to gfx950 kernels; ignored. "
+                            "Set UNGAR_AMD_JIT_FLAGS to change the hipcc optimisation flags.");
+        }
         const index_t nIn = bp.independentVariableSize + bp.parameterSize;
         // record (reference CreateModelsImpl, function.hpp:453-466)
         const std::vector<tape::AD> in = tape::Independent(static_cast<int>(nIn));
