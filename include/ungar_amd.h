@@ -72,8 +72,9 @@ typedef struct ungar_node_batch {
 
 /* ---- model lifetime ------------------------------------------------------------------------ */
 
-/* Opens one of the built-in node models: "quadrotor_cost" / "srbd_cost" (scalar stage costs of the quadrotor and
- * quadruped OCPs: value, gradient, upper Hessian), "srbd_ineq" (12 inequality rows per knot of the quadruped OCP and their Jacobian),
+/* Opens one of the built-in node models: "quadrotor_cost" / "srbd_cost" / "rc_car_cost" (scalar stage costs of the quadrotor,
+ * quadruped and RC-car OCPs: value, gradient, upper Hessian), "rc_car_ineq" (3 inequality rows per knot of the RC-car OCP),
+ * "srbd_feet" (world foot positions of the quadruped: the node-local part of its foot-contact equality rows), "srbd_ineq" (12 inequality rows per knot of the quadruped OCP and their Jacobian),
  * "quadrotor_ineq" (8 rotor-speed bound rows per knot of the quadrotor OCP),
  * "quadrotor", "rc_car", "srbd", "anymal" (structured
  * implicit differentiation, phased body with an LDS home), "anymal_reg" (same program, plain

@@ -10,6 +10,15 @@ here="$(cd "$(dirname "$0")" && pwd)"; root="$(cd "$here/../.." && pwd)"
 ref=${UNGAR_REFERENCE:-/root/reference}
 [ -d "$ref/example" ] || { echo "reference not present: nothing to build"; exit 0; }
 mkdir -p "$root/oracle/_ref"
+# Second build of every example on top of the REAL Eigen 3.4 the reference bundles (external/config/eigen/eigen-3.4.0.zip,
+# unpacked into a scratch directory OUTSIDE the repository): -DUNGAR_AMD_USE_SYSTEM_EIGEN makes the facade's vector /
+# quaternion / sparse types Eigen's own, i.e. what an existing Ungar installation already has in every translation unit.
+eigen=""
+if [ -f "$ref/external/config/eigen/eigen-3.4.0.zip" ]; then
+  scratch="${TMPDIR:-/tmp}/ungar_amd_reference_eigen"
+  [ -d "$scratch/eigen-3.4.0/Eigen" ] || { mkdir -p "$scratch" && unzip -q -o "$ref/external/config/eigen/eigen-3.4.0.zip" -d "$scratch"; }
+  eigen="$scratch/eigen-3.4.0"
+fi
 for name in "$@"; do
   src="$ref/example/mpc/${name}.example.cpp"
   [ -f "$src" ] || src="$ref/example/autodiff/${name}.example.cpp"
@@ -17,4 +26,9 @@ for name in "$@"; do
   g++ -std=c++20 -O2 -I "$root/ungar_amd/include" -o "$root/oracle/_ref/${name}_example" "$src" \
       -L "$root/ungar_amd/lib" -lungar_amd -Wl,-rpath,'$ORIGIN/../../ungar_amd/lib' -Wl,-rpath,/opt/rocm/lib
   echo "built oracle/_ref/${name}_example"
+  if [ -n "$eigen" ]; then
+    g++ -std=c++20 -O2 -DUNGAR_AMD_USE_SYSTEM_EIGEN -I "$eigen" -I "$root/ungar_amd/include" -o "$root/oracle/_ref/${name}_example_eigen" "$src" \
+        -L "$root/ungar_amd/lib" -lungar_amd -Wl,-rpath,'$ORIGIN/../../ungar_amd/lib' -Wl,-rpath,/opt/rocm/lib
+    echo "built oracle/_ref/${name}_example_eigen (real Eigen 3.4)"
+  fi
 done

@@ -49,6 +49,9 @@ DIMS = {  # name: (nx, nu, nw, np)
     "srbd": (13, 24, 4, 6),
     "anymal": (37, 12, 0, 1),
     "srbd_ineq": (13, 24, 4, 14),  # 12 outputs per knot (inequality rows), not a dynamics node
+    "quadrotor_ineq": (13, 4, 0, 1),  # 8 outputs: rotor-speed bounds
+    "rc_car_ineq": (6, 2, 0, 0),  # 3 outputs: input bounds, minimum forward velocity
+    "srbd_feet": (13, 24, 0, 0),  # 12 outputs: world foot positions
 }
 
 
@@ -537,7 +540,23 @@ def srbd_ineq_node(x, u, w, p):
     return torch.stack(rows)
 
 
-NODES = {"quadrotor": quadrotor_node, "rc_car": rc_car_node, "srbd": srbd_node, "anymal": anymal_node, "srbd_ineq": srbd_ineq_node}
+def quadrotor_ineq_node(x, u, w, p):
+    """quadrotor.example.cpp:280-288: per rotor [r - r_max, -r]; p = [max_rotor_speed]."""
+    return torch.stack([t for i in range(4) for t in (u[i] - p[0], -u[i])])
+
+
+def rc_car_ineq_node(x, u, w, p):
+    """rc_car.example.cpp:271-282: [|d| - 15, |delta| - 15, 0.3 - v_x]."""
+    return torch.stack((torch.abs(u[0]) - 15.0, torch.abs(u[1]) - 15.0, 0.3 - x[3]))
+
+
+def srbd_feet_node(x, u, w, p):
+    """quadruped.example.cpp:288-291: pFoot_i = p + q * r_i (the node-local part of the foot-contact equality rows)."""
+    return torch.cat([x[0:3] + quat_rotate(x[3:7], u[6 * i + 3:6 * i + 6]) for i in range(4)])
+
+
+NODES = {"quadrotor": quadrotor_node, "rc_car": rc_car_node, "srbd": srbd_node, "anymal": anymal_node, "srbd_ineq": srbd_ineq_node,
+         "quadrotor_ineq": quadrotor_ineq_node, "rc_car_ineq": rc_car_ineq_node, "srbd_feet": srbd_feet_node}
 
 
 # ----------------------------------------------------------------------------- evaluation API
@@ -564,7 +583,12 @@ def srbd_cost(x, u, p):
     return value
 
 
-COSTS = {"quadrotor_cost": (quadrotor_cost, 13, 4, 13), "srbd_cost": (srbd_cost, 13, 24, 25)}  # fn, nx, nu, np
+def rc_car_cost(x, u, p):
+    """Per-knot stage cost of example/mpc/rc_car.example.cpp:204-222 (input-variation term excluded): p = [reference_position(2)]."""
+    return ((x[0:2] - p[0:2]) ** 2).sum() + 1e-6 * (u ** 2).sum()
+
+
+COSTS = {"quadrotor_cost": (quadrotor_cost, 13, 4, 13), "srbd_cost": (srbd_cost, 13, 24, 25), "rc_car_cost": (rc_car_cost, 6, 2, 2)}  # fn, nx, nu, np
 
 
 def cost_value_gradient_hessian(x, u, p, name="quadrotor_cost"):
@@ -586,9 +610,11 @@ def cost_value_gradient_hessian(x, u, p, name="quadrotor_cost"):
 def synthetic_cost_inputs(count: int, seed: int = 0, name: str = "quadrotor_cost"):
     """States/inputs as for the dynamics node, references = perturbed states (some with flipped quaternion
     sign, so that both branches of the min are exercised); srbd_cost: plus perturbed footholds."""
-    x, u, _, _ = synthetic_inputs("quadrotor" if name == "quadrotor_cost" else "srbd", count, seed)
+    x, u, _, _ = synthetic_inputs({"quadrotor_cost": "quadrotor", "srbd_cost": "srbd", "rc_car_cost": "rc_car"}[name], count, seed)
     rng = np.random.default_rng(0xC057 + seed)
     ref = x + rng.normal(scale=0.3, size=x.shape)
+    if name == "rc_car_cost":
+        return x, u, ref[:, :2].copy()
     ref[:, 3:7] /= np.linalg.norm(ref[:, 3:7], axis=1, keepdims=True)
     ref[::2, 3:7] *= -1.0
     if name == "srbd_cost":
@@ -635,6 +661,10 @@ def default_params(name: str) -> np.ndarray:
         return np.array([1.0 / 20.0])
     if name == "srbd_ineq":  # quadruped.example.cpp:384-392
         return np.array([0.7, 0.2, 0.15, -0.1, 0.2, -0.15, -0.1, -0.2, 0.15, -0.1, -0.2, -0.15, -0.1, 0.42])
+    if name == "quadrotor_ineq":  # max_rotor_speed: twice the hover speed (quadrotor.example.cpp:356-358)
+        return np.array([2.0 * math.sqrt(1.5 * 9.80665 / (4 * 0.015))])
+    if name in ("rc_car_ineq", "srbd_feet"):
+        return np.zeros(0)
     raise KeyError(name)
 
 
@@ -673,6 +703,16 @@ def synthetic_inputs(name: str, count: int, seed: int = 0):
     elif name == "srbd_ineq":  # states/forces/footholds as for the srbd dynamics node; some constraints violated
         x, u, w, _ = synthetic_inputs("srbd", count, seed)
         u[::3, 2::6] *= -0.1  # pulling contact forces: unilateral and friction rows active
+    elif name == "quadrotor_ineq":  # rotor speeds on both sides of [0, r_max]
+        x, u, _, _ = synthetic_inputs("quadrotor", count, seed)
+        u[::4] *= 2.5
+        u[1::4, 0] *= -0.2
+    elif name == "rc_car_ineq":  # inputs on both sides of the bounds and of zero (the kink of |.|), slow and fast cars
+        x, u, _, _ = synthetic_inputs("rc_car", count, seed)
+        u *= 20.0
+        x[::3, 3] *= 0.1
+    elif name == "srbd_feet":
+        x, u, _, _ = synthetic_inputs("srbd", count, seed)
     else:
         raise KeyError(name)
     return x, u, w, p

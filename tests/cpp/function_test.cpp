@@ -201,7 +201,7 @@ static void QuadrotorNodeThroughFacade(const std::string& folder) {
     std::printf("\nQUADROTOR_F");
     for (index_t i = 0; i < y.size(); ++i) std::printf(" %.17g", y[i]);
     std::printf("\nQUADROTOR_J");
-    for (const real_t e : J.toDense()) std::printf(" %.17g", e);
+    for (const real_t e : Linalg::ToDense(J)) std::printf(" %.17g", e);
     std::printf("\n");
 }
 
@@ -228,8 +228,8 @@ static void TestCacheAndEmptyDerivatives(const std::string& folder) {
     for (int k = 0; k < 16; ++k) {
         const VectorXr xp = RandomVector(4, gen);
         EXPECT_TRUE(fresh(xp)[0] == cached(xp)[0]);
-        const std::vector<real_t> j0 = fresh.Jacobian(xp).toDense(), j1 = cached.Jacobian(xp).toDense();
-        const std::vector<real_t> h0 = fresh.Hessian(xp).toDense(), h1 = cached.Hessian(xp).toDense();
+        const std::vector<real_t> j0 = Linalg::ToDense(fresh.Jacobian(xp)), j1 = Linalg::ToDense(cached.Jacobian(xp));
+        const std::vector<real_t> h0 = Linalg::ToDense(fresh.Hessian(xp)), h1 = Linalg::ToDense(cached.Hessian(xp));
         EXPECT_TRUE(j0 == j1 && h0 == h1 && j0.size() == 3 && h0.size() == 9);
         EXPECT_TRUE(std::fabs(edited(xp)[0] - (fresh(xp)[0] + 1.0 * xp[3] * (xp[0] * xp[0] + xp[1] * xp[1] * xp[2]))) < 1e-12);
         EXPECT_TRUE(std::fabs(h0[0] - (2.0 * 1.5 * xp[3] - xp[2] * xp[2] * std::sin(xp[0] * xp[2]))) < 1e-12);
@@ -243,7 +243,7 @@ static void TestCacheAndEmptyDerivatives(const std::string& folder) {
     Autodiff::Function lin = Autodiff::MakeFunction(Autodiff::Function::Blueprint{linear, 3, 0, "function_test_linear_objective", EnabledDerivatives::ALL, folder}, true);
     const VectorXr x = RandomVector(3, gen);
     EXPECT_TRUE(lin.ImplementsHessian() && lin.Hessian(x).nonZeros() == 0 && lin.Hessian(x).rows() == 3);
-    const std::vector<real_t> jl = lin.Jacobian(x).toDense();
+    const std::vector<real_t> jl = Linalg::ToDense(lin.Jacobian(x));
     EXPECT_TRUE(jl.size() == 3 && jl[0] == 2.0 && jl[1] == -1.0 && jl[2] == 0.5);
     // a function of the parameters only: Jacobian enabled, structurally empty
     const auto paramOnly = [](const VectorXad& xp, VectorXad& y) {
@@ -265,7 +265,7 @@ static void TestCacheAndEmptyDerivatives(const std::string& folder) {
     for (const real_t z : {-2.0, 0.0, 4.0}) {
         VectorXr in{2};
         in << 3.0, z;
-        const std::vector<real_t> jg = grd.Jacobian(in).toDense(), hg = grd.Hessian(in).toDense();
+        const std::vector<real_t> jg = Linalg::ToDense(grd.Jacobian(in)), hg = Linalg::ToDense(grd.Hessian(in));
         EXPECT_TRUE(std::fabs(jg[0] - (z > 0 ? 0.5 : 1.0)) < 1e-15 && std::fabs(jg[1] - (z > 0 ? -0.5 * 3.0 / 8.0 : 0.0)) < 1e-15);
         for (const real_t e : hg) EXPECT_TRUE(std::isfinite(e));
     }

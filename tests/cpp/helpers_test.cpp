@@ -221,7 +221,11 @@ static void TestQuaternionLayer() {
         const Vector3r f = q * Vector3r{0.0, 0.0, 1.0};
         EXPECT_TRUE(Close(f[2], -1.0) && Close(q.norm(), 1.0));
         const Quaternionr a = randomUnit();
-        Eigen::DenseMatrix<real_t> R(3, 3);
+#if defined(UNGAR_AMD_USE_SYSTEM_EIGEN)
+        Eigen::Matrix3d R;
+#else
+        MatrixXr R(3, 3);
+#endif
         for (int c = 0; c < 3; ++c) {
             const Vector3r col = a * Vector3r::Unit(c);
             for (int rr = 0; rr < 3; ++rr) R(rr, c) = col[rr];

@@ -110,3 +110,23 @@ def test_header_is_plain_c(repo_root, tmp_path):
                    check=True)
     out = subprocess.run([exe], capture_output=True, text=True, check=True).stdout
     assert "quadrotor_cost nx=13 ny=1 hes_nnz=17" in out
+
+
+def _amd_model_test(repo_root, mode, tmp_path, env=None):
+    import subprocess
+    exe = os.path.join(repo_root, "build", "amd_model_test")
+    if not os.path.exists(exe):
+        pytest.skip("build/amd_model_test missing: run __graft_entry__.build()")
+    r = subprocess.run([exe, mode, str(tmp_path / "codegen")], capture_output=True, text=True, timeout=600, env={**os.environ, **(env or {})})
+    assert r.returncode == 0 and "amd_model_test OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_reference_side_adapter_compiles_and_reports_sparsity(repo_root, tmp_path):
+    """include/ungar_amd_model.hpp (AmdModel + TapeBuilder) with a hand-built tape; hipcc
+    cross-compiles the kernels here, evaluation is left to the GPU test below."""
+    _amd_model_test(repo_root, "sparsity", tmp_path, {"UNGAR_AMD_COMPILE_ONLY": "1"})
+
+
+@pytest.mark.gpu
+def test_reference_side_adapter_evaluates_closed_forms_on_gpu(repo_root, tmp_path):
+    _amd_model_test(repo_root, "gpu", tmp_path)

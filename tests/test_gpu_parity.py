@@ -336,7 +336,7 @@ def test_full_size_chain_node_jacobians_to_gauss_newton_term(ua):
     assert (torch.diagonal(got, dim1=1, dim2=2) >= 0).all()
 
 
-@pytest.mark.parametrize("name,fixture,nu,npar", [("quadrotor_cost", "cost_quadrotor.npz", 4, 13), ("srbd_cost", "cost_srbd.npz", 24, 25)])
+@pytest.mark.parametrize("name,fixture,nu,npar", [("quadrotor_cost", "cost_quadrotor.npz", 4, 13), ("srbd_cost", "cost_srbd.npz", 24, 25), ("rc_car_cost", "cost_rc_car.npz", 2, 2)])
 def test_stage_cost_value_gradient_hessian(ua, repo_root, name, fixture, nu, npar):
     """Scalar node models 'quadrotor_cost' / 'srbd_cost' (SURVEY.md section 8(f) N2): value, gradient and
     upper-triangular Hessian w.r.t. (x, u) against torch.autograd on the oracle's restatement of the
@@ -344,8 +344,10 @@ def test_stage_cost_value_gradient_hessian(ua, repo_root, name, fixture, nu, npa
     import torch
     g = np.load(f"{repo_root}/tests/golden/{fixture}")
     m = ua.NodeModel(name)
-    ncols = 13 + nu
-    assert (m.nx, m.nu, m.np, m.ny, m.jac_nnz) == (13, nu, npar, 1, ncols) and m.implements_hessian()
+    nx = g["x"].shape[1]
+    ncols = nx + nu
+    assert (m.nx, m.nu, m.np, m.ny) == (nx, nu, npar, 1) and m.implements_hessian()
+    grad_rows, grad_cols = m.jacobian_sparsity()  # rc_car_cost does not depend on every state: its gradient is sparse
     rows, cols = m.hessian_sparsity()
     assert (rows <= cols).all(), "upper triangle only (function.hpp:236-274)"
     count = g["x"].shape[0]
@@ -358,11 +360,14 @@ def test_stage_cost_value_gradient_hessian(ua, repo_root, name, fixture, nu, npa
         y = torch.full(shape(1), float("nan"), dtype=torch.float64, device=dev)
         grad = torch.full(shape(ncols), float("nan"), dtype=torch.float64, device=dev)
         hes = torch.full(shape(len(rows)), float("nan"), dtype=torch.float64, device=dev)
-        m.sparse_hessian(count, mk(x, 13), mk(u, nu), None, mk(p, npar), mk(y, 1), mk(grad, ncols), mk(hes, len(rows)))
+        m.sparse_hessian(count, mk(x, nx), mk(u, nu), None, mk(p, npar), mk(y, 1), mk(grad, ncols), mk(hes, len(rows)))
         torch.cuda.synchronize()
         Y, G, H = (a.cpu().numpy().T if layout == "soa" else a.cpu().numpy() for a in (y, grad, hes))
         assert np.abs(Y[:, 0] - g["y"]).max() <= 1e-12 * np.abs(g["y"]).max()
-        assert np.abs(G - g["g"]).max() <= 1e-12 * np.abs(g["g"]).max()
+        assert np.abs(G[:, grad_cols] - g["g"][:, grad_cols]).max() <= 1e-12 * np.abs(g["g"]).max()
+        off = np.ones(ncols, dtype=bool)
+        off[grad_cols] = False
+        assert np.abs(g["g"][:, off]).max(initial=0.0) == 0.0 and (np.isnan(G[:, off]) | (G[:, off] == 0.0)).all()  # structural zeros of the gradient
         assert np.abs(H - g["H"][:, rows, cols]).max() <= 1e-12
         dense = np.zeros_like(g["H"])
         dense[:, rows, cols] = H
@@ -375,7 +380,7 @@ def test_stage_cost_value_gradient_hessian(ua, repo_root, name, fixture, nu, npa
     m.dense_jacobian(count, ua.Operand.soa(x, count), ua.Operand.soa(u, count), None, ua.Operand.soa(p, count), ua.Operand.soa(y2, count), ua.Operand.soa(g2, count))
     torch.cuda.synchronize()
     assert np.abs(y2.cpu().numpy()[0] - g["y"]).max() <= 1e-12 * np.abs(g["y"]).max()
-    assert np.abs(g2.cpu().numpy().T - g["g"]).max() <= 1e-12 * np.abs(g["g"]).max()
+    assert np.abs(g2.cpu().numpy().T[:, grad_cols] - g["g"][:, grad_cols]).max() <= 1e-12 * np.abs(g["g"]).max()
     # vector-valued models refuse the Hessian entry point
     with pytest.raises(ua.UngarError):
         ua.NodeModel("quadrotor").hessian_sparsity()
@@ -419,6 +424,24 @@ def test_srbd_inequality_node_golden(ua, repo_root, layout, mode):
     assert np.abs(f - g["f"]).max() <= 1e-12 * max(1.0, np.abs(g["f"]).max())
     assert np.abs(J - g["J"]).max() <= 1e-12 * np.abs(g["J"]).max()
     assert (g["f"] > 0).any() and (g["f"] < 0).any(), "the fixture must contain violated and satisfied rows"
+
+
+@pytest.mark.parametrize("name,dims", [("quadrotor_ineq", (13, 4, 0, 1, 8)), ("rc_car_ineq", (6, 2, 0, 0, 3)), ("srbd_feet", (13, 24, 0, 0, 12))])
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+@pytest.mark.parametrize("mode", ["dense", "sparse"])
+def test_remaining_ocp_rows_golden(ua, repo_root, name, dims, layout, mode):
+    """The remaining per-knot rows of the reference's OCPs as node kernels: rotor-speed bounds (quadrotor.example.cpp:280-288),
+    RC-car input bounds through Utils::Abs and minimum forward velocity (rc_car.example.cpp:271-282: both sides of the kink of
+    |.| are in the fixture), world foot positions p + q * r_i of the quadruped's contact rows (quadruped.example.cpp:288-291)."""
+    g = np.load(f"{repo_root}/tests/golden/node_{name}.npz")
+    m = ua.NodeModel(name)
+    assert (m.nx, m.nu, m.nw, m.np, m.ny) == dims
+    f, J = m.evaluate_numpy(g["x"], g["u"], g["w"], g["p"], mode=mode, layout=layout)
+    assert f.shape == g["f"].shape and J.shape == g["J"].shape
+    assert np.abs(f - g["f"]).max() <= 1e-12 * max(1.0, np.abs(g["f"]).max())
+    assert np.abs(J - g["J"]).max() <= 1e-12 * np.abs(g["J"]).max()
+    if name != "srbd_feet":
+        assert (g["f"] > 0).any() and (g["f"] < 0).any(), "the fixture must contain violated and satisfied rows"
 
 
 def test_barrier_gauss_newton_term_on_device(ua, repo_root):

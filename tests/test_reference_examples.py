@@ -12,8 +12,13 @@ import pytest
 LINE = re.compile(r"t = ([\d.]+), obj = ([-\d.e+]+), eqs = ([-\d.e+]+), ineqs = ([-\d.e+]+).*?z ref = ([-\d.]+), z = ([-\d.]+), yaw ref = ([-\d.]+), yaw = ([-\d.]+)")
 
 
-def _run(repo_root, name, tmp_path, timeout):
-    exe = os.path.join(repo_root, "oracle", "_ref", f"{name}_example")
+# "" = built on the facade's own minimal algebra; "_eigen" = the same sources built on the REAL Eigen 3.4 the reference bundles
+# (-DUNGAR_AMD_USE_SYSTEM_EIGEN): the facade's types are then Eigen's own, as in an existing Ungar installation.
+VARIANTS = ["", "_eigen"]
+
+
+def _run(repo_root, name, tmp_path, timeout, variant=""):
+    exe = os.path.join(repo_root, "oracle", "_ref", f"{name}_example{variant}")
     if not os.path.exists(exe):
         pytest.skip(f"{exe} not built (needs the reference sources at build time)")
     out = subprocess.run([exe], cwd=tmp_path, capture_output=True, text=True, timeout=timeout)
@@ -22,10 +27,11 @@ def _run(repo_root, name, tmp_path, timeout):
 
 
 @pytest.mark.gpu
-def test_quadrotor_example_tracks_its_reference(repo_root, tmp_path):
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_quadrotor_example_tracks_its_reference(repo_root, tmp_path, variant):
     """quadrotor.example.cpp PART IV: 10 s of receding-horizon control; after the mission start the
     quadrotor must follow the sinusoidal height reference and the yaw ramp, dynamics constraints closed."""
-    rows = [tuple(map(float, m.groups())) for m in map(LINE.search, _run(repo_root, "quadrotor", tmp_path, 1500).splitlines()) if m]
+    rows = [tuple(map(float, m.groups())) for m in map(LINE.search, _run(repo_root, "quadrotor", tmp_path, 1500, variant).splitlines()) if m]
     assert len(rows) >= 290, "one log line per control step is expected"
     late = [r for r in rows if r[0] > 6.0]
     assert max(abs(r[2]) for r in late) < 1e-3, "dynamics equality constraints must be satisfied by the SQP iterates"
@@ -39,9 +45,10 @@ RC_LINE = re.compile(r"t = ([\d.]+), obj = ([-\d.e+]+), eqs = ([-\d.e+]+), ineqs
 
 
 @pytest.mark.gpu
-def test_rc_car_example_tracks_its_reference(repo_root, tmp_path):
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_rc_car_example_tracks_its_reference(repo_root, tmp_path, variant):
     """rc_car.example.cpp: the car must converge onto the reference path and stay on it."""
-    rows = [tuple(map(float, m.groups())) for m in map(RC_LINE.search, _run(repo_root, "rc_car", tmp_path, 600).splitlines()) if m]
+    rows = [tuple(map(float, m.groups())) for m in map(RC_LINE.search, _run(repo_root, "rc_car", tmp_path, 600, variant).splitlines()) if m]
     assert len(rows) >= 290
     late = [r for r in rows if r[0] > 2.0]
     assert max(abs(r[2]) for r in late) < 1e-3
@@ -49,17 +56,19 @@ def test_rc_car_example_tracks_its_reference(repo_root, tmp_path):
     assert max(abs(r[4] - r[6]) + abs(r[5] - r[7]) for r in late) < 0.05
 
 
-def test_variable_map_example_runs_on_the_host(repo_root, tmp_path):
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_variable_map_example_runs_on_the_host(repo_root, tmp_path, variant):
     """example/variable_map.example.cpp is pure layout (compile-time static_asserts on indices and on the
     view TYPES returned by VariableMap::Get, then setZero / setOnes / setLinSpaced through the views)."""
-    out = _run(repo_root, "variable_map", tmp_path, 60)
+    out = " ".join(_run(repo_root, "variable_map", tmp_path, 60, variant).split())  # real Eigen prints a column vector one coefficient per line
     assert "u0 = 0 0 0 0" in out and "u1 = 1 1 1 1" in out and "uN-1 = 2 4 6 8" in out
 
 
 @pytest.mark.gpu
-def test_function_example_self_checks(repo_root, tmp_path):
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_function_example_self_checks(repo_root, tmp_path, variant):
     """example/autodiff/function.example.cpp asserts TestJacobian / TestHessian (finite differences) itself."""
-    _run(repo_root, "function", tmp_path, 600)
+    _run(repo_root, "function", tmp_path, 600, variant)
 
 
 QP_LINE = re.compile(r"t = ([\d.]+), obj = ([-\d.e+]+), eqs = ([-\d.e+]+), ineqs = ([-\d.e+]+) \(\d+\), z ref = ([-\d.]+), z = ([-\d.]+), "
@@ -67,11 +76,12 @@ QP_LINE = re.compile(r"t = ([\d.]+), obj = ([-\d.e+]+), eqs = ([-\d.e+]+), ineqs
 
 
 @pytest.mark.gpu
-def test_quadruped_example_trots_and_tracks(repo_root, tmp_path):
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_quadruped_example_trots_and_tracks(repo_root, tmp_path, variant):
     """quadruped.example.cpp (single-rigid-body quadruped, friction cones, contact schedule): the base must
     keep its height and follow the yaw ramp while exactly one diagonal leg pair carries the weight."""
     import math
-    rows = [tuple(map(float, m.groups())) for m in map(QP_LINE.search, _run(repo_root, "quadruped", tmp_path, 1500).splitlines()) if m]
+    rows = [tuple(map(float, m.groups())) for m in map(QP_LINE.search, _run(repo_root, "quadruped", tmp_path, 1500, variant).splitlines()) if m]
     assert len(rows) >= 290
     late = [r for r in rows if r[0] > 5.0]
     assert max(abs(r[2]) for r in late) < 0.1 and max(r[3] for r in late) < 1e-2

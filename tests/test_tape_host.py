@@ -49,3 +49,19 @@ def test_operations_unsupported_on_recorded_scalars_do_not_compile(repo_root, tm
     r = subprocess.run(["g++", "-std=c++20", "-fsyntax-only", "-I", os.path.join(repo_root, "ungar_amd", "include"), str(ok)], capture_output=True, text=True,
                        timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
+
+
+def test_facade_on_the_real_eigen(repo_root):
+    """UNGAR_AMD_USE_SYSTEM_EIGEN (ungar/linalg.hpp): the facade's vector / quaternion / sparse types are the REAL Eigen 3.4's --
+    what an existing Ungar installation has in every translation unit.  The reference bundles Eigen as a zip; where it was
+    present at build time, the helper test and the optimisation-layer test were also built on it and must pass unchanged
+    (the reference's own examples built the same way are run by tests/test_reference_examples.py)."""
+    eigen = os.path.join(os.environ.get("TMPDIR", "/tmp"), "ungar_amd_reference_eigen", "eigen-3.4.0")
+    exe = os.path.join(repo_root, "build", "optimization_test_eigen")
+    if not os.path.exists(exe):
+        pytest.skip("the real-Eigen build needs the reference's bundled Eigen at build time")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "PASSED" in r.stdout, r.stdout[-2000:]
+    if os.path.isdir(os.path.join(eigen, "Eigen")):
+        _build_and_run(repo_root, "helpers_test", extra=("-DUNGAR_AMD_USE_SYSTEM_EIGEN", "-I", eigen))
+        os.remove(os.path.join(repo_root, "build", "helpers_test"))  # the next run rebuilds the default (built-in algebra) variant

@@ -21,7 +21,7 @@ LIBDIR = os.path.join(ROOT, "ungar_amd", "lib")
 LIB = os.path.join(LIBDIR, "libungar_amd.so")
 ORACLE_GEN = os.path.join(ROOT, "oracle", "_gen")
 RBD_MODELS = ("anymal_rnea", "anymal_crba", "anymal_minv", "anymal_feet", "anymal_centroidal")
-MODELS = ("quadrotor", "rc_car", "srbd", "srbd_ineq", "quadrotor_ineq", "anymal", "anymal_ad", "anymal_reg") + RBD_MODELS
+MODELS = ("quadrotor", "rc_car", "srbd", "srbd_ineq", "quadrotor_ineq", "rc_car_ineq", "srbd_feet", "anymal", "anymal_ad", "anymal_reg") + RBD_MODELS
 C_MODELS = ("quadrotor", "rc_car", "srbd", "anymal", "anymal_ad") + RBD_MODELS
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-Wno-unused-result"]
 
@@ -64,7 +64,7 @@ def generate(exe: str):
     edit to the generator recompiles just the kernels it affects (a from-scratch library build takes ~6 minutes)."""
     import filecmp
     import shutil
-    outs = [os.path.join(GEN, f"{m}_gen.hpp") for m in MODELS + ("quadrotor_cost", "srbd_cost")] + [os.path.join(ORACLE_GEN, f"{m}_cg.c") for m in C_MODELS]
+    outs = [os.path.join(GEN, f"{m}_gen.hpp") for m in MODELS + ("quadrotor_cost", "srbd_cost", "rc_car_cost")] + [os.path.join(ORACLE_GEN, f"{m}_cg.c") for m in C_MODELS]
     robot = os.path.join(ROOT, "ungar_amd", "data", "anymal_b.robot")
     stamp = os.path.join(BUILD, "codegen.stamp")
     if _newer(outs + [stamp], [exe, robot]):
@@ -157,6 +157,28 @@ def build_cpp_tests():
         if link:
             cmd += ["-L", LIBDIR, "-lungar_amd", "-Wl,-rpath,$ORIGIN/../ungar_amd/lib", "-Wl,-rpath,/opt/rocm/lib"]
         jobs.append(cmd)
+    # reference-side adapter of INTEGRATION.md section 2 (include/ungar_amd_model.hpp): plain C++17, no facade headers
+    amd_src, amd_exe = os.path.join(ROOT, "tests", "cpp", "amd_model_test.cpp"), os.path.join(BUILD, "amd_model_test")
+    if not _newer([amd_exe], [amd_src, os.path.join(ROOT, "include", "ungar_amd_model.hpp"), os.path.join(ROOT, "include", "ungar_amd.h"), LIB]):
+        jobs.append(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-o", amd_exe, amd_src, "-L", LIBDIR, "-lungar_amd", "-Wl,-rpath,$ORIGIN/../ungar_amd/lib",
+                     "-Wl,-rpath,/opt/rocm/lib"])
+    # the same facade tests on the REAL Eigen 3.4 bundled with the reference (UNGAR_AMD_USE_SYSTEM_EIGEN), where it is present
+    ref = os.environ.get("UNGAR_REFERENCE", "/root/reference")
+    eigen_zip = os.path.join(ref, "external", "config", "eigen", "eigen-3.4.0.zip")
+    if os.path.exists(eigen_zip):
+        scratch = os.path.join(os.environ.get("TMPDIR", "/tmp"), "ungar_amd_reference_eigen")
+        if not os.path.isdir(os.path.join(scratch, "eigen-3.4.0", "Eigen")):
+            os.makedirs(scratch, exist_ok=True)
+            _run(["unzip", "-q", "-o", eigen_zip, "-d", scratch])
+        for name, link in (("function_test", True), ("quadrotor_ocp_test", True), ("optimization_test", False)):
+            src = os.path.join(ROOT, "tests", "cpp", f"{name}.cpp")
+            exe = os.path.join(BUILD, name + "_eigen")
+            if _newer([exe], [src, *hdrs] + ([LIB] if link else [])):
+                continue
+            cmd = ["g++", "-std=c++20", "-O1", "-DUNGAR_AMD_USE_SYSTEM_EIGEN", "-I", os.path.join(scratch, "eigen-3.4.0"), "-I", inc, "-o", exe, src]
+            if link:
+                cmd += ["-L", LIBDIR, "-lungar_amd", "-Wl,-rpath,$ORIGIN/../ungar_amd/lib", "-Wl,-rpath,/opt/rocm/lib"]
+            jobs.append(cmd)
     # 4-lane CPU simulator of the lane-per-leg program (tests/test_quad_program.py)
     sim_src, sim_lib = os.path.join(ROOT, "tests", "cpp", "quad_sim.cpp"), os.path.join(BUILD, "libquad_sim.so")
     quad_gen = os.path.join(GEN, "anymal_quad_gen.hpp")
@@ -176,8 +198,10 @@ def build_reference_examples(names=("quadrotor", "rc_car", "quadruped", "functio
     for n in names:
         cands = [os.path.join(ref, "example", sub, f"{n}.example.cpp") for sub in ("mpc", "autodiff", "")]
         src = next((c for c in cands if os.path.exists(c)), cands[0])
-        exe = os.path.join(ROOT, "oracle", "_ref", f"{n}_example")
-        if os.path.exists(src) and not _newer([exe], [src, LIB] + _tree(os.path.join(ROOT, "ungar_amd", "include"))):
+        exes = [os.path.join(ROOT, "oracle", "_ref", f"{n}_example")]
+        if os.path.exists(os.path.join(ref, "external", "config", "eigen", "eigen-3.4.0.zip")):
+            exes.append(exes[0] + "_eigen")  # second build on the real Eigen the reference bundles
+        if os.path.exists(src) and not _newer(exes, [src, LIB, script] + _tree(os.path.join(ROOT, "ungar_amd", "include"))):
             todo.append(n)
     if todo:
         _run(["bash", script, *todo])

@@ -474,6 +474,8 @@ int main(int argc, char** argv) {
     specs.push_back({models::kSrbdDims, [](auto... a) { models::SrbdNode<AD>(a...); }});
     specs.push_back({models::kSrbdIneqDims, [](auto... a) { models::SrbdIneqNode<AD>(a...); }});
     specs.push_back({models::kQuadrotorIneqDims, [](auto... a) { models::QuadrotorIneqNode<AD>(a...); }});
+    specs.push_back({models::kRcCarIneqDims, [](auto... a) { models::RcCarIneqNode<AD>(a...); }});
+    specs.push_back({models::kSrbdFeetDims, [](auto... a) { models::SrbdFeetNode<AD>(a...); }});
     rbd::Model anymal;
     if (!robot.empty()) {
         anymal = rbd::BuildModel(rbd::ReadRobotDescription(robot));
@@ -582,6 +584,9 @@ int main(int argc, char** argv) {
         keep = only.empty();
         for (const auto& o : only) keep = keep || o == models::kSrbdCostDims.name;
         if (keep) EmitCostHip(models::kSrbdCostDims, models::SrbdCostNode<AD>, outDir);
+        keep = only.empty();
+        for (const auto& o : only) keep = keep || o == models::kRcCarCostDims.name;
+        if (keep) EmitCostHip(models::kRcCarCostDims, models::RcCarCostNode<AD>, outDir);
     }
     return 0;
 }

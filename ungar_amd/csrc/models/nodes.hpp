@@ -41,6 +41,13 @@ inline constexpr NodeDims kSrbdCostDims{"srbd_cost", 13, 24, 0, 25};
 /// Scalar stage cost of the quadrotor OCP (one output): p = [p_ref(3), q_ref(4), v_ref(3), omega_ref(3)].
 inline constexpr NodeDims kQuadrotorCostDims{"quadrotor_cost", 13, 4, 0, 13};
 inline constexpr NodeDims kSrbdDims{"srbd", 13, 24, 4, 6};
+/// Scalar stage cost of the RC-car OCP (rc_car.example.cpp:204-222 per knot): p = [reference_position(2)].
+inline constexpr NodeDims kRcCarCostDims{"rc_car_cost", 6, 2, 0, 2};
+/// Inequality rows of one knot of the RC-car OCP (rc_car.example.cpp:271-282): [|d| - 15, |delta| - 15, 0.3 - v_x].
+inline constexpr NodeDims kRcCarIneqDims{"rc_car_ineq", 6, 2, 0, 0, 3};
+/// World positions of the four feet, p + q * r_i (12 outputs): the node-local part of the quadruped OCP's foot-contact
+/// equality rows (quadruped.example.cpp:279-304), which combine the feet of knots k and k - 1 with the contact flags.
+inline constexpr NodeDims kSrbdFeetDims{"srbd_feet", 13, 24, 0, 0, 12};
 /// Inequality rows of one knot of the quadrotor OCP, h(u; p) <= 0: per rotor [r - r_max, -r] (8 outputs); p = [max_rotor_speed].
 inline constexpr NodeDims kQuadrotorIneqDims{"quadrotor_ineq", 13, 4, 0, 1, 8};
 inline constexpr NodeDims kAnymalDims{"anymal", 37, 12, 0, 1};
@@ -228,6 +235,34 @@ void QuadrotorIneqNode(const S* /*x*/, const S* u, const S* /*w*/, const S* p, S
     for (int i = 0; i < 4; ++i) {
         h[2 * i] = u[i] - p[0];
         h[2 * i + 1] = -u[i];
+    }
+}
+
+/// Stage cost of example/mpc/rc_car.example.cpp:204-222 for one knot: reference position tracking plus the input
+/// regularisation 1e-6 |u|^2; the input-VARIATION term (:216-220) couples u_k with u_{k-1} and lives in the whole-horizon function.
+template <class S>
+void RcCarCostNode(const S* x, const S* u, const S* /*w*/, const S* p, S* y) {
+    y[0] = (x[0] - p[0]) * (x[0] - p[0]) + (x[1] - p[1]) * (x[1] - p[1]) + 1e-6 * (u[0] * u[0] + u[1] * u[1]);
+}
+
+/// Inequality constraints of example/mpc/rc_car.example.cpp:271-282 for one knot: input bounds through Utils::Abs and the
+/// minimum forward velocity.
+template <class S>
+void RcCarIneqNode(const S* x, const S* u, const S* /*w*/, const S* /*p*/, S* h) {
+    using std::abs;
+    h[0] = abs(u[0]) - 15.0;
+    h[1] = abs(u[1]) - 15.0;
+    h[2] = 0.3 - x[3];
+}
+
+/// pFoot_i = p + q * r_i for the four legs (quadruped.example.cpp:288-291), u = 4 x [f(3), r(3)] as in SrbdNode.
+template <class S>
+void SrbdFeetNode(const S* x, const S* u, const S* /*w*/, const S* /*p*/, S* y) {
+    const Vec3<S> pos{x[0], x[1], x[2]};
+    const Quat<S> q{x[3], x[4], x[5], x[6]};
+    for (int i = 0; i < 4; ++i) {
+        const Vec3<S> foot = Add(pos, Rotate(q, Vec3<S>{u[6 * i + 3], u[6 * i + 4], u[6 * i + 5]}));
+        for (std::size_t k = 0; k < 3; ++k) y[3 * i + k] = foot[k];
     }
 }
 

@@ -35,6 +35,44 @@ constexpr bool operator&(const EnabledDerivatives a, const EnabledDerivatives b)
 
 }  // namespace Ungar
 
+#if defined(UNGAR_AMD_USE_SYSTEM_EIGEN)
+// ---- hooks real Eigen documents for custom scalar types (https://eigen.tuxfamily.org/dox/TopicCustomizing_CustomScalar.html)
+namespace Eigen {
+template <>
+struct NumTraits<::ungar_amd::tape::AD> : GenericNumTraits<::ungar_amd::tape::AD> {
+    using Real = ::ungar_amd::tape::AD;
+    using NonInteger = ::ungar_amd::tape::AD;
+    using Nested = ::ungar_amd::tape::AD;
+    using Literal = double;
+    enum { IsComplex = 0, IsInteger = 0, IsSigned = 1, RequireInitialization = 1, ReadCost = 1, AddCost = 2, MulCost = 2 };
+    static Real epsilon() { return Real{std::numeric_limits<double>::epsilon()}; }
+    static Real dummy_precision() { return Real{1e-12}; }
+    static Real highest() { return Real{std::numeric_limits<double>::max()}; }
+    static Real lowest() { return Real{std::numeric_limits<double>::lowest()}; }
+    static int digits10() { return std::numeric_limits<double>::digits10; }
+};
+// mixed recorded / real arithmetic keeps the recorded type (Eigen asks for this per binary operation)
+template <class BinaryOp>
+struct ScalarBinaryOpTraits<::ungar_amd::tape::AD, double, BinaryOp> {
+    using ReturnType = ::ungar_amd::tape::AD;
+};
+template <class BinaryOp>
+struct ScalarBinaryOpTraits<double, ::ungar_amd::tape::AD, BinaryOp> {
+    using ReturnType = ::ungar_amd::tape::AD;
+};
+}  // namespace Eigen
+
+namespace ungar_amd::tape {
+// the coefficient-wise helpers Eigen looks up by argument-dependent lookup on a custom scalar
+inline const AD& conj(const AD& x) { return x; }
+inline const AD& real(const AD& x) { return x; }
+inline AD imag(const AD&) { return AD{0.0}; }
+inline AD abs2(const AD& x) { return x * x; }
+inline bool isfinite(const AD&) { return true; }
+}  // namespace ungar_amd::tape
+
+#include "support/quaternion.hpp"  // AD-safe inverse / normalize(d) / slerp, as in the reference's autodiff/support/quaternion.hpp
+#else
 namespace Eigen {
 template <>
 struct NumTraits<::ungar_amd::tape::AD> {
@@ -43,3 +81,4 @@ struct NumTraits<::ungar_amd::tape::AD> {
     }
 };
 }  // namespace Eigen
+#endif

@@ -31,7 +31,7 @@
 namespace Ungar {
 namespace Autodiff {
 
-using SparseMatrix = Eigen::SparseMatrixCsr<real_t>;
+using SparseMatrix = Linalg::SparseView<real_t>;  // Eigen::Map<const Eigen::SparseMatrix<real_t, RowMajor>> on real Eigen (reference :217, :237)
 
 class Function {
   public:
@@ -66,7 +66,8 @@ class Function {
     void Evaluate(const Eigen::MatrixBase<XP>& xp, const Eigen::MatrixBase<Y>& y) const {
         CheckInput(xp.size());
         if (y.size() != _m) throw std::invalid_argument("Function::Evaluate: wrong output size");
-        Check(ungar_function_eval_host(_fn.get(), 0, xp.derived().data(), y.const_cast_derived().data()));
+        const auto& in = xp.derived().eval();  // contiguous storage (the reference reads xp.derived().data(), function.hpp:187)
+        Check(ungar_function_eval_host(_fn.get(), 0, in.data(), y.const_cast_derived().data()));
     }
     template <class XP>
     VectorXr operator()(const Eigen::MatrixBase<XP>& xp) const {
@@ -80,8 +81,9 @@ class Function {
     const SparseMatrix& Jacobian(const Eigen::MatrixBase<XP>& xp) const {
         if (!ImplementsJacobian()) throw std::logic_error("Function::Jacobian: function was made without JACOBIAN");
         CheckInput(xp.size());
-        Check(ungar_function_eval_host(_fn.get(), 1, xp.derived().data(), _jacData.data()));
-        return _jac;
+        const auto& in = xp.derived().eval();
+        Check(ungar_function_eval_host(_fn.get(), 1, in.data(), _jacData.data()));
+        return *_jac;
     }
     /// Upper-triangular n x n Hessian of dependent variable `i` (scalar functions only, :236-259).
     template <class XP>
@@ -89,8 +91,9 @@ class Function {
         if (!ImplementsHessian()) throw std::logic_error("Function::Hessian: function was made without HESSIAN");
         if (dependentVariableIndex != 0 || _m != 1) throw std::logic_error("The Hessian is implemented only for scalar functions.");
         CheckInput(xp.size());
-        Check(ungar_function_eval_host(_fn.get(), 2, xp.derived().data(), _hesData.data()));
-        return _hes;
+        const auto& in = xp.derived().eval();
+        Check(ungar_function_eval_host(_fn.get(), 2, in.data(), _hesData.data()));
+        return *_hes;
     }
     template <class XP>
     const SparseMatrix& Hessian(const Eigen::MatrixBase<XP>& xp) const {
@@ -117,7 +120,7 @@ class Function {
             z[j] = x0;
             for (index_t i = 0; i < _m; ++i) fd[static_cast<std::size_t>(i * _n + j)] = (yp[i] - ym[i]) / (2 * epsilon);
         }
-        const std::vector<real_t> ad = Jacobian(xp).toDense();
+        const std::vector<real_t> ad = Linalg::ToDense(Jacobian(xp));
         return Utils::CompareMatrices(ad.data(), "Autodiff Jacobian", fd.data(), "FD Jacobian", _m * _n);
     }
     template <class XP>
@@ -139,7 +142,7 @@ class Function {
                 fd[static_cast<std::size_t>(r * _n + c)] =
                     (f(r, epsilon, c, epsilon) - f(r, epsilon, c, -epsilon) - f(r, -epsilon, c, epsilon) + f(r, -epsilon, c, -epsilon)) /
                     (4 * epsilon * epsilon);
-        const std::vector<real_t> ad = Hessian(xp).toDense();  // upper triangle only
+        const std::vector<real_t> ad = Linalg::ToDense(Hessian(xp));  // upper triangle only
         return Utils::CompareMatrices(ad.data(), "Autodiff Hessian", fd.data(), "FD Hessian", _n * _n);
     }
 
@@ -197,7 +200,7 @@ class Function {
     bool _hasJac = false, _hasHes = false, _cacheHit = false;
     std::vector<int> _jacStarts, _jacIdx, _hesStarts, _hesIdx;
     mutable std::vector<real_t> _jacData, _hesData;
-    SparseMatrix _jac, _hes;
+    std::unique_ptr<SparseMatrix> _jac, _hes;  // views over the index / value arrays above (an Eigen::Map is not assignable)
 };
 
 class FunctionFactory {
@@ -251,13 +254,13 @@ class FunctionFactory {
             Function::Check(ungar_function_jacobian_sparsity(raw, &rows, &cols, &nnz));
             f.BuildCsr(rows, cols, nnz, f._m, f._jacStarts, f._jacIdx);
             f._jacData.assign(static_cast<std::size_t>(nnz), 0.0);
-            f._jac = SparseMatrix{f._m, f._n, f._jacStarts.data(), f._jacIdx.data(), f._jacData.data()};
+            f._jac = std::make_unique<SparseMatrix>(Linalg::MakeSparseView<real_t>(f._m, f._n, nnz, f._jacStarts.data(), f._jacIdx.data(), f._jacData.data()));
         }
         if (f._hasHes) {
             Function::Check(ungar_function_hessian_sparsity(raw, &rows, &cols, &nnz));
             f.BuildCsr(rows, cols, nnz, f._n, f._hesStarts, f._hesIdx);
             f._hesData.assign(static_cast<std::size_t>(nnz), 0.0);
-            f._hes = SparseMatrix{f._n, f._n, f._hesStarts.data(), f._hesIdx.data(), f._hesData.data()};
+            f._hes = std::make_unique<SparseMatrix>(Linalg::MakeSparseView<real_t>(f._n, f._n, nnz, f._hesStarts.data(), f._hesIdx.data(), f._hesData.data()));
         }
         return f;
     }

@@ -13,7 +13,7 @@ namespace Autodiff {
 class VectorComposer {
   public:
     template <class V>
-        requires std::is_same_v<typename V::S, ad_scalar_t>
+        requires std::is_same_v<std::remove_const_t<typename V::Scalar>, ad_scalar_t>
     VectorComposer& operator<<(const Eigen::MatrixBase<V>& vector) {
         for (index_t i = 0; i < vector.size(); ++i) _impl.push_back(vector[i]);
         return *this;

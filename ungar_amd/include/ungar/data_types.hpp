@@ -2,6 +2,7 @@
 #pragma once
 
 #include <string>
+#include <vector>
 #include <string_view>
 
 #include "assert.hpp"
@@ -39,10 +40,21 @@ using MapToQuaternionr = Eigen::Map<Quaternionr>;
 using MapToConstQuaternionr = Eigen::Map<const Quaternionr>;
 
 template <class S>
-using MatrixX = Eigen::DenseMatrix<S>;
+using MatrixX = Linalg::DenseMatrix<S>;
 using MatrixXr = MatrixX<real_t>;
 template <class S>
-using SparseMatrix = Eigen::SparseMatrixCsr<S>;  // row-major compressed view (function.hpp:375-383)
+using SparseMatrix = Linalg::SparseView<S>;  // row-major compressed view (function.hpp:375-383)
+
+namespace Linalg {
+/// Row-major dense copy of a compressed row-major sparse matrix (either algebra: the accessors share Eigen's names).
+template <class Sparse>
+inline std::vector<real_t> ToDense(const Sparse& m) {
+    std::vector<real_t> d(static_cast<std::size_t>(m.rows() * m.cols()), 0.0);
+    for (index_t r = 0; r < m.rows(); ++r)
+        for (int k = m.outerIndexPtr()[r]; k < m.outerIndexPtr()[r + 1]; ++k) d[static_cast<std::size_t>(r * m.cols() + m.innerIndexPtr()[k])] = m.valuePtr()[k];
+    return d;
+}
+}  // namespace Linalg
 
 namespace Concepts {
 template <class T>

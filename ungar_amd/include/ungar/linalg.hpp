@@ -10,7 +10,17 @@
 // Evaluation is eager (no expression templates): the scalar is usually an AD handle whose
 // operations are recorded once, so laziness buys nothing.  Formulas that define recorded
 // arithmetic (quaternion product, quaternion * vector) follow Eigen's, see models/small_math.hpp.
+//
+// UNGAR_AMD_USE_SYSTEM_EIGEN: a project that already builds against the real Eigen (every real Ungar installation does:
+// the reference bundles Eigen 3.4, external/config/eigen/) defines this macro and gets linalg_system_eigen.hpp instead --
+// the facade's types then ARE Eigen's, `namespace Eigen` is not touched by this project beyond the scalar-type hooks Eigen
+// documents for custom scalars, and Function::Jacobian returns the reference's own
+// Eigen::Map<const Eigen::SparseMatrix<real_t, Eigen::RowMajor>> (function.hpp:217, 237).
 #pragma once
+
+#if defined(UNGAR_AMD_USE_SYSTEM_EIGEN)
+#include "linalg_system_eigen.hpp"
+#else
 
 #include <array>
 #include <ostream>
@@ -1042,3 +1052,17 @@ class SparseMatrixCsr {
 };
 
 }  // namespace Eigen
+
+namespace Ungar::Linalg {
+/// Names the facade uses for the two matrix types whose spelling differs between the built-in algebra and real Eigen.
+template <class S>
+using DenseMatrix = Eigen::DenseMatrix<S>;
+template <class S>
+using SparseView = Eigen::SparseMatrixCsr<S>;  // row-major compressed view over (row starts, column indices, values)
+template <class S>
+inline SparseView<S> MakeSparseView(std::ptrdiff_t rows, std::ptrdiff_t cols, std::ptrdiff_t /*nnz*/, const int* starts, const int* indices, const S* values) {
+    return SparseView<S>{rows, cols, starts, indices, values};
+}
+}  // namespace Ungar::Linalg
+
+#endif  // UNGAR_AMD_USE_SYSTEM_EIGEN

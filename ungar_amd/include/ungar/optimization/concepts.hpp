@@ -55,13 +55,13 @@ class IdleTwiceDifferentiableFunction {
     template <class XP>
     Autodiff::SparseMatrix Jacobian(const XP& xp) const {
         Check(xp.size());
-        return Autodiff::SparseMatrix{0, _n, kNoStarts, nullptr, nullptr};
+        return Linalg::MakeSparseView<real_t>(0, _n, 0, kNoStarts, kNoIndices, kNoValues);
     }
     template <class XP>
     Autodiff::SparseMatrix Hessian(const index_t dependentVariableIndex, const XP& xp) const {
         Check(xp.size());
         if (dependentVariableIndex != 0) throw std::invalid_argument("IdleTwiceDifferentiableFunction: dependent variable index must be 0");
-        return Autodiff::SparseMatrix{};
+        return Linalg::MakeSparseView<real_t>(0, 0, 0, kNoStarts, kNoIndices, kNoValues);
     }
     index_t IndependentVariableSize() const {
         return _n;
@@ -78,6 +78,8 @@ class IdleTwiceDifferentiableFunction {
         if (size != _n + _p) throw std::invalid_argument("IdleTwiceDifferentiableFunction: xp must hold independent variables followed by parameters");
     }
     static inline const int kNoStarts[1] = {0};
+    static inline const int kNoIndices[1] = {0};
+    static inline const real_t kNoValues[1] = {0.0};
     index_t _n, _p;
 };
 

@@ -25,15 +25,15 @@ template <class T>
 inline constexpr bool is_ad_v = std::is_same_v<std::remove_cvref_t<T>, ad_scalar_t>;
 
 template <class V>
-inline typename V::S ApproximateNorm(const Eigen::MatrixBase<V>& v) {
-    using S = typename V::S;
+inline std::remove_const_t<typename V::Scalar> ApproximateNorm(const Eigen::MatrixBase<V>& v) {
+    using S = std::remove_const_t<typename V::Scalar>;
     using std::sqrt;
     return sqrt(v.squaredNorm() + Eigen::NumTraits<S>::epsilon());
 }
 
 template <class V>
-inline Quaternion<typename V::S> ApproximateExponentialMap(const Eigen::MatrixBase<V>& v) {
-    using S = typename V::S;
+inline Quaternion<std::remove_const_t<typename V::Scalar>> ApproximateExponentialMap(const Eigen::MatrixBase<V>& v) {
+    using S = std::remove_const_t<typename V::Scalar>;
     using std::cos;
     using std::sin;
     Quaternion<S> q;
@@ -46,7 +46,7 @@ inline Quaternion<typename V::S> ApproximateExponentialMap(const Eigen::MatrixBa
 /// Exact exponential map; real scalars only (the reference static_asserts on AD, utils.hpp:704-707).
 template <class V>
 inline Quaternion<real_t> ExponentialMap(const Eigen::MatrixBase<V>& v) {
-    static_assert(std::is_same_v<typename V::S, real_t>, "ExponentialMap is not implemented for AD scalars; use ApproximateExponentialMap");
+    static_assert(std::is_same_v<std::remove_const_t<typename V::Scalar>, real_t>, "ExponentialMap is not implemented for AD scalars; use ApproximateExponentialMap");
     const real_t n = v.norm();
     if (n == 0.0) return Quaternion<real_t>::Identity();
     const real_t s = std::sin(0.5 * n) / n;
@@ -118,7 +118,7 @@ inline Quaternion<S> ElementaryZQuaternion(const S& angle) {
 /// with the yaw folded into [0, pi]; tape scalars use the branch-free atan2 form (utils.hpp:956-966).
 template <class Q>
 inline auto QuaternionToYawPitchRoll(const Eigen::QuaternionBase<Q>& q) {
-    using S = typename Eigen::QuaternionBase<Q>::S;
+    using S = std::remove_const_t<typename Eigen::QuaternionBase<Q>::Scalar>;
     using std::atan2;
     using std::cos;
     using std::sin;

@@ -59,7 +59,8 @@ class VariableLazyMap {
 template <class Underlying, Concepts::Variable Var>
 auto MakeVariableLazyMap(Underlying& underlying, const Var& var) {
     using S = std::remove_const_t<typename std::remove_cvref_t<Underlying>::Scalar>;
-    constexpr bool mut = !std::is_const_v<Underlying> && !std::is_const_v<typename Eigen::Traits<std::remove_cvref_t<Underlying>>::Scalar>;
+    // writable iff the buffer is not const and does not view const data (a Map<const ...>): decided by what data() returns
+    constexpr bool mut = !std::is_const_v<Underlying> && !std::is_const_v<std::remove_pointer_t<decltype(underlying.data())>>;
     assert(underlying.size() == Var::Size());
     return VariableLazyMap<S, Var, mut>{underlying.data(), var};
 }
