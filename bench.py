@@ -122,10 +122,26 @@ def cpu_baseline(name, native: NativeOracleBuild | None, seconds=10.0, patience=
                      f"({'compiled on this box' if tag == 'native' else 'prebuilt portable library: native build unavailable'}), 1 thread",
            "sweeps": structured["sweeps"],
            "all_cores": {"value": share * len(threads) * reps / dt_all, "cores": len(threads), "seconds": dt_all}}
+    out["genuine_reference"] = genuine_reference_timing(min(seconds, 5.0))
     if taped:
         out["taped_aba"] = {"value": taped["value"], "sweeps": taped["sweeps"], "nnz": taped["nnz"],
                             "note": "same node function, derivatives by taping ABA (test/rbd/robot.test.cpp:124-135) -- the reference's own route"}
     return out
+
+
+def genuine_reference_timing(seconds):
+    """BASELINE.md section 3.2 / SURVEY.md section 8(d): where the reference's own stack is installed (<cppad/cg.hpp>), build and time the
+    REAL Ungar::Autodiff::Function (oracle/ref_timing/); otherwise say so.  In this image the stack is absent."""
+    import subprocess
+    script = os.path.join(ROOT, "oracle", "ref_timing", "build_reference_timing.sh")
+    try:
+        probe = subprocess.run(["bash", script], capture_output=True, text=True, timeout=600)
+        if probe.returncode != 0:
+            return (probe.stdout.strip().splitlines() or ["unavailable"])[-1]
+        run = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "time_reference_function"), str(seconds)], capture_output=True, text=True, timeout=120 + 4 * seconds)
+        return json.loads(run.stdout.strip().splitlines()[-1]) if run.returncode == 0 else "unavailable: the genuine-reference program failed at run time"
+    except Exception as exc:  # noqa: BLE001
+        return f"unavailable: {exc!r}"
 
 
 # ------------------------------------------------------------------------------------------------ GPU measurement
