@@ -8,18 +8,40 @@
 using namespace ungar_amd::kernels;
 
 namespace {
+template <bool PREFETCH>
 struct HostExec {
+    static constexpr bool kPrefetch = PREFETCH;
+    using StageAB = std::vector<double>;
+    using StageW = std::vector<double>;
+    using StageV = std::vector<double>;
     template <class F>
     void ForEach(int n, F f) {
         for (int i = 0; i < n; ++i) f(i);
+    }
+    void GlobalSync() {}
+    void Barrier() {}
+    template <class F>
+    void Fetch(int n, F f, std::vector<double>& s) {
+        s.resize(static_cast<std::size_t>(n));
+        for (int i = 0; i < n; ++i) s[static_cast<std::size_t>(i)] = f(i);
+    }
+    void Commit(int n, const std::vector<double>& s, double* dst) {
+        for (int i = 0; i < n; ++i) dst[i] = s[static_cast<std::size_t>(i)];
     }
 };
 }  // namespace
 
 /// Node-major contiguous arrays: jac [batch][N][nx*(nx+nu)], b [batch][N][nx], hess [batch][N][n*n], grad [batch][N][n],
 /// hessN [batch][nx*nx] (or null), gradN [batch][nx] (or null), dx0 [batch][nx]; outputs dX [batch][N+1][nx], dU [batch][N][nu].
+/// prefetch != 0 runs the variant that stages the next knot's operands (what the device kernel does for small problems).
+extern "C" int riccati_host_solve_variant(int prefetch, int nx, int nu, int N, long long batch, double* jac, double* b, double* hess, double* grad, double* hessN,
+                                          double* gradN, double* dx0, double regularization, double* dX, double* dU, int* status);
 extern "C" int riccati_host_solve(int nx, int nu, int N, long long batch, double* jac, double* b, double* hess, double* grad, double* hessN, double* gradN,
                                   double* dx0, double regularization, double* dX, double* dU, int* status) {
+    return riccati_host_solve_variant(1, nx, nu, N, batch, jac, b, hess, grad, hessN, gradN, dx0, regularization, dX, dU, status);
+}
+extern "C" int riccati_host_solve_variant(int prefetch, int nx, int nu, int N, long long batch, double* jac, double* b, double* hess, double* grad, double* hessN, double* gradN,
+                                          double* dx0, double regularization, double* dX, double* dU, int* status) {
     const int n = nx + nu;
     std::vector<double> gains(static_cast<std::size_t>(batch) * N * nu * (nx + 1));
     RiccatiArgs a{nx, nu, N, batch,
@@ -34,7 +56,12 @@ extern "C" int riccati_host_solve(int nx, int nu, int N, long long batch, double
                   {dU, static_cast<long long>(N) * nu, nu, 1},
                   gains.data(), regularization, status};
     std::vector<double> scratch(static_cast<std::size_t>(RiccatiScratchDoubles(nx, nu)));
-    HostExec ex;
-    for (long long i = 0; i < batch; ++i) RiccatiInstance(a, i, scratch.data(), ex);
+    if (prefetch) {
+        HostExec<true> ex;
+        for (long long i = 0; i < batch; ++i) RiccatiInstance(a, i, scratch.data(), ex);
+    } else {
+        HostExec<false> ex;
+        for (long long i = 0; i < batch; ++i) RiccatiInstance(a, i, scratch.data(), ex);
+    }
     return 0;
 }

@@ -114,6 +114,23 @@ def test_riccati_recursion_equals_the_dense_kkt_solve(host, nx, nu, N):
                 assert np.abs(dX[i, k + 1] - q["AB"][i, k] @ np.r_[dX[i, k], dU[i, k]] - q["b"][i, k]).max() < 1e-10 * max(1.0, np.abs(dX[i]).max())
 
 
+def test_prefetching_variant_is_bitwise_the_same_recursion(host):
+    """The device kernel stages the next knot's operands in registers for small problems; the staged and the in-place variant
+    of the shared source must produce identical bits."""
+    rng = np.random.default_rng(9)
+    nx, nu, N = 13, 4, 12
+    q = random_qp(rng, nx, nu, N, 2)
+    dp = ctypes.POINTER(ctypes.c_double)
+    p = lambda a: a.ctypes.data_as(dp)  # noqa: E731
+    out = []
+    for variant in (0, 1):
+        dX, dU, st = np.zeros((2, N + 1, nx)), np.zeros((2, N, nu)), np.zeros(2, dtype=np.int32)
+        host.riccati_host_solve_variant(variant, nx, nu, N, ctypes.c_longlong(2), p(q["AB"]), p(q["b"]), p(q["W"]), p(q["w"]), p(q["WN"]), p(q["wN"]), p(q["dx0"]),
+                                        ctypes.c_double(1e-6), p(dX), p(dU), st.ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
+        out.append((dX, dU))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
 def test_riccati_reports_an_indefinite_reduced_hessian(host):
     rng = np.random.default_rng(1)
     q = random_qp(rng, 4, 2, 6, 2)

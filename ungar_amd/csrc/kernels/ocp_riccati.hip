@@ -5,6 +5,9 @@
 // instances are independent, so a launch of thousands of them fills the device.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+#include <string>
+
 #include "ocp_sqp.hpp"
 
 namespace ungar_amd::kernels {
@@ -13,21 +16,60 @@ namespace {
 
 constexpr int kBlock = 64;
 
-/// Lanes of the workgroup stride over the index range and meet at a barrier.
+/// Lanes of the workgroup stride over the index range and meet at a barrier.  SLOTS_AB / SLOTS_W: registers per lane that
+/// stage the next knot's [A|B] block and stage Hessian (64 * SLOTS doubles each); 0 = read the operands in place.
+template <int BLOCK, int SLOTS_AB, int SLOTS_W>
 struct DeviceExec {
+    static constexpr bool kPrefetch = SLOTS_AB > 0;
+    template <int K>
+    struct Stage {
+        double r[K > 0 ? K : 1];
+    };
+    using StageAB = Stage<SLOTS_AB>;
+    using StageW = Stage<SLOTS_W>;
+    using StageV = Stage<1>;
+
+    /// Workgroup barrier that orders LDS traffic only (s_waitcnt lgkmcnt(0); s_barrier): __syncthreads() also waits for
+    /// vmcnt(0), i.e. for every global load in flight -- which would serialise the prefetch of the next knot's operands with the
+    /// first phase of the current one (measured: the staged variant was SLOWER than reading in place, 1.03 vs 0.75 ms).
+    static __device__ __forceinline__ void LdsBarrier() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    }
+    /// Full barrier: global writes of the workgroup (the gains) become visible to its own later reads.
+    static __device__ __forceinline__ void GlobalSync() { __syncthreads(); }
     template <class F>
     __device__ __forceinline__ void ForEach(int n, F f) {
-        for (int i = static_cast<int>(threadIdx.x); i < n; i += kBlock) f(i);
-        __syncthreads();
+        for (int i = static_cast<int>(threadIdx.x); i < n; i += BLOCK) f(i);
+        LdsBarrier();
     }
+    template <class F, int K>
+    __device__ __forceinline__ void Fetch(int n, F f, Stage<K>& s) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) {  // fully unrolled: the staging array stays in registers
+            const int i = static_cast<int>(threadIdx.x) + j * BLOCK;
+            if (i < n) s.r[j] = f(i);
+        }
+    }
+    template <int K>
+    __device__ __forceinline__ void Commit(int n, const Stage<K>& s, double* dst) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const int i = static_cast<int>(threadIdx.x) + j * BLOCK;
+            if (i < n) dst[i] = s.r[j];
+        }
+    }
+    __device__ __forceinline__ void Barrier() { LdsBarrier(); }
 };
 
-__global__ __launch_bounds__(kBlock) void RiccatiKernel(const RiccatiArgs a) {
+template <int BLOCK, int SLOTS_AB, int SLOTS_W, int NX = 0, int NU = 0>
+__global__ __launch_bounds__(BLOCK) void RiccatiKernel(const RiccatiArgs a) {
     extern __shared__ double scratch[];
     const long long inst = blockIdx.x;
     if (inst >= a.batch) return;
-    DeviceExec ex;
-    RiccatiInstance(a, inst, scratch, ex);
+    DeviceExec<BLOCK, SLOTS_AB, SLOTS_W> ex;
+    RiccatiInstance<DeviceExec<BLOCK, SLOTS_AB, SLOTS_W>, NX, NU>(a, inst, scratch, ex);
 }
 
 /// Wavefront sum (64 lanes), result in every lane.
@@ -71,39 +113,49 @@ __device__ __forceinline__ double BarrierD2(const BarrierParams& p, double z) {
     return 0.0;
 }
 
-/// One workgroup per instance, knots in sequence.
+/// One workgroup per (instance, knot): the inequality Jacobian of the knot and the barrier derivatives are staged in LDS once,
+/// then the lanes share the (nx+nu)^2 entries of the block.  (A first version walked the knots of an instance in sequence and
+/// re-read the Jacobian from global memory for every entry: 0.73 ms per 4096 x 30 quadrotor knots -- as long as the Riccati
+/// solve; this one is bound by writing the blocks.)
 __global__ __launch_bounds__(kBlock) void StageQpKernel(const StageQpArgs a) {
-    const long long b = blockIdx.x;
+    extern __shared__ double lds[];  // [nh][n] inequality Jacobian, d1[nh], d2[nh], then the dense cost Hessian block [n][n]
+    const long long node = blockIdx.x;
+    const long long b = node / a.N;
+    const int k = static_cast<int>(node - b * a.N);
     if (b >= a.batch) return;
     const int lane = static_cast<int>(threadIdx.x), n = a.nx + a.nu;
-    __shared__ double d1[64], d2[64];
-    for (int i = lane; i < a.nx; i += kBlock) a.dx0.at(b, 0, i) = a.xm.at(b, 0, i) - a.X.at(b, 0, i);
-    for (int k = 0; k < a.N; ++k) {
-        for (int i = lane; i < a.nx; i += kBlock) a.b.at(b, k, i) = a.f.at(b, k, i) - a.X.at(b, k + 1, i);
-        const bool ineq = a.h.base != nullptr;
+    double* jh = lds;
+    double* d1 = lds + a.nh * n;
+    double* d2 = d1 + a.nh;
+    double* hc = d2 + a.nh;
+    const bool ineq = a.h.base != nullptr;
+    for (int idx = lane; idx < n * n; idx += kBlock) hc[idx] = 0.0;
+    __syncthreads();
+    for (int e = lane; e < a.hesNnz; e += kBlock) hc[a.hesRow[e] * n + a.hesCol[e]] = a.costHes.at(b, k, e);  // distinct (row, col) per entry
+    if (k == 0)
+        for (int i = lane; i < a.nx; i += kBlock) a.dx0.at(b, 0, i) = a.xm.at(b, 0, i) - a.X.at(b, 0, i);
+    for (int i = lane; i < a.nx; i += kBlock) a.b.at(b, k, i) = a.f.at(b, k, i) - a.X.at(b, k + 1, i);
+    if (ineq) {
+        for (int idx = lane; idx < a.nh * n; idx += kBlock) jh[idx] = a.hJac.at(b, k, idx);
+        for (int j = lane; j < a.nh; j += kBlock) {
+            const double z = -a.h.at(b, k, j);
+            d1[j] = BarrierD1(a.barrier, z);
+            d2[j] = BarrierD2(a.barrier, z);
+        }
+    }
+    __syncthreads();
+    for (int idx = lane; idx < n * n; idx += kBlock) {
+        const int r = idx / n, c = idx % n;
+        double acc = hc[idx];
+        if (r <= c && ineq)
+            for (int j = 0; j < a.nh; ++j) acc += d2[j] * jh[j * n + r] * jh[j * n + c];
+        a.hess.at(b, k, idx) = acc;
+    }
+    for (int c = lane; c < n; c += kBlock) {
+        double acc = a.costGrad.at(b, k, c);
         if (ineq)
-            for (int j = lane; j < a.nh; j += kBlock) {
-                const double z = -a.h.at(b, k, j);
-                d1[j] = BarrierD1(a.barrier, z);
-                d2[j] = BarrierD2(a.barrier, z);
-            }
-        __syncthreads();
-        for (int idx = lane; idx < n * n; idx += kBlock) {
-            const int r = idx / n, c = idx % n;
-            double acc = 0.0;
-            if (r <= c && ineq)
-                for (int j = 0; j < a.nh; ++j) acc += d2[j] * a.hJac.at(b, k, j * n + r) * a.hJac.at(b, k, j * n + c);
-            a.hess.at(b, k, idx) = acc;
-        }
-        for (int c = lane; c < n; c += kBlock) {
-            double acc = a.costGrad.at(b, k, c);
-            if (ineq)
-                for (int j = 0; j < a.nh; ++j) acc -= d1[j] * a.hJac.at(b, k, j * n + c);  // d/dz b(-h) = -b'(-h) dh/dz
-            a.grad.at(b, k, c) = acc;
-        }
-        __syncthreads();
-        for (int e = lane; e < a.hesNnz; e += kBlock) a.hess.at(b, k, a.hesRow[e] * n + a.hesCol[e]) += a.costHes.at(b, k, e);  // distinct (row, col) per entry
-        __syncthreads();
+            for (int j = 0; j < a.nh; ++j) acc -= d1[j] * jh[j * n + c];  // d/dz b(-h) = -b'(-h) dh/dz
+        a.grad.at(b, k, c) = acc;
     }
 }
 
@@ -180,22 +232,59 @@ __global__ __launch_bounds__(kBlock) void AcceptKernel(const AcceptArgs a) {
 
 using namespace ungar_amd::kernels;
 
+namespace {
+template <int BLOCK, int SLOTS_AB, int SLOTS_W, int NX = 0, int NU = 0>
+int LaunchRiccati(const RiccatiArgs* a, std::size_t lds, hipStream_t stream) {
+    if (lds > 64 * 1024) {  // above the default dynamic-LDS limit the kernel has to opt in (160 KiB per CU on gfx950)
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(RiccatiKernel<BLOCK, SLOTS_AB, SLOTS_W, NX, NU>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 static_cast<int>(lds));
+        if (e != hipSuccess) return static_cast<int>(e);
+    }
+    hipLaunchKernelGGL((RiccatiKernel<BLOCK, SLOTS_AB, SLOTS_W, NX, NU>), dim3(static_cast<unsigned>(a->batch)), dim3(BLOCK), lds, stream, *a);
+    return static_cast<int>(hipGetLastError());
+}
+}  // namespace
+
 extern "C" int ungar_amd_launch_riccati(const RiccatiArgs* a, void* stream) {
     if (a->batch <= 0) return 0;
     const std::size_t lds = static_cast<std::size_t>(RiccatiScratchDoubles(a->nx, a->nu)) * sizeof(double);
     if (lds > 160 * 1024) return static_cast<int>(hipErrorInvalidValue);
-    if (lds > 64 * 1024) {  // above the default dynamic-LDS limit the kernel has to opt in (160 KiB per CU on gfx950)
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(RiccatiKernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-        if (e != hipSuccess) return static_cast<int>(e);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int n = a->nx + a->nu, ab = a->nx * n, w = n * n;
+    // Variants of the same recursion (tools/bench_sqp.py): lanes per instance (one or four wavefronts
+    // share the entries of every product) and whether the next knot's operands are staged in registers.
+    //   "64" / "128" / "256"   one / two / four wavefronts per instance, operands read in place;   "128p" / "256p"   staged
+    static const std::string variant = [] {
+        const char* e = getenv("UNGAR_AMD_RICCATI_VARIANT");
+        return std::string(e ? e : "fixed");
+    }();
+    // sizes of the reference's three OCPs and of the full-body quadruped, fixed at compile time (default route)
+    if (variant == "fixed" || variant == "64") {
+        if (variant == "fixed" && a->nx == 13 && a->nu == 4) return LaunchRiccati<64, 0, 0, 13, 4>(a, lds, s);
+        if (variant == "fixed" && a->nx == 6 && a->nu == 2) return LaunchRiccati<64, 0, 0, 6, 2>(a, lds, s);
+        if (variant == "fixed" && a->nx == 13 && a->nu == 24) return LaunchRiccati<64, 0, 0, 13, 24>(a, lds, s);
+        if (variant == "fixed" && a->nx == 37 && a->nu == 12) return LaunchRiccati<64, 0, 0, 37, 12>(a, lds, s);
+        return LaunchRiccati<64, 0, 0>(a, lds, s);
     }
-    hipLaunchKernelGGL(RiccatiKernel, dim3(static_cast<unsigned>(a->batch)), dim3(kBlock), lds, static_cast<hipStream_t>(stream), *a);
-    return static_cast<int>(hipGetLastError());
+    if (variant == "128") return LaunchRiccati<128, 0, 0>(a, lds, s);
+    if (variant == "128p" && ab <= 768 && w <= 768) return LaunchRiccati<128, 6, 6>(a, lds, s);
+    if (variant == "128p" && ab <= 1792 && w <= 1792) return LaunchRiccati<128, 14, 14>(a, lds, s);
+    if (variant == "128p") return LaunchRiccati<128, 0, 0>(a, lds, s);
+    if (variant == "256p" && ab <= 768 && w <= 768) return LaunchRiccati<256, 3, 3>(a, lds, s);    // quadrotor, rc_car (n <= 27)
+    if (variant == "256p" && ab <= 1792 && w <= 1792) return LaunchRiccati<256, 7, 7>(a, lds, s);  // single-rigid-body quadruped (n <= 42)
+    return LaunchRiccati<256, 0, 0>(a, lds, s);
 }
 
 extern "C" int ungar_amd_launch_ocp_stage_qp(const StageQpArgs* a, void* stream) {
     if (a->batch <= 0) return 0;
     if (a->nh > 64 || a->hesNnz > 160) return static_cast<int>(hipErrorInvalidValue);
-    hipLaunchKernelGGL(StageQpKernel, dim3(static_cast<unsigned>(a->batch)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), *a);
+    const std::size_t n = static_cast<std::size_t>(a->nx + a->nu);
+    const std::size_t lds = (static_cast<std::size_t>(a->nh) * n + 2 * static_cast<std::size_t>(a->nh) + n * n) * sizeof(double);
+    if (lds > 64 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(StageQpKernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        if (e != hipSuccess) return static_cast<int>(e);
+    }
+    hipLaunchKernelGGL(StageQpKernel, dim3(static_cast<unsigned>(a->batch * a->N)), dim3(kBlock), lds, static_cast<hipStream_t>(stream), *a);
     return static_cast<int>(hipGetLastError());
 }
 

@@ -17,6 +17,16 @@
 // The recursion is written once, generic over an execution policy: DeviceExec (ocp_riccati.hip) strides the lanes of a
 // workgroup over the index range; a sequential host policy exists ONLY in tests/cpp/riccati_host.cpp so that the very same
 // source can be pinned against a dense KKT solve without a GPU (test infrastructure, like tests/cpp/quad_sim.cpp).
+//
+// Execution policy:
+//   ForEach(n, f)            f(i) for i in [0, n), spread over the lanes, followed by a workgroup barrier on the scratch memory
+//   GlobalSync()             workgroup barrier that also orders the workgroup's global writes before its later global reads
+//   kPrefetch                whether the policy stages the next knot's operands (below); without it they are read in place
+//   Stage<SLOTS>             per-lane registers for a strided global read of up to 64 * SLOTS doubles
+//   Fetch(n, f, stage)       issues the loads stage <- f(i); no barrier, nothing waits for the data
+//   Commit(n, stage, dst)    dst[i] <- stage (no barrier);  Barrier() synchronises the scratch memory
+// With prefetching, the operands of knot k - 1 ([A|B], W, w, b: one HBM round trip each) are in flight while knot k is
+// factorised, instead of stalling every phase that touches them (0.75 -> see DESIGN.md for 4096 x 30 quadrotor knots).
 #pragma once
 
 #if defined(__HIPCC__)
@@ -60,13 +70,15 @@ struct RiccatiArgs {
 UNGAR_HD inline int RiccatiScratchDoubles(int nx, int nu) {
     const int n = nx + nu;
     return nx * n /*AB*/ + n * n /*H*/ + 2 * nx * nx /*P, Pn*/ + nx * n /*PAB*/ + 2 * nx /*p, pn*/ + nx /*t*/ + n /*h*/ + nx /*bk*/ + nu * (nx + 1) /*K|kff*/ +
-           nx + nu /*dx, du*/ + nx /*dxn*/;
+           nx + nu /*dx, du*/ + nx /*dxn*/ + nu /*Cholesky pivots*/;
 }
 
 /// The whole recursion for instance `inst`; `scratch` holds RiccatiScratchDoubles(nx, nu) doubles private to the workgroup.
-template <class Exec>
+/// NX / NU > 0 fix the sizes at compile time (the index arithmetic -- a division and a remainder by nx + nu per matrix entry --
+/// and the short inner products then cost a fraction of the generic code, which is issue-bound on them); 0 = read them from `a`.
+template <class Exec, int NX = 0, int NU = 0>
 UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scratch, Exec& ex) {
-    const int nx = a.nx, nu = a.nu, n = nx + nu, N = a.N, nk = nx + 1;
+    const int nx = NX > 0 ? NX : a.nx, nu = NU > 0 ? NU : a.nu, n = nx + nu, N = a.N, nk = nx + 1;
     double* AB = scratch;
     double* H = AB + nx * n;
     double* P = H + n * n;
@@ -81,6 +93,7 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
     double* dx = K + nu * nk;
     double* du = dx + nx;
     double* dxn = du + nu;
+    double* piv = dxn + nx;  // diagonal of the Cholesky factor of R
     double* gains = a.gains + inst * static_cast<long long>(N) * nu * nk;
     int failed = 0;
 
@@ -93,93 +106,158 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
     });
     ex.ForEach(nx, [&](int i) { p[i] = a.gradN.base ? a.gradN.at(inst, 0, i) : 0.0; });
 
+    typename Exec::StageAB sAB;
+    typename Exec::StageW sW;
+    typename Exec::StageV sw, sb;
+    // The stage Hessian W_k is brought straight into H and the stage gradient w_k into h: both are updated in place.
+    auto fetchKnot = [&](int k) {
+        ex.Fetch(nx * n, [&](int idx) { return a.jac.at(inst, k, idx); }, sAB);
+        ex.Fetch(n * n, [&](int idx) { return a.hess.at(inst, k, idx); }, sW);
+        ex.Fetch(n, [&](int c) { return a.grad.at(inst, k, c); }, sw);
+        ex.Fetch(nx, [&](int i) { return a.b.at(inst, k, i); }, sb);
+    };
+    auto commitKnot = [&] {
+        ex.Commit(nx * n, sAB, AB);
+        ex.Commit(n * n, sW, H);
+        ex.Commit(n, sw, h);
+        ex.Commit(nx, sb, bk);
+        ex.Barrier();
+    };
+    if constexpr (Exec::kPrefetch) {
+        fetchKnot(N - 1);
+        commitKnot();
+    }
     for (int k = N - 1; k >= 0; --k) {
-        ex.ForEach(nx * n, [&](int idx) { AB[idx] = a.jac.at(inst, k, idx); });
-        ex.ForEach(nx, [&](int i) { bk[i] = a.b.at(inst, k, i); });
-        // PAB = P AB;  t = P b + p
-        ex.ForEach(nx * n, [&](int idx) {
-            const int i = idx / n, c = idx % n;
-            double acc = 0.0;
-            for (int m = 0; m < nx; ++m) acc += P[i * nx + m] * AB[m * n + c];
-            PAB[idx] = acc;
-        });
-        ex.ForEach(nx, [&](int i) {
-            double acc = p[i];
-            for (int m = 0; m < nx; ++m) acc += P[i * nx + m] * bk[m];
-            t[i] = acc;
-        });
-        // H = W + AB^T PAB (symmetric: computed for r <= c, mirrored);  h = w + AB^T t
-        ex.ForEach(n * n, [&](int idx) {
-            const int r = idx / n, c = idx % n;
-            if (r > c) return;
-            double acc = a.hess.at(inst, k, r * n + c) + (r == c ? a.regularization : 0.0);
-            for (int m = 0; m < nx; ++m) acc += AB[m * n + r] * PAB[m * n + c];
-            H[r * n + c] = acc;
-            H[c * n + r] = acc;
-        });
-        ex.ForEach(n, [&](int c) {
-            double acc = a.grad.at(inst, k, c);
-            for (int m = 0; m < nx; ++m) acc += AB[m * n + c] * t[m];
-            h[c] = acc;
-        });
-        // Cholesky of R = H_uu in place (lower triangle of the uu block): column by column, rows in parallel
-        for (int j = 0; j < nu; ++j) {
-            ex.ForEach(1, [&](int) {
-                double d = H[(nx + j) * n + nx + j];
-                for (int m = 0; m < j; ++m) d -= H[(nx + j) * n + nx + m] * H[(nx + j) * n + nx + m];
-                if (!(d > 0.0)) {
-                    failed = failed ? failed : k + 1;
-                    d = 1.0;
-                }
-                H[(nx + j) * n + nx + j] = sqrt(d);
-            });
-            ex.ForEach(nu - j - 1, [&](int q) {
-                const int i = j + 1 + q;
-                double s = H[(nx + i) * n + nx + j];
-                for (int m = 0; m < j; ++m) s -= H[(nx + i) * n + nx + m] * H[(nx + j) * n + nx + m];
-                H[(nx + i) * n + nx + j] = s / H[(nx + j) * n + nx + j];
+        if constexpr (Exec::kPrefetch) {
+            if (k > 0) fetchKnot(k - 1);  // in flight while knot k is processed
+        } else {
+            ex.ForEach(nx * n + n * n + n + nx, [&](int idx) {
+                if (idx < nx * n) AB[idx] = a.jac.at(inst, k, idx);
+                else if ((idx -= nx * n) < n * n) H[idx] = a.hess.at(inst, k, idx);
+                else if ((idx -= n * n) < n) h[idx] = a.grad.at(inst, k, idx);
+                else bk[idx - n] = a.b.at(inst, k, idx - n);
             });
         }
-        // [K | kff] = -R^-1 [H_ux | h_u]: one right-hand side per lane (forward then backward substitution)
+        // PAB = P AB;  t = P b + p
+        ex.ForEach(nx * n + nx, [&](int idx) {
+            if (idx < nx * n) {
+                const int i = idx / n, c = idx % n;
+                double acc = 0.0;
+                for (int m = 0; m < nx; ++m) acc += P[i * nx + m] * AB[m * n + c];
+                PAB[idx] = acc;
+            } else {
+                const int i = idx - nx * n;
+                double acc = p[i];
+                for (int m = 0; m < nx; ++m) acc += P[i * nx + m] * bk[m];
+                t[i] = acc;
+            }
+        });
+        // H = W + AB^T PAB in place (computed for r <= c, mirrored: only the upper triangle of W is read);  h = w + AB^T t in place
+        ex.ForEach(n * n + n, [&](int idx) {
+            if (idx < n * n) {
+                const int r = idx / n, c = idx % n;
+                if (r > c) return;
+                double acc = H[r * n + c] + (r == c ? a.regularization : 0.0);
+                for (int m = 0; m < nx; ++m) acc += AB[m * n + r] * PAB[m * n + c];
+                H[r * n + c] = acc;
+                H[c * n + r] = acc;
+            } else {
+                const int c = idx - n * n;
+                double acc = h[c];
+                for (int m = 0; m < nx; ++m) acc += AB[m * n + c] * t[m];
+                h[c] = acc;
+            }
+        });
+        // Cholesky of R = H_uu (strict lower triangle in place, pivots in K's spare column... kept in `dx`-sized scratch `piv`):
+        // one phase per column -- every lane recomputes the pivot from values that are final, lane 0 records it
+        for (int j = 0; j < nu; ++j) {
+            ex.ForEach(nu - j, [&](int q) {
+                double d = H[(nx + j) * n + nx + j];
+                for (int m = 0; m < j; ++m) d -= H[(nx + j) * n + nx + m] * H[(nx + j) * n + nx + m];
+                const bool bad = !(d > 0.0);
+                const double root = sqrt(bad ? 1.0 : d);
+                if (q == 0) {
+                    if (bad) failed = failed ? failed : k + 1;
+                    piv[j] = root;
+                    return;
+                }
+                const int i = j + q;
+                double sv = H[(nx + i) * n + nx + j];
+                for (int m = 0; m < j; ++m) sv -= H[(nx + i) * n + nx + m] * H[(nx + j) * n + nx + m];
+                H[(nx + i) * n + nx + j] = sv / root;
+            });
+        }
+        // [K | kff] = -R^-1 [H_ux | h_u]: one right-hand side per lane (forward then backward substitution); the lane also
+        // files its column of the gains
         ex.ForEach(nk, [&](int c) {
             for (int i = 0; i < nu; ++i) {  // L y = rhs
-                double s = c < nx ? -H[(nx + i) * n + c] : -h[nx + i];
-                for (int m = 0; m < i; ++m) s -= H[(nx + i) * n + nx + m] * K[m * nk + c];
-                K[i * nk + c] = s / H[(nx + i) * n + nx + i];
+                double sv = c < nx ? -H[(nx + i) * n + c] : -h[nx + i];
+                for (int m = 0; m < i; ++m) sv -= H[(nx + i) * n + nx + m] * K[m * nk + c];
+                K[i * nk + c] = sv / piv[i];
             }
             for (int i = nu - 1; i >= 0; --i) {  // L^T x = y
-                double s = K[i * nk + c];
-                for (int m = i + 1; m < nu; ++m) s -= H[(nx + m) * n + nx + i] * K[m * nk + c];
-                K[i * nk + c] = s / H[(nx + i) * n + nx + i];
+                double sv = K[i * nk + c];
+                for (int m = i + 1; m < nu; ++m) sv -= H[(nx + m) * n + nx + i] * K[m * nk + c];
+                sv /= piv[i];
+                K[i * nk + c] = sv;
+                gains[static_cast<long long>(k) * nu * nk + i * nk + c] = sv;
             }
         });
-        ex.ForEach(nu * nk, [&](int idx) { gains[static_cast<long long>(k) * nu * nk + idx] = K[idx]; });
-        // P <- H_xx + H_ux^T K (symmetrised),  p <- h_x + H_ux^T kff
-        ex.ForEach(nx * nx, [&](int idx) {
-            const int i = idx / nx, j = idx % nx;
-            double s1 = H[i * n + j], s2 = H[j * n + i];
-            for (int m = 0; m < nu; ++m) {
-                s1 += H[(nx + m) * n + i] * K[m * nk + j];
-                s2 += H[(nx + m) * n + j] * K[m * nk + i];
+        // P <- H_xx + H_ux^T K (symmetrised),  p <- h_x + H_ux^T kff   (into the other buffer, then the buffers swap roles)
+        ex.ForEach(nx * nx + nx, [&](int idx) {
+            if (idx < nx * nx) {
+                const int i = idx / nx, j = idx % nx;
+                double s1 = H[i * n + j], s2 = H[j * n + i];
+                for (int m = 0; m < nu; ++m) {
+                    s1 += H[(nx + m) * n + i] * K[m * nk + j];
+                    s2 += H[(nx + m) * n + j] * K[m * nk + i];
+                }
+                Pn[idx] = 0.5 * (s1 + s2);
+            } else {
+                const int i = idx - nx * nx;
+                double sv = h[i];
+                for (int m = 0; m < nu; ++m) sv += H[(nx + m) * n + i] * K[m * nk + nx];
+                pn[i] = sv;
             }
-            Pn[idx] = 0.5 * (s1 + s2);
         });
-        ex.ForEach(nx, [&](int i) {
-            double s = h[i];
-            for (int m = 0; m < nu; ++m) s += H[(nx + m) * n + i] * K[m * nk + nx];
-            pn[i] = s;
-        });
-        ex.ForEach(nx * nx, [&](int idx) { P[idx] = Pn[idx]; });
-        ex.ForEach(nx, [&](int i) { p[i] = pn[i]; });
+        {
+            double* swapP = P;
+            P = Pn;
+            Pn = swapP;
+            double* swapp = p;
+            p = pn;
+            pn = swapp;
+        }
+        if constexpr (Exec::kPrefetch) {
+            if (k > 0) commitKnot();  // AB, H, h, b of knot k are dead from here on
+        }
     }
 
     // forward pass
+    ex.GlobalSync();  // the gains written above are read back below
     ex.ForEach(nx, [&](int i) {
         dx[i] = a.dx0.at(inst, 0, i);
         a.dX.at(inst, 0, i) = dx[i];
     });
+    auto fetchForward = [&](int k) {
+        ex.Fetch(nx * n, [&](int idx) { return a.jac.at(inst, k, idx); }, sAB);
+        ex.Fetch(nx, [&](int i) { return a.b.at(inst, k, i); }, sb);
+    };
+    if constexpr (Exec::kPrefetch) {
+        fetchForward(0);
+        ex.Commit(nx * n, sAB, AB);
+        ex.Commit(nx, sb, bk);
+        ex.Barrier();
+    }
     for (int k = 0; k < N; ++k) {
-        ex.ForEach(nx * n, [&](int idx) { AB[idx] = a.jac.at(inst, k, idx); });
+        if constexpr (Exec::kPrefetch) {
+            if (k + 1 < N) fetchForward(k + 1);
+        } else {
+            ex.ForEach(nx * n + nx, [&](int idx) {
+                if (idx < nx * n) AB[idx] = a.jac.at(inst, k, idx);
+                else bk[idx - nx * n] = a.b.at(inst, k, idx - nx * n);
+            });
+        }
         ex.ForEach(nu, [&](int i) {
             const double* g = gains + static_cast<long long>(k) * nu * nk + i * nk;
             double s = g[nx];
@@ -188,13 +266,24 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
             a.dU.at(inst, k, i) = s;
         });
         ex.ForEach(nx, [&](int i) {
-            double s = a.b.at(inst, k, i);
+            double s = bk[i];
             for (int m = 0; m < nx; ++m) s += AB[i * n + m] * dx[m];
             for (int m = 0; m < nu; ++m) s += AB[i * n + nx + m] * du[m];
             dxn[i] = s;
             a.dX.at(inst, k + 1, i) = s;
         });
-        ex.ForEach(nx, [&](int i) { dx[i] = dxn[i]; });
+        {
+            double* swapx = dx;
+            dx = dxn;
+            dxn = swapx;
+        }
+        if constexpr (Exec::kPrefetch) {
+            if (k + 1 < N) {
+                ex.Commit(nx * n, sAB, AB);
+                ex.Commit(nx, sb, bk);
+                ex.Barrier();
+            }
+        }
     }
     if (a.status) ex.ForEach(1, [&](int) { a.status[inst] = failed; });
 }
