@@ -10,13 +10,13 @@ import torch
 
 sys.path.insert(0, ".")
 import ungar_amd  # noqa: E402
-from bench import synth_device_inputs  # noqa: E402
+from ungar_amd.workloads import synth_device_inputs  # noqa: E402
 
 N, batch = 20, 4096
 count = N * batch
 m = ungar_amd.NodeModel("anymal")
 nx, ncols = m.nx, m.nx + m.nu
-x, u, _, p = synth_device_inputs("anymal", count, seed=0, torch=torch)
+x, u, _, p = synth_device_inputs("anymal", count, 0, torch)
 d = torch.rand((nx, count), device="cuda", dtype=torch.float64)
 Op = ungar_amd.Operand
 results = []

@@ -1,0 +1,26 @@
+#!/usr/bin/env bash
+# Copies the judged summaries of one `tools/gpu_round.sh` run out of gpurun_out/ (scratch) into profiles/ (tracked).
+# usage: tools/collect_round.sh <tag>     e.g. r02d
+set -euo pipefail
+tag=${1:?tag}
+cd "$(dirname "$0")/.."
+python tools/collect_profiles.py "$tag" anymal:4096
+cp_if() { [ -s "$1" ] && cp "$1" "$2" || echo "missing: $1"; }
+cp_if gpurun_out/bench.log                    profiles/bench_${tag}_anymal.json
+cp_if gpurun_out/bench_2rank_gloo.log         profiles/bench_${tag}_config5_2rank_gloo_1gpu.json
+cp_if gpurun_out/bench_config5_1gpu.log       profiles/bench_${tag}_config5_1gpu.json
+cp_if gpurun_out/bench_config5_shard_of_8.log profiles/bench_${tag}_config5_shard_of_8.json
+cp_if gpurun_out/bench_srbd.log               profiles/bench_${tag}_srbd.json
+cp_if gpurun_out/bench_anymal_sparse.log      profiles/bench_${tag}_anymal_sparse.json
+cp_if gpurun_out/bench_anymal_reg.log         profiles/bench_${tag}_anymal_reg.json
+cp_if gpurun_out/bench_anymal_ad.log          profiles/bench_${tag}_anymal_ad.json
+cp_if gpurun_out/gn_full.json                 profiles/${tag}_gn_hessian_full.json
+cp_if gpurun_out/gn_upper.json                profiles/${tag}_gn_hessian_upper.json
+cp_if gpurun_out/gn_lanes.json                profiles/${tag}_gn_hessian_lanes.json
+cp_if gpurun_out/layouts.log                  profiles/${tag}_layouts.log
+cp_if gpurun_out/ocp_step_srbd.json           profiles/${tag}_ocp_step_srbd.json
+cp_if gpurun_out/sqp_bench.log                profiles/${tag}_sqp_quadrotor_timing.json
+cp_if gpurun_out/sqp_prof/sqp_kernel_stats.csv profiles/${tag}_sqp_kernel_stats.csv
+cp_if gpurun_out/sq_counters.log              profiles/${tag}_sq_counters.log
+cp_if gpurun_out/pytest_gpu.log               profiles/pytest_gpu_${tag}.log
+cp_if gpurun_out/smoke.log                    profiles/smoke_${tag}.log

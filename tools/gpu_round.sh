@@ -1,22 +1,43 @@
 #!/usr/bin/env bash
-# Full round evidence on the GPU box: parity tests, smoke, bench (default line + 2-rank dry run of the config-5
-# partition), rocprofv3 kernel trace + HBM counters for the headline kernel.  Outputs under gpurun_out/
-# (tools/collect_profiles.py copies the judged summaries into profiles/).
+# Full round evidence on the GPU box: parity tests, smoke, bench (default line + 2-rank dry run of the config-5 partition), rocprofv3
+# kernel trace + HBM counters for the headline kernel, Gauss-Newton and SQP benches.  Outputs under gpurun_out/
+# (tools/collect_profiles.py and tools/collect_round.sh copy the judged summaries into profiles/).
 set -uo pipefail
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-echo "== pytest -m gpu"; timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -12 | tee gpurun_out/pytest_gpu.log
+echo "== pytest -m gpu"; timeout 3000 python -m pytest tests -m gpu -x -q 2>&1 | tail -12 | tee gpurun_out/pytest_gpu.log
 echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -4 | tee gpurun_out/smoke.log
-echo "== bench"; timeout 900 python bench.py 2>gpurun_out/bench.err | tail -1 | tee gpurun_out/bench.log
+echo "== bench"; timeout 900 python bench.py 2>gpurun_out/bench.err | tail -1 > gpurun_out/bench.log; cut -c1-400 gpurun_out/bench.log
 echo "== bench, 2 ranks sharing the device over gloo: control flow of the config-5 partition (65 536 instances)"
-UNGAR_BENCH_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 20 --warmup 3 2>gpurun_out/bench2.err | tail -1 | tee gpurun_out/bench_2rank_gloo.log
-timeout 600 python bench.py --total-batch 65536 --steps 20 --warmup 3 --no-cpu-baseline --no-sub-results 2>&1 | tail -1 | tee gpurun_out/bench_config5_1gpu.log
+UNGAR_BENCH_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 20 --warmup 3 2>gpurun_out/bench2.err | tail -1 > gpurun_out/bench_2rank_gloo.log
+timeout 600 python bench.py --total-batch 65536 --steps 20 --warmup 3 --no-cpu-baseline --no-sub-results 2>&1 | tail -1 > gpurun_out/bench_config5_1gpu.log
+timeout 600 python bench.py --total-batch 8192 --steps 50 --warmup 3 --no-cpu-baseline --no-sub-results 2>&1 | tail -1 > gpurun_out/bench_config5_shard_of_8.log
 for w in srbd; do timeout 300 python bench.py --workload $w --steps 50 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/bench_$w.log; done
 timeout 300 python bench.py --jacobian sparse --steps 50 --warmup 3 --no-cpu-baseline --no-sub-results 2>&1 | tail -1 > gpurun_out/bench_anymal_sparse.log
-echo "== rocprofv3 kernel trace"
+for m in anymal_reg anymal_ad; do timeout 300 python bench.py --model $m --steps 20 --warmup 3 --no-cpu-baseline --no-sub-results 2>&1 | tail -1 > gpurun_out/bench_$m.log; done
+for f in bench_2rank_gloo bench_config5_1gpu bench_config5_shard_of_8 bench_srbd bench_anymal_sparse bench_anymal_reg bench_anymal_ad; do python - "$f" <<'PY'
+import json, sys
+try:
+    d = json.loads(open(f"gpurun_out/{sys.argv[1]}.log").read())
+    print(f"{sys.argv[1]:28s} value {d['value']:.4g} evals/s  frac {d['roofline']['frac']:.3f}  kernel {d['roofline']['kernel_ms']:.4f} ms x {d['roofline']['launches_per_step']}  checksum {d['checksum']:.12g}")
+except Exception as e:
+    print(sys.argv[1], "FAILED", e)
+PY
+done
+echo "== Gauss-Newton term (MFMA kernels, lane-per-node kernel, chain) and layouts"
+timeout 300 python tools/bench_gn_hessian.py 2>&1 | tail -1 > gpurun_out/gn_full.json
+timeout 300 python tools/bench_gn_hessian.py --upper 2>&1 | tail -1 > gpurun_out/gn_upper.json
+timeout 300 python tools/bench_gn_lanes.py 2>&1 | tail -1 > gpurun_out/gn_lanes.json
+timeout 300 python tools/bench_layouts.py 2>&1 | tail -3 > gpurun_out/layouts.log
+timeout 300 python tools/bench_ocp_step.py 2>&1 | tail -1 > gpurun_out/ocp_step_srbd.json
+echo "== batched SQP"
+bash tools/gpu_sqp_profile.sh 2>&1 | tail -12
+echo "== rocprofv3 kernel trace + HBM counters (separate passes)"
 rm -rf gpurun_out/prof gpurun_out/pmc1 gpurun_out/pmc2
 B="python bench.py --no-cpu-baseline --no-sub-results"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o anymal -- $B > gpurun_out/prof_bench.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc1 -o anymal -- $B --steps 5 --warmup 1 > gpurun_out/pmc1.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc2 -o anymal -- $B --steps 5 --warmup 1 > gpurun_out/pmc2.log 2>&1
-head -3 gpurun_out/prof/anymal_kernel_stats.csv | cut -c1-200
+head -2 gpurun_out/prof/anymal_kernel_stats.csv | cut -c1-200
+echo "== SQ counters of the headline kernel"
+bash tools/gpu_pmc_sq.sh anymal 2>&1 | tail -18 | tee gpurun_out/sq_counters.log

@@ -3,7 +3,7 @@
 set -uo pipefail
 mkdir -p gpurun_out; export TMPDIR=/tmp
 rm -rf gpurun_out/sqp_prof
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/sqp_prof -o sqp -- python tools/bench_sqp.py 4096 2>&1 | tail -2 | tee gpurun_out/sqp_bench.log
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/sqp_prof -o sqp -- python tools/bench_sqp.py 4096 2>/dev/null | grep "^{" | tail -1 | tee gpurun_out/sqp_bench.log
 python - <<'PY'
 import csv, glob
 for f in glob.glob("gpurun_out/sqp_prof/**/*kernel_stats.csv", recursive=True):
