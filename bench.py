@@ -146,13 +146,13 @@ def genuine_reference_timing(seconds):
 
 # ------------------------------------------------------------------------------------------------ GPU measurement
 def measure(torch, ungar_amd, workload, instances, total_instances, begin, steps, warmup, jacobian="dense", kernel_model=None, fence=None,
-            seed=0, tile=None):
+            seed=0, tile=None, pad_stride=True, prewarm_s=0.0):
     """Times `steps` passes over the node range of instances [begin, begin + instances) of a `total_instances` batch.  The shard
     is stored as [tile][element][node of tile] (ungar_amd.sharding.tile_ranges) and a pass is one launch per tile on one stream.
     Returns per-rank figures (elapsed seconds on the host clock, mean launch duration from HIP events on the launch stream,
     nodes per step, output checksum)."""
     from ungar_amd import workloads as W
-    from ungar_amd.sharding import DEFAULT_TILE_INSTANCES, tile_ranges
+    from ungar_amd.sharding import DEFAULT_TILE_INSTANCES, tile_ranges, unit_fastest
     model_name, N, _ = W.WORKLOADS[workload]
     m = ungar_amd.NodeModel(kernel_model or model_name)
     nx, nu, ncols = m.nx, m.nu, m.nx + m.nu
@@ -165,12 +165,17 @@ def measure(torch, ungar_amd, workload, instances, total_instances, begin, steps
     for b, e in tile_ranges(instances, tile or DEFAULT_TILE_INSTANCES):
         tn = (e - b) * N
         sl = slice(b * N, e * N)
-        xt, ut, wt = x[:, sl].contiguous(), u[:, sl].contiguous(), None if w is None else w[:, sl].contiguous()
-        f = torch.empty((nx, tn), dtype=torch.float64, device="cuda")
-        J = torch.empty((jac_len, tn), dtype=torch.float64, device="cuda")
+        def operand(src_rows, src=None):  # (elements, tn) view whose element stride is padded off the power-of-two channel stride
+            t = unit_fastest(src_rows, tn, torch) if pad_stride else torch.empty((src_rows, tn), dtype=torch.float64, device="cuda")
+            if src is not None:
+                t.copy_(src)
+            return t
+        xt, ut, wt = operand(nx, x[:, sl]), operand(nu, u[:, sl]), None if w is None else operand(w.shape[0], w[:, sl])
+        f, J = operand(nx), operand(jac_len)
         outputs.append((f, J))
-        launches.append((tn, Op.soa(xt, tn, N), Op.soa(ut, tn, N), None if wt is None else Op.soa(wt, tn, N), Op.per_instance(p, m.np, shared=True),
-                         Op.soa(f, tn, N), Op.soa(J, tn, N)))
+        es = f.stride(0)
+        launches.append((tn, Op.soa(xt, es, N), Op.soa(ut, es, N), None if wt is None else Op.soa(wt, es, N), Op.per_instance(p, m.np, shared=True),
+                         Op.soa(f, es, N), Op.soa(J, es, N)))
     del x, u, w
     stream = torch.cuda.current_stream().cuda_stream
     call = m.dense_jacobian if jacobian == "dense" else m.sparse_jacobian
@@ -180,6 +185,14 @@ def measure(torch, ungar_amd, workload, instances, total_instances, begin, steps
             call(*ops, knots=N, stream=stream)
 
     fence = fence or torch.cuda.synchronize
+    # Untimed pre-warm: the clock governor needs a few hundred milliseconds of sustained load to reach the steady-state clocks this
+    # FP64-latency-bound kernel runs at (measured: 0.262-0.266 ms per launch right after start, 0.253-0.255 ms after 0.3 s of the
+    # same launches, profiles/r02e_prewarm.log).  It precedes the W warm-up steps; the timed region is exactly `steps` steps.
+    t_end = time.perf_counter() + prewarm_s
+    while time.perf_counter() < t_end:
+        for _ in range(50):
+            step()
+        torch.cuda.synchronize()
     for _ in range(warmup):
         step()
     fence()
@@ -221,6 +234,11 @@ def main():
     ap.add_argument("--batch-per-gpu", type=int, default=None, help="weak-scaling variant: this many instances on EVERY rank")
     ap.add_argument("--tile-instances", type=int, default=None,
                     help="instances per tile of the [tile][element][node] device layout (default ungar_amd.sharding.DEFAULT_TILE_INSTANCES = 8192)")
+    ap.add_argument("--prewarm-seconds", type=float, default=0.5,
+                    help="untimed launches of the same step BEFORE the --warmup steps, so that the timed steps run at steady-state clocks (0 disables)")
+    ap.add_argument("--no-stride-pad", action="store_true",
+                    help="A/B switch: element stride of the unit-fastest operands = nodes of the tile (consecutive elements a multiple of 2^17 bytes apart "
+                         "for these batch sizes: one memory channel per wavefront) instead of ungar_amd.sharding.padded_stride")
     ap.add_argument("--model", default=None, help="kernel variant of the workload's model (e.g. anymal_ad, anymal_reg)")
     ap.add_argument("--layout", default="soa", choices=["soa"])
     ap.add_argument("--jacobian", default="dense", choices=["dense", "sparse"],
@@ -270,7 +288,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    r = measure(torch, ungar_amd, args.workload, end - begin, total, begin, args.steps, args.warmup, args.jacobian, args.model, fence, tile=args.tile_instances)
+    r = measure(torch, ungar_amd, args.workload, end - begin, total, begin, args.steps, args.warmup, args.jacobian, args.model, fence, tile=args.tile_instances, pad_stride=not args.no_stride_pad, prewarm_s=args.prewarm_seconds)
     reduce_device = "cuda" if dist is None or dist.get_backend() == "nccl" else "cpu"
     elapsed, total_evals = reduce_timing(r["elapsed"], r["count"] * args.steps, dist, reduce_device)  # MAX time, SUM evals over ranks
     checksum, nodes_per_step = reduce_sums([r["checksum"], float(r["count"])], dist, reduce_device)  # SUM over ranks
@@ -290,6 +308,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "prewarm_s": args.prewarm_seconds,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": scaling,
@@ -298,7 +317,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.workload} shooting-node value + {'dense [A|B]' if args.jacobian == 'dense' else 'sparse (nnz=%d)' % r['nnz']} Jacobian, "
                                    f"nx={r['nx']} nu={r['nu']}, N={N}, batch={total} instances over {world} GPU(s) "
-                                   f"({end - begin} instances = {r['count']} nodes on rank 0 per step), unit-fastest (SoA) device layout in tiles of <= {args.tile_instances or 8192} instances",
+                                   f"({end - begin} instances = {r['count']} nodes on rank 0 per step), unit-fastest (SoA) device layout in tiles of <= {args.tile_instances or 8192} instances, element stride "
+                                   + ("= nodes of the tile" if args.no_stride_pad else "padded off the 2^17-byte channel stride (sharding.padded_stride)"),
                        "horizon": N, "total_batch": total, "batch_rank0": end - begin, "nodes_per_step": int(nodes_per_step), "kernel_variant": r["kernel_model"],
                        "parallelism": f"instance axis partitioned x{world} (shard_range), no data-path collective"},
             "checksum": checksum,
@@ -308,7 +328,7 @@ def main():
             subs = []
             for wl in ("quadrotor", "rc_car"):  # BASELINE.json configs[1], configs[2]
                 _, n_sub, b_sub = W.WORKLOADS[wl]
-                s = measure(torch, ungar_amd, wl, b_sub, b_sub, 0, max(20, args.steps // 2), max(2, args.warmup // 2))
+                s = measure(torch, ungar_amd, wl, b_sub, b_sub, 0, max(20, args.steps // 2), max(2, args.warmup // 2), pad_stride=not args.no_stride_pad, prewarm_s=min(args.prewarm_seconds, 0.2))
                 rl = roofline(s, "dense")
                 subs.append({"workload": f"{wl} N={n_sub} batch={b_sub} dense [A|B]", "value": s["count"] * max(20, args.steps // 2) / s["elapsed"],
                              "unit": "evals/s", "kernel_ms": s["kernel_ms"], "roofline_frac": rl["frac"], "achieved_GBps": rl["achieved"],

@@ -104,3 +104,44 @@ def test_operands_beyond_32bit_offsets_keep_the_quad_kernel(ua, mode):
     assert torch.isfinite(J).all()
     del J
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("mode", ["dense", "sparse"])
+def test_padded_element_stride_is_bit_identical(ua, mode):
+    """bench.py stores every unit-fastest operand with ungar_amd.sharding.padded_stride (element stride rotated off the
+    2^17-byte channel stride): the result of a node must not depend on the stride -- same bits as with stride = nodes, at the
+    headline size (4096 instances x 20 knots), with the padding columns of the outputs left untouched."""
+    import torch
+    from ungar_amd import workloads as W
+    from ungar_amd.sharding import padded_stride
+    count = 4096 * N
+    st = padded_stride(count)
+    assert st % 16 == 0 and st >= count + 32 and (st // 16) % 4 == 3
+    m = ua.NodeModel("anymal")
+    x, u, _, p = W.synth_device_inputs("anymal", count, 4, torch)
+    f0, J0 = _evaluate(ua, torch, x, u, p, count, mode)
+
+    def padded(rows, src=None):
+        t = torch.full((rows, st), float("nan"), dtype=torch.float64, device="cuda")
+        if src is not None:
+            t[:, :count] = src
+        return t
+    xp, up = padded(m.nx, x), padded(m.nu, u)
+    f, J = padded(m.nx), padded(J0.shape[0])
+    Op = ua.Operand
+    call = m.dense_jacobian if mode == "dense" else m.sparse_jacobian
+    call(count, Op.soa(xp, st, N), Op.soa(up, st, N), None, Op.per_instance(p, m.np, shared=True), Op.soa(f, st, N), Op.soa(J, st, N), knots=N)
+    torch.cuda.synchronize()
+    assert torch.equal(f[:, :count], f0) and torch.equal(J[:, :count], J0)
+    assert torch.isnan(f[:, count:]).all() and torch.isnan(J[:, count:]).all()
+    if mode == "dense":  # the Gauss-Newton contraction reads the padded Jacobian and writes a padded G: same bits as from the unpadded operands
+        rows, cols = m.nx, m.nx + m.nu
+        d0 = torch.rand((rows, count), dtype=torch.float64, device="cuda")
+        d = padded(rows, d0)
+        G0 = torch.full((cols * cols, count), float("nan"), dtype=torch.float64, device="cuda")
+        G = padded(cols * cols)
+        ua.gn_hessian_tiles(J0, d0, G0, rows, cols, count, True)
+        ua.gn_hessian_tiles(J, d, G, rows, cols, count, True)
+        torch.cuda.synchronize()
+        upper = torch.triu(torch.ones((cols, cols), dtype=torch.bool, device="cuda")).reshape(-1)
+        assert torch.equal(G[upper][:, :count], G0[upper]) and torch.isnan(G[:, count:]).all() and torch.isnan(G[~upper]).all()

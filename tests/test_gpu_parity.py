@@ -278,23 +278,28 @@ def test_gn_hessian_mfma(ua):
         assert torch.isnan(S[:, ~upper]).all()
 
 
-def test_gn_hessian_lane_per_node(ua):
-    """The lane-per-node contraction for unit-fastest Jacobians (gn_hessian_lanes.hip): ragged node counts (not a multiple of
-    64), column counts that are not a multiple of the 7 x 7 tile, weighted and unweighted, both output layouts; entries below
-    the diagonal are never written."""
+@pytest.mark.parametrize("kernel", ["gn_hessian_lanes", "gn_hessian_tiles"])
+def test_gn_hessian_lane_per_node(ua, kernel):
+    """The FP64-vector contractions for unit-fastest Jacobians -- one lane per node (gn_hessian_lanes.hip) and one lane per
+    (node, 7 x 7 block) with LDS-streamed rows (gn_hessian_tiles.hip; widths without a compiled instance are forwarded to the
+    former): ragged node counts (not a multiple of 64 / 16), column counts that are not a multiple of the 7 x 7 tile, row
+    counts that are not a multiple of the staging depth, weighted and unweighted, both output layouts; entries below the
+    diagonal are never written."""
     import torch
+    contract = getattr(ua, kernel)
     gen = torch.Generator(device="cuda")
     gen.manual_seed(5)
-    for rows, cols, count, weighted in ((37, 49, 1000, True), (12, 37, 130, True), (13, 17, 257, False), (6, 8, 5, True), (8, 17, 64, True)):
+    for rows, cols, count, weighted in ((37, 49, 1000, True), (12, 37, 130, True), (13, 17, 257, False), (6, 8, 5, True), (8, 17, 64, True), (1, 49, 17, False),
+                                        (5, 49, 31, True), (9, 23, 40, True), (37, 49, 1002, False), (8, 49, 48, True), (17, 49, 4098, True)):
         J = torch.rand((rows * cols, count), generator=gen, device="cuda", dtype=torch.float64) * 2 - 1
         d = torch.rand((rows, count), generator=gen, device="cuda", dtype=torch.float64) if weighted else None
         Jv = J.view(rows, cols, count)
         ref = torch.einsum("ran,rn,rbn->nab", Jv, d if weighted else torch.ones((rows, count), device="cuda", dtype=torch.float64), Jv)
         upper = torch.triu(torch.ones((cols, cols), dtype=torch.bool, device="cuda"))
         Guf = torch.full((cols * cols, count), float("nan"), dtype=torch.float64, device="cuda")
-        ua.gn_hessian_lanes(J, d, Guf, rows, cols, count, True)
+        contract(J, d, Guf, rows, cols, count, True)
         Gnm = torch.full((count, cols, cols), float("nan"), dtype=torch.float64, device="cuda")
-        ua.gn_hessian_lanes(J, d, Gnm, rows, cols, count, False)
+        contract(J, d, Gnm, rows, cols, count, False)
         torch.cuda.synchronize()
         got = Guf.view(cols, cols, count).permute(2, 0, 1)
         assert (got[:, upper] - ref[:, upper]).abs().max().item() <= 1e-12 * ref.abs().max().item()
@@ -304,8 +309,9 @@ def test_gn_hessian_lane_per_node(ua):
 
 def test_full_size_chain_node_jacobians_to_gauss_newton_term(ua):
     """BASELINE config 4 at full size (4096 instances x 20 knots = 81 920 nodes): ANYmal node Jacobians (unit-fastest) ->
-    G = J^T diag(d) J with no transposition, by BOTH contractions (FP64 vector lanes and LDS-staged MFMA); they agree with each
-    other on every node and with torch on a slice; trace(G) = sum_r d_r |J_r|^2 on every node."""
+    G = J^T diag(d) J with no transposition, by ALL THREE contractions (FP64 vector lane per node, lane per (node, block) with
+    LDS-streamed rows, LDS-staged MFMA); they agree with each other on every node and with torch on a slice;
+    trace(G) = sum_r d_r |J_r|^2 on every node."""
     import torch
     from ungar_amd import workloads as W
     N, batch = 20, 4096
@@ -322,10 +328,13 @@ def test_full_size_chain_node_jacobians_to_gauss_newton_term(ua):
     ua.gn_hessian_lanes(J, d, Guf, rows, cols, count, True)
     Gnm = torch.zeros((count, cols, cols), dtype=torch.float64, device="cuda")
     ua.gn_hessian_unit_fastest(J, d, Gnm, rows, cols, count)
+    Gt = torch.zeros((cols * cols, count), dtype=torch.float64, device="cuda")
+    ua.gn_hessian_tiles(J, d, Gt, rows, cols, count, True)
     torch.cuda.synchronize()
     upper = torch.triu(torch.ones((cols, cols), dtype=torch.bool, device="cuda"))
     got = Guf.view(cols, cols, count).permute(2, 0, 1)
     scale = got.abs().amax(dim=(1, 2), keepdim=True)
+    assert ((got - Gt.view(cols, cols, count).permute(2, 0, 1))[:, upper].abs() <= 1e-13 * scale.expand(-1, cols, cols)[:, upper]).all()  # same products, same order
     assert ((got - Gnm)[:, upper].abs() <= 1e-11 * scale.expand(-1, cols, cols)[:, upper]).all()  # vector lanes == matrix cores
     Jv = J.view(rows, cols, count)
     sl = slice(count - 2048, count)

@@ -60,3 +60,15 @@ def test_two_rank_timing_reduction_and_coverage():
 def test_reductions_are_identities_on_one_rank():
     assert reduce_timing(0.5, 7) == (0.5, 7)
     assert reduce_sums([1.5, 2]) == [1.5, 2.0]
+
+
+def test_padded_stride_properties():
+    """Element stride of unit-fastest operands (sharding.padded_stride): whole 128-byte segments, never smaller than the node
+    count, segment count 3 mod 4 (so never a multiple of a large power of two), idempotent enough to be cheap (< 128 nodes of padding)."""
+    from ungar_amd.sharding import padded_stride
+    for nodes in list(range(0, 200)) + [4096 * 20, 8192 * 20, 4096 * 128, 16384 * 200, 65536 * 20, 81937]:
+        st = padded_stride(nodes)
+        assert st >= nodes and st % 16 == 0 and (st // 16) % 4 == 3 and st - nodes < 128
+    assert padded_stride(4096 * 20) == 81968
+    with pytest.raises(ValueError):
+        padded_stride(-1)

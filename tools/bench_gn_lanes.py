@@ -42,8 +42,10 @@ def timeit(fn, reps=20):
 upper = cols * (cols + 1) // 2
 alg_bytes = count * 8 * (rows * cols + rows + upper)
 flops = count * 2 * rows * upper  # useful multiply-adds of the upper triangle
-out = {"unroll": os.environ.get("UNGAR_GN_LANES_UNROLL", "default"), "nodes": count}
-for name, fn in (("lanes_unit_fastest_out", lambda: ungar_amd.gn_hessian_lanes(J, d, G_uf, rows, cols, count, True)),
+out = {"unroll": os.environ.get("UNGAR_GN_LANES_UNROLL", "default"), "stage": os.environ.get("UNGAR_GN_TILES_STAGE", "default"), "nodes": count}
+for name, fn in (("tiles_unit_fastest_out", lambda: ungar_amd.gn_hessian_tiles(J, d, G_uf, rows, cols, count, True)),
+                 ("tiles_node_major_out", lambda: ungar_amd.gn_hessian_tiles(J, d, G_nm, rows, cols, count, False)),
+                 ("lanes_unit_fastest_out", lambda: ungar_amd.gn_hessian_lanes(J, d, G_uf, rows, cols, count, True)),
                  ("lanes_node_major_out", lambda: ungar_amd.gn_hessian_lanes(J, d, G_nm, rows, cols, count, False)),
                  ("mfma_lds_staged_node_major_out", lambda: ungar_amd.gn_hessian_unit_fastest(J, d, G_nm, rows, cols, count))):
     ms = timeit(fn)
@@ -51,7 +53,9 @@ for name, fn in (("lanes_unit_fastest_out", lambda: ungar_amd.gn_hessian_lanes(J
 ref = torch.einsum("ran,rn,rbn->abn", J.view(rows, cols, count)[:, :, :4096], d[:, :4096], J.view(rows, cols, count)[:, :, :4096])
 iu = torch.triu_indices(cols, cols, device="cuda")
 out["max_err_vs_torch"] = float((G_uf.view(cols, cols, count)[iu[0], iu[1], :4096] - ref[iu[0], iu[1]]).abs().max() / ref.abs().max())
-chain = timeit(lambda: (m.dense_jacobian(*ops, knots=N), ungar_amd.gn_hessian_lanes(J, d, G_uf, rows, cols, count, True)))
+ungar_amd.gn_hessian_tiles(J, d, G_uf, rows, cols, count, True)
+out["max_err_tiles_vs_torch"] = float((G_uf.view(cols, cols, count)[iu[0], iu[1], :4096] - ref[iu[0], iu[1]]).abs().max() / ref.abs().max())
+chain = timeit(lambda: (m.dense_jacobian(*ops, knots=N), ungar_amd.gn_hessian_tiles(J, d, G_uf, rows, cols, count, True)))
 out["chain_node_jacobian_plus_gn_ms"] = chain
 out["node_jacobian_ms"] = timeit(lambda: m.dense_jacobian(*ops, knots=N))
 print(json.dumps(out))

@@ -21,7 +21,7 @@ from dataclasses import dataclass
 
 import numpy as np
 
-__all__ = ["NodeModel", "Operand", "gn_hessian", "gn_hessian_lanes", "gn_hessian_unit_fastest", "library_path", "load_library", "UngarError", "MODELS"]
+__all__ = ["NodeModel", "Operand", "gn_hessian", "gn_hessian_lanes", "gn_hessian_tiles", "gn_hessian_unit_fastest", "library_path", "load_library", "UngarError", "MODELS"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 MODELS = ("quadrotor", "rc_car", "srbd", "anymal", "anymal_ad", "anymal_reg")
@@ -85,6 +85,8 @@ def load_library() -> ctypes.CDLL:
                                        ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, vp]
     lib.ungar_gn_hessian_upper_unit_fastest.argtypes = [vp, ctypes.c_int64, vp, ctypes.c_int64, vp, ctypes.c_int64, ctypes.c_int64,
                                                         ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, vp]
+    lib.ungar_gn_hessian_upper_tiles.argtypes = [vp, ctypes.c_int64, vp, ctypes.c_int64, vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
+                                                 ctypes.c_int64, vp]
     lib.ungar_gn_hessian_upper_lanes.argtypes = [vp, ctypes.c_int64, vp, ctypes.c_int64, vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
                                                  ctypes.c_int64, vp]
     lib.ungar_model_prepare.argtypes = [vp]
@@ -313,6 +315,14 @@ def gn_hessian_lanes(jac, d, g, rows: int, cols: int, count: int, unit_fastest_o
     lib = load_library()
     ges, gns = (g.stride(0), 1) if unit_fastest_out else (1, cols * cols)
     _check(lib.ungar_gn_hessian_upper_lanes(jac.data_ptr(), jac.stride(0), d.data_ptr() if d is not None else None, d.stride(0) if d is not None else 0, g.data_ptr(),
+                                            ges, gns, cols, rows, cols, count, NodeModel._stream(stream)))
+
+
+def gn_hessian_tiles(jac, d, g, rows: int, cols: int, count: int, unit_fastest_out: bool = True, stream=None):
+    """Upper triangle of G = J^T diag(d) J, one lane per (node, 7 x 7 block), Jacobian rows streamed once through LDS.  Operands as gn_hessian_lanes."""
+    lib = load_library()
+    ges, gns = (g.stride(0), 1) if unit_fastest_out else (1, cols * cols)
+    _check(lib.ungar_gn_hessian_upper_tiles(jac.data_ptr(), jac.stride(0), d.data_ptr() if d is not None else None, d.stride(0) if d is not None else 0, g.data_ptr(),
                                             ges, gns, cols, rows, cols, count, NodeModel._stream(stream)))
 
 

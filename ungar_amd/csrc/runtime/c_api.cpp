@@ -285,6 +285,20 @@ int ungar_gn_hessian_upper_lanes(const double* jac, int64_t j_es, const double* 
     if (err != 0) return Fail(UNGAR_E_HIP, std::string("gn_hessian (lane per node) launch failed: ") + hipGetErrorString(static_cast<hipError_t>(err)));
     return UNGAR_OK;
 }
+extern "C" int ungar_amd_gn_hessian_tiles_supported(int cols);
+extern "C" int ungar_amd_launch_gn_hessian_tiles(const double* jac, long long jes, const double* d, long long des, double* g, long long ges, long long gns,
+                                                  long long ldg, int rows, int cols, long long count, void* stream);
+int ungar_gn_hessian_upper_tiles(const double* jac, int64_t j_es, const double* d, int64_t d_es, double* g, int64_t g_es, int64_t g_ns, int64_t ld_g, int32_t rows,
+                                 int32_t cols, int64_t count, void* stream) {
+    if (!jac || !g) return Fail(UNGAR_E_INVALID, "ungar_gn_hessian_upper_tiles: null jac or g");
+    if (rows <= 0 || cols <= 0 || count < 0 || ld_g < cols || j_es < count || (d && d_es < count)) return Fail(UNGAR_E_INVALID, "ungar_gn_hessian_upper_tiles: bad dimensions");
+    if (count == 0) return UNGAR_OK;
+    // Block shapes without a compiled instance of the (node, block)-per-lane kernel take the lane-per-node kernel: same operands, same result.
+    if (!ungar_amd_gn_hessian_tiles_supported(cols)) return ungar_gn_hessian_upper_lanes(jac, j_es, d, d_es, g, g_es, g_ns, ld_g, rows, cols, count, stream);
+    const int err = ungar_amd_launch_gn_hessian_tiles(jac, j_es, d, d_es, g, g_es, g_ns, ld_g, rows, cols, count, stream);
+    if (err != 0) return Fail(UNGAR_E_HIP, std::string("gn_hessian (lane per block) launch failed: ") + hipGetErrorString(static_cast<hipError_t>(err)));
+    return UNGAR_OK;
+}
 namespace {
 int GnHessian(const double* jac, int64_t js, int64_t ld_j, const double* d, int64_t ds, double* g, int64_t gs, int64_t ld_g, int32_t rows, int32_t cols,
               int64_t count, int upperOnly, void* stream);

@@ -22,6 +22,26 @@ def shard_range(total_instances: int, world: int, rank: int) -> tuple[int, int]:
 DEFAULT_TILE_INSTANCES = 8192
 
 
+# Element stride of a unit-fastest operand.  With the natural stride (= nodes of the operand) the batch sizes of interest put
+# consecutive elements a multiple of 2^17 bytes apart (4096 instances x 20 knots x 8 B = 5 x 2^17), so all 1813 store streams
+# of a wavefront -- and all Jacobian rows a Gauss-Newton workgroup reads -- fall on the SAME memory channel.  Padding the
+# stride by a few 128-byte segments rotates them over the channels: ANYmal node Jacobians 0.30-0.31 -> 0.25 ms per 81 920 nodes,
+# the Gauss-Newton kernel 0.53 -> 0.45 ms (tools/bench_stride_pad.py, profiles/r02e_stride_pad.json).  Any pad >= 32 nodes
+# (256 B) recovers the node kernel; the contraction additionally prefers an odd number of segments.
+def padded_stride(nodes: int) -> int:
+    """Element stride (in doubles) for a unit-fastest operand of `nodes` nodes: a multiple of 16 nodes (128-byte segments stay
+    aligned) whose segment count is 3 mod 4, at least 32 nodes larger than a power-of-two-ish `nodes`."""
+    if nodes < 0:
+        raise ValueError("bad node count")
+    segments = -(-nodes // 16)
+    return 16 * ((segments + 2) | 3)
+
+
+def unit_fastest(elements: int, nodes: int, torch, device="cuda"):
+    """Uninitialised (elements, nodes) float64 view with the padded element stride; pass `t.stride(0)` as the operand's element stride."""
+    return torch.empty((elements, padded_stride(nodes)), dtype=torch.float64, device=device)[:, :nodes]
+
+
 def tile_ranges(instances: int, tile: int = DEFAULT_TILE_INSTANCES) -> list[tuple[int, int]]:
     """[begin, end) instance ranges of the tiles of a shard: as many equal tiles of at most `tile` instances as needed
     (sizes differ by at most one), so that no launch is much smaller than the others."""
