@@ -24,3 +24,10 @@ cp_if gpurun_out/sqp_prof/sqp_kernel_stats.csv profiles/${tag}_sqp_kernel_stats.
 cp_if gpurun_out/sq_counters.log              profiles/${tag}_sq_counters.log
 cp_if gpurun_out/pytest_gpu.log               profiles/pytest_gpu_${tag}.log
 cp_if gpurun_out/smoke.log                    profiles/smoke_${tag}.log
+cp_if gpurun_out/gn_chain.json                profiles/${tag}_gn_chain.json
+cp_if gpurun_out/gn_chain_natural_stride.json profiles/${tag}_gn_chain_natural_stride.json
+cp_if gpurun_out/gn_tiles_counters.json       profiles/${tag}_gn_tiles_counters.json
+cp_if gpurun_out/gnt_prof/gnt_kernel_stats.csv profiles/${tag}_gn_chain_kernel_stats.csv
+cp_if gpurun_out/gn_tiles_ablation.log        profiles/${tag}_gn_tiles_ablation.log
+cp_if gpurun_out/fp64_peaks.log               profiles/${tag}_fp64_peaks.log
+cp_if gpurun_out/prewarm.log                  profiles/${tag}_prewarm.log

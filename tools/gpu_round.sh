@@ -8,6 +8,8 @@ export TMPDIR=/tmp
 echo "== pytest -m gpu"; timeout 3000 python -m pytest tests -m gpu -x -q 2>&1 | tail -12 | tee gpurun_out/pytest_gpu.log
 echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -4 | tee gpurun_out/smoke.log
 echo "== bench"; timeout 900 python bench.py 2>gpurun_out/bench.err | tail -1 > gpurun_out/bench.log; cut -c1-400 gpurun_out/bench.log
+echo "== bench, the driver's command (20 steps, 5 warm-up) with and without the pre-warm"
+for p in 0 0.5 0 0.5; do timeout 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-sub-results --prewarm-seconds $p 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('prewarm $p: kernel_ms', round(d['roofline']['kernel_ms'],4), 'frac', round(d['roofline']['frac'],3), 'ms_per_step', round(d['ms_per_step'],4), 'value', round(d['value']/1e8,3), 'e8 evals/s')"; done | tee gpurun_out/prewarm.log
 echo "== bench, 2 ranks sharing the device over gloo: control flow of the config-5 partition (65 536 instances)"
 UNGAR_BENCH_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 20 --warmup 3 2>gpurun_out/bench2.err | tail -1 > gpurun_out/bench_2rank_gloo.log
 timeout 600 python bench.py --total-batch 65536 --steps 20 --warmup 3 --no-cpu-baseline --no-sub-results 2>&1 | tail -1 > gpurun_out/bench_config5_1gpu.log
@@ -28,6 +30,10 @@ echo "== Gauss-Newton term (MFMA kernels, lane-per-node kernel, chain) and layou
 timeout 300 python tools/bench_gn_hessian.py 2>&1 | tail -1 > gpurun_out/gn_full.json
 timeout 300 python tools/bench_gn_hessian.py --upper 2>&1 | tail -1 > gpurun_out/gn_upper.json
 timeout 300 python tools/bench_gn_lanes.py 2>&1 | tail -1 > gpurun_out/gn_lanes.json
+echo "== config-4 chain: node Jacobians -> Gauss-Newton term (lane-per-(node, block) kernel), kernel stats + HBM / SQ counters"
+bash tools/gpu_gn_tiles_profile.sh 2>&1 | tail -24
+tools/_bin/gn_tiles_bench 2>&1 | tail -4 | tee gpurun_out/gn_tiles_ablation.log
+tools/_bin/valu_f64_peak 2>&1 | tail -5 | tee gpurun_out/fp64_peaks.log; tools/_bin/mfma_f64_peak 2>&1 | tail -1 | tee -a gpurun_out/fp64_peaks.log
 timeout 300 python tools/bench_layouts.py 2>&1 | tail -3 > gpurun_out/layouts.log
 timeout 300 python tools/bench_ocp_step.py 2>&1 | tail -1 > gpurun_out/ocp_step_srbd.json
 echo "== batched SQP"

@@ -207,10 +207,24 @@ def build_reference_examples(names=("quadrotor", "rc_car", "quadruped", "functio
         _run(["bash", script, *todo])
 
 
+def build_tools():
+    """Standalone measurement harnesses of tools/ (not product code): FP64 issue-rate microbenchmarks and the ablation harness of
+    the Gauss-Newton tiles kernel.  Built into tools/_bin (git-ignored; travels to the GPU box with the snapshot)."""
+    out = os.path.join(ROOT, "tools", "_bin")
+    os.makedirs(out, exist_ok=True)
+    kernel = os.path.join(CSRC, "kernels", "gn_hessian_tiles.hip")
+    for name, deps in (("gn_tiles_bench", [kernel]), ("valu_f64_peak", []), ("mfma_f64_peak", [])):
+        src = os.path.join(ROOT, "tools", f"{name}.hip")
+        exe = os.path.join(out, name)
+        if not _newer([exe], [src, *deps]):
+            _run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-result", "-Wno-unused-value", "-o", exe, src])
+
+
 def build_all():
     generate(build_codegen())
     lib = build_library()
     build_cpp_tests()
+    build_tools()
     return lib
 
 

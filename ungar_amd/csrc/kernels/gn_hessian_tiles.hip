@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace ungar_amd::kernels {
 
@@ -228,6 +229,9 @@ __global__ __launch_bounds__(GnTilesShape<COLS>::block) void GnHessianTilesKerne
     store(finished);
 }
 
+/// 1 KiB of zeros: what the LDS-DMA copies of the rows past the end of a Jacobian read (they cannot be predicated into zeros).
+__device__ const double kGnTilesZeros[128] = {};
+
 /// The same pipeline with the global -> LDS copies done by the LDS-DMA path (global_load_lds_dwordx4: 16 bytes per lane, 1 KiB
 /// per wavefront instruction straight into LDS -- no staging registers, no ds_write pass, no wait-then-write in the instruction
 /// stream of the arithmetic).  A stage is 8 Jacobian rows = 8 * COLS row-column indices of 16 nodes = COLS KiB = COLS
@@ -236,6 +240,8 @@ __global__ __launch_bounds__(GnTilesShape<COLS>::block) void GnHessianTilesKerne
 /// COUNTED s_waitcnt vmcnt (the copies of the younger stages stay in flight across the barrier -- __syncthreads would drain
 /// them).  Result stores also count in vmcnt; loads complete in order among themselves, so "at most n outstanding" with n = the
 /// copies of the younger stages still implies that the stage is complete (a pending store only makes the wait longer).
+/// The arithmetic of a stage is straight-line code over its 8 rows with two operand sets (the LDS reads of row r + 1 are issued
+/// under the multiply-adds of row r) and immediate row offsets; a last stage with fewer rows contracts zeros.
 /// Needs 16-byte aligned operands: even `count`, `jes`, `des`, 16-byte aligned bases (the launcher checks).
 template <int COLS, int DEPTH, bool WEIGHTED, int DIAG = 0>
 __global__ __launch_bounds__(GnTilesShape<COLS>::block) void GnHessianTilesDmaKernel(const double* __restrict__ jac, long long jes, const double* __restrict__ d, long long des,
@@ -303,18 +309,18 @@ __global__ __launch_bounds__(GnTilesShape<COLS>::block) void GnHessianTilesDmaKe
                 auto* to = (__attribute__((address_space(3))) void*)(dst + c * 128);
                 if (first + 8 <= total) {
                     __builtin_amdgcn_global_load_lds(jacBytes + first * jes * static_cast<long long>(sizeof(double)) + laneBytes, to, 16, 0, 0);
-                } else {  // rows past the end (last stage only): any valid address -- the arithmetic stops at the last row
-                    long long rc = first + subIndex;
-                    if (rc > total - 1) rc = total - 1;
-                    __builtin_amdgcn_global_load_lds(jac + (rc * jes + node), to, 16, 0, 0);
+                } else {  // last stage of a Jacobian whose row count is not a multiple of 8: rows past the end are copied from zeros
+                    const long long rc = first + subIndex;
+                    const double* from = rc < total ? jac + (rc * jes + node) : kGnTilesZeros + lane * 2;
+                    __builtin_amdgcn_global_load_lds(from, to, 16, 0, 0);
                 }
             }
         }
         if constexpr (WEIGHTED) {
             if (wave == 0) {
-                long long r = static_cast<long long>(stage) * STAGE + subIndex;
-                if (r > rows - 1) r = rows - 1;
-                __builtin_amdgcn_global_load_lds(d + (r * des + node), (__attribute__((address_space(3))) void*)(dst + STAGE_ELEMS), 16, 0, 0);
+                const long long r = static_cast<long long>(stage) * STAGE + subIndex;
+                const double* from = r < rows ? d + (r * des + node) : kGnTilesZeros + lane * 2;
+                __builtin_amdgcn_global_load_lds(from, (__attribute__((address_space(3))) void*)(dst + STAGE_ELEMS), 16, 0, 0);
             }
         }
     };
@@ -341,21 +347,27 @@ __global__ __launch_bounds__(GnTilesShape<COLS>::block) void GnHessianTilesDmaKe
                 if (ga < COLS && gb < COLS && ga <= gb) __builtin_nontemporal_store(acc[a][b], gn + (static_cast<long long>(a) * ldg + b) * ges);
             }
     };
-    auto row = [&](unsigned rowBytes, unsigned weightBytes) {
-        double ja[kTile], jb[kTile];
+    // operands of row r of the current stage: base registers (advanced once per stage) + IMMEDIATE row offsets
+    unsigned pa[kTile], pb[kTile], pw = 0;
+    double ja[2][kTile], jb[2][kTile], jw[2];  // two operand sets: the reads of row r + 1 are in flight under the arithmetic of row r
+    auto fetchRow = [&](auto rIndex) {
+        constexpr int r = decltype(rIndex)::value;
 #pragma unroll
-        for (int a = 0; a < kTile; ++a) ja[a] = *reinterpret_cast<const double*>(ldsBytes + (aPtr[a] + rowBytes));
+        for (int a = 0; a < kTile; ++a) ja[r & 1][a] = *reinterpret_cast<const double*>(ldsBytes + pa[a] + r * ROW * sizeof(double));
 #pragma unroll
-        for (int b = 0; b < kTile; ++b) jb[b] = *reinterpret_cast<const double*>(ldsBytes + (bPtr[b] + rowBytes));
+        for (int b = 0; b < kTile; ++b) jb[r & 1][b] = *reinterpret_cast<const double*>(ldsBytes + pb[b] + r * ROW * sizeof(double));
+        if constexpr (WEIGHTED) jw[r & 1] = *reinterpret_cast<const double*>(ldsBytes + pw + r * kNodes * sizeof(double));
+    };
+    auto contractRow = [&](auto rIndex) {
+        constexpr int r = decltype(rIndex)::value;
         if constexpr (WEIGHTED) {
-            const double w = *reinterpret_cast<const double*>(ldsBytes + weightBytes);
 #pragma unroll
-            for (int a = 0; a < kTile; ++a) ja[a] *= w;
+            for (int a = 0; a < kTile; ++a) ja[r & 1][a] *= jw[r & 1];
         }
 #pragma unroll
         for (int a = 0; a < kTile; ++a)
 #pragma unroll
-            for (int b = 0; b < kTile; ++b) acc[a][b] = fma(ja[a], jb[b], acc[a][b]);
+            for (int b = 0; b < kTile; ++b) acc[a][b] = fma(ja[r & 1][a], jb[r & 1][b], acc[a][b]);
     };
     clear();
 
@@ -398,11 +410,29 @@ __global__ __launch_bounds__(GnTilesShape<COLS>::block) void GnHessianTilesDmaKe
             }
             if (computes && (DIAG != 2 || rows < 0)) {
                 const unsigned bufBytes = static_cast<unsigned>(buf * BUF * sizeof(double));
-                const unsigned weightBytes = bufBytes + static_cast<unsigned>((STAGE_ELEMS + n) * sizeof(double));
-                const int here = rows - s * STAGE;  // uniform: rows of this stage
-                const int bound = here < STAGE ? here : STAGE;
-#pragma unroll 2
-                for (int r = 0; r < bound; ++r) row(bufBytes + static_cast<unsigned>(r * ROW * sizeof(double)), weightBytes + static_cast<unsigned>(r * kNodes * sizeof(double)));
+#pragma unroll
+                for (int i = 0; i < kTile; ++i) {
+                    pa[i] = aPtr[i] + bufBytes;
+                    pb[i] = bPtr[i] + bufBytes;
+                }
+                pw = bufBytes + static_cast<unsigned>((STAGE_ELEMS + n) * sizeof(double));
+                // straight line, no branches: rows past the end of the Jacobian were copied from a block of zeros
+                fetchRow(std::integral_constant<int, 0>{});
+                fetchRow(std::integral_constant<int, 1>{});
+                contractRow(std::integral_constant<int, 0>{});
+                fetchRow(std::integral_constant<int, 2>{});
+                contractRow(std::integral_constant<int, 1>{});
+                fetchRow(std::integral_constant<int, 3>{});
+                contractRow(std::integral_constant<int, 2>{});
+                fetchRow(std::integral_constant<int, 4>{});
+                contractRow(std::integral_constant<int, 3>{});
+                fetchRow(std::integral_constant<int, 5>{});
+                contractRow(std::integral_constant<int, 4>{});
+                fetchRow(std::integral_constant<int, 6>{});
+                contractRow(std::integral_constant<int, 5>{});
+                fetchRow(std::integral_constant<int, 7>{});
+                contractRow(std::integral_constant<int, 6>{});
+                contractRow(std::integral_constant<int, 7>{});
             }
             buf = buf + 1 == DEPTH ? 0 : buf + 1;
         }
