@@ -155,7 +155,7 @@ int ungar_gn_hessian_upper_lanes(const double* jac, int64_t j_es, const double* 
 /* The same operands and result as ungar_gn_hessian_upper_lanes with ONE LANE PER (node, 7 x 7 block of G): a workgroup owns 16
  * consecutive nodes, streams their Jacobian rows once through LDS (double buffered) and every lane accumulates its block on
  * the FP64 vector ALU -- each Jacobian byte leaves HBM once (the lane-per-node kernel re-reads it 8 times through L1 / L2).
- * Compiled for the block widths of the built-in models (cols = 49, 37, 17, 8); other widths are forwarded to the
+ * Compiled for the block widths of the built-in models (cols = 49, 37, 17); other widths are forwarded to the
  * lane-per-node kernel.  This is the kernel of BASELINE config 4's chain node Jacobians -> Gauss-Newton term.
  * (soft_sqp.hpp:257-264). */
 int ungar_gn_hessian_upper_tiles(const double* jac, int64_t j_es, const double* d, int64_t d_es, double* g, int64_t g_es, int64_t g_ns, int64_t ld_g,

@@ -31,3 +31,4 @@ cp_if gpurun_out/gnt_prof/gnt_kernel_stats.csv profiles/${tag}_gn_chain_kernel_s
 cp_if gpurun_out/gn_tiles_ablation.log        profiles/${tag}_gn_tiles_ablation.log
 cp_if gpurun_out/fp64_peaks.log               profiles/${tag}_fp64_peaks.log
 cp_if gpurun_out/prewarm.log                  profiles/${tag}_prewarm.log
+cp_if gpurun_out/gn_shapes.json                profiles/${tag}_gn_shapes.json

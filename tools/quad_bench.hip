@@ -14,6 +14,9 @@
 using namespace ungar_amd::kernels;
 namespace Q = ungar_amd::gen::anymal_quad;
 
+#ifndef BENCH_BUF
+#define BENCH_BUF true  // MUBUF result stores: what the launcher picks when the operands span < 4 GiB
+#endif
 #ifndef BENCH_STREAM
 #define BENCH_STREAM true  // non-temporal stores: what the launcher picks for this 1.2 GB unit-fastest output
 #endif
@@ -160,7 +163,7 @@ int main(int argc, char** argv) {
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
     auto launch = [&] {
-        hipLaunchKernelGGL((QuadNodeKernel<64, Q::kLdsSlots, Q::kLdsUniformSlots, false, BENCH_STREAM, Body>), grid, block, 0, 0, a, static_cast<const double(*)[4]>(sym), Body{});
+        hipLaunchKernelGGL((QuadNodeKernel<64, Q::kLdsSlots, Q::kLdsUniformSlots, false, BENCH_STREAM, Body, NoSparsePlan, unsigned, BENCH_BUF>), grid, block, 0, 0, a, static_cast<const double(*)[4]>(sym), Body{});
     };
     const int mode = argc > 2 ? std::atoi(argv[2]) : 0;
     if (mode) {
@@ -214,9 +217,13 @@ int main(int argc, char** argv) {
         std::printf("\n");
         return 0;
     }
-    for (int i = 0; i < 3; ++i) launch();
+    // steady-state clocks first (bench.py does the same): ~0.5 s of untimed launches
+    for (int i = 0; i < 1800; ++i) {
+        launch();
+        if (i % 100 == 99) CK(hipDeviceSynchronize());
+    }
     CK(hipDeviceSynchronize());
-    const int reps = 20;
+    const int reps = 100;
     CK(hipEventRecord(e0));
     for (int i = 0; i < reps; ++i) launch();
     CK(hipEventRecord(e1));

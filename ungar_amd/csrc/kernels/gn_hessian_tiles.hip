@@ -445,71 +445,91 @@ __global__ __launch_bounds__(GnTilesShape<COLS>::block) void GnHessianTilesDmaKe
 
 }  // namespace ungar_amd::kernels
 
-/// 1 if the (cols) shape has a compiled instance.
-extern "C" int ungar_amd_gn_hessian_tiles_supported(int cols) { return cols == 49 || cols == 37 || cols == 17 || cols == 8; }
+namespace {
+
+using ungar_amd::kernels::GnHessianTilesDmaKernel;
+using ungar_amd::kernels::GnHessianTilesKernel;
+using ungar_amd::kernels::GnTilesShape;
+using ungar_amd::kernels::kNodes;
+using ungar_amd::kernels::kTile;
+
+struct GnTilesCall {
+    const double* jac;
+    long long jes;
+    const double* d;
+    long long des;
+    double* g;
+    long long ges, gns, ldg;
+    int rows;
+    long long count;
+    hipStream_t stream;
+    unsigned workgroups;
+};
+
+/// LDS-DMA pipeline (DEPTH stage buffers of 8 rows).
+template <int C, int DEPTH>
+void LaunchDma(const GnTilesCall& c) {
+    const size_t bytes = static_cast<size_t>(DEPTH) * (8 * C * kNodes + 8 * kNodes + (GnTilesShape<C>::side * kTile - C) * kNodes) * sizeof(double);
+    auto launch = [&](auto kernel) {
+        static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+        (void)once;
+        hipLaunchKernelGGL(kernel, dim3(c.workgroups), dim3(GnTilesShape<C>::block), bytes, c.stream, c.jac, c.jes, c.d, c.des, c.g, c.ges, c.gns, c.ldg, c.rows, c.count);
+    };
+    if (c.d) launch(GnHessianTilesDmaKernel<C, DEPTH, true>);
+    else launch(GnHessianTilesDmaKernel<C, DEPTH, false>);
+}
+
+/// Register-staged pipeline (STAGE rows per barrier): any alignment.
+template <int C, int STAGE>
+void LaunchStaged(const GnTilesCall& c) {
+    if (c.d) hipLaunchKernelGGL((GnHessianTilesKernel<C, STAGE, true>), dim3(c.workgroups), dim3(GnTilesShape<C>::block), 0, c.stream, c.jac, c.jes, c.d, c.des, c.g, c.ges, c.gns, c.ldg, c.rows, c.count);
+    else hipLaunchKernelGGL((GnHessianTilesKernel<C, STAGE, false>), dim3(c.workgroups), dim3(GnTilesShape<C>::block), 0, c.stream, c.jac, c.jes, c.d, c.des, c.g, c.ges, c.gns, c.ldg, c.rows, c.count);
+}
+
+}  // namespace
+
+/// 1 if the (cols) shape has a compiled instance: the widths of the built-in models' Jacobians with at least three 7-wide blocks
+/// (for 8 columns -- rc_car -- the lane-per-node kernel is the faster one: 0.73 against 0.90 ms per 3.3 M nodes).
+extern "C" int ungar_amd_gn_hessian_tiles_supported(int cols) { return cols == 49 || cols == 37 || cols == 17; }
 
 /// G(a, b) of node i at g[(a * ldg + b) * ges + i * gns]  (unit-fastest: ges >= count, gns = 1; node-major: ges = 1, gns = block stride).
 extern "C" int ungar_amd_launch_gn_hessian_tiles(const double* jac, long long jes, const double* d, long long des, double* g, long long ges, long long gns,
                                                   long long ldg, int rows, int cols, long long count, void* stream) {
-    using namespace ungar_amd::kernels;
     if (count <= 0) return 0;
-    hipStream_t s = static_cast<hipStream_t>(stream);
     static const int computeUnits = [] {
         int device = 0, cus = 256;
         if (hipGetDevice(&device) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
-        const char* e = getenv("UNGAR_GN_TILES_WORKGROUPS");  // tuning knob: persistent workgroups per launch (default: one per compute unit)
-        return e ? atoi(e) : cus;
+        return cus;
     }();
     const long long groups = (count + kNodes - 1) / kNodes;
     // persistent workgroups: one per compute unit for the 6-7 wavefront blocks of the wide Jacobians (their registers fill a compute
-    // unit), up to four of the small blocks (cols = 17: 2 wavefronts, cols = 8: 1)
+    // unit), four of the 2-wavefront blocks of cols = 17
     const int side = (cols + kTile - 1) / kTile, wavesPerGroup = (side * (side + 1) / 2 * kNodes + 63) / 64;
-    const long long resident = static_cast<long long>(computeUnits) * (wavesPerGroup >= 4 ? 1 : wavesPerGroup >= 2 ? 2 : 4);
-    const dim3 grid(static_cast<unsigned>(groups < resident ? groups : resident));
-    static const int stage = [] {  // tuning knob: Jacobian rows per barrier
-        const char* e = getenv("UNGAR_GN_TILES_STAGE");
-        return e ? atoi(e) : 4;
-    }();
-#define UNGAR_GN_TILES_LAUNCH(C, S)                                                                                                                         \
-    do {                                                                                                                                                    \
-        if (d) hipLaunchKernelGGL((GnHessianTilesKernel<C, S, true>), grid, dim3(GnTilesShape<C>::block), 0, s, jac, jes, d, des, g, ges, gns, ldg, rows, count);     \
-        else hipLaunchKernelGGL((GnHessianTilesKernel<C, S, false>), grid, dim3(GnTilesShape<C>::block), 0, s, jac, jes, d, des, g, ges, gns, ldg, rows, count);      \
-    } while (0)
-    // LDS-DMA pipeline: needs 16-byte aligned pairs of nodes everywhere
-    static const int depth = [] {  // tuning knob: 0 = register-staged pipeline, 2 / 3 = LDS-DMA pipeline with that many stage buffers
+    const long long resident = static_cast<long long>(computeUnits) * (wavesPerGroup >= 5 ? 1 : wavesPerGroup >= 3 ? 2 : 4);
+    static const int depth = [] {  // tuning knob: 0 = register-staged pipeline only, 2 / 3 = LDS-DMA pipeline with that many stage buffers
         const char* e = getenv("UNGAR_GN_TILES_DMA");
-        return e ? atoi(e) : 2;  // measured (81 920 ANYmal nodes): 0.427 ms with 2 buffers, 0.437 with 3
+        return e ? atoi(e) : 2;  // measured (81 920 ANYmal nodes): 0.427 ms with 2 buffers, 0.437 with 3; register-staged 0.56
     }();
+    const GnTilesCall call{jac, jes, d, des, g, ges, gns, ldg, rows, count, static_cast<hipStream_t>(stream), static_cast<unsigned>(groups < resident ? groups : resident)};
+    // the LDS-DMA path copies 16-byte pairs of nodes: even count and strides, 16-byte aligned bases
     const bool aligned = count % 2 == 0 && jes % 2 == 0 && reinterpret_cast<unsigned long long>(jac) % 16 == 0 &&
                          (!d || (des % 2 == 0 && reinterpret_cast<unsigned long long>(d) % 16 == 0));
-    if (depth >= 2 && aligned && cols == 49) {
-        auto launch = [&](auto kernel, int buffers) {
-            constexpr int C = 49;
-            const size_t bytes = static_cast<size_t>(buffers) * (8 * C * kNodes + 8 * kNodes + (GnTilesShape<C>::side * kTile - C) * kNodes) * sizeof(double);
-            static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
-            (void)once;
-            hipLaunchKernelGGL(kernel, grid, dim3(GnTilesShape<C>::block), bytes, s, jac, jes, d, des, g, ges, gns, ldg, rows, count);
-        };
-        if (depth == 2) {
-            if (d) launch(GnHessianTilesDmaKernel<49, 2, true>, 2);
-            else launch(GnHessianTilesDmaKernel<49, 2, false>, 2);
-        } else {
-            if (d) launch(GnHessianTilesDmaKernel<49, 3, true>, 3);
-            else launch(GnHessianTilesDmaKernel<49, 3, false>, 3);
-        }
-        return static_cast<int>(hipGetLastError());
-    }
+    const bool dma = depth >= 2 && aligned;
     switch (cols) {
         case 49:
-            if (stage == 2) UNGAR_GN_TILES_LAUNCH(49, 2);
-            else if (stage == 8) UNGAR_GN_TILES_LAUNCH(49, 8);
-            else UNGAR_GN_TILES_LAUNCH(49, 4);
+            if (dma && depth == 3) LaunchDma<49, 3>(call);
+            else if (dma) LaunchDma<49, 2>(call);
+            else LaunchStaged<49, 4>(call);
             break;
-        case 37: UNGAR_GN_TILES_LAUNCH(37, 4); break;
-        case 17: UNGAR_GN_TILES_LAUNCH(17, 8); break;
-        case 8: UNGAR_GN_TILES_LAUNCH(8, 8); break;
+        case 37:
+            if (dma) LaunchDma<37, 2>(call);
+            else LaunchStaged<37, 4>(call);
+            break;
+        case 17:
+            if (dma) LaunchDma<17, 2>(call);
+            else LaunchStaged<17, 8>(call);
+            break;
         default: return static_cast<int>(hipErrorInvalidValue);
     }
-#undef UNGAR_GN_TILES_LAUNCH
     return static_cast<int>(hipGetLastError());
 }
