@@ -161,6 +161,16 @@ int ungar_gn_hessian_upper_lanes(const double* jac, int64_t j_es, const double* 
 int ungar_gn_hessian_upper_tiles(const double* jac, int64_t j_es, const double* d, int64_t d_es, double* g, int64_t g_es, int64_t g_ns, int64_t ld_g,
                                  int32_t rows, int32_t cols, int64_t count, void* stream);
 
+/* ---- layout conversion ----------------------------------------------------------------------------------- */
+
+/* dst[n * dst_node_stride + e * dst_element_stride] = src[n * src_node_stride + e * src_element_stride]   for n < count, e < elements
+ * (strides in doubles), through 64 x 64 LDS tiles: coalesced on both sides when one operand is unit-fastest (node stride 1) and the other
+ * instance-major (element stride 1).  The reference hands instance-major data (`Eigen::Map`s over one VariableMap buffer per instance,
+ * function.hpp:186-257); the node kernels are fastest on unit-fastest operands -- for wide Jacobians (ANYmal: 5.8x) it pays to transpose
+ * the inputs in and the Jacobian out around the unit-fastest launch.  Device pointers; src and dst must not overlap. */
+int ungar_transpose_nodes(const double* src, int64_t src_node_stride, int64_t src_element_stride, double* dst, int64_t dst_node_stride, int64_t dst_element_stride,
+                          int64_t count, int32_t elements, void* stream);
+
 /* ---- whole-horizon assembly ------------------------------------------ */
 
 /* Sparsity of the equality-constraint Jacobian  d g / d [X | U]  of a horizon-N OCP built on `model`,

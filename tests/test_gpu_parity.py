@@ -487,3 +487,51 @@ def test_barrier_gauss_newton_term_on_device(ua, repo_root):
     iu = np.triu_indices(ncols)
     assert np.abs(Gh[:, iu[0], iu[1]] - ref[:, iu[0], iu[1]]).max() <= 1e-10 * np.abs(ref).max()
     assert np.abs(ref).max() > 1.0, "active barrier rows expected in the fixture"
+
+
+def test_transpose_nodes_between_the_two_layouts(ua):
+    """ungar_transpose_nodes: unit-fastest <-> instance-major, bit-exact, ragged sizes (not multiples of the 64 x 64 tile),
+    padded element strides and leading dimensions; cells outside (count, elements) are left untouched."""
+    import torch
+    from ungar_amd.sharding import padded_stride
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(11)
+    for count, elements in ((1000, 1813), (64, 64), (1, 1), (130, 49), (4099, 37)):
+        st, ld = padded_stride(count), elements + 3
+        soa = torch.full((elements, st), float("nan"), dtype=torch.float64, device="cuda")
+        soa[:, :count] = torch.rand((elements, count), generator=gen, device="cuda", dtype=torch.float64)
+        aos = torch.full((count, ld), float("nan"), dtype=torch.float64, device="cuda")
+        ua.transpose_nodes(soa, aos, count, elements, (1, st), (ld, 1))
+        torch.cuda.synchronize()
+        assert torch.equal(aos[:, :elements], soa[:, :count].t()) and torch.isnan(aos[:, elements:]).all()
+        back = torch.full((elements, st), float("nan"), dtype=torch.float64, device="cuda")
+        ua.transpose_nodes(aos, back, count, elements, (ld, 1), (1, st))
+        torch.cuda.synchronize()
+        assert torch.equal(back[:, :count], soa[:, :count]) and torch.isnan(back[:, count:]).all()
+
+
+def test_instance_major_caller_through_transposes_matches_direct_launch(ua):
+    """The recipe of INTEGRATION.md section 4 for instance-major callers of the wide ANYmal Jacobian: transpose (x, u) in, run the
+    unit-fastest kernel, transpose (f, J) out -- same bits as launching the kernel on the instance-major operands directly."""
+    import torch
+    from ungar_amd import workloads as W
+    from ungar_amd.sharding import unit_fastest
+    count = 2048
+    m = ua.NodeModel("anymal")
+    ncols = m.nx + m.nu
+    xs, us, _, p = W.synth_device_inputs("anymal", count, 6, torch)
+    x_aos, u_aos = xs.t().contiguous(), us.t().contiguous()
+    Op = ua.Operand
+    f_ref = torch.empty((count, m.nx), dtype=torch.float64, device="cuda")
+    J_ref = torch.empty((count, m.nx * ncols), dtype=torch.float64, device="cuda")
+    m.dense_jacobian(count, Op.aos(x_aos, m.nx), Op.aos(u_aos, m.nu), None, Op.per_instance(p, m.np, shared=True), Op.aos(f_ref, m.nx), Op.aos(J_ref, m.nx * ncols))
+    x, u, f, J = (unit_fastest(r, count, torch) for r in (m.nx, m.nu, m.nx, m.nx * ncols))
+    st = x.stride(0)
+    ua.transpose_nodes(x_aos, x, count, m.nx, (m.nx, 1), (1, st))
+    ua.transpose_nodes(u_aos, u, count, m.nu, (m.nu, 1), (1, st))
+    m.dense_jacobian(count, Op.soa(x, st), Op.soa(u, st), None, Op.per_instance(p, m.np, shared=True), Op.soa(f, st), Op.soa(J, st))
+    f_out, J_out = torch.empty_like(f_ref), torch.empty_like(J_ref)
+    ua.transpose_nodes(f, f_out, count, m.nx, (1, st), (m.nx, 1))
+    ua.transpose_nodes(J, J_out, count, m.nx * ncols, (1, st), (m.nx * ncols, 1))
+    torch.cuda.synchronize()
+    assert torch.equal(f_out, f_ref) and torch.equal(J_out, J_ref)

@@ -21,7 +21,7 @@ from dataclasses import dataclass
 
 import numpy as np
 
-__all__ = ["NodeModel", "Operand", "gn_hessian", "gn_hessian_lanes", "gn_hessian_tiles", "gn_hessian_unit_fastest", "library_path", "load_library", "UngarError", "MODELS"]
+__all__ = ["NodeModel", "Operand", "gn_hessian", "gn_hessian_lanes", "gn_hessian_tiles", "transpose_nodes", "gn_hessian_unit_fastest", "library_path", "load_library", "UngarError", "MODELS"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 MODELS = ("quadrotor", "rc_car", "srbd", "anymal", "anymal_ad", "anymal_reg")
@@ -85,6 +85,7 @@ def load_library() -> ctypes.CDLL:
                                        ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, vp]
     lib.ungar_gn_hessian_upper_unit_fastest.argtypes = [vp, ctypes.c_int64, vp, ctypes.c_int64, vp, ctypes.c_int64, ctypes.c_int64,
                                                         ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, vp]
+    lib.ungar_transpose_nodes.argtypes = [vp, ctypes.c_int64, ctypes.c_int64, vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, vp]
     lib.ungar_gn_hessian_upper_tiles.argtypes = [vp, ctypes.c_int64, vp, ctypes.c_int64, vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
                                                  ctypes.c_int64, vp]
     lib.ungar_gn_hessian_upper_lanes.argtypes = [vp, ctypes.c_int64, vp, ctypes.c_int64, vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
@@ -316,6 +317,14 @@ def gn_hessian_lanes(jac, d, g, rows: int, cols: int, count: int, unit_fastest_o
     ges, gns = (g.stride(0), 1) if unit_fastest_out else (1, cols * cols)
     _check(lib.ungar_gn_hessian_upper_lanes(jac.data_ptr(), jac.stride(0), d.data_ptr() if d is not None else None, d.stride(0) if d is not None else 0, g.data_ptr(),
                                             ges, gns, cols, rows, cols, count, NodeModel._stream(stream)))
+
+
+def transpose_nodes(src, dst, count: int, elements: int, src_strides, dst_strides, stream=None):
+    """dst[n * dns + e * des] = src[n * sns + e * ses]; src_strides = (node stride, element stride) in doubles, likewise dst_strides.
+    Unit-fastest tensors (elements, count) have strides (1, t.stride(0)); instance-major tensors (count, elements) have (t.stride(0), 1)."""
+    lib = load_library()
+    _check(lib.ungar_transpose_nodes(src.data_ptr(), src_strides[0], src_strides[1], dst.data_ptr(), dst_strides[0], dst_strides[1], count, elements,
+                                     NodeModel._stream(stream)))
 
 
 def gn_hessian_tiles(jac, d, g, rows: int, cols: int, count: int, unit_fastest_out: bool = True, stream=None):

@@ -514,7 +514,8 @@ extern "C" int ungar_amd_launch_gn_hessian_tiles(const double* jac, long long je
     // the LDS-DMA path copies 16-byte pairs of nodes: even count and strides, 16-byte aligned bases
     const bool aligned = count % 2 == 0 && jes % 2 == 0 && reinterpret_cast<unsigned long long>(jac) % 16 == 0 &&
                          (!d || (des % 2 == 0 && reinterpret_cast<unsigned long long>(d) % 16 == 0));
-    const bool dma = depth >= 2 && aligned;
+    const bool laneOffsetsFit32 = jes < (1LL << 26);  // (7 rows x jes + node) x 8 bytes is the 32-bit lane part of a copy's address
+    const bool dma = depth >= 2 && aligned && laneOffsetsFit32;
     switch (cols) {
         case 49:
             if (dma && depth == 3) LaunchDma<49, 3>(call);

@@ -285,6 +285,17 @@ int ungar_gn_hessian_upper_lanes(const double* jac, int64_t j_es, const double* 
     if (err != 0) return Fail(UNGAR_E_HIP, std::string("gn_hessian (lane per node) launch failed: ") + hipGetErrorString(static_cast<hipError_t>(err)));
     return UNGAR_OK;
 }
+extern "C" int ungar_amd_launch_transpose_nodes(const double* src, long long sns, long long ses, double* dst, long long dns, long long des, long long count, int elements,
+                                                 void* stream);
+int ungar_transpose_nodes(const double* src, int64_t src_node_stride, int64_t src_element_stride, double* dst, int64_t dst_node_stride, int64_t dst_element_stride,
+                          int64_t count, int32_t elements, void* stream) {
+    if (!src || !dst) return Fail(UNGAR_E_INVALID, "ungar_transpose_nodes: null src or dst");
+    if (count < 0 || elements < 0) return Fail(UNGAR_E_INVALID, "ungar_transpose_nodes: bad dimensions");
+    if (count == 0 || elements == 0) return UNGAR_OK;
+    const int err = ungar_amd_launch_transpose_nodes(src, src_node_stride, src_element_stride, dst, dst_node_stride, dst_element_stride, count, elements, stream);
+    if (err != 0) return Fail(UNGAR_E_HIP, std::string("transpose_nodes launch failed: ") + hipGetErrorString(static_cast<hipError_t>(err)));
+    return UNGAR_OK;
+}
 extern "C" int ungar_amd_gn_hessian_tiles_supported(int cols);
 extern "C" int ungar_amd_launch_gn_hessian_tiles(const double* jac, long long jes, const double* d, long long des, double* g, long long ges, long long gns,
                                                   long long ldg, int rows, int cols, long long count, void* stream);
