@@ -1,0 +1,31 @@
+#!/usr/bin/env bash
+# TEST INFRASTRUCTURE.  Compiles the reference's OWN unit tests -- test/variable.test.cpp, test/autodiff/function.test.cpp,
+# test/optimization/soft_sqp.test.cpp -- UNCHANGED, from the sources where they lie under /root/reference, against ungar_amd's
+# facade headers and library.  Nothing of the reference is copied and no reference header is on the include path; GoogleTest is not
+# in this image, so tests/gtest_shim/gtest/gtest.h provides the handful of macros those files use (what is under test is the
+# facade, not the reference).  variable.test builds on both algebras (built-in and the real Eigen 3.4 the reference bundles);
+# function.test and soft_sqp.test use Eigen expression forms the built-in algebra does not have and build on the real Eigen.
+# Not built: test/utils/utils.test.cpp (needs Boost.Hana in user code and the out-of-scope utility set), test/rbd/robot.test.cpp
+# (calls Pinocchio directly).  Outputs: oracle/_ref/ref_<name>_test[_eigen] (git-ignored, travel to the GPU box);
+# run by tests/test_reference_tests.py (variable: CPU; function / soft_sqp: -m gpu).
+set -euo pipefail
+here="$(cd "$(dirname "$0")" && pwd)"; root="$(cd "$here/../.." && pwd)"
+ref=${UNGAR_REFERENCE:-/root/reference}
+[ -d "$ref/test" ] || { echo "reference not present: nothing to build"; exit 0; }
+mkdir -p "$root/oracle/_ref"
+eigen=""
+if [ -f "$ref/external/config/eigen/eigen-3.4.0.zip" ]; then
+  scratch="${TMPDIR:-/tmp}/ungar_amd_reference_eigen"
+  [ -d "$scratch/eigen-3.4.0/Eigen" ] || { mkdir -p "$scratch" && unzip -q -o "$ref/external/config/eigen/eigen-3.4.0.zip" -d "$scratch"; }
+  eigen="$scratch/eigen-3.4.0"
+fi
+common=(-std=c++20 -O1 -I "$root/tests/gtest_shim" -I "$root/ungar_amd/include")
+link=(-L "$root/ungar_amd/lib" -lungar_amd -Wl,-rpath,'$ORIGIN/../../ungar_amd/lib' -Wl,-rpath,/opt/rocm/lib)
+g++ "${common[@]}" -o "$root/oracle/_ref/ref_variable_test" "$ref/test/variable.test.cpp"
+echo "built oracle/_ref/ref_variable_test"
+if [ -n "$eigen" ]; then
+  g++ "${common[@]}" -DUNGAR_AMD_USE_SYSTEM_EIGEN -I "$eigen" -o "$root/oracle/_ref/ref_variable_test_eigen" "$ref/test/variable.test.cpp"
+  g++ "${common[@]}" -DUNGAR_AMD_USE_SYSTEM_EIGEN -I "$eigen" -o "$root/oracle/_ref/ref_function_test_eigen" "$ref/test/autodiff/function.test.cpp" "${link[@]}"
+  g++ "${common[@]}" -DUNGAR_AMD_USE_SYSTEM_EIGEN -I "$eigen" -o "$root/oracle/_ref/ref_soft_sqp_test_eigen" "$ref/test/optimization/soft_sqp.test.cpp" "${link[@]}"
+  echo "built oracle/_ref/ref_{variable,function,soft_sqp}_test_eigen (real Eigen 3.4)"
+fi

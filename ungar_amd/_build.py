@@ -187,6 +187,7 @@ def build_cpp_tests():
     with ThreadPoolExecutor(max_workers=4) as pool:
         list(pool.map(_run, jobs))
     build_reference_examples()
+    build_reference_tests()
 
 
 def build_reference_examples(names=("quadrotor", "rc_car", "quadruped", "function", "variable_map")):
@@ -205,6 +206,22 @@ def build_reference_examples(names=("quadrotor", "rc_car", "quadruped", "functio
             todo.append(n)
     if todo:
         _run(["bash", script, *todo])
+
+
+def build_reference_tests():
+    """The reference's own unit tests (variable / function / soft_sqp) compiled unchanged against the facade
+    (oracle/ref_tests): only where the reference is present; binaries land in oracle/_ref and travel to the GPU box."""
+    script = os.path.join(ROOT, "oracle", "ref_tests", "build_ref_tests.sh")
+    ref = os.environ.get("UNGAR_REFERENCE", "/root/reference")
+    srcs = [os.path.join(ref, "test", *rel) for rel in (("variable.test.cpp",), ("autodiff", "function.test.cpp"), ("optimization", "soft_sqp.test.cpp"))]
+    if not all(os.path.exists(f) for f in srcs):
+        return
+    exes = [os.path.join(ROOT, "oracle", "_ref", "ref_variable_test")]
+    if os.path.exists(os.path.join(ref, "external", "config", "eigen", "eigen-3.4.0.zip")):
+        exes += [os.path.join(ROOT, "oracle", "_ref", f"ref_{n}_test_eigen") for n in ("variable", "function", "soft_sqp")]
+    shim = os.path.join(ROOT, "tests", "gtest_shim", "gtest", "gtest.h")
+    if not _newer(exes, srcs + [LIB, script, shim] + _tree(os.path.join(ROOT, "ungar_amd", "include"))):
+        _run(["bash", script])
 
 
 def build_tools():

@@ -59,6 +59,87 @@ inline std::vector<real_t> ToDense(const Sparse& m) {
 namespace Concepts {
 template <class T>
 concept Scalar = std::is_arithmetic_v<T> || requires(T a) { a.IsLiteral(); };
+/// All of `Us` are the type `T` (data_types.hpp:141-142).
+template <class T, class... Us>
+concept Same = (std::same_as<T, Us> && ...);
 }
+
+#if defined(UNGAR_AMD_USE_SYSTEM_EIGEN)
+// The reference's alias families over real Eigen types (data_types.hpp:212-330): Matrix / Vector / RowVector and their
+// Eigen::Ref / Eigen::Map wrappers for sizes 2, 3, 4, X -- `...r` for real_t, templates over the scalar otherwise.  With the
+// built-in algebra (fixed-size vectors and dynamic matrices only) just the subset declared above exists.
+namespace Concepts {
+template <class M>
+concept DenseMatrixExpression = std::derived_from<std::remove_cvref_t<M>, Eigen::MatrixBase<std::remove_cvref_t<M>>>;
+template <class V>
+concept DenseVectorExpression = DenseMatrixExpression<V> && (std::remove_cvref_t<V>::ColsAtCompileTime == 1);
+template <class M>
+concept SparseMatrixExpression = std::derived_from<std::remove_cvref_t<M>, Eigen::SparseMatrixBase<std::remove_cvref_t<M>>>;
+}  // namespace Concepts
+
+#define UNGAR_AMD_ALIAS_FAMILY(N, Suffix)                                                       \
+    template <class S> using Matrix##Suffix = Eigen::Matrix<S, N, N>;                          \
+    template <class S> using RowVector##Suffix = Eigen::Matrix<S, 1, N>;                       \
+    template <class S> using RefToMatrix##Suffix = Eigen::Ref<Eigen::Matrix<S, N, N>>;         \
+    template <class S> using RefToVector##Suffix = Eigen::Ref<Eigen::Matrix<S, N, 1>>;         \
+    template <class S> using RefToRowVector##Suffix = Eigen::Ref<Eigen::Matrix<S, 1, N>>;      \
+    template <class S> using RefToConstMatrix##Suffix = Eigen::Ref<const Eigen::Matrix<S, N, N>>; \
+    template <class S> using RefToConstVector##Suffix = Eigen::Ref<const Eigen::Matrix<S, N, 1>>; \
+    template <class S> using RefToConstRowVector##Suffix = Eigen::Ref<const Eigen::Matrix<S, 1, N>>; \
+    template <class S> using MapToMatrix##Suffix = Eigen::Map<Eigen::Matrix<S, N, N>>;         \
+    template <class S> using MapToVector##Suffix = Eigen::Map<Eigen::Matrix<S, N, 1>>;         \
+    template <class S> using MapToRowVector##Suffix = Eigen::Map<Eigen::Matrix<S, 1, N>>;      \
+    template <class S> using MapToConstMatrix##Suffix = Eigen::Map<const Eigen::Matrix<S, N, N>>; \
+    template <class S> using MapToConstVector##Suffix = Eigen::Map<const Eigen::Matrix<S, N, 1>>; \
+    template <class S> using MapToConstRowVector##Suffix = Eigen::Map<const Eigen::Matrix<S, 1, N>>; \
+    using Matrix##Suffix##r = Matrix##Suffix<real_t>;                                           \
+    using RowVector##Suffix##r = RowVector##Suffix<real_t>;                                     \
+    using RefToMatrix##Suffix##r = RefToMatrix##Suffix<real_t>;                                 \
+    using RefToVector##Suffix##r = RefToVector##Suffix<real_t>;                                 \
+    using RefToRowVector##Suffix##r = RefToRowVector##Suffix<real_t>;                           \
+    using RefToConstMatrix##Suffix##r = RefToConstMatrix##Suffix<real_t>;                       \
+    using RefToConstVector##Suffix##r = RefToConstVector##Suffix<real_t>;                       \
+    using RefToConstRowVector##Suffix##r = RefToConstRowVector##Suffix<real_t>;                 \
+    using MapToMatrix##Suffix##r = MapToMatrix##Suffix<real_t>;                                 \
+    using MapToRowVector##Suffix##r = MapToRowVector##Suffix<real_t>;                           \
+    using MapToConstMatrix##Suffix##r = MapToConstMatrix##Suffix<real_t>;                       \
+    using MapToConstRowVector##Suffix##r = MapToConstRowVector##Suffix<real_t>
+UNGAR_AMD_ALIAS_FAMILY(2, 2);
+UNGAR_AMD_ALIAS_FAMILY(3, 3);
+UNGAR_AMD_ALIAS_FAMILY(4, 4);
+#undef UNGAR_AMD_ALIAS_FAMILY
+// size X: MatrixX / MatrixXr are declared above (Linalg::DenseMatrix IS Eigen::Matrix<S, Dynamic, Dynamic> in this mode)
+template <class S> using RowVectorX = Eigen::Matrix<S, 1, Eigen::Dynamic>;
+template <class S> using RefToMatrixX = Eigen::Ref<Eigen::Matrix<S, Eigen::Dynamic, Eigen::Dynamic>>;
+template <class S> using RefToVectorX = Eigen::Ref<Eigen::Matrix<S, Eigen::Dynamic, 1>>;
+template <class S> using RefToConstMatrixX = Eigen::Ref<const Eigen::Matrix<S, Eigen::Dynamic, Eigen::Dynamic>>;
+template <class S> using RefToConstVectorX = Eigen::Ref<const Eigen::Matrix<S, Eigen::Dynamic, 1>>;
+template <class S> using MapToMatrixX = Eigen::Map<Eigen::Matrix<S, Eigen::Dynamic, Eigen::Dynamic>>;
+template <class S> using MapToVectorX = Eigen::Map<Eigen::Matrix<S, Eigen::Dynamic, 1>>;
+template <class S> using MapToConstMatrixX = Eigen::Map<const Eigen::Matrix<S, Eigen::Dynamic, Eigen::Dynamic>>;
+template <class S> using MapToConstVectorX = Eigen::Map<const Eigen::Matrix<S, Eigen::Dynamic, 1>>;
+using RowVectorXr = RowVectorX<real_t>;
+using RefToMatrixXr = RefToMatrixX<real_t>;
+using RefToVectorXr = RefToVectorX<real_t>;
+using RefToConstMatrixXr = RefToConstMatrixX<real_t>;
+using RefToConstVectorXr = RefToConstVectorX<real_t>;
+using MapToMatrixXr = MapToMatrixX<real_t>;
+using MapToConstMatrixXr = MapToConstMatrixX<real_t>;
+using MapToVector2r = Eigen::Map<Vector2r>;
+using MapToConstVector2r = Eigen::Map<const Vector2r>;
+using MapToVector4r = Eigen::Map<Vector4r>;
+using MapToConstVector4r = Eigen::Map<const Vector4r>;
+template <class S, int N> using RowVector = Eigen::Matrix<S, 1, N>;
+template <class S, int N> using RefToVector = Eigen::Ref<Eigen::Matrix<S, N, 1>>;
+template <class S, int N> using RefToRowVector = Eigen::Ref<Eigen::Matrix<S, 1, N>>;
+template <class S, int N> using RefToConstVector = Eigen::Ref<const Eigen::Matrix<S, N, 1>>;
+template <class S, int N> using RefToConstRowVector = Eigen::Ref<const Eigen::Matrix<S, 1, N>>;
+template <class S> using MapToQuaternion = Eigen::Map<Eigen::Quaternion<S>>;
+template <class S> using MapToConstQuaternion = Eigen::Map<const Eigen::Quaternion<S>>;
+template <class S> using AngleAxis = Eigen::AngleAxis<S>;
+using AngleAxisr = Eigen::AngleAxis<real_t>;
+template <class S> using Rotation2D = Eigen::Rotation2D<S>;
+using Rotation2Dr = Eigen::Rotation2D<real_t>;
+#endif  // UNGAR_AMD_USE_SYSTEM_EIGEN
 
 }  // namespace Ungar

@@ -678,6 +678,19 @@ class Map<const Matrix<S_, N>> : public MatrixBase<Map<const Matrix<S_, N>>> {
 };
 
 // ---- Quaternion (coefficients stored x, y, z, w) -----------------------------------------------------------
+/// Coefficient-wise equality of two vector expressions (Eigen's operator==: sizes must agree).
+template <class A, class B>
+inline bool operator==(const MatrixBase<A>& a, const MatrixBase<B>& b) {
+    assert(a.size() == b.size());
+    for (Index i = 0; i < a.size(); ++i)
+        if (!(a.derived().data()[i] == b.derived().data()[i])) return false;
+    return true;
+}
+template <class A, class B>
+inline bool operator!=(const MatrixBase<A>& a, const MatrixBase<B>& b) {
+    return !(a == b);
+}
+
 template <class Derived>
 class QuaternionBase {
   public:
@@ -688,6 +701,16 @@ class QuaternionBase {
     }
     Derived& derived() {
         return static_cast<Derived&>(*this);
+    }
+    template <class Other>
+    bool operator==(const QuaternionBase<Other>& o) const {  // Eigen 3.4: coeffs() == o.coeffs()
+        for (int i = 0; i < 4; ++i)
+            if (!(derived().data()[i] == o.derived().data()[i])) return false;
+        return true;
+    }
+    template <class Other>
+    bool operator!=(const QuaternionBase<Other>& o) const {
+        return !(*this == o);
     }
     const S& x() const { return derived().data()[0]; }
     const S& y() const { return derived().data()[1]; }

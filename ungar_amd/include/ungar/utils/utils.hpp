@@ -7,6 +7,9 @@
 // exponential map recorded on a tape is always the *approximate*, branch-free one.
 #pragma once
 
+#include <tuple>
+#include <utility>
+
 #include <cmath>
 #include <cstdio>
 #include <stdexcept>
@@ -183,6 +186,137 @@ inline bool CompareMatrices(const real_t* a, std::string_view nameA, const real_
         }
     }
     return ok;
+}
+
+inline constexpr std::string_view DASH_LINE_SEPARATOR = "----------------------------------------------------------------";
+inline constexpr std::string_view STAR_LINE_SEPARATOR = "****************************************************************";
+
+// ---- Decompose / Compose (reference utils/utils.hpp:232-480) -----------------------------------------------------------
+// Decompose<SIZES...>(v) splits a vector into a tuple of views, in order: a size-1 piece is a REFERENCE to the scalar, a piece of
+// size Q an Eigen::Map of a quaternion over 4 coefficients, any other piece an Eigen::Map of a fixed-size vector; the views are
+// const when the vector is (a const lvalue, or an Eigen::Map / Eigen::Ref / block of const data).  Compose(a, b, ...) is the
+// inverse: scalars and vectors concatenated `.In(target)`, `.ToDynamic()` or (all sizes fixed) `.ToFixed()`.
+namespace detail {
+
+constexpr int PieceSize(int size) { return size == static_cast<int>(Q) ? 4 : size; }
+
+template <class S, int SIZE, bool CONST>
+struct Piece {
+    using Data = std::conditional_t<CONST, const S, S>;
+    using type = Eigen::Map<std::conditional_t<CONST, const Vector<S, SIZE>, Vector<S, SIZE>>>;
+    static type Make(Data* p) { return type{p}; }
+};
+template <class S, bool CONST>
+struct Piece<S, 1, CONST> {
+    using Data = std::conditional_t<CONST, const S, S>;
+    using type = Data&;
+    static type Make(Data* p) { return *p; }
+};
+template <class S, bool CONST>
+struct Piece<S, static_cast<int>(Q), CONST> {
+    using Data = std::conditional_t<CONST, const S, S>;
+    using type = Eigen::Map<std::conditional_t<CONST, const Quaternion<S>, Quaternion<S>>>;
+    static type Make(Data* p) { return type{p}; }
+};
+
+template <bool CONST, int... SIZES, class V, std::size_t... IS>
+auto DecomposeAt(V& v, std::index_sequence<IS...>) {
+    using S = std::remove_const_t<typename std::remove_cvref_t<V>::Scalar>;
+    constexpr int sizes[] = {PieceSize(SIZES)..., 0};
+    constexpr auto offset = [](std::size_t i) {
+        int o = 0;
+        for (std::size_t k = 0; k < i; ++k) o += sizes[k];
+        return o;
+    };
+    UNGAR_ASSERT(static_cast<int>(v.size()) == offset(sizeof...(SIZES)));
+    auto* base = const_cast<std::conditional_t<CONST, const S, S>*>(v.data());
+    return std::tuple<typename Piece<S, SIZES, CONST>::type...>{Piece<S, SIZES, CONST>::Make(base + offset(IS))...};
+}
+
+/// Does this vector expression only give const access to its coefficients?
+template <class V>
+inline constexpr bool kReadOnly = std::is_const_v<std::remove_reference_t<V>> ||
+                                  std::is_const_v<std::remove_pointer_t<decltype(std::declval<std::remove_cvref_t<V>&>().data())>>;
+
+template <class T>
+inline constexpr bool kIsVector = requires(const std::remove_cvref_t<T>& t) { t.size(); t.data(); typename std::remove_cvref_t<T>::Scalar; } ||
+                                  requires(const std::remove_cvref_t<T>& t) { t.size(); t[0]; typename std::remove_cvref_t<T>::Scalar; };
+
+template <class T>
+struct ComposableTraits {  // scalars
+    using Scalar = std::remove_cvref_t<T>;
+    static constexpr int size = 1;
+};
+template <class T>
+    requires kIsVector<T>
+struct ComposableTraits<T> {
+    using Scalar = std::remove_const_t<typename std::remove_cvref_t<T>::Scalar>;
+    static constexpr int size = static_cast<int>(std::remove_cvref_t<T>::RowsAtCompileTime);
+};
+
+template <class... Ts>
+class Composition {
+  public:
+    static constexpr bool kAllFixed = ((ComposableTraits<Ts>::size >= 0) && ...);
+    static constexpr int kSize = kAllFixed ? (ComposableTraits<Ts>::size + ... + 0) : -1;
+    using ScalarType = std::common_type_t<typename ComposableTraits<Ts>::Scalar...>;
+
+    explicit Composition(Ts&&... parts) : parts_{std::forward<Ts>(parts)...} {}
+
+    /// Writes the concatenation into `target` (resized when dynamic; a fixed-size target must have the composed size).
+    template <class Target>
+    void In(Target&& target) {
+        auto& out = const_cast<std::remove_cvref_t<Target>&>(static_cast<const std::remove_cvref_t<Target>&>(target));
+        const index_t total = std::apply([](const auto&... p) { return (index_t{0} + ... + Extent(p)); }, parts_);
+        if constexpr (std::remove_cvref_t<Target>::RowsAtCompileTime < 0) {
+            if (static_cast<index_t>(out.size()) != total) out.resize(total);
+        } else {
+            UNGAR_ASSERT(static_cast<index_t>(out.size()) == total);
+        }
+        index_t at = 0;
+        std::apply([&](const auto&... p) { (Put(out, at, p), ...); }, parts_);
+    }
+    auto ToDynamic() {
+        VectorX<ScalarType> v;
+        In(v);
+        return v;
+    }
+    auto ToFixed()
+        requires kAllFixed
+    {
+        Vector<ScalarType, kSize> v;
+        In(v);
+        return v;
+    }
+
+  private:
+    template <class P>
+    static index_t Extent(const P& p) {
+        if constexpr (kIsVector<P>) return static_cast<index_t>(p.size());
+        else return 1;
+    }
+    template <class Out, class P>
+    static void Put(Out& out, index_t& at, const P& p) {
+        if constexpr (kIsVector<P>) {
+            for (index_t i = 0; i < static_cast<index_t>(p.size()); ++i) out[at + i] = p[i];
+            at += static_cast<index_t>(p.size());
+        } else {
+            out[at++] = p;
+        }
+    }
+    std::tuple<Ts&&...> parts_;
+};
+
+}  // namespace detail
+
+template <int... SIZES, class V>
+inline auto Decompose(V&& vector) {
+    return detail::DecomposeAt<detail::kReadOnly<V>, SIZES...>(vector, std::make_index_sequence<sizeof...(SIZES)>{});
+}
+
+template <class... Ts>
+inline detail::Composition<Ts&&...> Compose(Ts&&... parts) {
+    return detail::Composition<Ts&&...>{std::forward<Ts>(parts)...};
 }
 
 }  // namespace Utils

@@ -21,6 +21,12 @@ class VariableLazyMap {
     using Ptr = std::conditional_t<MUTABLE, Scalar*, const Scalar*>;
     constexpr VariableLazyMap(Ptr data, const Var& var) : _data{data}, _var{var} {
     }
+    /// Over a vector-like buffer (`VariableLazyMap{map.Get(), variables}`, reference variable_lazy_map.hpp:87-100; see the deduction guide below).
+    template <class Underlying>
+        requires requires(Underlying& u) { u.data(); u.size(); }
+    constexpr VariableLazyMap(Underlying& underlying, const Var& var) : _data{underlying.data()}, _var{var} {
+        assert(static_cast<index_t>(underlying.size()) == Var::Size());
+    }
 
     /// View of the sub-variable addressed by `args` (same grammar as Variable::operator()).
     template <class... Args>
@@ -33,6 +39,11 @@ class VariableLazyMap {
     }
     Ptr Data() const {
         return _data;
+    }
+    /// View of an already resolved sub-variable, e.g. `variables(srbd_state, k, i)` (reference variable_lazy_map.hpp:251-275).
+    template <Concepts::Variable V>
+    decltype(auto) Get1(const V& v) const {
+        return View(v);
     }
 
     /// View of an already resolved sub-variable (a result of Variable::operator()).
@@ -54,6 +65,12 @@ class VariableLazyMap {
     Ptr _data;
     Var _var;
 };
+
+/// Writable iff the buffer is not const and does not view const data (a Map<const ...>): decided by what data() returns.
+template <class Underlying, Concepts::Variable Var>
+VariableLazyMap(Underlying&, const Var&)
+    -> VariableLazyMap<std::remove_const_t<typename std::remove_cvref_t<Underlying>::Scalar>, Var,
+                       !std::is_const_v<Underlying> && !std::is_const_v<std::remove_pointer_t<decltype(std::declval<Underlying&>().data())>>>;
 
 /// reference variable_lazy_map.hpp:341-361
 template <class Underlying, Concepts::Variable Var>
@@ -112,6 +129,15 @@ class VariableMap {
     template <class... Vars>
     auto GetTuple(const Vars&... vars) const {
         return std::tuple<decltype(Get(vars))...>{Get(vars)...};
+    }
+    /// View of an already resolved sub-variable (reference variable_map.hpp:166-200).
+    template <Concepts::Variable V>
+    decltype(auto) Get1(const V& v) {
+        return Cached<true>(v);
+    }
+    template <Concepts::Variable V>
+    decltype(auto) Get1(const V& v) const {
+        return Cached<false>(v);
     }
 
   private:
