@@ -5,8 +5,9 @@
 # in this image, so tests/gtest_shim/gtest/gtest.h provides the handful of macros those files use (what is under test is the
 # facade, not the reference).  variable.test builds on both algebras (built-in and the real Eigen 3.4 the reference bundles);
 # function.test and soft_sqp.test use Eigen expression forms the built-in algebra does not have and build on the real Eigen.
-# Not built: test/utils/utils.test.cpp (needs Boost.Hana in user code and the out-of-scope utility set), test/rbd/robot.test.cpp
-# (calls Pinocchio directly).  Outputs: oracle/_ref/ref_<name>_test[_eigen] (git-ignored, travel to the GPU box);
+# test/utils/utils.test.cpp uses Boost.Hana in USER code (`hana::unpack`): it is built against the real Hana 1.84 the reference
+# bundles (external/config/hana/hana-boost-1.84.0.zip, unpacked into a scratch directory outside the repository, like Eigen).
+# Not built: test/rbd/robot.test.cpp (calls Pinocchio directly).  Outputs: oracle/_ref/ref_<name>_test[_eigen] (git-ignored, travel to the GPU box);
 # run by tests/test_reference_tests.py (variable: CPU; function / soft_sqp: -m gpu).
 set -euo pipefail
 here="$(cd "$(dirname "$0")" && pwd)"; root="$(cd "$here/../.." && pwd)"
@@ -28,4 +29,10 @@ if [ -n "$eigen" ]; then
   g++ "${common[@]}" -DUNGAR_AMD_USE_SYSTEM_EIGEN -I "$eigen" -o "$root/oracle/_ref/ref_function_test_eigen" "$ref/test/autodiff/function.test.cpp" "${link[@]}"
   g++ "${common[@]}" -DUNGAR_AMD_USE_SYSTEM_EIGEN -I "$eigen" -o "$root/oracle/_ref/ref_soft_sqp_test_eigen" "$ref/test/optimization/soft_sqp.test.cpp" "${link[@]}"
   echo "built oracle/_ref/ref_{variable,function,soft_sqp}_test_eigen (real Eigen 3.4)"
+  if [ -f "$ref/external/config/hana/hana-boost-1.84.0.zip" ]; then
+    hscratch="${TMPDIR:-/tmp}/ungar_amd_reference_hana"
+    [ -d "$hscratch/hana-boost-1.84.0/include/boost" ] || { mkdir -p "$hscratch" && unzip -q -o "$ref/external/config/hana/hana-boost-1.84.0.zip" -d "$hscratch"; }
+    g++ "${common[@]}" -DUNGAR_AMD_USE_SYSTEM_EIGEN -I "$eigen" -I "$hscratch/hana-boost-1.84.0/include" -o "$root/oracle/_ref/ref_utils_test_eigen" "$ref/test/utils/utils.test.cpp"
+    echo "built oracle/_ref/ref_utils_test_eigen (real Eigen 3.4 + real Boost.Hana 1.84)"
+  fi
 fi

@@ -1,9 +1,12 @@
 """The reference's OWN unit tests -- test/variable.test.cpp, test/autodiff/function.test.cpp, test/optimization/soft_sqp.test.cpp --
-compiled UNCHANGED from where they lie against ungar_amd's facade (oracle/ref_tests/build_ref_tests.sh -> oracle/_ref/ref_*_test*,
+and test/utils/utils.test.cpp, compiled UNCHANGED from where they lie against ungar_amd's facade (oracle/ref_tests/build_ref_tests.sh -> oracle/_ref/ref_*_test*,
 GoogleTest macros from tests/gtest_shim) and run here: every TEST of those files must pass.
 
   * variable.test.cpp  (CPU): VariableMap / VariableLazyMap access and assignment over a 10-knot, 6-body variable hierarchy, 1024 random
     fills -- on the built-in algebra AND on the real Eigen 3.4;
+  * utils.test.cpp     (CPU): Decompose / Compose (view types, constness, quaternion pieces, zero-size pieces), snake case, yaw-pitch-roll <->
+    quaternion <-> rotation matrix round trips and elementary rotations at 1024 random points, 3 x 3 / block 6 x 6 inverses, sparse
+    stacking -- on the real Eigen 3.4 and the real Boost.Hana 1.84 the reference bundles (its user code calls `hana::unpack`);
   * function.test.cpp  (GPU): ApproximateExponentialMap against the exact exponential map at 1025 points, Jacobian and Hessian of
     closed-form functions against their closed forms, and the reference's own finite-difference self-tests
     (Function::TestFunction / TestJacobian / TestHessian) at 1024 random points each -- through MakeFunction -> hipcc -> hipModule;
@@ -36,6 +39,10 @@ def _check(out, expected_tests):
 @pytest.mark.parametrize("variant", ["", "_eigen"])
 def test_reference_variable_test_passes_unchanged(repo_root, tmp_path, variant):
     _check(_run(repo_root, f"ref_variable_test{variant}", tmp_path), 2)
+
+
+def test_reference_utils_test_passes_unchanged(repo_root, tmp_path):
+    _check(_run(repo_root, "ref_utils_test_eigen", tmp_path), 5)
 
 
 @pytest.mark.gpu

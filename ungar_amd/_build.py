@@ -219,6 +219,9 @@ def build_reference_tests():
     exes = [os.path.join(ROOT, "oracle", "_ref", "ref_variable_test")]
     if os.path.exists(os.path.join(ref, "external", "config", "eigen", "eigen-3.4.0.zip")):
         exes += [os.path.join(ROOT, "oracle", "_ref", f"ref_{n}_test_eigen") for n in ("variable", "function", "soft_sqp")]
+        if os.path.exists(os.path.join(ref, "external", "config", "hana", "hana-boost-1.84.0.zip")) and os.path.exists(os.path.join(ref, "test", "utils", "utils.test.cpp")):
+            exes.append(os.path.join(ROOT, "oracle", "_ref", "ref_utils_test_eigen"))
+            srcs.append(os.path.join(ref, "test", "utils", "utils.test.cpp"))
     shim = os.path.join(ROOT, "tests", "gtest_shim", "gtest", "gtest.h")
     if not _newer(exes, srcs + [LIB, script, shim] + _tree(os.path.join(ROOT, "ungar_amd", "include"))):
         _run(["bash", script])

@@ -10,9 +10,24 @@
 #include "linalg.hpp"
 #include "variable.hpp"
 
+// User code written against the reference may use Boost.Hana through the alias the reference exports
+// (`hana::unpack(Utils::Decompose<...>(v), ...)`, utils.test.cpp:118-137).  The facade itself does not need Hana; when the
+// header is on the include path the alias is provided.
+#if defined(__has_include)
+#if __has_include(<boost/hana.hpp>)
+#include <boost/hana.hpp>
+#include <boost/hana/ext/std/array.hpp>
+#include <boost/hana/ext/std/tuple.hpp>
+#define UNGAR_AMD_HAS_HANA 1
+#endif
+#endif
+
 namespace Ungar {
 
 using namespace std::literals;
+#if defined(UNGAR_AMD_HAS_HANA)
+namespace hana = boost::hana;
+#endif
 
 template <class S, index_t N>
 using Vector = Eigen::Vector<S, N>;
@@ -42,8 +57,13 @@ using MapToConstQuaternionr = Eigen::Map<const Quaternionr>;
 template <class S>
 using MatrixX = Linalg::DenseMatrix<S>;
 using MatrixXr = MatrixX<real_t>;
+#if defined(UNGAR_AMD_USE_SYSTEM_EIGEN)
+template <class S>
+using SparseMatrix = Eigen::SparseMatrix<S>;  // the reference's alias (data_types.hpp:316-317); Function returns Autodiff::SparseMatrix views
+#else
 template <class S>
 using SparseMatrix = Linalg::SparseView<S>;  // row-major compressed view (function.hpp:375-383)
+#endif
 
 namespace Linalg {
 /// Row-major dense copy of a compressed row-major sparse matrix (either algebra: the accessors share Eigen's names).

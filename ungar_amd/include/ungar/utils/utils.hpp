@@ -7,7 +7,11 @@
 // exponential map recorded on a tape is always the *approximate*, branch-free one.
 #pragma once
 
+#include <numbers>
+#include <random>
+#include <string>
 #include <tuple>
+#include <vector>
 #include <utility>
 
 #include <cmath>
@@ -187,6 +191,138 @@ inline bool CompareMatrices(const real_t* a, std::string_view nameA, const real_
     }
     return ok;
 }
+
+/// CamelCase -> snake_case; digits kept, any other non-letter becomes '_' (reference utils.hpp:499-522: "CCWord" -> "cc_word").
+inline std::string ToSnakeCase(std::string_view in) {
+    std::string out;
+    const auto lower = [](char c) { return c >= 'a' && c <= 'z'; };
+    const auto upper = [](char c) { return c >= 'A' && c <= 'Z'; };
+    for (std::size_t i = 0; i < in.size(); ++i) {
+        const char c = in[i];
+        if (c >= '0' && c <= '9') {
+            out += c;
+        } else if (lower(c) || upper(c)) {
+            out += static_cast<char>(upper(c) ? c - 'A' + 'a' : c);
+            const bool wordEnds = i + 1 < in.size() && lower(c) && upper(in[i + 1]);                               // "lC" -> "l_c"
+            const bool acronymEnds = i + 2 < in.size() && upper(c) && upper(in[i + 1]) && lower(in[i + 2]);       // "CCW" + "o" -> "cc_w"
+            if (wordEnds || acronymEnds) out += '_';
+        } else {
+            out += '_';
+        }
+    }
+    return out;
+}
+
+#if defined(UNGAR_AMD_USE_SYSTEM_EIGEN)
+// Rotation helpers on matrix types and the small block inverses (reference utils.hpp:765-960); real Eigen only -- the built-in
+// algebra has no fixed-size matrices.
+template <class S>
+inline Matrix3<S> ElementaryXRotationMatrix(const S& angle) {
+    const S c = cos(angle), s = sin(angle);
+    Matrix3<S> R;
+    R << S{1.0}, S{0.0}, S{0.0}, S{0.0}, c, -s, S{0.0}, s, c;
+    return R;
+}
+template <class S>
+inline Matrix3<S> ElementaryYRotationMatrix(const S& angle) {
+    const S c = cos(angle), s = sin(angle);
+    Matrix3<S> R;
+    R << c, S{0.0}, s, S{0.0}, S{1.0}, S{0.0}, -s, S{0.0}, c;
+    return R;
+}
+template <class S>
+inline Matrix3<S> ElementaryZRotationMatrix(const S& angle) {
+    const S c = cos(angle), s = sin(angle);
+    Matrix3<S> R;
+    R << c, -s, S{0.0}, s, c, S{0.0}, S{0.0}, S{0.0}, S{1.0};
+    return R;
+}
+/// ypr = (roll, pitch, yaw): R = Rz(yaw) Ry(pitch) Rx(roll).
+template <class V>
+inline Matrix3<typename V::Scalar> RotationMatrixFromYawPitchRoll(const Eigen::MatrixBase<V>& ypr) {
+    return ElementaryZRotationMatrix(ypr.z()) * ElementaryYRotationMatrix(ypr.y()) * ElementaryXRotationMatrix(ypr.x());
+}
+template <class V>
+inline Quaternion<typename V::Scalar> QuaternionFromYawPitchRoll(const Eigen::MatrixBase<V>& ypr) {
+    return ElementaryZQuaternion(ypr.z()) * ElementaryYQuaternion(ypr.y()) * ElementaryXQuaternion(ypr.x());
+}
+/// Inverse of an invertible 3 x 3 matrix by cofactors.
+template <class M>
+inline Matrix3<typename M::Scalar> Inverse3(const Eigen::MatrixBase<M>& m) {
+    using S = typename M::Scalar;
+    UNGAR_ASSERT(m.rows() == 3 && m.cols() == 3);
+    Matrix3<S> adj;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {  // adj(j, i) = cofactor(i, j), cyclic index form (sign included)
+            const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+            adj(j, i) = m(i1, j1) * m(i2, j2) - m(i1, j2) * m(i2, j1);
+        }
+    const S det = m(0, 0) * adj(0, 0) + m(0, 1) * adj(1, 0) + m(0, 2) * adj(2, 0);
+    return adj / det;
+}
+/// Inverse of a 6 x 6 block upper-triangular matrix [A B; 0 C] with invertible 3 x 3 blocks A, C.
+template <class M>
+inline Eigen::Matrix<typename M::Scalar, 6, 6> Inverse6(const Eigen::MatrixBase<M>& m) {
+    using S = typename M::Scalar;
+    UNGAR_ASSERT(m.rows() == 6 && m.cols() == 6);
+    const Matrix3<S> Ai = Inverse3(m.derived().template topLeftCorner<3, 3>()), Ci = Inverse3(m.derived().template bottomRightCorner<3, 3>());
+    Eigen::Matrix<S, 6, 6> inv;
+    inv.template topLeftCorner<3, 3>() = Ai;
+    inv.template topRightCorner<3, 3>() = -(Ai * m.derived().template topRightCorner<3, 3>() * Ci);
+    inv.template bottomLeftCorner<3, 3>().setZero();
+    inv.template bottomRightCorner<3, 3>() = Ci;
+    return inv;
+}
+
+namespace detail {
+/// Sparse matrices (any storage order / expression) stacked on top of each other (reference utils.hpp:140-230).
+template <class... Ms>
+class SparseStack {
+  public:
+    using ScalarType = std::common_type_t<typename std::remove_cvref_t<Ms>::Scalar...>;
+    explicit SparseStack(Ms&&... ms) : parts_{std::forward<Ms>(ms)...} {}
+    template <class Target>
+    void In(const Eigen::SparseMatrixBase<Target>& target) {
+        Fill(const_cast<Target&>(target.derived()));
+    }
+    SparseMatrix<ScalarType> ToSparse() {
+        SparseMatrix<ScalarType> out;
+        Fill(out);
+        return out;
+    }
+
+  private:
+    template <class Target>
+    void Fill(Target& out) {
+        std::vector<Eigen::Triplet<ScalarType>> entries;
+        index_t rows = 0, cols = -1;
+        std::apply(
+            [&](const auto&... m) {
+                (Append(m, entries, rows, cols), ...);
+            },
+            parts_);
+        out.resize(rows, cols < 0 ? 0 : cols);
+        out.setFromTriplets(entries.begin(), entries.end());
+    }
+    template <class Mat>
+    static void Append(const Mat& expr, std::vector<Eigen::Triplet<ScalarType>>& entries, index_t& rows, index_t& cols) {
+        const Eigen::SparseMatrix<ScalarType> m = expr;  // evaluates sparse views / products
+        UNGAR_ASSERT(cols < 0 || cols == m.cols());
+        cols = m.cols();
+        for (int k = 0; k < m.outerSize(); ++k)
+            for (typename Eigen::SparseMatrix<ScalarType>::InnerIterator it(m, k); it; ++it) entries.emplace_back(rows + it.row(), it.col(), it.value());
+        rows += m.rows();
+    }
+    std::tuple<Ms&&...> parts_;
+};
+}  // namespace detail
+
+template <class... Ms>
+    requires(sizeof...(Ms) > 0)
+inline auto VerticallyStackSparseMatrices(Ms&&... ms) {
+    return detail::SparseStack<Ms&&...>{std::forward<Ms>(ms)...};
+}
+#endif  // UNGAR_AMD_USE_SYSTEM_EIGEN
 
 inline constexpr std::string_view DASH_LINE_SEPARATOR = "----------------------------------------------------------------";
 inline constexpr std::string_view STAR_LINE_SEPARATOR = "****************************************************************";
