@@ -19,15 +19,24 @@ if [ -f "$ref/external/config/eigen/eigen-3.4.0.zip" ]; then
   [ -d "$scratch/eigen-3.4.0/Eigen" ] || { mkdir -p "$scratch" && unzip -q -o "$ref/external/config/eigen/eigen-3.4.0.zip" -d "$scratch"; }
   eigen="$scratch/eigen-3.4.0"
 fi
+# Boost.Hana: only user code needs it (variable.example.cpp defines a BOOST_HANA_DEFINE_STRUCT and logs it); the real Hana 1.84 the
+# reference bundles is unpacked next to Eigen and put on the include path of every example (the facade picks it up through
+# __has_include and exports the `hana` alias the reference exports).
+hana=()
+if [ -f "$ref/external/config/hana/hana-boost-1.84.0.zip" ]; then
+  hscratch="${TMPDIR:-/tmp}/ungar_amd_reference_hana"
+  [ -d "$hscratch/hana-boost-1.84.0/include/boost" ] || { mkdir -p "$hscratch" && unzip -q -o "$ref/external/config/hana/hana-boost-1.84.0.zip" -d "$hscratch"; }
+  hana=(-I "$hscratch/hana-boost-1.84.0/include")
+fi
 for name in "$@"; do
   src="$ref/example/mpc/${name}.example.cpp"
   [ -f "$src" ] || src="$ref/example/autodiff/${name}.example.cpp"
   [ -f "$src" ] || src="$ref/example/${name}.example.cpp"
-  g++ -std=c++20 -O2 -I "$root/ungar_amd/include" -o "$root/oracle/_ref/${name}_example" "$src" \
+  g++ -std=c++20 -O2 "${hana[@]}" -I "$root/ungar_amd/include" -o "$root/oracle/_ref/${name}_example" "$src" \
       -L "$root/ungar_amd/lib" -lungar_amd -Wl,-rpath,'$ORIGIN/../../ungar_amd/lib' -Wl,-rpath,/opt/rocm/lib
   echo "built oracle/_ref/${name}_example"
   if [ -n "$eigen" ]; then
-    g++ -std=c++20 -O2 -DUNGAR_AMD_USE_SYSTEM_EIGEN -I "$eigen" -I "$root/ungar_amd/include" -o "$root/oracle/_ref/${name}_example_eigen" "$src" \
+    g++ -std=c++20 -O2 -DUNGAR_AMD_USE_SYSTEM_EIGEN -I "$eigen" "${hana[@]}" -I "$root/ungar_amd/include" -o "$root/oracle/_ref/${name}_example_eigen" "$src" \
         -L "$root/ungar_amd/lib" -lungar_amd -Wl,-rpath,'$ORIGIN/../../ungar_amd/lib' -Wl,-rpath,/opt/rocm/lib
     echo "built oracle/_ref/${name}_example_eigen (real Eigen 3.4)"
   fi

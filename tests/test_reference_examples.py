@@ -64,6 +64,17 @@ def test_variable_map_example_runs_on_the_host(repo_root, tmp_path, variant):
     assert "u0 = 0 0 0 0" in out and "u1 = 1 1 1 1" in out and "uN-1 = 2 4 6 8" in out
 
 
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_variable_example_runs_on_the_host(repo_root, tmp_path, variant):
+    """example/variable.example.cpp: the variable hierarchy of the single-rigid-body model, ~40 compile-time static_asserts on sizes /
+    indices / `At<"name">` lookups, then `ForEach` over the sub-variables of `x`, each logged as a Boost.Hana struct with the reference's
+    compact presentation `{:c}` (built against the real Hana the reference bundles)."""
+    out = _run(repo_root, "variable", tmp_path, 60, variant)
+    for line in ("{ x, 0, 13, 'vector' }", "{ position, 0, 3, 'vector' }", "{ orientation, 3, 4, 'quaternion' }", "{ linear_velocity, 7, 3, 'vector' }",
+                 "{ angular_velocity, 10, 3, 'vector' }"):
+        assert line in out, out[-1500:]
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("variant", VARIANTS)
 def test_function_example_self_checks(repo_root, tmp_path, variant):

@@ -190,7 +190,7 @@ def build_cpp_tests():
     build_reference_tests()
 
 
-def build_reference_examples(names=("quadrotor", "rc_car", "quadruped", "function", "variable_map")):
+def build_reference_examples(names=("quadrotor", "rc_car", "quadruped", "function", "variable_map", "variable")):
     """The reference's own example/mpc programs against ungar_amd's headers (oracle/ref_examples):
     only where the reference is present; the binaries land in oracle/_ref and travel to the GPU box."""
     script = os.path.join(ROOT, "oracle", "ref_examples", "build_examples.sh")

@@ -5,29 +5,15 @@
 #include <vector>
 #include <string_view>
 
+#include "hana_support.hpp"
 #include "assert.hpp"
 #include "io/logging.hpp"
 #include "linalg.hpp"
 #include "variable.hpp"
 
-// User code written against the reference may use Boost.Hana through the alias the reference exports
-// (`hana::unpack(Utils::Decompose<...>(v), ...)`, utils.test.cpp:118-137).  The facade itself does not need Hana; when the
-// header is on the include path the alias is provided.
-#if defined(__has_include)
-#if __has_include(<boost/hana.hpp>)
-#include <boost/hana.hpp>
-#include <boost/hana/ext/std/array.hpp>
-#include <boost/hana/ext/std/tuple.hpp>
-#define UNGAR_AMD_HAS_HANA 1
-#endif
-#endif
-
 namespace Ungar {
 
 using namespace std::literals;
-#if defined(UNGAR_AMD_HAS_HANA)
-namespace hana = boost::hana;
-#endif
 
 template <class S, index_t N>
 using Vector = Eigen::Vector<S, N>;

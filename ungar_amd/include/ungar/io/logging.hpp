@@ -9,6 +9,8 @@
 #include <string_view>
 #include <type_traits>
 
+#include "../hana_support.hpp"
+
 namespace Ungar {
 namespace Log {
 
@@ -66,6 +68,20 @@ std::string ToText(const T& v, const Spec& sp) {
         return out;
     } else if constexpr (requires { v.IsLiteral(); }) {
         return ToText(Value(v), sp);
+#if defined(UNGAR_AMD_HAS_HANA)
+    } else if constexpr (boost::hana::Struct<T>::value) {
+        // the reference's formatter for Boost.Hana structs (io/logging.hpp:93-145): 'c' = "{ m0, m1 }", default 'v' = one "key = value" per line
+        const bool compact = sp.type == 'c';
+        std::string body;
+        bool first = true;
+        boost::hana::for_each(boost::hana::accessors<T>(), [&](auto accessor) {
+            body += first ? (compact ? "" : "\t") : (compact ? ", " : ",\n\t");
+            first = false;
+            if (!compact) body += std::string(boost::hana::to<const char*>(boost::hana::first(accessor))) + " = ";
+            body += ToText(boost::hana::second(accessor)(v), Spec{});
+        });
+        return compact ? "{ " + body + " }" : "\n{\n" + body + "\n}";
+#endif
     } else {
         std::ostringstream os;
         os << v;

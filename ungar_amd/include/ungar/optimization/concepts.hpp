@@ -16,9 +16,11 @@ namespace Ungar {
 /// Stand-in for an absent objective term / constraint set (the reference uses boost::hana::nothing).
 struct nothing_t {};
 inline constexpr nothing_t nothing{};
+#if !defined(UNGAR_AMD_HAS_HANA)
 namespace hana {
 using ::Ungar::nothing;
 }
+#endif
 
 namespace Concepts {
 
@@ -110,6 +112,12 @@ auto OrIdle(F&& f, index_t, index_t) {
 inline IdleTwiceDifferentiableFunction OrIdle(nothing_t, index_t n, index_t p) {
     return IdleTwiceDifferentiableFunction{n, p};
 }
+#if defined(UNGAR_AMD_HAS_HANA)
+/// With the real Boost.Hana on the include path `hana::nothing` is Hana's own empty optional.
+inline IdleTwiceDifferentiableFunction OrIdle(std::remove_cvref_t<decltype(boost::hana::nothing)>, index_t n, index_t p) {
+    return IdleTwiceDifferentiableFunction{n, p};
+}
+#endif
 }  // namespace Internal
 
 /// Any of the two constraint sets may be `hana::nothing`.

@@ -18,14 +18,19 @@
 #include <array>
 #include <cstddef>
 #include <ranges>
+#include <string>
 #include <string_view>
 #include <tuple>
 #include <type_traits>
 #include <utility>
 
+#include "hana_support.hpp"
+#include "io/logging.hpp"
 #include "linalg.hpp"
 
 namespace Ungar {
+
+using namespace std::literals;  // the reference exports the std literal operators to `using namespace Ungar` code
 
 using real_t = double;
 using index_t = Eigen::Index;
