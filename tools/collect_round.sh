@@ -32,3 +32,5 @@ cp_if gpurun_out/gn_tiles_ablation.log        profiles/${tag}_gn_tiles_ablation.
 cp_if gpurun_out/fp64_peaks.log               profiles/${tag}_fp64_peaks.log
 cp_if gpurun_out/prewarm.log                  profiles/${tag}_prewarm.log
 cp_if gpurun_out/gn_shapes.json                profiles/${tag}_gn_shapes.json
+cp_if gpurun_out/rbd_nodes.json                profiles/${tag}_rbd_nodes.json
+cp_if gpurun_out/layouts_all.log              profiles/${tag}_layouts_all.log

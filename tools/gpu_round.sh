@@ -34,6 +34,8 @@ echo "== config-4 chain: node Jacobians -> Gauss-Newton term (lane-per-(node, bl
 bash tools/gpu_gn_tiles_profile.sh 2>&1 | tail -24
 tools/_bin/gn_tiles_bench 2>&1 | tail -4 | tee gpurun_out/gn_tiles_ablation.log
 timeout 300 python tools/bench_gn_shapes.py 2>/dev/null | tail -1 > gpurun_out/gn_shapes.json
+timeout 300 python tools/bench_rbd_nodes.py 2>/dev/null | tail -1 > gpurun_out/rbd_nodes.json
+for m in anymal quadrotor rc_car; do timeout 300 python tools/bench_layouts.py $m $([ $m = anymal ] && echo 81920 || ([ $m = quadrotor ] && echo 524288 || echo 3276800)) 2>/dev/null | tail -1; done > gpurun_out/layouts_all.log
 tools/_bin/valu_f64_peak 2>&1 | tail -5 | tee gpurun_out/fp64_peaks.log; tools/_bin/mfma_f64_peak 2>&1 | tail -1 | tee -a gpurun_out/fp64_peaks.log
 timeout 300 python tools/bench_layouts.py 2>&1 | tail -3 > gpurun_out/layouts.log
 timeout 300 python tools/bench_ocp_step.py 2>&1 | tail -1 > gpurun_out/ocp_step_srbd.json
