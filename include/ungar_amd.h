@@ -283,6 +283,23 @@ int ungar_ocp_line_search_accept(int64_t nx, int64_t nu, int64_t horizon, int64_
                                  const double* theta0, const double* phi0, const double* slope, const double* theta_trial, const double* phi_trial,
                                  double* accepted, const ungar_operand* X, const ungar_operand* U, const ungar_operand* Xt, const ungar_operand* Ut, void* stream);
 
+/* The whole backtracking search in THREE launches instead of three per candidate (the GPU-native form of
+ * backtracking_line_search.hpp:116-151: with thousands of instances somebody always needs a short step, so all candidates get
+ * evaluated anyway -- as 14 x 6 small launches one after the other, or as a few large ones):
+ *   ungar_ocp_trial_points       Xt(c * batch + i) = X(i) + alphas[c] dX(i), likewise Ut: `candidates * batch` STACKED trial points
+ *                                (candidate c of instance i is stacked instance c * batch + i; alphas: host array, at most 16);
+ *   node values / ungar_ocp_merit_stacked over the candidates * batch stacked instances (args->batch = candidates * batch; operands
+ *                                X, f, cost, h, theta, phi indexed by the stacked instance, xm by instance % period, period = batch);
+ *   ungar_ocp_line_search_select per instance, the FIRST candidate (largest step) that passes the test is copied into (X, U) and its
+ *                                step size recorded in accepted[instance] (0 = none acceptable: instance left unchanged).
+ * Same result as the candidate-by-candidate loop over ungar_ocp_trial_point / ungar_ocp_line_search_accept. */
+int ungar_ocp_trial_points(int64_t nx, int64_t nu, int64_t horizon, int64_t batch, const ungar_operand* X, const ungar_operand* U, const ungar_operand* dX,
+                           const ungar_operand* dU, const double* alphas, int64_t candidates, const ungar_operand* Xt, const ungar_operand* Ut, void* stream);
+int ungar_ocp_merit_stacked(const ungar_ocp_merit_args* args, int64_t period, void* stream);
+int ungar_ocp_line_search_select(int64_t nx, int64_t nu, int64_t horizon, int64_t batch, const ungar_line_search_parameters* parameters, const double* alphas,
+                                 int64_t candidates, const double* theta0, const double* phi0, const double* slope, const double* theta_trial, const double* phi_trial,
+                                 double* accepted, const ungar_operand* X, const ungar_operand* U, const ungar_operand* Xt, const ungar_operand* Ut, void* stream);
+
 /* ---- run-time function factory (any recorded function, not only the built-in node models) ----- */
 
 /* One node of a recorded expression tape, in topological order (operands refer to EARLIER nodes).

@@ -252,6 +252,13 @@ def test_one_sqp_iteration_quadrotor_4096_instances(repo_root):
         assert abs(th0[i] - theta) <= 1e-10 * max(1.0, theta) and abs(ph0[i] - phi) <= 1e-10 * max(1.0, abs(phi)) and abs(sl[i] - slope) <= 1e-9 * max(1.0, abs(slope))
         assert acc[i] == alpha
         assert np.abs(Xn[i] - Xr).max() <= 1e-9 * max(1.0, np.abs(Xr).max()) and np.abs(Un[i] - Ur).max() <= 1e-9 * max(1.0, np.abs(Ur).max())
+    # the stacked line search (all candidates in one batch: the default) and the candidate-by-candidate loop give the same bits
+    solver2 = sqp.BatchedSoftSqp("quadrotor", "quadrotor_cost", N, batch, inequality="quadrotor_ineq")
+    X2, U2 = dev(X), dev(U)
+    accepted2 = solver2.iterate(X2, U2, xmd, pd, pc, pi, stacked=False)
+    torch.cuda.synchronize()
+    assert torch.equal(accepted2, accepted) and torch.equal(X2, Xd) and torch.equal(U2, Ud)
+    assert len(solver.candidate_steps()) == 14 and solver.candidate_steps()[-1] >= 1e-4
     # further iterations: the dynamics defect of every instance goes down by orders of magnitude
     theta_first = th0.copy()
     t0 = time.perf_counter()

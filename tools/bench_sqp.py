@@ -40,6 +40,10 @@ def timeit(fn, reps):
 
 
 qp_ms = timeit(lambda: solver.qp_step(Xd, Ud, xmd, pd, pc, pi), 20)
-it_ms = timeit(lambda: solver.iterate(Xd, Ud, xmd, pd, pc, pi), 10)
-print(json.dumps({"workload": f"quadrotor OCP N={N}, {batch} instances, rotor bounds behind the POLY barrier", "ms_per_qp_step": qp_ms, "ms_per_sqp_iteration": it_ms,
+X0, U0 = Xd.clone(), Ud.clone()
+it_seq_ms = timeit(lambda: solver.iterate(Xd, Ud, xmd, pd, pc, pi, stacked=False), 10)  # six small launches per candidate
+Xd.copy_(X0)
+Ud.copy_(U0)
+it_ms = timeit(lambda: solver.iterate(Xd, Ud, xmd, pd, pc, pi), 10)  # stacked line search (default)
+print(json.dumps({"workload": f"quadrotor OCP N={N}, {batch} instances, rotor bounds behind the POLY barrier", "ms_per_qp_step": qp_ms, "ms_per_sqp_iteration": it_ms, "ms_per_sqp_iteration_candidate_by_candidate": it_seq_ms, "line_search_candidates": len(solver.candidate_steps()),
                   "instances_per_s": batch / it_ms * 1e3, "knots_per_s": batch * N / it_ms * 1e3, "riccati_status_nonzero": int((solver.status != 0).sum())}))

@@ -164,8 +164,9 @@ __global__ __launch_bounds__(kBlock) void MeritKernel(const MeritArgs a) {
     if (b >= a.batch) return;
     const int lane = static_cast<int>(threadIdx.x);
     double g2 = 0.0, phi = 0.0, slope = 0.0;
+    const long long bm = a.xmPeriod > 0 ? b % a.xmPeriod : b;  // stacked trial points share the measured state of their instance
     for (int i = lane; i < a.nx; i += kBlock) {
-        const double r = a.X.at(b, 0, i) - a.xm.at(b, 0, i);
+        const double r = a.X.at(b, 0, i) - a.xm.at(bm, 0, i);
         g2 += r * r;
     }
     for (int idx = lane; idx < a.N * a.nx; idx += kBlock) {
@@ -199,16 +200,43 @@ __global__ __launch_bounds__(kBlock) void MeritKernel(const MeritArgs a) {
 }
 
 __global__ __launch_bounds__(kBlock) void TrialKernel(const TrialArgs a) {
-    const long long b = blockIdx.x;
-    if (b >= a.batch) return;
+    const long long out = blockIdx.x;  // stacked: candidate out / batch of instance out % batch
+    const long long b = a.candidates > 0 ? out % a.batch : out;
+    if (out >= (a.candidates > 0 ? a.candidates * a.batch : a.batch)) return;
+    const double alpha = a.candidates > 0 ? a.alphas[out / a.batch] : a.alpha;
     for (int idx = static_cast<int>(threadIdx.x); idx < (a.N + 1) * a.nx; idx += kBlock) {
         const int k = idx / a.nx, i = idx % a.nx;
-        a.Xt.at(b, k, i) = a.X.at(b, k, i) + a.alpha * a.dX.at(b, k, i);
+        a.Xt.at(out, k, i) = a.X.at(b, k, i) + alpha * a.dX.at(b, k, i);
     }
     for (int idx = static_cast<int>(threadIdx.x); idx < a.N * a.nu; idx += kBlock) {
         const int k = idx / a.nu, i = idx % a.nu;
-        a.Ut.at(b, k, i) = a.U.at(b, k, i) + a.alpha * a.dU.at(b, k, i);
+        a.Ut.at(out, k, i) = a.U.at(b, k, i) + alpha * a.dU.at(b, k, i);
     }
+}
+
+/// Acceptance test of backtracking_line_search.hpp:116-151 for one candidate.
+__device__ inline bool StepAcceptable(double theta, double phi, double slope, double thetaNext, double phiNext, double alpha, double thetaMin, double thetaMax, double eta,
+                                      double gammaPhi, double gammaTheta) {
+    if (thetaNext > thetaMax) return thetaNext < (1.0 - gammaTheta) * theta;
+    if (fmax(theta, thetaNext) < thetaMin && slope < 0.0) return phiNext < phi + eta * alpha * slope;
+    return phiNext < (1.0 - gammaPhi) * phi || thetaNext < (1.0 - gammaTheta) * theta;
+}
+
+__global__ __launch_bounds__(kBlock) void SelectKernel(const SelectArgs a) {
+    const long long b = blockIdx.x;
+    if (b >= a.batch) return;
+    const double theta = a.theta0[b], phi = a.phi0[b], slope = a.slope[b];
+    int chosen = -1;  // uniform over the workgroup: every lane runs the same scalar search
+    for (int c = 0; c < a.candidates && chosen < 0; ++c)
+        if (StepAcceptable(theta, phi, slope, a.thetaT[c * a.batch + b], a.phiT[c * a.batch + b], a.alphas[c], a.thetaMin, a.thetaMax, a.eta, a.gammaPhi, a.gammaTheta)) chosen = c;
+    if (chosen < 0) {
+        if (threadIdx.x == 0) a.accepted[b] = 0.0;
+        return;
+    }
+    const long long from = chosen * a.batch + b;
+    for (int idx = static_cast<int>(threadIdx.x); idx < (a.N + 1) * a.nx; idx += kBlock) a.X.at(b, idx / a.nx, idx % a.nx) = a.Xt.at(from, idx / a.nx, idx % a.nx);
+    for (int idx = static_cast<int>(threadIdx.x); idx < a.N * a.nu; idx += kBlock) a.U.at(b, idx / a.nu, idx % a.nu) = a.Ut.at(from, idx / a.nu, idx % a.nu);
+    if (threadIdx.x == 0) a.accepted[b] = a.alphas[chosen];
 }
 
 __global__ __launch_bounds__(kBlock) void AcceptKernel(const AcceptArgs a) {
@@ -216,11 +244,7 @@ __global__ __launch_bounds__(kBlock) void AcceptKernel(const AcceptArgs a) {
     if (b >= a.batch) return;
     if (a.accepted[b] != 0.0) return;  // uniform over the workgroup
     const double theta = a.theta0[b], phi = a.phi0[b], thetaNext = a.thetaT[b], phiNext = a.phiT[b], slope = a.slope[b];
-    bool ok;
-    if (thetaNext > a.thetaMax) ok = thetaNext < (1.0 - a.gammaTheta) * theta;
-    else if (fmax(theta, thetaNext) < a.thetaMin && slope < 0.0) ok = phiNext < phi + a.eta * a.alpha * slope;
-    else ok = phiNext < (1.0 - a.gammaPhi) * phi || thetaNext < (1.0 - a.gammaTheta) * theta;
-    if (!ok) return;
+    if (!StepAcceptable(theta, phi, slope, thetaNext, phiNext, a.alpha, a.thetaMin, a.thetaMax, a.eta, a.gammaPhi, a.gammaTheta)) return;
     for (int idx = static_cast<int>(threadIdx.x); idx < (a.N + 1) * a.nx; idx += kBlock) a.X.at(b, idx / a.nx, idx % a.nx) = a.Xt.at(b, idx / a.nx, idx % a.nx);
     for (int idx = static_cast<int>(threadIdx.x); idx < a.N * a.nu; idx += kBlock) a.U.at(b, idx / a.nu, idx % a.nu) = a.Ut.at(b, idx / a.nu, idx % a.nu);
     __syncthreads();
@@ -296,7 +320,14 @@ extern "C" int ungar_amd_launch_ocp_merit(const MeritArgs* a, void* stream) {
 
 extern "C" int ungar_amd_launch_ocp_trial(const TrialArgs* a, void* stream) {
     if (a->batch <= 0) return 0;
-    hipLaunchKernelGGL(TrialKernel, dim3(static_cast<unsigned>(a->batch)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), *a);
+    const long long groups = a->candidates > 0 ? a->candidates * a->batch : a->batch;
+    hipLaunchKernelGGL(TrialKernel, dim3(static_cast<unsigned>(groups)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), *a);
+    return static_cast<int>(hipGetLastError());
+}
+
+extern "C" int ungar_amd_launch_ocp_select(const SelectArgs* a, void* stream) {
+    if (a->batch <= 0) return 0;
+    hipLaunchKernelGGL(SelectKernel, dim3(static_cast<unsigned>(a->batch)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), *a);
     return static_cast<int>(hipGetLastError());
 }
 

@@ -27,13 +27,32 @@ struct MeritArgs {
     double* theta;  // out, per instance
     double* phi;    // out, per instance: objective + barrier
     double* slope;  // out, per instance (written only when grad.base and dX.base are given)
+    long long xmPeriod = 0;  // > 0: `batch` counts STACKED trial points (candidate c of instance i at c * xmPeriod + i) and xm is read at instance % xmPeriod
 };
+
+constexpr int kMaxLineSearchCandidates = 16;
 
 struct TrialArgs {
     int nx, nu, N;
     long long batch;
     RiccatiView X, U, dX, dU, Xt, Ut;
     double alpha;
+    // candidates > 0: ALL trial points of the backtracking search at once -- workgroup c * batch + i writes
+    // Xt(c * batch + i) = X(i) + alphas[c] dX(i) (Xt / Ut hold candidates * batch stacked instances)
+    int candidates = 0;
+    double alphas[kMaxLineSearchCandidates] = {};
+};
+
+/// The whole backtracking search of one instance from the merit terms of ALL its candidates (stacked: candidate c of
+/// instance i at c * batch + i): the first candidate -- largest step -- that passes the acceptance test is copied into (X, U).
+struct SelectArgs {
+    int nx, nu, N, candidates;
+    long long batch;
+    double thetaMin, thetaMax, eta, gammaPhi, gammaTheta;
+    double alphas[kMaxLineSearchCandidates];
+    const double *theta0, *phi0, *slope, *thetaT, *phiT;
+    double* accepted;  // per instance: the accepted step size, 0 = none of the candidates is acceptable
+    RiccatiView X, U, Xt, Ut;
 };
 
 /// Acceptance test of the reference's backtracking line search (backtracking_line_search.hpp:116-151) for one candidate
@@ -70,3 +89,4 @@ extern "C" int ungar_amd_launch_riccati(const ungar_amd::kernels::RiccatiArgs* a
 extern "C" int ungar_amd_launch_ocp_merit(const ungar_amd::kernels::MeritArgs* a, void* stream);
 extern "C" int ungar_amd_launch_ocp_trial(const ungar_amd::kernels::TrialArgs* a, void* stream);
 extern "C" int ungar_amd_launch_ocp_accept(const ungar_amd::kernels::AcceptArgs* a, void* stream);
+extern "C" int ungar_amd_launch_ocp_select(const ungar_amd::kernels::SelectArgs* a, void* stream);

@@ -91,14 +91,44 @@ int ungar_ocp_riccati_solve(const ungar_ocp_qp* q, void* stream) {
     return Launched(ungar_amd_launch_riccati(&k, stream), "ungar_ocp_riccati_solve");
 }
 
-int ungar_ocp_merit(const ungar_ocp_merit_args* a, void* stream) {
-    if (!a || BadDims(a->nx, a->nu, a->horizon, a->batch) || a->nh < 0) return Fail(UNGAR_E_INVALID, "ungar_ocp_merit: bad dimensions");
+int ungar_ocp_merit(const ungar_ocp_merit_args* a, void* stream) { return ungar_ocp_merit_stacked(a, 0, stream); }
+
+int ungar_ocp_merit_stacked(const ungar_ocp_merit_args* a, int64_t period, void* stream) {
+    if (!a || BadDims(a->nx, a->nu, a->horizon, a->batch) || a->nh < 0 || period < 0 || (period > 0 && a->batch % period != 0))
+        return Fail(UNGAR_E_INVALID, "ungar_ocp_merit: bad dimensions");
     if (a->batch == 0) return UNGAR_OK;
     if (!a->X.base || !a->xm.base || !a->f.base || !a->theta || !a->phi) return Fail(UNGAR_E_INVALID, "ungar_ocp_merit: null operand base");
-    const MeritArgs k{static_cast<int>(a->nx), static_cast<int>(a->nu), static_cast<int>(a->horizon), static_cast<int>(a->nh), a->batch, View(a->X), View(a->xm), View(a->f),
+    MeritArgs k{static_cast<int>(a->nx), static_cast<int>(a->nu), static_cast<int>(a->horizon), static_cast<int>(a->nh), a->batch, View(a->X), View(a->xm), View(a->f),
                       View(a->cost), View(a->cost_terminal), a->nh > 0 ? View(a->h) : RiccatiView{nullptr, 0, 0, 0}, Barrier(a->barrier), a->violation_multiplier,
                       View(a->cost_grad), View(a->cost_grad_terminal), View(a->dX), View(a->dU), a->theta, a->phi, a->slope};
+    k.xmPeriod = period;
     return Launched(ungar_amd_launch_ocp_merit(&k, stream), "ungar_ocp_merit");
+}
+
+int ungar_ocp_trial_points(int64_t nx, int64_t nu, int64_t horizon, int64_t batch, const ungar_operand* X, const ungar_operand* U, const ungar_operand* dX,
+                           const ungar_operand* dU, const double* alphas, int64_t candidates, const ungar_operand* Xt, const ungar_operand* Ut, void* stream) {
+    if (BadDims(nx, nu, horizon, batch) || !X || !U || !dX || !dU || !Xt || !Ut || !alphas || candidates < 1 || candidates > kMaxLineSearchCandidates)
+        return Fail(UNGAR_E_INVALID, "ungar_ocp_trial_points: bad argument (1 <= candidates <= 16)");
+    if (batch == 0) return UNGAR_OK;
+    if (!X->base || !U->base || !dX->base || !dU->base || !Xt->base || !Ut->base) return Fail(UNGAR_E_INVALID, "ungar_ocp_trial_points: null operand base");
+    TrialArgs k{static_cast<int>(nx), static_cast<int>(nu), static_cast<int>(horizon), batch, View(*X), View(*U), View(*dX), View(*dU), View(*Xt), View(*Ut), 0.0};
+    k.candidates = static_cast<int>(candidates);
+    for (int64_t c = 0; c < candidates; ++c) k.alphas[c] = alphas[c];
+    return Launched(ungar_amd_launch_ocp_trial(&k, stream), "ungar_ocp_trial_points");
+}
+
+int ungar_ocp_line_search_select(int64_t nx, int64_t nu, int64_t horizon, int64_t batch, const ungar_line_search_parameters* p, const double* alphas, int64_t candidates,
+                                 const double* theta0, const double* phi0, const double* slope, const double* theta_trial, const double* phi_trial, double* accepted,
+                                 const ungar_operand* X, const ungar_operand* U, const ungar_operand* Xt, const ungar_operand* Ut, void* stream) {
+    if (BadDims(nx, nu, horizon, batch) || !p || !alphas || candidates < 1 || candidates > kMaxLineSearchCandidates || !theta0 || !phi0 || !slope || !theta_trial || !phi_trial ||
+        !accepted || !X || !U || !Xt || !Ut)
+        return Fail(UNGAR_E_INVALID, "ungar_ocp_line_search_select: bad argument (1 <= candidates <= 16)");
+    if (batch == 0) return UNGAR_OK;
+    if (!X->base || !U->base || !Xt->base || !Ut->base) return Fail(UNGAR_E_INVALID, "ungar_ocp_line_search_select: null operand base");
+    SelectArgs k{static_cast<int>(nx), static_cast<int>(nu), static_cast<int>(horizon), static_cast<int>(candidates), batch, p->theta_min, p->theta_max, p->eta, p->gamma_phi,
+                 p->gamma_theta, {}, theta0, phi0, slope, theta_trial, phi_trial, accepted, View(*X), View(*U), View(*Xt), View(*Ut)};
+    for (int64_t c = 0; c < candidates; ++c) k.alphas[c] = alphas[c];
+    return Launched(ungar_amd_launch_ocp_select(&k, stream), "ungar_ocp_line_search_select");
 }
 
 int ungar_ocp_trial_point(int64_t nx, int64_t nu, int64_t horizon, int64_t batch, const ungar_operand* X, const ungar_operand* U, const ungar_operand* dX,

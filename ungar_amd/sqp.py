@@ -66,6 +66,10 @@ def _declare(lib):
     lib.ungar_ocp_riccati_solve.argtypes = [ctypes.POINTER(_Qp), vp]
     lib.ungar_ocp_merit.argtypes = [ctypes.POINTER(_MeritArgs), vp]
     lib.ungar_ocp_trial_point.argtypes = [ctypes.c_int64] * 4 + [op] * 4 + [ctypes.c_double] + [op] * 2 + [vp]
+    lib.ungar_ocp_merit_stacked.argtypes = [ctypes.POINTER(_MeritArgs), ctypes.c_int64, vp]
+    lib.ungar_ocp_trial_points.argtypes = [ctypes.c_int64] * 4 + [op] * 4 + [ctypes.POINTER(ctypes.c_double), ctypes.c_int64] + [op] * 2 + [vp]
+    lib.ungar_ocp_line_search_select.argtypes = ([ctypes.c_int64] * 4 + [ctypes.POINTER(_LineSearchParameters), ctypes.POINTER(ctypes.c_double), ctypes.c_int64] + [vp] * 6 +
+                                                 [op] * 4 + [vp])
     lib.ungar_ocp_line_search_accept.argtypes = [ctypes.c_int64] * 4 + [ctypes.POINTER(_LineSearchParameters), ctypes.c_double] + [vp] * 6 + [op] * 4 + [vp]
     lib._ungar_sqp_declared = True
     return lib
@@ -147,6 +151,7 @@ class BatchedSoftSqp:
         self.theta0, self.phi0, self.slope, self.thetaT, self.phiT, self.accepted = (z(B) for _ in range(6))
         self.status = torch.zeros((B,), dtype=torch.int32, device="cuda")
         self.workspace = z(max(1, self.lib.ungar_ocp_riccati_workspace(nx, nu, N, B)))
+        self._stack = None  # buffers of the stacked line search, allocated on first use
 
     # -- operands -----------------------------------------------------------------------------------------------------
     def _states(self, X):  # knots 0..N-1 of the (batch, N+1, nx) buffer as the x operand of the node models
@@ -196,14 +201,68 @@ class BatchedSoftSqp:
                 self.regularization, self.status.data_ptr())
         _check(self.lib.ungar_ocp_riccati_solve(ctypes.byref(q), stream))
 
-    def iterate(self, X, U, xm, p_dyn=None, p_cost=None, p_ineq=None, w=None, stream=None):
+    def candidate_steps(self):
+        """Step sizes the backtracking search tries, largest first: 1, gamma, gamma^2, ... >= alpha_min (backtracking_line_search.hpp:116-151)."""
+        steps, alpha = [], 1.0
+        while alpha >= self.ls.alpha_min:
+            steps.append(alpha)
+            alpha *= self.ls.gamma_alpha
+        return steps
+
+    def _stacked_search(self, X, U, xm, p_dyn, p_cost, p_ineq, w, s):
+        """All candidates at once: stacked trial points -> one launch per node model -> one merit launch -> one selection launch."""
+        torch, nx, nu, N, B, n = self.torch, self.nx, self.nu, self.N, self.batch, self.nx + self.nu
+        steps = self.candidate_steps()
+        K = len(steps)
+        if K > 16:
+            raise ValueError("the stacked line search handles at most 16 candidate steps")
+        if self._stack is None or self._stack["K"] != K:
+            z = lambda *shape: torch.empty(shape, dtype=torch.float64, device="cuda")  # noqa: E731
+            self._stack = {"K": K, "Xt": z(K * B, N + 1, nx), "Ut": z(K * B, N, nu), "f": z(K * B, N, nx), "c": z(K * B, N, 1),
+                           "h": z(K * B, N, self.nh) if self.nh else None, "theta": z(K * B), "phi": z(K * B)}
+        st = self._stack
+        alphas = (ctypes.c_double * K)(*steps)
+        Xo, Uo, dXo, dUo = _node(X, nx, N + 1)._c(), _node(U, nu, N)._c(), _node(self.dX, nx, N + 1)._c(), _node(self.dU, nu, N)._c()
+        Xt, Ut = _node(st["Xt"], nx, N + 1)._c(), _node(st["Ut"], nu, N)._c()
+        _check(self.lib.ungar_ocp_trial_points(nx, nu, N, B, ctypes.byref(Xo), ctypes.byref(Uo), ctypes.byref(dXo), ctypes.byref(dUo), alphas, K, ctypes.byref(Xt),
+                                               ctypes.byref(Ut), s))
+        # node values of the K * B stacked instances: per-instance parameters / node parameters are repeated per candidate
+        rep = lambda t: None if t is None else (t if t.dim() == 1 else t.repeat(K, *([1] * (t.dim() - 1))))  # noqa: E731
+        count = K * B * N
+        xo = Operand(st["Xt"], instance_stride=(N + 1) * nx, knot_stride=nx, element_stride=1)
+        uo = _node(st["Ut"], nu, N)
+        ws = rep(w)
+        wo = None if ws is None else _node(ws, ws.shape[-1], N)
+        par = lambda t, m: None if m.np == 0 else Operand.per_instance(rep(t), m.np, shared=t.dim() == 1)  # noqa: E731
+        self.dyn.forward_zero(count, xo, uo, wo if self.dyn.nw else None, par(p_dyn, self.dyn), _node(st["f"], nx, N), knots=N, stream=s)
+        self.cost.forward_zero(count, xo, uo, wo if self.cost.nw else None, par(p_cost, self.cost), _node(st["c"], 1, N), knots=N, stream=s)
+        if self.ineq is not None:
+            self.ineq.forward_zero(count, xo, uo, wo if self.ineq.nw else None, par(p_ineq, self.ineq), _node(st["h"], self.nh, N), knots=N, stream=s)
+        a = _MeritArgs(nx, nu, N, K * B, self.nh, Xt, _inst(xm, nx)._c(), _node(st["f"], nx, N)._c(), _node(st["c"], 1, N)._c(), _NULL,
+                       _node(st["h"], self.nh, N)._c() if self.nh else _NULL, self.barrier, self.multiplier, _NULL, _NULL, _NULL, _NULL, st["theta"].data_ptr(),
+                       st["phi"].data_ptr(), None)
+        _check(self.lib.ungar_ocp_merit_stacked(ctypes.byref(a), B, s))
+        params = _LineSearchParameters(self.ls.alpha_min, self.ls.theta_min, self.ls.theta_max, self.ls.eta, self.ls.gamma_phi, self.ls.gamma_theta, self.ls.gamma_alpha)
+        _check(self.lib.ungar_ocp_line_search_select(nx, nu, N, B, ctypes.byref(params), alphas, K, self.theta0.data_ptr(), self.phi0.data_ptr(), self.slope.data_ptr(),
+                                                     st["theta"].data_ptr(), st["phi"].data_ptr(), self.accepted.data_ptr(), ctypes.byref(Xo), ctypes.byref(Uo),
+                                                     ctypes.byref(Xt), ctypes.byref(Ut), s))
+        return self.accepted
+
+    def iterate(self, X, U, xm, p_dyn=None, p_cost=None, p_ineq=None, w=None, stream=None, stacked: bool = True):
         """One SQP iteration in place on (X, U): QP step, then the backtracking line search of the reference on
         phi = cost + barrier, theta = c |g| (soft_sqp.hpp:68-87).  Returns the per-instance accepted step sizes (device tensor,
-        0 = no acceptable step: that instance was left unchanged, the reference's `break`)."""
+        0 = no acceptable step: that instance was left unchanged, the reference's `break`).
+
+        stacked (default): all candidate steps are evaluated as ONE stacked batch of candidates x batch trial points -- one launch per
+        node model, one merit launch, one selection launch instead of six small launches per candidate; with thousands of instances
+        every candidate is needed by somebody, so no work is added, only launches removed.  stacked=False walks the candidates one
+        after the other (same result; candidates x less memory)."""
         s = NodeModel._stream(stream)
         nx, nu, N, B = self.nx, self.nu, self.N, self.batch
         self.qp_step(X, U, xm, p_dyn, p_cost, p_ineq, w, stream)
         self._merit(X, xm, self.theta0, self.phi0, True, s)  # node values at (X, U) are still in f / c / h
+        if stacked:
+            return self._stacked_search(X, U, xm, p_dyn, p_cost, p_ineq, w, s)
         self.accepted.zero_()
         params = _LineSearchParameters(self.ls.alpha_min, self.ls.theta_min, self.ls.theta_max, self.ls.eta, self.ls.gamma_phi, self.ls.gamma_theta, self.ls.gamma_alpha)
         Xo, Uo, Xt, Ut = (_node(X, nx, N + 1)._c(), _node(U, nu, N)._c(), _node(self.Xt, nx, N + 1)._c(), _node(self.Ut, nu, N)._c())
