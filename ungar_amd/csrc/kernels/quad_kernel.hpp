@@ -182,7 +182,12 @@ struct QuadIO {
 
 /// GEN is the generated namespace (ValueJacobianQuad, kLegConstantsDev).  BLOCK lanes = BLOCK/4 nodes.
 template <int BLOCK, int LDS_SLOTS, int LDS_USLOTS, bool SPARSE, bool STREAM, class Body, class PLAN = NoSparsePlan, class OFF = unsigned, bool BUF = false>
-__global__ __launch_bounds__(BLOCK) void QuadNodeKernel(const NodeLaunch a, const double (*ctab)[4], Body body) {
+#if defined(UNGAR_QUAD_WAVES_PER_EU)  // experiment knob of tools/quad_bench.hip: ask for N resident wavefronts per SIMD (register budget 512 / N)
+#define UNGAR_QUAD_OCCUPANCY __attribute__((amdgpu_waves_per_eu(UNGAR_QUAD_WAVES_PER_EU, UNGAR_QUAD_WAVES_PER_EU)))
+#else
+#define UNGAR_QUAD_OCCUPANCY
+#endif
+__global__ __launch_bounds__(BLOCK) UNGAR_QUAD_OCCUPANCY void QuadNodeKernel(const NodeLaunch a, const double (*ctab)[4], Body body) {
     static_assert(BLOCK == 64, "the LDS home is laid out for one wavefront per workgroup");
     __shared__ double lds[(LDS_SLOTS > 0 ? LDS_SLOTS : 1) * BLOCK + LDS_USLOTS * (BLOCK / 4)];
     const int L = (threadIdx.x >> 2) & 3;
