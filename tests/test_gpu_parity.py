@@ -290,7 +290,8 @@ def test_gn_hessian_lane_per_node(ua, kernel):
     gen = torch.Generator(device="cuda")
     gen.manual_seed(5)
     for rows, cols, count, weighted in ((37, 49, 1000, True), (12, 37, 130, True), (13, 17, 257, False), (6, 8, 5, True), (8, 17, 64, True), (1, 49, 17, False),
-                                        (5, 49, 31, True), (9, 23, 40, True), (37, 49, 1002, False), (8, 49, 48, True), (17, 49, 4098, True)):
+                                        (5, 49, 31, True), (9, 23, 40, True), (37, 49, 1002, False), (8, 49, 48, True), (17, 49, 4098, True), (100, 49, 18, True),
+                                        (37, 49, 2, True), (3, 37, 34, False), (29, 17, 1026, True)):
         J = torch.rand((rows * cols, count), generator=gen, device="cuda", dtype=torch.float64) * 2 - 1
         d = torch.rand((rows, count), generator=gen, device="cuda", dtype=torch.float64) if weighted else None
         Jv = J.view(rows, cols, count)
