@@ -1,0 +1,35 @@
+"""bench.py's output contract (the driver parses this line): one JSON object on the last stdout line with the metric of BASELINE.json,
+whole-job value, exact step / warm-up echo, `roofline` (HBM bound, achieved = algorithmic bytes / measured launch time, frac = achieved / peak)
+and, on one GPU, `cpu_baseline`.  Run with the driver's own arguments (`--gpus 1 --steps 20 --warmup 5`)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_bench_line_has_the_contract_fields(repo_root):
+    out = subprocess.run([sys.executable, os.path.join(repo_root, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--cpu-seconds", "2"], cwd=repo_root,
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["metric"].startswith("shooting-node Jacobian evals/sec") and d["unit"] == "evals/s" and d["higher_is_better"] is True
+    assert (d["n_gpus"], d["steps"], d["warmup"]) == (1, 20, 5) and d["dtype"] == "f64" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert d["scaling"] in ("strong", "weak") and "workload" in d["config"] and "model" not in d["config"]
+    assert d["config"]["total_batch"] == 4096 and d["config"]["nodes_per_step"] == 4096 * 20
+    # value is the whole-job rate over the timed region; ms_per_step is that region / steps
+    assert abs(d["value"] - d["config"]["nodes_per_step"] / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["algorithmic_bytes_per_eval"] == 15192
+    assert abs(r["achieved"] - r["nodes_per_launch"] * 15192 / (r["kernel_ms"] * 1e-3) / 1e9) <= 1e-6 * r["achieved"]
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.3 < r["frac"] < 1.0
+    assert r["kernel_ms"] <= d["ms_per_step"] * 1.001, "the kernel cannot take longer than the step that contains it"
+    assert r["traffic"] is None or (0.9 < r["traffic"] / (r["nodes_per_launch"] * 15192) < 1.2 and "profiles/" in r["traffic_source"])
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] == 1 and c["value"] > 1e4 and "sample" in c
+    assert d["value"] / c["value"] > 100, "one GPU against one CPU core"
+    assert abs(d["checksum"] - 5033491.53798481) < 1e-3, "synthetic inputs and results are deterministic"
+    assert len(d["sub_results"]) == 2 and all(0.3 < s["roofline_frac"] < 1.0 for s in d["sub_results"])
