@@ -8,5 +8,35 @@ int main(void) {
     ungar_model_info info;
     if (rc == UNGAR_OK && ungar_model_get_info(m, &info) == UNGAR_OK) printf("%s nx=%lld ny=%lld hes_nnz=%lld version=%s\n", ungar_model_name(m), (long long)info.nx, (long long)info.ny, (long long)info.hes_nnz, ungar_version());
     ungar_model_close(m);
+    if (rc != UNGAR_OK) return rc;
+    /* Error behaviour of the batched entry points: arguments are validated before anything touches a device, so a bad call returns
+     * UNGAR_E_INVALID (never crashes, never launches) and leaves a message for ungar_last_error() -- also on a machine without a GPU. */
+    {
+        double dummy[4] = {0, 0, 0, 0};
+        double alphas[17] = {1, .5, .25, .125, .0625, .03125, .015625, .0078125, .00390625, .001953125, .0009765625, .00048828125, .000244140625, .0001220703125, 6e-5, 3e-5, 1e-5};
+        ungar_operand op = {0, 0, 0, 0};
+        ungar_line_search_parameters ls = {1e-4, 1e-6, 1e-2, 1e-4, 1e-6, 1e-6, 0.5};
+        ungar_ocp_merit_args merit;
+        int bad = 0;
+        op.base = dummy;
+        bad += ungar_transpose_nodes(0, 1, 1, dummy, 1, 1, 4, 1, 0) != UNGAR_E_INVALID;
+        bad += ungar_transpose_nodes(dummy, 1, 1, dummy, 1, 1, -1, 1, 0) != UNGAR_E_INVALID;
+        bad += ungar_transpose_nodes(dummy, 1, 1, dummy, 1, 1, 0, 1, 0) != UNGAR_OK; /* empty batch: nothing to do */
+        bad += ungar_gn_hessian_upper_tiles(0, 4, 0, 0, dummy, 4, 1, 2, 1, 2, 4, 0) != UNGAR_E_INVALID;
+        bad += ungar_gn_hessian_upper_tiles(dummy, 2, 0, 0, dummy, 4, 1, 2, 1, 2, 4, 0) != UNGAR_E_INVALID; /* element stride < count */
+        bad += ungar_gn_hessian_upper_lanes(dummy, 4, 0, 0, dummy, 4, 1, 1, 1, 2, 4, 0) != UNGAR_E_INVALID;  /* ld_g < cols */
+        bad += ungar_ocp_trial_points(13, 4, 30, 8, &op, &op, &op, &op, alphas, 17, &op, &op, 0) != UNGAR_E_INVALID; /* > 16 candidates */
+        bad += ungar_ocp_trial_points(13, 4, 30, 8, &op, &op, &op, &op, 0, 14, &op, &op, 0) != UNGAR_E_INVALID;
+        bad += ungar_ocp_line_search_select(13, 4, 30, 8, &ls, alphas, 14, 0, dummy, dummy, dummy, dummy, dummy, &op, &op, &op, &op, 0) != UNGAR_E_INVALID;
+        merit.nx = 13; merit.nu = 4; merit.horizon = 30; merit.batch = 10; merit.nh = 0;
+        merit.X = op; merit.xm = op; merit.f = op; merit.cost = op; merit.cost_terminal = op; merit.h = op;
+        merit.barrier.type = 0; merit.barrier.reserved = 0; merit.barrier.stiffness = 1; merit.barrier.epsilon = 1;
+        merit.violation_multiplier = 1; merit.cost_grad = op; merit.cost_grad_terminal = op; merit.dX = op; merit.dU = op;
+        merit.theta = dummy; merit.phi = dummy; merit.slope = 0;
+        bad += ungar_ocp_merit_stacked(&merit, 4, 0) != UNGAR_E_INVALID; /* the stacked batch is not a multiple of the period */
+        bad += ungar_last_error()[0] == 0;
+        printf("argument checks: %d unexpected\n", bad);
+        if (bad) return 100 + bad;
+    }
     return rc;
 }

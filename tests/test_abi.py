@@ -109,7 +109,7 @@ def test_header_is_plain_c(repo_root, tmp_path):
                     os.path.join(repo_root, "tests", "c", "abi_smoke.c"), "-o", exe, "-L", lib, "-lungar_amd", f"-Wl,-rpath,{lib}", "-Wl,-rpath,/opt/rocm/lib"],
                    check=True)
     out = subprocess.run([exe], capture_output=True, text=True, check=True).stdout
-    assert "quadrotor_cost nx=13 ny=1 hes_nnz=17" in out
+    assert "quadrotor_cost nx=13 ny=1 hes_nnz=17" in out and "argument checks: 0 unexpected" in out
 
 
 def _amd_model_test(repo_root, mode, tmp_path, env=None):
