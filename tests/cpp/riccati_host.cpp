@@ -56,7 +56,14 @@ extern "C" int riccati_host_solve_variant(int prefetch, int nx, int nu, int N, l
                   {dU, static_cast<long long>(N) * nu, nu, 1},
                   gains.data(), regularization, status};
     std::vector<double> scratch(static_cast<std::size_t>(RiccatiScratchDoubles(nx, nu)));
-    if (prefetch) {
+    if (prefetch == 2) {  // the instantiations with sizes fixed at compile time (what the device launches for the reference's OCPs): in-register Cholesky for nu <= 8
+        HostExec<false> ex;
+        for (long long i = 0; i < batch; ++i) {
+            if (nx == 13 && nu == 4) RiccatiInstance<HostExec<false>, 13, 4>(a, i, scratch.data(), ex);
+            else if (nx == 6 && nu == 2) RiccatiInstance<HostExec<false>, 6, 2>(a, i, scratch.data(), ex);
+            else return 1;
+        }
+    } else if (prefetch) {
         HostExec<true> ex;
         for (long long i = 0; i < batch; ++i) RiccatiInstance(a, i, scratch.data(), ex);
     } else {

@@ -131,6 +131,32 @@ def test_prefetching_variant_is_bitwise_the_same_recursion(host):
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
 
 
+@pytest.mark.parametrize("nx,nu", [(13, 4), (6, 2)])
+def test_fixed_size_instantiation_matches_the_generic_recursion(host, nx, nu):
+    """For the reference's OCP sizes the device launches an instantiation with (nx, nu) fixed at compile time, whose Cholesky of the
+    nu x nu block runs in registers inside the solve phase (one phase instead of nu + 1): same recursion, same solution up to the
+    rounding of the differently associated sums, and the indefinite-block report still works."""
+    rng = np.random.default_rng(21)
+    N = 9
+    q = random_qp(rng, nx, nu, N, 3)
+    dp = ctypes.POINTER(ctypes.c_double)
+    p = lambda a: a.ctypes.data_as(dp)  # noqa: E731
+    out = []
+    for variant in (0, 2):
+        dX, dU, st = np.zeros((3, N + 1, nx)), np.zeros((3, N, nu)), np.zeros(3, dtype=np.int32)
+        rc = host.riccati_host_solve_variant(variant, nx, nu, N, ctypes.c_longlong(3), p(q["AB"]), p(q["b"]), p(q["W"]), p(q["w"]), p(q["WN"]), p(q["wN"]), p(q["dx0"]),
+                                             ctypes.c_double(1e-6), p(dX), p(dU), st.ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
+        assert rc == 0 and (st == 0).all()
+        out.append((dX, dU))
+    scale = max(1.0, np.abs(out[0][0]).max(), np.abs(out[0][1]).max())
+    assert np.abs(out[0][0] - out[1][0]).max() <= 1e-11 * scale and np.abs(out[0][1] - out[1][1]).max() <= 1e-11 * scale
+    q["W"][2, 5] = -np.eye(nx + nu) * 50.0  # knot 5 of instance 2: concave in the inputs
+    dX, dU, st = np.zeros((3, N + 1, nx)), np.zeros((3, N, nu)), np.zeros(3, dtype=np.int32)
+    host.riccati_host_solve_variant(2, nx, nu, N, ctypes.c_longlong(3), p(q["AB"]), p(q["b"]), p(q["W"]), p(q["w"]), p(q["WN"]), p(q["wN"]), p(q["dx0"]), ctypes.c_double(1e-6),
+                                    p(dX), p(dU), st.ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
+    assert st[0] == 0 and st[1] == 0 and st[2] == 6
+
+
 def test_riccati_reports_an_indefinite_reduced_hessian(host):
     rng = np.random.default_rng(1)
     q = random_qp(rng, 4, 2, 6, 2)

@@ -168,41 +168,86 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
                 h[c] = acc;
             }
         });
-        // Cholesky of R = H_uu (strict lower triangle in place, pivots in K's spare column... kept in `dx`-sized scratch `piv`):
-        // one phase per column -- every lane recomputes the pivot from values that are final, lane 0 records it
-        for (int j = 0; j < nu; ++j) {
-            ex.ForEach(nu - j, [&](int q) {
-                double d = H[(nx + j) * n + nx + j];
-                for (int m = 0; m < j; ++m) d -= H[(nx + j) * n + nx + m] * H[(nx + j) * n + nx + m];
-                const bool bad = !(d > 0.0);
-                const double root = sqrt(bad ? 1.0 : d);
-                if (q == 0) {
-                    if (bad) failed = failed ? failed : k + 1;
-                    piv[j] = root;
-                    return;
+        if constexpr (NU > 0 && NU <= 8) {
+            // Small input dimension fixed at compile time: every lane factorises R = H_uu = L L^T itself, in registers (NU^3 / 6
+            // multiply-adds from NU (NU + 1) / 2 LDS reads), and goes straight on to its right-hand side of
+            // [K | kff] = -R^-1 [H_ux | h_u] -- one phase instead of NU + 1 (a barrier and an LDS round trip per Cholesky column).
+            ex.ForEach(nk, [&](int c) {
+                double L[NU][NU];
+                bool bad = false;
+#pragma unroll
+                for (int j = 0; j < NU; ++j) {
+                    double d = H[(nx + j) * n + nx + j];
+#pragma unroll
+                    for (int m = 0; m < j; ++m) d -= L[j][m] * L[j][m];
+                    const bool neg = !(d > 0.0);
+                    bad = bad || neg;
+                    L[j][j] = sqrt(neg ? 1.0 : d);
+#pragma unroll
+                    for (int i = j + 1; i < NU; ++i) {
+                        double sv = H[(nx + i) * n + nx + j];
+#pragma unroll
+                        for (int m = 0; m < j; ++m) sv -= L[i][m] * L[j][m];
+                        L[i][j] = sv / L[j][j];
+                    }
                 }
-                const int i = j + q;
-                double sv = H[(nx + i) * n + nx + j];
-                for (int m = 0; m < j; ++m) sv -= H[(nx + i) * n + nx + m] * H[(nx + j) * n + nx + m];
-                H[(nx + i) * n + nx + j] = sv / root;
+                if (c == 0 && bad) failed = failed ? failed : k + 1;
+                double y[NU];
+#pragma unroll
+                for (int i = 0; i < NU; ++i) {  // L y = rhs
+                    double sv = c < nx ? -H[(nx + i) * n + c] : -h[nx + i];
+#pragma unroll
+                    for (int m = 0; m < i; ++m) sv -= L[i][m] * y[m];
+                    y[i] = sv / L[i][i];
+                }
+#pragma unroll
+                for (int i = NU - 1; i >= 0; --i) {  // L^T x = y
+                    double sv = y[i];
+#pragma unroll
+                    for (int m = i + 1; m < NU; ++m) sv -= L[m][i] * y[m];
+                    sv /= L[i][i];
+                    y[i] = sv;
+                    K[i * nk + c] = sv;
+                    gains[static_cast<long long>(k) * nu * nk + i * nk + c] = sv;
+                }
+            });
+        } else {
+            // Cholesky of R = H_uu (strict lower triangle in place, pivots in K's spare column... kept in `dx`-sized scratch `piv`):
+            // one phase per column -- every lane recomputes the pivot from values that are final, lane 0 records it
+            for (int j = 0; j < nu; ++j) {
+                ex.ForEach(nu - j, [&](int q) {
+                    double d = H[(nx + j) * n + nx + j];
+                    for (int m = 0; m < j; ++m) d -= H[(nx + j) * n + nx + m] * H[(nx + j) * n + nx + m];
+                    const bool bad = !(d > 0.0);
+                    const double root = sqrt(bad ? 1.0 : d);
+                    if (q == 0) {
+                        if (bad) failed = failed ? failed : k + 1;
+                        piv[j] = root;
+                        return;
+                    }
+                    const int i = j + q;
+                    double sv = H[(nx + i) * n + nx + j];
+                    for (int m = 0; m < j; ++m) sv -= H[(nx + i) * n + nx + m] * H[(nx + j) * n + nx + m];
+                    H[(nx + i) * n + nx + j] = sv / root;
+                });
+            }
+            // [K | kff] = -R^-1 [H_ux | h_u]: one right-hand side per lane (forward then backward substitution); the lane also
+            // files its column of the gains
+            ex.ForEach(nk, [&](int c) {
+                for (int i = 0; i < nu; ++i) {  // L y = rhs
+                    double sv = c < nx ? -H[(nx + i) * n + c] : -h[nx + i];
+                    for (int m = 0; m < i; ++m) sv -= H[(nx + i) * n + nx + m] * K[m * nk + c];
+                    K[i * nk + c] = sv / piv[i];
+                }
+                for (int i = nu - 1; i >= 0; --i) {  // L^T x = y
+                    double sv = K[i * nk + c];
+                    for (int m = i + 1; m < nu; ++m) sv -= H[(nx + m) * n + nx + i] * K[m * nk + c];
+                    sv /= piv[i];
+                    K[i * nk + c] = sv;
+                    gains[static_cast<long long>(k) * nu * nk + i * nk + c] = sv;
+                }
             });
         }
-        // [K | kff] = -R^-1 [H_ux | h_u]: one right-hand side per lane (forward then backward substitution); the lane also
-        // files its column of the gains
-        ex.ForEach(nk, [&](int c) {
-            for (int i = 0; i < nu; ++i) {  // L y = rhs
-                double sv = c < nx ? -H[(nx + i) * n + c] : -h[nx + i];
-                for (int m = 0; m < i; ++m) sv -= H[(nx + i) * n + nx + m] * K[m * nk + c];
-                K[i * nk + c] = sv / piv[i];
-            }
-            for (int i = nu - 1; i >= 0; --i) {  // L^T x = y
-                double sv = K[i * nk + c];
-                for (int m = i + 1; m < nu; ++m) sv -= H[(nx + m) * n + nx + i] * K[m * nk + c];
-                sv /= piv[i];
-                K[i * nk + c] = sv;
-                gains[static_cast<long long>(k) * nu * nk + i * nk + c] = sv;
-            }
-        });
         // P <- H_xx + H_ux^T K (symmetrised),  p <- h_x + H_ux^T kff   (into the other buffer, then the buffers swap roles)
         ex.ForEach(nx * nx + nx, [&](int idx) {
             if (idx < nx * nx) {
