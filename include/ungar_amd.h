@@ -73,7 +73,8 @@ typedef struct ungar_node_batch {
 /* ---- model lifetime ------------------------------------------------------------------------ */
 
 /* Opens one of the built-in node models: "quadrotor_cost" / "srbd_cost" / "rc_car_cost" (scalar stage costs of the quadrotor,
- * quadruped and RC-car OCPs: value, gradient, upper Hessian), "rc_car_ineq" (3 inequality rows per knot of the RC-car OCP),
+ * quadruped and RC-car OCPs: value, gradient, upper Hessian), "anymal_cost" (tracking cost of the full-body quadruped, x = [q(19); v(18)],
+ * u = 12 torques, p = [x_ref(37), 5 weights]: the engine's own -- the reference has no full-body OCP), "rc_car_ineq" (3 inequality rows per knot of the RC-car OCP),
  * "srbd_feet" (world foot positions of the quadruped: the node-local part of its foot-contact equality rows), "srbd_ineq" (12 inequality rows per knot of the quadruped OCP and their Jacobian),
  * "quadrotor_ineq" (8 rotor-speed bound rows per knot of the quadrotor OCP),
  * "quadrotor", "rc_car", "srbd", "anymal" (structured

@@ -588,7 +588,18 @@ def rc_car_cost(x, u, p):
     return ((x[0:2] - p[0:2]) ** 2).sum() + 1e-6 * (u ** 2).sum()
 
 
-COSTS = {"quadrotor_cost": (quadrotor_cost, 13, 4, 13), "srbd_cost": (srbd_cost, 13, 24, 25), "rc_car_cost": (rc_car_cost, 6, 2, 2)}  # fn, nx, nu, np
+def anymal_cost(x, u, p):
+    """Stage cost of the full-body quadruped (ungar_amd's own: the reference has no full-body OCP; restated here from its definition in
+    DESIGN.md section 4.9, not from the product's source): p = [x_ref(37), w_position, w_orientation, w_joints, w_velocity, w_torque],
+    orientation through the sign-invariant min(|q - q_ref|^2, |q + q_ref|^2) of quadrotor.example.cpp:206-212."""
+    ref, (wp, wq, wj, wv, wt) = p[:37], p[37:42]
+    quat = torch.minimum(((x[3:7] - ref[3:7]) ** 2).sum(), ((x[3:7] + ref[3:7]) ** 2).sum())
+    return (wp * ((x[0:3] - ref[0:3]) ** 2).sum() + wq * quat + wj * ((x[7:19] - ref[7:19]) ** 2).sum() + wv * ((x[19:37] - ref[19:37]) ** 2).sum() +
+            wt * (u ** 2).sum())
+
+
+COSTS = {"quadrotor_cost": (quadrotor_cost, 13, 4, 13), "srbd_cost": (srbd_cost, 13, 24, 25), "rc_car_cost": (rc_car_cost, 6, 2, 2),
+         "anymal_cost": (anymal_cost, 37, 12, 42)}  # fn, nx, nu, np
 
 
 def cost_value_gradient_hessian(x, u, p, name="quadrotor_cost"):
@@ -610,11 +621,16 @@ def cost_value_gradient_hessian(x, u, p, name="quadrotor_cost"):
 def synthetic_cost_inputs(count: int, seed: int = 0, name: str = "quadrotor_cost"):
     """States/inputs as for the dynamics node, references = perturbed states (some with flipped quaternion
     sign, so that both branches of the min are exercised); srbd_cost: plus perturbed footholds."""
-    x, u, _, _ = synthetic_inputs({"quadrotor_cost": "quadrotor", "srbd_cost": "srbd", "rc_car_cost": "rc_car"}[name], count, seed)
+    x, u, _, _ = synthetic_inputs({"quadrotor_cost": "quadrotor", "srbd_cost": "srbd", "rc_car_cost": "rc_car", "anymal_cost": "anymal"}[name], count, seed)
     rng = np.random.default_rng(0xC057 + seed)
     ref = x + rng.normal(scale=0.3, size=x.shape)
     if name == "rc_car_cost":
         return x, u, ref[:, :2].copy()
+    if name == "anymal_cost":
+        ref[:, 3:7] /= np.linalg.norm(ref[:, 3:7], axis=1, keepdims=True)
+        ref[::2, 3:7] *= -1.0
+        weights = rng.uniform(0.1, 10.0, size=(count, 5)) * np.array([1.0, 1.0, 1.0, 0.1, 1e-3])
+        return x, u, np.concatenate((ref, weights), axis=1)
     ref[:, 3:7] /= np.linalg.norm(ref[:, 3:7], axis=1, keepdims=True)
     ref[::2, 3:7] *= -1.0
     if name == "srbd_cost":

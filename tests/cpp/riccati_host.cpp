@@ -61,6 +61,8 @@ extern "C" int riccati_host_solve_variant(int prefetch, int nx, int nu, int N, l
         for (long long i = 0; i < batch; ++i) {
             if (nx == 13 && nu == 4) RiccatiInstance<HostExec<false>, 13, 4>(a, i, scratch.data(), ex);
             else if (nx == 6 && nu == 2) RiccatiInstance<HostExec<false>, 6, 2>(a, i, scratch.data(), ex);
+            else if (nx == 37 && nu == 12) RiccatiInstance<HostExec<false>, 37, 12>(a, i, scratch.data(), ex);  // 2 x 4 register tiles
+            else if (nx == 13 && nu == 24) RiccatiInstance<HostExec<false>, 13, 24>(a, i, scratch.data(), ex);
             else return 1;
         }
     } else if (prefetch) {

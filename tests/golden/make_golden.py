@@ -24,7 +24,7 @@ for name, count in COUNTS.items():
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", f"node_{name}.npz"), x=x, u=u, w=w, p=p, f=f, J=J)
     print(name, count, "max|J|", np.abs(J).max())
 
-for cost, fname in (("quadrotor_cost", "cost_quadrotor.npz"), ("srbd_cost", "cost_srbd.npz"), ("rc_car_cost", "cost_rc_car.npz")):
+for cost, fname in (("quadrotor_cost", "cost_quadrotor.npz"), ("srbd_cost", "cost_srbd.npz"), ("rc_car_cost", "cost_rc_car.npz"), ("anymal_cost", "cost_anymal.npz")):
     if ONLY and cost not in ONLY:
         continue
     x, u, ref = O.synthetic_cost_inputs(32, seed=7, name=cost)

@@ -346,7 +346,7 @@ def test_full_size_chain_node_jacobians_to_gauss_newton_term(ua):
     assert (torch.diagonal(got, dim1=1, dim2=2) >= 0).all()
 
 
-@pytest.mark.parametrize("name,fixture,nu,npar", [("quadrotor_cost", "cost_quadrotor.npz", 4, 13), ("srbd_cost", "cost_srbd.npz", 24, 25), ("rc_car_cost", "cost_rc_car.npz", 2, 2)])
+@pytest.mark.parametrize("name,fixture,nu,npar", [("quadrotor_cost", "cost_quadrotor.npz", 4, 13), ("srbd_cost", "cost_srbd.npz", 24, 25), ("rc_car_cost", "cost_rc_car.npz", 2, 2), ("anymal_cost", "cost_anymal.npz", 12, 42)])
 def test_stage_cost_value_gradient_hessian(ua, repo_root, name, fixture, nu, npar):
     """Scalar node models 'quadrotor_cost' / 'srbd_cost' (SURVEY.md section 8(f) N2): value, gradient and
     upper-triangular Hessian w.r.t. (x, u) against torch.autograd on the oracle's restatement of the

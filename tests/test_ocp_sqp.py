@@ -131,10 +131,11 @@ def test_prefetching_variant_is_bitwise_the_same_recursion(host):
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
 
 
-@pytest.mark.parametrize("nx,nu", [(13, 4), (6, 2)])
+@pytest.mark.parametrize("nx,nu", [(13, 4), (6, 2), (37, 12), (13, 24)])
 def test_fixed_size_instantiation_matches_the_generic_recursion(host, nx, nu):
     """For the reference's OCP sizes the device launches an instantiation with (nx, nu) fixed at compile time, whose Cholesky of the
-    nu x nu block runs in registers inside the solve phase (one phase instead of nu + 1): same recursion, same solution up to the
+    nu x nu block runs in registers inside the solve phase (one phase instead of nu + 1; nu <= 8) and whose two large products use 2 x 4
+    register tiles (nx >= 24): same recursion, same solution up to the
     rounding of the differently associated sums, and the indefinite-block report still works."""
     rng = np.random.default_rng(21)
     N = 9
@@ -220,7 +221,10 @@ def _reference_iteration(X, U, xm, p_dyn, p_cost, p_ineq, dyn, cost, N, k_barrie
         else:
             f, J = O.node_value(dyn, Xc[:N], Uc, w0, pd), None
             c, g, H = O.cost_value_gradient_hessian(Xc[:N], Uc, pc, name=cost)[0], None, None
-        h = np.stack((Uc - p_ineq[0], -Uc), axis=2).reshape(N, 2 * nu)  # [r - r_max, -r] per rotor
+        if p_ineq is None:
+            h = np.zeros((N, 0))  # no inequality rows (the full-body quadruped problem below)
+        else:
+            h = np.stack((Uc - p_ineq[0], -Uc), axis=2).reshape(N, 2 * nu)  # [r - r_max, -r] per rotor
         return f, J, c, g, H, h
 
     def merit(Xc, f, c, h):
@@ -228,8 +232,8 @@ def _reference_iteration(X, U, xm, p_dyn, p_cost, p_ineq, dyn, cost, N, k_barrie
         return mult * np.sqrt((gres ** 2).sum()), c.sum() + poly_barrier(-h, k_barrier, eps).sum()
 
     f, J, c, g, H, h = evaluate(X, U, True)
-    Jh = np.zeros((N, 2 * nu, n))
-    for i in range(nu):
+    Jh = np.zeros((N, 2 * nu if p_ineq is not None else 0, n))
+    for i in range(nu if p_ineq is not None else 0):
         Jh[:, 2 * i, nx + i] = 1.0
         Jh[:, 2 * i + 1, nx + i] = -1.0
     d1, d2 = poly_barrier(-h, k_barrier, eps, 1), poly_barrier(-h, k_barrier, eps, 2)
@@ -356,3 +360,55 @@ def test_sqp_iterations_quadruped_srbd_with_friction_cones():
     torch.cuda.synchronize()
     assert torch.isfinite(Xd).all() and torch.isfinite(Ud).all()
     assert (solver.theta0 < first).float().mean().item() > 0.9 and solver.theta0.median().item() < 0.8 * first.median().item()
+
+
+def _anymal_problem(batch, N, seed):
+    """Full-body quadruped OCP instances (BASELINE config 4's model: nx = 37, nu = 12, N = 20): trajectories around random postures,
+    tracking cost towards the first state of each instance (`anymal_cost`), no inequality rows."""
+    rng = np.random.default_rng(seed)
+    x, u, _, p = O.synthetic_inputs("anymal", batch * (N + 1), seed=seed)
+    X = x.reshape(batch, N + 1, 37).copy()
+    X[:, 1:] = X[:, :1] + 0.05 * (X[:, 1:] - X[:, :1])  # a trajectory is a small perturbation of its first state
+    X[:, :, 3:7] /= np.linalg.norm(X[:, :, 3:7], axis=2, keepdims=True)
+    U = u.reshape(batch, N + 1, 12)[:, :N].copy()
+    xm = X[:, 0] + rng.normal(size=(batch, 37)) * 0.01
+    ref = X[:, 0].copy()
+    ref[:, 19:] = 0.0  # come to rest at the initial posture
+    p_cost = np.concatenate((ref, np.tile([10.0, 10.0, 1.0, 0.1, 1e-3], (batch, 1))), axis=1)
+    p_dyn = np.tile(p[0], (batch, 1))
+    return X, U, xm, p_dyn, p_cost
+
+
+@gpu
+def test_one_sqp_iteration_full_body_quadruped():
+    """BASELINE config 4's model end to end: ANYmal node Jacobians (lane-per-leg kernel, node-major operands), `anymal_cost`
+    value / gradient / Hessian, stage QP data, Riccati solve with (nx, nu) = (37, 12) and the stacked line search -- one batched SQP
+    iteration equals the numpy + torch-oracle restatement of SoftSQPOptimizer::Optimize on individual instances."""
+    import torch
+    from ungar_amd import sqp
+    batch, N = 64, 20
+    X, U, xm, p_dyn, p_cost = _anymal_problem(batch, N, 5)
+    dev = lambda a: torch.as_tensor(np.ascontiguousarray(a), device="cuda")  # noqa: E731
+    Xd, Ud, xmd, pd, pc = dev(X), dev(U), dev(xm), dev(p_dyn), dev(p_cost)
+    solver = sqp.BatchedSoftSqp("anymal", "anymal_cost", N, batch)
+    accepted = solver.iterate(Xd, Ud, xmd, pd, pc)
+    torch.cuda.synchronize()
+    assert (solver.status == 0).all()
+    acc = accepted.cpu().numpy()
+    dXd, dUd, Xn, Un = solver.dX.cpu().numpy(), solver.dU.cpu().numpy(), Xd.cpu().numpy(), Ud.cpu().numpy()
+    th0, ph0 = solver.theta0.cpu().numpy(), solver.phi0.cpu().numpy()
+    assert (acc > 0).mean() > 0.9
+    for i in (0, 37):
+        dX, dU, alpha, Xr, Ur, (theta, phi, slope) = _reference_iteration(X[i], U[i], xm[i], p_dyn[i], p_cost[i], None, "anymal", "anymal_cost", N)
+        scale = max(1.0, np.abs(dX).max(), np.abs(dU).max())
+        assert np.abs(dXd[i] - dX).max() <= 1e-8 * scale and np.abs(dUd[i] - dU).max() <= 1e-8 * scale
+        assert abs(th0[i] - theta) <= 1e-9 * max(1.0, theta) and abs(ph0[i] - phi) <= 1e-9 * max(1.0, abs(phi))
+        assert acc[i] == alpha
+        assert np.abs(Xn[i] - Xr).max() <= 1e-8 * max(1.0, np.abs(Xr).max()) and np.abs(Un[i] - Ur).max() <= 1e-8 * max(1.0, np.abs(Ur).max())
+    # a few more iterations: the dynamics defect keeps shrinking
+    theta_first = th0.copy()
+    for _ in range(3):
+        solver.iterate(Xd, Ud, xmd, pd, pc)
+    torch.cuda.synchronize()
+    assert (solver.status == 0).all()
+    assert np.median(solver.theta0.cpu().numpy() / theta_first) < 0.5

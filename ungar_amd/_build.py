@@ -64,7 +64,7 @@ def generate(exe: str):
     edit to the generator recompiles just the kernels it affects (a from-scratch library build takes ~6 minutes)."""
     import filecmp
     import shutil
-    outs = [os.path.join(GEN, f"{m}_gen.hpp") for m in MODELS + ("quadrotor_cost", "srbd_cost", "rc_car_cost")] + [os.path.join(ORACLE_GEN, f"{m}_cg.c") for m in C_MODELS]
+    outs = [os.path.join(GEN, f"{m}_gen.hpp") for m in MODELS + ("quadrotor_cost", "srbd_cost", "rc_car_cost", "anymal_cost")] + [os.path.join(ORACLE_GEN, f"{m}_cg.c") for m in C_MODELS]
     robot = os.path.join(ROOT, "ungar_amd", "data", "anymal_b.robot")
     stamp = os.path.join(BUILD, "codegen.stamp")
     if _newer(outs + [stamp], [exe, robot]):

@@ -587,6 +587,9 @@ int main(int argc, char** argv) {
         keep = only.empty();
         for (const auto& o : only) keep = keep || o == models::kRcCarCostDims.name;
         if (keep) EmitCostHip(models::kRcCarCostDims, models::RcCarCostNode<AD>, outDir);
+        keep = only.empty();
+        for (const auto& o : only) keep = keep || o == models::kAnymalCostDims.name;
+        if (keep) EmitCostHip(models::kAnymalCostDims, models::AnymalCostNode<AD>, outDir);
     }
     return 0;
 }

@@ -283,11 +283,25 @@ extern "C" int ungar_amd_launch_riccati(const RiccatiArgs* a, void* stream) {
         return std::string(e ? e : "fixed");
     }();
     // sizes of the reference's three OCPs and of the full-body quadruped, fixed at compile time (default route)
-    if (variant == "fixed" || variant == "64") {
-        if (variant == "fixed" && a->nx == 13 && a->nu == 4) return LaunchRiccati<64, 0, 0, 13, 4>(a, lds, s);
-        if (variant == "fixed" && a->nx == 6 && a->nu == 2) return LaunchRiccati<64, 0, 0, 6, 2>(a, lds, s);
-        if (variant == "fixed" && a->nx == 13 && a->nu == 24) return LaunchRiccati<64, 0, 0, 13, 24>(a, lds, s);
-        if (variant == "fixed" && a->nx == 37 && a->nu == 12) return LaunchRiccati<64, 0, 0, 37, 12>(a, lds, s);
+    if (variant == "fixedp") {  // compile-time sizes AND the next knot's operands staged in registers while this knot is processed
+        if (a->nx == 13 && a->nu == 4) return LaunchRiccati<64, 4, 5, 13, 4>(a, lds, s);
+        if (a->nx == 6 && a->nu == 2) return LaunchRiccati<64, 1, 1, 6, 2>(a, lds, s);
+        if (a->nx == 13 && a->nu == 24) return LaunchRiccati<256, 2, 6, 13, 24>(a, lds, s);
+        if (a->nx == 37 && a->nu == 12) return LaunchRiccati<256, 8, 10, 37, 12>(a, lds, s);
+    }
+    if (variant == "fixed" || variant == "fixed1" || variant == "fixedp" || variant == "64") {
+        // small blocks: the next knot's operands are staged in registers while this knot is processed (quadrotor QP step 1.03 -> 0.92 ms;
+        // for the 37 + 12 block the staging registers cost more than the hidden latency: 8.9 -> 9.7 ms)
+        if (variant == "fixed" && a->nx == 13 && a->nu == 4) return LaunchRiccati<64, 4, 5, 13, 4>(a, lds, s);
+        if (variant == "fixed" && a->nx == 6 && a->nu == 2) return LaunchRiccati<64, 1, 1, 6, 2>(a, lds, s);
+        if (variant == "fixed1" && a->nx == 13 && a->nu == 4) return LaunchRiccati<64, 0, 0, 13, 4>(a, lds, s);
+        if (variant == "fixed1" && a->nx == 6 && a->nu == 2) return LaunchRiccati<64, 0, 0, 6, 2>(a, lds, s);
+        // the two large blocks fit only 2-4 instances per CU by their LDS (74 / 30 KB): four wavefronts per instance keep the SIMDs busy
+        // (full-body quadruped, 4096 instances x N = 20: QP step 20.7 ms with one wavefront per instance, 14.0 generic x 4 wavefronts)
+        if (variant == "fixed" && a->nx == 13 && a->nu == 24) return LaunchRiccati<256, 0, 0, 13, 24>(a, lds, s);
+        if (variant == "fixed" && a->nx == 37 && a->nu == 12) return LaunchRiccati<256, 0, 0, 37, 12>(a, lds, s);
+        if (variant == "fixed1" && a->nx == 13 && a->nu == 24) return LaunchRiccati<64, 0, 0, 13, 24>(a, lds, s);
+        if (variant == "fixed1" && a->nx == 37 && a->nu == 12) return LaunchRiccati<64, 0, 0, 37, 12>(a, lds, s);
         return LaunchRiccati<64, 0, 0>(a, lds, s);
     }
     if (variant == "128") return LaunchRiccati<128, 0, 0>(a, lds, s);

@@ -138,38 +138,96 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
                 else bk[idx - n] = a.b.at(inst, k, idx - n);
             });
         }
-        // PAB = P AB;  t = P b + p
-        ex.ForEach(nx * n + nx, [&](int idx) {
-            if (idx < nx * n) {
-                const int i = idx / n, c = idx % n;
-                double acc = 0.0;
-                for (int m = 0; m < nx; ++m) acc += P[i * nx + m] * AB[m * n + c];
-                PAB[idx] = acc;
-            } else {
-                const int i = idx - nx * n;
-                double acc = p[i];
-                for (int m = 0; m < nx; ++m) acc += P[i * nx + m] * bk[m];
-                t[i] = acc;
-            }
-        });
-        // H = W + AB^T PAB in place (computed for r <= c, mirrored: only the upper triangle of W is read);  h = w + AB^T t in place
-        ex.ForEach(n * n + n, [&](int idx) {
-            if (idx < n * n) {
-                const int r = idx / n, c = idx % n;
-                if (r > c) return;
-                double acc = H[r * n + c] + (r == c ? a.regularization : 0.0);
-                for (int m = 0; m < nx; ++m) acc += AB[m * n + r] * PAB[m * n + c];
-                H[r * n + c] = acc;
-                H[c * n + r] = acc;
-            } else {
-                const int c = idx - n * n;
-                double acc = h[c];
-                for (int m = 0; m < nx; ++m) acc += AB[m * n + c] * t[m];
-                h[c] = acc;
-            }
-        });
-        if constexpr (NU > 0 && NU <= 8) {
-            // Small input dimension fixed at compile time: every lane factorises R = H_uu = L L^T itself, in registers (NU^3 / 6
+        if constexpr (NX >= 24) {
+            // Large blocks, sizes fixed at compile time: 2 x 4 register tiles -- eight multiply-adds per six LDS reads instead of per
+            // sixteen, and no bounds checks inside the product (a tile on the edge reads past its row / matrix into the neighbouring
+            // scratch arrays, which is harmless: only the stores are guarded).
+            constexpr int TI = 2, TC = 4, tilesI = (NX + TI - 1) / TI, tilesC = (NX + NU + TC - 1) / TC;
+            ex.ForEach(tilesI * tilesC + nx, [&](int idx) {
+                if (idx < tilesI * tilesC) {
+                    const int i0 = TI * (idx / tilesC), c0 = TC * (idx % tilesC);
+                    double acc[TI][TC] = {};
+                    for (int m = 0; m < nx; ++m) {
+                        double pv[TI], bv[TC];
+                        for (int a2 = 0; a2 < TI; ++a2) pv[a2] = P[(i0 + a2) * nx + m];
+                        for (int b2 = 0; b2 < TC; ++b2) bv[b2] = AB[m * n + c0 + b2];
+                        for (int a2 = 0; a2 < TI; ++a2)
+                            for (int b2 = 0; b2 < TC; ++b2) acc[a2][b2] += pv[a2] * bv[b2];
+                    }
+                    for (int a2 = 0; a2 < TI; ++a2)
+                        for (int b2 = 0; b2 < TC; ++b2)
+                            if (i0 + a2 < nx && c0 + b2 < n) PAB[(i0 + a2) * n + c0 + b2] = acc[a2][b2];
+                } else {
+                    const int i = idx - tilesI * tilesC;
+                    double acc = p[i];
+                    for (int m = 0; m < nx; ++m) acc += P[i * nx + m] * bk[m];
+                    t[i] = acc;
+                }
+            });
+            // H = W + AB^T PAB: the tiles that touch the upper triangle; entries r <= c are updated and mirrored
+            constexpr int tilesR = (NX + NU + TI - 1) / TI;
+            ex.ForEach(tilesR * tilesC + n, [&](int idx) {
+                if (idx < tilesR * tilesC) {
+                    const int r0 = TI * (idx / tilesC), c0 = TC * (idx % tilesC);
+                    if (r0 > c0 + TC - 1) return;  // entirely below the diagonal
+                    double acc[TI][TC] = {};
+                    for (int m = 0; m < nx; ++m) {
+                        double lv[TI], qv[TC];
+                        for (int a2 = 0; a2 < TI; ++a2) lv[a2] = AB[m * n + r0 + a2];
+                        for (int b2 = 0; b2 < TC; ++b2) qv[b2] = PAB[m * n + c0 + b2];
+                        for (int a2 = 0; a2 < TI; ++a2)
+                            for (int b2 = 0; b2 < TC; ++b2) acc[a2][b2] += lv[a2] * qv[b2];
+                    }
+                    for (int a2 = 0; a2 < TI; ++a2)
+                        for (int b2 = 0; b2 < TC; ++b2) {
+                            const int r = r0 + a2, c = c0 + b2;
+                            if (r <= c && c < n) {
+                                const double e = H[r * n + c] + (r == c ? a.regularization : 0.0) + acc[a2][b2];
+                                H[r * n + c] = e;
+                                H[c * n + r] = e;
+                            }
+                        }
+                } else {
+                    const int c = idx - tilesR * tilesC;
+                    double acc = h[c];
+                    for (int m = 0; m < nx; ++m) acc += AB[m * n + c] * t[m];
+                    h[c] = acc;
+                }
+            });
+        } else {
+            // PAB = P AB;  t = P b + p
+            ex.ForEach(nx * n + nx, [&](int idx) {
+                if (idx < nx * n) {
+                    const int i = idx / n, c = idx % n;
+                    double acc = 0.0;
+                    for (int m = 0; m < nx; ++m) acc += P[i * nx + m] * AB[m * n + c];
+                    PAB[idx] = acc;
+                } else {
+                    const int i = idx - nx * n;
+                    double acc = p[i];
+                    for (int m = 0; m < nx; ++m) acc += P[i * nx + m] * bk[m];
+                    t[i] = acc;
+                }
+            });
+            // H = W + AB^T PAB in place (computed for r <= c, mirrored: only the upper triangle of W is read);  h = w + AB^T t in place
+            ex.ForEach(n * n + n, [&](int idx) {
+                if (idx < n * n) {
+                    const int r = idx / n, c = idx % n;
+                    if (r > c) return;
+                    double acc = H[r * n + c] + (r == c ? a.regularization : 0.0);
+                    for (int m = 0; m < nx; ++m) acc += AB[m * n + r] * PAB[m * n + c];
+                    H[r * n + c] = acc;
+                    H[c * n + r] = acc;
+                } else {
+                    const int c = idx - n * n;
+                    double acc = h[c];
+                    for (int m = 0; m < nx; ++m) acc += AB[m * n + c] * t[m];
+                    h[c] = acc;
+                }
+            });
+        }
+        if constexpr (NU > 0 && NU <= 12) {
+            // Input dimension <= 12 fixed at compile time: every lane factorises R = H_uu = L L^T itself, in registers (NU^3 / 6
             // multiply-adds from NU (NU + 1) / 2 LDS reads), and goes straight on to its right-hand side of
             // [K | kff] = -R^-1 [H_ux | h_u] -- one phase instead of NU + 1 (a barrier and an LDS round trip per Cholesky column).
             ex.ForEach(nk, [&](int c) {
@@ -234,17 +292,40 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
             // [K | kff] = -R^-1 [H_ux | h_u]: one right-hand side per lane (forward then backward substitution); the lane also
             // files its column of the gains
             ex.ForEach(nk, [&](int c) {
-                for (int i = 0; i < nu; ++i) {  // L y = rhs
-                    double sv = c < nx ? -H[(nx + i) * n + c] : -h[nx + i];
-                    for (int m = 0; m < i; ++m) sv -= H[(nx + i) * n + nx + m] * K[m * nk + c];
-                    K[i * nk + c] = sv / piv[i];
-                }
-                for (int i = nu - 1; i >= 0; --i) {  // L^T x = y
-                    double sv = K[i * nk + c];
-                    for (int m = i + 1; m < nu; ++m) sv -= H[(nx + m) * n + nx + i] * K[m * nk + c];
-                    sv /= piv[i];
-                    K[i * nk + c] = sv;
-                    gains[static_cast<long long>(k) * nu * nk + i * nk + c] = sv;
+                if constexpr (NU > 0) {
+                    // the lane's column of K stays in registers during both substitutions: through LDS every multiply-add would wait
+                    // for a write -> read round trip of the value the same lane has just produced
+                    double y[NU];
+#pragma unroll
+                    for (int i = 0; i < NU; ++i) {  // L y = rhs
+                        double sv = c < nx ? -H[(nx + i) * n + c] : -h[nx + i];
+#pragma unroll
+                        for (int m = 0; m < i; ++m) sv -= H[(nx + i) * n + nx + m] * y[m];
+                        y[i] = sv / piv[i];
+                    }
+#pragma unroll
+                    for (int i = NU - 1; i >= 0; --i) {  // L^T x = y
+                        double sv = y[i];
+#pragma unroll
+                        for (int m = i + 1; m < NU; ++m) sv -= H[(nx + m) * n + nx + i] * y[m];
+                        sv /= piv[i];
+                        y[i] = sv;
+                        K[i * nk + c] = sv;
+                        gains[static_cast<long long>(k) * nu * nk + i * nk + c] = sv;
+                    }
+                } else {
+                    for (int i = 0; i < nu; ++i) {  // L y = rhs
+                        double sv = c < nx ? -H[(nx + i) * n + c] : -h[nx + i];
+                        for (int m = 0; m < i; ++m) sv -= H[(nx + i) * n + nx + m] * K[m * nk + c];
+                        K[i * nk + c] = sv / piv[i];
+                    }
+                    for (int i = nu - 1; i >= 0; --i) {  // L^T x = y
+                        double sv = K[i * nk + c];
+                        for (int m = i + 1; m < nu; ++m) sv -= H[(nx + m) * n + nx + i] * K[m * nk + c];
+                        sv /= piv[i];
+                        K[i * nk + c] = sv;
+                        gains[static_cast<long long>(k) * nu * nk + i * nk + c] = sv;
+                    }
                 }
             });
         }

@@ -43,6 +43,7 @@ inline constexpr NodeDims kQuadrotorCostDims{"quadrotor_cost", 13, 4, 0, 13};
 inline constexpr NodeDims kSrbdDims{"srbd", 13, 24, 4, 6};
 /// Scalar stage cost of the RC-car OCP (rc_car.example.cpp:204-222 per knot): p = [reference_position(2)].
 inline constexpr NodeDims kRcCarCostDims{"rc_car_cost", 6, 2, 0, 2};
+inline constexpr NodeDims kAnymalCostDims{"anymal_cost", 37, 12, 0, 42};
 /// Inequality rows of one knot of the RC-car OCP (rc_car.example.cpp:271-282): [|d| - 15, |delta| - 15, 0.3 - v_x].
 inline constexpr NodeDims kRcCarIneqDims{"rc_car_ineq", 6, 2, 0, 0, 3};
 /// World positions of the four feet, p + q * r_i (12 outputs): the node-local part of the quadruped OCP's foot-contact
@@ -243,6 +244,26 @@ void QuadrotorIneqNode(const S* /*x*/, const S* u, const S* /*w*/, const S* p, S
 template <class S>
 void RcCarCostNode(const S* x, const S* u, const S* /*w*/, const S* p, S* y) {
     y[0] = (x[0] - p[0]) * (x[0] - p[0]) + (x[1] - p[1]) * (x[1] - p[1]) + 1e-6 * (u[0] * u[0] + u[1] * u[1]);
+}
+
+/// Stage cost for the full-body quadruped (x = [q(19); v(18)], u = 12 joint torques).  The reference has NO full-body MPC example
+/// (its ANYmal model appears only in test/rbd/robot.test.cpp), so this is the engine's own tracking cost in
+/// the style of the reference's stage costs (quadrotor.example.cpp:196-236): weighted squared distance to a reference state --
+/// base position, orientation through the sign-invariant term min(|q - q_ref|^2, |q + q_ref|^2), joint angles, velocities -- plus
+/// input regularisation.  p = [x_ref(37), w_position, w_orientation, w_joints, w_velocity, w_torque].
+template <class S>
+void AnymalCostNode(const S* x, const S* u, const S* /*w*/, const S* p, S* y) {
+    const S *ref = p, wPos = p[37], wQuat = p[38], wJoint = p[39], wVel = p[40], wTau = p[41];
+    S pos{0.0}, qm{0.0}, qp{0.0}, joint{0.0}, vel{0.0}, tau{0.0};
+    for (int i = 0; i < 3; ++i) pos = pos + (x[i] - ref[i]) * (x[i] - ref[i]);
+    for (int i = 3; i < 7; ++i) {
+        qm = qm + (x[i] - ref[i]) * (x[i] - ref[i]);
+        qp = qp + (x[i] + ref[i]) * (x[i] + ref[i]);
+    }
+    for (int i = 7; i < 19; ++i) joint = joint + (x[i] - ref[i]) * (x[i] - ref[i]);
+    for (int i = 19; i < 37; ++i) vel = vel + (x[i] - ref[i]) * (x[i] - ref[i]);
+    for (int i = 0; i < 12; ++i) tau = tau + u[i] * u[i];
+    y[0] = wPos * pos + wQuat * Min(qm, qp) + wJoint * joint + wVel * vel + wTau * tau;
 }
 
 /// Inequality constraints of example/mpc/rc_car.example.cpp:271-282 for one knot: input bounds through Utils::Abs and the

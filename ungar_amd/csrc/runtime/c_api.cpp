@@ -37,6 +37,7 @@ UNGAR_AMD_DECLARE_MODEL(quadrotor_ineq)
 UNGAR_AMD_DECLARE_MODEL(rc_car_ineq)
 UNGAR_AMD_DECLARE_MODEL(srbd_feet)
 UNGAR_AMD_DECLARE_MODEL(rc_car_cost)
+UNGAR_AMD_DECLARE_MODEL(anymal_cost)
 UNGAR_AMD_DECLARE_MODEL(anymal_rnea)
 UNGAR_AMD_DECLARE_MODEL(anymal_crba)
 UNGAR_AMD_DECLARE_MODEL(anymal_minv)
@@ -88,6 +89,7 @@ const BuiltinEntry kBuiltins[] = {
     {"rc_car_ineq", ungar_amd_launch_rc_car_ineq, ungar_amd_pattern_rc_car_ineq, ungar_amd_dims_rc_car_ineq},
     {"srbd_feet", ungar_amd_launch_srbd_feet, ungar_amd_pattern_srbd_feet, ungar_amd_dims_srbd_feet},
     {"rc_car_cost", ungar_amd_launch_rc_car_cost, ungar_amd_pattern_rc_car_cost, ungar_amd_dims_rc_car_cost, true},
+    {"anymal_cost", ungar_amd_launch_anymal_cost, ungar_amd_pattern_anymal_cost, ungar_amd_dims_anymal_cost, true},
     {"quadrotor_cost", ungar_amd_launch_quadrotor_cost, ungar_amd_pattern_quadrotor_cost, ungar_amd_dims_quadrotor_cost, true},
     {"srbd_cost", ungar_amd_launch_srbd_cost, ungar_amd_pattern_srbd_cost, ungar_amd_dims_srbd_cost, true},
 };
@@ -204,7 +206,7 @@ int ungar_model_open(const char* name, ungar_model** out) {
         *out = m;
         return UNGAR_OK;
     }
-    return Fail(UNGAR_E_INVALID, std::string("unknown model '") + name + "' (built-ins: quadrotor, rc_car, srbd, anymal, anymal_ad, anymal_reg, srbd_ineq, quadrotor_ineq, rc_car_ineq, srbd_feet, quadrotor_cost, srbd_cost, rc_car_cost, anymal_rnea, anymal_crba, anymal_minv, anymal_feet, anymal_centroidal)");
+    return Fail(UNGAR_E_INVALID, std::string("unknown model '") + name + "' (built-ins: quadrotor, rc_car, srbd, anymal, anymal_ad, anymal_reg, srbd_ineq, quadrotor_ineq, rc_car_ineq, srbd_feet, quadrotor_cost, srbd_cost, rc_car_cost, anymal_cost, anymal_rnea, anymal_crba, anymal_minv, anymal_feet, anymal_centroidal)");
 }
 
 void ungar_model_close(ungar_model* model) {
