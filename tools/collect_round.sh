@@ -34,3 +34,5 @@ cp_if gpurun_out/prewarm.log                  profiles/${tag}_prewarm.log
 cp_if gpurun_out/gn_shapes.json                profiles/${tag}_gn_shapes.json
 cp_if gpurun_out/rbd_nodes.json                profiles/${tag}_rbd_nodes.json
 cp_if gpurun_out/layouts_all.log              profiles/${tag}_layouts_all.log
+cp_if gpurun_out/sqp_anymal.json              profiles/${tag}_sqp_anymal_timing.json
+cp_if gpurun_out/sqp_bench.log                profiles/${tag}_sqp_quadrotor_timing.json
