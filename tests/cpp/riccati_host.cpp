@@ -11,6 +11,7 @@ namespace {
 template <bool PREFETCH>
 struct HostExec {
     static constexpr bool kPrefetch = PREFETCH;
+    static constexpr bool kAhead = true;
     using StageAB = std::vector<double>;
     using StageW = std::vector<double>;
     using StageV = std::vector<double>;

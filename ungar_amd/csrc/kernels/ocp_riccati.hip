@@ -18,9 +18,10 @@ constexpr int kBlock = 64;
 
 /// Lanes of the workgroup stride over the index range and meet at a barrier.  SLOTS_AB / SLOTS_W: registers per lane that
 /// stage the next knot's [A|B] block and stage Hessian (64 * SLOTS doubles each); 0 = read the operands in place.
-template <int BLOCK, int SLOTS_AB, int SLOTS_W>
+template <int BLOCK, int SLOTS_AB, int SLOTS_W, bool AHEAD = true>
 struct DeviceExec {
     static constexpr bool kPrefetch = SLOTS_AB > 0;
+    static constexpr bool kAhead = AHEAD;
     template <int K>
     struct Stage {
         double r[K > 0 ? K : 1];
@@ -63,13 +64,13 @@ struct DeviceExec {
     __device__ __forceinline__ void Barrier() { LdsBarrier(); }
 };
 
-template <int BLOCK, int SLOTS_AB, int SLOTS_W, int NX = 0, int NU = 0>
+template <int BLOCK, int SLOTS_AB, int SLOTS_W, int NX = 0, int NU = 0, bool AHEAD = true>
 __global__ __launch_bounds__(BLOCK) void RiccatiKernel(const RiccatiArgs a) {
     extern __shared__ double scratch[];
     const long long inst = blockIdx.x;
     if (inst >= a.batch) return;
-    DeviceExec<BLOCK, SLOTS_AB, SLOTS_W> ex;
-    RiccatiInstance<DeviceExec<BLOCK, SLOTS_AB, SLOTS_W>, NX, NU>(a, inst, scratch, ex);
+    DeviceExec<BLOCK, SLOTS_AB, SLOTS_W, AHEAD> ex;
+    RiccatiInstance<DeviceExec<BLOCK, SLOTS_AB, SLOTS_W, AHEAD>, NX, NU>(a, inst, scratch, ex);
 }
 
 /// Wavefront sum (64 lanes), result in every lane.
@@ -257,14 +258,14 @@ __global__ __launch_bounds__(kBlock) void AcceptKernel(const AcceptArgs a) {
 using namespace ungar_amd::kernels;
 
 namespace {
-template <int BLOCK, int SLOTS_AB, int SLOTS_W, int NX = 0, int NU = 0>
+template <int BLOCK, int SLOTS_AB, int SLOTS_W, int NX = 0, int NU = 0, bool AHEAD = true>
 int LaunchRiccati(const RiccatiArgs* a, std::size_t lds, hipStream_t stream) {
     if (lds > 64 * 1024) {  // above the default dynamic-LDS limit the kernel has to opt in (160 KiB per CU on gfx950)
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(RiccatiKernel<BLOCK, SLOTS_AB, SLOTS_W, NX, NU>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(RiccatiKernel<BLOCK, SLOTS_AB, SLOTS_W, NX, NU, AHEAD>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                  static_cast<int>(lds));
         if (e != hipSuccess) return static_cast<int>(e);
     }
-    hipLaunchKernelGGL((RiccatiKernel<BLOCK, SLOTS_AB, SLOTS_W, NX, NU>), dim3(static_cast<unsigned>(a->batch)), dim3(BLOCK), lds, stream, *a);
+    hipLaunchKernelGGL((RiccatiKernel<BLOCK, SLOTS_AB, SLOTS_W, NX, NU, AHEAD>), dim3(static_cast<unsigned>(a->batch)), dim3(BLOCK), lds, stream, *a);
     return static_cast<int>(hipGetLastError());
 }
 }  // namespace
@@ -289,7 +290,7 @@ extern "C" int ungar_amd_launch_riccati(const RiccatiArgs* a, void* stream) {
         if (a->nx == 13 && a->nu == 24) return LaunchRiccati<256, 2, 6, 13, 24>(a, lds, s);
         if (a->nx == 37 && a->nu == 12) return LaunchRiccati<256, 8, 10, 37, 12>(a, lds, s);
     }
-    if (variant == "fixed" || variant == "fixed1" || variant == "fixedp" || variant == "64") {
+    if (variant == "fixed" || variant == "fixeds" || variant == "fixed1" || variant == "fixedp" || variant == "64") {
         // small blocks: the next knot's operands are staged in registers while this knot is processed (quadrotor QP step 1.03 -> 0.92 ms;
         // for the 37 + 12 block the staging registers cost more than the hidden latency: 8.9 -> 9.7 ms)
         if (variant == "fixed" && a->nx == 13 && a->nu == 4) return LaunchRiccati<64, 4, 5, 13, 4>(a, lds, s);
@@ -300,6 +301,9 @@ extern "C" int ungar_amd_launch_riccati(const RiccatiArgs* a, void* stream) {
         // (full-body quadruped, 4096 instances x N = 20: QP step 20.7 ms with one wavefront per instance, 14.0 generic x 4 wavefronts)
         if (variant == "fixed" && a->nx == 13 && a->nu == 24) return LaunchRiccati<256, 0, 0, 13, 24>(a, lds, s);
         if (variant == "fixed" && a->nx == 37 && a->nu == 12) return LaunchRiccati<256, 0, 0, 37, 12>(a, lds, s);
+        // "fixeds": each knot's operands staged in registers at its top (17 loads per lane back to back instead of one latency each): the
+        // recursion itself gets 1.5x faster per instance, but the 40 staging registers push the kernel past 256 -> one workgroup per CU: slower overall
+        if (variant == "fixeds" && a->nx == 37 && a->nu == 12) return LaunchRiccati<256, 8, 10, 37, 12, false>(a, lds, s);
         if (variant == "fixed1" && a->nx == 13 && a->nu == 24) return LaunchRiccati<64, 0, 0, 13, 24>(a, lds, s);
         if (variant == "fixed1" && a->nx == 37 && a->nu == 12) return LaunchRiccati<64, 0, 0, 37, 12>(a, lds, s);
         return LaunchRiccati<64, 0, 0>(a, lds, s);

@@ -21,7 +21,8 @@
 // Execution policy:
 //   ForEach(n, f)            f(i) for i in [0, n), spread over the lanes, followed by a workgroup barrier on the scratch memory
 //   GlobalSync()             workgroup barrier that also orders the workgroup's global writes before its later global reads
-//   kPrefetch                whether the policy stages the next knot's operands (below); without it they are read in place
+//   kPrefetch                whether the policy stages a knot's operands in registers (below); without it they are read in place
+//   kAhead                   with kPrefetch: stage the NEXT knot's operands while this one is processed (else: this knot's, at its top)
 //   Stage<SLOTS>             per-lane registers for a strided global read of up to 64 * SLOTS doubles
 //   Fetch(n, f, stage)       issues the loads stage <- f(i); no barrier, nothing waits for the data
 //   Commit(n, stage, dst)    dst[i] <- stage (no barrier);  Barrier() synchronises the scratch memory
@@ -123,13 +124,20 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
         ex.Commit(nx, sb, bk);
         ex.Barrier();
     };
-    if constexpr (Exec::kPrefetch) {
+    // kPrefetch: operands go through register stages (all loads of a knot issued back to back).  kAhead: the stage is filled one
+    // knot early and committed after the knot (latency hidden, registers held across the knot); otherwise filled and committed at
+    // the top of the knot (one exposed round trip per knot instead of one per load, no registers held).
+    constexpr bool ahead = Exec::kPrefetch && Exec::kAhead;
+    if constexpr (ahead) {
         fetchKnot(N - 1);
         commitKnot();
     }
     for (int k = N - 1; k >= 0; --k) {
-        if constexpr (Exec::kPrefetch) {
+        if constexpr (ahead) {
             if (k > 0) fetchKnot(k - 1);  // in flight while knot k is processed
+        } else if constexpr (Exec::kPrefetch) {
+            fetchKnot(k);
+            commitKnot();
         } else {
             ex.ForEach(nx * n + n * n + n + nx, [&](int idx) {
                 if (idx < nx * n) AB[idx] = a.jac.at(inst, k, idx);
@@ -141,46 +149,50 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
         if constexpr (NX >= 24) {
             // Large blocks, sizes fixed at compile time: 2 x 4 register tiles -- eight multiply-adds per six LDS reads instead of per
             // sixteen, and no bounds checks inside the product (a tile on the edge reads past its row / matrix into the neighbouring
-            // scratch arrays, which is harmless: only the stores are guarded).
+            // scratch arrays, which is harmless: only the stores are guarded).  A tile's columns are INTERLEAVED (tc, tc + tilesC, ...):
+            // neighbouring lanes then read neighbouring LDS words.  With four contiguous columns per lane the lanes of a read were 32
+            // bytes apart and, paired into ds_read2_b64 (32-bank mode), collided four ways: SQ_LDS_BANK_CONFLICT was 4x the LDS issue cycles.
             constexpr int TI = 2, TC = 4, tilesI = (NX + TI - 1) / TI, tilesC = (NX + NU + TC - 1) / TC;
             ex.ForEach(tilesI * tilesC + nx, [&](int idx) {
                 if (idx < tilesI * tilesC) {
-                    const int i0 = TI * (idx / tilesC), c0 = TC * (idx % tilesC);
+                    const int i0 = idx / tilesC, c0 = idx % tilesC;  // rows i0 + a2 tilesI, columns c0 + b2 tilesC
                     double acc[TI][TC] = {};
+#pragma unroll 4
                     for (int m = 0; m < nx; ++m) {
                         double pv[TI], bv[TC];
-                        for (int a2 = 0; a2 < TI; ++a2) pv[a2] = P[(i0 + a2) * nx + m];
-                        for (int b2 = 0; b2 < TC; ++b2) bv[b2] = AB[m * n + c0 + b2];
+                        for (int a2 = 0; a2 < TI; ++a2) pv[a2] = P[(i0 + a2 * tilesI) * nx + m];
+                        for (int b2 = 0; b2 < TC; ++b2) bv[b2] = AB[m * n + c0 + b2 * tilesC];
                         for (int a2 = 0; a2 < TI; ++a2)
                             for (int b2 = 0; b2 < TC; ++b2) acc[a2][b2] += pv[a2] * bv[b2];
                     }
                     for (int a2 = 0; a2 < TI; ++a2)
                         for (int b2 = 0; b2 < TC; ++b2)
-                            if (i0 + a2 < nx && c0 + b2 < n) PAB[(i0 + a2) * n + c0 + b2] = acc[a2][b2];
+                            if (i0 + a2 * tilesI < nx && c0 + b2 * tilesC < n) PAB[(i0 + a2 * tilesI) * n + c0 + b2 * tilesC] = acc[a2][b2];
                 } else {
                     const int i = idx - tilesI * tilesC;
                     double acc = p[i];
+#pragma unroll 8
                     for (int m = 0; m < nx; ++m) acc += P[i * nx + m] * bk[m];
                     t[i] = acc;
                 }
             });
-            // H = W + AB^T PAB: the tiles that touch the upper triangle; entries r <= c are updated and mirrored
+            // H = W + AB^T PAB: all tiles (interleaved rows and columns straddle the diagonal); entries r <= c are updated and mirrored
             constexpr int tilesR = (NX + NU + TI - 1) / TI;
             ex.ForEach(tilesR * tilesC + n, [&](int idx) {
                 if (idx < tilesR * tilesC) {
-                    const int r0 = TI * (idx / tilesC), c0 = TC * (idx % tilesC);
-                    if (r0 > c0 + TC - 1) return;  // entirely below the diagonal
+                    const int r0 = idx / tilesC, c0 = idx % tilesC;
                     double acc[TI][TC] = {};
+#pragma unroll 4
                     for (int m = 0; m < nx; ++m) {
                         double lv[TI], qv[TC];
-                        for (int a2 = 0; a2 < TI; ++a2) lv[a2] = AB[m * n + r0 + a2];
-                        for (int b2 = 0; b2 < TC; ++b2) qv[b2] = PAB[m * n + c0 + b2];
+                        for (int a2 = 0; a2 < TI; ++a2) lv[a2] = AB[m * n + r0 + a2 * tilesR];
+                        for (int b2 = 0; b2 < TC; ++b2) qv[b2] = PAB[m * n + c0 + b2 * tilesC];
                         for (int a2 = 0; a2 < TI; ++a2)
                             for (int b2 = 0; b2 < TC; ++b2) acc[a2][b2] += lv[a2] * qv[b2];
                     }
                     for (int a2 = 0; a2 < TI; ++a2)
                         for (int b2 = 0; b2 < TC; ++b2) {
-                            const int r = r0 + a2, c = c0 + b2;
+                            const int r = r0 + a2 * tilesR, c = c0 + b2 * tilesC;
                             if (r <= c && c < n) {
                                 const double e = H[r * n + c] + (r == c ? a.regularization : 0.0) + acc[a2][b2];
                                 H[r * n + c] = e;
@@ -190,6 +202,7 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
                 } else {
                     const int c = idx - tilesR * tilesC;
                     double acc = h[c];
+#pragma unroll 8
                     for (int m = 0; m < nx; ++m) acc += AB[m * n + c] * t[m];
                     h[c] = acc;
                 }
@@ -200,11 +213,13 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
                 if (idx < nx * n) {
                     const int i = idx / n, c = idx % n;
                     double acc = 0.0;
+#pragma unroll 8
                     for (int m = 0; m < nx; ++m) acc += P[i * nx + m] * AB[m * n + c];
                     PAB[idx] = acc;
                 } else {
                     const int i = idx - nx * n;
                     double acc = p[i];
+#pragma unroll 8
                     for (int m = 0; m < nx; ++m) acc += P[i * nx + m] * bk[m];
                     t[i] = acc;
                 }
@@ -215,12 +230,14 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
                     const int r = idx / n, c = idx % n;
                     if (r > c) return;
                     double acc = H[r * n + c] + (r == c ? a.regularization : 0.0);
+#pragma unroll 8
                     for (int m = 0; m < nx; ++m) acc += AB[m * n + r] * PAB[m * n + c];
                     H[r * n + c] = acc;
                     H[c * n + r] = acc;
                 } else {
                     const int c = idx - n * n;
                     double acc = h[c];
+#pragma unroll 8
                     for (int m = 0; m < nx; ++m) acc += AB[m * n + c] * t[m];
                     h[c] = acc;
                 }
@@ -334,6 +351,7 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
             if (idx < nx * nx) {
                 const int i = idx / nx, j = idx % nx;
                 double s1 = H[i * n + j], s2 = H[j * n + i];
+#pragma unroll 8
                 for (int m = 0; m < nu; ++m) {
                     s1 += H[(nx + m) * n + i] * K[m * nk + j];
                     s2 += H[(nx + m) * n + j] * K[m * nk + i];
@@ -342,6 +360,7 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
             } else {
                 const int i = idx - nx * nx;
                 double sv = h[i];
+#pragma unroll 8
                 for (int m = 0; m < nu; ++m) sv += H[(nx + m) * n + i] * K[m * nk + nx];
                 pn[i] = sv;
             }
@@ -354,7 +373,7 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
             p = pn;
             pn = swapp;
         }
-        if constexpr (Exec::kPrefetch) {
+        if constexpr (ahead) {
             if (k > 0) commitKnot();  // AB, H, h, b of knot k are dead from here on
         }
     }
@@ -387,13 +406,16 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
         ex.ForEach(nu, [&](int i) {
             const double* g = gains + static_cast<long long>(k) * nu * nk + i * nk;
             double s = g[nx];
+#pragma unroll 8
             for (int m = 0; m < nx; ++m) s += g[m] * dx[m];
             du[i] = s;
             a.dU.at(inst, k, i) = s;
         });
         ex.ForEach(nx, [&](int i) {
             double s = bk[i];
+#pragma unroll 8
             for (int m = 0; m < nx; ++m) s += AB[i * n + m] * dx[m];
+#pragma unroll 8
             for (int m = 0; m < nu; ++m) s += AB[i * n + nx + m] * du[m];
             dxn[i] = s;
             a.dX.at(inst, k + 1, i) = s;
