@@ -19,6 +19,10 @@ struct HostExec {
     void ForEach(int n, F f) {
         for (int i = 0; i < n; ++i) f(i);
     }
+    template <class F>
+    void ForEachNoSync(int n, F f) {
+        for (int i = 0; i < n; ++i) f(i);
+    }
     void GlobalSync() {}
     void Barrier() {}
     template <class F>

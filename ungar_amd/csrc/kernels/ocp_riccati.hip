@@ -45,6 +45,11 @@ struct DeviceExec {
         for (int i = static_cast<int>(threadIdx.x); i < n; i += BLOCK) f(i);
         LdsBarrier();
     }
+    /// The same loop without the closing barrier: several of them may share one Barrier().
+    template <class F>
+    __device__ __forceinline__ void ForEachNoSync(int n, F f) {
+        for (int i = static_cast<int>(threadIdx.x); i < n; i += BLOCK) f(i);
+    }
     template <class F, int K>
     __device__ __forceinline__ void Fetch(int n, F f, Stage<K>& s) {
 #pragma unroll

@@ -21,6 +21,7 @@
 // Execution policy:
 //   ForEach(n, f)            f(i) for i in [0, n), spread over the lanes, followed by a workgroup barrier on the scratch memory
 //   GlobalSync()             workgroup barrier that also orders the workgroup's global writes before its later global reads
+//   ForEachNoSync(n, f)      the same without the closing barrier (followed by other loops and one Barrier())
 //   kPrefetch                whether the policy stages a knot's operands in registers (below); without it they are read in place
 //   kAhead                   with kPrefetch: stage the NEXT knot's operands while this one is processed (else: this knot's, at its top)
 //   Stage<SLOTS>             per-lane registers for a strided global read of up to 64 * SLOTS doubles
@@ -139,12 +140,14 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
             fetchKnot(k);
             commitKnot();
         } else {
-            ex.ForEach(nx * n + n * n + n + nx, [&](int idx) {
-                if (idx < nx * n) AB[idx] = a.jac.at(inst, k, idx);
-                else if ((idx -= nx * n) < n * n) H[idx] = a.hess.at(inst, k, idx);
-                else if ((idx -= n * n) < n) h[idx] = a.grad.at(inst, k, idx);
-                else bk[idx - n] = a.b.at(inst, k, idx - n);
-            });
+            // one loop per operand, ONE barrier: inside a loop every iteration is `LDS[i] = global[i]`, which the compiler unrolls into
+            // a batch of loads followed by the stores; a single loop over all four operands with an if-chain serialised them
+            // (17 dependent round trips per lane for the 37 + 12 block)
+            ex.ForEachNoSync(nx * n, [&](int idx) { AB[idx] = a.jac.at(inst, k, idx); });
+            ex.ForEachNoSync(n * n, [&](int idx) { H[idx] = a.hess.at(inst, k, idx); });
+            ex.ForEachNoSync(n, [&](int idx) { h[idx] = a.grad.at(inst, k, idx); });
+            ex.ForEachNoSync(nx, [&](int idx) { bk[idx] = a.b.at(inst, k, idx); });
+            ex.Barrier();
         }
         if constexpr (NX >= 24) {
             // Large blocks, sizes fixed at compile time: 2 x 4 register tiles -- eight multiply-adds per six LDS reads instead of per
