@@ -40,6 +40,10 @@
 
 #include <cmath>
 
+#ifndef UNGAR_RICCATI_TILE_MIN_NX
+#define UNGAR_RICCATI_TILE_MIN_NX 6  // register tiles in the two large products for compile-time sizes from this nx on
+#endif
+
 namespace ungar_amd::kernels {
 
 /// Strided view (instance, knot, element) of one operand, in doubles.
@@ -149,13 +153,13 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
             ex.ForEachNoSync(nx, [&](int idx) { bk[idx] = a.b.at(inst, k, idx); });
             ex.Barrier();
         }
-        if constexpr (NX >= 24) {
+        if constexpr (NX >= UNGAR_RICCATI_TILE_MIN_NX) {
             // Large blocks, sizes fixed at compile time: 2 x 4 register tiles -- eight multiply-adds per six LDS reads instead of per
             // sixteen, and no bounds checks inside the product (a tile on the edge reads past its row / matrix into the neighbouring
             // scratch arrays, which is harmless: only the stores are guarded).  A tile's columns are INTERLEAVED (tc, tc + tilesC, ...):
             // neighbouring lanes then read neighbouring LDS words.  With four contiguous columns per lane the lanes of a read were 32
             // bytes apart and, paired into ds_read2_b64 (32-bank mode), collided four ways: SQ_LDS_BANK_CONFLICT was 4x the LDS issue cycles.
-            constexpr int TI = 2, TC = 4, tilesI = (NX + TI - 1) / TI, tilesC = (NX + NU + TC - 1) / TC;
+            constexpr int TI = 2, TC = NX >= 24 ? 4 : 2, tilesI = (NX + TI - 1) / TI, tilesC = (NX + NU + TC - 1) / TC;
             ex.ForEach(tilesI * tilesC + nx, [&](int idx) {
                 if (idx < tilesI * tilesC) {
                     const int i0 = idx / tilesC, c0 = idx % tilesC;  // rows i0 + a2 tilesI, columns c0 + b2 tilesC
