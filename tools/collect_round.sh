@@ -36,3 +36,4 @@ cp_if gpurun_out/rbd_nodes.json                profiles/${tag}_rbd_nodes.json
 cp_if gpurun_out/layouts_all.log              profiles/${tag}_layouts_all.log
 cp_if gpurun_out/sqp_anymal.json              profiles/${tag}_sqp_anymal_timing.json
 cp_if gpurun_out/sqp_bench.log                profiles/${tag}_sqp_quadrotor_timing.json
+cp_if gpurun_out/sqp_srbd.json                profiles/${tag}_sqp_srbd_timing.json

@@ -42,6 +42,7 @@ timeout 300 python tools/bench_ocp_step.py 2>&1 | tail -1 > gpurun_out/ocp_step_
 echo "== batched SQP"
 bash tools/gpu_sqp_profile.sh 2>&1 | tail -12
 timeout 300 python tools/bench_sqp_anymal.py 2>/dev/null | tail -1 | tee gpurun_out/sqp_anymal.json | cut -c1-400
+timeout 300 python tools/bench_sqp_srbd.py 2>/dev/null | tail -1 | tee gpurun_out/sqp_srbd.json | cut -c1-400
 echo "== rocprofv3 kernel trace + HBM counters (separate passes)"
 rm -rf gpurun_out/prof gpurun_out/pmc1 gpurun_out/pmc2
 B="python bench.py --no-cpu-baseline --no-sub-results"

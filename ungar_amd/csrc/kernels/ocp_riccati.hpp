@@ -294,64 +294,54 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
                 }
             });
         } else {
-            // Cholesky of R = H_uu (strict lower triangle in place, pivots in K's spare column... kept in `dx`-sized scratch `piv`):
-            // one phase per column -- every lane recomputes the pivot from values that are final, lane 0 records it
+            // Larger (or run-time) input dimension: R = H_uu is factorised as L D L^T by RIGHT-LOOKING elimination, applied at the
+            // same time to the right-hand sides [K | kff] = -[H_ux | h_u] (forward substitution), then the back substitution is
+            // eliminated column by column as well.  Every phase is a flat set of independent rank-one updates over all lanes:
+            //   forward, column j:   d_j = R[j][j];   R[i][k] -= R[i][j] R[k][j] / d_j  (j < k <= i);   K[i][:] -= R[i][j] / d_j K[j][:]  (i > j)
+            //   scale:               K[i][:] /= d_i
+            //   backward, column j:  K[i][:] -= R[j][i] / d_i K[j][:]  (i < j)
+            // (2 nu + 1 phases; the left-looking column-by-column Cholesky + one right-hand side per lane it replaces ran nu-long
+            // dependent chains of LDS round trips on at most nu lanes: 187 k cycles per knot for the 13 + 24 block of the reference's
+            // quadruped OCP.)  The strict lower triangle of R holds the UNSCALED columns L[i][j] d_j afterwards.
+            ex.ForEach(nu * nk, [&](int idx) {
+                const int i = idx / nk, c = idx % nk;
+                K[idx] = c < nx ? -H[(nx + i) * n + c] : -h[nx + i];
+            });
             for (int j = 0; j < nu; ++j) {
-                ex.ForEach(nu - j, [&](int q) {
-                    double d = H[(nx + j) * n + nx + j];
-                    for (int m = 0; m < j; ++m) d -= H[(nx + j) * n + nx + m] * H[(nx + j) * n + nx + m];
-                    const bool bad = !(d > 0.0);
-                    const double root = sqrt(bad ? 1.0 : d);
-                    if (q == 0) {
-                        if (bad) failed = failed ? failed : k + 1;
-                        piv[j] = root;
-                        return;
+                const int rest = nu - 1 - j, pairs = rest * (rest + 1) / 2;
+                ex.ForEach(pairs + rest * nk + 1, [&](int idx) {
+                    const double dj = H[(nx + j) * n + nx + j];
+                    const bool bad = !(dj > 0.0);
+                    const double rd = 1.0 / (bad ? 1.0 : dj);
+                    if (idx < pairs) {  // trailing block: entries (i, k2) with j < k2 <= i, unranked row by row of the triangle
+                        int q = 0, left = idx;
+                        while (left > q) {
+                            left -= q + 1;
+                            ++q;
+                        }
+                        const int i = j + 1 + q, k2 = j + 1 + left;
+                        H[(nx + i) * n + nx + k2] -= H[(nx + i) * n + nx + j] * H[(nx + k2) * n + nx + j] * rd;
+                    } else if (idx < pairs + rest * nk) {
+                        const int e = idx - pairs, i = j + 1 + e / nk, c = e % nk;
+                        K[i * nk + c] -= H[(nx + i) * n + nx + j] * rd * K[j * nk + c];
+                    } else if (bad) {
+                        failed = failed ? failed : k + 1;
                     }
-                    const int i = j + q;
-                    double sv = H[(nx + i) * n + nx + j];
-                    for (int m = 0; m < j; ++m) sv -= H[(nx + i) * n + nx + m] * H[(nx + j) * n + nx + m];
-                    H[(nx + i) * n + nx + j] = sv / root;
                 });
             }
-            // [K | kff] = -R^-1 [H_ux | h_u]: one right-hand side per lane (forward then backward substitution); the lane also
-            // files its column of the gains
-            ex.ForEach(nk, [&](int c) {
-                if constexpr (NU > 0) {
-                    // the lane's column of K stays in registers during both substitutions: through LDS every multiply-add would wait
-                    // for a write -> read round trip of the value the same lane has just produced
-                    double y[NU];
-#pragma unroll
-                    for (int i = 0; i < NU; ++i) {  // L y = rhs
-                        double sv = c < nx ? -H[(nx + i) * n + c] : -h[nx + i];
-#pragma unroll
-                        for (int m = 0; m < i; ++m) sv -= H[(nx + i) * n + nx + m] * y[m];
-                        y[i] = sv / piv[i];
-                    }
-#pragma unroll
-                    for (int i = NU - 1; i >= 0; --i) {  // L^T x = y
-                        double sv = y[i];
-#pragma unroll
-                        for (int m = i + 1; m < NU; ++m) sv -= H[(nx + m) * n + nx + i] * y[m];
-                        sv /= piv[i];
-                        y[i] = sv;
-                        K[i * nk + c] = sv;
-                        gains[static_cast<long long>(k) * nu * nk + i * nk + c] = sv;
-                    }
-                } else {
-                    for (int i = 0; i < nu; ++i) {  // L y = rhs
-                        double sv = c < nx ? -H[(nx + i) * n + c] : -h[nx + i];
-                        for (int m = 0; m < i; ++m) sv -= H[(nx + i) * n + nx + m] * K[m * nk + c];
-                        K[i * nk + c] = sv / piv[i];
-                    }
-                    for (int i = nu - 1; i >= 0; --i) {  // L^T x = y
-                        double sv = K[i * nk + c];
-                        for (int m = i + 1; m < nu; ++m) sv -= H[(nx + m) * n + nx + i] * K[m * nk + c];
-                        sv /= piv[i];
-                        K[i * nk + c] = sv;
-                        gains[static_cast<long long>(k) * nu * nk + i * nk + c] = sv;
-                    }
-                }
+            ex.ForEach(nu * nk, [&](int idx) {
+                const int i = idx / nk;
+                const double di = H[(nx + i) * n + nx + i];
+                K[idx] /= (di > 0.0 ? di : 1.0);
             });
+            for (int j = nu - 1; j > 0; --j) {
+                ex.ForEach(j * nk, [&](int idx) {
+                    const int i = idx / nk, c = idx % nk;
+                    const double di = H[(nx + i) * n + nx + i];
+                    K[i * nk + c] -= H[(nx + j) * n + nx + i] / (di > 0.0 ? di : 1.0) * K[j * nk + c];
+                });
+            }
+            ex.ForEachNoSync(nu * nk, [&](int idx) { gains[static_cast<long long>(k) * nu * nk + idx] = K[idx]; });
         }
         // P <- H_xx + H_ux^T K (symmetrised),  p <- h_x + H_ux^T kff   (into the other buffer, then the buffers swap roles)
         ex.ForEach(nx * nx + nx, [&](int idx) {

@@ -45,6 +45,10 @@ def default_params(name: str) -> np.ndarray:
         return np.array([1.0 / 30.0, 25.0, 0.048125, 0.093125, 0.055625, 9.80665])
     if name == "anymal":  # dt = 1 / N of BASELINE config 4
         return np.array([1.0 / 20.0])
+    if name == "srbd_ineq":  # example/mpc/quadruped.example.cpp:384-392: friction coefficient, four hip offsets, maximum leg extension
+        return np.array([0.7, 0.2, 0.15, -0.1, 0.2, -0.15, -0.1, -0.2, 0.15, -0.1, -0.2, -0.15, -0.1, 0.42])
+    if name == "quadrotor_ineq":  # maximum rotor speed: twice the hover speed (example/mpc/quadrotor.example.cpp:356-358)
+        return np.array([2.0 * np.sqrt(1.5 * 9.80665 / (4 * 0.015))])
     raise KeyError(name)
 
 
