@@ -123,41 +123,41 @@ __device__ __forceinline__ double BarrierD2(const BarrierParams& p, double z) {
 /// then the lanes share the (nx+nu)^2 entries of the block.  (A first version walked the knots of an instance in sequence and
 /// re-read the Jacobian from global memory for every entry: 0.73 ms per 4096 x 30 quadrotor knots -- as long as the Riccati
 /// solve; this one is bound by writing the blocks.)
-__global__ __launch_bounds__(kBlock) void StageQpKernel(const StageQpArgs a) {
+__global__ __launch_bounds__(256) void StageQpKernel(const StageQpArgs a) {
     extern __shared__ double lds[];  // [nh][n] inequality Jacobian, d1[nh], d2[nh], then the dense cost Hessian block [n][n]
     const long long node = blockIdx.x;
     const long long b = node / a.N;
     const int k = static_cast<int>(node - b * a.N);
     if (b >= a.batch) return;
-    const int lane = static_cast<int>(threadIdx.x), n = a.nx + a.nu;
+    const int lane = static_cast<int>(threadIdx.x), n = a.nx + a.nu, lanes = static_cast<int>(blockDim.x);  // 64 lanes for small stages, 256 from n = 32 on
     double* jh = lds;
     double* d1 = lds + a.nh * n;
     double* d2 = d1 + a.nh;
     double* hc = d2 + a.nh;
     const bool ineq = a.h.base != nullptr;
-    for (int idx = lane; idx < n * n; idx += kBlock) hc[idx] = 0.0;
+    for (int idx = lane; idx < n * n; idx += lanes) hc[idx] = 0.0;
     __syncthreads();
-    for (int e = lane; e < a.hesNnz; e += kBlock) hc[a.hesRow[e] * n + a.hesCol[e]] = a.costHes.at(b, k, e);  // distinct (row, col) per entry
+    for (int e = lane; e < a.hesNnz; e += lanes) hc[a.hesRow[e] * n + a.hesCol[e]] = a.costHes.at(b, k, e);  // distinct (row, col) per entry
     if (k == 0)
-        for (int i = lane; i < a.nx; i += kBlock) a.dx0.at(b, 0, i) = a.xm.at(b, 0, i) - a.X.at(b, 0, i);
-    for (int i = lane; i < a.nx; i += kBlock) a.b.at(b, k, i) = a.f.at(b, k, i) - a.X.at(b, k + 1, i);
+        for (int i = lane; i < a.nx; i += lanes) a.dx0.at(b, 0, i) = a.xm.at(b, 0, i) - a.X.at(b, 0, i);
+    for (int i = lane; i < a.nx; i += lanes) a.b.at(b, k, i) = a.f.at(b, k, i) - a.X.at(b, k + 1, i);
     if (ineq) {
-        for (int idx = lane; idx < a.nh * n; idx += kBlock) jh[idx] = a.hJac.at(b, k, idx);
-        for (int j = lane; j < a.nh; j += kBlock) {
+        for (int idx = lane; idx < a.nh * n; idx += lanes) jh[idx] = a.hJac.at(b, k, idx);
+        for (int j = lane; j < a.nh; j += lanes) {
             const double z = -a.h.at(b, k, j);
             d1[j] = BarrierD1(a.barrier, z);
             d2[j] = BarrierD2(a.barrier, z);
         }
     }
     __syncthreads();
-    for (int idx = lane; idx < n * n; idx += kBlock) {
+    for (int idx = lane; idx < n * n; idx += lanes) {
         const int r = idx / n, c = idx % n;
         double acc = hc[idx];
         if (r <= c && ineq)
             for (int j = 0; j < a.nh; ++j) acc += d2[j] * jh[j * n + r] * jh[j * n + c];
         a.hess.at(b, k, idx) = acc;
     }
-    for (int c = lane; c < n; c += kBlock) {
+    for (int c = lane; c < n; c += lanes) {
         double acc = a.costGrad.at(b, k, c);
         if (ineq)
             for (int j = 0; j < a.nh; ++j) acc -= d1[j] * jh[j * n + c];  // d/dz b(-h) = -b'(-h) dh/dz
@@ -331,7 +331,7 @@ extern "C" int ungar_amd_launch_ocp_stage_qp(const StageQpArgs* a, void* stream)
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(StageQpKernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
         if (e != hipSuccess) return static_cast<int>(e);
     }
-    hipLaunchKernelGGL(StageQpKernel, dim3(static_cast<unsigned>(a->batch * a->N)), dim3(kBlock), lds, static_cast<hipStream_t>(stream), *a);
+    hipLaunchKernelGGL(StageQpKernel, dim3(static_cast<unsigned>(a->batch * a->N)), dim3(n >= 32 ? 256 : kBlock), lds, static_cast<hipStream_t>(stream), *a);
     return static_cast<int>(hipGetLastError());
 }
 
