@@ -307,40 +307,38 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
                 const int i = idx / nk, c = idx % nk;
                 K[idx] = c < nx ? -H[(nx + i) * n + c] : -h[nx + i];
             });
-            for (int j = 0; j < nu; ++j) {
-                const int rest = nu - 1 - j, pairs = rest * (rest + 1) / 2;
-                ex.ForEach(pairs + rest * nk + 1, [&](int idx) {
+            // The reciprocal of a pivot is computed once (piv) and multiplied with afterwards.
+            auto forwardColumn = [&](int j) {
+                const int rest = nu - 1 - j;
+                const float restInv = rest > 0 ? 1.0f / static_cast<float>(rest) : 0.0f;
+                ex.ForEach(rest * rest + rest * nk + 1, [&](int idx) {
                     const double dj = H[(nx + j) * n + nx + j];
                     const bool bad = !(dj > 0.0);
                     const double rd = 1.0 / (bad ? 1.0 : dj);
-                    if (idx < pairs) {  // trailing block: entries (i, k2) with j < k2 <= i, unranked row by row of the triangle
-                        int q = 0, left = idx;
-                        while (left > q) {
-                            left -= q + 1;
-                            ++q;
-                        }
-                        const int i = j + 1 + q, k2 = j + 1 + left;
-                        H[(nx + i) * n + nx + k2] -= H[(nx + i) * n + nx + j] * H[(nx + k2) * n + nx + j] * rd;
-                    } else if (idx < pairs + rest * nk) {
-                        const int e = idx - pairs, i = j + 1 + e / nk, c = e % nk;
+                    if (idx < rest * rest) {  // trailing block, entries (i, k2) with j < k2 <= i (the square index space is cheaper to decode than the triangle)
+                        // quotient by the run-time `rest` through a float reciprocal: exact here (idx + 0.5 is never a multiple of rest, the
+                        // operands are far below 2^20), and an integer division costs ~30 instructions per item
+                        const int qi = static_cast<int>((static_cast<float>(idx) + 0.5f) * restInv);
+                        const int i = j + 1 + qi, k2 = j + 1 + (idx - qi * rest);
+                        if (k2 <= i) H[(nx + i) * n + nx + k2] -= H[(nx + i) * n + nx + j] * H[(nx + k2) * n + nx + j] * rd;
+                    } else if (idx < rest * rest + rest * nk) {
+                        const int e = idx - rest * rest, i = j + 1 + e / nk, c = e % nk;
                         K[i * nk + c] -= H[(nx + i) * n + nx + j] * rd * K[j * nk + c];
-                    } else if (bad) {
-                        failed = failed ? failed : k + 1;
+                    } else {
+                        piv[j] = rd;
+                        if (bad) failed = failed ? failed : k + 1;
                     }
                 });
-            }
-            ex.ForEach(nu * nk, [&](int idx) {
-                const int i = idx / nk;
-                const double di = H[(nx + i) * n + nx + i];
-                K[idx] /= (di > 0.0 ? di : 1.0);
-            });
-            for (int j = nu - 1; j > 0; --j) {
+            };
+            auto backwardColumn = [&](int j) {
                 ex.ForEach(j * nk, [&](int idx) {
                     const int i = idx / nk, c = idx % nk;
-                    const double di = H[(nx + i) * n + nx + i];
-                    K[i * nk + c] -= H[(nx + j) * n + nx + i] / (di > 0.0 ? di : 1.0) * K[j * nk + c];
+                    K[i * nk + c] -= H[(nx + j) * n + nx + i] * piv[i] * K[j * nk + c];
                 });
-            }
+            };
+            for (int j = 0; j < nu; ++j) forwardColumn(j);  // (not unrolled: 47 unrolled phase bodies cost the third wavefront per SIMD)
+            ex.ForEach(nu * nk, [&](int idx) { K[idx] *= piv[idx / nk]; });
+            for (int j = nu - 1; j > 0; --j) backwardColumn(j);
             ex.ForEachNoSync(nu * nk, [&](int idx) { gains[static_cast<long long>(k) * nu * nk + idx] = K[idx]; });
         }
         // P <- H_xx + H_ux^T K (symmetrised),  p <- h_x + H_ux^T kff   (into the other buffer, then the buffers swap roles)
