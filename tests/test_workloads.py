@@ -14,6 +14,8 @@ def test_dims_and_parameters_match_the_oracle():
         assert tuple(O.DIMS[name]) == dims
         np.testing.assert_array_equal(W.default_params(name), O.default_params(name))
         assert len(W.default_params(name)) == dims[3]
+    for name in ("srbd_ineq", "quadrotor_ineq"):  # parameter blocks of the inequality nodes used by the SQP benches
+        np.testing.assert_allclose(W.default_params(name), O.default_params(name), rtol=1e-15)
 
 
 def test_algorithmic_bytes_are_the_survey_figures():
