@@ -117,7 +117,7 @@ def build_library(jobs: int | None = None):
     # the two comparison kernels (taped ABA / structured, lane per node: 40-60 k statements in one basic block)
     # spend > 90 % of their compile time in the machine schedulers; without them the from-scratch build drops
     # from 12.7 to ~6 minutes.  The product kernels keep the full pipeline.
-    fast = ("model_anymal_ad.hip", "model_anymal_reg.hip", "model_anymal_rnea.hip", "model_anymal_centroidal.hip")  # the last two: 12-23 k statements, not hot
+    fast = ("model_anymal_ad.hip", "model_anymal_reg.hip")
     no_sched = ["-mllvm", "-enable-misched=false", "-mllvm", "-enable-post-misched=false"]
 
     # identity of the tape engine (recorder, derivative transforms, emitters, run-time factory): part of the key of

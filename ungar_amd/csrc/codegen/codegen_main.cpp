@@ -31,6 +31,10 @@ struct NodeSpec {
     models::NodeDims dims;
     std::function<void(const AD*, const AD*, const AD*, const AD*, AD*)> fn;
     bool valueOnly = false;  // no Jacobian program (ungar_model_has_sparse_jacobian() == 0)
+    int phasedLdsSlots = 0;  // > 0: additionally emit the phased body with this many per-lane LDS home slots
+    int jacMode = 0;         // 0 = fewer statements decides; 1 = forward, 2 = reverse accumulation
+    // The three settings above were measured per model on MI355X (tools/run_rbd_variants.sh, profiles/r02k_rbd_variants.log):
+    // phases are Jacobian columns for forward programs and Jacobian rows (one adjoint sweep each) for reverse ones.
 };
 
 struct Generated {
@@ -221,7 +225,8 @@ std::string HipPrologue(const models::NodeDims& d, const std::vector<char>& used
     return os.str();
 }
 
-void EmitHip(const Generated& g, const std::string& dir, bool columnMajorEmission = false, int ldsSlots = 0, int rematConsumers = 2, int rematDepth = 3, int prefetch = 48) {
+void EmitHip(const Generated& g, const std::string& dir, bool columnMajorEmission = false, int ldsSlots = 0, int rematConsumers = 2, int rematDepth = 3, int prefetch = 48,
+             bool phaseByRow = false) {
     const auto& d = g.dims;
     const std::string name = d.name;
     std::ostringstream os;
@@ -309,10 +314,16 @@ void EmitHip(const Generated& g, const std::string& dir, bool columnMajorEmissio
         } else {
             for (int c = 0; c < g.jac.cols; ++c) colOrder.push_back(c);
         }
+        // Reverse-accumulated programs (one adjoint sweep per output row) are cut by ROW instead: the primal
+        // values every sweep reads are the cross-phase set that gets the LDS home.
+        if (phaseByRow) {
+            colOrder.clear();
+            for (int r = 0; r < g.jac.rows; ++r) colOrder.push_back(r);
+        }
         for (int c : colOrder) {
             std::vector<tape::OutputSlot> ph;
             for (std::size_t k = 0; k < g.jac.Nnz(); ++k)
-                if (g.jac.col[k] == c)
+                if ((phaseByRow ? g.jac.row[k] : g.jac.col[k]) == c)
                     ph.push_back({g.jac.value[k],
                                   "io.j(" + std::to_string(k) + ", " + std::to_string(g.jac.row[k]) + ", " + std::to_string(g.jac.col[k]) + ", %s);"});
             if (!ph.empty()) phases.push_back(std::move(ph));
@@ -434,6 +445,7 @@ int main(int argc, char** argv) {
     bool quadPrefetchAcross = false;  // ... and may cross into the tail of the previous phase
     int quadUniformSlots = 80;  // compact (one copy per quad) LDS slots; budget: quadLdsSlots + quadUniformSlots / 4 <= 80
     int quadLdsSlots = 60;  // 64-lane workgroups, four per CU: 160 KiB / 4 / 64 lanes / 8 B
+    int rbdLdsSlots = -1;  // >= 0 overrides the per-lane LDS home of the phased rigid-body quantity Jacobians (0 = plain bodies only)
     std::vector<std::string> only;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
@@ -458,6 +470,7 @@ int main(int argc, char** argv) {
             quadRematConsumers = std::atoi(argv[++i]);
             quadRematDepth = std::atoi(argv[++i]);
         }
+        else if (a == "--rbd-lds-slots" && i + 1 < argc) rbdLdsSlots = std::atoi(argv[++i]);
         else if (a == "--model" && i + 1 < argc) only.push_back(argv[++i]);
         else {
             std::fprintf(stderr, "usage: %s --out DIR [--c-oracle DIR] [--anymal-robot FILE] [--jac-mode 0|1|2] [--model NAME]...\n", argv[0]);
@@ -489,11 +502,11 @@ int main(int argc, char** argv) {
                              models::FloatingBaseNode<AD>(anymal, x, u, w, p, xn);
                          }});
         // rigid-body quantities as node models
-        specs.push_back({models::kAnymalRneaDims, [&anymal](const AD* x, const AD* u, const AD*, const AD*, AD* y) { models::JointTorquesNode<AD>(anymal, x, u, y); }});
-        specs.push_back({models::kAnymalCrbaDims, [&anymal](const AD* x, const AD*, const AD*, const AD*, AD* y) { models::InertiaMatrixNode<AD>(anymal, x, y); }});
+        specs.push_back({models::kAnymalRneaDims, [&anymal](const AD* x, const AD* u, const AD*, const AD*, AD* y) { models::JointTorquesNode<AD>(anymal, x, u, y); }, false, 160, 1});
+        specs.push_back({models::kAnymalCrbaDims, [&anymal](const AD* x, const AD*, const AD*, const AD*, AD* y) { models::InertiaMatrixNode<AD>(anymal, x, y); }, false, 320, 1});
         specs.push_back({models::kAnymalMinvDims, [&anymal](const AD* x, const AD*, const AD*, const AD*, AD* y) { models::InertiaInverseNode<AD>(anymal, x, y); }, true});
         specs.push_back({models::kAnymalFeetDims, [&anymal](const AD* x, const AD*, const AD*, const AD*, AD* y) { models::FootFramesNode<AD>(anymal, x, y); }});
-        specs.push_back({models::kAnymalCentroidalDims, [&anymal](const AD* x, const AD*, const AD*, const AD*, AD* y) { models::CentroidalMomentumNode<AD>(anymal, x, y); }});
+        specs.push_back({models::kAnymalCentroidalDims, [&anymal](const AD* x, const AD*, const AD*, const AD*, AD* y) { models::CentroidalMomentumNode<AD>(anymal, x, y); }, false, 160, 2});
     }
     auto wanted = [&](const char* nm) {
         if (only.empty()) return true;
@@ -572,8 +585,9 @@ int main(int argc, char** argv) {
             for (const auto& o : only) keep = keep || o == s.dims.name;
             if (!keep) continue;
         }
-        const Generated g = Record(s, jacMode);
-        EmitHip(g, outDir);
+        const Generated g = Record(s, jacMode ? jacMode : s.jacMode);
+        const int slots = rbdLdsSlots >= 0 && s.phasedLdsSlots > 0 ? rbdLdsSlots : s.phasedLdsSlots;
+        EmitHip(g, outDir, false, slots, slots > 0 ? 4 : rematConsumers, slots > 0 ? 4 : rematDepth, prefetch, g.jacMode == 2);
         if (!cDir.empty()) EmitC(g, cDir);
     }
     // scalar stage-cost nodes (value + gradient + upper Hessian)

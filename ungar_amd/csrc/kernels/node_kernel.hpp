@@ -301,8 +301,12 @@ __global__ __launch_bounds__(BLOCK) void NodeKernelPhased(const NodeLaunch a) {
          a.p.base + b * a.p.bs + k * a.p.ks, a.f.base ? a.f.base + b * a.f.bs + k * a.f.ks : nullptr,
          a.jac.base + b * a.jac.bs + k * a.jac.ks, a.x.es, a.u.es, a.w.es, a.p.es, a.f.es, a.jac.es},
         lds + threadIdx.x};
-    if constexpr (MODE == kModeDenseJacobian)
-        detail::StoreZeros<M, false>(io.jb, io.je, std::make_index_sequence<M::kJacRows * M::kJacCols - M::kJacNnz>{});
+    if constexpr (MODE == kModeDenseJacobian) {
+        if constexpr (M::kJacRows * M::kJacCols - M::kJacNnz <= detail::kMaxUnrolledZeros)
+            detail::StoreZeros<M, false>(io.jb, io.je, std::make_index_sequence<M::kJacRows * M::kJacCols - M::kJacNnz>{});
+        else
+            detail::StoreZerosFromTable<M, false>(io.jb, io.je);
+    }
     M::ValueJacobianPhased(io);
 }
 
