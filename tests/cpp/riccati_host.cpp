@@ -12,6 +12,7 @@ template <bool PREFETCH>
 struct HostExec {
     static constexpr bool kPrefetch = PREFETCH;
     static constexpr bool kAhead = true;
+    static constexpr int kLanes = 64;
     using StageAB = std::vector<double>;
     using StageW = std::vector<double>;
     using StageV = std::vector<double>;
@@ -33,6 +34,41 @@ struct HostExec {
     void Commit(int n, const std::vector<double>& s, double* dst) {
         for (int i = 0; i < n; ++i) dst[i] = s[static_cast<std::size_t>(i)];
     }
+};
+
+/// The asynchronous-copy protocol of the device policy (kDma), sequentially: a copy lands either AT ONCE (a destination that is
+/// still live is clobbered as early as possible) or only when its owner WAITS for it (a destination read before the wait still holds
+/// the old data) -- the recursion must produce the same bits under both schedules.
+template <bool DEFERRED>
+struct HostDmaExec : HostExec<false> {
+    static constexpr bool kDma = true;
+    static constexpr int kDmaOwners = 3, kLanes = 256;  // the work-item mapping of the four-wavefront kernels
+    struct Copy {
+        const double* from;
+        double* to;
+    };
+    std::vector<Copy> pending[kDmaOwners + 1];  // [0]: the all-hands copies
+    template <class F>
+    void Issue(std::vector<Copy>& q, int n, F addr, double* dst) {
+        for (int i = 0; i < n; ++i) {
+            if (DEFERRED) q.push_back({addr(i), dst + i});
+            else dst[i] = *addr(i);
+        }
+    }
+    static void Land(std::vector<Copy>& q) {
+        for (const Copy& c : q) *c.to = *c.from;
+        q.clear();
+    }
+    template <class F>
+    void DmaFetch(int n, F addr, double* dst) {
+        Issue(pending[0], n, addr, dst);
+    }
+    void DmaWait() { Land(pending[0]); }
+    template <class F>
+    void DmaFetchOne(int owner, int n, F addr, double* dst) {
+        Issue(pending[1 + owner % kDmaOwners], n, addr, dst);
+    }
+    void DmaWaitOne(int owner) { Land(pending[1 + owner % kDmaOwners]); }
 };
 }  // namespace
 
@@ -70,6 +106,18 @@ extern "C" int riccati_host_solve_variant(int prefetch, int nx, int nu, int N, l
             else if (nx == 13 && nu == 24) RiccatiInstance<HostExec<false>, 13, 24>(a, i, scratch.data(), ex);
             else return 1;
         }
+    } else if (prefetch == 3 || prefetch == 4) {  // compile-time sizes with the asynchronous-copy protocol (3: copies land at once, 4: at the wait)
+        auto run = [&](auto ex) {
+            using E = decltype(ex);
+            for (long long i = 0; i < batch; ++i) {
+                if (nx == 13 && nu == 4) RiccatiInstance<E, 13, 4>(a, i, scratch.data(), ex);
+                else if (nx == 37 && nu == 12) RiccatiInstance<E, 37, 12>(a, i, scratch.data(), ex);
+                else if (nx == 13 && nu == 24) RiccatiInstance<E, 13, 24>(a, i, scratch.data(), ex);
+                else return 1;
+            }
+            return 0;
+        };
+        return prefetch == 3 ? run(HostDmaExec<false>{}) : run(HostDmaExec<true>{});
     } else if (prefetch) {
         HostExec<true> ex;
         for (long long i = 0; i < batch; ++i) RiccatiInstance(a, i, scratch.data(), ex);

@@ -158,6 +158,28 @@ def test_fixed_size_instantiation_matches_the_generic_recursion(host, nx, nu):
     assert st[0] == 0 and st[1] == 0 and st[2] == 6
 
 
+@pytest.mark.parametrize("nx,nu", [(13, 4), (37, 12), (13, 24)])
+def test_asynchronous_operand_copies_do_not_change_a_bit(host, nx, nu):
+    """The four-wavefront device kernels request a knot's operands by LDS-DMA the moment their destination dies in the previous knot
+    (the stage Hessian parked, folded, in the retired cost-to-go buffer) and run the forward pass three knots ahead.  Sequential
+    stand-in for that protocol: copies that land at once and copies that land only when waited for must both reproduce the bits of
+    the plain fixed-size recursion -- a destination that is still live, or read before its wait, would show."""
+    rng = np.random.default_rng(33)
+    N = 11
+    q = random_qp(rng, nx, nu, N, 3)
+    dp = ctypes.POINTER(ctypes.c_double)
+    p = lambda a: a.ctypes.data_as(dp)  # noqa: E731
+    out = []
+    for variant in (2, 3, 4):
+        dX, dU, st = np.full((3, N + 1, nx), np.nan), np.full((3, N, nu), np.nan), np.zeros(3, dtype=np.int32)
+        rc = host.riccati_host_solve_variant(variant, nx, nu, N, ctypes.c_longlong(3), p(q["AB"]), p(q["b"]), p(q["W"]), p(q["w"]), p(q["WN"]), p(q["wN"]), p(q["dx0"]),
+                                             ctypes.c_double(1e-6), p(dX), p(dU), st.ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
+        assert rc == 0 and (st == 0).all()
+        out.append((dX, dU))
+    for dX, dU in out[1:]:
+        assert np.array_equal(out[0][0], dX) and np.array_equal(out[0][1], dU)
+
+
 def test_riccati_reports_an_indefinite_reduced_hessian(host):
     rng = np.random.default_rng(1)
     q = random_qp(rng, 4, 2, 6, 2)

@@ -18,10 +18,15 @@ constexpr int kBlock = 64;
 
 /// Lanes of the workgroup stride over the index range and meet at a barrier.  SLOTS_AB / SLOTS_W: registers per lane that
 /// stage the next knot's [A|B] block and stage Hessian (64 * SLOTS doubles each); 0 = read the operands in place.
-template <int BLOCK, int SLOTS_AB, int SLOTS_W, bool AHEAD = true>
+/// DMA: operands are copied global -> LDS by the LDS-DMA path (global_load_lds_dword; no registers, nothing waits until DmaWait).
+template <int BLOCK, int SLOTS_AB, int SLOTS_W, bool AHEAD = true, bool DMA = false>
 struct DeviceExec {
     static constexpr bool kPrefetch = SLOTS_AB > 0;
     static constexpr bool kAhead = AHEAD;
+    static constexpr bool kDma = DMA;
+    static constexpr int kLanes = BLOCK;
+    static constexpr int kWaves = BLOCK / 64, kDmaOwners = kWaves > 1 ? kWaves - 1 : 1;
+    static_assert(!DMA || (kWaves > 1 && SLOTS_AB == 0), "the copies are owned by the wavefronts beyond the first; no register staging with them");
     template <int K>
     struct Stage {
         double r[K > 0 ? K : 1];
@@ -67,15 +72,68 @@ struct DeviceExec {
         }
     }
     __device__ __forceinline__ void Barrier() { LdsBarrier(); }
+
+    /// dst[i] <- *addr(i), i < n, 32 doubles per instruction: lane l moves dword l & 1 of element 32 c + l / 2 of chunk c (any element
+    /// stride, 8-byte alignment); the LDS side of a copy is (wave-uniform base) + 4 l.  Chunks firstChunk, firstChunk + step, ...
+    template <class F>
+    static __device__ __forceinline__ void DmaIssue(int n, F addr, double* dst, int firstChunk, int step) {
+        const int lane = static_cast<int>(threadIdx.x) & 63, chunks = (n + 31) >> 5;
+        for (int c = firstChunk; c < chunks; c += step) {
+            const int e = (c << 5) + (lane >> 1);
+            if (e < n)
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const unsigned*>(addr(e)) + (lane & 1), (__attribute__((address_space(3))) void*)(dst + (c << 5)), 4, 0, 0);
+        }
+    }
+    static __device__ __forceinline__ int Wave() { return __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6); }
+    template <class F>
+    __device__ __forceinline__ void DmaFetch(int n, F addr, double* dst) {
+        DmaIssue(n, addr, dst, Wave(), kWaves);
+    }
+    __device__ __forceinline__ void DmaWait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    template <class F>
+    __device__ __forceinline__ void DmaFetchOne(int owner, int n, F addr, double* dst) {
+        if (Wave() == 1 + owner % kDmaOwners) DmaIssue(n, addr, dst, 0, 1);
+    }
+    __device__ __forceinline__ void DmaWaitOne(int owner) {
+        if (Wave() == 1 + owner % kDmaOwners) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+#ifdef UNGAR_RICCATI_CLOCKS
+    /// Diagnostic build: cycles of the first workgroup's first lane between consecutive marks, summed per mark id
+    /// (read back with ungar_amd_debug_riccati_clocks; tools/bench_riccati_phases.py).
+    unsigned long long last = 0;
+    __device__ __forceinline__ void Mark(int id);
+#endif
 };
 
-template <int BLOCK, int SLOTS_AB, int SLOTS_W, int NX = 0, int NU = 0, bool AHEAD = true>
-__global__ __launch_bounds__(BLOCK) void RiccatiKernel(const RiccatiArgs a) {
+#ifdef UNGAR_RICCATI_CLOCKS
+__device__ unsigned long long gRiccatiClocks[8];
+template <int BLOCK, int SLOTS_AB, int SLOTS_W, bool AHEAD, bool DMA>
+__device__ __forceinline__ void DeviceExec<BLOCK, SLOTS_AB, SLOTS_W, AHEAD, DMA>::Mark(int id) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const unsigned long long now = __builtin_amdgcn_s_memtime();
+        if (id > 0) gRiccatiClocks[id] += now - last;
+        last = now;
+    }
+}
+#endif
+
+/// Wavefronts per SIMD the register allocation has to leave room for: what the LDS footprint of the instantiation admits anyway
+/// (37 + 12: two workgroups of four wavefronts per CU; 13 + 4 on one wavefront: four).  Without the bound the allocator takes a
+/// few registers more than the next occupancy step allows (131 of 128, 256 + AGPRs of 256) for no measurable gain per wavefront.
+template <int BLOCK, int NX, int NU>
+#ifdef UNGAR_RICCATI_NO_OCCUPANCY_BOUND
+inline constexpr int kRiccatiWavesPerSimd = 1;
+#else
+inline constexpr int kRiccatiWavesPerSimd = (NX == 37 && NU == 12) ? 2 : (NX == 13 && NU == 4 && BLOCK == 64) ? 4 : 1;
+#endif
+
+template <int BLOCK, int SLOTS_AB, int SLOTS_W, int NX = 0, int NU = 0, bool AHEAD = true, bool DMA = false>
+__global__ __launch_bounds__(BLOCK, (kRiccatiWavesPerSimd<BLOCK, NX, NU>)) void RiccatiKernel(const RiccatiArgs a) {
     extern __shared__ double scratch[];
     const long long inst = blockIdx.x;
     if (inst >= a.batch) return;
-    DeviceExec<BLOCK, SLOTS_AB, SLOTS_W, AHEAD> ex;
-    RiccatiInstance<DeviceExec<BLOCK, SLOTS_AB, SLOTS_W, AHEAD>, NX, NU>(a, inst, scratch, ex);
+    DeviceExec<BLOCK, SLOTS_AB, SLOTS_W, AHEAD, DMA> ex;
+    RiccatiInstance<DeviceExec<BLOCK, SLOTS_AB, SLOTS_W, AHEAD, DMA>, NX, NU>(a, inst, scratch, ex);
 }
 
 /// Wavefront sum (64 lanes), result in every lane.
@@ -263,14 +321,14 @@ __global__ __launch_bounds__(kBlock) void AcceptKernel(const AcceptArgs a) {
 using namespace ungar_amd::kernels;
 
 namespace {
-template <int BLOCK, int SLOTS_AB, int SLOTS_W, int NX = 0, int NU = 0, bool AHEAD = true>
+template <int BLOCK, int SLOTS_AB, int SLOTS_W, int NX = 0, int NU = 0, bool AHEAD = true, bool DMA = false>
 int LaunchRiccati(const RiccatiArgs* a, std::size_t lds, hipStream_t stream) {
     if (lds > 64 * 1024) {  // above the default dynamic-LDS limit the kernel has to opt in (160 KiB per CU on gfx950)
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(RiccatiKernel<BLOCK, SLOTS_AB, SLOTS_W, NX, NU, AHEAD>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(RiccatiKernel<BLOCK, SLOTS_AB, SLOTS_W, NX, NU, AHEAD, DMA>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                  static_cast<int>(lds));
         if (e != hipSuccess) return static_cast<int>(e);
     }
-    hipLaunchKernelGGL((RiccatiKernel<BLOCK, SLOTS_AB, SLOTS_W, NX, NU, AHEAD>), dim3(static_cast<unsigned>(a->batch)), dim3(BLOCK), lds, stream, *a);
+    hipLaunchKernelGGL((RiccatiKernel<BLOCK, SLOTS_AB, SLOTS_W, NX, NU, AHEAD, DMA>), dim3(static_cast<unsigned>(a->batch)), dim3(BLOCK), lds, stream, *a);
     return static_cast<int>(hipGetLastError());
 }
 }  // namespace
@@ -295,17 +353,22 @@ extern "C" int ungar_amd_launch_riccati(const RiccatiArgs* a, void* stream) {
         if (a->nx == 13 && a->nu == 24) return LaunchRiccati<256, 2, 6, 13, 24>(a, lds, s);
         if (a->nx == 37 && a->nu == 12) return LaunchRiccati<256, 8, 10, 37, 12>(a, lds, s);
     }
-    if (variant == "fixed" || variant == "fixeds" || variant == "fixed1" || variant == "fixedp" || variant == "64") {
+    if (variant == "fixed" || variant == "fixeds" || variant == "fixed1" || variant == "fixedp" || variant == "fixedn" || variant == "64") {
         // small blocks: the next knot's operands are staged in registers while this knot is processed (quadrotor QP step 1.03 -> 0.92 ms;
         // for the 37 + 12 block the staging registers cost more than the hidden latency: 8.9 -> 9.7 ms)
-        if (variant == "fixed" && a->nx == 13 && a->nu == 4) return LaunchRiccati<64, 4, 5, 13, 4>(a, lds, s);
-        if (variant == "fixed" && a->nx == 6 && a->nu == 2) return LaunchRiccati<64, 1, 1, 6, 2>(a, lds, s);
+        if ((variant == "fixed" || variant == "fixedn") && a->nx == 13 && a->nu == 4) return LaunchRiccati<64, 4, 5, 13, 4>(a, lds, s);
+        if ((variant == "fixed" || variant == "fixedn") && a->nx == 6 && a->nu == 2) return LaunchRiccati<64, 1, 1, 6, 2>(a, lds, s);
         if (variant == "fixed1" && a->nx == 13 && a->nu == 4) return LaunchRiccati<64, 0, 0, 13, 4>(a, lds, s);
         if (variant == "fixed1" && a->nx == 6 && a->nu == 2) return LaunchRiccati<64, 0, 0, 6, 2>(a, lds, s);
         // the two large blocks fit only 2-4 instances per CU by their LDS (74 / 30 KB): four wavefronts per instance keep the SIMDs busy
         // (full-body quadruped, 4096 instances x N = 20: QP step 20.7 ms with one wavefront per instance, 14.0 generic x 4 wavefronts)
-        if (variant == "fixed" && a->nx == 13 && a->nu == 24) return LaunchRiccati<256, 0, 0, 13, 24>(a, lds, s);
-        if (variant == "fixed" && a->nx == 37 && a->nu == 12) return LaunchRiccati<256, 0, 0, 37, 12>(a, lds, s);
+        // ... and get their operands by LDS-DMA one knot ahead, the forward pass three knots ahead (no registers held: the staging
+        // registers of "fixeds" cost the second workgroup per CU).  QP step, 4096 instances: 6.74 -> 5.81 ms (37 + 12), 5.47 -> 5.31 ms (13 + 24);
+        // "fixedn" = the same kernels reading their operands in place at the top of every knot
+        if (variant == "fixed" && a->nx == 13 && a->nu == 24) return LaunchRiccati<256, 0, 0, 13, 24, true, true>(a, lds, s);
+        if (variant == "fixed" && a->nx == 37 && a->nu == 12) return LaunchRiccati<256, 0, 0, 37, 12, true, true>(a, lds, s);
+        if (variant == "fixedn" && a->nx == 13 && a->nu == 24) return LaunchRiccati<256, 0, 0, 13, 24>(a, lds, s);
+        if (variant == "fixedn" && a->nx == 37 && a->nu == 12) return LaunchRiccati<256, 0, 0, 37, 12>(a, lds, s);
         // "fixeds": each knot's operands staged in registers at its top (17 loads per lane back to back instead of one latency each): the
         // recursion itself gets 1.5x faster per instance, but the 40 staging registers push the kernel past 256 -> one workgroup per CU: slower overall
         if (variant == "fixeds" && a->nx == 37 && a->nu == 12) return LaunchRiccati<256, 8, 10, 37, 12, false>(a, lds, s);
@@ -359,3 +422,13 @@ extern "C" int ungar_amd_launch_ocp_accept(const AcceptArgs* a, void* stream) {
     hipLaunchKernelGGL(AcceptKernel, dim3(static_cast<unsigned>(a->batch)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), *a);
     return static_cast<int>(hipGetLastError());
 }
+
+#ifdef UNGAR_RICCATI_CLOCKS
+/// Diagnostic builds only (tools/make_riccati_clocks.sh): copies and clears the phase clocks of DeviceExec::Mark.
+extern "C" int ungar_amd_debug_riccati_clocks(unsigned long long* out) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(ungar_amd::kernels::gRiccatiClocks), 8 * sizeof(unsigned long long));
+    if (e != hipSuccess) return static_cast<int>(e);
+    const unsigned long long zero[8] = {};
+    return static_cast<int>(hipMemcpyToSymbol(HIP_SYMBOL(ungar_amd::kernels::gRiccatiClocks), zero, sizeof zero));
+}
+#endif

@@ -27,6 +27,12 @@
 //   Stage<SLOTS>             per-lane registers for a strided global read of up to 64 * SLOTS doubles
 //   Fetch(n, f, stage)       issues the loads stage <- f(i); no barrier, nothing waits for the data
 //   Commit(n, stage, dst)    dst[i] <- stage (no barrier);  Barrier() synchronises the scratch memory
+//   kDma (optional)          the policy copies global memory into the scratch memory asynchronously, without registers:
+//     DmaFetch(n, addr, dst)        every lane group takes part: dst[i] <- *addr(i), i < n; returns at once, nothing waits
+//     DmaWait()                     this lane group's copies have landed (a Barrier() then publishes them to the workgroup)
+//     kDmaOwners, DmaFetchOne(o, n, addr, dst), DmaWaitOne(o)   the same issued / awaited by ONE of kDmaOwners lane groups
+//   A knot's operands are then requested the moment their destination dies in the PREVIOUS knot ([A|B] after the H phase, b and the
+//   packed stage Hessian after the P [A|B] phase into the retired cost-to-go buffer), and the forward pass runs kDmaOwners knots ahead.
 // With prefetching, the operands of knot k - 1 ([A|B], W, w, b: one HBM round trip each) are in flight while knot k is
 // factorised, instead of stalling every phase that touches them (0.75 -> see DESIGN.md for 4096 x 30 quadrotor knots).
 #pragma once
@@ -76,7 +82,48 @@ struct RiccatiArgs {
 UNGAR_HD inline int RiccatiScratchDoubles(int nx, int nu) {
     const int n = nx + nu;
     return nx * n /*AB*/ + n * n /*H*/ + 2 * nx * nx /*P, Pn*/ + nx * n /*PAB*/ + 2 * nx /*p, pn*/ + nx /*t*/ + n /*h*/ + nx /*bk*/ + nu * (nx + 1) /*K|kff*/ +
-           nx + nu /*dx, du*/ + nx /*dxn*/ + nu /*Cholesky pivots*/;
+           nx + nu /*dx, du*/ + nx /*dxn*/ + nu /*Cholesky pivots*/ + n /*next knot's stage gradient (kDma)*/;
+}
+
+/// Register tile of the two large products: the smallest one with which all tiles of a rows x cols product fit the lanes of the
+/// workgroup ONCE (the accompanying dot products t = P b + p, h += [A|B]^T t follow as one item each: a short second pass at most).
+/// The fixed 2 x 4 / 2 x 2 tiles needed a second pass of TILES for H: 374 items on 256 lanes for the 37 + 12 block, 98 on 64 for 13 + 4.
+/// (Measured and dropped: folding the dot products onto the spare lanes of the first pass, several per lane -- as consecutive chains
+/// they outlast the tiles, as interleaved chains the 37 + 12 phase still ran 40 % longer than with the short second pass.)
+struct RiccatiTile {
+    int ti, tc;
+};
+constexpr RiccatiTile RiccatiChooseTile(int rows, int cols, int lanes) {
+    constexpr RiccatiTile candidates[] = {{2, 2}, {2, 3}, {2, 4}, {3, 4}, {4, 4}};
+    for (const RiccatiTile t : candidates)
+        if (((rows + t.ti - 1) / t.ti) * ((cols + t.tc - 1) / t.tc) <= lanes) return t;
+    return rows >= 24 ? RiccatiTile{2, 4} : RiccatiTile{2, 2};  // more tiles than lanes either way: several passes
+}
+
+template <class Exec>
+constexpr bool RiccatiExecHasDma() {
+    if constexpr (requires { Exec::kDma; }) return Exec::kDma;
+    else return false;
+}
+
+/// Upper triangle (r <= c) of a symmetric n x n matrix folded into a ((n + 1) / 2) x (n + 1) rectangle: row q of the rectangle holds
+/// row q of the triangle (n - q entries) followed by row n - 1 - q (q + 1 entries) -- decodable with one division by n + 1.
+UNGAR_HD inline int RiccatiFoldedIndex(int n, int r, int c) {
+    return r <= n - 1 - r ? r * (n + 1) + (c - r) : (n - 1 - r) * (n + 1) + (n - (n - 1 - r)) + (c - r);
+}
+/// Inverse: index in the rectangle -> r * n + c of the entry it holds, or -1 for the unused tail of the middle row (n odd).
+UNGAR_HD inline int RiccatiFoldedSource(int n, int i) {
+    const int q = i / (n + 1), j = i - q * (n + 1);
+    if (j < n - q) return q * n + q + j;
+    const int r = n - 1 - q;
+    if (r == q) return -1;
+    return r * n + r + (j - (n - q));
+}
+
+/// Phase clocks (diagnostic builds only: a policy with a Mark(id) member accumulates the cycles since its previous call under `id`).
+template <class Exec>
+UNGAR_HD inline void RiccatiMark(Exec& ex, int id) {
+    if constexpr (requires { ex.Mark(id); }) ex.Mark(id);
 }
 
 /// The whole recursion for instance `inst`; `scratch` holds RiccatiScratchDoubles(nx, nu) doubles private to the workgroup.
@@ -100,6 +147,12 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
     double* du = dx + nx;
     double* dxn = du + nu;
     double* piv = dxn + nx;  // diagonal of the Cholesky factor of R
+    double* wn = piv + nu;   // kDma: stage gradient of the next knot
+    // Asynchronous operand copies (policies with kDma, compile-time sizes).  The stage Hessian of the next knot is parked, folded,
+    // in the cost-to-go buffer that retired after the P [A|B] phase -- when it fits there.
+    constexpr bool dma = NX >= UNGAR_RICCATI_TILE_MIN_NX && RiccatiExecHasDma<Exec>();
+    constexpr int nFold = ((NX + NU + 1) / 2) * (NX + NU + 1);
+    constexpr bool foldW = dma && nFold <= NX * NX;
     double* gains = a.gains + inst * static_cast<long long>(N) * nu * nk;
     int failed = 0;
 
@@ -137,8 +190,36 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
         fetchKnot(N - 1);
         commitKnot();
     }
+    [[maybe_unused]] auto dmaAfterPab = [&](int k, double* retired) {  // b_k's and (folded) W_k's destinations are free once P [A|B] and t exist
+        if constexpr (dma) {
+            ex.DmaFetch(nx, [&](int i) { return &a.b.at(inst, k, i); }, bk);
+            if constexpr (foldW)
+                ex.DmaFetch(nFold, [&](int i) {
+                    const int src = RiccatiFoldedSource(n, i);
+                    return &a.hess.at(inst, k, src < 0 ? 0 : src);
+                }, retired);
+        }
+    };
+    [[maybe_unused]] auto dmaAfterH = [&](int k) {  // [A|B]'s once H exists; the gradient has its own buffer but one copy in flight
+        if constexpr (dma) {
+            ex.DmaFetch(nx * n, [&](int idx) { return &a.jac.at(inst, k, idx); }, AB);
+            if constexpr (foldW) ex.DmaFetch(n, [&](int c) { return &a.grad.at(inst, k, c); }, wn);
+        }
+    };
+    if constexpr (dma) {
+        dmaAfterPab(N - 1, Pn);
+        dmaAfterH(N - 1);
+    }
+    RiccatiMark(ex, 0);
     for (int k = N - 1; k >= 0; --k) {
-        if constexpr (ahead) {
+        if constexpr (dma) {
+            ex.DmaWait();
+            if constexpr (!foldW) {
+                ex.ForEachNoSync(n * n, [&](int idx) { H[idx] = a.hess.at(inst, k, idx); });
+                ex.ForEachNoSync(n, [&](int idx) { h[idx] = a.grad.at(inst, k, idx); });
+            }
+            ex.Barrier();
+        } else if constexpr (ahead) {
             if (k > 0) fetchKnot(k - 1);  // in flight while knot k is processed
         } else if constexpr (Exec::kPrefetch) {
             fetchKnot(k);
@@ -153,15 +234,17 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
             ex.ForEachNoSync(nx, [&](int idx) { bk[idx] = a.b.at(inst, k, idx); });
             ex.Barrier();
         }
+        RiccatiMark(ex, 1);  // operands of the knot
         if constexpr (NX >= UNGAR_RICCATI_TILE_MIN_NX) {
-            // Large blocks, sizes fixed at compile time: 2 x 4 register tiles -- eight multiply-adds per six LDS reads instead of per
-            // sixteen, and no bounds checks inside the product (a tile on the edge reads past its row / matrix into the neighbouring
+            // Sizes fixed at compile time: TI x TC register tiles (RiccatiChooseTile; 2 x 4: eight multiply-adds per six LDS reads instead of
+            // per sixteen) and no bounds checks inside the product (a tile on the edge reads past its row / matrix into the neighbouring
             // scratch arrays, which is harmless: only the stores are guarded).  A tile's columns are INTERLEAVED (tc, tc + tilesC, ...):
             // neighbouring lanes then read neighbouring LDS words.  With four contiguous columns per lane the lanes of a read were 32
             // bytes apart and, paired into ds_read2_b64 (32-bank mode), collided four ways: SQ_LDS_BANK_CONFLICT was 4x the LDS issue cycles.
-            constexpr int TI = 2, TC = NX >= 24 ? 4 : 2, tilesI = (NX + TI - 1) / TI, tilesC = (NX + NU + TC - 1) / TC;
-            ex.ForEach(tilesI * tilesC + nx, [&](int idx) {
-                if (idx < tilesI * tilesC) {
+            constexpr RiccatiTile tileP = RiccatiChooseTile(NX, NX + NU, Exec::kLanes);
+            constexpr int TI = tileP.ti, TC = tileP.tc, tilesI = (NX + TI - 1) / TI, tilesC = (NX + NU + TC - 1) / TC, tilesP = tilesI * tilesC;
+            ex.ForEach(tilesP + nx, [&](int idx) {
+                if (idx < tilesP) {
                     const int i0 = idx / tilesC, c0 = idx % tilesC;  // rows i0 + a2 tilesI, columns c0 + b2 tilesC
                     double acc[TI][TC] = {};
 #pragma unroll 4
@@ -176,39 +259,47 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
                         for (int b2 = 0; b2 < TC; ++b2)
                             if (i0 + a2 * tilesI < nx && c0 + b2 * tilesC < n) PAB[(i0 + a2 * tilesI) * n + c0 + b2 * tilesC] = acc[a2][b2];
                 } else {
-                    const int i = idx - tilesI * tilesC;
+                    const int i = idx - tilesP;
                     double acc = p[i];
 #pragma unroll 8
                     for (int m = 0; m < nx; ++m) acc += P[i * nx + m] * bk[m];
                     t[i] = acc;
                 }
             });
+            RiccatiMark(ex, 2);  // P [A|B]
+            if constexpr (dma) {
+                if (k > 0) dmaAfterPab(k - 1, P);  // P retired with the phase above; the folded W_k read below sits in Pn
+            }
             // H = W + AB^T PAB: all tiles (interleaved rows and columns straddle the diagonal); entries r <= c are updated and mirrored
-            constexpr int tilesR = (NX + NU + TI - 1) / TI;
-            ex.ForEach(tilesR * tilesC + n, [&](int idx) {
-                if (idx < tilesR * tilesC) {
-                    const int r0 = idx / tilesC, c0 = idx % tilesC;
-                    double acc[TI][TC] = {};
+            constexpr RiccatiTile tileH = RiccatiChooseTile(NX + NU, NX + NU, Exec::kLanes);
+            constexpr int HI = tileH.ti, HC = tileH.tc, tilesR = (NX + NU + HI - 1) / HI, tilesD = (NX + NU + HC - 1) / HC, tilesH = tilesR * tilesD;
+            ex.ForEach(tilesH + n, [&](int idx) {
+                if (idx < tilesH) {
+                    const int r0 = idx / tilesD, c0 = idx % tilesD;
+                    double acc[HI][HC] = {};
 #pragma unroll 4
                     for (int m = 0; m < nx; ++m) {
-                        double lv[TI], qv[TC];
-                        for (int a2 = 0; a2 < TI; ++a2) lv[a2] = AB[m * n + r0 + a2 * tilesR];
-                        for (int b2 = 0; b2 < TC; ++b2) qv[b2] = PAB[m * n + c0 + b2 * tilesC];
-                        for (int a2 = 0; a2 < TI; ++a2)
-                            for (int b2 = 0; b2 < TC; ++b2) acc[a2][b2] += lv[a2] * qv[b2];
+                        double lv[HI], qv[HC];
+                        for (int a2 = 0; a2 < HI; ++a2) lv[a2] = AB[m * n + r0 + a2 * tilesR];
+                        for (int b2 = 0; b2 < HC; ++b2) qv[b2] = PAB[m * n + c0 + b2 * tilesD];
+                        for (int a2 = 0; a2 < HI; ++a2)
+                            for (int b2 = 0; b2 < HC; ++b2) acc[a2][b2] += lv[a2] * qv[b2];
                     }
-                    for (int a2 = 0; a2 < TI; ++a2)
-                        for (int b2 = 0; b2 < TC; ++b2) {
-                            const int r = r0 + a2 * tilesR, c = c0 + b2 * tilesC;
+                    for (int a2 = 0; a2 < HI; ++a2)
+                        for (int b2 = 0; b2 < HC; ++b2) {
+                            const int r = r0 + a2 * tilesR, c = c0 + b2 * tilesD;
                             if (r <= c && c < n) {
-                                const double e = H[r * n + c] + (r == c ? a.regularization : 0.0) + acc[a2][b2];
+                                double wv;
+                                if constexpr (foldW) wv = Pn[RiccatiFoldedIndex(n, r, c)];
+                                else wv = H[r * n + c];
+                                const double e = wv + (r == c ? a.regularization : 0.0) + acc[a2][b2];
                                 H[r * n + c] = e;
                                 H[c * n + r] = e;
                             }
                         }
                 } else {
-                    const int c = idx - tilesR * tilesC;
-                    double acc = h[c];
+                    const int c = idx - tilesH;
+                    double acc = foldW ? wn[c] : h[c];
 #pragma unroll 8
                     for (int m = 0; m < nx; ++m) acc += AB[m * n + c] * t[m];
                     h[c] = acc;
@@ -249,6 +340,10 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
                     h[c] = acc;
                 }
             });
+        }
+        RiccatiMark(ex, 3);  // H (for the untiled path: both products)
+        if constexpr (dma) {
+            if (k > 0) dmaAfterH(k - 1);
         }
         if constexpr (NU > 0 && NU <= 12) {
             // Input dimension <= 12 fixed at compile time: every lane factorises R = H_uu = L L^T itself, in registers (NU^3 / 6
@@ -341,6 +436,7 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
             for (int j = nu - 1; j > 0; --j) backwardColumn(j);
             ex.ForEachNoSync(nu * nk, [&](int idx) { gains[static_cast<long long>(k) * nu * nk + idx] = K[idx]; });
         }
+        RiccatiMark(ex, 4);  // factorisation of R and gains
         // P <- H_xx + H_ux^T K (symmetrised),  p <- h_x + H_ux^T kff   (into the other buffer, then the buffers swap roles)
         ex.ForEach(nx * nx + nx, [&](int idx) {
             if (idx < nx * nx) {
@@ -368,10 +464,12 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
             p = pn;
             pn = swapp;
         }
+        RiccatiMark(ex, 5);  // cost-to-go update
         if constexpr (ahead) {
             if (k > 0) commitKnot();  // AB, H, h, b of knot k are dead from here on
         }
     }
+    RiccatiMark(ex, 6);
 
     // forward pass
     ex.GlobalSync();  // the gains written above are read back below
@@ -379,27 +477,9 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
         dx[i] = a.dx0.at(inst, 0, i);
         a.dX.at(inst, 0, i) = dx[i];
     });
-    auto fetchForward = [&](int k) {
-        ex.Fetch(nx * n, [&](int idx) { return a.jac.at(inst, k, idx); }, sAB);
-        ex.Fetch(nx, [&](int i) { return a.b.at(inst, k, i); }, sb);
-    };
-    if constexpr (Exec::kPrefetch) {
-        fetchForward(0);
-        ex.Commit(nx * n, sAB, AB);
-        ex.Commit(nx, sb, bk);
-        ex.Barrier();
-    }
-    for (int k = 0; k < N; ++k) {
-        if constexpr (Exec::kPrefetch) {
-            if (k + 1 < N) fetchForward(k + 1);
-        } else {
-            ex.ForEach(nx * n + nx, [&](int idx) {
-                if (idx < nx * n) AB[idx] = a.jac.at(inst, k, idx);
-                else bk[idx - nx * n] = a.b.at(inst, k, idx - nx * n);
-            });
-        }
+    auto forwardKnot = [&](int k, const double* ABk, const double* bkk, const double* gk) {  // gk: [K | kff] of the knot (scratch copy or global)
         ex.ForEach(nu, [&](int i) {
-            const double* g = gains + static_cast<long long>(k) * nu * nk + i * nk;
+            const double* g = gk + i * nk;
             double s = g[nx];
 #pragma unroll 8
             for (int m = 0; m < nx; ++m) s += g[m] * dx[m];
@@ -407,27 +487,71 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
             a.dU.at(inst, k, i) = s;
         });
         ex.ForEach(nx, [&](int i) {
-            double s = bk[i];
+            double s = bkk[i];
 #pragma unroll 8
-            for (int m = 0; m < nx; ++m) s += AB[i * n + m] * dx[m];
+            for (int m = 0; m < nx; ++m) s += ABk[i * n + m] * dx[m];
 #pragma unroll 8
-            for (int m = 0; m < nu; ++m) s += AB[i * n + nx + m] * du[m];
+            for (int m = 0; m < nu; ++m) s += ABk[i * n + nx + m] * du[m];
             dxn[i] = s;
             a.dX.at(inst, k + 1, i) = s;
         });
-        {
-            double* swapx = dx;
-            dx = dxn;
-            dxn = swapx;
+        double* swapx = dx;
+        dx = dxn;
+        dxn = swapx;
+    };
+    // Asynchronous copies: the two phases of a knot occupy the first lanes only (nu, nx <= 64), so the OTHER lane groups own the
+    // copies -- knot j belongs to owner j % kDmaOwners and lands in buffer j % kDmaOwners of the (now dead) matrix scratch, requested
+    // kDmaOwners knots ahead.  (The computing lanes issue no copies: their loads of the gains return in order behind older copies.)
+    constexpr bool dmaForward = dma && NX <= 64 && NU <= 64;
+    if constexpr (dmaForward) {
+        // per knot: [A|B], b and the gains (read back from global memory otherwise: one exposed round trip per knot)
+        constexpr int D = Exec::kDmaOwners, S = NX * (NX + NU) + NX + NU * (NX + 1);
+        static_assert(D * S <= 2 * NX * (NX + NU) + (NX + NU) * (NX + NU) + 2 * NX * NX, "forward-pass buffers exceed the matrix scratch");
+        auto request = [&](int k) {
+            double* buf = scratch + (k % D) * S;
+            ex.DmaFetchOne(k, nx * n, [&](int idx) { return &a.jac.at(inst, k, idx); }, buf);
+            ex.DmaFetchOne(k, nx, [&](int i) { return &a.b.at(inst, k, i); }, buf + nx * n);
+            ex.DmaFetchOne(k, nu * nk, [&](int i) { return gains + static_cast<long long>(k) * nu * nk + i; }, buf + nx * n + nx);
+        };
+        for (int k = 0; k < D && k < N; ++k) request(k);
+        for (int k = 0; k < N; ++k) {
+            ex.DmaWaitOne(k);
+            ex.Barrier();
+            const double* buf = scratch + (k % D) * S;
+            forwardKnot(k, buf, buf + nx * n, buf + nx * n + nx);
+            if (k + D < N) request(k + D);  // behind the closing barrier of the knot: its buffer is free
         }
+    } else {
+        // (Staging the gains in registers as well was measured and dropped: 0.88 -> 0.90 ms for the quadrotor QP step.)
+        auto fetchForward = [&](int k) {
+            ex.Fetch(nx * n, [&](int idx) { return a.jac.at(inst, k, idx); }, sAB);
+            ex.Fetch(nx, [&](int i) { return a.b.at(inst, k, i); }, sb);
+        };
+        auto commitForward = [&] {
+            ex.Commit(nx * n, sAB, AB);
+            ex.Commit(nx, sb, bk);
+            ex.Barrier();
+        };
         if constexpr (Exec::kPrefetch) {
-            if (k + 1 < N) {
-                ex.Commit(nx * n, sAB, AB);
-                ex.Commit(nx, sb, bk);
-                ex.Barrier();
+            fetchForward(0);
+            commitForward();
+        }
+        for (int k = 0; k < N; ++k) {
+            if constexpr (Exec::kPrefetch) {
+                if (k + 1 < N) fetchForward(k + 1);
+            } else {
+                ex.ForEach(nx * n + nx, [&](int idx) {
+                    if (idx < nx * n) AB[idx] = a.jac.at(inst, k, idx);
+                    else bk[idx - nx * n] = a.b.at(inst, k, idx - nx * n);
+                });
+            }
+            forwardKnot(k, AB, bk, gains + static_cast<long long>(k) * nu * nk);
+            if constexpr (Exec::kPrefetch) {
+                if (k + 1 < N) commitForward();
             }
         }
     }
+    RiccatiMark(ex, 7);  // forward pass
     if (a.status) ex.ForEach(1, [&](int) { a.status[inst] = failed; });
 }
 
