@@ -431,7 +431,10 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
                     K[i * nk + c] -= H[(nx + j) * n + nx + i] * piv[i] * K[j * nk + c];
                 });
             };
-            for (int j = 0; j < nu; ++j) forwardColumn(j);  // (not unrolled: 47 unrolled phase bodies cost the third wavefront per SIMD)
+            // (not unrolled: 47 unrolled phase bodies cost the third wavefront per SIMD.  Also measured and dropped for nu = 24: factorising
+            // in 24 phases and running both substitutions of a right-hand side in the registers of one lane -- 2 x 276 multiply-adds behind
+            // column-wise LDS round trips on 14 lanes, 175 registers: QP step 5.25 -> 6.94 ms.)
+            for (int j = 0; j < nu; ++j) forwardColumn(j);
             ex.ForEach(nu * nk, [&](int idx) { K[idx] *= piv[idx / nk]; });
             for (int j = nu - 1; j > 0; --j) backwardColumn(j);
             ex.ForEachNoSync(nu * nk, [&](int idx) { gains[static_cast<long long>(k) * nu * nk + idx] = K[idx]; });
