@@ -350,8 +350,8 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
             // multiply-adds from NU (NU + 1) / 2 LDS reads), and goes straight on to its right-hand side of
             // [K | kff] = -R^-1 [H_ux | h_u] -- one phase instead of NU + 1 (a barrier and an LDS round trip per Cholesky column).
             ex.ForEach(nk, [&](int c) {
-                double L[NU][NU];
-                bool bad = false;
+                double L[NU][NU], inv[NU];  // inv[j] = 1 / L[j][j]: one division per column instead of one per entry (a double-precision
+                bool bad = false;           // division is a ~12-instruction dependent sequence)
 #pragma unroll
                 for (int j = 0; j < NU; ++j) {
                     double d = H[(nx + j) * n + nx + j];
@@ -360,12 +360,13 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
                     const bool neg = !(d > 0.0);
                     bad = bad || neg;
                     L[j][j] = sqrt(neg ? 1.0 : d);
+                    inv[j] = 1.0 / L[j][j];
 #pragma unroll
                     for (int i = j + 1; i < NU; ++i) {
                         double sv = H[(nx + i) * n + nx + j];
 #pragma unroll
                         for (int m = 0; m < j; ++m) sv -= L[i][m] * L[j][m];
-                        L[i][j] = sv / L[j][j];
+                        L[i][j] = sv * inv[j];
                     }
                 }
                 if (c == 0 && bad) failed = failed ? failed : k + 1;
@@ -375,14 +376,14 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
                     double sv = c < nx ? -H[(nx + i) * n + c] : -h[nx + i];
 #pragma unroll
                     for (int m = 0; m < i; ++m) sv -= L[i][m] * y[m];
-                    y[i] = sv / L[i][i];
+                    y[i] = sv * inv[i];
                 }
 #pragma unroll
                 for (int i = NU - 1; i >= 0; --i) {  // L^T x = y
                     double sv = y[i];
 #pragma unroll
                     for (int m = i + 1; m < NU; ++m) sv -= L[m][i] * y[m];
-                    sv /= L[i][i];
+                    sv *= inv[i];
                     y[i] = sv;
                     K[i * nk + c] = sv;
                     gains[static_cast<long long>(k) * nu * nk + i * nk + c] = sv;
@@ -441,24 +442,43 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
         }
         RiccatiMark(ex, 4);  // factorisation of R and gains
         // P <- H_xx + H_ux^T K (symmetrised),  p <- h_x + H_ux^T kff   (into the other buffer, then the buffers swap roles)
-        ex.ForEach(nx * nx + nx, [&](int idx) {
-            if (idx < nx * nx) {
-                const int i = idx / nx, j = idx % nx;
-                double s1 = H[i * n + j], s2 = H[j * n + i];
+        auto costToGoEntry = [&](int i, int j) {  // the symmetrised entry (i, j): the same bits for (j, i)
+            double s1 = H[i * n + j], s2 = H[j * n + i];
 #pragma unroll 8
-                for (int m = 0; m < nu; ++m) {
-                    s1 += H[(nx + m) * n + i] * K[m * nk + j];
-                    s2 += H[(nx + m) * n + j] * K[m * nk + i];
-                }
-                Pn[idx] = 0.5 * (s1 + s2);
-            } else {
-                const int i = idx - nx * nx;
-                double sv = h[i];
-#pragma unroll 8
-                for (int m = 0; m < nu; ++m) sv += H[(nx + m) * n + i] * K[m * nk + nx];
-                pn[i] = sv;
+            for (int m = 0; m < nu; ++m) {
+                s1 += H[(nx + m) * n + i] * K[m * nk + j];
+                s2 += H[(nx + m) * n + j] * K[m * nk + i];
             }
-        });
+            return 0.5 * (s1 + s2);
+        };
+        auto costToGoVector = [&](int i) {
+            double sv = h[i];
+#pragma unroll 8
+            for (int m = 0; m < nu; ++m) sv += H[(nx + m) * n + i] * K[m * nk + nx];
+            pn[i] = sv;
+        };
+        if constexpr (NX > 0) {
+            // compile-time size: one item per PAIR i <= j (each entry computes both orientations anyway), found through the folded
+            // rectangle with one division -- half the items of the per-entry loop below
+            constexpr int pairs = ((NX + 1) / 2) * (NX + 1);
+            ex.ForEach(pairs + nx, [&](int idx) {
+                if (idx < pairs) {
+                    const int src = RiccatiFoldedSource(nx, idx);
+                    if (src < 0) return;
+                    const int i = src / nx, j = src - i * nx;
+                    const double v = costToGoEntry(i, j);
+                    Pn[i * nx + j] = v;
+                    Pn[j * nx + i] = v;
+                } else {
+                    costToGoVector(idx - pairs);
+                }
+            });
+        } else {
+            ex.ForEach(nx * nx + nx, [&](int idx) {
+                if (idx < nx * nx) Pn[idx] = costToGoEntry(idx / nx, idx % nx);
+                else costToGoVector(idx - nx * nx);
+            });
+        }
         {
             double* swapP = P;
             P = Pn;
