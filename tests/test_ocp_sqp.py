@@ -98,7 +98,7 @@ def solve_host(lib, nx, nu, N, q, reg, terminal=True):
     return dX, dU, st
 
 
-@pytest.mark.parametrize("nx,nu,N", [(13, 4, 30), (6, 2, 20), (13, 24, 8), (3, 1, 5), (37, 12, 6)])
+@pytest.mark.parametrize("nx,nu,N", [(13, 4, 30), (6, 2, 20), (13, 24, 8), (3, 1, 5), (37, 12, 6), (2, 6, 7)])  # the last one: more inputs than nx^2
 def test_riccati_recursion_equals_the_dense_kkt_solve(host, nx, nu, N):
     rng = np.random.default_rng(nx * 100 + nu)
     q = random_qp(rng, nx, nu, N, 3)

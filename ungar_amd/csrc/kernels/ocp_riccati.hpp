@@ -434,7 +434,9 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
             };
             // (not unrolled: 47 unrolled phase bodies cost the third wavefront per SIMD.  Also measured and dropped for nu = 24: factorising
             // in 24 phases and running both substitutions of a right-hand side in the registers of one lane -- 2 x 276 multiply-adds behind
-            // column-wise LDS round trips on 14 lanes, 175 registers: QP step 5.25 -> 6.94 ms.)
+            // column-wise LDS round trips on 14 lanes, 175 registers: QP step 5.25 -> 6.94 ms; and eliminating an identity along with the
+            // right-hand sides, so that L^-1 turns the back substitution into ONE product -- nu + 3 phases instead of 2 nu + 1, but heavier
+            // ones and a 23-term chain per entry of the product: 5.16 -> 5.75 ms.)
             for (int j = 0; j < nu; ++j) forwardColumn(j);
             ex.ForEach(nu * nk, [&](int idx) { K[idx] *= piv[idx / nk]; });
             for (int j = nu - 1; j > 0; --j) backwardColumn(j);
