@@ -82,7 +82,8 @@ struct RiccatiArgs {
 UNGAR_HD inline int RiccatiScratchDoubles(int nx, int nu) {
     const int n = nx + nu;
     return nx * n /*AB*/ + n * n /*H*/ + 2 * nx * nx /*P, Pn*/ + nx * n /*PAB*/ + 2 * nx /*p, pn*/ + nx /*t*/ + n /*h*/ + nx /*bk*/ + nu * (nx + 1) /*K|kff*/ +
-           nx + nu /*dx, du*/ + nx /*dxn*/ + nu /*Cholesky pivots*/ + n /*next knot's stage gradient (kDma)*/;
+           nx + nu /*dx, du*/ + nx /*dxn*/ + nu /*Cholesky pivots*/ + n /*next knot's stage gradient (kDma)*/ +
+           (((n + 1) / 2) * (n + 1) > nx * nx ? ((n + 1) / 2) * (n + 1) : 0) /*next knot's folded stage Hessian where the retired cost-to-go buffer is too small (kDma)*/;
 }
 
 /// Register tile of the two large products: the smallest one with which all tiles of a rows x cols product fit the lanes of the
@@ -148,13 +149,21 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
     double* dxn = du + nu;
     double* piv = dxn + nx;  // diagonal of the Cholesky factor of R
     double* wn = piv + nu;   // kDma: stage gradient of the next knot
-    // Asynchronous operand copies (policies with kDma, compile-time sizes).  The stage Hessian of the next knot is parked, folded,
-    // in the cost-to-go buffer that retired after the P [A|B] phase -- when it fits there.
-    constexpr bool dma = NX >= UNGAR_RICCATI_TILE_MIN_NX && RiccatiExecHasDma<Exec>();
-    constexpr int nFold = ((NX + NU + 1) / 2) * (NX + NU + 1);
-    constexpr bool foldW = dma && nFold <= NX * NX;
+    double* wf = wn + n;     // kDma: folded stage Hessian of the next knot, for sizes where it does not fit the retired cost-to-go buffer
     double* gains = a.gains + inst * static_cast<long long>(N) * nu * nk;
     int failed = 0;
+    // Asynchronous operand copies (policies with kDma, compile-time sizes).  The stage Hessian of the next knot is parked, folded,
+    // in the cost-to-go buffer that retired after the P [A|B] phase (requested right after that phase) -- when it fits there;
+    // otherwise in a buffer of its own, requested once the H phase has consumed the current one.
+    constexpr bool dma = NX >= UNGAR_RICCATI_TILE_MIN_NX && RiccatiExecHasDma<Exec>();
+    constexpr int nFold = ((NX + NU + 1) / 2) * (NX + NU + 1);
+    constexpr bool foldW = dma, foldInP = dma && nFold <= NX * NX;
+    auto foldedSource = [&](int k) {
+        return [&a, inst, k, n](int i) {
+            const int src = RiccatiFoldedSource(n, i);
+            return &a.hess.at(inst, k, src < 0 ? 0 : src);
+        };
+    };
 
     // terminal cost-to-go
     ex.ForEach(nx * nx, [&](int idx) {
@@ -193,17 +202,14 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
     [[maybe_unused]] auto dmaAfterPab = [&](int k, double* retired) {  // b_k's and (folded) W_k's destinations are free once P [A|B] and t exist
         if constexpr (dma) {
             ex.DmaFetch(nx, [&](int i) { return &a.b.at(inst, k, i); }, bk);
-            if constexpr (foldW)
-                ex.DmaFetch(nFold, [&](int i) {
-                    const int src = RiccatiFoldedSource(n, i);
-                    return &a.hess.at(inst, k, src < 0 ? 0 : src);
-                }, retired);
+            if constexpr (foldInP) ex.DmaFetch(nFold, foldedSource(k), retired);
         }
     };
-    [[maybe_unused]] auto dmaAfterH = [&](int k) {  // [A|B]'s once H exists; the gradient has its own buffer but one copy in flight
+    [[maybe_unused]] auto dmaAfterH = [&](int k) {  // [A|B]'s once H exists; the gradient (and a folded W outside P) has its own buffer but one copy in flight
         if constexpr (dma) {
             ex.DmaFetch(nx * n, [&](int idx) { return &a.jac.at(inst, k, idx); }, AB);
-            if constexpr (foldW) ex.DmaFetch(n, [&](int c) { return &a.grad.at(inst, k, c); }, wn);
+            ex.DmaFetch(n, [&](int c) { return &a.grad.at(inst, k, c); }, wn);
+            if constexpr (!foldInP) ex.DmaFetch(nFold, foldedSource(k), wf);
         }
     };
     if constexpr (dma) {
@@ -290,7 +296,7 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
                             const int r = r0 + a2 * tilesR, c = c0 + b2 * tilesD;
                             if (r <= c && c < n) {
                                 double wv;
-                                if constexpr (foldW) wv = Pn[RiccatiFoldedIndex(n, r, c)];
+                                if constexpr (foldW) wv = (foldInP ? Pn : wf)[RiccatiFoldedIndex(n, r, c)];
                                 else wv = H[r * n + c];
                                 const double e = wv + (r == c ? a.regularization : 0.0) + acc[a2][b2];
                                 H[r * n + c] = e;
