@@ -70,6 +70,37 @@ struct HostDmaExec : HostExec<false> {
     }
     void DmaWaitOne(int owner) { Land(pending[1 + owner % kDmaOwners]); }
 };
+
+/// The single-wavefront kernels' forward pass: the computing lanes issue their own copies, 32 doubles per instruction, which land in
+/// issue order; a wait names how many of the YOUNGEST instructions may still be in flight.  DEFERRED: nothing lands before a wait
+/// demands it; otherwise everything lands at once.
+template <bool DEFERRED>
+struct HostSelfDmaExec : HostExec<true> {
+    static constexpr bool kDmaSelf = true;
+    struct Copy {
+        const double* from;
+        double* to;
+    };
+    std::vector<std::vector<Copy>> inFlight;  // one entry per copy instruction, oldest first
+    template <class F>
+    void DmaFetchSelf(int n, F addr, double* dst) {
+        for (int c = 0; c < n; c += 32) {
+            std::vector<Copy> instr;
+            for (int i = c; i < n && i < c + 32; ++i) {
+                if (DEFERRED) instr.push_back({addr(i), dst + i});
+                else dst[i] = *addr(i);
+            }
+            inFlight.push_back(std::move(instr));
+        }
+    }
+    template <int YOUNGER>
+    void DmaWaitSelf() {
+        while (inFlight.size() > static_cast<std::size_t>(YOUNGER)) {
+            for (const Copy& c : inFlight.front()) *c.to = *c.from;
+            inFlight.erase(inFlight.begin());
+        }
+    }
+};
 }  // namespace
 
 /// Node-major contiguous arrays: jac [batch][N][nx*(nx+nu)], b [batch][N][nx], hess [batch][N][n*n], grad [batch][N][n],
@@ -106,6 +137,17 @@ extern "C" int riccati_host_solve_variant(int prefetch, int nx, int nu, int N, l
             else if (nx == 13 && nu == 24) RiccatiInstance<HostExec<false>, 13, 24>(a, i, scratch.data(), ex);
             else return 1;
         }
+    } else if (prefetch == 5 || prefetch == 6) {  // one-wavefront kernels: staged backward pass, forward pass on self-issued copies with counted waits
+        auto run = [&](auto ex) {
+            using E = decltype(ex);
+            for (long long i = 0; i < batch; ++i) {
+                if (nx == 13 && nu == 4) RiccatiInstance<E, 13, 4>(a, i, scratch.data(), ex);
+                else if (nx == 6 && nu == 2) RiccatiInstance<E, 6, 2>(a, i, scratch.data(), ex);
+                else return 1;
+            }
+            return 0;
+        };
+        return prefetch == 5 ? run(HostSelfDmaExec<false>{}) : run(HostSelfDmaExec<true>{});
     } else if (prefetch == 3 || prefetch == 4) {  // compile-time sizes with the asynchronous-copy protocol (3: copies land at once, 4: at the wait)
         auto run = [&](auto ex) {
             using E = decltype(ex);

@@ -180,6 +180,27 @@ def test_asynchronous_operand_copies_do_not_change_a_bit(host, nx, nu):
         assert np.array_equal(out[0][0], dX) and np.array_equal(out[0][1], dU)
 
 
+@pytest.mark.parametrize("nx,nu", [(13, 4), (6, 2)])
+def test_counted_waits_of_the_single_wavefront_forward_pass(host, nx, nu):
+    """The one-wavefront kernels run their forward pass three knots ahead on copies they issue themselves and await by COUNT (all but the
+    copy instructions of the two younger knots).  Sequential stand-in: nothing lands before a wait demands it / everything lands at once;
+    both must reproduce the bits of the plain fixed-size recursion -- a count that is off by one instruction would leave stale data."""
+    rng = np.random.default_rng(44)
+    dp = ctypes.POINTER(ctypes.c_double)
+    p = lambda a: a.ctypes.data_as(dp)  # noqa: E731
+    for N in (1, 2, 3, 4, 9):  # shorter than, equal to and longer than the pipeline
+        q = random_qp(rng, nx, nu, N, 2)
+        out = []
+        for variant in (2, 5, 6):
+            dX, dU, st = np.full((2, N + 1, nx), np.nan), np.full((2, N, nu), np.nan), np.zeros(2, dtype=np.int32)
+            rc = host.riccati_host_solve_variant(variant, nx, nu, N, ctypes.c_longlong(2), p(q["AB"]), p(q["b"]), p(q["W"]), p(q["w"]), p(q["WN"]), p(q["wN"]), p(q["dx0"]),
+                                                 ctypes.c_double(1e-6), p(dX), p(dU), st.ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
+            assert rc == 0 and (st == 0).all()
+            out.append((dX, dU))
+        for dX, dU in out[1:]:
+            assert np.array_equal(out[0][0], dX) and np.array_equal(out[0][1], dU), N
+
+
 def test_riccati_reports_an_indefinite_reduced_hessian(host):
     rng = np.random.default_rng(1)
     q = random_qp(rng, 4, 2, 6, 2)

@@ -97,6 +97,21 @@ struct DeviceExec {
     __device__ __forceinline__ void DmaWaitOne(int owner) {
         if (Wave() == 1 + owner % kDmaOwners) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    /// One wavefront per instance: it issues its own copies (they land in issue order) and waits for all but the youngest YOUNGER.
+#ifndef UNGAR_RICCATI_NO_SELF_DMA
+    static constexpr bool kDmaSelf = BLOCK == 64;
+#else
+    static constexpr bool kDmaSelf = false;
+#endif
+    template <class F>
+    __device__ __forceinline__ void DmaFetchSelf(int n, F addr, double* dst) {
+        DmaIssue(n, addr, dst, 0, 1);
+    }
+    template <int YOUNGER>
+    __device__ __forceinline__ void DmaWaitSelf() {
+        static_assert(YOUNGER >= 0 && YOUNGER <= 63);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER) : "memory");
+    }
 #ifdef UNGAR_RICCATI_CLOCKS
     /// Diagnostic build: cycles of the first workgroup's first lane between consecutive marks, summed per mark id
     /// (read back with ungar_amd_debug_riccati_clocks; tools/bench_riccati_phases.py).

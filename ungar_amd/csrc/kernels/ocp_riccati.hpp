@@ -31,6 +31,8 @@
 //     DmaFetch(n, addr, dst)        every lane group takes part: dst[i] <- *addr(i), i < n; returns at once, nothing waits
 //     DmaWait()                     this lane group's copies have landed (a Barrier() then publishes them to the workgroup)
 //     kDmaOwners, DmaFetchOne(o, n, addr, dst), DmaWaitOne(o)   the same issued / awaited by ONE of kDmaOwners lane groups
+//   kDmaSelf (optional)      one lane group per instance that issues its own copies and waits for them by COUNT:
+//     DmaFetchSelf(n, addr, dst), DmaWaitSelf<YOUNGER>()   all copies but the youngest YOUNGER copy instructions (32 doubles each) have landed
 //   A knot's operands are then requested the moment their destination dies in the PREVIOUS knot ([A|B] after the H phase, b and the
 //   packed stage Hessian after the P [A|B] phase into the retired cost-to-go buffer), and the forward pass runs kDmaOwners knots ahead.
 // With prefetching, the operands of knot k - 1 ([A|B], W, w, b: one HBM round trip each) are in flight while knot k is
@@ -104,6 +106,12 @@ constexpr RiccatiTile RiccatiChooseTile(int rows, int cols, int lanes) {
 template <class Exec>
 constexpr bool RiccatiExecHasDma() {
     if constexpr (requires { Exec::kDma; }) return Exec::kDma;
+    else return false;
+}
+
+template <class Exec>
+constexpr bool RiccatiExecHasSelfDma() {
+    if constexpr (requires { Exec::kDmaSelf; }) return Exec::kDmaSelf;
     else return false;
 }
 
@@ -534,6 +542,11 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
     // copies -- knot j belongs to owner j % kDmaOwners and lands in buffer j % kDmaOwners of the (now dead) matrix scratch, requested
     // kDmaOwners knots ahead.  (The computing lanes issue no copies: their loads of the gains return in order behind older copies.)
     constexpr bool dmaForward = dma && NX <= 64 && NU <= 64;
+    // (single lane group, below) three buffers in the dead matrix scratch and a wait counter of six bits bound the sizes it serves
+    constexpr int kSelfDepth = 3, selfKnotDoubles = NX * (NX + NU) + NX + NU * (NX + 1);
+    constexpr int selfKnotCopies = (NX * (NX + NU) + 31) / 32 + (NX + 31) / 32 + (NU * (NX + 1) + 31) / 32;  // copy instructions of one knot
+    constexpr bool selfForward = !dma && NX > 0 && NX <= 64 && NU <= 64 && RiccatiExecHasSelfDma<Exec>() && (kSelfDepth - 1) * selfKnotCopies <= 63 &&
+                                 kSelfDepth * selfKnotDoubles <= 2 * NX * (NX + NU) + (NX + NU) * (NX + NU) + 2 * NX * NX;
     if constexpr (dmaForward) {
         // per knot: [A|B], b and the gains (read back from global memory otherwise: one exposed round trip per knot)
         constexpr int D = Exec::kDmaOwners, S = NX * (NX + NU) + NX + NU * (NX + 1);
@@ -551,6 +564,27 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
             const double* buf = scratch + (k % D) * S;
             forwardKnot(k, buf, buf + nx * n, buf + nx * n + nx);
             if (k + D < N) request(k + D);  // behind the closing barrier of the knot: its buffer is free
+        }
+    } else if constexpr (selfForward) {
+        // One lane group per instance: the same three-deep pipeline, issued and awaited by the computing lanes themselves.  Copies
+        // land in order, so "all but the copies of the two younger knots" is a COUNTED wait (the stores of dX / dU issued in between
+        // complete in any order and only make the wait conservative); the last knots wait for everything.  The gains come through
+        // the scratch memory too: read back from global memory they were one exposed round trip per knot (28 % of the 13 + 4 recursion).
+        constexpr int D = kSelfDepth, S = selfKnotDoubles, perKnot = selfKnotCopies;
+        auto request = [&](int k) {
+            double* buf = scratch + (k % D) * S;
+            ex.DmaFetchSelf(nx * n, [&](int idx) { return &a.jac.at(inst, k, idx); }, buf);
+            ex.DmaFetchSelf(nx, [&](int i) { return &a.b.at(inst, k, i); }, buf + nx * n);
+            ex.DmaFetchSelf(nu * nk, [&](int i) { return gains + static_cast<long long>(k) * nu * nk + i; }, buf + nx * n + nx);
+        };
+        for (int k = 0; k < D && k < N; ++k) request(k);
+        for (int k = 0; k < N; ++k) {
+            if (k + D - 1 < N) ex.template DmaWaitSelf<(D - 1) * perKnot>();
+            else ex.template DmaWaitSelf<0>();
+            ex.Barrier();
+            const double* buf = scratch + (k % D) * S;
+            forwardKnot(k, buf, buf + nx * n, buf + nx * n + nx);
+            if (k + D < N) request(k + D);
         }
     } else {
         // (Staging the gains in registers as well was measured and dropped: 0.88 -> 0.90 ms for the quadrotor QP step.)
