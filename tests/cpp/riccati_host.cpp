@@ -101,6 +101,23 @@ struct HostSelfDmaExec : HostExec<true> {
         }
     }
 };
+
+/// One wavefront per instance with asynchronous operand copies in BOTH passes (device variant "fixedq"): the backward protocol of
+/// HostDmaExec on 64 lanes plus the counted forward pipeline.
+template <bool DEFERRED>
+struct HostDmaSelfExec : HostDmaExec<DEFERRED> {
+    static constexpr int kLanes = 64;
+    static constexpr bool kDmaSelf = true;
+    HostSelfDmaExec<DEFERRED> self;
+    template <class F>
+    void DmaFetchSelf(int n, F addr, double* dst) {
+        self.DmaFetchSelf(n, addr, dst);
+    }
+    template <int YOUNGER>
+    void DmaWaitSelf() {
+        self.template DmaWaitSelf<YOUNGER>();
+    }
+};
 }  // namespace
 
 /// Node-major contiguous arrays: jac [batch][N][nx*(nx+nu)], b [batch][N][nx], hess [batch][N][n*n], grad [batch][N][n],
@@ -137,6 +154,17 @@ extern "C" int riccati_host_solve_variant(int prefetch, int nx, int nu, int N, l
             else if (nx == 13 && nu == 24) RiccatiInstance<HostExec<false>, 13, 24>(a, i, scratch.data(), ex);
             else return 1;
         }
+    } else if (prefetch == 7 || prefetch == 8) {  // one wavefront, asynchronous copies in both passes
+        auto run = [&](auto ex) {
+            using E = decltype(ex);
+            for (long long i = 0; i < batch; ++i) {
+                if (nx == 13 && nu == 4) RiccatiInstance<E, 13, 4>(a, i, scratch.data(), ex);
+                else if (nx == 6 && nu == 2) RiccatiInstance<E, 6, 2>(a, i, scratch.data(), ex);
+                else return 1;
+            }
+            return 0;
+        };
+        return prefetch == 7 ? run(HostDmaSelfExec<false>{}) : run(HostDmaSelfExec<true>{});
     } else if (prefetch == 5 || prefetch == 6) {  // one-wavefront kernels: staged backward pass, forward pass on self-issued copies with counted waits
         auto run = [&](auto ex) {
             using E = decltype(ex);

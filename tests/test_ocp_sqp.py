@@ -191,7 +191,7 @@ def test_counted_waits_of_the_single_wavefront_forward_pass(host, nx, nu):
     for N in (1, 2, 3, 4, 9):  # shorter than, equal to and longer than the pipeline
         q = random_qp(rng, nx, nu, N, 2)
         out = []
-        for variant in (2, 5, 6):
+        for variant in (2, 5, 6, 7, 8):  # 7 / 8: asynchronous copies in the backward pass as well (device variant "fixedq")
             dX, dU, st = np.full((2, N + 1, nx), np.nan), np.full((2, N, nu), np.nan), np.zeros(2, dtype=np.int32)
             rc = host.riccati_host_solve_variant(variant, nx, nu, N, ctypes.c_longlong(2), p(q["AB"]), p(q["b"]), p(q["W"]), p(q["w"]), p(q["WN"]), p(q["wN"]), p(q["dx0"]),
                                                  ctypes.c_double(1e-6), p(dX), p(dU), st.ctypes.data_as(ctypes.POINTER(ctypes.c_int)))

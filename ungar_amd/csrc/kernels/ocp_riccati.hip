@@ -26,7 +26,7 @@ struct DeviceExec {
     static constexpr bool kDma = DMA;
     static constexpr int kLanes = BLOCK;
     static constexpr int kWaves = BLOCK / 64, kDmaOwners = kWaves > 1 ? kWaves - 1 : 1;
-    static_assert(!DMA || (kWaves > 1 && SLOTS_AB == 0), "the copies are owned by the wavefronts beyond the first; no register staging with them");
+    static_assert(!DMA || SLOTS_AB == 0, "no register staging next to the asynchronous copies");
     template <int K>
     struct Stage {
         double r[K > 0 ? K : 1];
@@ -368,9 +368,11 @@ extern "C" int ungar_amd_launch_riccati(const RiccatiArgs* a, void* stream) {
         if (a->nx == 13 && a->nu == 24) return LaunchRiccati<256, 2, 6, 13, 24>(a, lds, s);
         if (a->nx == 37 && a->nu == 12) return LaunchRiccati<256, 8, 10, 37, 12>(a, lds, s);
     }
-    if (variant == "fixed" || variant == "fixeds" || variant == "fixed1" || variant == "fixedp" || variant == "fixedn" || variant == "64") {
+    if (variant == "fixed" || variant == "fixeds" || variant == "fixed1" || variant == "fixedp" || variant == "fixedn" || variant == "fixedq" || variant == "64") {
         // small blocks: the next knot's operands are staged in registers while this knot is processed (quadrotor QP step 1.03 -> 0.92 ms;
         // for the 37 + 12 block the staging registers cost more than the hidden latency: 8.9 -> 9.7 ms)
+        if (variant == "fixedq" && a->nx == 13 && a->nu == 4) return LaunchRiccati<64, 0, 0, 13, 4, true, true>(a, lds, s);  // one wavefront, backward operands by LDS-DMA too: 0.877 vs 0.852 ms (register staging wins here)
+        if (variant == "fixedq" && a->nx == 6 && a->nu == 2) return LaunchRiccati<64, 0, 0, 6, 2, true, true>(a, lds, s);
         if ((variant == "fixed" || variant == "fixedn") && a->nx == 13 && a->nu == 4) return LaunchRiccati<64, 4, 5, 13, 4>(a, lds, s);
         if ((variant == "fixed" || variant == "fixedn") && a->nx == 6 && a->nu == 2) return LaunchRiccati<64, 1, 1, 6, 2>(a, lds, s);
         if (variant == "fixed1" && a->nx == 13 && a->nu == 4) return LaunchRiccati<64, 0, 0, 13, 4>(a, lds, s);

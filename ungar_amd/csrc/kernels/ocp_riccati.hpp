@@ -541,11 +541,11 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
     // Asynchronous copies: the two phases of a knot occupy the first lanes only (nu, nx <= 64), so the OTHER lane groups own the
     // copies -- knot j belongs to owner j % kDmaOwners and lands in buffer j % kDmaOwners of the (now dead) matrix scratch, requested
     // kDmaOwners knots ahead.  (The computing lanes issue no copies: their loads of the gains return in order behind older copies.)
-    constexpr bool dmaForward = dma && NX <= 64 && NU <= 64;
+    constexpr bool dmaForward = dma && NX <= 64 && NU <= 64 && Exec::kLanes > 64;  // needs lane groups beyond the computing one
     // (single lane group, below) three buffers in the dead matrix scratch and a wait counter of six bits bound the sizes it serves
     constexpr int kSelfDepth = 3, selfKnotDoubles = NX * (NX + NU) + NX + NU * (NX + 1);
     constexpr int selfKnotCopies = (NX * (NX + NU) + 31) / 32 + (NX + 31) / 32 + (NU * (NX + 1) + 31) / 32;  // copy instructions of one knot
-    constexpr bool selfForward = !dma && NX > 0 && NX <= 64 && NU <= 64 && RiccatiExecHasSelfDma<Exec>() && (kSelfDepth - 1) * selfKnotCopies <= 63 &&
+    constexpr bool selfForward = !dmaForward && NX > 0 && NX <= 64 && NU <= 64 && RiccatiExecHasSelfDma<Exec>() && (kSelfDepth - 1) * selfKnotCopies <= 63 &&
                                  kSelfDepth * selfKnotDoubles <= 2 * NX * (NX + NU) + (NX + NU) * (NX + NU) + 2 * NX * NX;
     if constexpr (dmaForward) {
         // per knot: [A|B], b and the gains (read back from global memory otherwise: one exposed round trip per knot)
