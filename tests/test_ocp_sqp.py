@@ -232,6 +232,23 @@ def test_device_riccati_equals_the_dense_kkt_solve(nx, nu, N, batch):
     assert np.abs(res).max() <= 1e-9 * max(1.0, np.abs(dX).max())
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("nx,nu", [(13, 4), (13, 24), (37, 12), (4, 2)])
+def test_device_riccati_reports_an_indefinite_reduced_hessian(nx, nu):
+    """Every device instantiation (register Cholesky, L D L^T phases, run-time sizes; one and four wavefronts per instance) reports the
+    knot whose input block is not positive definite for exactly the instance concerned, as the host policy does."""
+    import torch
+    from ungar_amd import sqp
+    rng = np.random.default_rng(3)
+    N, batch = 7, 5
+    q = random_qp(rng, nx, nu, N, batch)
+    q["W"][3, 4] = -np.eye(nx + nu) * 50.0  # knot 4 of instance 3: concave in the inputs
+    dev = lambda a: torch.as_tensor(a, device="cuda")  # noqa: E731
+    _, _, st = sqp.riccati_solve(nx, nu, N, batch, dev(q["AB"]), dev(q["b"]), dev(q["W"]), dev(q["w"]), dev(q["dx0"]), dev(q["WN"]), dev(q["wN"]))
+    torch.cuda.synchronize()
+    assert st.cpu().tolist() == [0, 0, 0, 5, 0]
+
+
 def _quadrotor_problem(batch, N, seed, torch):
     """Random-but-reasonable instances of the quadrotor OCP: states near hover, references 1 m away, inputs around hover speed."""
     rng = np.random.default_rng(seed)

@@ -413,30 +413,38 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
             // (2 nu + 1 phases; the left-looking column-by-column Cholesky + one right-hand side per lane it replaces ran nu-long
             // dependent chains of LDS round trips on at most nu lanes: 187 k cycles per knot for the 13 + 24 block of the reference's
             // quadruped OCP.)  The strict lower triangle of R holds the UNSCALED columns L[i][j] d_j afterwards.
-            ex.ForEach(nu * nk, [&](int idx) {
-                const int i = idx / nk, c = idx % nk;
-                K[idx] = c < nx ? -H[(nx + i) * n + c] : -h[nx + i];
+            // The reciprocal of pivot j is produced one phase EARLY, by the lane that finishes the diagonal entry (j, j) in phase j - 1
+            // (column 0: with the right-hand sides below): a phase then starts from an LDS read instead of every lane's own
+            // double-precision division.  A pivot that is not positive is replaced by 1 and reported; every participating lane
+            // sees it (they all read d_j), so the first lane -- which writes the status -- does.
+            ex.ForEach(nu * nk + 1, [&](int idx) {
+                if (idx < nu * nk) {
+                    const int i = idx / nk, c = idx % nk;
+                    K[idx] = c < nx ? -H[(nx + i) * n + c] : -h[nx + i];
+                } else {
+                    const double d0 = H[nx * n + nx];
+                    piv[0] = 1.0 / (d0 > 0.0 ? d0 : 1.0);
+                }
             });
-            // The reciprocal of a pivot is computed once (piv) and multiplied with afterwards.
             auto forwardColumn = [&](int j) {
                 const int rest = nu - 1 - j;
                 const float restInv = rest > 0 ? 1.0f / static_cast<float>(rest) : 0.0f;
                 ex.ForEach(rest * rest + rest * nk + 1, [&](int idx) {
-                    const double dj = H[(nx + j) * n + nx + j];
-                    const bool bad = !(dj > 0.0);
-                    const double rd = 1.0 / (bad ? 1.0 : dj);
+                    if (!(H[(nx + j) * n + nx + j] > 0.0)) failed = failed ? failed : k + 1;
+                    const double rd = piv[j];
                     if (idx < rest * rest) {  // trailing block, entries (i, k2) with j < k2 <= i (the square index space is cheaper to decode than the triangle)
                         // quotient by the run-time `rest` through a float reciprocal: exact here (idx + 0.5 is never a multiple of rest, the
                         // operands are far below 2^20), and an integer division costs ~30 instructions per item
                         const int qi = static_cast<int>((static_cast<float>(idx) + 0.5f) * restInv);
                         const int i = j + 1 + qi, k2 = j + 1 + (idx - qi * rest);
-                        if (k2 <= i) H[(nx + i) * n + nx + k2] -= H[(nx + i) * n + nx + j] * H[(nx + k2) * n + nx + j] * rd;
+                        if (k2 <= i) {
+                            const double v = H[(nx + i) * n + nx + k2] - H[(nx + i) * n + nx + j] * H[(nx + k2) * n + nx + j] * rd;
+                            H[(nx + i) * n + nx + k2] = v;
+                            if (i == j + 1) piv[j + 1] = 1.0 / (v > 0.0 ? v : 1.0);  // (k2 == i == j + 1: the next pivot is final)
+                        }
                     } else if (idx < rest * rest + rest * nk) {
                         const int e = idx - rest * rest, i = j + 1 + e / nk, c = e % nk;
                         K[i * nk + c] -= H[(nx + i) * n + nx + j] * rd * K[j * nk + c];
-                    } else {
-                        piv[j] = rd;
-                        if (bad) failed = failed ? failed : k + 1;
                     }
                 });
             };
