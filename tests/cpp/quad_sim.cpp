@@ -107,3 +107,11 @@ extern "C" void anymal_quad_sim_sparse(const double* x, const double* u, const d
     io.Jsparse = Jsparse;
     ungar_amd::gen::anymal_quad::ValueJacobianQuad<Quad>(io);
 }
+
+/// The value-only program (the value sinks of the same recording): what forward_zero launches for this model.
+extern "C" void anymal_quad_sim_value(const double* x, const double* u, const double* p, double* f) {
+    for (int i = 0; i < 37; ++i) f[i] = NAN;
+    double unused[1] = {0.0};
+    SimIO io{x, u, p, f, unused};
+    ungar_amd::gen::anymal_quad::ValueQuad<Quad>(io);
+}

@@ -36,6 +36,21 @@ def test_quad_program_matches_golden(repo_root, sim):
         assert np.abs(J - g["J"][b]).max() <= 1e-10 * np.abs(g["J"][b]).max()
 
 
+def test_value_only_quad_program_matches_golden_and_the_full_program(repo_root, sim):
+    """forward_zero of the 'anymal' model runs the value sinks of the same recording (2.2 k statements per lane): every value written,
+    equal to the golden vectors and bit-identical to the values the value + Jacobian program produces."""
+    g = np.load(f"{repo_root}/tests/golden/node_anymal.npz")
+    dp = ctypes.POINTER(ctypes.c_double)
+    for b in range(g["x"].shape[0]):
+        x, u, p = (np.ascontiguousarray(g[k][b]) for k in ("x", "u", "p"))
+        f, f2, J = np.zeros(37), np.zeros(37), np.zeros((37, 49))
+        sim.anymal_quad_sim_value(x.ctypes.data_as(dp), u.ctypes.data_as(dp), p.ctypes.data_as(dp), f.ctypes.data_as(dp))
+        sim.anymal_quad_sim(x.ctypes.data_as(dp), u.ctypes.data_as(dp), p.ctypes.data_as(dp), f2.ctypes.data_as(dp), J.ctypes.data_as(dp))
+        assert not np.isnan(f).any()
+        assert np.abs(f - g["f"][b]).max() <= 1e-11 * max(1.0, np.abs(g["f"][b]).max())
+        assert np.array_equal(f, f2)
+
+
 def test_quad_program_sparse_addressing(repo_root, sim):
     """Every Jacobian sink also carries its CSR index per lane; the values collected that way must be the
     dense block gathered through the committed sparsity pattern, with every pattern entry written."""

@@ -572,7 +572,18 @@ int main(int argc, char** argv) {
                     std::snprintf(buf, sizeof buf, "    {%.17g, %.17g, %.17g, %.17g},\n", c[0], c[1], c[2], c[3]);
                     qo << buf;
                 }
-                qo << "};\n#endif\n\n" << fn << "\n}  // namespace ungar_amd::gen::anymal_quad\n";
+                // value only: the same recorded program with the value sinks alone (everything the Jacobian columns need is unreachable
+                // from them and is not emitted): what forward_zero and the SQP's stacked line search launch for this model
+                codegen::QuadProgram qv = qp;
+                qv.slots.clear();
+                qv.phaseStarts.clear();
+                for (const auto& sl : qp.slots)
+                    if (sl.sink.rfind("io.f_base(", 0) == 0 || sl.sink.rfind("io.f_leg(", 0) == 0) qv.slots.push_back(sl);
+                tape::EmitStats vs;
+                const std::string fnValue = codegen::EmitQuadProgram(qv, "ValueQuad", &vs, false);
+                qo << "};\n#endif\n\n" << fn << "\n// value only: " << vs.statements << " statements, " << vs.flops << " flops per lane\n" << fnValue
+                   << "\n}  // namespace ungar_amd::gen::anymal_quad\n";
+                std::fprintf(stderr, "[codegen] anymal_quad value only: %zu statements, %zu flops per lane\n", vs.statements, vs.flops);
                 std::ofstream qf(outDir + "/anymal_quad_gen.hpp");
                 qf << qo.str();
                 std::fprintf(stderr, "[codegen] anymal_quad (lane per leg): %zu statements, %zu flops per lane, %zu table constants\n", qs.statements, qs.flops,

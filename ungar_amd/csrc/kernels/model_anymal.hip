@@ -17,6 +17,12 @@ struct AnymalQuadBody {
     template <class IO>
     __device__ __forceinline__ void operator()(IO& io) const { gen::anymal_quad::ValueJacobianQuad<double>(io); }
 };
+/// Value only (forward_zero; the SQP's stacked line search): the value sinks of the same lane-per-leg program, 2.2 k statements per
+/// lane instead of the 7.3 k-statement lane-per-node body (1.4 KB of scratch per lane).
+struct AnymalQuadValueBody {
+    template <class IO>
+    __device__ __forceinline__ void operator()(IO& io) const { gen::anymal_quad::ValueQuad<double>(io); }
+};
 }  // namespace ungar_amd::kernels
 
 extern "C" int ungar_amd_launch_anymal_quad_sparse(const ungar_amd::kernels::NodeLaunch* a, void* stream);  // quad_anymal_sparse.hip
@@ -29,6 +35,17 @@ extern "C" int ungar_amd_launch_anymal(int mode, const ungar_amd::kernels::NodeL
     // with a negative element stride are left to the lane-per-node kernel
     const bool jacobian = mode == kModeDenseJacobian || mode == kModeSparseJacobian;
     if (jacobian && !QuadOffsetsFit32(*a) && a->jac.es >= 0) return ungar_amd_launch_anymal_quad_wide(mode, a, stream);
+    static const bool laneValue = getenv("UNGAR_AMD_ANYMAL_VALUE_LANE_PER_NODE") != nullptr;  // A/B switch (tools/bench_anymal_value.py)
+    if (mode == kModeValue && !laneValue) {
+        if (a->count <= 0 || !a->f.base) return 0;
+        void* vsym = nullptr;
+        const hipError_t ve = hipGetSymbolAddress(&vsym, HIP_SYMBOL(ungar_amd::gen::anymal_quad::kLegConstantsDev));
+        if (ve != hipSuccess) return static_cast<int>(ve);
+        const dim3 vgrid(static_cast<unsigned>((a->count + 15) / 16)), vblock(64);
+        hipLaunchKernelGGL((QuadNodeKernel<64, 0, 0, false, false, AnymalQuadValueBody>), vgrid, vblock, 0, static_cast<hipStream_t>(stream), *a,
+                           static_cast<const double(*)[4]>(vsym), AnymalQuadValueBody{});
+        return static_cast<int>(hipGetLastError());
+    }
     const bool quadOk = jacobian && QuadOffsetsFit32(*a);
     if (quadOk && mode == kModeSparseJacobian) return ungar_amd_launch_anymal_quad_sparse(a, stream);
     if (!quadOk) return static_cast<int>(LaunchNodeModel<Model_anymal, 64>(mode, *a, static_cast<hipStream_t>(stream)));
