@@ -253,6 +253,35 @@ def test_full_size_launch_against_the_c_checker_on_every_node(ua, repo_root, nam
     assert not Jh[:, off].any()  # structural zeros are exact zeros in every block
 
 
+def test_anymal_value_only_program_layouts_and_ragged_counts(ua):
+    """forward_zero of the 'anymal' model runs the lane-per-leg VALUE program (16 nodes per wavefront): a count that is not a multiple of
+    16, both device layouts, knots > 1 -- bit-identical among themselves and equal to the values the value + Jacobian kernel writes up to
+    the rounding of differently contracted multiply-adds (the two bodies are compiled separately; in the 4-lane simulator they agree bit
+    for bit, tests/test_quad_program.py)."""
+    import torch
+    m = ua.NodeModel("anymal")
+    batch, N = 331, 3
+    count = batch * N  # 993 = 62 * 16 + 1
+    x, u, p = _device_inputs("anymal", count, seed=31)
+    P = ua.Operand.per_instance(p, m.np, shared=True)
+    f_ref = torch.empty((m.nx, count), dtype=torch.float64, device="cuda")
+    J = torch.empty((m.nx * (m.nx + m.nu), count), dtype=torch.float64, device="cuda")
+    m.dense_jacobian(count, ua.Operand.soa(x, count), ua.Operand.soa(u, count), None, P, ua.Operand.soa(f_ref, count), ua.Operand.soa(J, count))
+    f = torch.full((m.nx, count + 7), float("nan"), dtype=torch.float64, device="cuda")
+    m.forward_zero(count, ua.Operand.soa(x, count), ua.Operand.soa(u, count), None, P, ua.Operand.soa(f, count + 7))
+    assert ((f[:, :count] - f_ref).abs().max() <= 1e-11 * f_ref.abs().max().clamp(min=1.0)).item()
+    assert torch.isnan(f[:, count:]).all()  # nothing written past the last node
+    f_ref = f[:, :count].clone()
+    xa, ua_ = x.t().contiguous(), u.t().contiguous()
+    fa = torch.empty((count, m.nx), dtype=torch.float64, device="cuda")
+    m.forward_zero(count, ua.Operand.aos(xa, m.nx), ua.Operand.aos(ua_, m.nu), None, P, ua.Operand.aos(fa, m.nx))
+    assert torch.equal(fa.t(), f_ref)
+    fk = torch.empty((batch, N, m.nx), dtype=torch.float64, device="cuda")  # (instance, knot, element) with explicit knot strides
+    m.forward_zero(count, ua.Operand(xa, instance_stride=N * m.nx, knot_stride=m.nx, element_stride=1), ua.Operand(ua_, instance_stride=N * m.nu, knot_stride=m.nu, element_stride=1),
+                   None, P, ua.Operand(fk, instance_stride=N * m.nx, knot_stride=m.nx, element_stride=1), knots=N)
+    assert torch.equal(fk.reshape(count, m.nx).t(), f_ref)
+
+
 def test_structured_and_taped_aba_kernels_agree_at_full_size(ua):
     """'anymal' (implicit differentiation: CRBA + RNEA tangents + U D U^T solves) and 'anymal_ad'
     (derivatives by taping ABA, the reference's route) are different algorithms for the same
