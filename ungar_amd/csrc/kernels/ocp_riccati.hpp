@@ -374,7 +374,7 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
                     const bool neg = !(d > 0.0);
                     bad = bad || neg;
                     L[j][j] = sqrt(neg ? 1.0 : d);
-                    inv[j] = 1.0 / L[j][j];
+                    inv[j] = 1.0 / L[j][j];  // (rsqrt + multiply instead: 37 + 12 QP step 4.80 -> 4.76 ms, 13 + 4 0.82 -> 0.87 ms on the same box: dropped)
 #pragma unroll
                     for (int i = j + 1; i < NU; ++i) {
                         double sv = H[(nx + i) * n + nx + j];
