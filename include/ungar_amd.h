@@ -217,7 +217,7 @@ typedef struct ungar_barrier {
 
 /* Stage data of the QP subproblem from the node kernels' outputs (soft_sqp.hpp:143-155, 247-264 per knot):
  *   b_k = f_k - x_{k+1},   dx0 = x_m - x_0,
- *   hess_k = hess cost_k + J_h^T diag(b''(-h)) J_h   (dense (nx+nu)^2 row-major, upper triangle filled, rest zero),
+ *   hess_k = hess cost_k + J_h^T diag(b''(-h)) J_h   (dense (nx+nu)^2 row-major; the upper triangle is written, the strict lower triangle is left untouched),
  *   grad_k = grad cost_k - J_h^T b'(-h). */
 typedef struct ungar_ocp_stage_qp_args {
     int64_t nx, nu, horizon, batch;

@@ -223,10 +223,11 @@ __global__ __launch_bounds__(256) void StageQpKernel(const StageQpArgs a) {
         }
     }
     __syncthreads();
-    for (int idx = lane; idx < n * n; idx += lanes) {
-        const int r = idx / n, c = idx % n;
+    for (int idx = lane; idx < n * n; idx += lanes) {  // upper triangle only: nobody reads the rest (ungar_ocp_riccati_solve: "upper triangle read"),
+        const int r = idx / n, c = idx % n;            // and writing it was half of this kernel's HBM traffic
+        if (r > c) continue;
         double acc = hc[idx];
-        if (r <= c && ineq)
+        if (ineq)
             for (int j = 0; j < a.nh; ++j) acc += d2[j] * jh[j * n + r] * jh[j * n + c];
         a.hess.at(b, k, idx) = acc;
     }
