@@ -11,7 +11,7 @@
 //       H = W_k + AB^T P AB,   h = w_k + AB^T (P b_k + p)                  (n x n, n = nx + nu)
 //       R = H_uu = L L^T,  [K | kff] = -R^-1 [H_ux | h_u],   P <- H_xx + H_ux^T K,   p <- h_x + H_ux^T kff
 //     forward:  du_k = K_k dx_k + kff_k,  dx_{k+1} = AB [dx_k; du_k] + b_k.
-// One 64-lane workgroup owns one MPC instance: every matrix of the recursion lives in LDS, the lanes share the entries of
+// One workgroup (one wavefront for the small blocks, four for 13 + 24 and 37 + 12) owns one MPC instance: every matrix of the recursion lives in LDS, the lanes share the entries of
 // each product (Exec::ForEach) and meet at workgroup barriers; thousands of instances fill the device.
 //
 // The recursion is written once, generic over an execution policy: DeviceExec (ocp_riccati.hip) strides the lanes of a
@@ -22,6 +22,7 @@
 //   ForEach(n, f)            f(i) for i in [0, n), spread over the lanes, followed by a workgroup barrier on the scratch memory
 //   GlobalSync()             workgroup barrier that also orders the workgroup's global writes before its later global reads
 //   ForEachNoSync(n, f)      the same without the closing barrier (followed by other loops and one Barrier())
+//   kLanes                   lanes that share a ForEach (device: the workgroup size; picks the register tiles of the two large products)
 //   kPrefetch                whether the policy stages a knot's operands in registers (below); without it they are read in place
 //   kAhead                   with kPrefetch: stage the NEXT knot's operands while this one is processed (else: this knot's, at its top)
 //   Stage<SLOTS>             per-lane registers for a strided global read of up to 64 * SLOTS doubles
