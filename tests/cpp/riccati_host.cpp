@@ -197,3 +197,7 @@ extern "C" int riccati_host_solve_variant(int prefetch, int nx, int nu, int N, l
     }
     return 0;
 }
+
+/// The folded-triangle index maps of ocp_riccati.hpp, for tests/test_ocp_sqp.py.
+extern "C" int riccati_folded_index(int n, int r, int c) { return RiccatiFoldedIndex(n, r, c); }
+extern "C" int riccati_folded_source(int n, int i) { return RiccatiFoldedSource(n, i); }

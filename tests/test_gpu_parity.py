@@ -198,9 +198,9 @@ def test_full_size_properties(ua, name):
         assert (f[3:7].norm(dim=0) - 1).abs().max().item() < 1e-12
 
 
-@pytest.mark.parametrize("name", ["anymal", "quadrotor"])
+@pytest.mark.parametrize("name", ["anymal", "quadrotor", "rc_car"])
 def test_full_size_launch_against_the_c_checker_on_every_node(ua, repo_root, name):
-    """BASELINE-size launch (anymal: 81 920 nodes = config 4; quadrotor: 524 288 = config 1), EVERY node compared with the oracle's
+    """BASELINE-size launch (anymal: 81 920 nodes = config 4; quadrotor: 524 288 = config 1; rc_car: 3 276 800 = config 2), EVERY node compared with the oracle's
     generated C (oracle/_gen/*_cg.c, compiled by __graft_entry__.build(); pinned against the independent torch oracle's golden vectors
     by tests/test_codegen_c.py).  The C body is lowered from the same tape as the taped kernels but shares nothing with the launch
     geometry, the lane-per-leg program, the operand addressing or the store path of the kernel under test."""

@@ -201,6 +201,24 @@ def test_counted_waits_of_the_single_wavefront_forward_pass(host, nx, nu):
             assert np.array_equal(out[0][0], dX) and np.array_equal(out[0][1], dU), N
 
 
+@pytest.mark.parametrize("n", [1, 2, 8, 17, 37, 49])
+def test_folded_triangle_index_maps_are_inverse_bijections(host, n):
+    """The upper triangle of a symmetric n x n block is parked in a ((n + 1) / 2) x (n + 1) rectangle (stage Hessian of the next knot,
+    pairs of the cost-to-go update): every (r <= c) has its own cell, the source map inverts the index map, and the only cells without
+    a source are the unused tail of the middle row when n is odd."""
+    cells = ((n + 1) // 2) * (n + 1)
+    seen = {}
+    for r in range(n):
+        for c in range(r, n):
+            i = host.riccati_folded_index(n, r, c)
+            assert 0 <= i < cells and i not in seen
+            seen[i] = (r, c)
+            assert host.riccati_folded_source(n, i) == r * n + c
+    unused = [i for i in range(cells) if i not in seen]
+    assert len(unused) == cells - n * (n + 1) // 2 == ((n + 1) // 2 if n % 2 else 0)
+    assert all(host.riccati_folded_source(n, i) == -1 for i in unused)
+
+
 def test_riccati_reports_an_indefinite_reduced_hessian(host):
     rng = np.random.default_rng(1)
     q = random_qp(rng, 4, 2, 6, 2)
