@@ -6,6 +6,9 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+HERE = os.path.dirname(os.path.abspath(__file__))  # helper modules next to the tests (c_checker.py)
+if HERE not in sys.path:
+    sys.path.insert(0, HERE)
 
 
 def pytest_configure(config):

@@ -63,6 +63,10 @@ def test_config5_shard_and_whole_batch(ua, instances):
     scale = np.abs(rJ).max(axis=(1, 2), keepdims=True)
     assert np.abs(gf - rf).max() <= 1e-10 * max(1.0, np.abs(rf).max())
     assert (np.abs(gJ - rJ) <= 1e-9 * scale).all()
+    # (1b) the whole batch: EVERY one of its 1 310 720 nodes against the oracle's generated C, 81 920 nodes at a time
+    if instances == 65536:
+        from c_checker import compare_launch_with_c_checker
+        compare_launch_with_c_checker("anymal", x, u, p, f, J, count, chunk=81920)
     # (2) a node's result does not depend on the launch it is part of: re-evaluate 4 096 nodes from the middle alone
     lo = (count // 2 // N) * N
     sub = slice(lo, lo + 4096 * 1)

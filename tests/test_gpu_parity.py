@@ -203,54 +203,20 @@ def test_full_size_launch_against_the_c_checker_on_every_node(ua, repo_root, nam
     """BASELINE-size launch (anymal: 81 920 nodes = config 4; quadrotor: 524 288 = config 1; rc_car: 3 276 800 = config 2), EVERY node compared with the oracle's
     generated C (oracle/_gen/*_cg.c, compiled by __graft_entry__.build(); pinned against the independent torch oracle's golden vectors
     by tests/test_codegen_c.py).  The C body is lowered from the same tape as the taped kernels but shares nothing with the launch
-    geometry, the lane-per-leg program, the operand addressing or the store path of the kernel under test."""
-    import ctypes
-    import os
-    from concurrent.futures import ThreadPoolExecutor
-
+    geometry, the lane-per-leg program, the operand addressing or the store path of the kernel under test (tests/c_checker.py)."""
     import torch
-    from oracle import build_oracle
-    path = build_oracle.lib_path("portable")
-    if not os.path.exists(path):
-        pytest.skip("oracle C library not built: run __graft_entry__.build()")
-    clib = ctypes.CDLL(path)
+    from c_checker import compare_launch_with_c_checker
     batch, N = FULL[name]
     count = batch * N
     m = ua.NodeModel(name)
-    nx, nu, ncols = m.nx, m.nu, m.nx + m.nu
+    nx, ncols = m.nx, m.nx + m.nu
     x, u, p = _device_inputs(name, count, seed=23)
     P = ua.Operand.per_instance(p, m.np, shared=True)
     f = torch.empty((nx, count), dtype=torch.float64, device="cuda")
     J = torch.empty((nx * ncols, count), dtype=torch.float64, device="cuda")
     m.dense_jacobian(count, ua.Operand.soa(x, count), ua.Operand.soa(u, count), None, P, ua.Operand.soa(f, count), ua.Operand.soa(J, count))
     torch.cuda.synchronize()
-    xh, uh, ph = np.ascontiguousarray(x.t().cpu().numpy()), np.ascontiguousarray(u.t().cpu().numpy()), np.ascontiguousarray(p.cpu().numpy())
-    fh, Jh = np.ascontiguousarray(f.t().cpu().numpy()), np.ascontiguousarray(J.t().cpu().numpy())
-    nnz = ctypes.c_int.in_dll(clib, f"{name}_jac_nnz").value
-    rows = np.ctypeslib.as_array((ctypes.c_int * nnz).in_dll(clib, f"{name}_jac_row")).astype(np.int64)
-    cols = np.ctypeslib.as_array((ctypes.c_int * nnz).in_dll(clib, f"{name}_jac_col")).astype(np.int64)
-    flat = rows * ncols + cols
-    fn = getattr(clib, f"{name}_sparse_jacobian")
-    dp = ctypes.POINTER(ctypes.c_double)
-    fn.argtypes = [dp] * 6
-    rf, rj = np.empty((count, nx)), np.empty((count, nnz))
-    w0 = np.zeros(1)
-
-    def chunk(lo, hi):  # ctypes releases the GIL inside the call
-        for i in range(lo, hi):
-            fn(xh[i].ctypes.data_as(dp), uh[i].ctypes.data_as(dp), w0.ctypes.data_as(dp), ph.ctypes.data_as(dp), rf[i].ctypes.data_as(dp), rj[i].ctypes.data_as(dp))
-
-    workers = min(16, os.cpu_count() or 1)
-    step = (count + workers - 1) // workers
-    with ThreadPoolExecutor(workers) as pool:
-        list(pool.map(lambda k: chunk(k * step, min(count, (k + 1) * step)), range(workers)))
-    scale_f = max(1.0, np.abs(rf).max())
-    assert np.abs(fh - rf).max() <= 1e-10 * scale_f
-    block_scale = np.abs(rj).max(axis=1, keepdims=True)
-    assert (np.abs(Jh[:, flat] - rj) / block_scale).max() <= 1e-9  # block-relative, as everywhere in this file
-    off = np.ones(nx * ncols, dtype=bool)
-    off[flat] = False
-    assert not Jh[:, off].any()  # structural zeros are exact zeros in every block
+    compare_launch_with_c_checker(name, x, u, p, f, J, count)
 
 
 def test_anymal_value_only_program_layouts_and_ragged_counts(ua):
