@@ -198,6 +198,53 @@ extern "C" int riccati_host_solve_variant(int prefetch, int nx, int nu, int N, l
     return 0;
 }
 
+/// Stage equality rows E_k [dx; du] + e_k = 0 (eq [batch][N][ne*n], eqv [batch][N][ne]) next to the operands above; variant 0: run-time
+/// sizes, 1: run-time sizes with staged operands, 2: the compile-time instantiations of the reference's OCPs with carried quantities
+/// (quadrotor 17 + 4, RC car 8 + 2, quadruped 25 + 24 with 16 foot-contact rows), 3 / 4: those under the asynchronous-copy protocol.
+extern "C" int riccati_host_solve_eq(int variant, int nx, int nu, int ne, int N, long long batch, double* jac, double* b, double* hess, double* grad, double* hessN, int hessNld,
+                                     double* gradN, double* dx0, double* eq, double* eqv, double regularization, double* dX, double* dU, int* status) {
+    const int n = nx + nu;
+    std::vector<double> gains(static_cast<std::size_t>(batch) * N * nu * (nx + 1));
+    const int ldN = hessNld > 0 ? hessNld : nx;
+    RiccatiArgs a{nx, nu, N, batch,
+                  {jac, static_cast<long long>(N) * nx * n, static_cast<long long>(nx) * n, 1},
+                  {b, static_cast<long long>(N) * nx, nx, 1},
+                  {hess, static_cast<long long>(N) * n * n, static_cast<long long>(n) * n, 1},
+                  {grad, static_cast<long long>(N) * n, n, 1},
+                  {hessN, static_cast<long long>(nx) * ldN, 0, 1},
+                  {gradN, nx, 0, 1},
+                  {dx0, nx, 0, 1},
+                  {dX, static_cast<long long>(N + 1) * nx, nx, 1},
+                  {dU, static_cast<long long>(N) * nu, nu, 1},
+                  gains.data(), regularization, status};
+    a.ne = ne;
+    a.eq = {eq, static_cast<long long>(N) * ne * n, static_cast<long long>(ne) * n, 1};
+    a.eqv = {eqv, static_cast<long long>(N) * ne, ne, 1};
+    a.hessNld = hessNld;
+    std::vector<double> scratch(static_cast<std::size_t>(RiccatiScratchDoubles(nx, nu, ne)));
+    auto fixed = [&](auto ex) {
+        using E = decltype(ex);
+        for (long long i = 0; i < batch; ++i) {
+            if (nx == 17 && nu == 4 && ne == 0) RiccatiInstance<E, 17, 4, 0>(a, i, scratch.data(), ex);
+            else if (nx == 8 && nu == 2 && ne == 0) RiccatiInstance<E, 8, 2, 0>(a, i, scratch.data(), ex);
+            else if (nx == 25 && nu == 24 && ne == 16) RiccatiInstance<E, 25, 24, 16>(a, i, scratch.data(), ex);
+            else return 1;
+        }
+        return 0;
+    };
+    if (variant == 2) return fixed(HostExec<false>{});
+    if (variant == 3) return fixed(HostDmaExec<false>{});
+    if (variant == 4) return fixed(HostDmaExec<true>{});
+    if (variant == 1) {
+        HostExec<true> ex;
+        for (long long i = 0; i < batch; ++i) RiccatiInstance(a, i, scratch.data(), ex);
+    } else {
+        HostExec<false> ex;
+        for (long long i = 0; i < batch; ++i) RiccatiInstance(a, i, scratch.data(), ex);
+    }
+    return 0;
+}
+
 /// The folded-triangle index maps of ocp_riccati.hpp, for tests/test_ocp_sqp.py.
 extern "C" int riccati_folded_index(int n, int r, int c) { return RiccatiFoldedIndex(n, r, c); }
 extern "C" int riccati_folded_source(int n, int i) { return RiccatiFoldedSource(n, i); }

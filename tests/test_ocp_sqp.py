@@ -23,8 +23,9 @@ from oracle import ungar_oracle as O
 
 
 # ------------------------------------------------------------------------------------------------ numpy reference pieces
-def kkt_dense(nx, nu, N, AB, b, W, w, dx0, reg, WN=None, wN=None):
-    """Dense solve of  min 1/2 d^T H d + g^T d  s.t.  dx_0 = dx0, dx_{k+1} = A dx_k + B du_k + b_k  (one instance)."""
+def kkt_dense(nx, nu, N, AB, b, W, w, dx0, reg, WN=None, wN=None, E=None, e=None):
+    """Dense solve of  min 1/2 d^T H d + g^T d  s.t.  dx_0 = dx0, dx_{k+1} = A dx_k + B du_k + b_k  (one instance); optional stage
+    equality rows E_k [dx_k; du_k] + e_k = 0 (rows that are identically zero are dropped, as OSQP's l = A x = u leaves them inert)."""
     n, nz = nx + nu, (N + 1) * nx + N * nu
     H, g = np.zeros((nz, nz)), np.zeros(nz)
     xs = lambda k: np.arange(k * nx, (k + 1) * nx)  # noqa: E731
@@ -49,6 +50,18 @@ def kkt_dense(nx, nu, N, AB, b, W, w, dx0, reg, WN=None, wN=None):
         A[np.ix_(r, xs(k))] = -AB[k][:, :nx]
         A[np.ix_(r, us(k))] = -AB[k][:, nx:]
         c[r] = b[k]
+    if E is not None:
+        rows, vals = [], []
+        for k in range(N):
+            for j in range(E[k].shape[0]):
+                if np.any(E[k][j] != 0.0):
+                    row = np.zeros(nz)
+                    row[np.r_[xs(k), us(k)]] = E[k][j]
+                    rows.append(row)
+                    vals.append(-e[k][j])
+        if rows:
+            A, c = np.vstack([A, np.array(rows)]), np.r_[c, vals]
+            m = A.shape[0]
     sol = np.linalg.solve(np.block([[H, A.T], [A, np.zeros((m, m))]]), np.r_[-g, c])
     return sol[:(N + 1) * nx].reshape(N + 1, nx), sol[(N + 1) * nx:nz].reshape(N, nu)
 
@@ -112,6 +125,75 @@ def test_riccati_recursion_equals_the_dense_kkt_solve(host, nx, nu, N):
             # the solution satisfies the linearised dynamics exactly (feasibility of the QP's equality constraints)
             for k in range(N):
                 assert np.abs(dX[i, k + 1] - q["AB"][i, k] @ np.r_[dX[i, k], dU[i, k]] - q["b"][i, k]).max() < 1e-10 * max(1.0, np.abs(dX[i]).max())
+
+
+def solve_host_eq(lib, variant, nx, nu, ne, N, q, reg, terminal_ld=0):
+    batch = q["AB"].shape[0]
+    dX, dU, st = np.zeros((batch, N + 1, nx)), np.zeros((batch, N, nu)), np.zeros(batch, dtype=np.int32)
+    dp = ctypes.POINTER(ctypes.c_double)
+    p = lambda a: a.ctypes.data_as(dp)  # noqa: E731
+    WN = q["WN"]
+    if terminal_ld:  # the terminal block as the leading nx x nx part of a wider row-major block
+        wide = np.zeros((batch, nx, terminal_ld))
+        wide[:, :, :nx] = WN
+        WN = np.ascontiguousarray(wide)
+    rc = lib.riccati_host_solve_eq(variant, nx, nu, ne, N, ctypes.c_longlong(batch), p(q["AB"]), p(q["b"]), p(q["W"]), p(q["w"]), p(WN), terminal_ld, p(q["wN"]), p(q["dx0"]),
+                                   p(q["E"]), p(q["e"]), ctypes.c_double(reg), p(dX), p(dU), st.ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
+    assert rc == 0
+    return dX, dU, st
+
+
+def random_eq_rows(rng, nx, nu, ne, N, batch, zero_fraction=0.3):
+    """Stage equality rows with a state part and an input part of full row rank; a fraction of the rows is identically zero
+    (an inactive contact: coefficient 0 times the Jacobian row, quadruped.example.cpp:301-302)."""
+    n = nx + nu
+    E = rng.normal(size=(batch, N, ne, n))
+    e = rng.normal(size=(batch, N, ne)) * 0.1
+    off = rng.random(size=(batch, N, ne)) < zero_fraction
+    E[off] = 0.0
+    e[off] = 0.0
+    return np.ascontiguousarray(E), np.ascontiguousarray(e)
+
+
+@pytest.mark.parametrize("nx,nu,ne,N", [(5, 4, 2, 6), (13, 24, 12, 5), (25, 24, 16, 4), (7, 3, 3, 9)])
+def test_riccati_with_stage_equality_rows_equals_the_dense_kkt_solve(host, nx, nu, ne, N):
+    """Stage equality rows E_k [dx; du] + e_k = 0 (the foot-contact rows of the reference's quadruped OCP, quadruped.example.cpp:279-304, are
+    hard equalities of its QP, soft_sqp.hpp:155-157): the recursion eliminates the stage KKT block [R D^T; D 0] and must reproduce the dense
+    solve of the whole KKT system, rows that are identically zero included; the terminal block may be the corner of a wider one."""
+    rng = np.random.default_rng(1000 * nx + 10 * nu + ne)
+    q = random_qp(rng, nx, nu, N, 3)
+    q["E"], q["e"] = random_eq_rows(rng, nx, nu, ne, N, 3)
+    for variant, ld in ((0, 0), (1, nx + nu)):
+        dX, dU, st = solve_host_eq(host, variant, nx, nu, ne, N, q, 1e-6, ld)
+        assert (st == 0).all()
+        for i in range(3):
+            rX, rU = kkt_dense(nx, nu, N, q["AB"][i], q["b"][i], q["Wfull"][i], q["w"][i], q["dx0"][i], 1e-6, q["WN"][i], q["wN"][i], q["E"][i], q["e"][i])
+            scale = max(1.0, np.abs(rX).max(), np.abs(rU).max())
+            assert np.abs(dX[i] - rX).max() <= 2e-9 * scale and np.abs(dU[i] - rU).max() <= 2e-9 * scale
+            for k in range(N):  # the rows hold along the solution
+                r = q["E"][i, k] @ np.r_[dX[i, k], dU[i, k]] + q["e"][i, k]
+                assert np.abs(r).max() <= 1e-9 * scale
+
+
+@pytest.mark.parametrize("nx,nu,ne", [(17, 4, 0), (8, 2, 0), (25, 24, 16)])
+def test_fixed_size_instantiations_with_carried_quantities(host, nx, nu, ne):
+    """The instantiations for the reference's OCPs once the carried quantities (previous input, previous foot positions) are part of
+    the stage state -- 17 + 4, 8 + 2, 25 + 24 with 16 contact rows -- agree with the run-time-sized recursion, also under both extreme
+    schedules of the asynchronous operand copies."""
+    rng = np.random.default_rng(77 + nx)
+    N = 5
+    q = random_qp(rng, nx, nu, N, 2)
+    q["E"], q["e"] = random_eq_rows(rng, nx, nu, max(ne, 1), N, 2)  # (ne == 0: the arrays are not read)
+    ref = solve_host_eq(host, 0, nx, nu, ne, N, q, 1e-6)
+    assert (ref[2] == 0).all()
+    fixed = solve_host_eq(host, 2, nx, nu, ne, N, q, 1e-6)
+    scale = max(1.0, np.abs(ref[0]).max(), np.abs(ref[1]).max())
+    assert np.abs(fixed[0] - ref[0]).max() <= 1e-9 * scale and np.abs(fixed[1] - ref[1]).max() <= 1e-9 * scale
+    for variant in (3, 4):
+        out = solve_host_eq(host, variant, nx, nu, ne, N, q, 1e-6)
+        assert np.abs(out[0] - fixed[0]).max() <= 1e-9 * scale and np.abs(out[1] - fixed[1]).max() <= 1e-9 * scale
+    a, b = solve_host_eq(host, 3, nx, nu, ne, N, q, 1e-6), solve_host_eq(host, 4, nx, nu, ne, N, q, 1e-6)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
 
 
 def test_prefetching_variant_is_bitwise_the_same_recursion(host):

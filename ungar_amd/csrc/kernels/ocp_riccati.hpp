@@ -79,14 +79,22 @@ struct RiccatiArgs {
     double* gains;      // workspace: batch * N * nu * (nx + 1) doubles (feedback gains and feed-forward terms)
     double regularization;  // added to the diagonal of every H and of P_N (the reference's 1e-6 I, soft_sqp.hpp:149-151)
     int* status;        // per instance: 0 ok, k+1 = R_k not positive definite at knot k (may be null)
+    // Stage equality rows  E_k [dx_k; du_k] + e_k = 0  (k < N; the foot-contact rows of example/mpc/quadruped.example.cpp:279-304 enter the
+    // reference's QP as hard equalities next to the dynamics, soft_sqp.hpp:155-157).  ne rows per node, dense row-major ne x (nx+nu); a row
+    // that is identically zero (an inactive contact) is skipped; the input parts of the other rows must be linearly independent.
+    int ne = 0;
+    RiccatiView eq{nullptr, 0, 0, 0};   // ne x (nx+nu) per node
+    RiccatiView eqv{nullptr, 0, 0, 0};  // ne per node
+    int hessNld = 0;    // leading dimension of hessN (0: nx) -- lets the terminal block be the leading nx x nx part of a wider stage block
 };
 
 /// Doubles of LDS (or host scratch) one instance needs.
-UNGAR_HD inline int RiccatiScratchDoubles(int nx, int nu) {
+UNGAR_HD inline int RiccatiScratchDoubles(int nx, int nu, int ne = 0) {
     const int n = nx + nu;
-    return nx * n /*AB*/ + n * n /*H*/ + 2 * nx * nx /*P, Pn*/ + nx * n /*PAB*/ + 2 * nx /*p, pn*/ + nx /*t*/ + n /*h*/ + nx /*bk*/ + nu * (nx + 1) /*K|kff*/ +
-           nx + nu /*dx, du*/ + nx /*dxn*/ + nu /*Cholesky pivots*/ + n /*next knot's stage gradient (kDma)*/ +
-           (((n + 1) / 2) * (n + 1) > nx * nx ? ((n + 1) / 2) * (n + 1) : 0) /*next knot's folded stage Hessian where the retired cost-to-go buffer is too small (kDma)*/;
+    return nx * n /*AB*/ + n * n /*H*/ + 2 * nx * nx /*P, Pn*/ + nx * n /*PAB*/ + 2 * nx /*p, pn*/ + nx /*t*/ + n /*h*/ + nx /*bk*/ + (nu + ne) * (nx + 1) /*K|kff (and the multiplier feedback)*/ +
+           nx + nu /*dx, du*/ + nx /*dxn*/ + nu + ne /*pivots*/ + n /*next knot's stage gradient (kDma)*/ +
+           (((n + 1) / 2) * (n + 1) > nx * nx ? ((n + 1) / 2) * (n + 1) : 0) /*next knot's folded stage Hessian where the retired cost-to-go buffer is too small (kDma)*/ +
+           ne * (n + ne) + ne /*equality rows [C | D | 0] and their values*/;
 }
 
 /// Register tile of the two large products: the smallest one with which all tiles of a rows x cols product fit the lanes of the
@@ -139,9 +147,11 @@ UNGAR_HD inline void RiccatiMark(Exec& ex, int id) {
 /// The whole recursion for instance `inst`; `scratch` holds RiccatiScratchDoubles(nx, nu) doubles private to the workgroup.
 /// NX / NU > 0 fix the sizes at compile time (the index arithmetic -- a division and a remainder by nx + nu per matrix entry --
 /// and the short inner products then cost a fraction of the generic code, which is issue-bound on them); 0 = read them from `a`.
-template <class Exec, int NX = 0, int NU = 0>
+/// NE: equality rows per knot for the compile-time sizes (with NX == 0 they are read from `a` as well).
+template <class Exec, int NX = 0, int NU = 0, int NE = 0>
 UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scratch, Exec& ex) {
     const int nx = NX > 0 ? NX : a.nx, nu = NU > 0 ? NU : a.nu, n = nx + nu, N = a.N, nk = nx + 1;
+    const int ne = NX > 0 ? NE : a.ne, nuE = nu + ne, ldq = n + ne;  // (u, lambda) block of the stage KKT matrix: rows / columns nx .. nx + nuE - 1
     double* AB = scratch;
     double* H = AB + nx * n;
     double* P = H + n * n;
@@ -153,12 +163,41 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
     double* h = t + nx;
     double* bk = h + n;
     double* K = bk + nx;  // nu x (nx + 1): [K | kff]
-    double* dx = K + nu * nk;
+    double* dx = K + nuE * nk;
     double* du = dx + nx;
     double* dxn = du + nu;
     double* piv = dxn + nx;  // diagonal of the Cholesky factor of R
-    double* wn = piv + nu;   // kDma: stage gradient of the next knot
+    double* wn = piv + nuE;  // kDma: stage gradient of the next knot
     double* wf = wn + n;     // kDma: folded stage Hessian of the next knot, for sizes where it does not fit the retired cost-to-go buffer
+    double* Eq = wf + (((n + 1) / 2) * (n + 1) > nx * nx ? ((n + 1) / 2) * (n + 1) : 0);  // ne x (n + ne): [C | D | 0], eliminated in place with R
+    double* ev = Eq + ne * ldq;
+    // Row i of the (u, lambda) block and of its couplings: entry (i, j) at rowOf(i)[nx + j], the state coupling (H_ux or C) at rowOf(i)[c], c < nx.
+    auto rowOf = [&](int i) -> double* {
+        if constexpr (NX > 0 && NE == 0) return H + (nx + i) * n;
+        else return i < nu ? H + (nx + i) * n : Eq + (i - nu) * ldq;
+    };
+    auto rhsOf = [&](int i) -> double {  // affine term of row i: h_u or e
+        if constexpr (NX > 0 && NE == 0) return h[nx + i];
+        else return i < nu ? h[nx + i] : ev[i - nu];
+    };
+    // Pivot j of the L D L^T: positive in the input block; negative in the multiplier block (minus a Schur complement D R^-1 D^T),
+    // or EXACTLY zero for a row that is identically zero -- such a row is skipped (reciprocal 0: it neither updates nor is updated).
+    auto pivotReciprocal = [&](double d, int j) -> double {
+        if (j < nu) return 1.0 / (d > 0.0 ? d : 1.0);
+        return d < 0.0 ? 1.0 / d : 0.0;
+    };
+    auto pivotBad = [&](double d, int j) -> bool { return j < nu ? !(d > 0.0) : !(d <= 0.0); };
+    auto loadEqualityRows = [&](int k) {  // (no closing barrier)
+        if (ne > 0)
+            ex.ForEachNoSync(ne * ldq + ne, [&](int idx) {
+                if (idx < ne * ldq) {
+                    const int j = idx / ldq, c = idx - j * ldq;
+                    Eq[idx] = c < n ? a.eq.at(inst, k, j * n + c) : 0.0;
+                } else {
+                    ev[idx - ne * ldq] = a.eqv.at(inst, k, idx - ne * ldq);
+                }
+            });
+    };
     double* gains = a.gains + inst * static_cast<long long>(N) * nu * nk;
     int failed = 0;
     // Asynchronous operand copies (policies with kDma, compile-time sizes).  The stage Hessian of the next knot is parked, folded,
@@ -178,7 +217,8 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
     ex.ForEach(nx * nx, [&](int idx) {
         const int i = idx / nx, j = idx % nx;
         double v = 0.0;
-        if (a.hessN.base) v = i <= j ? a.hessN.at(inst, 0, i * nx + j) : a.hessN.at(inst, 0, j * nx + i);
+        const int ldN = a.hessNld > 0 ? a.hessNld : nx;
+        if (a.hessN.base) v = i <= j ? a.hessN.at(inst, 0, i * ldN + j) : a.hessN.at(inst, 0, j * ldN + i);
         P[idx] = v + (i == j ? a.regularization : 0.0);
     });
     ex.ForEach(nx, [&](int i) { p[i] = a.gradN.base ? a.gradN.at(inst, 0, i) : 0.0; });
@@ -233,11 +273,17 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
                 ex.ForEachNoSync(n * n, [&](int idx) { H[idx] = a.hess.at(inst, k, idx); });
                 ex.ForEachNoSync(n, [&](int idx) { h[idx] = a.grad.at(inst, k, idx); });
             }
+            loadEqualityRows(k);
             ex.Barrier();
         } else if constexpr (ahead) {
             if (k > 0) fetchKnot(k - 1);  // in flight while knot k is processed
+            if (ne > 0) {
+                loadEqualityRows(k);
+                ex.Barrier();
+            }
         } else if constexpr (Exec::kPrefetch) {
             fetchKnot(k);
+            loadEqualityRows(k);
             commitKnot();
         } else {
             // one loop per operand, ONE barrier: inside a loop every iteration is `LDS[i] = global[i]`, which the compiler unrolls into
@@ -247,6 +293,7 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
             ex.ForEachNoSync(n * n, [&](int idx) { H[idx] = a.hess.at(inst, k, idx); });
             ex.ForEachNoSync(n, [&](int idx) { h[idx] = a.grad.at(inst, k, idx); });
             ex.ForEachNoSync(nx, [&](int idx) { bk[idx] = a.b.at(inst, k, idx); });
+            loadEqualityRows(k);
             ex.Barrier();
         }
         RiccatiMark(ex, 1);  // operands of the knot
@@ -360,7 +407,7 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
         if constexpr (dma) {
             if (k > 0) dmaAfterH(k - 1);
         }
-        if constexpr (NU > 0 && NU <= 12) {
+        if constexpr (NU > 0 && NU <= 12 && NE == 0) {
             // Input dimension <= 12 fixed at compile time: every lane factorises R = H_uu = L L^T itself, in registers (NU^3 / 6
             // multiply-adds from NU (NU + 1) / 2 LDS reads), and goes straight on to its right-hand side of
             // [K | kff] = -R^-1 [H_ux | h_u] -- one phase instead of NU + 1 (a barrier and an LDS round trip per Cholesky column).
@@ -418,20 +465,22 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
             // (column 0: with the right-hand sides below): a phase then starts from an LDS read instead of every lane's own
             // double-precision division.  A pivot that is not positive is replaced by 1 and reported; every participating lane
             // sees it (they all read d_j), so the first lane -- which writes the status -- does.
-            ex.ForEach(nu * nk + 1, [&](int idx) {
-                if (idx < nu * nk) {
+            // With equality rows the block is the stage KKT matrix [R D^T; D 0] of order nuE = nu + ne, eliminated in the same order
+            // (quasi-definite: positive pivots, then negative ones; exactly-zero rows skipped): rows nu.. of K then hold the multiplier
+            // feedback, which enters the cost-to-go below and is not stored.
+            ex.ForEach(nuE * nk + 1, [&](int idx) {
+                if (idx < nuE * nk) {
                     const int i = idx / nk, c = idx % nk;
-                    K[idx] = c < nx ? -H[(nx + i) * n + c] : -h[nx + i];
+                    K[idx] = c < nx ? -rowOf(i)[c] : -rhsOf(i);
                 } else {
-                    const double d0 = H[nx * n + nx];
-                    piv[0] = 1.0 / (d0 > 0.0 ? d0 : 1.0);
+                    piv[0] = pivotReciprocal(rowOf(0)[nx], 0);
                 }
             });
             auto forwardColumn = [&](int j) {
-                const int rest = nu - 1 - j;
+                const int rest = nuE - 1 - j;
                 const float restInv = rest > 0 ? 1.0f / static_cast<float>(rest) : 0.0f;
                 ex.ForEach(rest * rest + rest * nk + 1, [&](int idx) {
-                    if (!(H[(nx + j) * n + nx + j] > 0.0)) failed = failed ? failed : k + 1;
+                    if (pivotBad(rowOf(j)[nx + j], j)) failed = failed ? failed : k + 1;
                     const double rd = piv[j];
                     if (idx < rest * rest) {  // trailing block, entries (i, k2) with j < k2 <= i (the square index space is cheaper to decode than the triangle)
                         // quotient by the run-time `rest` through a float reciprocal: exact here (idx + 0.5 is never a multiple of rest, the
@@ -439,20 +488,21 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
                         const int qi = static_cast<int>((static_cast<float>(idx) + 0.5f) * restInv);
                         const int i = j + 1 + qi, k2 = j + 1 + (idx - qi * rest);
                         if (k2 <= i) {
-                            const double v = H[(nx + i) * n + nx + k2] - H[(nx + i) * n + nx + j] * H[(nx + k2) * n + nx + j] * rd;
-                            H[(nx + i) * n + nx + k2] = v;
-                            if (i == j + 1) piv[j + 1] = 1.0 / (v > 0.0 ? v : 1.0);  // (k2 == i == j + 1: the next pivot is final)
+                            double* ri = rowOf(i);
+                            const double v = ri[nx + k2] - ri[nx + j] * rowOf(k2)[nx + j] * rd;
+                            ri[nx + k2] = v;
+                            if (i == j + 1) piv[j + 1] = pivotReciprocal(v, j + 1);  // (k2 == i == j + 1: the next pivot is final)
                         }
                     } else if (idx < rest * rest + rest * nk) {
                         const int e = idx - rest * rest, i = j + 1 + e / nk, c = e % nk;
-                        K[i * nk + c] -= H[(nx + i) * n + nx + j] * rd * K[j * nk + c];
+                        K[i * nk + c] -= rowOf(i)[nx + j] * rd * K[j * nk + c];
                     }
                 });
             };
             auto backwardColumn = [&](int j) {
                 ex.ForEach(j * nk, [&](int idx) {
                     const int i = idx / nk, c = idx % nk;
-                    K[i * nk + c] -= H[(nx + j) * n + nx + i] * piv[i] * K[j * nk + c];
+                    K[i * nk + c] -= rowOf(j)[nx + i] * piv[i] * K[j * nk + c];
                 });
             };
             // (not unrolled: 47 unrolled phase bodies cost the third wavefront per SIMD.  Also measured and dropped for nu = 24: factorising
@@ -460,9 +510,9 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
             // column-wise LDS round trips on 14 lanes, 175 registers: QP step 5.25 -> 6.94 ms; and eliminating an identity along with the
             // right-hand sides, so that L^-1 turns the back substitution into ONE product -- nu + 3 phases instead of 2 nu + 1, but heavier
             // ones and a 23-term chain per entry of the product: 5.16 -> 5.75 ms.)
-            for (int j = 0; j < nu; ++j) forwardColumn(j);
-            ex.ForEach(nu * nk, [&](int idx) { K[idx] *= piv[idx / nk]; });
-            for (int j = nu - 1; j > 0; --j) backwardColumn(j);
+            for (int j = 0; j < nuE; ++j) forwardColumn(j);
+            ex.ForEach(nuE * nk, [&](int idx) { K[idx] *= piv[idx / nk]; });
+            for (int j = nuE - 1; j > 0; --j) backwardColumn(j);
             ex.ForEachNoSync(nu * nk, [&](int idx) { gains[static_cast<long long>(k) * nu * nk + idx] = K[idx]; });
         }
         RiccatiMark(ex, 4);  // factorisation of R and gains
@@ -474,12 +524,18 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
                 s1 += H[(nx + m) * n + i] * K[m * nk + j];
                 s2 += H[(nx + m) * n + j] * K[m * nk + i];
             }
+            for (int m = nu; m < nuE; ++m) {  // C^T Lambda: the multiplier feedback of the stage equality rows
+                const double* row = Eq + (m - nu) * ldq;
+                s1 += row[i] * K[m * nk + j];
+                s2 += row[j] * K[m * nk + i];
+            }
             return 0.5 * (s1 + s2);
         };
         auto costToGoVector = [&](int i) {
             double sv = h[i];
 #pragma unroll 8
             for (int m = 0; m < nu; ++m) sv += H[(nx + m) * n + i] * K[m * nk + nx];
+            for (int m = nu; m < nuE; ++m) sv += Eq[(m - nu) * ldq + i] * K[m * nk + nx];
             pn[i] = sv;
         };
         if constexpr (NX > 0) {
