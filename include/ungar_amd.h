@@ -250,6 +250,13 @@ typedef struct ungar_ocp_qp {
     int64_t workspace_doubles;
     double regularization;
     int32_t* status;
+    /* Stage equality rows  E_k [dx_k; du_k] + e_k = 0  for k < N -- the foot-contact rows of example/mpc/quadruped.example.cpp:279-304 are hard
+     * equalities of the reference's QP next to the dynamics (soft_sqp.hpp:155-157).  ne rows per node (0: none), eq = dense row-major
+     * ne x (nx+nu) per node, eq_values = ne per node.  A row that is identically zero (an inactive contact) is skipped; the input parts
+     * of the other rows of a node must be linearly independent (status k+1 otherwise). */
+    int64_t ne;
+    ungar_operand eq, eq_values;
+    int64_t hess_terminal_ld;      /* leading dimension of hess_terminal (0: nx): the terminal block may be the corner of a wider one */
 } ungar_ocp_qp;
 int64_t ungar_ocp_riccati_workspace(int64_t nx, int64_t nu, int64_t horizon, int64_t batch);
 int ungar_ocp_riccati_solve(const ungar_ocp_qp* qp, void* stream);
@@ -300,6 +307,97 @@ int ungar_ocp_merit_stacked(const ungar_ocp_merit_args* args, int64_t period, vo
 int ungar_ocp_line_search_select(int64_t nx, int64_t nu, int64_t horizon, int64_t batch, const ungar_line_search_parameters* parameters, const double* alphas,
                                  int64_t candidates, const double* theta0, const double* phi0, const double* slope, const double* theta_trial, const double* phi_trial,
                                  double* accepted, const ungar_operand* X, const ungar_operand* U, const ungar_operand* Xt, const ungar_operand* Ut, void* stream);
+
+/* ---- shooting problems with carried quantities and stage equality rows (the reference's three OCPs as written) ------------------
+ * The objective of example/mpc/quadrotor.example.cpp:222-227 and rc_car.example.cpp:216-220 couples u_k with u_{k-1}; the foot-contact
+ * rows of quadruped.example.cpp:279-304 couple the foot positions of knots k and k-1.  Both are stage-local once the quantity of the
+ * previous knot is CARRIED in the stage state: z_k = [c_k; x_k], c_{k+1} = kappa(x_k, u_k) (kappa = u_k, or a recorded function).
+ * Every node (instance, knot k <= N) owns one ROW of nv = nc+nx+nu+nw+np doubles [c | x | u | w | p] of a node-major DEVICE array
+ * rows[batch][N+1][nv]; stage functions are ungar_functions over a contiguous slice of the row -- dynamics / carry over [x|u ; w|p]
+ * (n = nx+nu), cost / equality / inequality rows over [c|x|u ; w|p] (n = nc+nx+nu) -- evaluated with ungar_function_*_nodes into
+ * node-major outputs of N+1 knots per instance (values in the order of ungar_function_*_sparsity).  Row N holds x_N; its cost is the
+ * terminal cost (input derivatives ignored).  One SQP iteration = SoftSQPOptimizer::Optimize's loop body (soft_sqp.hpp:62-112):
+ *   stage derivatives -> ungar_shooting_assemble -> ungar_ocp_riccati_solve (nx := nc+nx, ne rows) -> ungar_shooting_merit ->
+ *   ungar_shooting_trial_rows -> stage values on the stacked rows -> ungar_shooting_merit (stacked) -> ungar_shooting_select.
+ * include/../ungar_amd/include/ungar/optimization/batched_soft_sqp.hpp drives exactly this from C++20. */
+typedef struct ungar_stage_pattern {
+    const int32_t* rows; /* DEVICE arrays */
+    const int32_t* cols;
+    int64_t nnz;
+} ungar_stage_pattern;
+
+typedef struct ungar_shooting_dims {
+    int64_t nx, nu, nc, nw, np, horizon, batch;
+    int32_t carry_inputs; /* 1: c_{k+1} = u_k (nc == nu), no carry function */
+    int32_t reserved;
+} ungar_shooting_dims;
+
+/* QP data of every node (soft_sqp.hpp:143-155, 247-264): with nz = nc+nx, nd = nz+nu,
+ *   AB[batch][N][nz*nd]   rows 0..nc-1 carry Jacobian (identity on u for carry_inputs), rows nc.. dynamics Jacobian, c columns zero
+ *   b[batch][N][nz]       [0; f_k - x_{k+1}]          dz0[batch][nz] = [0; x_m - x_0]
+ *   W[batch][N+1][nd*nd]  upper triangle of hess cost + J_h^T diag(b''(-h)) J_h + regularization on the (x, u) diagonal (knot N: cost only)
+ *   w[batch][N+1][nd]     grad cost - J_h^T b'(-h)
+ *   E[batch][N][ne*nd]    dense equality-row Jacobian (values: the equality function's own output). */
+typedef struct ungar_shooting_assemble_args {
+    ungar_shooting_dims dims;
+    const double* rows;
+    const double* xm;                       /* batch x nx measured states */
+    const double *f, *f_jac;                /* dynamics value (nx) and sparse Jacobian values per node */
+    const double* carry_jac;                /* null with carry_inputs */
+    const double *cost_grad, *cost_hes;     /* sparse gradient (1 x nd) and upper Hessian values per node */
+    const double *h, *h_jac;                /* nh inequality values and sparse Jacobian values per node (null: none) */
+    const double* eq_jac;                   /* sparse Jacobian values of the ne equality rows (null: none) */
+    ungar_stage_pattern f_pattern, carry_pattern, cost_grad_pattern, cost_hes_pattern, h_pattern, eq_pattern;
+    int64_t nh, ne;
+    ungar_barrier barrier;
+    double regularization;
+    double *AB, *b, *W, *w, *E, *dz0;       /* outputs */
+} ungar_shooting_assemble_args;
+int ungar_shooting_assemble(const ungar_shooting_assemble_args* args, void* stream);
+
+/* theta = multiplier * |[x_0 - x_m; x_{k+1} - f_k; e_k]|_2, objective = sum_{k<=N} cost_k, phi = objective + barrier terms, and (cost_grad,
+ * dZ, dU given) slope = grad objective . step, per instance (soft_sqp.hpp:68-87).  period > 0: dims.batch counts STACKED trial points
+ * (candidate c of instance i at c * period + i); xm, dZ, dU are indexed by instance % period. */
+typedef struct ungar_shooting_merit_args {
+    ungar_shooting_dims dims;
+    const double* rows;
+    const double* xm;
+    const double *f, *cost, *h, *eq;        /* node values, N+1 knots per (stacked) instance; h / eq may be null */
+    int64_t nh, ne;
+    ungar_barrier barrier;
+    double violation_multiplier;
+    const double* cost_grad;                /* null: no slope */
+    ungar_stage_pattern cost_grad_pattern;
+    const double *dZ, *dU;                  /* dZ[batch][N+1][nz], dU[batch][N][nu] */
+    double *theta, *phi, *objective, *slope; /* device, one per (stacked) instance; objective / slope may be null */
+    int64_t period;
+} ungar_shooting_merit_args;
+int ungar_shooting_merit(const ungar_shooting_merit_args* args, void* stream);
+
+/* trial[c * batch + b][k] = rows[b][k] with [c|x|u] += alphas[c] * [dZ; dU] (parameters copied; `alphas` host array, at most 16 candidates).
+ * With carry_inputs the carried slots of row k+1 are the trial inputs of row k; otherwise the caller refreshes them with the carry function
+ * (output operand = the carried slots of rows 1..N). */
+int ungar_shooting_trial_rows(const ungar_shooting_dims* dims, const double* rows, const double* dZ, const double* dU, const double* alphas, int64_t candidates,
+                              double* trial, void* stream);
+
+/* Backtracking search over the stacked candidates (backtracking_line_search.hpp:116-151) and the iteration bookkeeping of
+ * SoftSQPOptimizer::Optimize (soft_sqp.hpp:88-99) per instance: the first acceptable candidate's [c|x|u] is copied into `rows`, accepted[b] = its
+ * step size (0: none); active[b] (may be null) is cleared when no step is acceptable or the objective decreased by less than 1e-6, and instances
+ * that are not active are left untouched.  status (may be null): the Riccati solve's per-instance report; an instance whose QP was not solved
+ * (non-zero) takes no step and stops -- the reference asserts on a failed QP (soft_sqp.hpp:223-230). */
+int ungar_shooting_select(const ungar_shooting_dims* dims, const ungar_line_search_parameters* parameters, const double* alphas, int64_t candidates,
+                          const double* theta0, const double* phi0, const double* objective0, const double* slope, const double* theta_trial,
+                          const double* phi_trial, const double* objective_trial, double* accepted, int32_t* active, const int32_t* status, double* rows, const double* trial,
+                          void* stream);
+
+/* ---- device memory for host code that is not compiled with hipcc (the C++20 facade) ------------------------------------------------ */
+int ungar_device_malloc(void** out, int64_t bytes);
+int ungar_device_free(void* ptr);
+int ungar_device_upload(void* dst_device, const void* src_host, int64_t bytes);     /* synchronous */
+int ungar_device_download(void* dst_host, const void* src_device, int64_t bytes);   /* synchronous (after all work of the null stream) */
+int ungar_device_zero(void* dst_device, int64_t bytes, void* stream);
+int ungar_device_copy(void* dst_device, const void* src_device, int64_t bytes, void* stream);  /* stream-ordered */
+int ungar_device_synchronize(void);
 
 /* ---- run-time function factory (any recorded function, not only the built-in node models) ----- */
 
@@ -352,6 +450,13 @@ int ungar_function_hessian_sparsity(const ungar_function* fn, const int32_t** ro
 int ungar_function_forward_zero(const ungar_function* fn, const ungar_operand* xp, const ungar_operand* y, int64_t batch, void* stream);
 int ungar_function_sparse_jacobian(const ungar_function* fn, const ungar_operand* xp, const ungar_operand* jac, int64_t batch, void* stream);
 int ungar_function_sparse_hessian(const ungar_function* fn, const ungar_operand* xp, const ungar_operand* hes, int64_t batch, void* stream);
+
+/* The same over shooting NODES: node i = (instance i / knots, knot i % knots), element e at
+ * base[instance * instance_stride + knot * knot_stride + e * element_stride] for both operands -- the nodes k < N (or k <= N) of every
+ * instance of a batch of horizons in one launch, inputs read from and outputs written into per-instance buffers in place. */
+int ungar_function_forward_zero_nodes(const ungar_function* fn, const ungar_operand* xp, const ungar_operand* y, int64_t count, int64_t knots, void* stream);
+int ungar_function_sparse_jacobian_nodes(const ungar_function* fn, const ungar_operand* xp, const ungar_operand* jac, int64_t count, int64_t knots, void* stream);
+int ungar_function_sparse_hessian_nodes(const ungar_function* fn, const ungar_operand* xp, const ungar_operand* hes, int64_t count, int64_t knots, void* stream);
 
 /* Single-instance HOST call (what Ungar::Autodiff::Function::operator()/Jacobian/Hessian need):
  * copies xp to the device, launches batch = 1, copies the result back, synchronously.

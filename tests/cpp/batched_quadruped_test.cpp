@@ -1,0 +1,399 @@
+// GPU test (C++20 host code over the C ABI): the reference's quadruped OCP AS WRITTEN -- single-rigid-body dynamics with contact flags,
+// horizon 30, 1123 decision variables, 883 equality rows of which 480 are the foot-contact rows that couple knots k and k-1
+// (example/mpc/quadruped.example.cpp:209-338) -- solved for a BATCH of instances with random gaits by Ungar::BatchedSoftSQPOptimizer
+// (stage functions with the previous foot positions carried in the stage state; Riccati recursion with stage equality rows) and, for a
+// sample of the instances, by the facade's whole-horizon Ungar::SoftSQPOptimizer (sparse KKT solve of the QP the reference hands to
+// OSQP, soft_sqp.hpp:143-158).  Search direction, accepted step size and iterate must agree after one and after two iterations.
+//   usage: batched_quadruped_test <codegen folder> [batch] [compared instances]
+#include <cmath>
+#include <cstdio>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "ungar/autodiff/function.hpp"
+#include "ungar/autodiff/vector_composer.hpp"
+#include "ungar/optimization/batched_soft_sqp.hpp"
+#include "ungar/optimization/soft_sqp.hpp"
+#include "ungar/variable_map.hpp"
+
+using namespace Ungar;
+
+constexpr auto N = 30_c;
+constexpr auto LEGS = 4_c;
+// ---- the whole-horizon variables of the reference's example (:57-139)
+UNGAR_VARIABLE(position, 3);
+UNGAR_VARIABLE(orientation, Q);
+UNGAR_VARIABLE(linear_velocity, 3);
+UNGAR_VARIABLE(b_angular_velocity, 3);
+UNGAR_VARIABLE(x) <<= (position, orientation, linear_velocity, b_angular_velocity);
+UNGAR_VARIABLE(X) <<= (N + 1_c) * x;
+UNGAR_VARIABLE(ground_reaction_force, 3);
+UNGAR_VARIABLE(b_foot_position, 3);
+UNGAR_VARIABLE(leg_input) <<= (ground_reaction_force, b_foot_position);
+UNGAR_VARIABLE(u) <<= LEGS * leg_input;
+UNGAR_VARIABLE(U) <<= N * u;
+UNGAR_VARIABLE(reference_position, 3);
+UNGAR_VARIABLE(reference_orientation, Q);
+UNGAR_VARIABLE(reference_linear_velocity, 3);
+UNGAR_VARIABLE(b_reference_angular_velocity, 3);
+UNGAR_VARIABLE(reference_state) <<= (reference_position, reference_orientation, reference_linear_velocity, b_reference_angular_velocity);
+UNGAR_VARIABLE(reference_contact_state, 1);
+UNGAR_VARIABLE(b_reference_foot_position, 3);
+UNGAR_VARIABLE(reference_leg_state) <<= (reference_contact_state, b_reference_foot_position);
+UNGAR_VARIABLE(p) <<= (reference_state, LEGS * reference_leg_state);
+UNGAR_VARIABLE(P) <<= (N + 1_c) * p;
+UNGAR_VARIABLE(step_size, 1);
+UNGAR_VARIABLE(mass, 1);
+UNGAR_VARIABLE(b_moi_diagonal, 3);
+UNGAR_VARIABLE(inertial_properties) <<= (mass, b_moi_diagonal);
+UNGAR_VARIABLE(b_hip_position, 3);
+UNGAR_VARIABLE(leg_length, 1);
+UNGAR_VARIABLE(geometric_data) <<= (LEGS * b_hip_position, leg_length);
+UNGAR_VARIABLE(standard_gravity, 1);
+UNGAR_VARIABLE(friction_coefficient, 1);
+UNGAR_VARIABLE(physical_constants) <<= (standard_gravity, friction_coefficient);
+UNGAR_VARIABLE(measured_position, 3);
+UNGAR_VARIABLE(measured_orientation, Q);
+UNGAR_VARIABLE(measured_linear_velocity, 3);
+UNGAR_VARIABLE(b_measured_angular_velocity, 3);
+UNGAR_VARIABLE(measured_state) <<= (measured_position, measured_orientation, measured_linear_velocity, b_measured_angular_velocity);
+UNGAR_VARIABLE(measured_contact_state, 1);
+UNGAR_VARIABLE(measured_foot_position, 3);
+UNGAR_VARIABLE(measured_leg_state) <<= (measured_contact_state, measured_foot_position);
+UNGAR_VARIABLE(Rho) <<= (step_size, inertial_properties, geometric_data, physical_constants, measured_state, LEGS * measured_leg_state);
+UNGAR_VARIABLE(decision_variables) <<= (X, U);
+UNGAR_VARIABLE(parameters) <<= (P, Rho);
+UNGAR_VARIABLE(variables) <<= (decision_variables, parameters);
+// ---- one node of the stage form: row = [previous foot positions | x | u | knot parameters | instance parameters]
+UNGAR_VARIABLE(previous_foot_position, 3);
+UNGAR_VARIABLE(previous_feet) <<= LEGS * previous_foot_position;  // world positions of the feet at knot k - 1 (row 0: the measured ones)
+UNGAR_VARIABLE(previous_contact_state, 1);                        // s_{k-1} (row 0: the measured contact state)
+UNGAR_VARIABLE(input_weight, 1);                                  // 1 for k < N, 0 at the terminal knot (:233-243)
+UNGAR_VARIABLE(knot_parameters) <<= (p, LEGS * previous_contact_state, input_weight);
+UNGAR_VARIABLE(instance_parameters) <<= (step_size, inertial_properties, geometric_data, physical_constants);
+UNGAR_VARIABLE(dynamics_node) <<= (x, u, knot_parameters, instance_parameters);
+UNGAR_VARIABLE(stage_node) <<= (previous_feet, x, u, knot_parameters, instance_parameters);
+
+/// quadruped.example.cpp:148-203; Knot holds the contact flags, Inst the inertial data.
+template <class Knot, class Inst>
+static VectorXad Dynamics(const VectorXad& xk, const VectorXad& uk, const Knot& p_, const Inst& rho_) {
+    const auto x_ = MakeVariableLazyMap(xk, x);
+    const auto u_ = MakeVariableLazyMap(uk, u);
+    const auto [dt, g0, m, moi] = rho_.GetTuple(step_size, standard_gravity, mass, b_moi_diagonal);
+    const auto [pos, q, pDot, bOmega] = x_.GetTuple(position, orientation, linear_velocity, b_angular_velocity);
+    Vector3ad pDotDot = -g0 * Vector3r::UnitZ();
+    Vector3ad bOmegaDot = -bOmega.cross(moi.asDiagonal() * bOmega);
+    for (const auto i : enumerate(LEGS)) {
+        const auto f = u_.Get(ground_reaction_force, i);
+        const auto r = u_.Get(b_foot_position, i);
+        const auto& s = p_.Get(reference_contact_state, i);
+        pDotDot += s * f / m;
+        bOmegaDot += s * r.cross(q * f);
+    }
+    bOmegaDot = bOmegaDot.array() / moi.array();
+    VectorXad next{x.Size()};
+    auto next_ = MakeVariableLazyMap(next, x);
+    auto [pN, qN, pDotN, bOmegaN] = next_.GetTuple(position, orientation, linear_velocity, b_angular_velocity);
+    pDotN = pDot + dt * pDotDot;
+    bOmegaN = bOmega + dt * bOmegaDot;
+    pN = pos + dt * pDotN;
+    qN = q * Utils::ApproximateExponentialMap(dt * bOmegaN);
+    return next_.Get();
+}
+
+int main(int argc, char** argv) {
+    const std::string folder = argc > 1 ? argv[1] : "/tmp/ungar_amd_batched_quadruped";
+    const index_t batch = argc > 2 ? std::atol(argv[2]) : 1024, compared = argc > 3 ? std::atol(argv[3]) : 8;
+    try {
+        // ---- whole-horizon problem (quadruped.example.cpp:209-368)
+        const auto objective = [&](const VectorXad& v, VectorXad& y) {
+            const auto v_ = MakeVariableLazyMap(v, variables);
+            ad_scalar_t value{0.0};
+            for (const auto k : enumerate(N + 1_step)) {
+                const auto q = v_.Get(orientation, k);
+                const auto qRef = v_.Get(reference_orientation, k);
+                value += Vector3r{0.1, 0.1, 10.0}.cwiseProduct(v_.Get(position, k) - v_.Get(reference_position, k)).squaredNorm() +
+                         Utils::Min((q.coeffs() - qRef.coeffs()).squaredNorm(), (q.coeffs() + qRef.coeffs()).squaredNorm()) +
+                         (v_.Get(linear_velocity, k) - v_.Get(reference_linear_velocity, k)).squaredNorm() +
+                         (v_.Get(b_angular_velocity, k) - v_.Get(b_reference_angular_velocity, k)).squaredNorm();
+                if (k != N)
+                    for (const auto i : enumerate(LEGS)) {
+                        value += (v_.Get(b_foot_position, k, i) - v_.Get(b_reference_foot_position, k, i)).squaredNorm();
+                        value += 1e-8 * v_.Get(ground_reaction_force, k, i).squaredNorm();
+                    }
+            }
+            y.resize(1_idx);
+            y << value;
+        };
+        const auto equality = [&](const VectorXad& v, VectorXad& y) {
+            const auto v_ = MakeVariableLazyMap(v, variables);
+            Autodiff::VectorComposer composer;
+            composer << v_.Get(x, 0_step) - v_.Get(measured_state);
+            for (const auto k : enumerate(N)) {
+                const VectorXad pk = v_.Get(p, k), rho = v_.Get(Rho);
+                composer << v_.Get(x, k + 1_step) - Dynamics(v_.Get(x, k), v_.Get(u, k), MakeVariableLazyMap(pk, p), MakeVariableLazyMap(rho, Rho));
+            }
+            for (const auto k : enumerate(N))
+                for (const auto i : enumerate(LEGS)) {
+                    const auto& s = v_.Get(reference_contact_state, k, i);
+                    const auto& sPrev = k ? v_.Get(reference_contact_state, k - 1_step, i) : v_.Get(measured_contact_state, i);
+                    const Vector3ad pFoot = v_.Get(position, k) + v_.Get(orientation, k) * v_.Get(b_foot_position, k, i);
+                    Vector3ad pFootPrev;
+                    if (k) pFootPrev = v_.Get(position, k - 1_step) + v_.Get(orientation, k - 1_step) * v_.Get(b_foot_position, k - 1_step, i);
+                    else pFootPrev = v_.Get(measured_foot_position, i);
+                    composer << (1.0 - sPrev) * s * pFoot.z();
+                    composer << sPrev * s * (pFoot - pFootPrev);
+                }
+            y = composer.Compose();
+        };
+        const auto inequality = [&](const VectorXad& v, VectorXad& y) {
+            const auto v_ = MakeVariableLazyMap(v, variables);
+            Autodiff::VectorComposer composer;
+            const auto& mu = v_.Get(friction_coefficient);
+            for (const auto k : enumerate(N))
+                for (const auto i : enumerate(LEGS)) {
+                    const auto& s = v_.Get(reference_contact_state, k, i);
+                    const auto f = v_.Get(ground_reaction_force, k, i);
+                    const auto r = v_.Get(b_foot_position, k, i);
+                    composer << -s * f.z();
+                    composer << s * Utils::ApproximateNorm(f.template head<2>()) - mu * f.z();
+                    composer << s * Utils::ApproximateNorm(r - v_.Get(b_hip_position, i)) - v_.Get(leg_length);
+                }
+            y = composer.Compose();
+        };
+        auto nlp = MakeNLPProblem(
+            Autodiff::MakeFunction({objective, decision_variables.Size(), parameters.Size(), "bqp_whole_obj", EnabledDerivatives::ALL, folder}, false),
+            Autodiff::MakeFunction({equality, decision_variables.Size(), parameters.Size(), "bqp_whole_eqs", EnabledDerivatives::JACOBIAN, folder}, false),
+            Autodiff::MakeFunction({inequality, decision_variables.Size(), parameters.Size(), "bqp_whole_ineqs", EnabledDerivatives::JACOBIAN, folder}, false));
+        if (nlp.equalityConstraints.DependentVariableSize() != 883 || nlp.inequalityConstraints.DependentVariableSize() != 360 || decision_variables.Size() != 1123) {
+            std::printf("FAIL sizes\n");
+            return 1;
+        }
+
+        // ---- the same problem in stage form
+        const index_t nPar = knot_parameters.Size() + instance_parameters.Size(), nxu = x.Size() + u.Size(), nd = previous_feet.Size() + nxu;
+        const auto stageDynamics = [&](const VectorXad& v, VectorXad& y) {
+            const auto n_ = MakeVariableLazyMap(v, dynamics_node);
+            const VectorXad xk = n_.Get(x), uk = n_.Get(u), pk = n_.Get(p), rho = n_.Get(instance_parameters);
+            y = Dynamics(xk, uk, MakeVariableLazyMap(pk, p), MakeVariableLazyMap(rho, instance_parameters));
+        };
+        const auto stageFeet = [&](const VectorXad& v, VectorXad& y) {  // the carried quantity: world positions of the feet (:288-291)
+            const auto n_ = MakeVariableLazyMap(v, dynamics_node);
+            Autodiff::VectorComposer composer;
+            for (const auto i : enumerate(LEGS)) composer << n_.Get(position) + n_.Get(orientation) * n_.Get(b_foot_position, i);
+            y = composer.Compose();
+        };
+        const auto stageCost = [&](const VectorXad& v, VectorXad& y) {
+            const auto n_ = MakeVariableLazyMap(v, stage_node);
+            const auto q = n_.Get(orientation);
+            const auto qRef = n_.Get(reference_orientation);
+            ad_scalar_t value = Vector3r{0.1, 0.1, 10.0}.cwiseProduct(n_.Get(position) - n_.Get(reference_position)).squaredNorm() +
+                                Utils::Min((q.coeffs() - qRef.coeffs()).squaredNorm(), (q.coeffs() + qRef.coeffs()).squaredNorm()) +
+                                (n_.Get(linear_velocity) - n_.Get(reference_linear_velocity)).squaredNorm() +
+                                (n_.Get(b_angular_velocity) - n_.Get(b_reference_angular_velocity)).squaredNorm();
+            for (const auto i : enumerate(LEGS)) {
+                value += n_.Get(input_weight) * (n_.Get(b_foot_position, i) - n_.Get(b_reference_foot_position, i)).squaredNorm();
+                value += n_.Get(input_weight) * 1e-8 * n_.Get(ground_reaction_force, i).squaredNorm();
+            }
+            y.resize(1_idx);
+            y << value;
+        };
+        const auto stageEquality = [&](const VectorXad& v, VectorXad& y) {
+            const auto n_ = MakeVariableLazyMap(v, stage_node);
+            Autodiff::VectorComposer composer;
+            for (const auto i : enumerate(LEGS)) {
+                const auto& s = n_.Get(reference_contact_state, i);
+                const auto& sPrev = n_.Get(previous_contact_state, i);
+                const Vector3ad pFoot = n_.Get(position) + n_.Get(orientation) * n_.Get(b_foot_position, i);
+                const Vector3ad pFootPrev = n_.Get(previous_foot_position, i);
+                composer << (1.0 - sPrev) * s * pFoot.z();
+                composer << sPrev * s * (pFoot - pFootPrev);
+            }
+            y = composer.Compose();
+        };
+        const auto stageInequality = [&](const VectorXad& v, VectorXad& y) {
+            const auto n_ = MakeVariableLazyMap(v, stage_node);
+            Autodiff::VectorComposer composer;
+            const auto& mu = n_.Get(friction_coefficient);
+            for (const auto i : enumerate(LEGS)) {
+                const auto& s = n_.Get(reference_contact_state, i);
+                const auto f = n_.Get(ground_reaction_force, i);
+                const auto r = n_.Get(b_foot_position, i);
+                composer << -s * f.z();
+                composer << s * Utils::ApproximateNorm(f.template head<2>()) - mu * f.z();
+                composer << s * Utils::ApproximateNorm(r - n_.Get(b_hip_position, i)) - n_.Get(leg_length);
+            }
+            y = composer.Compose();
+        };
+        ShootingProblem problem;
+        problem.horizon = N;
+        problem.stateSize = x.Size();
+        problem.inputSize = u.Size();
+        problem.carrySize = previous_feet.Size();
+        problem.knotParameterSize = knot_parameters.Size();
+        problem.instanceParameterSize = instance_parameters.Size();
+        problem.dynamics.emplace(Autodiff::MakeFunction({stageDynamics, nxu, nPar, "bqp_stage_dyn", EnabledDerivatives::JACOBIAN, folder}, false));
+        problem.carry.emplace(Autodiff::MakeFunction({stageFeet, nxu, nPar, "bqp_stage_feet", EnabledDerivatives::JACOBIAN, folder}, false));
+        problem.cost.emplace(Autodiff::MakeFunction({stageCost, nd, nPar, "bqp_stage_cost", EnabledDerivatives::ALL, folder}, false));
+        problem.equality.emplace(Autodiff::MakeFunction({stageEquality, nd, nPar, "bqp_stage_eq", EnabledDerivatives::JACOBIAN, folder}, false));
+        problem.inequality.emplace(Autodiff::MakeFunction({stageInequality, nd, nPar, "bqp_stage_ineq", EnabledDerivatives::JACOBIAN, folder}, false));
+        const index_t nv = problem.RowSize();
+        if (nv != stage_node.Size() || problem.equality->DependentVariableSize() != 16 || problem.inequality->DependentVariableSize() != 12) {
+            std::printf("FAIL stage sizes\n");
+            return 1;
+        }
+        const real_t dt = 1.0 / static_cast<real_t>(N);
+        BatchedSoftSQPOptimizer batched{std::move(problem), batch, false, dt, 2, 1.0, 1.0};  // the example's optimizer settings (:444)
+
+        // ---- instances: parameter values of quadruped.example.cpp:378-430, a random gait and a perturbed initial guess each
+        std::mt19937_64 rng{20260930};
+        std::normal_distribution<real_t> normal{0.0, 1.0};
+        std::uniform_real_distribution<real_t> uniform{0.0, 1.0};
+        std::vector<VectorXr> instances;
+        const Vector3r hips[4] = {{0.2, 0.15, -0.1}, {0.2, -0.15, -0.1}, {-0.2, 0.15, -0.1}, {-0.2, -0.15, -0.1}};
+        const Vector3r stance[4] = {{0.2, 0.1, 0.0}, {0.2, -0.1, 0.0}, {-0.2, 0.1, 0.0}, {-0.2, -0.1, 0.0}};
+        for (index_t b = 0; b < batch; ++b) {
+            VectorXr data{variables.Size()};
+            data.setZero();
+            auto v_ = MakeVariableLazyMap(data, variables);
+            v_.Get(step_size) = dt;
+            v_.Get(mass) = 25.0;
+            v_.Get(b_moi_diagonal) = Vector3r{0.048125, 0.093125, 0.055625};
+            for (const auto i : enumerate(LEGS)) v_.Get(b_hip_position, i) = hips[i];
+            v_.Get(leg_length) = 0.42;
+            v_.Get(standard_gravity) = 9.80665;
+            v_.Get(friction_coefficient) = 0.7;
+            const real_t height = 0.38, yaw = 0.2 * normal(rng);
+            v_.Get(measured_position) = Vector3r(0.01 * normal(rng), 0.01 * normal(rng), height + 0.005 * normal(rng));
+            v_.Get(measured_orientation) = Quaternionr(1.0, 0.01 * normal(rng), 0.01 * normal(rng), 0.5 * yaw).normalized();
+            v_.Get(measured_linear_velocity) = 0.05 * Vector3r(normal(rng), normal(rng), normal(rng));
+            v_.Get(b_measured_angular_velocity) = 0.05 * Vector3r(normal(rng), normal(rng), normal(rng));
+            // gait: per leg a period of 10-16 knots, 60 % stance, random phase; instance 0 keeps all feet down (the example's initial gait)
+            int period[4], phase[4];
+            for (int i = 0; i < 4; ++i) {
+                period[i] = 10 + static_cast<int>(uniform(rng) * 7.0);
+                phase[i] = static_cast<int>(uniform(rng) * period[i]);
+            }
+            auto contact = [&](int i, index_t k) -> real_t {  // k = -1: the measured contact state
+                if (b == 0) return 1.0;
+                const int t = static_cast<int>((k + 1 + phase[i]) % period[i]);
+                return t < (6 * period[i]) / 10 ? 1.0 : 0.0;
+            };
+            for (const auto i : enumerate(LEGS)) {
+                v_.Get(measured_contact_state, i) = contact(static_cast<int>(i), -1);
+                v_.Get(measured_foot_position, i) = stance[i] + 0.01 * Vector3r(normal(rng), normal(rng), contact(static_cast<int>(i), -1) > 0.5 ? 0.0 : 5.0 + normal(rng));
+            }
+            for (const auto k : enumerate(N + 1_step)) {
+                const real_t t = static_cast<real_t>(k) * dt;
+                v_.Get(position, k) = v_.Get(measured_position) + 0.01 * Vector3r(normal(rng), normal(rng), normal(rng));
+                v_.Get(orientation, k) = Quaternionr(1.0, 0.01 * normal(rng), 0.01 * normal(rng), 0.5 * yaw * (1.0 + t)).normalized();
+                v_.Get(linear_velocity, k) = 0.05 * Vector3r(normal(rng), normal(rng), normal(rng));
+                v_.Get(b_angular_velocity, k) = Vector3r(0.05 * normal(rng), 0.05 * normal(rng), yaw);
+                v_.Get(reference_position, k) = Vector3r(0.0, 0.0, height + 0.03 * std::sin(2.0 * t));
+                v_.Get(reference_orientation, k) = Quaternionr(b % 2 ? -std::cos(0.5 * yaw * t) : std::cos(0.5 * yaw * t), 0.0, 0.0, std::sin(0.5 * yaw * t)).normalized();
+                v_.Get(reference_linear_velocity, k).setZero();
+                v_.Get(b_reference_angular_velocity, k) = Vector3r(0.0, 0.0, yaw);
+                for (const auto i : enumerate(LEGS)) {
+                    v_.Get(reference_contact_state, k, i) = contact(static_cast<int>(i), static_cast<index_t>(k));
+                    v_.Get(b_reference_foot_position, k, i) = Vector3r(stance[i].x(), stance[i].y(), -height) + 0.01 * Vector3r(normal(rng), normal(rng), 0.0);
+                }
+            }
+            for (const auto k : enumerate(N))
+                for (const auto i : enumerate(LEGS)) {
+                    v_.Get(ground_reaction_force, k, i) = Vector3r(2.0 * normal(rng), 2.0 * normal(rng), 25.0 * 9.80665 / 4.0 * (1.0 + 0.3 * normal(rng)));
+                    v_.Get(b_foot_position, k, i) = Vector3r(stance[i].x(), stance[i].y(), -height) + 0.01 * Vector3r(normal(rng), normal(rng), normal(rng));
+                }
+            instances.push_back(data);
+        }
+
+        // ---- node rows
+        const index_t nx = x.Size(), nu = u.Size(), nc = previous_feet.Size(), nz = nc + nx, dec = decision_variables.Size();
+        std::vector<real_t> rows(static_cast<std::size_t>(batched.RowsSize())), xm(static_cast<std::size_t>(batch * nx));
+        for (index_t b = 0; b < batch; ++b) {
+            const auto v_ = MakeVariableLazyMap(instances[static_cast<std::size_t>(b)], variables);
+            for (index_t k = 0; k <= N; ++k) {
+                VectorXr row{nv};
+                row.setZero();
+                auto n_ = MakeVariableLazyMap(row, stage_node);
+                for (const auto i : enumerate(LEGS)) {
+                    n_.Get(previous_foot_position, i) = v_.Get(measured_foot_position, i);  // row 0; rows 1..N are refreshed by the optimizer
+                    n_.Get(previous_contact_state, i) = k ? v_.Get(reference_contact_state, k - 1, i) : v_.Get(measured_contact_state, i);
+                    n_.Get(b_hip_position, i) = v_.Get(b_hip_position, i);
+                }
+                n_.Get(x) = v_.Get(x, k);
+                n_.Get(u) = v_.Get(u, k < N ? k : N - 1);  // row N: a dummy input (weight 0)
+                n_.Get(p) = v_.Get(p, k);
+                n_.Get(input_weight) = k < N ? 1.0 : 0.0;
+                n_.Get(step_size) = v_.Get(step_size);
+                n_.Get(mass) = v_.Get(mass);
+                n_.Get(b_moi_diagonal) = v_.Get(b_moi_diagonal);
+                n_.Get(leg_length) = v_.Get(leg_length);
+                n_.Get(standard_gravity) = v_.Get(standard_gravity);
+                n_.Get(friction_coefficient) = v_.Get(friction_coefficient);
+                for (index_t j = 0; j < nv; ++j) rows[static_cast<std::size_t>((b * (N + 1) + k) * nv + j)] = row[j];
+            }
+            const VectorXr m = v_.Get(measured_state);
+            for (index_t j = 0; j < nx; ++j) xm[static_cast<std::size_t>(b * nx + j)] = m[j];
+        }
+        batched.SetRows(rows.data(), xm.data());
+
+        // ---- iterate both; compare on the sampled instances
+        real_t worstStep = 0.0, worstIterate = 0.0, worstAlpha = 0.0;
+        std::vector<VectorXr> facade(static_cast<std::size_t>(compared));
+        std::vector<index_t> sample;
+        for (index_t s = 0; s < compared; ++s) sample.push_back(s < 3 ? s : (s * 131 + 7) % batch);
+        for (int iteration = 1; iteration <= 2; ++iteration) {
+            batched.Iterate();
+            const std::vector<real_t> dZ = batched.StateSteps(), dU = batched.InputSteps(), accepted = batched.AcceptedStepSizes();
+            const std::vector<int32_t> status = batched.QpStatus();
+            batched.GetRows(rows.data());
+            index_t failed = 0;
+            for (const int32_t st : status) failed += st != 0;
+            if (failed) {
+                std::printf("FAIL %td instances report an unsolved QP\n", failed);
+                return 1;
+            }
+            for (index_t s = 0; s < compared; ++s) {
+                const index_t b = sample[static_cast<std::size_t>(s)];
+                VectorXr& z = facade[static_cast<std::size_t>(s)];
+                if (iteration == 1) z = instances[static_cast<std::size_t>(b)];
+                const VectorXr before = z;
+                SoftSQPOptimizer optimizer{false, dt, index_t{1}, 1.0, 1.0};
+                const VectorXr after = optimizer.Optimize(nlp, z);
+                const std::vector<real_t>& d = optimizer.LastStep();
+                real_t num = 0.0, den = 0.0, scaleD = 0.0, scaleX = 0.0;
+                for (index_t i = 0; i < dec; ++i) {
+                    num += (after[i] - before[i]) * d[static_cast<std::size_t>(i)];
+                    den += d[static_cast<std::size_t>(i)] * d[static_cast<std::size_t>(i)];
+                    scaleD = std::max(scaleD, std::abs(d[static_cast<std::size_t>(i)]));
+                    scaleX = std::max(scaleX, std::abs(after[i]));
+                }
+                const real_t alphaFacade = den > 0.0 ? num / den : 0.0;
+                worstAlpha = std::max(worstAlpha, std::abs(alphaFacade - accepted[static_cast<std::size_t>(b)]));
+                for (index_t k = 0; k <= N; ++k)
+                    for (index_t i = 0; i < nx; ++i) {
+                        worstStep = std::max(worstStep, std::abs(dZ[static_cast<std::size_t>((b * (N + 1) + k) * nz + nc + i)] - d[static_cast<std::size_t>(k * nx + i)]) / scaleD);
+                        worstIterate = std::max(worstIterate, std::abs(rows[static_cast<std::size_t>((b * (N + 1) + k) * nv + nc + i)] - after[k * nx + i]) / scaleX);
+                    }
+                for (index_t k = 0; k < N; ++k)
+                    for (index_t i = 0; i < nu; ++i) {
+                        worstStep = std::max(worstStep, std::abs(dU[static_cast<std::size_t>((b * N + k) * nu + i)] - d[static_cast<std::size_t>((N + 1) * nx + k * nu + i)]) / scaleD);
+                        worstIterate = std::max(worstIterate, std::abs(rows[static_cast<std::size_t>((b * (N + 1) + k) * nv + nz + i)] - after[(N + 1) * nx + k * nu + i]) / scaleX);
+                    }
+                for (index_t i = 0; i < dec; ++i) z[i] = after[i];
+                std::printf("iteration %d instance %4td: step size facade %.6g batched %.6g  (|d|max %.3g)\n", iteration, b, alphaFacade, accepted[static_cast<std::size_t>(b)], scaleD);
+            }
+            index_t moved = 0;
+            for (const real_t a : accepted) moved += a > 0.0;
+            std::printf("iteration %d: %td of %td instances accepted a step; worst |d - d_facade| / |d|max = %.3e, worst |x - x_facade| / |x|max = %.3e, worst step-size difference %.3e\n",
+                        iteration, moved, batch, worstStep, worstIterate, worstAlpha);
+        }
+        const bool ok = worstStep <= 1e-9 && worstIterate <= 1e-9 && worstAlpha <= 1e-9;
+        std::printf("%s batched quadruped SQP (batch %td, %td compared)\n", ok ? "PASS" : "FAIL", batch, compared);
+        return ok ? 0 : 1;
+    } catch (const std::exception& e) {
+        std::printf("EXCEPTION %s\n", e.what());
+        return 2;
+    }
+}

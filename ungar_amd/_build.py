@@ -102,7 +102,8 @@ def build_library(jobs: int | None = None):
     for name in sorted(os.listdir(os.path.join(CSRC, "kernels"))):
         if name.endswith(".hip") and not name.startswith("model_"):
             src = os.path.join(CSRC, "kernels", name)
-            extra = ([os.path.join(CSRC, "kernels", "ocp_sqp.hpp"), os.path.join(CSRC, "kernels", "ocp_riccati.hpp")] if name.startswith("ocp_riccati") else
+            sqp_hdrs = [os.path.join(CSRC, "kernels", h) for h in ("ocp_sqp.hpp", "ocp_riccati.hpp", "ocp_barrier.hpp", "ocp_shooting.hpp")]
+            extra = (sqp_hdrs if name.startswith(("ocp_riccati", "ocp_shooting")) else
                      [os.path.join(CSRC, "kernels", "ocp_assembly.hpp")] if name.startswith("ocp_assembly") else
                      quad_deps if name.startswith("quad_") else
                      [os.path.join(GEN, f"{name[5:-4]}_cost_gen.hpp"), os.path.join(CSRC, "kernels", "cost_kernel.hpp")] if name.startswith("cost_") else [])
@@ -110,7 +111,7 @@ def build_library(jobs: int | None = None):
     src = os.path.join(CSRC, "runtime", "c_api.cpp")
     units.append((src, os.path.join(BUILD, "c_api.o"), [src, kernel_hdr, abi_hdr, os.path.join(CSRC, "kernels", "ocp_assembly.hpp")]))
     src = os.path.join(CSRC, "runtime", "c_api_sqp.cpp")
-    units.append((src, os.path.join(BUILD, "c_api_sqp.o"), [src, abi_hdr, os.path.join(CSRC, "kernels", "ocp_sqp.hpp"), os.path.join(CSRC, "kernels", "ocp_riccati.hpp")]))
+    units.append((src, os.path.join(BUILD, "c_api_sqp.o"), [src, abi_hdr] + [os.path.join(CSRC, "kernels", h) for h in ("ocp_sqp.hpp", "ocp_riccati.hpp", "ocp_shooting.hpp")]))
     src = os.path.join(CSRC, "runtime", "function.cpp")
     units.append((src, os.path.join(BUILD, "function.o"), [src, abi_hdr] + _tree(os.path.join(CSRC, "tape"))))
 

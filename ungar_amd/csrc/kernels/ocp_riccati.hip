@@ -9,6 +9,7 @@
 #include <string>
 
 #include "ocp_sqp.hpp"
+#include "ocp_barrier.hpp"
 
 namespace ungar_amd::kernels {
 
@@ -142,54 +143,13 @@ inline constexpr int kRiccatiWavesPerSimd = 1;
 inline constexpr int kRiccatiWavesPerSimd = (NX == 37 && NU == 12) ? 2 : (NX == 13 && NU == 4 && BLOCK == 64) ? 4 : 1;
 #endif
 
-template <int BLOCK, int SLOTS_AB, int SLOTS_W, int NX = 0, int NU = 0, bool AHEAD = true, bool DMA = false>
+template <int BLOCK, int SLOTS_AB, int SLOTS_W, int NX = 0, int NU = 0, bool AHEAD = true, bool DMA = false, int NE = 0>
 __global__ __launch_bounds__(BLOCK, (kRiccatiWavesPerSimd<BLOCK, NX, NU>)) void RiccatiKernel(const RiccatiArgs a) {
     extern __shared__ double scratch[];
     const long long inst = blockIdx.x;
     if (inst >= a.batch) return;
     DeviceExec<BLOCK, SLOTS_AB, SLOTS_W, AHEAD, DMA> ex;
-    RiccatiInstance<DeviceExec<BLOCK, SLOTS_AB, SLOTS_W, AHEAD, DMA>, NX, NU>(a, inst, scratch, ex);
-}
-
-/// Wavefront sum (64 lanes), result in every lane.
-__device__ __forceinline__ double WaveSum(double v) {
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-
-__device__ __forceinline__ double Barrier(const BarrierParams& p, double z) {
-    const double k = p.stiffness, eps = p.epsilon;
-    if (p.type == 1) {  // relaxed log barrier (soft_inequality_constraint.hpp:98-105)
-        if (z >= eps) return -k * log(z);
-        const double t = (z - 2.0 * eps) / eps;
-        return 0.5 * k * (t * t - 1.0) - k * log(eps);
-    }
-    // relaxed polynomial barrier (:131-190): quadratic below 0, cubic on [0, eps), 0 above
-    const double a1 = k, b1 = -0.5 * k * eps;
-    const double c1 = -(1.0 / 3.0) * (-b1 - a1 * eps) * eps - 0.5 * a1 * eps * eps - b1 * eps;
-    if (z < 0.0) return 0.5 * a1 * z * z + b1 * z + c1;
-    if (z < eps) {
-        const double a2 = (-b1 - a1 * eps) / (eps * eps);
-        return (1.0 / 3.0) * a2 * z * z * z + 0.5 * a1 * z * z + b1 * z + c1;
-    }
-    return 0.0;
-}
-
-__device__ __forceinline__ double BarrierD1(const BarrierParams& p, double z) {
-    const double k = p.stiffness, eps = p.epsilon;
-    if (p.type == 1) return z >= eps ? -k / z : k * (z - 2.0 * eps) / (eps * eps);
-    const double a1 = k, b1 = -0.5 * k * eps;
-    if (z < 0.0) return a1 * z + b1;
-    if (z < eps) return (-b1 - a1 * eps) / (eps * eps) * z * z + a1 * z + b1;
-    return 0.0;
-}
-__device__ __forceinline__ double BarrierD2(const BarrierParams& p, double z) {
-    const double k = p.stiffness, eps = p.epsilon;
-    if (p.type == 1) return z >= eps ? k / (z * z) : k / (eps * eps);
-    const double a1 = k, b1 = -0.5 * k * eps;
-    if (z < 0.0) return a1;
-    if (z < eps) return 2.0 * (-b1 - a1 * eps) / (eps * eps) * z + a1;
-    return 0.0;
+    RiccatiInstance<DeviceExec<BLOCK, SLOTS_AB, SLOTS_W, AHEAD, DMA>, NX, NU, NE>(a, inst, scratch, ex);
 }
 
 /// One workgroup per (instance, knot): the inequality Jacobian of the knot and the barrier derivatives are staged in LDS once,
@@ -294,14 +254,6 @@ __global__ __launch_bounds__(kBlock) void TrialKernel(const TrialArgs a) {
     }
 }
 
-/// Acceptance test of backtracking_line_search.hpp:116-151 for one candidate.
-__device__ inline bool StepAcceptable(double theta, double phi, double slope, double thetaNext, double phiNext, double alpha, double thetaMin, double thetaMax, double eta,
-                                      double gammaPhi, double gammaTheta) {
-    if (thetaNext > thetaMax) return thetaNext < (1.0 - gammaTheta) * theta;
-    if (fmax(theta, thetaNext) < thetaMin && slope < 0.0) return phiNext < phi + eta * alpha * slope;
-    return phiNext < (1.0 - gammaPhi) * phi || thetaNext < (1.0 - gammaTheta) * theta;
-}
-
 __global__ __launch_bounds__(kBlock) void SelectKernel(const SelectArgs a) {
     const long long b = blockIdx.x;
     if (b >= a.batch) return;
@@ -337,24 +289,31 @@ __global__ __launch_bounds__(kBlock) void AcceptKernel(const AcceptArgs a) {
 using namespace ungar_amd::kernels;
 
 namespace {
-template <int BLOCK, int SLOTS_AB, int SLOTS_W, int NX = 0, int NU = 0, bool AHEAD = true, bool DMA = false>
+template <int BLOCK, int SLOTS_AB, int SLOTS_W, int NX = 0, int NU = 0, bool AHEAD = true, bool DMA = false, int NE = 0>
 int LaunchRiccati(const RiccatiArgs* a, std::size_t lds, hipStream_t stream) {
     if (lds > 64 * 1024) {  // above the default dynamic-LDS limit the kernel has to opt in (160 KiB per CU on gfx950)
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(RiccatiKernel<BLOCK, SLOTS_AB, SLOTS_W, NX, NU, AHEAD, DMA>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(RiccatiKernel<BLOCK, SLOTS_AB, SLOTS_W, NX, NU, AHEAD, DMA, NE>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                  static_cast<int>(lds));
         if (e != hipSuccess) return static_cast<int>(e);
     }
-    hipLaunchKernelGGL((RiccatiKernel<BLOCK, SLOTS_AB, SLOTS_W, NX, NU, AHEAD, DMA>), dim3(static_cast<unsigned>(a->batch)), dim3(BLOCK), lds, stream, *a);
+    hipLaunchKernelGGL((RiccatiKernel<BLOCK, SLOTS_AB, SLOTS_W, NX, NU, AHEAD, DMA, NE>), dim3(static_cast<unsigned>(a->batch)), dim3(BLOCK), lds, stream, *a);
     return static_cast<int>(hipGetLastError());
 }
 }  // namespace
 
 extern "C" int ungar_amd_launch_riccati(const RiccatiArgs* a, void* stream) {
     if (a->batch <= 0) return 0;
-    const std::size_t lds = static_cast<std::size_t>(RiccatiScratchDoubles(a->nx, a->nu)) * sizeof(double);
+    const std::size_t lds = static_cast<std::size_t>(RiccatiScratchDoubles(a->nx, a->nu, a->ne)) * sizeof(double);
     if (lds > 160 * 1024) return static_cast<int>(hipErrorInvalidValue);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int n = a->nx + a->nu, ab = a->nx * n, w = n * n;
+    // The reference's OCPs with their carried quantities in the stage state (ocp_shooting.hpp): quadrotor [u_prev; x] 17 + 4,
+    // RC car 8 + 2 (one wavefront, next knot's operands staged in registers), quadruped [feet_prev; x] 25 + 24 with its 16
+    // foot-contact rows (four wavefronts, operands by LDS-DMA).
+    if (a->ne == 0 && a->nx == 17 && a->nu == 4) return LaunchRiccati<64, 6, 7, 17, 4>(a, lds, s);
+    if (a->ne == 0 && a->nx == 8 && a->nu == 2) return LaunchRiccati<64, 2, 2, 8, 2>(a, lds, s);
+    if (a->ne == 16 && a->nx == 25 && a->nu == 24) return LaunchRiccati<256, 0, 0, 25, 24, true, true, 16>(a, lds, s);
+    if (a->ne > 0) return n >= 32 ? LaunchRiccati<256, 0, 0>(a, lds, s) : LaunchRiccati<64, 0, 0>(a, lds, s);  // run-time sizes
     // Variants of the same recursion (tools/bench_sqp.py): lanes per instance (one or four wavefronts
     // share the entries of every product) and whether the next knot's operands are staged in registers.
     //   "64" / "128" / "256"   one / two / four wavefronts per instance, operands read in place;   "128p" / "256p"   staged

@@ -68,7 +68,7 @@ struct AcceptArgs {
 
 /// Stage data of the QP from the node kernels' outputs (soft_sqp.hpp:143-155, 247-264 restricted to one knot):
 ///   b_k = f_k - x_{k+1},  dx_0 = x_m - x_0,
-///   W_k = hess cost_k + J_h^T diag(b''(-h)) J_h   (upper triangle of the dense (nx+nu)^2 block; the rest is zeroed),
+///   W_k = hess cost_k + J_h^T diag(b''(-h)) J_h   (upper triangle of the dense (nx+nu)^2 block; the strict lower triangle is left untouched),
 ///   w_k = grad cost_k - J_h^T b'(-h).
 struct StageQpArgs {
     int nx, nu, N, nh, hesNnz;

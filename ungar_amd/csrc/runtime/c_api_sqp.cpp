@@ -1,10 +1,11 @@
 // ungar_amd :: C ABI of the batched SQP iteration (include/ungar_amd.h, "batched SQP iteration"): argument checks and launches.
 #include <hip/hip_runtime.h>
 
+#include <cstdint>
 #include <string>
 
 #include "../../../include/ungar_amd.h"
-#include "../kernels/ocp_sqp.hpp"
+#include "../kernels/ocp_shooting.hpp"
 
 namespace ungar_amd::runtime {
 int Fail(int code, const std::string& msg);  // c_api.cpp
@@ -25,7 +26,23 @@ BarrierParams Barrier(const ungar_barrier& b) {
     return {b.type, b.stiffness, b.epsilon};
 }
 bool BadDims(int64_t nx, int64_t nu, int64_t N, int64_t batch) {
-    return nx < 1 || nu < 1 || N < 1 || batch < 0 || nx > 255 || nu > 255 || N > (1 << 20);
+    // grids are 32-bit: batch * (N + 1) workgroups (x 16 stacked candidates) must stay below 2^31, and the (row, column) bytes of the
+    // stage-QP pattern need nx + nu <= 256
+    return nx < 1 || nu < 1 || N < 1 || batch < 0 || nx > 255 || nu > 255 || nx + nu > 256 || N > (1 << 20) || batch * (N + 1) > (INT32_MAX >> 4);
+}
+bool ToDims(const ungar_shooting_dims& d, ShootingDims* out) {
+    if (d.nx < 1 || d.nu < 1 || d.nc < 0 || d.nw < 0 || d.np < 0 || d.horizon < 1 || d.batch < 0 || d.nc + d.nx + d.nu > 256 || d.nw + d.np > (1 << 20) ||
+        d.horizon > (1 << 20) || d.batch * (d.horizon + 1) > (INT32_MAX >> 4) || (d.carry_inputs && d.nc != d.nu))
+        return false;
+    *out = ShootingDims{static_cast<int>(d.nx), static_cast<int>(d.nu), static_cast<int>(d.nc), static_cast<int>(d.nw), static_cast<int>(d.np), static_cast<int>(d.horizon),
+                        d.carry_inputs ? 1 : 0, d.batch};
+    return true;
+}
+StagePattern Pattern(const ungar_stage_pattern& p) {
+    return {p.rows, p.cols, static_cast<int>(p.nnz)};
+}
+bool BadPattern(const ungar_stage_pattern& p, const double* values) {
+    return p.nnz < 0 || p.nnz > (1 << 20) || (p.nnz > 0 && (!p.rows || !p.cols || !values));
 }
 int Launched(int err, const char* what) {
     if (err != 0) return Fail(UNGAR_E_HIP, std::string(what) + ": " + hipGetErrorString(static_cast<hipError_t>(err)));
@@ -84,10 +101,18 @@ int ungar_ocp_riccati_solve(const ungar_ocp_qp* q, void* stream) {
         return Fail(UNGAR_E_INVALID, "ungar_ocp_riccati_solve: null operand base");
     if (!q->workspace || q->workspace_doubles < ungar_ocp_riccati_workspace(q->nx, q->nu, q->horizon, q->batch))
         return Fail(UNGAR_E_INVALID, "ungar_ocp_riccati_solve: workspace too small (see ungar_ocp_riccati_workspace)");
-    if (static_cast<std::size_t>(RiccatiScratchDoubles(static_cast<int>(q->nx), static_cast<int>(q->nu))) * sizeof(double) > 160 * 1024)
+    if (q->ne < 0 || q->ne > 64 || (q->ne > 0 && (!q->eq.base || !q->eq_values.base)) || q->hess_terminal_ld < 0 || (q->hess_terminal_ld > 0 && q->hess_terminal_ld < q->nx))
+        return Fail(UNGAR_E_INVALID, "ungar_ocp_riccati_solve: bad equality block (at most 64 rows) or terminal leading dimension");
+    if (static_cast<std::size_t>(RiccatiScratchDoubles(static_cast<int>(q->nx), static_cast<int>(q->nu), static_cast<int>(q->ne))) * sizeof(double) > 160 * 1024)
         return Fail(UNGAR_E_UNSUPPORTED, "ungar_ocp_riccati_solve: nx + nu too large for the LDS-resident recursion (160 KiB per workgroup)");
-    const RiccatiArgs k{static_cast<int>(q->nx), static_cast<int>(q->nu), static_cast<int>(q->horizon), q->batch, View(q->jac), View(q->b), View(q->hess), View(q->grad),
-                        View(q->hess_terminal), View(q->grad_terminal), View(q->dx0), View(q->dX), View(q->dU), q->workspace, q->regularization, q->status};
+    RiccatiArgs k{static_cast<int>(q->nx), static_cast<int>(q->nu), static_cast<int>(q->horizon), q->batch, View(q->jac), View(q->b), View(q->hess), View(q->grad),
+                  View(q->hess_terminal), View(q->grad_terminal), View(q->dx0), View(q->dX), View(q->dU), q->workspace, q->regularization, q->status};
+    k.ne = static_cast<int>(q->ne);
+    if (q->ne > 0) {
+        k.eq = View(q->eq);
+        k.eqv = View(q->eq_values);
+    }
+    k.hessNld = static_cast<int>(q->hess_terminal_ld);
     return Launched(ungar_amd_launch_riccati(&k, stream), "ungar_ocp_riccati_solve");
 }
 
@@ -150,6 +175,168 @@ int ungar_ocp_line_search_accept(int64_t nx, int64_t nu, int64_t horizon, int64_
     const AcceptArgs k{static_cast<int>(nx), static_cast<int>(nu), static_cast<int>(horizon), batch, alpha, p->theta_min, p->theta_max, p->eta, p->gamma_phi, p->gamma_theta,
                        theta0, phi0, slope, theta_trial, phi_trial, accepted, View(*X), View(*U), View(*Xt), View(*Ut)};
     return Launched(ungar_amd_launch_ocp_accept(&k, stream), "ungar_ocp_line_search_accept");
+}
+
+int ungar_shooting_assemble(const ungar_shooting_assemble_args* a, void* stream) {
+    ShootingAssembleArgs k{};
+    if (!a || !ToDims(a->dims, &k.d)) return Fail(UNGAR_E_INVALID, "ungar_shooting_assemble: bad dimensions");
+    if (k.d.batch == 0) return UNGAR_OK;
+    if (!a->rows || !a->xm || !a->f || !a->AB || !a->b || !a->W || !a->w || !a->dz0) return Fail(UNGAR_E_INVALID, "ungar_shooting_assemble: null argument");
+    if (a->nh < 0 || a->nh > 256 || a->ne < 0 || a->ne > 64 || (a->nh > 0 && !a->h) || (a->ne > 0 && !a->E)) return Fail(UNGAR_E_INVALID, "ungar_shooting_assemble: bad row counts");
+    if (BadPattern(a->f_pattern, a->f_jac) || BadPattern(a->cost_grad_pattern, a->cost_grad) || BadPattern(a->cost_hes_pattern, a->cost_hes) ||
+        (a->nh > 0 && BadPattern(a->h_pattern, a->h_jac)) || (a->ne > 0 && BadPattern(a->eq_pattern, a->eq_jac)) || (!k.d.carryInputs && k.d.nc > 0 && BadPattern(a->carry_pattern, a->carry_jac)))
+        return Fail(UNGAR_E_INVALID, "ungar_shooting_assemble: bad sparsity pattern");
+    k.rows = a->rows;
+    k.xm = a->xm;
+    k.f = a->f;
+    k.fJ = a->f_jac;
+    k.cJ = a->carry_jac;
+    k.lg = a->cost_grad;
+    k.lH = a->cost_hes;
+    k.h = a->nh > 0 ? a->h : nullptr;
+    k.hJ = a->nh > 0 ? a->h_jac : nullptr;
+    k.eJ = a->ne > 0 ? a->eq_jac : nullptr;
+    k.pf = Pattern(a->f_pattern);
+    k.pc = !k.d.carryInputs && k.d.nc > 0 ? Pattern(a->carry_pattern) : StagePattern{nullptr, nullptr, 0};
+    k.pg = Pattern(a->cost_grad_pattern);
+    k.pH = Pattern(a->cost_hes_pattern);
+    k.ph = a->nh > 0 ? Pattern(a->h_pattern) : StagePattern{nullptr, nullptr, 0};
+    k.pe = a->ne > 0 ? Pattern(a->eq_pattern) : StagePattern{nullptr, nullptr, 0};
+    k.nh = static_cast<int>(a->nh);
+    k.ne = static_cast<int>(a->ne);
+    k.barrier = Barrier(a->barrier);
+    k.regularization = a->regularization;
+    k.AB = a->AB;
+    k.b = a->b;
+    k.W = a->W;
+    k.w = a->w;
+    k.E = a->E;
+    k.dz0 = a->dz0;
+    return Launched(ungar_amd_launch_shooting_assemble(&k, stream), "ungar_shooting_assemble");
+}
+
+int ungar_shooting_merit(const ungar_shooting_merit_args* a, void* stream) {
+    ShootingMeritArgs k{};
+    if (!a || !ToDims(a->dims, &k.d) || a->period < 0 || (a->period > 0 && a->dims.batch % a->period != 0) || a->nh < 0 || a->ne < 0)
+        return Fail(UNGAR_E_INVALID, "ungar_shooting_merit: bad dimensions");
+    if (k.d.batch == 0) return UNGAR_OK;
+    if (!a->rows || !a->xm || !a->f || !a->cost || !a->theta || !a->phi) return Fail(UNGAR_E_INVALID, "ungar_shooting_merit: null argument");
+    if (a->cost_grad && (BadPattern(a->cost_grad_pattern, a->cost_grad) || !a->dZ || !a->dU || !a->slope)) return Fail(UNGAR_E_INVALID, "ungar_shooting_merit: the slope needs the gradient pattern, dZ, dU and slope");
+    k.rows = a->rows;
+    k.xm = a->xm;
+    k.f = a->f;
+    k.l = a->cost;
+    k.h = a->nh > 0 ? a->h : nullptr;
+    k.e = a->ne > 0 ? a->eq : nullptr;
+    k.nh = static_cast<int>(a->nh);
+    k.ne = static_cast<int>(a->ne);
+    k.barrier = Barrier(a->barrier);
+    k.violationMultiplier = a->violation_multiplier;
+    k.lg = a->cost_grad;
+    k.pg = a->cost_grad ? Pattern(a->cost_grad_pattern) : StagePattern{nullptr, nullptr, 0};
+    k.dZ = a->dZ;
+    k.dU = a->dU;
+    k.theta = a->theta;
+    k.phi = a->phi;
+    k.objective = a->objective;
+    k.slope = a->slope;
+    k.period = a->period;
+    return Launched(ungar_amd_launch_shooting_merit(&k, stream), "ungar_shooting_merit");
+}
+
+int ungar_shooting_trial_rows(const ungar_shooting_dims* dims, const double* rows, const double* dZ, const double* dU, const double* alphas, int64_t candidates,
+                              double* trial, void* stream) {
+    ShootingTrialArgs k{};
+    if (!dims || !ToDims(*dims, &k.d) || !alphas || candidates < 1 || candidates > kMaxLineSearchCandidates)
+        return Fail(UNGAR_E_INVALID, "ungar_shooting_trial_rows: bad argument (1 <= candidates <= 16)");
+    if (k.d.batch == 0) return UNGAR_OK;
+    if (!rows || !dZ || !dU || !trial) return Fail(UNGAR_E_INVALID, "ungar_shooting_trial_rows: null argument");
+    k.rows = rows;
+    k.dZ = dZ;
+    k.dU = dU;
+    k.trial = trial;
+    k.candidates = static_cast<int>(candidates);
+    for (int64_t c = 0; c < candidates; ++c) k.alphas[c] = alphas[c];
+    return Launched(ungar_amd_launch_shooting_trial(&k, stream), "ungar_shooting_trial_rows");
+}
+
+int ungar_shooting_select(const ungar_shooting_dims* dims, const ungar_line_search_parameters* p, const double* alphas, int64_t candidates, const double* theta0,
+                          const double* phi0, const double* objective0, const double* slope, const double* theta_trial, const double* phi_trial,
+                          const double* objective_trial, double* accepted, int32_t* active, const int32_t* status, double* rows, const double* trial, void* stream) {
+    ShootingSelectArgs k{};
+    if (!dims || !ToDims(*dims, &k.d) || !p || !alphas || candidates < 1 || candidates > kMaxLineSearchCandidates)
+        return Fail(UNGAR_E_INVALID, "ungar_shooting_select: bad argument (1 <= candidates <= 16)");
+    if (k.d.batch == 0) return UNGAR_OK;
+    if (!theta0 || !phi0 || !objective0 || !slope || !theta_trial || !phi_trial || !objective_trial || !accepted || !rows || !trial)
+        return Fail(UNGAR_E_INVALID, "ungar_shooting_select: null argument");
+    k.candidates = static_cast<int>(candidates);
+    k.thetaMin = p->theta_min;
+    k.thetaMax = p->theta_max;
+    k.eta = p->eta;
+    k.gammaPhi = p->gamma_phi;
+    k.gammaTheta = p->gamma_theta;
+    for (int64_t c = 0; c < candidates; ++c) k.alphas[c] = alphas[c];
+    k.theta0 = theta0;
+    k.phi0 = phi0;
+    k.objective0 = objective0;
+    k.slope = slope;
+    k.thetaT = theta_trial;
+    k.phiT = phi_trial;
+    k.objectiveT = objective_trial;
+    k.accepted = accepted;
+    k.active = active;
+    k.status = status;
+    k.rows = rows;
+    k.trial = trial;
+    return Launched(ungar_amd_launch_shooting_select(&k, stream), "ungar_shooting_select");
+}
+
+int ungar_device_malloc(void** out, int64_t bytes) {
+    if (!out || bytes < 0) return Fail(UNGAR_E_INVALID, "ungar_device_malloc: bad argument");
+    *out = nullptr;
+    if (bytes == 0) return UNGAR_OK;
+    const hipError_t e = hipMalloc(out, static_cast<std::size_t>(bytes));
+    if (e != hipSuccess) return Fail(UNGAR_E_HIP, std::string("ungar_device_malloc: ") + hipGetErrorString(e));
+    return UNGAR_OK;
+}
+int ungar_device_free(void* ptr) {
+    if (!ptr) return UNGAR_OK;
+    const hipError_t e = hipFree(ptr);
+    if (e != hipSuccess) return Fail(UNGAR_E_HIP, std::string("ungar_device_free: ") + hipGetErrorString(e));
+    return UNGAR_OK;
+}
+int ungar_device_upload(void* dst, const void* src, int64_t bytes) {
+    if (bytes < 0 || (bytes > 0 && (!dst || !src))) return Fail(UNGAR_E_INVALID, "ungar_device_upload: bad argument");
+    if (bytes == 0) return UNGAR_OK;
+    const hipError_t e = hipMemcpy(dst, src, static_cast<std::size_t>(bytes), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return Fail(UNGAR_E_HIP, std::string("ungar_device_upload: ") + hipGetErrorString(e));
+    return UNGAR_OK;
+}
+int ungar_device_download(void* dst, const void* src, int64_t bytes) {
+    if (bytes < 0 || (bytes > 0 && (!dst || !src))) return Fail(UNGAR_E_INVALID, "ungar_device_download: bad argument");
+    if (bytes == 0) return UNGAR_OK;
+    const hipError_t e = hipMemcpy(dst, src, static_cast<std::size_t>(bytes), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return Fail(UNGAR_E_HIP, std::string("ungar_device_download: ") + hipGetErrorString(e));
+    return UNGAR_OK;
+}
+int ungar_device_zero(void* dst, int64_t bytes, void* stream) {
+    if (bytes < 0 || (bytes > 0 && !dst)) return Fail(UNGAR_E_INVALID, "ungar_device_zero: bad argument");
+    if (bytes == 0) return UNGAR_OK;
+    const hipError_t e = hipMemsetAsync(dst, 0, static_cast<std::size_t>(bytes), static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return Fail(UNGAR_E_HIP, std::string("ungar_device_zero: ") + hipGetErrorString(e));
+    return UNGAR_OK;
+}
+int ungar_device_copy(void* dst, const void* src, int64_t bytes, void* stream) {
+    if (bytes < 0 || (bytes > 0 && (!dst || !src))) return Fail(UNGAR_E_INVALID, "ungar_device_copy: bad argument");
+    if (bytes == 0) return UNGAR_OK;
+    const hipError_t e = hipMemcpyAsync(dst, src, static_cast<std::size_t>(bytes), hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return Fail(UNGAR_E_HIP, std::string("ungar_device_copy: ") + hipGetErrorString(e));
+    return UNGAR_OK;
+}
+int ungar_device_synchronize(void) {
+    const hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) return Fail(UNGAR_E_HIP, std::string("ungar_device_synchronize: ") + hipGetErrorString(e));
+    return UNGAR_OK;
 }
 
 }  // extern "C"

@@ -237,11 +237,13 @@ std::string EmitKernel(const std::string& kernelName, const tape::Graph& g, int6
     // launched with 64-lane workgroups (LaunchFn): tell the compiler, so that it may use the full register file
     os << "extern \"C\" __global__ __launch_bounds__(64) void " << kernelName
        << "(const double* __restrict__ xp, long long xbs, long long xes, double* __restrict__ outBase, long long obs, long long oes, long long "
-          "batch) {\n"
+          "batch, long long knots, long long xks, long long oks) {\n"
        << "    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;\n"
        << "    if (i >= batch) return;\n"
-       << "    const double* __restrict__ in = xp + i * xbs;\n"
-       << "    double* __restrict__ out = outBase + i * obs;\n";
+       // node i = (instance i / knots, knot i % knots): the shooting nodes of a batch of horizons, each instance a strided run of knots
+       << "    const long long ib = knots > 1 ? i / knots : i, ik = i - ib * knots;\n"
+       << "    const double* __restrict__ in = xp + ib * xbs + ik * xks;\n"
+       << "    double* __restrict__ out = outBase + ib * obs + ik * oks;\n";
     tape::Emitter em{g, inNames};
     os << em.Emit(slots) << "}\n\n";
     if (statements) *statements = em.Stats().statements;
@@ -306,6 +308,10 @@ int ungar_function_make(const ungar_tape_node* nodes, int64_t num_nodes, const i
     key.Str(kArch);
     key.Str(ToolchainVersion());  // the ROCm release whose compiler produces the code objects
     key.Str(custom ? custom : "");
+    {
+        const char* compiler = std::getenv("UNGAR_HIPCC");  // a different compiler (or a wrapper that adds flags) must not share entries
+        key.Str(compiler ? compiler : "");
+    }
     key.Int(n);
     key.Int(p);
     key.Int(m);
@@ -563,16 +569,17 @@ int ungar_function_hessian_sparsity(const ungar_function* fn, const int32_t** ro
 }
 
 static int LaunchFn(const ungar_function* fn, hipFunction_t k, const char* what, const ungar_operand* xp, const ungar_operand* out,
-                    int64_t batch, void* stream) {
+                    int64_t batch, void* stream, int64_t knotsPerInstance = 1) {
     if (!fn || !xp || !out) return Fail(UNGAR_E_INVALID, std::string(what) + ": null argument");
     if (!k) return Fail(UNGAR_E_UNSUPPORTED, std::string(what) + ": kernel not available for function '" + fn->name + "' (derivative not enabled, or made with UNGAR_AMD_COMPILE_ONLY)");
-    if (batch < 0) return Fail(UNGAR_E_INVALID, std::string(what) + ": negative batch");
+    if (batch < 0 || knotsPerInstance < 1) return Fail(UNGAR_E_INVALID, std::string(what) + ": negative batch or knots < 1");
     if (batch == 0) return UNGAR_OK;
     if (!xp->base || !out->base) return Fail(UNGAR_E_INVALID, std::string(what) + ": null operand base");
     const double* in = xp->base;
     long long xbs = xp->instance_stride, xes = xp->element_stride, obs = out->instance_stride, oes = out->element_stride, b = batch;
     double* o = out->base;
-    void* args[] = {&in, &xbs, &xes, &o, &obs, &oes, &b};
+    long long knots = knotsPerInstance, xks = xp->knot_stride, oks = out->knot_stride;
+    void* args[] = {&in, &xbs, &xes, &o, &obs, &oes, &b, &knots, &xks, &oks};
     const unsigned block = 64;
     const hipError_t e = hipModuleLaunchKernel(k, static_cast<unsigned>((batch + block - 1) / block), 1, 1, block, 1, 1, 0,
                                                static_cast<hipStream_t>(stream), args, nullptr);
@@ -593,6 +600,19 @@ int ungar_function_sparse_jacobian(const ungar_function* fn, const ungar_operand
 int ungar_function_sparse_hessian(const ungar_function* fn, const ungar_operand* xp, const ungar_operand* hes, int64_t batch, void* stream) {
     if (fn && xp && hes && batch >= 0 && (fn->enabled & kEnableHessian) && fn->hesRows.empty()) return UNGAR_OK;
     return LaunchFn(fn, fn ? fn->kHes : nullptr, "ungar_function_sparse_hessian", xp, hes, batch, stream);
+}
+
+// Shooting nodes: node i = (instance i / knots, knot i % knots) at base + instance * instance_stride + knot * knot_stride.
+int ungar_function_forward_zero_nodes(const ungar_function* fn, const ungar_operand* xp, const ungar_operand* y, int64_t count, int64_t knots, void* stream) {
+    return LaunchFn(fn, fn ? fn->kValue : nullptr, "ungar_function_forward_zero_nodes", xp, y, count, stream, knots);
+}
+int ungar_function_sparse_jacobian_nodes(const ungar_function* fn, const ungar_operand* xp, const ungar_operand* jac, int64_t count, int64_t knots, void* stream) {
+    if (fn && xp && jac && count >= 0 && (fn->enabled & kEnableJacobian) && fn->jacRows.empty()) return UNGAR_OK;
+    return LaunchFn(fn, fn ? fn->kJac : nullptr, "ungar_function_sparse_jacobian_nodes", xp, jac, count, stream, knots);
+}
+int ungar_function_sparse_hessian_nodes(const ungar_function* fn, const ungar_operand* xp, const ungar_operand* hes, int64_t count, int64_t knots, void* stream) {
+    if (fn && xp && hes && count >= 0 && (fn->enabled & kEnableHessian) && fn->hesRows.empty()) return UNGAR_OK;
+    return LaunchFn(fn, fn ? fn->kHes : nullptr, "ungar_function_sparse_hessian_nodes", xp, hes, count, stream, knots);
 }
 
 /// Single-instance host call: H2D, batch-1 launch, D2H, on the null stream, synchronous.

@@ -1,0 +1,421 @@
+// ungar_amd :: soft SQP for a BATCH of independent shooting problems, entirely on the device -- the batched counterpart of
+// SoftSQPOptimizer (soft_sqp.hpp in this directory; reference include/ungar/optimization/soft_sqp.hpp:42-283).
+//
+// The reference solves ONE optimal-control problem per SoftSQPOptimizer::Optimize call: whole-horizon objective / equality /
+// inequality functions, one OSQP instance (soft_sqp.hpp:62-112, 143-158).  An MPC fleet, a sampling-based planner or a parameter
+// sweep solves thousands of instances of the SAME problem; here they advance together, one launch per step of the iteration:
+//
+//   user side     the problem is described by its STAGE functions -- the lambdas the reference's examples inline N times into
+//                 their whole-horizon tapes (example/mpc/quadrotor.example.cpp:126-190, 196-291) -- as ordinary
+//                 Ungar::Autodiff::Functions over one node's variables:
+//                     dynamics    [x | u ; w | p] -> x+                         (JACOBIAN)
+//                     carry       [x | u ; w | p] -> c+   (optional)            (JACOBIAN)
+//                     cost        [c | x | u ; w | p] -> 1 value                (ALL)       row N: the terminal cost
+//                     equality    [c | x | u ; w | p] -> ne rows (= 0)          (JACOBIAN)  optional
+//                     inequality  [c | x | u ; w | p] -> nh rows (<= 0)         (JACOBIAN)  optional, behind the relaxed barrier
+//                 with w = parameters of the knot (references, contact flags, weights that switch terms off at k = 0 / k = N) and
+//                 p = parameters of the instance.  c carries a quantity of the PREVIOUS knot into the stage, which is how the
+//                 cross-knot terms of the reference's OCPs become stage-local: the input-rate cost 1e-6 |u_k - u_{k-1}|^2
+//                 (quadrotor.example.cpp:222-227, rc_car.example.cpp:216-220: carry the inputs) and the foot-contact rows
+//                 pFoot_k - pFoot_{k-1} (quadruped.example.cpp:279-304: carry the foot positions).
+//   device side   node rows [c|x|u|w|p] of all instances in one array; per iteration (SoftSQPOptimizer::Optimize's loop body):
+//                 stage derivatives (ungar_function_*_nodes) -> ungar_shooting_assemble -> ungar_ocp_riccati_solve (the exact
+//                 solution of the QP the reference hands to OSQP, stage equality rows included) -> merit terms -> all candidate steps
+//                 of the backtracking search as one stacked batch -> per-instance selection and stopping rule.
+// Host code is plain C++20 over the C ABI (include/ungar_amd.h); no HIP headers, no host round trip inside an iteration.
+#pragma once
+
+#include <cstdint>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../autodiff/function.hpp"
+#include "backtracking_line_search.hpp"
+#include "soft_sqp.hpp"
+
+namespace Ungar {
+
+/// One shooting problem in stage form.  Sizes: state nx, input nu, carried quantity nc (0: none), knot parameters nw, instance
+/// parameters np; every function takes nw + np parameters (whether it uses them or not), so that one node row serves all of them.
+struct ShootingProblem {
+    index_t horizon = 0, stateSize = 0, inputSize = 0, carrySize = 0, knotParameterSize = 0, instanceParameterSize = 0;
+    bool carryInputs = false;  ///< c_{k+1} = u_k without a carry function (carrySize == inputSize)
+    std::optional<Autodiff::Function> dynamics, carry, cost, equality, inequality;
+
+    index_t RowSize() const {
+        return carrySize + stateSize + inputSize + knotParameterSize + instanceParameterSize;
+    }
+    index_t CarryOffset() const { return 0; }
+    index_t StateOffset() const { return carrySize; }
+    index_t InputOffset() const { return carrySize + stateSize; }
+    index_t KnotParameterOffset() const { return carrySize + stateSize + inputSize; }
+    index_t InstanceParameterOffset() const { return carrySize + stateSize + inputSize + knotParameterSize; }
+};
+
+class BatchedSoftSQPOptimizer {
+  public:
+    /// Same parameters as SoftSQPOptimizer (reference soft_sqp.hpp:44-60) plus the number of instances.
+    BatchedSoftSQPOptimizer(ShootingProblem problem, const index_t batch, const bool verbose = false, const real_t constraintViolationMultiplier = 1.0,
+                            const index_t maxIterations = 10, const real_t stiffness = 100.0, const real_t epsilon = 2e-5,
+                            const RelaxedBarrierType relaxedBarrierType = RelaxedBarrierType::POLY)
+        : _p{std::move(problem)}, _batch{batch}, _verbose{verbose}, _multiplier{constraintViolationMultiplier}, _maxIterations{maxIterations} {
+        _barrier.type = relaxedBarrierType == RelaxedBarrierType::LOG ? UNGAR_BARRIER_LOG : UNGAR_BARRIER_POLY;
+        _barrier.reserved = 0;
+        _barrier.stiffness = stiffness;
+        _barrier.epsilon = epsilon;
+        Validate();
+        _dims = {_p.stateSize, _p.inputSize, _p.carrySize, _p.knotParameterSize, _p.instanceParameterSize, _p.horizon, _batch, _p.carryInputs ? 1 : 0, 0};
+        for (real_t alpha = 1.0; alpha >= _ls.alphaMin; alpha *= _ls.gammaAlpha) _alphas.push_back(alpha);  // backtracking_line_search.hpp:116-151
+        if (_alphas.empty() || _alphas.size() > 16) throw std::invalid_argument("BatchedSoftSQPOptimizer: the line search must try between 1 and 16 step sizes");
+        Allocate();
+    }
+    BatchedSoftSQPOptimizer(const BatchedSoftSQPOptimizer&) = delete;
+    BatchedSoftSQPOptimizer& operator=(const BatchedSoftSQPOptimizer&) = delete;
+    ~BatchedSoftSQPOptimizer() {
+        for (void* ptr : _owned) (void)ungar_device_free(ptr);
+    }
+
+    const ShootingProblem& Problem() const { return _p; }
+    index_t Batch() const { return _batch; }
+    index_t RowSize() const { return _p.RowSize(); }
+    /// Doubles of the host image of all node rows: batch x (horizon + 1) x RowSize(), row (b, k) at ((b (N + 1)) + k) RowSize().
+    index_t RowsSize() const { return _batch * (_p.horizon + 1) * _p.RowSize(); }
+
+    /// Uploads the node rows [c | x | u | w | p] of every instance and the measured states (batch x nx); the carried slots of rows
+    /// 1..N are then made consistent with (x, u) of the previous row (row 0's carried slots are the caller's: the quantity measured
+    /// before the horizon, e.g. measured foot positions).  All instances become active.
+    void SetRows(const real_t* rows, const real_t* measuredStates) {
+        Check(ungar_device_upload(_rows, rows, Bytes(RowsSize())));
+        Check(ungar_device_upload(_xm, measuredStates, Bytes(_batch * _p.stateSize)));
+        RefreshCarried();
+        std::vector<int32_t> ones(static_cast<std::size_t>(_batch), 1);
+        Check(ungar_device_upload(_active, ones.data(), static_cast<int64_t>(ones.size() * sizeof(int32_t))));
+    }
+    void GetRows(real_t* rows) const { Check(ungar_device_download(rows, _rows, Bytes(RowsSize()))); }
+    /// Device pointer of the node rows (for callers that fill them on the device) -- call RefreshCarried() after writing (x, u).
+    real_t* DeviceRows() const { return _rows; }
+    real_t* DeviceMeasuredStates() const { return _xm; }
+
+    void RefreshCarried() {
+        if (_p.carrySize == 0) return;
+        if (_p.carryInputs) {  // a zero-length step through the trial kernel copies u_k into the carried slots of row k + 1
+            const index_t N = _p.horizon;
+            Check(ungar_device_zero(_dZ, Bytes(_batch * (N + 1) * Nz()), _stream));
+            Check(ungar_device_zero(_dU, Bytes(_batch * N * _p.inputSize), _stream));
+            const real_t one = 1.0;
+            Check(ungar_shooting_trial_rows(&_dims, _rows, _dZ, _dU, &one, 1, _trial, _stream));
+            Check(ungar_device_copy(_rows, _trial, Bytes(RowsSize()), _stream));
+        } else {
+            CarryValues(_rows, _batch);
+        }
+    }
+
+    /// One SQP iteration of every active instance (the body of the reference's loop, soft_sqp.hpp:68-99).
+    void Iterate() {
+        const index_t N = _p.horizon, B = _batch, K = static_cast<index_t>(_alphas.size());
+        // ---- derivatives at the current rows
+        Evaluate(*_p.dynamics, 0, _rows, _p.StateOffset(), _f, B * (N + 1));
+        Evaluate(*_p.dynamics, 1, _rows, _p.StateOffset(), _fJ, B * (N + 1));
+        if (_p.carry) Evaluate(*_p.carry, 1, _rows, _p.StateOffset(), _cJ, B * (N + 1));
+        Evaluate(*_p.cost, 0, _rows, 0, _l, B * (N + 1));
+        Evaluate(*_p.cost, 1, _rows, 0, _lg, B * (N + 1));
+        Evaluate(*_p.cost, 2, _rows, 0, _lH, B * (N + 1));
+        if (_p.inequality) {
+            Evaluate(*_p.inequality, 0, _rows, 0, _h, B * (N + 1));
+            Evaluate(*_p.inequality, 1, _rows, 0, _hJ, B * (N + 1));
+        }
+        if (_p.equality) {
+            Evaluate(*_p.equality, 0, _rows, 0, _e, B * (N + 1));
+            Evaluate(*_p.equality, 1, _rows, 0, _eJ, B * (N + 1));
+        }
+        // ---- QP data and solve (soft_sqp.hpp:143-158)
+        ungar_shooting_assemble_args a{};
+        a.dims = _dims;
+        a.rows = _rows;
+        a.xm = _xm;
+        a.f = _f;
+        a.f_jac = _fJ;
+        a.carry_jac = _cJ;
+        a.cost_grad = _lg;
+        a.cost_hes = _lH;
+        a.h = _h;
+        a.h_jac = _hJ;
+        a.eq_jac = _eJ;
+        a.f_pattern = _pf;
+        a.carry_pattern = _pc;
+        a.cost_grad_pattern = _pg;
+        a.cost_hes_pattern = _pH;
+        a.h_pattern = _ph;
+        a.eq_pattern = _pe;
+        a.nh = Nh();
+        a.ne = Ne();
+        a.barrier = _barrier;
+        a.regularization = 1e-6;  // soft_sqp.hpp:149-151
+        a.AB = _AB;
+        a.b = _b;
+        a.W = _W;
+        a.w = _w;
+        a.E = _E;
+        a.dz0 = _dz0;
+        Check(ungar_shooting_assemble(&a, _stream));
+        const index_t nz = Nz(), nu = _p.inputSize, nd = nz + nu;
+        ungar_ocp_qp q{};
+        q.nx = nz;
+        q.nu = nu;
+        q.horizon = N;
+        q.batch = B;
+        q.jac = {_AB, N * nz * nd, nz * nd, 1};
+        q.b = {_b, N * nz, nz, 1};
+        q.hess = {_W, (N + 1) * nd * nd, nd * nd, 1};
+        q.grad = {_w, (N + 1) * nd, nd, 1};
+        q.hess_terminal = {_W + N * nd * nd, (N + 1) * nd * nd, 0, 1};  // the z block of row N
+        q.hess_terminal_ld = nd;
+        q.grad_terminal = {_w + N * nd, (N + 1) * nd, 0, 1};
+        q.dx0 = {_dz0, nz, 0, 1};
+        q.dX = {_dZ, (N + 1) * nz, nz, 1};
+        q.dU = {_dU, N * nu, nu, 1};
+        q.workspace = _workspace;
+        q.workspace_doubles = _workspaceDoubles;
+        q.regularization = 0.0;  // already on the decision variables' diagonal (the carried slots take none)
+        q.status = _status;
+        q.ne = Ne();
+        if (Ne() > 0) {
+            q.eq = {_E, N * Ne() * nd, Ne() * nd, 1};
+            q.eq_values = {_e, (N + 1) * Ne(), Ne(), 1};
+        }
+        Check(ungar_ocp_riccati_solve(&q, _stream));
+        // ---- merit terms at the current point (soft_sqp.hpp:68-87) and along all candidate steps at once
+        ungar_shooting_merit_args m{};
+        m.dims = _dims;
+        m.rows = _rows;
+        m.xm = _xm;
+        m.f = _f;
+        m.cost = _l;
+        m.h = _h;
+        m.eq = _e;
+        m.nh = Nh();
+        m.ne = Ne();
+        m.barrier = _barrier;
+        m.violation_multiplier = _multiplier;
+        m.cost_grad = _lg;
+        m.cost_grad_pattern = _pg;
+        m.dZ = _dZ;
+        m.dU = _dU;
+        m.theta = _theta0;
+        m.phi = _phi0;
+        m.objective = _obj0;
+        m.slope = _slope;
+        m.period = 0;
+        Check(ungar_shooting_merit(&m, _stream));
+        Check(ungar_shooting_trial_rows(&_dims, _rows, _dZ, _dU, _alphas.data(), K, _trial, _stream));
+        if (_p.carry) CarryValues(_trial, K * B);
+        Evaluate(*_p.dynamics, 0, _trial, _p.StateOffset(), _fT, K * B * (N + 1));
+        Evaluate(*_p.cost, 0, _trial, 0, _lT, K * B * (N + 1));
+        if (_p.inequality) Evaluate(*_p.inequality, 0, _trial, 0, _hT, K * B * (N + 1));
+        if (_p.equality) Evaluate(*_p.equality, 0, _trial, 0, _eT, K * B * (N + 1));
+        ungar_shooting_merit_args t = m;
+        t.dims.batch = K * B;
+        t.rows = _trial;
+        t.f = _fT;
+        t.cost = _lT;
+        t.h = _hT;
+        t.eq = _eT;
+        t.cost_grad = nullptr;
+        t.slope = nullptr;
+        t.theta = _thetaT;
+        t.phi = _phiT;
+        t.objective = _objT;
+        t.period = B;
+        Check(ungar_shooting_merit(&t, _stream));
+        const ungar_line_search_parameters ls{_ls.alphaMin, _ls.thetaMin, _ls.thetaMax, _ls.eta, _ls.gammaPhi, _ls.gammaTheta, _ls.gammaAlpha};
+        Check(ungar_shooting_select(&_dims, &ls, _alphas.data(), K, _theta0, _phi0, _obj0, _slope, _thetaT, _phiT, _objT, _accepted, _active, _status, _rows, _trial, _stream));
+        ++_iterations;
+    }
+
+    /// Up to maxIterations iterations; an instance stops on its own when no step is acceptable or its objective decreases by less
+    /// than 1e-6 (soft_sqp.hpp:88-99).  Returns the number of iterations launched (all of them when nobody asks: with thousands of
+    /// instances somebody is always still active, and finished instances cost nothing but their share of the launches).
+    index_t Optimize(const bool stopWhenAllInstancesAreDone = false) {
+        _iterations = 0;
+        for (index_t it = 0; it < _maxIterations; ++it) {
+            if (_verbose) UNGAR_LOG(trace, "Starting batched soft SQP iteration {}...", it);
+            Iterate();
+            if (stopWhenAllInstancesAreDone) {
+                bool any = false;
+                for (const int32_t v : Active()) any = any || v != 0;
+                if (!any) break;
+            }
+        }
+        return _iterations;
+    }
+
+    // ---- results of the last iteration (each call synchronises) --------------------------------------------------------------
+    std::vector<real_t> AcceptedStepSizes() const { return Download<real_t>(_accepted, _batch); }
+    std::vector<int32_t> Active() const { return Download<int32_t>(_active, _batch); }
+    std::vector<int32_t> QpStatus() const { return Download<int32_t>(_status, _batch); }
+    /// Search direction of the last QP: dZ batch x (N + 1) x (nc + nx), dU batch x N x nu.
+    std::vector<real_t> StateSteps() const { return Download<real_t>(_dZ, _batch * (_p.horizon + 1) * Nz()); }
+    std::vector<real_t> InputSteps() const { return Download<real_t>(_dU, _batch * _p.horizon * _p.inputSize); }
+    std::vector<real_t> ConstraintViolations() const { return Download<real_t>(_theta0, _batch); }
+    std::vector<real_t> Objectives() const { return Download<real_t>(_obj0, _batch); }
+    index_t Iterations() const { return _iterations; }
+    void SetStream(void* hipStream) { _stream = hipStream; }
+    void SetLineSearchParameters(const BacktrackingLineSearch::Parameters& parameters) {
+        std::vector<real_t> alphas;
+        for (real_t alpha = 1.0; alpha >= parameters.alphaMin; alpha *= parameters.gammaAlpha) alphas.push_back(alpha);
+        if (alphas.size() != _alphas.size()) throw std::invalid_argument("BatchedSoftSQPOptimizer: the number of candidate steps is fixed at construction");
+        _ls = parameters;
+        _alphas = alphas;
+    }
+
+  private:
+    static void Check(int code) {
+        if (code != UNGAR_OK) throw std::runtime_error(std::string("ungar_amd: ") + ungar_last_error());
+    }
+    static int64_t Bytes(index_t doubles) { return static_cast<int64_t>(doubles) * static_cast<int64_t>(sizeof(real_t)); }
+    index_t Nz() const { return _p.carrySize + _p.stateSize; }
+    index_t Nh() const { return _p.inequality ? _p.inequality->DependentVariableSize() : 0; }
+    index_t Ne() const { return _p.equality ? _p.equality->DependentVariableSize() : 0; }
+
+    void Validate() const {
+        const index_t par = _p.knotParameterSize + _p.instanceParameterSize, nxu = _p.stateSize + _p.inputSize, nd = _p.carrySize + nxu;
+        auto bad = [](const char* what) { throw std::invalid_argument(std::string("BatchedSoftSQPOptimizer: ") + what); };
+        if (_p.horizon < 1 || _p.stateSize < 1 || _p.inputSize < 1 || _p.carrySize < 0 || _batch < 1) bad("sizes must be positive");
+        if (!_p.dynamics || !_p.cost) bad("dynamics and cost are required");
+        if (_p.carryInputs && (_p.carrySize != _p.inputSize || _p.carry)) bad("carryInputs needs carrySize == inputSize and no carry function");
+        if (!_p.carryInputs && (_p.carrySize > 0) != _p.carry.has_value()) bad("a carried quantity needs a carry function (or carryInputs)");
+        auto check = [&](const Autodiff::Function& f, index_t n, index_t m, bool jac, bool hes, const char* name) {
+            if (f.IndependentVariableSize() != n || f.ParameterSize() != par || (m > 0 && f.DependentVariableSize() != m) || (jac && !f.ImplementsJacobian()) ||
+                (hes && !f.ImplementsHessian()))
+                throw std::invalid_argument(std::string("BatchedSoftSQPOptimizer: stage function '") + name + "' has the wrong sizes or lacks a derivative");
+        };
+        check(*_p.dynamics, nxu, _p.stateSize, true, false, "dynamics");
+        if (_p.carry) check(*_p.carry, nxu, _p.carrySize, true, false, "carry");
+        check(*_p.cost, nd, 1, true, true, "cost");
+        if (_p.equality) check(*_p.equality, nd, 0, true, false, "equality");
+        if (_p.inequality) check(*_p.inequality, nd, 0, true, false, "inequality");
+    }
+
+    template <class T>
+    T* Device(index_t count) {
+        void* ptr = nullptr;
+        Check(ungar_device_malloc(&ptr, static_cast<int64_t>(count > 0 ? count : 1) * static_cast<int64_t>(sizeof(T))));
+        _owned.push_back(ptr);
+        return static_cast<T*>(ptr);
+    }
+    ungar_stage_pattern UploadPattern(const Autodiff::Function& f, bool hessian) {
+        const int32_t *rows = nullptr, *cols = nullptr;
+        int64_t nnz = 0;
+        Check(hessian ? ungar_function_hessian_sparsity(f.Handle(), &rows, &cols, &nnz) : ungar_function_jacobian_sparsity(f.Handle(), &rows, &cols, &nnz));
+        int32_t* dr = Device<int32_t>(nnz);
+        int32_t* dc = Device<int32_t>(nnz);
+        Check(ungar_device_upload(dr, rows, nnz * static_cast<int64_t>(sizeof(int32_t))));
+        Check(ungar_device_upload(dc, cols, nnz * static_cast<int64_t>(sizeof(int32_t))));
+        return {dr, dc, nnz};
+    }
+    void Allocate() {
+        const index_t N = _p.horizon, B = _batch, K = static_cast<index_t>(_alphas.size()), nv = _p.RowSize(), nx = _p.stateSize, nu = _p.inputSize, nz = Nz(), nd = nz + nu;
+        const index_t nodes = B * (N + 1), stacked = K * nodes;
+        _pf = UploadPattern(*_p.dynamics, false);
+        if (_p.carry) _pc = UploadPattern(*_p.carry, false);
+        _pg = UploadPattern(*_p.cost, false);
+        _pH = UploadPattern(*_p.cost, true);
+        if (_p.inequality) _ph = UploadPattern(*_p.inequality, false);
+        if (_p.equality) _pe = UploadPattern(*_p.equality, false);
+        _rows = Device<real_t>(nodes * nv);
+        _xm = Device<real_t>(B * nx);
+        _trial = Device<real_t>(stacked * nv);
+        _f = Device<real_t>(nodes * nx);
+        _fJ = Device<real_t>(nodes * _pf.nnz);
+        _cJ = _p.carry ? Device<real_t>(nodes * _pc.nnz) : nullptr;
+        _l = Device<real_t>(nodes);
+        _lg = Device<real_t>(nodes * _pg.nnz);
+        _lH = Device<real_t>(nodes * _pH.nnz);
+        _h = _p.inequality ? Device<real_t>(nodes * Nh()) : nullptr;
+        _hJ = _p.inequality ? Device<real_t>(nodes * _ph.nnz) : nullptr;
+        _e = _p.equality ? Device<real_t>(nodes * Ne()) : nullptr;
+        _eJ = _p.equality ? Device<real_t>(nodes * _pe.nnz) : nullptr;
+        _fT = Device<real_t>(stacked * nx);
+        _lT = Device<real_t>(stacked);
+        _hT = _p.inequality ? Device<real_t>(stacked * Nh()) : nullptr;
+        _eT = _p.equality ? Device<real_t>(stacked * Ne()) : nullptr;
+        _AB = Device<real_t>(B * N * nz * nd);
+        _b = Device<real_t>(B * N * nz);
+        _W = Device<real_t>(nodes * nd * nd);
+        _w = Device<real_t>(nodes * nd);
+        _E = _p.equality ? Device<real_t>(B * N * Ne() * nd) : nullptr;
+        _dz0 = Device<real_t>(B * nz);
+        _dZ = Device<real_t>(nodes * nz);
+        _dU = Device<real_t>(B * N * nu);
+        _workspaceDoubles = ungar_ocp_riccati_workspace(nz, nu, N, B);
+        if (_workspaceDoubles < 0) throw std::invalid_argument("BatchedSoftSQPOptimizer: sizes not supported by the batched QP solver");
+        _workspace = Device<real_t>(_workspaceDoubles);
+        _status = Device<int32_t>(B);
+        _active = Device<int32_t>(B);
+        _theta0 = Device<real_t>(B);
+        _phi0 = Device<real_t>(B);
+        _obj0 = Device<real_t>(B);
+        _slope = Device<real_t>(B);
+        _accepted = Device<real_t>(B);
+        _thetaT = Device<real_t>(K * B);
+        _phiT = Device<real_t>(K * B);
+        _objT = Device<real_t>(K * B);
+        Check(ungar_device_zero(_W, Bytes(nodes * nd * nd), nullptr));  // the strict lower triangles are never written nor read
+        Check(ungar_device_zero(_status, B * static_cast<int64_t>(sizeof(int32_t)), nullptr));
+        Check(ungar_device_zero(_accepted, Bytes(B), nullptr));
+        Check(ungar_device_synchronize());
+    }
+
+    /// what: 0 value, 1 sparse Jacobian, 2 sparse Hessian of `f` for `count` consecutive node rows starting at `rows`; the function's
+    /// variables begin `offset` doubles into each row.
+    void Evaluate(const Autodiff::Function& f, int what, real_t* rows, index_t offset, real_t* out, index_t count) {
+        const index_t nv = _p.RowSize();
+        int64_t width = f.DependentVariableSize();
+        if (what != 0) {
+            const int32_t *r = nullptr, *c = nullptr;
+            Check(what == 1 ? ungar_function_jacobian_sparsity(f.Handle(), &r, &c, &width) : ungar_function_hessian_sparsity(f.Handle(), &r, &c, &width));
+        }
+        const ungar_operand xp{rows + offset, nv, 0, 1}, y{out, width, 0, 1};
+        Check(what == 0   ? ungar_function_forward_zero_nodes(f.Handle(), &xp, &y, count, 1, _stream)
+              : what == 1 ? ungar_function_sparse_jacobian_nodes(f.Handle(), &xp, &y, count, 1, _stream)
+                          : ungar_function_sparse_hessian_nodes(f.Handle(), &xp, &y, count, 1, _stream));
+    }
+    /// c of row k + 1 <- carry(x, u, w, p of row k) for k < N of `instances` consecutive instances (rows in place).
+    void CarryValues(real_t* rows, index_t instances) {
+        const index_t N = _p.horizon, nv = _p.RowSize();
+        const ungar_operand xp{rows + _p.StateOffset(), (N + 1) * nv, nv, 1}, y{rows + nv, (N + 1) * nv, nv, 1};
+        Check(ungar_function_forward_zero_nodes(_p.carry->Handle(), &xp, &y, instances * N, N, _stream));
+    }
+    template <class T>
+    std::vector<T> Download(const T* device, index_t count) const {
+        std::vector<T> host(static_cast<std::size_t>(count));
+        Check(ungar_device_synchronize());
+        Check(ungar_device_download(host.data(), device, static_cast<int64_t>(count) * static_cast<int64_t>(sizeof(T))));
+        return host;
+    }
+
+    ShootingProblem _p;
+    index_t _batch;
+    bool _verbose;
+    real_t _multiplier;
+    index_t _maxIterations, _iterations = 0;
+    ungar_barrier _barrier{};
+    ungar_shooting_dims _dims{};
+    BacktrackingLineSearch::Parameters _ls{};
+    std::vector<real_t> _alphas;
+    void* _stream = nullptr;
+    std::vector<void*> _owned;
+    ungar_stage_pattern _pf{}, _pc{}, _pg{}, _pH{}, _ph{}, _pe{};
+    real_t *_rows = nullptr, *_xm = nullptr, *_trial = nullptr;
+    real_t *_f = nullptr, *_fJ = nullptr, *_cJ = nullptr, *_l = nullptr, *_lg = nullptr, *_lH = nullptr, *_h = nullptr, *_hJ = nullptr, *_e = nullptr, *_eJ = nullptr;
+    real_t *_fT = nullptr, *_lT = nullptr, *_hT = nullptr, *_eT = nullptr;
+    real_t *_AB = nullptr, *_b = nullptr, *_W = nullptr, *_w = nullptr, *_E = nullptr, *_dz0 = nullptr, *_dZ = nullptr, *_dU = nullptr, *_workspace = nullptr;
+    int64_t _workspaceDoubles = 0;
+    int32_t *_status = nullptr, *_active = nullptr;
+    real_t *_theta0 = nullptr, *_phi0 = nullptr, *_obj0 = nullptr, *_slope = nullptr, *_accepted = nullptr, *_thetaT = nullptr, *_phiT = nullptr, *_objT = nullptr;
+};
+
+}  // namespace Ungar

@@ -39,7 +39,8 @@ class _StageQpArgs(ctypes.Structure):
 class _Qp(ctypes.Structure):
     _fields_ = [("nx", ctypes.c_int64), ("nu", ctypes.c_int64), ("horizon", ctypes.c_int64), ("batch", ctypes.c_int64), ("jac", _Operand), ("b", _Operand),
                 ("hess", _Operand), ("grad", _Operand), ("hess_terminal", _Operand), ("grad_terminal", _Operand), ("dx0", _Operand), ("dX", _Operand), ("dU", _Operand),
-                ("workspace", ctypes.c_void_p), ("workspace_doubles", ctypes.c_int64), ("regularization", ctypes.c_double), ("status", ctypes.c_void_p)]
+                ("workspace", ctypes.c_void_p), ("workspace_doubles", ctypes.c_int64), ("regularization", ctypes.c_double), ("status", ctypes.c_void_p),
+                ("ne", ctypes.c_int64), ("eq", _Operand), ("eq_values", _Operand), ("hess_terminal_ld", ctypes.c_int64)]
 
 
 class _MeritArgs(ctypes.Structure):
