@@ -7,6 +7,7 @@
 //   usage: batched_quadruped_test <codegen folder> [batch] [compared instances]
 #include <cmath>
 #include <cstdio>
+#include <fstream>
 #include <random>
 #include <string>
 #include <vector>
@@ -105,6 +106,7 @@ static VectorXad Dynamics(const VectorXad& xk, const VectorXad& uk, const Knot& 
 int main(int argc, char** argv) {
     const std::string folder = argc > 1 ? argv[1] : "/tmp/ungar_amd_batched_quadruped";
     const index_t batch = argc > 2 ? std::atol(argv[2]) : 1024, compared = argc > 3 ? std::atol(argv[3]) : 8;
+    const std::string dumpFolder = argc > 4 ? argv[4] : "";  // diagnostics: QP data and both steps of the compared instances (tools/qp_accuracy.py)
     try {
         // ---- whole-horizon problem (quadruped.example.cpp:209-368)
         const auto objective = [&](const VectorXad& v, VectorXad& y) {
@@ -348,6 +350,7 @@ int main(int argc, char** argv) {
             const std::vector<real_t> dZ = batched.StateSteps(), dU = batched.InputSteps(), accepted = batched.AcceptedStepSizes();
             const std::vector<int32_t> status = batched.QpStatus();
             batched.GetRows(rows.data());
+            BatchedSoftSQPOptimizer::Qp qp;
             index_t failed = 0;
             for (const int32_t st : status) failed += st != 0;
             if (failed) {
@@ -382,6 +385,26 @@ int main(int argc, char** argv) {
                         worstIterate = std::max(worstIterate, std::abs(rows[static_cast<std::size_t>((b * (N + 1) + k) * nv + nz + i)] - after[(N + 1) * nx + k * nu + i]) / scaleX);
                     }
                 for (index_t i = 0; i < dec; ++i) z[i] = after[i];
+                if (!dumpFolder.empty()) {
+                    if (s == 0) qp = batched.AssembledQp();
+                    std::ofstream out(dumpFolder + "/qp_it" + std::to_string(iteration) + "_inst" + std::to_string(b) + ".txt");
+                    out.precision(17);
+                    const index_t ne = 16, ndd = nz + nu;
+                    out << N << " " << nz << " " << nu << " " << ne << " " << nc << "\n";
+                    auto block = [&](const std::vector<real_t>& a, index_t perInstance) {
+                        for (index_t i = 0; i < perInstance; ++i) out << a[static_cast<std::size_t>(b * perInstance + i)] << "\n";
+                    };
+                    block(qp.AB, N * nz * ndd);
+                    block(qp.b, N * nz);
+                    block(qp.W, (N + 1) * ndd * ndd);
+                    block(qp.w, (N + 1) * ndd);
+                    block(qp.E, N * ne * ndd);
+                    block(qp.e, (N + 1) * ne);
+                    block(qp.dz0, nz);
+                    block(dZ, (N + 1) * nz);
+                    block(dU, N * nu);
+                    for (index_t i = 0; i < dec; ++i) out << d[static_cast<std::size_t>(i)] << "\n";
+                }
                 std::printf("iteration %d instance %4td: step size facade %.6g batched %.6g  (|d|max %.3g)\n", iteration, b, alphaFacade, accepted[static_cast<std::size_t>(b)], scaleD);
             }
             index_t moved = 0;

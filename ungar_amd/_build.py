@@ -149,7 +149,8 @@ def build_cpp_tests():
     inc = os.path.join(ROOT, "ungar_amd", "include")
     hdrs = _tree(inc, os.path.join(CSRC, "tape"), os.path.join(CSRC, "rbd")) + [os.path.join(ROOT, "include", "ungar_amd.h")]
     jobs = []
-    for name, link in (("layout_dump", False), ("function_test", True), ("quadrotor_ocp_test", True), ("rbd_test", True), ("optimization_test", False)):
+    for name, link in (("layout_dump", False), ("function_test", True), ("quadrotor_ocp_test", True), ("rbd_test", True), ("optimization_test", False),
+                       ("batched_quadrotor_test", True), ("batched_quadruped_test", True)):
         src = os.path.join(ROOT, "tests", "cpp", f"{name}.cpp")
         exe = os.path.join(BUILD, name)
         if _newer([exe], [src, *hdrs] + ([LIB] if link else [])):

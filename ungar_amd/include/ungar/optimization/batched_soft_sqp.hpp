@@ -262,6 +262,26 @@ class BatchedSoftSQPOptimizer {
     std::vector<real_t> ConstraintViolations() const { return Download<real_t>(_theta0, _batch); }
     std::vector<real_t> Objectives() const { return Download<real_t>(_obj0, _batch); }
     index_t Iterations() const { return _iterations; }
+    /// The QP of the last iteration as assembled on the device (diagnostics; whole arrays, node-major): with nz = nc + nx, nd = nz + nu,
+    /// AB batch x N x nz x nd, b batch x N x nz, W batch x (N + 1) x nd x nd (upper triangles), w batch x (N + 1) x nd,
+    /// E batch x N x ne x nd, e batch x (N + 1) x ne, dz0 batch x nz.
+    struct Qp {
+        std::vector<real_t> AB, b, W, w, E, e, dz0;
+    };
+    Qp AssembledQp() const {
+        const index_t N = _p.horizon, B = _batch, nz = Nz(), nd = nz + _p.inputSize;
+        Qp q;
+        q.AB = Download<real_t>(_AB, B * N * nz * nd);
+        q.b = Download<real_t>(_b, B * N * nz);
+        q.W = Download<real_t>(_W, B * (N + 1) * nd * nd);
+        q.w = Download<real_t>(_w, B * (N + 1) * nd);
+        if (Ne() > 0) {
+            q.E = Download<real_t>(_E, B * N * Ne() * nd);
+            q.e = Download<real_t>(_e, B * (N + 1) * Ne());
+        }
+        q.dz0 = Download<real_t>(_dz0, B * nz);
+        return q;
+    }
     void SetStream(void* hipStream) { _stream = hipStream; }
     void SetLineSearchParameters(const BacktrackingLineSearch::Parameters& parameters) {
         std::vector<real_t> alphas;
