@@ -222,6 +222,30 @@ def roofline(r, jacobian, traffic=None, traffic_source=None):
             "kernel": f"NodeKernel<{r['kernel_model']}, {jacobian} Jacobian>"}
 
 
+def launcher_command(gpus: int, argv: list[str], port: int | None = None) -> list[str]:
+    """The one-process-per-GPU launch of this file: `python bench.py --gpus N` run directly (no WORLD_SIZE in the environment)
+    re-executes itself under torch.distributed.run on 127.0.0.1 -- the same command the driver uses."""
+    import socket
+    if port is None:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+            os.path.abspath(__file__), *argv]
+
+
+def reduce_min_max(value: float, dist=None, device=None) -> tuple[float, float]:
+    """(min, max) of a per-rank figure over the ranks."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return value, value
+    import torch
+    lo = torch.tensor([value], dtype=torch.float64, device=device)
+    hi = lo.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    return float(lo.item()), float(hi.item())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -248,11 +272,17 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # started directly: become the launcher of one rank per GPU (rank 0 prints the JSON line, which passes through)
+        import subprocess
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        raise SystemExit(subprocess.call(launcher_command(args.gpus, sys.argv[1:]), env=env))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    # the CPU baseline belongs to the single-GPU line (rank 0, N = 1); multi-rank lines say so instead of dropping it silently
     want_cpu = not args.no_cpu_baseline and world == 1 and rank == 0
     from ungar_amd import workloads as W
     model_name = W.WORKLOADS[args.workload][0]
@@ -292,6 +322,9 @@ def main():
     reduce_device = "cuda" if dist is None or dist.get_backend() == "nccl" else "cpu"
     elapsed, total_evals = reduce_timing(r["elapsed"], r["count"] * args.steps, dist, reduce_device)  # MAX time, SUM evals over ranks
     checksum, nodes_per_step = reduce_sums([r["checksum"], float(r["count"])], dist, reduce_device)  # SUM over ranks
+    rate_min, rate_max = reduce_min_max(r["count"] * args.steps / r["elapsed"], dist, reduce_device)  # per-rank evals/s
+    kernel_min, kernel_max = reduce_min_max(r["kernel_ms"], dist, reduce_device)
+    ranks_seen = dist.get_world_size() if dist is not None else 1  # what the process group reports, not what the environment asked for
 
     if rank == 0:
         traffic = traffic_source = None
@@ -306,6 +339,10 @@ def main():
             "value": total_evals / elapsed,
             "unit": "evals/s",
             "n_gpus": world,
+            "ranks_seen": ranks_seen,
+            "backend": (dist.get_backend() if dist is not None else None),
+            "per_rank_evals_per_s": {"min": rate_min, "max": rate_max},
+            "per_rank_kernel_ms": {"min": kernel_min, "max": kernel_max},
             "steps": args.steps,
             "warmup": args.warmup,
             "prewarm_s": args.prewarm_seconds,
@@ -336,6 +373,8 @@ def main():
             out["sub_results"] = subs
         if want_cpu:
             out["cpu_baseline"] = cpu_baseline(model_name, native, args.cpu_seconds)
+        elif world > 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = {"skipped": "timed on rank 0 of the single-GPU run only (python bench.py --gpus 1): host cores are shared by the ranks here"}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

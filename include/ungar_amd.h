@@ -283,13 +283,15 @@ int ungar_ocp_trial_point(int64_t nx, int64_t nu, int64_t horizon, int64_t batch
 
 /* One candidate step size of BacktrackingLineSearch::Do (backtracking_line_search.hpp:116-151) for every instance that has
  * not accepted a larger one: the three-way test on (theta, phi) -> (theta_trial, phi_trial); accepting instances copy the
- * trial point into (X, U) and record alpha in accepted[instance] (0 = still searching). */
+ * trial point into (X, U) and record alpha in accepted[instance] (0 = still searching).  status (device, may be null): the report of
+ * ungar_ocp_riccati_solve; an instance whose QP was not solved (non-zero) takes no step -- the reference asserts there (soft_sqp.hpp:223-230). */
 typedef struct ungar_line_search_parameters {
     double alpha_min, theta_min, theta_max, eta, gamma_phi, gamma_theta, gamma_alpha; /* reference defaults: 1e-4 1e-6 1e-2 1e-4 1e-6 1e-6 0.5 */
 } ungar_line_search_parameters;
 int ungar_ocp_line_search_accept(int64_t nx, int64_t nu, int64_t horizon, int64_t batch, const ungar_line_search_parameters* parameters, double alpha,
                                  const double* theta0, const double* phi0, const double* slope, const double* theta_trial, const double* phi_trial,
-                                 double* accepted, const ungar_operand* X, const ungar_operand* U, const ungar_operand* Xt, const ungar_operand* Ut, void* stream);
+                                 double* accepted, const ungar_operand* X, const ungar_operand* U, const ungar_operand* Xt, const ungar_operand* Ut,
+                                 const int32_t* status, void* stream);
 
 /* The whole backtracking search in THREE launches instead of three per candidate (the GPU-native form of
  * backtracking_line_search.hpp:116-151: with thousands of instances somebody always needs a short step, so all candidates get
@@ -306,7 +308,8 @@ int ungar_ocp_trial_points(int64_t nx, int64_t nu, int64_t horizon, int64_t batc
 int ungar_ocp_merit_stacked(const ungar_ocp_merit_args* args, int64_t period, void* stream);
 int ungar_ocp_line_search_select(int64_t nx, int64_t nu, int64_t horizon, int64_t batch, const ungar_line_search_parameters* parameters, const double* alphas,
                                  int64_t candidates, const double* theta0, const double* phi0, const double* slope, const double* theta_trial, const double* phi_trial,
-                                 double* accepted, const ungar_operand* X, const ungar_operand* U, const ungar_operand* Xt, const ungar_operand* Ut, void* stream);
+                                 double* accepted, const ungar_operand* X, const ungar_operand* U, const ungar_operand* Xt, const ungar_operand* Ut,
+                                 const int32_t* status, void* stream);
 
 /* ---- shooting problems with carried quantities and stage equality rows (the reference's three OCPs as written) ------------------
  * The objective of example/mpc/quadrotor.example.cpp:222-227 and rc_car.example.cpp:216-220 couples u_k with u_{k-1}; the foot-contact

@@ -2,6 +2,7 @@
  * include/ungar_amd.h carries no C++ in its declarations, and exercises the host-only entry points. */
 #include "ungar_amd.h"
 #include <stdio.h>
+#include <string.h>
 int main(void) {
     ungar_model* m = 0;
     int rc = ungar_model_open("quadrotor_cost", &m);
@@ -27,13 +28,28 @@ int main(void) {
         bad += ungar_gn_hessian_upper_lanes(dummy, 4, 0, 0, dummy, 4, 1, 1, 1, 2, 4, 0) != UNGAR_E_INVALID;  /* ld_g < cols */
         bad += ungar_ocp_trial_points(13, 4, 30, 8, &op, &op, &op, &op, alphas, 17, &op, &op, 0) != UNGAR_E_INVALID; /* > 16 candidates */
         bad += ungar_ocp_trial_points(13, 4, 30, 8, &op, &op, &op, &op, 0, 14, &op, &op, 0) != UNGAR_E_INVALID;
-        bad += ungar_ocp_line_search_select(13, 4, 30, 8, &ls, alphas, 14, 0, dummy, dummy, dummy, dummy, dummy, &op, &op, &op, &op, 0) != UNGAR_E_INVALID;
+        bad += ungar_ocp_line_search_select(13, 4, 30, 8, &ls, alphas, 14, 0, dummy, dummy, dummy, dummy, dummy, &op, &op, &op, &op, 0, 0) != UNGAR_E_INVALID;
         merit.nx = 13; merit.nu = 4; merit.horizon = 30; merit.batch = 10; merit.nh = 0;
         merit.X = op; merit.xm = op; merit.f = op; merit.cost = op; merit.cost_terminal = op; merit.h = op;
         merit.barrier.type = 0; merit.barrier.reserved = 0; merit.barrier.stiffness = 1; merit.barrier.epsilon = 1;
         merit.violation_multiplier = 1; merit.cost_grad = op; merit.cost_grad_terminal = op; merit.dX = op; merit.dU = op;
         merit.theta = dummy; merit.phi = dummy; merit.slope = 0;
         bad += ungar_ocp_merit_stacked(&merit, 4, 0) != UNGAR_E_INVALID; /* the stacked batch is not a multiple of the period */
+        {   /* shooting problems with carried quantities: dimensions and candidate counts are checked before anything is launched */
+            ungar_shooting_dims dims = {13, 4, 4, 15, 21, 30, 8, 1, 0};
+            ungar_shooting_dims wrong = {13, 4, 3, 15, 21, 30, 8, 1, 0}; /* carry_inputs needs nc == nu */
+            ungar_shooting_assemble_args asm_args;
+            void* ptr = dummy;
+            memset(&asm_args, 0, sizeof asm_args);
+            asm_args.dims = dims;
+            bad += ungar_shooting_trial_rows(&dims, dummy, dummy, dummy, alphas, 17, dummy, 0) != UNGAR_E_INVALID;
+            bad += ungar_shooting_trial_rows(&wrong, dummy, dummy, dummy, alphas, 14, dummy, 0) != UNGAR_E_INVALID;
+            bad += ungar_shooting_assemble(&asm_args, 0) != UNGAR_E_INVALID; /* null operands */
+            bad += ungar_shooting_select(&dims, &ls, alphas, 14, 0, dummy, dummy, dummy, dummy, dummy, dummy, dummy, 0, 0, dummy, dummy, 0) != UNGAR_E_INVALID;
+            bad += ungar_device_malloc(&ptr, -1) != UNGAR_E_INVALID;
+            bad += ungar_device_malloc(&ptr, 0) != UNGAR_OK || ptr != 0;
+            bad += ungar_function_forward_zero_nodes(0, &op, &op, 4, 2, 0) != UNGAR_E_INVALID;
+        }
         bad += ungar_last_error()[0] == 0;
         printf("argument checks: %d unexpected\n", bad);
         if (bad) return 100 + bad;

@@ -72,3 +72,33 @@ def test_padded_stride_properties():
     assert padded_stride(4096 * 20) == 81968
     with pytest.raises(ValueError):
         padded_stride(-1)
+
+
+def test_bench_launches_its_own_ranks(repo_root, monkeypatch):
+    """`python bench.py --gpus N` started directly (no WORLD_SIZE) re-executes itself under torch.distributed.run on 127.0.0.1 with one
+    process per GPU; under a launcher it checks --gpus against WORLD_SIZE instead of guessing."""
+    import importlib.util
+    import subprocess
+    import sys
+    spec = importlib.util.spec_from_file_location("ungar_bench", os.path.join(repo_root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    cmd = bench.launcher_command(4, ["--gpus", "4", "--steps", "3"], port=29999)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29999"
+    assert cmd[-5] == os.path.join(repo_root, "bench.py") and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
+    free = bench.launcher_command(2, [])
+    assert 1024 < int(free[free.index("--master-port") + 1]) < 65536
+    calls = []
+    monkeypatch.setattr(subprocess, "call", lambda c, **kw: calls.append((c, kw)) or 0)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1"])
+    with pytest.raises(SystemExit) as stop:
+        bench.main()
+    assert stop.value.code == 0 and len(calls) == 1 and "--nproc-per-node=2" in calls[0][0] and calls[0][0][-6:] == ["--gpus", "2", "--steps", "3", "--warmup", "1"]
+    # under a launcher that disagrees with --gpus: refuse (no silent single-rank run reported as N GPUs)
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    with pytest.raises(SystemExit) as stop:
+        bench.main()
+    assert "WORLD_SIZE=1" in str(stop.value.code)
+    assert bench.reduce_min_max(3.5) == (3.5, 3.5)

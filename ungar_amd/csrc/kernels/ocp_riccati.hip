@@ -259,7 +259,8 @@ __global__ __launch_bounds__(kBlock) void SelectKernel(const SelectArgs a) {
     if (b >= a.batch) return;
     const double theta = a.theta0[b], phi = a.phi0[b], slope = a.slope[b];
     int chosen = -1;  // uniform over the workgroup: every lane runs the same scalar search
-    for (int c = 0; c < a.candidates && chosen < 0; ++c)
+    const bool solved = !a.status || a.status[b] == 0;
+    for (int c = 0; solved && c < a.candidates && chosen < 0; ++c)
         if (StepAcceptable(theta, phi, slope, a.thetaT[c * a.batch + b], a.phiT[c * a.batch + b], a.alphas[c], a.thetaMin, a.thetaMax, a.eta, a.gammaPhi, a.gammaTheta)) chosen = c;
     if (chosen < 0) {
         if (threadIdx.x == 0) a.accepted[b] = 0.0;
@@ -275,6 +276,7 @@ __global__ __launch_bounds__(kBlock) void AcceptKernel(const AcceptArgs a) {
     const long long b = blockIdx.x;
     if (b >= a.batch) return;
     if (a.accepted[b] != 0.0) return;  // uniform over the workgroup
+    if (a.status && a.status[b] != 0) return;
     const double theta = a.theta0[b], phi = a.phi0[b], thetaNext = a.thetaT[b], phiNext = a.phiT[b], slope = a.slope[b];
     if (!StepAcceptable(theta, phi, slope, thetaNext, phiNext, a.alpha, a.thetaMin, a.thetaMax, a.eta, a.gammaPhi, a.gammaTheta)) return;
     for (int idx = static_cast<int>(threadIdx.x); idx < (a.N + 1) * a.nx; idx += kBlock) a.X.at(b, idx / a.nx, idx % a.nx) = a.Xt.at(b, idx / a.nx, idx % a.nx);

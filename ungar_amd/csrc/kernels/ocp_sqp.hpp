@@ -53,6 +53,7 @@ struct SelectArgs {
     const double *theta0, *phi0, *slope, *thetaT, *phiT;
     double* accepted;  // per instance: the accepted step size, 0 = none of the candidates is acceptable
     RiccatiView X, U, Xt, Ut;
+    const int* status = nullptr;  // Riccati report per instance (may be null): non-zero = QP not solved, the instance takes no step (soft_sqp.hpp:223-230 asserts there)
 };
 
 /// Acceptance test of the reference's backtracking line search (backtracking_line_search.hpp:116-151) for one candidate
@@ -64,6 +65,7 @@ struct AcceptArgs {
     const double *theta0, *phi0, *slope, *thetaT, *phiT;
     double* accepted;  // per instance: 0 = still searching, else the accepted step size
     RiccatiView X, U, Xt, Ut;
+    const int* status = nullptr;  // as in SelectArgs
 };
 
 /// Stage data of the QP from the node kernels' outputs (soft_sqp.hpp:143-155, 247-264 restricted to one knot):

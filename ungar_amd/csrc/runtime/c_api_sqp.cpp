@@ -144,7 +144,7 @@ int ungar_ocp_trial_points(int64_t nx, int64_t nu, int64_t horizon, int64_t batc
 
 int ungar_ocp_line_search_select(int64_t nx, int64_t nu, int64_t horizon, int64_t batch, const ungar_line_search_parameters* p, const double* alphas, int64_t candidates,
                                  const double* theta0, const double* phi0, const double* slope, const double* theta_trial, const double* phi_trial, double* accepted,
-                                 const ungar_operand* X, const ungar_operand* U, const ungar_operand* Xt, const ungar_operand* Ut, void* stream) {
+                                 const ungar_operand* X, const ungar_operand* U, const ungar_operand* Xt, const ungar_operand* Ut, const int32_t* status, void* stream) {
     if (BadDims(nx, nu, horizon, batch) || !p || !alphas || candidates < 1 || candidates > kMaxLineSearchCandidates || !theta0 || !phi0 || !slope || !theta_trial || !phi_trial ||
         !accepted || !X || !U || !Xt || !Ut)
         return Fail(UNGAR_E_INVALID, "ungar_ocp_line_search_select: bad argument (1 <= candidates <= 16)");
@@ -153,6 +153,7 @@ int ungar_ocp_line_search_select(int64_t nx, int64_t nu, int64_t horizon, int64_
     SelectArgs k{static_cast<int>(nx), static_cast<int>(nu), static_cast<int>(horizon), static_cast<int>(candidates), batch, p->theta_min, p->theta_max, p->eta, p->gamma_phi,
                  p->gamma_theta, {}, theta0, phi0, slope, theta_trial, phi_trial, accepted, View(*X), View(*U), View(*Xt), View(*Ut)};
     for (int64_t c = 0; c < candidates; ++c) k.alphas[c] = alphas[c];
+    k.status = status;
     return Launched(ungar_amd_launch_ocp_select(&k, stream), "ungar_ocp_line_search_select");
 }
 
@@ -167,13 +168,14 @@ int ungar_ocp_trial_point(int64_t nx, int64_t nu, int64_t horizon, int64_t batch
 
 int ungar_ocp_line_search_accept(int64_t nx, int64_t nu, int64_t horizon, int64_t batch, const ungar_line_search_parameters* p, double alpha, const double* theta0,
                                  const double* phi0, const double* slope, const double* theta_trial, const double* phi_trial, double* accepted, const ungar_operand* X,
-                                 const ungar_operand* U, const ungar_operand* Xt, const ungar_operand* Ut, void* stream) {
+                                 const ungar_operand* U, const ungar_operand* Xt, const ungar_operand* Ut, const int32_t* status, void* stream) {
     if (BadDims(nx, nu, horizon, batch) || !p || !theta0 || !phi0 || !slope || !theta_trial || !phi_trial || !accepted || !X || !U || !Xt || !Ut)
         return Fail(UNGAR_E_INVALID, "ungar_ocp_line_search_accept: bad argument");
     if (batch == 0) return UNGAR_OK;
     if (!X->base || !U->base || !Xt->base || !Ut->base) return Fail(UNGAR_E_INVALID, "ungar_ocp_line_search_accept: null operand base");
-    const AcceptArgs k{static_cast<int>(nx), static_cast<int>(nu), static_cast<int>(horizon), batch, alpha, p->theta_min, p->theta_max, p->eta, p->gamma_phi, p->gamma_theta,
-                       theta0, phi0, slope, theta_trial, phi_trial, accepted, View(*X), View(*U), View(*Xt), View(*Ut)};
+    AcceptArgs k{static_cast<int>(nx), static_cast<int>(nu), static_cast<int>(horizon), batch, alpha, p->theta_min, p->theta_max, p->eta, p->gamma_phi, p->gamma_theta,
+                 theta0, phi0, slope, theta_trial, phi_trial, accepted, View(*X), View(*U), View(*Xt), View(*Ut)};
+    k.status = status;
     return Launched(ungar_amd_launch_ocp_accept(&k, stream), "ungar_ocp_line_search_accept");
 }
 

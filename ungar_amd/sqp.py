@@ -70,8 +70,8 @@ def _declare(lib):
     lib.ungar_ocp_merit_stacked.argtypes = [ctypes.POINTER(_MeritArgs), ctypes.c_int64, vp]
     lib.ungar_ocp_trial_points.argtypes = [ctypes.c_int64] * 4 + [op] * 4 + [ctypes.POINTER(ctypes.c_double), ctypes.c_int64] + [op] * 2 + [vp]
     lib.ungar_ocp_line_search_select.argtypes = ([ctypes.c_int64] * 4 + [ctypes.POINTER(_LineSearchParameters), ctypes.POINTER(ctypes.c_double), ctypes.c_int64] + [vp] * 6 +
-                                                 [op] * 4 + [vp])
-    lib.ungar_ocp_line_search_accept.argtypes = [ctypes.c_int64] * 4 + [ctypes.POINTER(_LineSearchParameters), ctypes.c_double] + [vp] * 6 + [op] * 4 + [vp]
+                                                 [op] * 4 + [vp, vp])
+    lib.ungar_ocp_line_search_accept.argtypes = [ctypes.c_int64] * 4 + [ctypes.POINTER(_LineSearchParameters), ctypes.c_double] + [vp] * 6 + [op] * 4 + [vp, vp]
     lib._ungar_sqp_declared = True
     return lib
 
@@ -139,6 +139,9 @@ class BatchedSoftSqp:
         self.multiplier, self.regularization = constraint_violation_multiplier, regularization
         self.barrier = _Barrier(1 if barrier == "log" else 0, 0, stiffness, epsilon)
         self.ls = line_search or LineSearchParameters()
+        # the stacked search evaluates all candidates in one batch of at most 16; more candidates (gamma_alpha closer to 1, smaller alpha_min)
+        # are walked one after the other -- decided here, not in the middle of an iteration
+        self._stackable = len(self.candidate_steps()) <= 16
         self.dyn.prepare()
         rows, cols = self.cost.hessian_sparsity()
         self._hes_rows, self._hes_cols = np.ascontiguousarray(rows, dtype=np.int32), np.ascontiguousarray(cols, dtype=np.int32)
@@ -157,6 +160,13 @@ class BatchedSoftSqp:
         if nx * n >= 1024 and self.dyn.nw == 0:
             from .sharding import unit_fastest
             self._wide = (unit_fastest(nx, B * (N + 1), torch), unit_fastest(nu, B * N, torch), unit_fastest(nx, B * N, torch), unit_fastest(nx * n, B * N, torch))
+
+    def _on(self, stream):
+        """torch's own kernels (fills, copies) issued on the SAME stream as the C-ABI launches; the default stream is torch's current one."""
+        import contextlib
+        if not stream or (isinstance(stream, ctypes.c_void_p) and not stream.value):
+            return contextlib.nullcontext()
+        return self.torch.cuda.stream(self.torch.cuda.ExternalStream(stream.value if isinstance(stream, ctypes.c_void_p) else stream))
 
     # -- operands -----------------------------------------------------------------------------------------------------
     def _states(self, X):  # knots 0..N-1 of the (batch, N+1, nx) buffer as the x operand of the node models
@@ -232,12 +242,10 @@ class BatchedSoftSqp:
         torch, nx, nu, N, B, n = self.torch, self.nx, self.nu, self.N, self.batch, self.nx + self.nu
         steps = self.candidate_steps()
         K = len(steps)
-        if K > 16:
-            raise ValueError("the stacked line search handles at most 16 candidate steps")
         if self._stack is None or self._stack["K"] != K:
             z = lambda *shape: torch.empty(shape, dtype=torch.float64, device="cuda")  # noqa: E731
             self._stack = {"K": K, "Xt": z(K * B, N + 1, nx), "Ut": z(K * B, N, nu), "f": z(K * B, N, nx), "c": z(K * B, N, 1),
-                           "h": z(K * B, N, self.nh) if self.nh else None, "theta": z(K * B), "phi": z(K * B)}
+                           "h": z(K * B, N, self.nh) if self.nh else None, "theta": z(K * B), "phi": z(K * B), "rep": {}}
         st = self._stack
         alphas = (ctypes.c_double * K)(*steps)
         Xo, Uo, dXo, dUo = _node(X, nx, N + 1)._c(), _node(U, nu, N)._c(), _node(self.dX, nx, N + 1)._c(), _node(self.dU, nu, N)._c()
@@ -245,7 +253,19 @@ class BatchedSoftSqp:
         _check(self.lib.ungar_ocp_trial_points(nx, nu, N, B, ctypes.byref(Xo), ctypes.byref(Uo), ctypes.byref(dXo), ctypes.byref(dUo), alphas, K, ctypes.byref(Xt),
                                                ctypes.byref(Ut), s))
         # node values of the K * B stacked instances: per-instance parameters / node parameters are repeated per candidate
-        rep = lambda t: None if t is None else (t if t.dim() == 1 else t.repeat(K, *([1] * (t.dim() - 1))))  # noqa: E731
+        def rep(t):  # cached per source tensor: the copies outlive the launches that read them and are not reallocated every iteration
+            if t is None or t.dim() == 1:
+                return t
+            key = (t.data_ptr(), tuple(t.shape))
+            hit = st["rep"].get(key)
+            if hit is None:
+                if len(st["rep"]) >= 8:
+                    st["rep"].clear()
+                hit = (t, torch.empty((K * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device))
+                st["rep"][key] = hit
+            with self._on(s):
+                hit[1].view((K,) + tuple(t.shape)).copy_(t.unsqueeze(0).expand((K,) + tuple(t.shape)))
+            return hit[1]
         count = K * B * N
         xo = Operand(st["Xt"], instance_stride=(N + 1) * nx, knot_stride=nx, element_stride=1)
         uo = _node(st["Ut"], nu, N)
@@ -263,13 +283,14 @@ class BatchedSoftSqp:
         params = _LineSearchParameters(self.ls.alpha_min, self.ls.theta_min, self.ls.theta_max, self.ls.eta, self.ls.gamma_phi, self.ls.gamma_theta, self.ls.gamma_alpha)
         _check(self.lib.ungar_ocp_line_search_select(nx, nu, N, B, ctypes.byref(params), alphas, K, self.theta0.data_ptr(), self.phi0.data_ptr(), self.slope.data_ptr(),
                                                      st["theta"].data_ptr(), st["phi"].data_ptr(), self.accepted.data_ptr(), ctypes.byref(Xo), ctypes.byref(Uo),
-                                                     ctypes.byref(Xt), ctypes.byref(Ut), s))
+                                                     ctypes.byref(Xt), ctypes.byref(Ut), self.status.data_ptr(), s))
         return self.accepted
 
     def iterate(self, X, U, xm, p_dyn=None, p_cost=None, p_ineq=None, w=None, stream=None, stacked: bool = True):
         """One SQP iteration in place on (X, U): QP step, then the backtracking line search of the reference on
         phi = cost + barrier, theta = c |g| (soft_sqp.hpp:68-87).  Returns the per-instance accepted step sizes (device tensor,
-        0 = no acceptable step: that instance was left unchanged, the reference's `break`).
+        0 = no acceptable step: that instance was left unchanged, the reference's `break`).  An instance whose QP could not be solved
+        (self.status != 0: reduced input Hessian not positive definite) takes no step either -- the reference asserts there.
 
         stacked (default): all candidate steps are evaluated as ONE stacked batch of candidates x batch trial points -- one launch per
         node model, one merit launch, one selection launch instead of six small launches per candidate; with thousands of instances
@@ -279,9 +300,10 @@ class BatchedSoftSqp:
         nx, nu, N, B = self.nx, self.nu, self.N, self.batch
         self.qp_step(X, U, xm, p_dyn, p_cost, p_ineq, w, stream)
         self._merit(X, xm, self.theta0, self.phi0, True, s)  # node values at (X, U) are still in f / c / h
-        if stacked:
+        if stacked and self._stackable:
             return self._stacked_search(X, U, xm, p_dyn, p_cost, p_ineq, w, s)
-        self.accepted.zero_()
+        with self._on(s):
+            self.accepted.zero_()
         params = _LineSearchParameters(self.ls.alpha_min, self.ls.theta_min, self.ls.theta_max, self.ls.eta, self.ls.gamma_phi, self.ls.gamma_theta, self.ls.gamma_alpha)
         Xo, Uo, Xt, Ut = (_node(X, nx, N + 1)._c(), _node(U, nu, N)._c(), _node(self.Xt, nx, N + 1)._c(), _node(self.Ut, nu, N)._c())
         dXo, dUo = _node(self.dX, nx, N + 1)._c(), _node(self.dU, nu, N)._c()
@@ -293,6 +315,6 @@ class BatchedSoftSqp:
             self._merit(self.Xt, xm, self.thetaT, self.phiT, False, s)
             _check(self.lib.ungar_ocp_line_search_accept(nx, nu, N, B, ctypes.byref(params), alpha, self.theta0.data_ptr(), self.phi0.data_ptr(), self.slope.data_ptr(),
                                                          self.thetaT.data_ptr(), self.phiT.data_ptr(), self.accepted.data_ptr(), ctypes.byref(Xo), ctypes.byref(Uo),
-                                                         ctypes.byref(Xt), ctypes.byref(Ut), s))
+                                                         ctypes.byref(Xt), ctypes.byref(Ut), self.status.data_ptr(), s))
             alpha *= self.ls.gamma_alpha
         return self.accepted
