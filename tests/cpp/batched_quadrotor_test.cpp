@@ -4,6 +4,7 @@
 // by the facade's whole-horizon Ungar::SoftSQPOptimizer (sparse KKT solve of the very QP the reference hands to OSQP,
 // soft_sqp.hpp:143-158).  Search direction, accepted step size and iterate must agree after one and after two iterations.
 //   usage: batched_quadrotor_test <codegen folder> [batch] [compared instances]
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <random>
@@ -311,6 +312,15 @@ int main(int argc, char** argv) {
             for (const real_t a : accepted) moved += a > 0.0;
             std::printf("iteration %d: %td of %td instances accepted a step; worst |d - d_facade| / |d|max = %.3e, worst |x - x_facade| / |x|max = %.3e, worst step-size difference %.3e\n",
                         iteration, moved, batch, worstStep, worstIterate, worstAlpha);
+        }
+        {   // wall clock of further iterations (all instances, device only): synchronise, iterate, synchronise
+            const int timed = 5;
+            (void)batched.AcceptedStepSizes();
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int i = 0; i < timed; ++i) batched.Iterate();
+            (void)batched.AcceptedStepSizes();
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / timed;
+            std::printf("timing: %.3f ms per SQP iteration of %td instances (%.3g instances/s)\n", ms, batch, static_cast<double>(batch) / ms * 1e3);
         }
         const bool ok = worstStep <= 1e-9 && worstIterate <= 1e-9 && worstAlpha <= 1e-9;
         std::printf("%s batched quadrotor SQP (batch %td, %td compared)\n", ok ? "PASS" : "FAIL", batch, compared);

@@ -65,3 +65,19 @@ def test_facade_on_the_real_eigen(repo_root):
     if os.path.isdir(os.path.join(eigen, "Eigen")):
         _build_and_run(repo_root, "helpers_test", extra=("-DUNGAR_AMD_USE_SYSTEM_EIGEN", "-I", eigen))
         os.remove(os.path.join(repo_root, "build", "helpers_test"))  # the next run rebuilds the default (built-in algebra) variant
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["1", "2"])  # accumulation mode of the Jacobian: forward, reverse
+def test_helpers_on_the_device(repo_root, tmp_path, mode):
+    """SURVEY.md section 8(a) row A10 on the DEVICE: Sign, Min, Abs, SmoothAbs, SmoothMin, Pow(x, y), the LOG and POLY relaxed
+    barriers, quaternion inverse / normalized / slerp go through Autodiff::MakeFunction -> HIP emission -> hipcc -> gfx950 and their
+    value / Jacobian / Hessian kernels are checked against closed forms on either side of every switching point
+    (tests/cpp/helpers_device_test.cpp; reference utils.hpp:969-1021, autodiff/support/quaternion.hpp:34-192,
+    soft_inequality_constraint.hpp:77-205)."""
+    import subprocess
+    exe = os.path.join(repo_root, "build", "helpers_device_test")
+    assert os.path.exists(exe), "build/helpers_device_test missing: run __graft_entry__.build()"
+    r = subprocess.run([exe, str(tmp_path / "codegen")], capture_output=True, text=True, timeout=1200, env={**os.environ, "UNGAR_AMD_JACOBIAN_MODE": mode})
+    print(r.stdout[-4000:], r.stderr[-2000:])
+    assert r.returncode == 0 and "helpers_device_test OK" in r.stdout

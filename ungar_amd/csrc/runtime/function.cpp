@@ -312,6 +312,10 @@ int ungar_function_make(const ungar_tape_node* nodes, int64_t num_nodes, const i
         const char* compiler = std::getenv("UNGAR_HIPCC");  // a different compiler (or a wrapper that adds flags) must not share entries
         key.Str(compiler ? compiler : "");
     }
+    // accumulation mode of the Jacobian: 0 = cheaper of the two by the tape's cost estimate, 1 = forward, 2 = reverse (tests force each one)
+    int jacobianMode = 0;
+    if (const char* forced = std::getenv("UNGAR_AMD_JACOBIAN_MODE")) jacobianMode = std::atoi(forced) == 1 ? 1 : std::atoi(forced) == 2 ? 2 : 0;
+    key.Int(jacobianMode);
     key.Int(n);
     key.Int(p);
     key.Int(m);
@@ -387,7 +391,7 @@ int ungar_function_make(const ungar_tape_node* nodes, int64_t num_nodes, const i
         tape::SparseEntries jac, hes;
         tape::Differentiator diff{t};
         if (enabled_derivatives & kEnableJacobian) {
-            jac = diff.Jacobian(static_cast<int>(n));
+            jac = diff.Jacobian(static_cast<int>(n), jacobianMode);
             meta.jacRows.assign(jac.row.begin(), jac.row.end());
             meta.jacCols.assign(jac.col.begin(), jac.col.end());
         }
