@@ -355,8 +355,23 @@ typedef struct ungar_shooting_assemble_args {
     ungar_barrier barrier;
     double regularization;
     double *AB, *b, *W, *w, *E, *dz0;       /* outputs */
+    /* eliminate_equalities != 0: the stage equality rows are eliminated here, node by node in parallel, instead of inside the sequential
+     * recursion: Gauss-Jordan on [D | C | e] picks one pivot input per active row, u_j = -(E'_i . [z; u] + e'_i); the substitution turns
+     * (AB, b, W, w) into an UNCONSTRAINED stage problem in which u_j is a decoupled dummy, so ungar_ocp_riccati_solve is called with
+     * ne = 0 and ungar_shooting_recover_inputs restores the eliminated inputs afterwards.  E then receives the reduced rows E', eq_reduced
+     * (batch x N x ne) their residuals e', eq_pivots (batch x N x ne) the pivot input of every row (-1: row inactive, -2: a row that the
+     * inputs of its knot cannot meet -- reported through `status` by the recover call).  eq: the equality function's values (N+1 knots). */
+    int32_t eliminate_equalities;
+    int32_t reserved;
+    const double* eq;
+    double* eq_reduced;
+    int32_t* eq_pivots;
 } ungar_shooting_assemble_args;
 int ungar_shooting_assemble(const ungar_shooting_assemble_args* args, void* stream);
+/* After the Riccati solve of a problem assembled with eliminate_equalities: dU[b][k][j] = -(E'_i . [dz_k; du_k] + e'_i) for every reduced
+ * row i with pivot input j; status[b] = -(k+1) for a row that cannot be met (status may be null). */
+int ungar_shooting_recover_inputs(const ungar_shooting_dims* dims, int64_t ne, const double* E, const double* eq_reduced, const int32_t* eq_pivots, const double* dZ,
+                                  double* dU, int32_t* status, void* stream);
 
 /* theta = multiplier * |[x_0 - x_m; x_{k+1} - f_k; e_k]|_2, objective = sum_{k<=N} cost_k, phi = objective + barrier terms, and (cost_grad,
  * dZ, dU given) slope = grad objective . step, per instance (soft_sqp.hpp:68-87).  period > 0: dims.batch counts STACKED trial points

@@ -8,6 +8,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <fstream>
 #include <random>
 #include <string>
@@ -248,6 +249,7 @@ int main(int argc, char** argv) {
         }
         const real_t dt = 1.0 / static_cast<real_t>(N);
         BatchedSoftSQPOptimizer batched{std::move(problem), batch, false, dt, 2, 1.0, 1.0};  // the example's optimizer settings (:444)
+        if (const char* inside = std::getenv("UNGAR_TEST_EQUALITY_ROWS_IN_RECURSION")) batched.EliminateEqualityRowsBeforeTheRecursion(inside[0] != '1');
 
         // ---- instances: parameter values of quadruped.example.cpp:378-430, a random gait and a perturbed initial guess each
         std::mt19937_64 rng{20260930};

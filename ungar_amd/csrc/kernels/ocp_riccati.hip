@@ -315,6 +315,7 @@ extern "C" int ungar_amd_launch_riccati(const RiccatiArgs* a, void* stream) {
     if (a->ne == 0 && a->nx == 17 && a->nu == 4) return LaunchRiccati<64, 6, 7, 17, 4>(a, lds, s);
     if (a->ne == 0 && a->nx == 8 && a->nu == 2) return LaunchRiccati<64, 2, 2, 8, 2>(a, lds, s);
     if (a->ne == 16 && a->nx == 25 && a->nu == 24) return LaunchRiccati<256, 0, 0, 25, 24, true, true, 16>(a, lds, s);
+    if (a->ne == 0 && a->nx == 25 && a->nu == 24) return LaunchRiccati<256, 0, 0, 25, 24, true, true>(a, lds, s);  // ... with the rows eliminated before the recursion
     if (a->ne > 0) return n >= 32 ? LaunchRiccati<256, 0, 0>(a, lds, s) : LaunchRiccati<64, 0, 0>(a, lds, s);  // run-time sizes
     // Variants of the same recursion (tools/bench_sqp.py): lanes per instance (one or four wavefronts
     // share the entries of every product) and whether the next knot's operands are staged in registers.

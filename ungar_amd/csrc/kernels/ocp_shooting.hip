@@ -4,6 +4,8 @@
 // backtracking_line_search.hpp:116-151).  The QP itself is solved by the Riccati kernel (ocp_riccati.hip) on what is assembled here.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "ocp_barrier.hpp"
 #include "ocp_shooting.hpp"
 
@@ -17,7 +19,8 @@ __device__ __forceinline__ const double* RowOf(const double* rows, const Shootin
 }
 
 /// One workgroup per node (instance, knot <= N).  Sparse values are scattered into dense LDS images first (a dense block is written
-/// to global memory exactly once, coalesced; zero-filling and scattering in global memory would race), then the barrier terms are added.
+/// to global memory exactly once, coalesced; zero-filling and scattering in global memory would race), then the barrier terms are added
+/// and -- on request -- the stage equality rows eliminated.  Dense loops map (wavefront -> row, lane -> column): no index divisions.
 __global__ __launch_bounds__(256) void ShootingAssembleKernel(const ShootingAssembleArgs a) {
     extern __shared__ double lds[];
     const ShootingDims& d = a.d;
@@ -26,6 +29,7 @@ __global__ __launch_bounds__(256) void ShootingAssembleKernel(const ShootingAsse
     const int k = static_cast<int>(node - b * (d.N + 1));
     if (b >= d.batch) return;
     const int lane = static_cast<int>(threadIdx.x), lanes = static_cast<int>(blockDim.x);
+    const int wave = lane >> 6, wl = lane & 63, waves = lanes >> 6;
     const int nz = d.nz(), nd = d.nd(), nc = d.nc, nx = d.nx;
     const bool stage = k < d.N;  // knot N: terminal cost only
     double* Wd = lds;                 // nd x nd
@@ -35,6 +39,15 @@ __global__ __launch_bounds__(256) void ShootingAssembleKernel(const ShootingAsse
     double* d2 = d1 + a.nh;           // nh
     double* ABd = d2 + a.nh;          // nz x nd
     double* Ed = ABd + nz * nd;       // ne x nd
+    double* bd = Ed + a.ne * nd;      // nz
+    double* ed = bd + nz;             // ne
+    double* prow = ed + a.ne;         // nd + 1: pivot row of the elimination / column of W being eliminated
+    double* fcol = prow + nd + 1;     // max(ne, nz): column factors
+    double* vbuf = fcol + (a.ne > nz ? a.ne : nz);  // 2 + ne x nd: pivot-search keys, then W_BB G of the elimination
+    int* pivCol = reinterpret_cast<int*>(vbuf + 2 + a.ne * nd);  // ne pivot inputs
+    int* used = pivCol + a.ne;        // nu flags
+    int* list = used + d.nu;          // max(nd, ne) indices of a support
+    int* listSize = list + (nd > a.ne ? nd : a.ne);
     const int total = nd * nd + nd + a.nh * nd + 2 * a.nh + nz * nd + a.ne * nd;
     for (int i = lane; i < total; i += lanes) lds[i] = 0.0;
     __syncthreads();
@@ -58,31 +71,173 @@ __global__ __launch_bounds__(256) void ShootingAssembleKernel(const ShootingAsse
         for (int e = lane; e < a.pe.nnz; e += lanes) Ed[a.pe.rows[e] * nd + a.pe.cols[e]] = a.eJ[nodeOff * a.pe.nnz + e];
     }
     __syncthreads();
-    // W (upper triangle), w
-    double* W = a.W + nodeOff * nd * nd;
+    // W (barrier terms and regularisation added; kept in LDS, both triangles), w
+    const float ndInv = 1.0f / static_cast<float>(nd);  // row of a flat index through a float reciprocal: exact for nd <= 256 (idx + 0.5 is never a multiple of nd)
     for (int idx = lane; idx < nd * nd; idx += lanes) {
-        const int r = idx / nd, c = idx - r * nd;
+        const int r = static_cast<int>((static_cast<float>(idx) + 0.5f) * ndInv), c = idx - r * nd;
         if (r > c) continue;
         double acc = Wd[idx];
         if (stage)
             for (int j = 0; j < a.nh; ++j) acc += d2[j] * Jh[j * nd + r] * Jh[j * nd + c];
         if (r == c && r >= nc && (stage || r < nz)) acc += a.regularization;  // the reference's 1e-6 I over its decision variables (soft_sqp.hpp:149-151)
-        W[idx] = acc;
+        Wd[idx] = acc;
+        Wd[c * nd + r] = acc;
     }
-    double* w = a.w + nodeOff * nd;
     for (int c = lane; c < nd; c += lanes) {
         double acc = gd[c];
         if (stage)
             for (int j = 0; j < a.nh; ++j) acc -= d1[j] * Jh[j * nd + c];  // d/dz b(-h) = -b'(-h) dh/dz
-        w[c] = acc;
+        gd[c] = acc;
     }
+    const long long stageOff = b * d.N + k;
     if (stage) {
-        const long long stageOff = b * d.N + k;
+        const double* next = RowOf(a.rows, d, b, k + 1);
+        for (int i = lane; i < nz; i += lanes) bd[i] = i < nc ? 0.0 : a.f[nodeOff * nx + (i - nc)] - next[i];
+        for (int j = lane; j < a.ne; j += lanes) ed[j] = a.e ? a.e[nodeOff * a.ne + j] : 0.0;
+    }
+    __syncthreads();
+    if (stage && a.eliminate && a.ne > 0) {
+        /// list <- {c < n : pred(c)} in ascending order, by the first wavefront (no closing barrier)
+        auto buildList = [&](int n, auto pred) {
+            if (wave == 0) {
+                int size = 0;
+                for (int c0 = 0; c0 < n; c0 += 64) {
+                    const int c = c0 + wl;
+                    const bool in = c < n && pred(c);
+                    const unsigned long long mask = __ballot(in);
+                    if (in) list[size + __popcll(mask & ((1ull << wl) - 1ull))] = c;
+                    size += __popcll(mask);
+                }
+                if (wl == 0) *listSize = size;
+            }
+        };
+        // ---- Gauss-Jordan on [C | D | e] (Ed, ed): one pivot input per active row.  The pivot of a row is its largest unused input
+        // coefficient, found with ONE LDS atomic per lane: for non-negative doubles the bit pattern orders like the value, so
+        // max(bits(|v|) with the low byte replaced by 255 - input) is the largest coefficient up to 2^-44 relative, ties to the lowest input.
+        unsigned long long* keys = reinterpret_cast<unsigned long long*>(vbuf);  // [0]: pivot key, [1]: bits of the row's largest |entry|
+        for (int j = lane; j < d.nu; j += lanes) used[j] = 0;
+        if (lane < 2) keys[lane] = 0ull;
+        __syncthreads();
+        for (int i = 0; i < a.ne; ++i) {
+            for (int c = lane; c <= nd; c += lanes) {
+                const double v = fabs(c < nd ? Ed[i * nd + c] : ed[i]);
+                const unsigned long long bits = static_cast<unsigned long long>(__double_as_longlong(v));
+                if (bits) atomicMax(&keys[1], bits);
+                if (c >= nz && c < nd && bits && !used[c - nz]) atomicMax(&keys[0], (bits & ~0xFFull) | static_cast<unsigned long long>(255 - (c - nz)));
+            }
+            __syncthreads();
+            const unsigned long long key = keys[0];
+            const double best = __longlong_as_double(static_cast<long long>(key & ~0xFFull)), rowMax = __longlong_as_double(static_cast<long long>(keys[1]));
+            // no usable input coefficient: an identically-zero (or redundant) row takes no pivot; anything else cannot be met by this knot's inputs
+            int j = key ? 255 - static_cast<int>(key & 0xFFull) : -1;
+            if (j >= 0 && best <= 1e-12 * rowMax) j = -2;
+            if (j == -1 && rowMax > 0.0) j = -2;
+            if (j >= 0) {
+                const double rpiv = 1.0 / Ed[i * nd + nz + j];
+                for (int c = lane; c <= nd; c += lanes) prow[c] = c == nz + j ? 1.0 : (c < nd ? Ed[i * nd + c] : ed[i]) * rpiv;  // (the pivot exactly 1)
+                for (int r = lane; r < a.ne; r += lanes) fcol[r] = r == i ? 0.0 : Ed[r * nd + nz + j];
+                buildList(a.ne, [&](int r) { return r != i && Ed[r * nd + nz + j] != 0.0; });  // the rows that hold this input: few (one leg's)
+            }
+            __syncthreads();
+            if (lane == 0) {
+                pivCol[i] = j;
+                if (j >= 0) used[j] = 1;
+                keys[0] = 0ull;
+                keys[1] = 0ull;
+            }
+            if (j >= 0) {
+                const int rowsHit = *listSize;
+                for (int t = wave; t < rowsHit; t += waves) {
+                    const int r = list[t];
+                    const double f = fcol[r];
+                    for (int c = wl; c <= nd; c += 64) {
+                        double* at = c < nd ? &Ed[r * nd + c] : &ed[r];
+                        *at -= f * prow[c];
+                    }
+                }
+                for (int c = lane; c <= nd; c += lanes) *(c < nd ? &Ed[i * nd + c] : &ed[i]) = prow[c];
+            }
+            __syncthreads();
+        }
+        // ---- substitute u_j = -(G_i . [z; u] + g0_i) for ALL pivot rows at once (the reduced rows have zeros in each other's pivot columns):
+        //   W'[a][c] = W[a][c] - sum_i (W[a][J_i] G_i[c] + G_i[a] W[J_i][c]) + sum_i G_i[a] V_i[c],   V_i[c] = sum_i' W[J_i][J_i'] G_i'[c]
+        // for a, c outside the pivot set (in place: only pivot rows / columns are read besides the entry itself); likewise w, [A|B], b.
+        buildList(a.ne, [&](int r) { return pivCol[r] >= 0; });
+        __syncthreads();
+        const int pivots = a.eliminate == 2 ? 0 : *listSize;  // (2: measurement only -- rows reduced, substitution skipped)
+        for (int t = wave; t < pivots; t += waves) {
+            const int J = nz + pivCol[list[t]];
+            for (int c = wl; c < nd; c += 64) {
+                double acc = 0.0;
+                for (int t2 = 0; t2 < pivots; ++t2) acc += Wd[J * nd + nz + pivCol[list[t2]]] * Ed[list[t2] * nd + c];
+                vbuf[2 + t * nd + c] = acc;
+            }
+        }
+        for (int c = lane; c < nd; c += lanes) {  // w + W s,  s = -sum_i e_(J_i) g0_i
+            double acc = gd[c];
+            for (int t = 0; t < pivots; ++t) acc -= Wd[c * nd + nz + pivCol[list[t]]] * ed[list[t]];
+            prow[c] = acc;
+        }
+        for (int r = lane; r < nz; r += lanes) {
+            double acc = bd[r];
+            for (int t = 0; t < pivots; ++t) acc -= ABd[r * nd + nz + pivCol[list[t]]] * ed[list[t]];
+            bd[r] = acc;
+        }
+        __syncthreads();
+        auto isPivot = [&](int c) { return c >= nz && used[c - nz] != 0; };
+        for (int r = wave; r < nd; r += waves) {
+            if (isPivot(r)) continue;
+            for (int c = r + wl; c < nd; c += 64) {
+                if (isPivot(c)) continue;
+                double acc = Wd[r * nd + c];
+                for (int t = 0; t < pivots; ++t) {
+                    const int i = list[t], J = nz + pivCol[i];
+                    const double gr = Ed[i * nd + r], gc = Ed[i * nd + c];
+                    acc += gr * (vbuf[2 + t * nd + c] - Wd[J * nd + c]) - Wd[r * nd + J] * gc;
+                }
+                Wd[r * nd + c] = acc;
+                Wd[c * nd + r] = acc;
+            }
+        }
+        for (int c = lane; c < nd; c += lanes) {
+            double acc = prow[c];
+            for (int t = 0; t < pivots; ++t) acc -= Ed[list[t] * nd + c] * prow[nz + pivCol[list[t]]];
+            gd[c] = isPivot(c) ? 0.0 : acc;
+        }
+        for (int r = wave; r < nz; r += waves)
+            for (int c = wl; c < nd; c += 64) {
+                if (isPivot(c)) continue;
+                double acc = ABd[r * nd + c];
+                for (int t = 0; t < pivots; ++t) acc -= ABd[r * nd + nz + pivCol[list[t]]] * Ed[list[t] * nd + c];
+                ABd[r * nd + c] = acc;
+            }
+        __syncthreads();  // every read of a pivot row / column is done: they become the dummies' identity rows
+        for (int t = wave; t < pivots; t += waves) {
+            const int J = nz + pivCol[list[t]];
+            for (int c = wl; c < nd; c += 64) {
+                Wd[J * nd + c] = c == J ? 1.0 : 0.0;
+                Wd[c * nd + J] = c == J ? 1.0 : 0.0;
+            }
+            for (int r = wl; r < nz; r += 64) ABd[r * nd + J] = 0.0;
+        }
+        __syncthreads();
+        for (int i = lane; i < a.ne; i += lanes) {
+            a.pivots[stageOff * a.ne + i] = pivCol[i];
+            a.er[stageOff * a.ne + i] = ed[i];
+        }
+    }
+    double* W = a.W + nodeOff * nd * nd;
+    for (int idx = lane; idx < nd * nd; idx += lanes) {
+        const int r = static_cast<int>((static_cast<float>(idx) + 0.5f) * ndInv);
+        if (r <= idx - r * nd) W[idx] = Wd[idx];
+    }
+    double* w = a.w + nodeOff * nd;
+    for (int c = lane; c < nd; c += lanes) w[c] = gd[c];
+    if (stage) {
         double* AB = a.AB + stageOff * nz * nd;
         for (int idx = lane; idx < nz * nd; idx += lanes) AB[idx] = ABd[idx];
-        const double* next = RowOf(a.rows, d, b, k + 1);
         double* bo = a.b + stageOff * nz;
-        for (int i = lane; i < nz; i += lanes) bo[i] = i < nc ? 0.0 : a.f[nodeOff * nx + (i - nc)] - next[i];
+        for (int i = lane; i < nz; i += lanes) bo[i] = bd[i];
         if (a.ne > 0) {
             double* E = a.E + stageOff * a.ne * nd;
             for (int idx = lane; idx < a.ne * nd; idx += lanes) E[idx] = Ed[idx];
@@ -92,6 +247,30 @@ __global__ __launch_bounds__(256) void ShootingAssembleKernel(const ShootingAsse
             for (int i = lane; i < nz; i += lanes) a.dz0[b * nz + i] = i < nc ? 0.0 : a.xm[b * nx + (i - nc)] - row0[i];
         }
     }
+}
+
+/// One lane per (stage node, reduced row).
+__global__ __launch_bounds__(256) void ShootingRecoverKernel(const ShootingRecoverArgs a) {
+    const ShootingDims& d = a.d;
+    const long long idx = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (idx >= d.batch * d.N * a.ne) return;
+    const long long node = idx / a.ne;
+    const int i = static_cast<int>(idx - node * a.ne), nz = d.nz(), nd = d.nd();
+    const long long b = node / d.N;
+    const int k = static_cast<int>(node - b * d.N);
+    const int j = a.pivots[idx];
+    if (j == -2 && a.status) a.status[b] = -(k + 1);  // (several lanes may write: any of them is a true report)
+    if (j < 0) return;
+    const double* row = a.E + idx * nd;
+    const double* dz = a.dZ + (b * (d.N + 1) + k) * nz;
+    double* du = a.dU + node * d.nu;
+    double acc = a.er[idx];
+    for (int c = 0; c < nz; ++c) acc += row[c] * dz[c];
+    for (int c = 0; c < d.nu; ++c) {
+        const double coefficient = row[nz + c];
+        if (c != j && coefficient != 0.0) acc += coefficient * du[c];  // the other pivot inputs have exact zeros here: never read while they are written
+    }
+    du[j] = -acc;
 }
 
 __global__ __launch_bounds__(kBlock) void ShootingMeritKernel(const ShootingMeritArgs a) {
@@ -212,13 +391,27 @@ using namespace ungar_amd::kernels;
 extern "C" int ungar_amd_launch_shooting_assemble(const ShootingAssembleArgs* a, void* stream) {
     if (a->d.batch <= 0) return 0;
     const std::size_t nd = static_cast<std::size_t>(a->d.nd()), nz = static_cast<std::size_t>(a->d.nz());
-    const std::size_t lds = (nd * nd + nd + static_cast<std::size_t>(a->nh) * nd + 2 * static_cast<std::size_t>(a->nh) + nz * nd + static_cast<std::size_t>(a->ne) * nd) * sizeof(double);
+    const std::size_t ne = static_cast<std::size_t>(a->ne), nu = static_cast<std::size_t>(a->d.nu);
+    const std::size_t lds = (nd * nd + nd + static_cast<std::size_t>(a->nh) * nd + 2 * static_cast<std::size_t>(a->nh) + nz * nd + ne * nd + nz + ne + (nd + 1) + (ne > nz ? ne : nz) + 2 + ne * nd) * sizeof(double) +
+                            (ne + nu + (nd > ne ? nd : ne) + 2) * sizeof(int) + 16;
     if (lds > 160 * 1024) return static_cast<int>(hipErrorInvalidValue);
     if (lds > 64 * 1024) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ShootingAssembleKernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
         if (e != hipSuccess) return static_cast<int>(e);
     }
-    hipLaunchKernelGGL(ShootingAssembleKernel, dim3(static_cast<unsigned>(a->d.batch * (a->d.N + 1))), dim3(nd >= 32 ? 256 : kBlock), lds, static_cast<hipStream_t>(stream), *a);
+    static const int forcedLanes = [] {
+        const char* e = getenv("UNGAR_AMD_ASSEMBLE_LANES");  // measurement knob: 64 / 128 / 256 lanes per node
+        return e ? atoi(e) : 0;
+    }();
+    const int lanesPerNode = forcedLanes == 64 || forcedLanes == 128 || forcedLanes == 256 ? forcedLanes : (nd >= 32 ? 256 : kBlock);
+    hipLaunchKernelGGL(ShootingAssembleKernel, dim3(static_cast<unsigned>(a->d.batch * (a->d.N + 1))), dim3(lanesPerNode), lds, static_cast<hipStream_t>(stream), *a);
+    return static_cast<int>(hipGetLastError());
+}
+
+extern "C" int ungar_amd_launch_shooting_recover(const ShootingRecoverArgs* a, void* stream) {
+    const long long items = a->d.batch * a->d.N * a->ne;
+    if (items <= 0) return 0;
+    hipLaunchKernelGGL(ShootingRecoverKernel, dim3(static_cast<unsigned>((items + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
     return static_cast<int>(hipGetLastError());
 }
 

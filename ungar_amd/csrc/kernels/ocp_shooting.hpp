@@ -50,6 +50,29 @@ struct ShootingAssembleArgs {
     BarrierParams barrier;
     double regularization;
     double *AB, *b, *W, *w, *E, *dz0;  // outputs: AB / b / E hold N knots per instance, W / w hold N + 1
+    // Elimination of the stage equality rows BEFORE the recursion (eliminate != 0), node by node in parallel: Gauss-Jordan on
+    // [D | C | e] with the largest input coefficient of a row as its pivot expresses one input per active row through the state and
+    // the remaining inputs, u_j = -(g . [z; u] + g0); substituting it into the stage cost and the linearised dynamics leaves an
+    // UNCONSTRAINED stage problem in which u_j is a decoupled dummy (unit Hessian, zero gradient, zero column of [A|B]).  The Riccati
+    // recursion then runs without equality rows -- its sequential chain no longer carries the (nu + ne)-order KKT block of every knot --
+    // and ShootingRecoverKernel restores the eliminated inputs from the reduced rows afterwards.  Rows that are identically zero take
+    // no pivot; a row without an input part but with a state part or a residual cannot be met by the inputs of its knot: reported.
+    int eliminate;
+    const double* e;   // equality values (the equality function's output), N + 1 knots per instance
+    double* er;        // out: residuals of the reduced rows, N knots per instance x ne
+    int* pivots;       // out: pivot input of every row (-1: none, -2: cannot be met), N knots per instance x ne
+};
+
+/// du_j <- -(E'_i . [dz; du] + e'_i) for every reduced row i with pivot input j (after the Riccati solve of the eliminated problem);
+/// a row reported as unsatisfiable marks its instance in `status` (-(k + 1)).
+struct ShootingRecoverArgs {
+    ShootingDims d;
+    int ne;
+    const double *E, *er;
+    const int* pivots;
+    const double* dZ;
+    double* dU;
+    int* status;
 };
 
 /// Merit terms per (stacked) instance (soft_sqp.hpp:68-87):  theta = c |[x_0 - x_m; x_{k+1} - f_k; e_k]|_2,  objective = sum_{k <= N} l_k,
@@ -100,6 +123,7 @@ struct ShootingSelectArgs {
 }  // namespace ungar_amd::kernels
 
 extern "C" int ungar_amd_launch_shooting_assemble(const ungar_amd::kernels::ShootingAssembleArgs* a, void* stream);
+extern "C" int ungar_amd_launch_shooting_recover(const ungar_amd::kernels::ShootingRecoverArgs* a, void* stream);
 extern "C" int ungar_amd_launch_shooting_merit(const ungar_amd::kernels::ShootingMeritArgs* a, void* stream);
 extern "C" int ungar_amd_launch_shooting_trial(const ungar_amd::kernels::ShootingTrialArgs* a, void* stream);
 extern "C" int ungar_amd_launch_shooting_select(const ungar_amd::kernels::ShootingSelectArgs* a, void* stream);

@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 #include <string>
 
 #include "../../../include/ungar_amd.h"
@@ -214,7 +215,28 @@ int ungar_shooting_assemble(const ungar_shooting_assemble_args* a, void* stream)
     k.w = a->w;
     k.E = a->E;
     k.dz0 = a->dz0;
+    k.eliminate = a->eliminate_equalities && a->ne > 0 ? (getenv("UNGAR_AMD_ASSEMBLE_SKIP_SUBSTITUTION") ? 2 : 1) : 0;
+    k.e = a->eq;
+    k.er = a->eq_reduced;
+    k.pivots = a->eq_pivots;
+    if (k.eliminate && (!a->eq || !a->eq_reduced || !a->eq_pivots)) return Fail(UNGAR_E_INVALID, "ungar_shooting_assemble: eliminating the equality rows needs eq, eq_reduced and eq_pivots");
     return Launched(ungar_amd_launch_shooting_assemble(&k, stream), "ungar_shooting_assemble");
+}
+
+int ungar_shooting_recover_inputs(const ungar_shooting_dims* dims, int64_t ne, const double* E, const double* eq_reduced, const int32_t* eq_pivots, const double* dZ, double* dU,
+                                  int32_t* status, void* stream) {
+    ShootingRecoverArgs k{};
+    if (!dims || !ToDims(*dims, &k.d) || ne < 0 || ne > 64) return Fail(UNGAR_E_INVALID, "ungar_shooting_recover_inputs: bad dimensions");
+    if (k.d.batch == 0 || ne == 0) return UNGAR_OK;
+    if (!E || !eq_reduced || !eq_pivots || !dZ || !dU) return Fail(UNGAR_E_INVALID, "ungar_shooting_recover_inputs: null argument");
+    k.ne = static_cast<int>(ne);
+    k.E = E;
+    k.er = eq_reduced;
+    k.pivots = eq_pivots;
+    k.dZ = dZ;
+    k.dU = dU;
+    k.status = status;
+    return Launched(ungar_amd_launch_shooting_recover(&k, stream), "ungar_shooting_recover_inputs");
 }
 
 int ungar_shooting_merit(const ungar_shooting_merit_args* a, void* stream) {

@@ -160,6 +160,11 @@ class BatchedSoftSQPOptimizer {
         a.w = _w;
         a.E = _E;
         a.dz0 = _dz0;
+        const bool eliminate = _eliminateEqualities && Ne() > 0;
+        a.eliminate_equalities = eliminate ? 1 : 0;
+        a.eq = _e;
+        a.eq_reduced = _er;
+        a.eq_pivots = _pivots;
         Check(ungar_shooting_assemble(&a, _stream));
         const index_t nz = Nz(), nu = _p.inputSize, nd = nz + nu;
         ungar_ocp_qp q{};
@@ -181,12 +186,13 @@ class BatchedSoftSQPOptimizer {
         q.workspace_doubles = _workspaceDoubles;
         q.regularization = 0.0;  // already on the decision variables' diagonal (the carried slots take none)
         q.status = _status;
-        q.ne = Ne();
-        if (Ne() > 0) {
+        q.ne = eliminate ? 0 : Ne();
+        if (q.ne > 0) {
             q.eq = {_E, N * Ne() * nd, Ne() * nd, 1};
             q.eq_values = {_e, (N + 1) * Ne(), Ne(), 1};
         }
         Check(ungar_ocp_riccati_solve(&q, _stream));
+        if (eliminate) Check(ungar_shooting_recover_inputs(&_dims, Ne(), _E, _er, _pivots, _dZ, _dU, _status, _stream));
         // ---- merit terms at the current point (soft_sqp.hpp:68-87) and along all candidate steps at once
         ungar_shooting_merit_args m{};
         m.dims = _dims;
@@ -283,6 +289,9 @@ class BatchedSoftSQPOptimizer {
         return q;
     }
     void SetStream(void* hipStream) { _stream = hipStream; }
+    /// Stage equality rows: eliminated node by node before the recursion (default; the sequential chain then carries no constraint
+    /// block) or kept inside the Riccati recursion as the stage KKT block of every knot (false; same solution, for comparison).
+    void EliminateEqualityRowsBeforeTheRecursion(const bool on) { _eliminateEqualities = on; }
     void SetLineSearchParameters(const BacktrackingLineSearch::Parameters& parameters) {
         std::vector<real_t> alphas;
         for (real_t alpha = 1.0; alpha >= parameters.alphaMin; alpha *= parameters.gammaAlpha) alphas.push_back(alpha);
@@ -367,6 +376,8 @@ class BatchedSoftSQPOptimizer {
         _W = Device<real_t>(nodes * nd * nd);
         _w = Device<real_t>(nodes * nd);
         _E = _p.equality ? Device<real_t>(B * N * Ne() * nd) : nullptr;
+        _er = _p.equality ? Device<real_t>(B * N * Ne()) : nullptr;
+        _pivots = _p.equality ? Device<int32_t>(B * N * Ne()) : nullptr;
         _dz0 = Device<real_t>(B * nz);
         _dZ = Device<real_t>(nodes * nz);
         _dU = Device<real_t>(B * N * nu);
@@ -434,7 +445,9 @@ class BatchedSoftSQPOptimizer {
     real_t *_fT = nullptr, *_lT = nullptr, *_hT = nullptr, *_eT = nullptr;
     real_t *_AB = nullptr, *_b = nullptr, *_W = nullptr, *_w = nullptr, *_E = nullptr, *_dz0 = nullptr, *_dZ = nullptr, *_dU = nullptr, *_workspace = nullptr;
     int64_t _workspaceDoubles = 0;
-    int32_t *_status = nullptr, *_active = nullptr;
+    real_t* _er = nullptr;
+    int32_t *_status = nullptr, *_active = nullptr, *_pivots = nullptr;
+    bool _eliminateEqualities = true;
     real_t *_theta0 = nullptr, *_phi0 = nullptr, *_obj0 = nullptr, *_slope = nullptr, *_accepted = nullptr, *_thetaT = nullptr, *_phiT = nullptr, *_objT = nullptr;
 };
 
