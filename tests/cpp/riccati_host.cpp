@@ -228,6 +228,7 @@ extern "C" int riccati_host_solve_eq(int variant, int nx, int nu, int ne, int N,
             if (nx == 17 && nu == 4 && ne == 0) RiccatiInstance<E, 17, 4, 0>(a, i, scratch.data(), ex);
             else if (nx == 8 && nu == 2 && ne == 0) RiccatiInstance<E, 8, 2, 0>(a, i, scratch.data(), ex);
             else if (nx == 25 && nu == 24 && ne == 16) RiccatiInstance<E, 25, 24, 16>(a, i, scratch.data(), ex);
+            else if (nx == 25 && nu == 24 && ne == 0) RiccatiInstance<E, 25, 24, 0>(a, i, scratch.data(), ex);  // rows eliminated before the recursion: blocked Cholesky
             else return 1;
         }
         return 0;

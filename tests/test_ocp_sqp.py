@@ -175,7 +175,7 @@ def test_riccati_with_stage_equality_rows_equals_the_dense_kkt_solve(host, nx, n
                 assert np.abs(r).max() <= 1e-9 * scale
 
 
-@pytest.mark.parametrize("nx,nu,ne", [(17, 4, 0), (8, 2, 0), (25, 24, 16)])
+@pytest.mark.parametrize("nx,nu,ne", [(17, 4, 0), (8, 2, 0), (25, 24, 16), (25, 24, 0)])
 def test_fixed_size_instantiations_with_carried_quantities(host, nx, nu, ne):
     """The instantiations for the reference's OCPs once the carried quantities (previous input, previous foot positions) are part of
     the stage state -- 17 + 4, 8 + 2, 25 + 24 with 16 contact rows -- agree with the run-time-sized recursion, also under both extreme

@@ -113,6 +113,136 @@ struct DeviceExec {
         static_assert(YOUNGER >= 0 && YOUNGER <= 63);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER) : "memory");
     }
+    // ---- the two large products of a knot on the FP64 matrix cores (four-wavefront kernels) ------------------------------------
+    // v_mfma_f64_16x16x4_f64: A[i][k] in lane 16 k + i, B[k][j] in lane 16 k + j, D[(lane >> 4) + 4 r][lane & 15] in element r.
+#ifndef UNGAR_RICCATI_NO_MFMA
+    static constexpr bool kMatrixCores = BLOCK == 256 && DMA;
+#else
+    static constexpr bool kMatrixCores = false;
+#endif
+    using f64x4 = __attribute__((__vector_size__(4 * sizeof(double)))) double;
+    /// PAB = P [A|B] (NX x n) and t = P b + p.  P is symmetric (bitwise: it is written symmetrised), so A[i][k] = P[k][i] is read along rows.
+    /// Wavefront w owns the tile columns w, w + 4, ...; padded rows / columns / k-steps contribute zeros.
+    template <int NX, int NU>
+    __device__ __forceinline__ void ProductPab(const double* P, const double* AB, const double* bk, const double* p, double* PAB, double* t) {
+        constexpr int n = NX + NU, TR = (NX + 15) / 16, TC = (n + 1 + 15) / 16, KS = (NX + 3) / 4;
+        const int lane = static_cast<int>(threadIdx.x) & 63, li = lane & 15, lk = lane >> 4;
+        for (int tj = Wave(); tj < TC; tj += kWaves) {
+            f64x4 acc[TR];
+#pragma unroll
+            for (int ti = 0; ti < TR; ++ti) acc[ti] = f64x4{0.0, 0.0, 0.0, 0.0};
+            const int col = 16 * tj + li;
+            // operands are loaded unconditionally from clamped addresses and zeroed by a select: no branches between the matrix instructions
+            const double* bBase = col < n ? AB + col : bk;
+            const int bStride = col < n ? n : 1;
+            const bool colOk = col <= n;
+            int rowC[TR];
+            bool rowOk[TR];
+#pragma unroll
+            for (int ti = 0; ti < TR; ++ti) {
+                rowOk[ti] = 16 * ti + li < NX;
+                rowC[ti] = rowOk[ti] ? 16 * ti + li : NX - 1;
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int kk = 4 * ks + lk;
+                const bool kOk = kk < NX;
+                const int kc = kOk ? kk : NX - 1;
+                const double braw = bBase[kc * bStride];
+                const double bv = (kOk && colOk) ? braw : 0.0;
+                double av[TR];
+#pragma unroll
+                for (int ti = 0; ti < TR; ++ti) {
+                    const double araw = P[kc * NX + rowC[ti]];
+                    av[ti] = (kOk && rowOk[ti]) ? araw : 0.0;
+                }
+#pragma unroll
+                for (int ti = 0; ti < TR; ++ti) acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ti], bv, acc[ti], 0, 0, 0);
+            }
+#pragma unroll
+            for (int ti = 0; ti < TR; ++ti)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * ti + lk + 4 * r;
+                    if (row < NX) {
+                        if (col < n) PAB[row * n + col] = acc[ti][r];
+                        else if (col == n) t[row] = acc[ti][r] + p[row];
+                    }
+                }
+        }
+        LdsBarrier();
+    }
+    /// H = W + [A|B]^T PAB on and above the diagonal (mirrored), h = w + [A|B]^T t.  W: folded upper triangle (RiccatiFoldedIndex) or
+    /// null = in place in H; the upper tiles (column-major) are dealt to the wavefronts in contiguous runs.
+    template <int NX, int NU>
+    __device__ __forceinline__ void ProductH(const double* AB, const double* PAB, const double* t, const double* Wfold, const double* wv, double reg, double* H, double* h) {
+        constexpr int n = NX + NU, TT = (n + 1 + 15) / 16, tiles = TT * (TT + 1) / 2, CH = (tiles + kWaves - 1) / kWaves, KS = (NX + 3) / 4;
+        const int lane = static_cast<int>(threadIdx.x) & 63, li = lane & 15, lk = lane >> 4;
+        const int first = Wave() * CH;
+        f64x4 acc[CH];
+        int ti[CH], tj[CH], rowC[CH], bStride[CH];
+        const double* bBase[CH];
+        bool rowOk[CH], colOk[CH], live[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            acc[c] = f64x4{0.0, 0.0, 0.0, 0.0};
+            int idx = first + c, j = 0;  // column-major upper triangle: tile idx -> (i, j), i <= j
+            live[c] = idx < tiles;
+            if (!live[c]) idx = 0;
+            while (idx > j) {
+                idx -= j + 1;
+                ++j;
+            }
+            ti[c] = idx;
+            tj[c] = j;
+            const int row = 16 * idx + li, col = 16 * j + li;
+            rowOk[c] = live[c] && row < n;
+            rowC[c] = row < n ? row : n - 1;
+            colOk[c] = live[c] && col <= n;
+            bBase[c] = col < n ? PAB + col : t;
+            bStride[c] = col < n ? n : 1;
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int kk = 4 * ks + lk;
+            const bool kOk = kk < NX;
+            const int kc = kOk ? kk : NX - 1;
+            double av[CH], bv[CH];
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const double araw = AB[kc * n + rowC[c]], braw = bBase[c][kc * bStride[c]];
+                av[c] = (kOk && rowOk[c]) ? araw : 0.0;
+                bv[c] = (kOk && colOk[c]) ? braw : 0.0;
+            }
+#pragma unroll
+            for (int c = 0; c < CH; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[c], bv[c], acc[c], 0, 0, 0);
+        }
+#ifdef UNGAR_RICCATI_CLOCKS
+        Mark(6);  // (diagnostic builds: the matrix-instruction loop of the H phase under "-", its epilogue and barrier under "H")
+#endif
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            if (!live[c]) continue;  // uniform over the wavefront
+            const int col = 16 * tj[c] + li;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * ti[c] + lk + 4 * r;
+                if (row >= n) continue;
+                if (col < n) {
+                    if (row <= col) {
+                        const double w = Wfold ? Wfold[RiccatiFoldedIndex(n, row, col)] : H[row * n + col];
+                        const double e = w + (row == col ? reg : 0.0) + acc[c][r];
+                        H[row * n + col] = e;
+                        H[col * n + row] = e;
+                    }
+                } else if (col == n) {
+                    h[row] = wv[row] + acc[c][r];
+                }
+            }
+        }
+        LdsBarrier();
+    }
+
 #ifdef UNGAR_RICCATI_CLOCKS
     /// Diagnostic build: cycles of the first workgroup's first lane between consecutive marks, summed per mark id
     /// (read back with ungar_amd_debug_riccati_clocks; tools/bench_riccati_phases.py).
@@ -140,7 +270,7 @@ template <int BLOCK, int NX, int NU>
 #ifdef UNGAR_RICCATI_NO_OCCUPANCY_BOUND
 inline constexpr int kRiccatiWavesPerSimd = 1;
 #else
-inline constexpr int kRiccatiWavesPerSimd = (NX == 37 && NU == 12) ? 2 : (NX == 13 && NU == 4 && BLOCK == 64) ? 4 : 1;
+inline constexpr int kRiccatiWavesPerSimd = ((NX == 37 && NU == 12) || (NX == 25 && NU == 24 && BLOCK == 256)) ? 2 : (NX == 13 && NU == 4 && BLOCK == 64) ? 4 : 1;
 #endif
 
 template <int BLOCK, int SLOTS_AB, int SLOTS_W, int NX = 0, int NU = 0, bool AHEAD = true, bool DMA = false, int NE = 0>

@@ -53,6 +53,18 @@
 #define UNGAR_RICCATI_TILE_MIN_NX 6  // register tiles in the two large products for compile-time sizes from this nx on
 #endif
 
+#ifndef UNGAR_RICCATI_MFMA_MIN_NX
+#define UNGAR_RICCATI_MFMA_MIN_NX 24  // state dimension from which the four-wavefront kernels run their two large products on the matrix cores
+#endif
+
+#ifndef UNGAR_RICCATI_BLOCKED_MIN_NX
+#define UNGAR_RICCATI_BLOCKED_MIN_NX 24  // blocked Cholesky from this state dimension on: such blocks fit two workgroups per CU by their LDS anyway, so its registers cost
+#endif                                 // no occupancy (13 + 24 runs five workgroups per CU on the rank-one phases: 4.8 ms against 5.7 blocked, r03e)
+
+#ifndef UNGAR_RICCATI_BLOCK
+#define UNGAR_RICCATI_BLOCK 8  // diagonal block of the blocked Cholesky for input dimensions above 12 (factorised in registers by every lane)
+#endif
+
 namespace ungar_amd::kernels {
 
 /// Strided view (instance, knot, element) of one operand, in doubles.
@@ -115,6 +127,12 @@ constexpr RiccatiTile RiccatiChooseTile(int rows, int cols, int lanes) {
 template <class Exec>
 constexpr bool RiccatiExecHasDma() {
     if constexpr (requires { Exec::kDma; }) return Exec::kDma;
+    else return false;
+}
+
+template <class Exec>
+constexpr bool RiccatiExecHasMatrixCores() {
+    if constexpr (requires { Exec::kMatrixCores; }) return Exec::kMatrixCores;
     else return false;
 }
 
@@ -297,7 +315,20 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
             ex.Barrier();
         }
         RiccatiMark(ex, 1);  // operands of the knot
-        if constexpr (NX >= UNGAR_RICCATI_TILE_MIN_NX) {
+        if constexpr (RiccatiExecHasMatrixCores<Exec>() && NX >= UNGAR_RICCATI_MFMA_MIN_NX) {
+            // The two large products on the FP64 matrix cores (policies that have them: the four-wavefront device kernels).  What this
+            // buys is not arithmetic rate -- v_mfma_f64_16x16x4_f64 and v_fma_f64 peak alike on gfx950 -- but operand traffic: a wavefront
+            // reads two LDS words per lane for 1024 multiply-adds instead of (TI + TC) per TI x TC (these phases were bound by LDS issue,
+            // 47 % of the 37 + 12 recursion), and no index arithmetic is left in the inner loop.  b rides along as column n of [A|B]
+            // (t = P b + p) and t as column n of P [A|B] (h = w + [A|B]^T t): both fall into tiles that are computed anyway.
+            ex.template ProductPab<NX, NU>(P, AB, bk, p, PAB, t);
+            RiccatiMark(ex, 2);  // P [A|B]
+            if constexpr (dma) {
+                if (k > 0) dmaAfterPab(k - 1, P);
+            }
+            const double* Wsrc = foldW ? (foldInP ? Pn : wf) : nullptr;
+            ex.template ProductH<NX, NU>(AB, PAB, t, Wsrc, foldW ? wn : h, a.regularization, H, h);
+        } else if constexpr (NX >= UNGAR_RICCATI_TILE_MIN_NX) {
             // Sizes fixed at compile time: TI x TC register tiles (RiccatiChooseTile; 2 x 4: eight multiply-adds per six LDS reads instead of
             // per sixteen) and no bounds checks inside the product (a tile on the edge reads past its row / matrix into the neighbouring
             // scratch arrays, which is harmless: only the stores are guarded).  A tile's columns are INTERLEAVED (tc, tc + tilesC, ...):
@@ -451,6 +482,112 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
                     gains[static_cast<long long>(k) * nu * nk + i * nk + c] = sv;
                 }
             });
+        } else if constexpr (NU > 12 && NU % UNGAR_RICCATI_BLOCK == 0 && NU <= 4 * UNGAR_RICCATI_BLOCK && NE == 0 && NX >= UNGAR_RICCATI_BLOCKED_MIN_NX) {
+            // Input dimension 24 next to a large state (the reference's quadruped with the previous foot positions carried, 25 + 24): BLOCKED Cholesky with NB x NB diagonal blocks that
+            // every lane factorises itself, in registers, exactly as above -- 3 NU / NB - 1 phases of register-level work instead of the
+            // 2 NU + 1 barrier-separated rank-one phases of the branch below (49 for NU = 24, two thirds of that recursion's time):
+            //   A_b  one lane per column of [R_(b, later) | G_b]:  L_bb (registers) from the block's lower triangle,  Y = L_bb^-1 column
+            //        (the panel L_(i,b)^T written over R[i][b], i later; the forward-substituted right-hand side over G_b)
+            //   B_b  R[i][k] -= Y_i . Y_k (later i >= k),  G[i][:] -= Y_i . Y_G[:]          (Schur complement of the block)
+            //   C_b  (blocks in reverse)  one lane per right-hand side:  x_b = L_bb^-T (y_b - sum_(later i) L_(i,b)^T x_i)
+            // R = H_uu is read and updated in its LOWER triangle (row i holds R[i][0..i]); G = -[H_ux | h_u] lives in K.
+            constexpr int NB = UNGAR_RICCATI_BLOCK, blocks = NU / NB;
+            ex.ForEach(nu * nk, [&](int idx) {
+                const int i = idx / nk, c = idx - i * nk;
+                K[idx] = c < nx ? -H[(nx + i) * n + c] : -h[nx + i];
+            });
+            auto factorBlock = [&](int b0, double (&L)[NB][NB], double (&inv)[NB]) {  // L L^T = R[b0.., b0..] (lower triangle read); true if not positive definite
+                bool bad = false;
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    double d = H[(nx + b0 + j) * n + nx + b0 + j];
+#pragma unroll
+                    for (int m = 0; m < j; ++m) d -= L[j][m] * L[j][m];
+                    const bool neg = !(d > 0.0);
+                    bad = bad || neg;
+                    L[j][j] = sqrt(neg ? 1.0 : d);
+                    inv[j] = 1.0 / L[j][j];
+#pragma unroll
+                    for (int i = j + 1; i < NB; ++i) {
+                        double sv = H[(nx + b0 + i) * n + nx + b0 + j];
+#pragma unroll
+                        for (int m = 0; m < j; ++m) sv -= L[i][m] * L[j][m];
+                        L[i][j] = sv * inv[j];
+                    }
+                }
+                return bad;
+            };
+            for (int b = 0; b < blocks; ++b) {
+                const int b0 = b * NB, later = nu - b0 - NB;
+                ex.ForEach(later + nk, [&](int c) {  // A_b: columns R[b-rows][b0 + NB + c] (c < later), then the right-hand sides
+                    double L[NB][NB], inv[NB], y[NB];
+                    const bool bad = factorBlock(b0, L, inv);
+                    if (c == 0 && bad) failed = failed ? failed : k + 1;
+                    double* col = c < later ? H + (nx + b0 + NB + c) * n + nx + b0 : nullptr;  // row (b0 + NB + c) of R, entries of block b: the column by symmetry
+#pragma unroll
+                    for (int i = 0; i < NB; ++i) {
+                        double sv = col ? col[i] : K[(b0 + i) * nk + (c - later)];
+#pragma unroll
+                        for (int m = 0; m < i; ++m) sv -= L[i][m] * y[m];
+                        y[i] = sv * inv[i];
+                    }
+#pragma unroll
+                    for (int i = 0; i < NB; ++i) {
+                        if (col) col[i] = y[i];
+                        else K[(b0 + i) * nk + (c - later)] = y[i];
+                    }
+                });
+                if (later > 0) {
+                    const int pairs = later * (later + 1) / 2;
+                    ex.ForEach(pairs + later * nk, [&](int idx) {  // B_b
+                        if (idx < pairs) {
+                            int i = 0, rest = idx;  // (i, k2), k2 <= i, of the later x later lower triangle
+                            while (rest > i) {
+                                rest -= i + 1;
+                                ++i;
+                            }
+                            const double* yi = H + (nx + b0 + NB + i) * n + nx + b0;
+                            const double* yk = H + (nx + b0 + NB + rest) * n + nx + b0;
+                            double acc = 0.0;
+#pragma unroll
+                            for (int m = 0; m < NB; ++m) acc += yi[m] * yk[m];
+                            H[(nx + b0 + NB + i) * n + nx + b0 + NB + rest] -= acc;
+                        } else {
+                            const int e = idx - pairs, i = e / nk, c = e - i * nk;
+                            const double* yi = H + (nx + b0 + NB + i) * n + nx + b0;
+                            double acc = 0.0;
+#pragma unroll
+                            for (int m = 0; m < NB; ++m) acc += yi[m] * K[(b0 + m) * nk + c];
+                            K[(b0 + NB + i) * nk + c] -= acc;
+                        }
+                    });
+                }
+            }
+            for (int b = blocks - 1; b >= 0; --b) {
+                const int b0 = b * NB, later = nu - b0 - NB;
+                ex.ForEach(nk, [&](int c) {  // C_b
+                    double L[NB][NB], inv[NB], y[NB];
+                    (void)factorBlock(b0, L, inv);
+#pragma unroll
+                    for (int m = 0; m < NB; ++m) y[m] = K[(b0 + m) * nk + c];
+                    for (int i = 0; i < later; ++i) {
+                        const double xi = K[(b0 + NB + i) * nk + c];
+                        const double* yi = H + (nx + b0 + NB + i) * n + nx + b0;
+#pragma unroll
+                        for (int m = 0; m < NB; ++m) y[m] -= yi[m] * xi;
+                    }
+#pragma unroll
+                    for (int i = NB - 1; i >= 0; --i) {  // L^T x = y
+                        double sv = y[i];
+#pragma unroll
+                        for (int m = i + 1; m < NB; ++m) sv -= L[m][i] * y[m];
+                        sv *= inv[i];
+                        y[i] = sv;
+                        K[(b0 + i) * nk + c] = sv;
+                        gains[static_cast<long long>(k) * nu * nk + (b0 + i) * nk + c] = sv;
+                    }
+                });
+            }
         } else {
             // Larger (or run-time) input dimension: R = H_uu is factorised as L D L^T by RIGHT-LOOKING elimination, applied at the
             // same time to the right-hand sides [K | kff] = -[H_ux | h_u] (forward substitution), then the back substitution is
