@@ -25,21 +25,22 @@ def compare_launch_with_c_checker(name, x, u, p, f, J, count, chunk=1 << 19):
     flat = rows * ncols + cols
     off = np.ones(nx * ncols, dtype=bool)
     off[flat] = False
-    fn = getattr(clib, f"{name}_sparse_jacobian")
     dp = ctypes.POINTER(ctypes.c_double)
-    fn.argtypes = [dp] * 6
+    loop = getattr(clib, f"{name}_sparse_jacobian_batch_shared")  # C loop over a range of nodes: one foreign call per thread and chunk
+    loop.argtypes = [dp] * 6 + [ctypes.c_long, ctypes.c_long]
+    loop.restype = None
     ph, w0 = np.ascontiguousarray(p.cpu().numpy()), np.zeros(1)
     workers = min(16, os.cpu_count() or 1)
     for lo in range(0, count, chunk):
         hi = min(count, lo + chunk)
         m = hi - lo
-        xh, uh = np.ascontiguousarray(x[:, lo:hi].t().cpu().numpy()), np.ascontiguousarray(u[:, lo:hi].t().cpu().numpy())
-        fh, Jh = np.ascontiguousarray(f[:, lo:hi].t().cpu().numpy()), np.ascontiguousarray(J[:, lo:hi].t().cpu().numpy())
+        # node-major on the DEVICE (a 1.2 GB block transposed by numpy on the host cost more than the C checker itself)
+        xh, uh = x[:, lo:hi].t().contiguous().cpu().numpy(), u[:, lo:hi].t().contiguous().cpu().numpy()
+        fh, Jh = f[:, lo:hi].t().contiguous().cpu().numpy(), J[:, lo:hi].t().contiguous().cpu().numpy()
         rf, rj = np.empty((m, nx)), np.empty((m, nnz))
 
         def part(a, b):  # ctypes releases the GIL inside the call
-            for i in range(a, b):
-                fn(xh[i].ctypes.data_as(dp), uh[i].ctypes.data_as(dp), w0.ctypes.data_as(dp), ph.ctypes.data_as(dp), rf[i].ctypes.data_as(dp), rj[i].ctypes.data_as(dp))
+            loop(xh.ctypes.data_as(dp), uh.ctypes.data_as(dp), w0.ctypes.data_as(dp), ph.ctypes.data_as(dp), rf.ctypes.data_as(dp), rj.ctypes.data_as(dp), a, b)
 
         step = (m + workers - 1) // workers
         with ThreadPoolExecutor(workers) as pool:
