@@ -156,6 +156,8 @@ class BatchedSoftSqp:
         self.status = torch.zeros((B,), dtype=torch.int32, device="cuda")
         self.workspace = z(max(1, self.lib.ungar_ocp_riccati_workspace(nx, nu, N, B)))
         self._stack = None  # buffers of the stacked line search, allocated on first use
+        import os
+        self._transpose_jacobian = os.environ.get("UNGAR_AMD_SQP_JACOBIAN_IN_PLACE") != "1"
         self._wide = None   # unit-fastest scratch of a wide dynamics Jacobian (>= 1024 entries per node and no node parameters w)
         if nx * n >= 1024 and self.dyn.nw == 0:
             from .sharding import unit_fastest
@@ -190,7 +192,13 @@ class BatchedSoftSqp:
             self.dyn.dense_jacobian(count, Operand(sx, instance_stride=N + 1, knot_stride=1, element_stride=sx.stride(0)), Operand.soa(su, su.stride(0), N), wd,
                                     par(p_dyn, self.dyn), Operand.soa(sf, st, N), Operand.soa(sJ, st, N), knots=N, stream=stream)
             transpose_nodes(sf, self.f, count, nx, (1, st), (nx, 1), stream=stream)
-            transpose_nodes(sJ, self.J, count, nx * n, (1, st), (nx * n, 1), stream=stream)
+            # [A|B] is transposed into node-major blocks for the Riccati recursion (0.31 ms per 81 920 nodes).  Reading it IN PLACE through the
+            # element stride (the recursion's LDS-DMA copies take 8-byte elements from any address; UNGAR_AMD_SQP_JACOBIAN_IN_PLACE=1, identical
+            # bits) was measured and is slower: every element of a knot then comes from its own cache line, shared only with the same
+            # instance's seven neighbouring knots, which the 512 concurrent instances evict before they are used -- QP step 6.29 ms against
+            # 4.70 ms through the transpose (profiles/r03f_jacobian_in_place_ab.log).
+            if self._transpose_jacobian:
+                transpose_nodes(sJ, self.J, count, nx * n, (1, st), (nx * n, 1), stream=stream)
         elif derivatives:
             self.dyn.dense_jacobian(count, xo, uo, wd, par(p_dyn, self.dyn), _node(self.f, nx, N), _node(self.J, nx * n, N), knots=N, stream=stream)
         if derivatives:
@@ -224,7 +232,12 @@ class BatchedSoftSqp:
                          _node(self.h, self.nh, N)._c() if self.nh else _NULL, _node(self.hJ, self.nh * n, N)._c() if self.nh else _NULL, self.barrier,
                          _node(self.b, nx, N)._c(), _node(self.W, n * n, N)._c(), _node(self.w, n, N)._c(), _inst(self.dx0, nx)._c())
         _check(self.lib.ungar_ocp_stage_qp(ctypes.byref(a), stream))
-        q = _Qp(nx, nu, N, B, _node(self.J, nx * n, N)._c(), _node(self.b, nx, N)._c(), _node(self.W, n * n, N)._c(), _node(self.w, n, N)._c(), _NULL, _NULL,
+        if self._wide is not None and not self._transpose_jacobian:
+            sJ = self._wide[3]
+            jac = Operand(sJ, instance_stride=N, knot_stride=1, element_stride=sJ.stride(0))  # node (b, k) = column b N + k of the unit-fastest scratch
+        else:
+            jac = _node(self.J, nx * n, N)
+        q = _Qp(nx, nu, N, B, jac._c(), _node(self.b, nx, N)._c(), _node(self.W, n * n, N)._c(), _node(self.w, n, N)._c(), _NULL, _NULL,
                 _inst(self.dx0, nx)._c(), _node(self.dX, nx, N + 1)._c(), _node(self.dU, nu, N)._c(), self.workspace.data_ptr(), self.workspace.numel(),
                 self.regularization, self.status.data_ptr())
         _check(self.lib.ungar_ocp_riccati_solve(ctypes.byref(q), stream))
