@@ -8,6 +8,10 @@
 #include <cstdlib>
 #include <string>
 
+#ifndef UNGAR_RICCATI_MFMA_MIN_NX_ONE_WAVE
+#define UNGAR_RICCATI_MFMA_MIN_NX_ONE_WAVE 6
+#endif
+
 #include "ocp_sqp.hpp"
 #include "ocp_barrier.hpp"
 
@@ -116,10 +120,13 @@ struct DeviceExec {
     // ---- the two large products of a knot on the FP64 matrix cores (four-wavefront kernels) ------------------------------------
     // v_mfma_f64_16x16x4_f64: A[i][k] in lane 16 k + i, B[k][j] in lane 16 k + j, D[(lane >> 4) + 4 r][lane & 15] in element r.
 #ifndef UNGAR_RICCATI_NO_MFMA
-    static constexpr bool kMatrixCores = BLOCK == 256 && DMA;
+    static constexpr bool kMatrixCores = (BLOCK == 256 && DMA) || BLOCK == 64;
 #else
     static constexpr bool kMatrixCores = false;
 #endif
+    // state dimension from which the two large products run on the matrix cores: the one-wavefront kernels share a SIMD with two or three
+    // other instances and are bound by VALU / LDS issue there, so even a single padded 16 x 16 tile pays (the matrix pipe runs beside the VALU)
+    static constexpr int kMatrixCoresMinNx = BLOCK == 64 ? UNGAR_RICCATI_MFMA_MIN_NX_ONE_WAVE : UNGAR_RICCATI_MFMA_MIN_NX;
     using f64x4 = __attribute__((__vector_size__(4 * sizeof(double)))) double;
     /// PAB = P [A|B] (NX x n) and t = P b + p.  P is symmetric (bitwise: it is written symmetrised), so A[i][k] = P[k][i] is read along rows.
     /// Wavefront w owns the tile columns w, w + 4, ...; padded rows / columns / k-steps contribute zeros.
@@ -220,23 +227,30 @@ struct DeviceExec {
 #ifdef UNGAR_RICCATI_CLOCKS
         Mark(6);  // (diagnostic builds: the matrix-instruction loop of the H phase under "-", its epilogue and barrier under "H")
 #endif
+        // epilogue, tile by tile: the four stage-Hessian / gradient words of the lane's entries are loaded first (clamped addresses, no branches),
+        // then added and stored under the lane's conditions -- one LDS round trip per tile instead of one per entry
+        const double* Wsrc = Wfold ? Wfold : H;
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
             if (!live[c]) continue;  // uniform over the wavefront
-            const int col = 16 * tj[c] + li;
+            const int col = 16 * tj[c] + li, cc = col < n ? col : n - 1;
+            double base[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * ti[c] + lk + 4 * r, rc = row < n ? row : n - 1;
+                const int lo = rc < cc ? rc : cc, hi = rc < cc ? cc : rc;
+                const int at = Wfold ? RiccatiFoldedIndex(n, lo, hi) : lo * n + hi;
+                base[r] = col == n ? wv[rc] : Wsrc[at];
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 16 * ti[c] + lk + 4 * r;
-                if (row >= n) continue;
-                if (col < n) {
-                    if (row <= col) {
-                        const double w = Wfold ? Wfold[RiccatiFoldedIndex(n, row, col)] : H[row * n + col];
-                        const double e = w + (row == col ? reg : 0.0) + acc[c][r];
-                        H[row * n + col] = e;
-                        H[col * n + row] = e;
-                    }
-                } else if (col == n) {
-                    h[row] = wv[row] + acc[c][r];
+                const double e = base[r] + acc[c][r] + ((row == col) ? reg : 0.0);
+                if (row < n && col < n && row <= col) {
+                    H[row * n + col] = e;
+                    H[col * n + row] = e;
+                } else if (row < n && col == n) {
+                    h[row] = e;
                 }
             }
         }

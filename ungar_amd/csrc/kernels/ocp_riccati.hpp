@@ -136,6 +136,17 @@ constexpr bool RiccatiExecHasMatrixCores() {
     else return false;
 }
 
+/// State dimension from which the policy runs the two large products on the matrix cores (0: never).
+template <class Exec>
+constexpr int RiccatiMatrixCoresFrom() {
+    if constexpr (RiccatiExecHasMatrixCores<Exec>()) {
+        if constexpr (requires { Exec::kMatrixCoresMinNx; }) return Exec::kMatrixCoresMinNx;
+        else return UNGAR_RICCATI_MFMA_MIN_NX;
+    } else {
+        return 0;
+    }
+}
+
 template <class Exec>
 constexpr bool RiccatiExecHasSelfDma() {
     if constexpr (requires { Exec::kDmaSelf; }) return Exec::kDmaSelf;
@@ -315,7 +326,7 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
             ex.Barrier();
         }
         RiccatiMark(ex, 1);  // operands of the knot
-        if constexpr (RiccatiExecHasMatrixCores<Exec>() && NX >= UNGAR_RICCATI_MFMA_MIN_NX) {
+        if constexpr (RiccatiMatrixCoresFrom<Exec>() > 0 && NX >= RiccatiMatrixCoresFrom<Exec>()) {
             // The two large products on the FP64 matrix cores (policies that have them: the four-wavefront device kernels).  What this
             // buys is not arithmetic rate -- v_mfma_f64_16x16x4_f64 and v_fma_f64 peak alike on gfx950 -- but operand traffic: a wavefront
             // reads two LDS words per lane for 1024 multiply-adds instead of (TI + TC) per TI x TC (these phases were bound by LDS issue,
