@@ -257,6 +257,59 @@ struct DeviceExec {
         LdsBarrier();
     }
 
+    /// Cost-to-go update P' = H_xx + H_ux^T K (symmetrised), p' = h_x + H_ux^T kff with K = [K | kff] (NU x (NX + 1)):  for every upper
+    /// tile both T = H_ux^T K and its mirror image K^T H_ux are accumulated (the same lane holds T[i][j] and T[j][i]), so that the entry and
+    /// its transpose get the same bits.
+    template <int NX, int NU>
+    __device__ __forceinline__ void ProductCostToGo(const double* H, const double* h, const double* K, double* Pn, double* pn) {
+        constexpr int n = NX + NU, nk = NX + 1, TT = (nk + 15) / 16, tiles = TT * (TT + 1) / 2, CH = (tiles + kWaves - 1) / kWaves, KS = (NU + 3) / 4;
+        const int lane = static_cast<int>(threadIdx.x) & 63, li = lane & 15, lk = lane >> 4;
+        const int first = Wave() * CH;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            int idx = first + c, tj = 0;  // column-major upper triangle: tile idx -> (ti, tj), ti <= tj
+            if (idx >= tiles) break;      // uniform over the wavefront
+            while (idx > tj) {
+                idx -= tj + 1;
+                ++tj;
+            }
+            const int ti = idx, row = 16 * ti + li, col = 16 * tj + li;
+            const int rowC = row < NX ? row : NX - 1, colC = col < nk ? col : nk - 1, colX = col < NX ? col : NX - 1;
+            f64x4 t1 = f64x4{0.0, 0.0, 0.0, 0.0}, t2 = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int m = 4 * ks + lk;
+                const bool mOk = m < NU;
+                const int mc = mOk ? m : NU - 1;
+                const double* Hrow = H + (NX + mc) * n;  // row m of H_ux
+                const double* Krow = K + mc * nk;
+                const double a1raw = Hrow[rowC], b1raw = Krow[colC], a2raw = Krow[rowC], b2raw = Hrow[colX];
+                const double a1 = (mOk && row < NX) ? a1raw : 0.0, b1 = (mOk && col < nk) ? b1raw : 0.0;
+                const double a2 = (mOk && row < NX) ? a2raw : 0.0, b2 = (mOk && col < NX) ? b2raw : 0.0;
+                t1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, t1, 0, 0, 0);
+                t2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, t2, 0, 0, 0);
+            }
+            double base[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rw = 16 * ti + lk + 4 * r, rc = rw < NX ? rw : NX - 1;
+                base[r] = col == NX ? h[rc] : H[rc * n + colX];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rw = 16 * ti + lk + 4 * r;
+                if (rw < NX && col < NX && rw <= col) {
+                    const double v = base[r] + 0.5 * (t1[r] + t2[r]);
+                    Pn[rw * NX + col] = v;
+                    Pn[col * NX + rw] = v;
+                } else if (rw < NX && col == NX) {
+                    pn[rw] = base[r] + t1[r];
+                }
+            }
+        }
+        LdsBarrier();
+    }
+
 #ifdef UNGAR_RICCATI_CLOCKS
     /// Diagnostic build: cycles of the first workgroup's first lane between consecutive marks, summed per mark id
     /// (read back with ungar_amd_debug_riccati_clocks; tools/bench_riccati_phases.py).

@@ -686,7 +686,10 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
             for (int m = nu; m < nuE; ++m) sv += Eq[(m - nu) * ldq + i] * K[m * nk + nx];
             pn[i] = sv;
         };
-        if constexpr (NX > 0) {
+        if constexpr (RiccatiMatrixCoresFrom<Exec>() > 0 && NX >= RiccatiMatrixCoresFrom<Exec>() && NE == 0 && Exec::kLanes > 64) {
+            // on the matrix cores as well (four-wavefront kernels; for the one-wavefront kernels the extra accumulators cost more than the phase saves: measured): T = H_ux^T [K | kff] and its transpose tile by tile, P = H_xx + (T + T^T) / 2, p = h_x + T[:, nx]
+            ex.template ProductCostToGo<NX, NU>(H, h, K, Pn, pn);
+        } else if constexpr (NX > 0) {
             // compile-time size: one item per PAIR i <= j (each entry computes both orientations anyway), found through the folded
             // rectangle with one division -- half the items of the per-entry loop below
             constexpr int pairs = ((NX + 1) / 2) * (NX + 1);
