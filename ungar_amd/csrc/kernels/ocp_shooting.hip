@@ -32,23 +32,23 @@ __global__ __launch_bounds__(256) void ShootingAssembleKernel(const ShootingAsse
     const int wave = lane >> 6, wl = lane & 63, waves = lanes >> 6;
     const int nz = d.nz(), nd = d.nd(), nc = d.nc, nx = d.nx;
     const bool stage = k < d.N;  // knot N: terminal cost only
+    const float ndInv = 1.0f / static_cast<float>(nd);  // row of a flat index through a float reciprocal: exact for nd <= 256 (idx + 0.5 is never a multiple of nd)
     double* Wd = lds;                 // nd x nd
     double* gd = Wd + nd * nd;        // nd
     double* Jh = gd + nd;             // nh x nd
     double* d1 = Jh + a.nh * nd;      // nh
     double* d2 = d1 + a.nh;           // nh
     double* ABd = d2 + a.nh;          // nz x nd
-    double* Ed = ABd + nz * nd;       // ne x nd
-    double* bd = Ed + a.ne * nd;      // nz
-    double* ed = bd + nz;             // ne
-    double* prow = ed + a.ne;         // nd + 1: pivot row of the elimination / column of W being eliminated
-    double* fcol = prow + nd + 1;     // max(ne, nz): column factors
-    double* vbuf = fcol + (a.ne > nz ? a.ne : nz);  // 2 + ne x nd: pivot-search keys, then W_BB G of the elimination
-    int* pivCol = reinterpret_cast<int*>(vbuf + 2 + a.ne * nd);  // ne pivot inputs
+    const int ld = nd + 1;            // equality tableau [C | D | e]: row stride
+    double* Ed = ABd + nz * nd;       // ne x (nd + 1)
+    double* bd = Ed + a.ne * ld;      // nz
+    double* prow = bd + nz;           // nd + 1: w + W s of the substitution
+    double* vbuf = prow + nd + 1;     // 6 + ne x (nd + 1): pivot-search keys, the second tableau of the elimination, then W_BB G
+    int* pivCol = reinterpret_cast<int*>(vbuf + 6 + a.ne * ld);  // ne pivot inputs
     int* used = pivCol + a.ne;        // nu flags
     int* list = used + d.nu;          // max(nd, ne) indices of a support
     int* listSize = list + (nd > a.ne ? nd : a.ne);
-    const int total = nd * nd + nd + a.nh * nd + 2 * a.nh + nz * nd + a.ne * nd;
+    const int total = nd * nd + nd + a.nh * nd + 2 * a.nh + nz * nd + a.ne * ld;
     for (int i = lane; i < total; i += lanes) lds[i] = 0.0;
     __syncthreads();
     const long long nodeOff = b * (d.N + 1) + k;
@@ -68,11 +68,10 @@ __global__ __launch_bounds__(256) void ShootingAssembleKernel(const ShootingAsse
         } else {
             for (int e = lane; e < a.pc.nnz; e += lanes) ABd[a.pc.rows[e] * nd + nc + a.pc.cols[e]] = a.cJ[nodeOff * a.pc.nnz + e];
         }
-        for (int e = lane; e < a.pe.nnz; e += lanes) Ed[a.pe.rows[e] * nd + a.pe.cols[e]] = a.eJ[nodeOff * a.pe.nnz + e];
+        for (int e = lane; e < a.pe.nnz; e += lanes) Ed[a.pe.rows[e] * ld + a.pe.cols[e]] = a.eJ[nodeOff * a.pe.nnz + e];
     }
     __syncthreads();
     // W (barrier terms and regularisation added; kept in LDS, both triangles), w
-    const float ndInv = 1.0f / static_cast<float>(nd);  // row of a flat index through a float reciprocal: exact for nd <= 256 (idx + 0.5 is never a multiple of nd)
     for (int idx = lane; idx < nd * nd; idx += lanes) {
         const int r = static_cast<int>((static_cast<float>(idx) + 0.5f) * ndInv), c = idx - r * nd;
         if (r > c) continue;
@@ -93,7 +92,7 @@ __global__ __launch_bounds__(256) void ShootingAssembleKernel(const ShootingAsse
     if (stage) {
         const double* next = RowOf(a.rows, d, b, k + 1);
         for (int i = lane; i < nz; i += lanes) bd[i] = i < nc ? 0.0 : a.f[nodeOff * nx + (i - nc)] - next[i];
-        for (int j = lane; j < a.ne; j += lanes) ed[j] = a.e ? a.e[nodeOff * a.ne + j] : 0.0;
+        for (int j = lane; j < a.ne; j += lanes) Ed[j * ld + nd] = a.e ? a.e[nodeOff * a.ne + j] : 0.0;
     }
     __syncthreads();
     if (stage && a.eliminate && a.ne > 0) {
@@ -111,106 +110,123 @@ __global__ __launch_bounds__(256) void ShootingAssembleKernel(const ShootingAsse
                 if (wl == 0) *listSize = size;
             }
         };
-        // ---- Gauss-Jordan on [C | D | e] (Ed, ed): one pivot input per active row.  The pivot of a row is its largest unused input
+        // ---- Gauss-Jordan on the tableau [C | D | e]: one pivot input per active row.  The pivot of a row is its largest unused input
         // coefficient, found with ONE LDS atomic per lane: for non-negative doubles the bit pattern orders like the value, so
         // max(bits(|v|) with the low byte replaced by 255 - input) is the largest coefficient up to 2^-44 relative, ties to the lowest input.
-        unsigned long long* keys = reinterpret_cast<unsigned long long*>(vbuf);  // [0]: pivot key, [1]: bits of the row's largest |entry|
+        // Step i reads one tableau and writes the other (no read-after-write inside a step) and, while writing row i + 1, already
+        // collects that row's keys: ONE barrier per step.  Three key sets rotate so that a set is cleared a full step before its reuse.
+        unsigned long long* keys = reinterpret_cast<unsigned long long*>(vbuf);  // set s: [2 s] pivot key, [2 s + 1] bits of the row's largest |entry|
+        double* T[2] = {Ed, vbuf + 6};
+        const float ldInv = 1.0f / static_cast<float>(ld);
+        auto offer = [&](int set, int c, double value, int excluded) {  // entry c of the row whose keys are collected into `set`
+            const unsigned long long bits = static_cast<unsigned long long>(__double_as_longlong(fabs(value)));
+            if (!bits) return;
+            atomicMax(&keys[2 * set + 1], bits);
+            if (c >= nz && c < nd && c - nz != excluded && !used[c - nz]) atomicMax(&keys[2 * set], (bits & ~0xFFull) | static_cast<unsigned long long>(255 - (c - nz)));
+        };
         for (int j = lane; j < d.nu; j += lanes) used[j] = 0;
-        if (lane < 2) keys[lane] = 0ull;
+        if (lane < 6) keys[lane] = 0ull;
         __syncthreads();
+        for (int c = lane; c < ld; c += lanes) offer(0, c, Ed[c], -1);
+        __syncthreads();
+        int cur = 0;
         for (int i = 0; i < a.ne; ++i) {
-            for (int c = lane; c <= nd; c += lanes) {
-                const double v = fabs(c < nd ? Ed[i * nd + c] : ed[i]);
-                const unsigned long long bits = static_cast<unsigned long long>(__double_as_longlong(v));
-                if (bits) atomicMax(&keys[1], bits);
-                if (c >= nz && c < nd && bits && !used[c - nz]) atomicMax(&keys[0], (bits & ~0xFFull) | static_cast<unsigned long long>(255 - (c - nz)));
-            }
-            __syncthreads();
-            const unsigned long long key = keys[0];
-            const double best = __longlong_as_double(static_cast<long long>(key & ~0xFFull)), rowMax = __longlong_as_double(static_cast<long long>(keys[1]));
+            const double* src = T[cur];
+            const int set = i % 3, nextSet = (i + 1) % 3;
+            const unsigned long long key = keys[2 * set];
+            const double best = __longlong_as_double(static_cast<long long>(key & ~0xFFull)), rowMax = __longlong_as_double(static_cast<long long>(keys[2 * set + 1]));
             // no usable input coefficient: an identically-zero (or redundant) row takes no pivot; anything else cannot be met by this knot's inputs
             int j = key ? 255 - static_cast<int>(key & 0xFFull) : -1;
             if (j >= 0 && best <= 1e-12 * rowMax) j = -2;
             if (j == -1 && rowMax > 0.0) j = -2;
-            if (j >= 0) {
-                const double rpiv = 1.0 / Ed[i * nd + nz + j];
-                for (int c = lane; c <= nd; c += lanes) prow[c] = c == nz + j ? 1.0 : (c < nd ? Ed[i * nd + c] : ed[i]) * rpiv;  // (the pivot exactly 1)
-                for (int r = lane; r < a.ne; r += lanes) fcol[r] = r == i ? 0.0 : Ed[r * nd + nz + j];
-                buildList(a.ne, [&](int r) { return r != i && Ed[r * nd + nz + j] != 0.0; });  // the rows that hold this input: few (one leg's)
-            }
-            __syncthreads();
             if (lane == 0) {
                 pivCol[i] = j;
-                if (j >= 0) used[j] = 1;
-                keys[0] = 0ull;
-                keys[1] = 0ull;
+                if (j >= 0) used[j] = 1;  // (readers of this step exclude j themselves; later steps see the flag behind the barrier)
+                keys[2 * ((i + 2) % 3)] = 0ull;
+                keys[2 * ((i + 2) % 3) + 1] = 0ull;
             }
             if (j >= 0) {
-                const int rowsHit = *listSize;
-                for (int t = wave; t < rowsHit; t += waves) {
-                    const int r = list[t];
-                    const double f = fcol[r];
-                    for (int c = wl; c <= nd; c += 64) {
-                        double* at = c < nd ? &Ed[r * nd + c] : &ed[r];
-                        *at -= f * prow[c];
-                    }
+                double* dst = T[cur ^ 1];
+                const int J = nz + j;
+                const double rpiv = 1.0 / src[i * ld + J];
+                for (int idx = lane; idx < a.ne * ld; idx += lanes) {
+                    const int r = static_cast<int>((static_cast<float>(idx) + 0.5f) * ldInv), c = idx - r * ld;
+                    const double p = c == J ? 1.0 : src[i * ld + c] * rpiv;  // (the pivot exactly 1, its column exactly 0 elsewhere)
+                    const double v = r == i ? p : (c == J ? 0.0 : src[idx] - src[r * ld + J] * p);
+                    dst[idx] = v;
+                    if (r == i + 1) offer(nextSet, c, v, j);
                 }
-                for (int c = lane; c <= nd; c += lanes) *(c < nd ? &Ed[i * nd + c] : &ed[i]) = prow[c];
+                cur ^= 1;
+            } else if (i + 1 < a.ne) {
+                for (int c = lane; c < ld; c += lanes) offer(nextSet, c, src[(i + 1) * ld + c], -1);
             }
             __syncthreads();
         }
+        if (cur) {  // the reduced rows back where the substitution and the output expect them
+            for (int idx = lane; idx < a.ne * ld; idx += lanes) Ed[idx] = T[1][idx];
+            __syncthreads();
+        }
+        double* V = vbuf + 6;  // pivots x nd (the second tableau is dead)
         // ---- substitute u_j = -(G_i . [z; u] + g0_i) for ALL pivot rows at once (the reduced rows have zeros in each other's pivot columns):
         //   W'[a][c] = W[a][c] - sum_i (W[a][J_i] G_i[c] + G_i[a] W[J_i][c]) + sum_i G_i[a] V_i[c],   V_i[c] = sum_i' W[J_i][J_i'] G_i'[c]
         // for a, c outside the pivot set (in place: only pivot rows / columns are read besides the entry itself); likewise w, [A|B], b.
         buildList(a.ne, [&](int r) { return pivCol[r] >= 0; });
         __syncthreads();
         const int pivots = a.eliminate == 2 ? 0 : *listSize;  // (2: measurement only -- rows reduced, substitution skipped)
-        for (int t = wave; t < pivots; t += waves) {
+        for (int idx = lane; idx < pivots * nd; idx += lanes) {
+            const int t = static_cast<int>((static_cast<float>(idx) + 0.5f) * ndInv), c = idx - t * nd;
             const int J = nz + pivCol[list[t]];
-            for (int c = wl; c < nd; c += 64) {
-                double acc = 0.0;
-                for (int t2 = 0; t2 < pivots; ++t2) acc += Wd[J * nd + nz + pivCol[list[t2]]] * Ed[list[t2] * nd + c];
-                vbuf[2 + t * nd + c] = acc;
-            }
+            double acc = 0.0;
+            for (int t2 = 0; t2 < pivots; ++t2) acc += Wd[J * nd + nz + pivCol[list[t2]]] * Ed[list[t2] * ld + c];
+            V[idx] = acc;
         }
         for (int c = lane; c < nd; c += lanes) {  // w + W s,  s = -sum_i e_(J_i) g0_i
             double acc = gd[c];
-            for (int t = 0; t < pivots; ++t) acc -= Wd[c * nd + nz + pivCol[list[t]]] * ed[list[t]];
+            for (int t = 0; t < pivots; ++t) acc -= Wd[c * nd + nz + pivCol[list[t]]] * Ed[list[t] * ld + nd];
             prow[c] = acc;
         }
         for (int r = lane; r < nz; r += lanes) {
             double acc = bd[r];
-            for (int t = 0; t < pivots; ++t) acc -= ABd[r * nd + nz + pivCol[list[t]]] * ed[list[t]];
+            for (int t = 0; t < pivots; ++t) acc -= ABd[r * nd + nz + pivCol[list[t]]] * Ed[list[t] * ld + nd];
             bd[r] = acc;
         }
         __syncthreads();
         auto isPivot = [&](int c) { return c >= nz && used[c - nz] != 0; };
-        for (int r = wave; r < nd; r += waves) {
-            if (isPivot(r)) continue;
-            for (int c = r + wl; c < nd; c += 64) {
-                if (isPivot(c)) continue;
-                double acc = Wd[r * nd + c];
-                for (int t = 0; t < pivots; ++t) {
-                    const int i = list[t], J = nz + pivCol[i];
-                    const double gr = Ed[i * nd + r], gc = Ed[i * nd + c];
-                    acc += gr * (vbuf[2 + t * nd + c] - Wd[J * nd + c]) - Wd[r * nd + J] * gc;
-                }
-                Wd[r * nd + c] = acc;
-                Wd[c * nd + r] = acc;
+        // upper triangle r <= c through the folded rectangle ((nd + 1) / 2 rows of nd + 1: row q of the triangle followed by row nd - 1 - q)
+        const int foldRows = (nd + 1) / 2;
+        for (int idx = lane; idx < foldRows * ld; idx += lanes) {
+            const int q = static_cast<int>((static_cast<float>(idx) + 0.5f) * ldInv), jj = idx - q * ld;
+            int r, c;
+            if (jj < nd - q) {
+                r = q;
+                c = q + jj;
+            } else {
+                r = nd - 1 - q;
+                if (r == q) continue;  // unused tail of the middle row (nd odd)
+                c = r + (jj - (nd - q));
             }
+            if (isPivot(r) || isPivot(c)) continue;
+            double acc = Wd[r * nd + c];
+            for (int t = 0; t < pivots; ++t) {
+                const int i = list[t], J = nz + pivCol[i];
+                const double gr = Ed[i * ld + r], gc = Ed[i * ld + c];
+                acc += gr * (V[t * nd + c] - Wd[J * nd + c]) - Wd[r * nd + J] * gc;
+            }
+            Wd[r * nd + c] = acc;
+            Wd[c * nd + r] = acc;
         }
         for (int c = lane; c < nd; c += lanes) {
             double acc = prow[c];
-            for (int t = 0; t < pivots; ++t) acc -= Ed[list[t] * nd + c] * prow[nz + pivCol[list[t]]];
+            for (int t = 0; t < pivots; ++t) acc -= Ed[list[t] * ld + c] * prow[nz + pivCol[list[t]]];
             gd[c] = isPivot(c) ? 0.0 : acc;
         }
-        for (int r = wave; r < nz; r += waves)
-            for (int c = wl; c < nd; c += 64) {
-                if (isPivot(c)) continue;
-                double acc = ABd[r * nd + c];
-                for (int t = 0; t < pivots; ++t) acc -= ABd[r * nd + nz + pivCol[list[t]]] * Ed[list[t] * nd + c];
-                ABd[r * nd + c] = acc;
-            }
+        for (int idx = lane; idx < nz * nd; idx += lanes) {
+            const int r = static_cast<int>((static_cast<float>(idx) + 0.5f) * ndInv), c = idx - r * nd;
+            if (isPivot(c)) continue;
+            double acc = ABd[idx];
+            for (int t = 0; t < pivots; ++t) acc -= ABd[r * nd + nz + pivCol[list[t]]] * Ed[list[t] * ld + c];
+            ABd[idx] = acc;
+        }
         __syncthreads();  // every read of a pivot row / column is done: they become the dummies' identity rows
         for (int t = wave; t < pivots; t += waves) {
             const int J = nz + pivCol[list[t]];
@@ -223,7 +239,7 @@ __global__ __launch_bounds__(256) void ShootingAssembleKernel(const ShootingAsse
         __syncthreads();
         for (int i = lane; i < a.ne; i += lanes) {
             a.pivots[stageOff * a.ne + i] = pivCol[i];
-            a.er[stageOff * a.ne + i] = ed[i];
+            a.er[stageOff * a.ne + i] = Ed[i * ld + nd];
         }
     }
     double* W = a.W + nodeOff * nd * nd;
@@ -240,7 +256,10 @@ __global__ __launch_bounds__(256) void ShootingAssembleKernel(const ShootingAsse
         for (int i = lane; i < nz; i += lanes) bo[i] = bd[i];
         if (a.ne > 0) {
             double* E = a.E + stageOff * a.ne * nd;
-            for (int idx = lane; idx < a.ne * nd; idx += lanes) E[idx] = Ed[idx];
+            for (int idx = lane; idx < a.ne * nd; idx += lanes) {
+                const int r = static_cast<int>((static_cast<float>(idx) + 0.5f) * ndInv);
+                E[idx] = Ed[r * ld + (idx - r * nd)];
+            }
         }
         if (k == 0) {
             const double* row0 = RowOf(a.rows, d, b, 0);
@@ -392,7 +411,7 @@ extern "C" int ungar_amd_launch_shooting_assemble(const ShootingAssembleArgs* a,
     if (a->d.batch <= 0) return 0;
     const std::size_t nd = static_cast<std::size_t>(a->d.nd()), nz = static_cast<std::size_t>(a->d.nz());
     const std::size_t ne = static_cast<std::size_t>(a->ne), nu = static_cast<std::size_t>(a->d.nu);
-    const std::size_t lds = (nd * nd + nd + static_cast<std::size_t>(a->nh) * nd + 2 * static_cast<std::size_t>(a->nh) + nz * nd + ne * nd + nz + ne + (nd + 1) + (ne > nz ? ne : nz) + 2 + ne * nd) * sizeof(double) +
+    const std::size_t lds = (nd * nd + nd + static_cast<std::size_t>(a->nh) * nd + 2 * static_cast<std::size_t>(a->nh) + nz * nd + 2 * ne * (nd + 1) + nz + (nd + 1) + 6) * sizeof(double) +
                             (ne + nu + (nd > ne ? nd : ne) + 2) * sizeof(int) + 16;
     if (lds > 160 * 1024) return static_cast<int>(hipErrorInvalidValue);
     if (lds > 64 * 1024) {
