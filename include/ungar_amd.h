@@ -402,11 +402,17 @@ int ungar_shooting_trial_rows(const ungar_shooting_dims* dims, const double* row
  * SoftSQPOptimizer::Optimize (soft_sqp.hpp:88-99) per instance: the first acceptable candidate's [c|x|u] is copied into `rows`, accepted[b] = its
  * step size (0: none); active[b] (may be null) is cleared when no step is acceptable or the objective decreased by less than 1e-6, and instances
  * that are not active are left untouched.  status (may be null): the Riccati solve's per-instance report; an instance whose QP was not solved
- * (non-zero) takes no step and stops -- the reference asserts on a failed QP (soft_sqp.hpp:223-230). */
+ * (non-zero) takes no step and stops -- the reference asserts on a failed QP (soft_sqp.hpp:223-230).
+ * stage: 0 = the whole search in one call.  The candidates may also be offered in several calls, largest steps first (the order of
+ * backtracking_line_search.hpp:116-151 is kept: an instance takes the first acceptable candidate over all calls): UNGAR_SEARCH_NOT_LAST on every call but
+ * the last (an instance without an acceptable candidate is then left for the next call and counted in *unresolved, a device counter the caller
+ * zeroes), UNGAR_SEARCH_NOT_FIRST on every call but the first (instances that took a step in an earlier call are skipped). */
+#define UNGAR_SEARCH_NOT_FIRST 1
+#define UNGAR_SEARCH_NOT_LAST 2
 int ungar_shooting_select(const ungar_shooting_dims* dims, const ungar_line_search_parameters* parameters, const double* alphas, int64_t candidates,
                           const double* theta0, const double* phi0, const double* objective0, const double* slope, const double* theta_trial,
                           const double* phi_trial, const double* objective_trial, double* accepted, int32_t* active, const int32_t* status, double* rows, const double* trial,
-                          void* stream);
+                          int32_t stage, int32_t* unresolved, void* stream);
 
 /* ---- device memory for host code that is not compiled with hipcc (the C++20 facade) ------------------------------------------------ */
 int ungar_device_malloc(void** out, int64_t bytes);

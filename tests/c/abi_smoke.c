@@ -45,7 +45,7 @@ int main(void) {
             bad += ungar_shooting_trial_rows(&dims, dummy, dummy, dummy, alphas, 17, dummy, 0) != UNGAR_E_INVALID;
             bad += ungar_shooting_trial_rows(&wrong, dummy, dummy, dummy, alphas, 14, dummy, 0) != UNGAR_E_INVALID;
             bad += ungar_shooting_assemble(&asm_args, 0) != UNGAR_E_INVALID; /* null operands */
-            bad += ungar_shooting_select(&dims, &ls, alphas, 14, 0, dummy, dummy, dummy, dummy, dummy, dummy, dummy, 0, 0, dummy, dummy, 0) != UNGAR_E_INVALID;
+            bad += ungar_shooting_select(&dims, &ls, alphas, 14, 0, dummy, dummy, dummy, dummy, dummy, dummy, dummy, 0, 0, dummy, dummy, 0, 0, 0) != UNGAR_E_INVALID;
             bad += ungar_device_malloc(&ptr, -1) != UNGAR_E_INVALID;
             bad += ungar_device_malloc(&ptr, 0) != UNGAR_OK || ptr != 0;
             bad += ungar_function_forward_zero_nodes(0, &op, &op, 4, 2, 0) != UNGAR_E_INVALID;

@@ -7,6 +7,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <random>
 #include <string>
 #include <vector>
@@ -192,6 +193,7 @@ int main(int argc, char** argv) {
             return 1;
         }
         BatchedSoftSQPOptimizer batched{std::move(problem), batch, false, 1.0, 2};
+        if (const char* stage = std::getenv("UNGAR_TEST_FIRST_STAGE")) batched.SetFirstLineSearchStage(std::atol(stage));  // staged line search: same iterates
 
         // ---- perturbed instances: one whole-horizon variable vector each (parameter values of quadrotor.example.cpp:326-358)
         std::mt19937_64 rng{20260929};

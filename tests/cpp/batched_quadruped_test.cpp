@@ -249,6 +249,7 @@ int main(int argc, char** argv) {
         }
         const real_t dt = 1.0 / static_cast<real_t>(N);
         BatchedSoftSQPOptimizer batched{std::move(problem), batch, false, dt, 2, 1.0, 1.0};  // the example's optimizer settings (:444)
+        if (const char* stage = std::getenv("UNGAR_TEST_FIRST_STAGE")) batched.SetFirstLineSearchStage(std::atol(stage));  // staged line search: same iterates
         if (const char* inside = std::getenv("UNGAR_TEST_EQUALITY_ROWS_IN_RECURSION")) batched.EliminateEqualityRowsBeforeTheRecursion(inside[0] != '1');
 
         // ---- instances: parameter values of quadruped.example.cpp:378-430, a random gait and a perturbed initial guess each

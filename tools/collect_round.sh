@@ -37,3 +37,8 @@ cp_if gpurun_out/layouts_all.log              profiles/${tag}_layouts_all.log
 cp_if gpurun_out/sqp_anymal.json              profiles/${tag}_sqp_anymal_timing.json
 cp_if gpurun_out/sqp_bench.log                profiles/${tag}_sqp_quadrotor_timing.json
 cp_if gpurun_out/sqp_srbd.json                profiles/${tag}_sqp_srbd_timing.json
+cp_if gpurun_out/riccati_sizes.log            profiles/${tag}_riccati_sizes.log
+cp_if gpurun_out/riccati_sizes_clocks.log     profiles/${tag}_riccati_phase_clocks.log
+cp_if gpurun_out/batched_quadrotor_kernel_stats.csv profiles/${tag}_batched_quadrotor_kernel_stats.csv
+cp_if gpurun_out/batched_quadruped_kernel_stats.csv profiles/${tag}_batched_quadruped_kernel_stats.csv
+cat gpurun_out/batched_quadrotor_timing.log gpurun_out/batched_quadruped_timing.log 2>/dev/null | grep timing > profiles/${tag}_batched_sqp_timing.log || true

@@ -43,6 +43,10 @@ echo "== batched SQP"
 bash tools/gpu_sqp_profile.sh 2>&1 | tail -12
 timeout 300 python tools/bench_sqp_anymal.py 2>/dev/null | tail -1 | tee gpurun_out/sqp_anymal.json | cut -c1-400
 timeout 300 python tools/bench_sqp_srbd.py 2>/dev/null | tail -1 | tee gpurun_out/sqp_srbd.json | cut -c1-400
+echo "== Riccati solve alone (all block sizes) and the C++ batched SQP on the reference's OCPs as written"
+timeout 300 python tools/bench_riccati_sizes.py 4096 2>/dev/null | grep nx | tee gpurun_out/riccati_sizes.log | cut -c1-120
+[ -f build/variants/lib_riccati_clocks.so ] && UNGAR_AMD_LIBRARY=$PWD/build/variants/lib_riccati_clocks.so timeout 300 python tools/bench_riccati_sizes.py 4096 2>/dev/null | grep nx > gpurun_out/riccati_sizes_clocks.log
+bash tools/gpu_batched_sqp_profile.sh 4096 2>&1 | tail -30
 echo "== rocprofv3 kernel trace + HBM counters (separate passes)"
 rm -rf gpurun_out/prof gpurun_out/pmc1 gpurun_out/pmc2
 B="python bench.py --no-cpu-baseline --no-sub-results"

@@ -374,9 +374,10 @@ __global__ __launch_bounds__(kBlock) void ShootingSelectKernel(const ShootingSel
     const long long b = blockIdx.x;
     if (b >= d.batch) return;
     if (a.active && a.active[b] == 0) {  // uniform over the workgroup
-        if (threadIdx.x == 0) a.accepted[b] = 0.0;
+        if (threadIdx.x == 0 && a.first) a.accepted[b] = 0.0;
         return;
     }
+    if (!a.first && a.accepted[b] != 0.0) return;  // took its step in an earlier stage of this search
     const double theta = a.theta0[b], phi = a.phi0[b], slope = a.slope[b];
     int chosen = -1;
     const bool solved = !a.status || a.status[b] == 0;
@@ -385,7 +386,11 @@ __global__ __launch_bounds__(kBlock) void ShootingSelectKernel(const ShootingSel
     if (chosen < 0) {
         if (threadIdx.x == 0) {
             a.accepted[b] = 0.0;
-            if (a.active) a.active[b] = 0;  // the reference's `break` on a rejected step (soft_sqp.hpp:88-90)
+            if (a.last || !solved) {
+                if (a.active) a.active[b] = 0;  // the reference's `break` on a rejected step (soft_sqp.hpp:88-90)
+            } else if (a.unresolved) {
+                atomicAdd(a.unresolved, 1);
+            }
         }
         return;
     }

@@ -115,6 +115,11 @@ struct ShootingSelectArgs {
     const double *theta0, *phi0, *objective0, *slope, *thetaT, *phiT, *objectiveT;
     double* accepted;
     int* active;
+    // Staged search: the candidates may be offered in several calls (the largest steps first, the rest only if some instance still needs
+    // them).  first: this call opens the search of the iteration; last: it closes it (an instance without an acceptable step stops iterating);
+    // a call that is not the last one counts the instances it leaves unresolved in *unresolved instead.
+    int first, last;
+    int* unresolved;
     const int* status;  // per instance, from the Riccati solve: non-zero = the QP was not solved (the reference asserts there, soft_sqp.hpp:223-230): no step, instance stops
     double* rows;
     const double* trial;

@@ -286,7 +286,8 @@ int ungar_shooting_trial_rows(const ungar_shooting_dims* dims, const double* row
 
 int ungar_shooting_select(const ungar_shooting_dims* dims, const ungar_line_search_parameters* p, const double* alphas, int64_t candidates, const double* theta0,
                           const double* phi0, const double* objective0, const double* slope, const double* theta_trial, const double* phi_trial,
-                          const double* objective_trial, double* accepted, int32_t* active, const int32_t* status, double* rows, const double* trial, void* stream) {
+                          const double* objective_trial, double* accepted, int32_t* active, const int32_t* status, double* rows, const double* trial, int32_t stage,
+                          int32_t* unresolved, void* stream) {
     ShootingSelectArgs k{};
     if (!dims || !ToDims(*dims, &k.d) || !p || !alphas || candidates < 1 || candidates > kMaxLineSearchCandidates)
         return Fail(UNGAR_E_INVALID, "ungar_shooting_select: bad argument (1 <= candidates <= 16)");
@@ -310,6 +311,9 @@ int ungar_shooting_select(const ungar_shooting_dims* dims, const ungar_line_sear
     k.accepted = accepted;
     k.active = active;
     k.status = status;
+    k.first = (stage & UNGAR_SEARCH_NOT_FIRST) ? 0 : 1;
+    k.last = (stage & UNGAR_SEARCH_NOT_LAST) ? 0 : 1;
+    k.unresolved = unresolved;
     k.rows = rows;
     k.trial = trial;
     return Launched(ungar_amd_launch_shooting_select(&k, stream), "ungar_shooting_select");

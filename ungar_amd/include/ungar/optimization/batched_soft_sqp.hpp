@@ -216,28 +216,41 @@ class BatchedSoftSQPOptimizer {
         m.slope = _slope;
         m.period = 0;
         Check(ungar_shooting_merit(&m, _stream));
-        Check(ungar_shooting_trial_rows(&_dims, _rows, _dZ, _dU, _alphas.data(), K, _trial, _stream));
-        if (_p.carry) CarryValues(_trial, K * B);
-        Evaluate(*_p.dynamics, 0, _trial, _p.StateOffset(), _fT, K * B * (N + 1));
-        Evaluate(*_p.cost, 0, _trial, 0, _lT, K * B * (N + 1));
-        if (_p.inequality) Evaluate(*_p.inequality, 0, _trial, 0, _hT, K * B * (N + 1));
-        if (_p.equality) Evaluate(*_p.equality, 0, _trial, 0, _eT, K * B * (N + 1));
-        ungar_shooting_merit_args t = m;
-        t.dims.batch = K * B;
-        t.rows = _trial;
-        t.f = _fT;
-        t.cost = _lT;
-        t.h = _hT;
-        t.eq = _eT;
-        t.cost_grad = nullptr;
-        t.slope = nullptr;
-        t.theta = _thetaT;
-        t.phi = _phiT;
-        t.objective = _objT;
-        t.period = B;
-        Check(ungar_shooting_merit(&t, _stream));
+        // candidate steps, largest first: all at once (no host decision inside the iteration), or in two stages -- the first few, and the rest only
+        // if some instance found none of them acceptable (one counter read back per iteration)
+        const index_t stageA = _firstStage > 0 && _firstStage < K ? _firstStage : K;
         const ungar_line_search_parameters ls{_ls.alphaMin, _ls.thetaMin, _ls.thetaMax, _ls.eta, _ls.gammaPhi, _ls.gammaTheta, _ls.gammaAlpha};
-        Check(ungar_shooting_select(&_dims, &ls, _alphas.data(), K, _theta0, _phi0, _obj0, _slope, _thetaT, _phiT, _objT, _accepted, _active, _status, _rows, _trial, _stream));
+        for (index_t begin = 0; begin < K;) {
+            const index_t count = begin == 0 ? stageA : K - begin;
+            const bool last = begin + count == K;
+            Check(ungar_shooting_trial_rows(&_dims, _rows, _dZ, _dU, _alphas.data() + begin, count, _trial, _stream));
+            if (_p.carry) CarryValues(_trial, count * B);
+            Evaluate(*_p.dynamics, 0, _trial, _p.StateOffset(), _fT, count * B * (N + 1));
+            Evaluate(*_p.cost, 0, _trial, 0, _lT, count * B * (N + 1));
+            if (_p.inequality) Evaluate(*_p.inequality, 0, _trial, 0, _hT, count * B * (N + 1));
+            if (_p.equality) Evaluate(*_p.equality, 0, _trial, 0, _eT, count * B * (N + 1));
+            ungar_shooting_merit_args t = m;
+            t.dims.batch = count * B;
+            t.rows = _trial;
+            t.f = _fT;
+            t.cost = _lT;
+            t.h = _hT;
+            t.eq = _eT;
+            t.cost_grad = nullptr;
+            t.slope = nullptr;
+            t.theta = _thetaT;
+            t.phi = _phiT;
+            t.objective = _objT;
+            t.period = B;
+            Check(ungar_shooting_merit(&t, _stream));
+            if (!last) Check(ungar_device_zero(_unresolved, static_cast<int64_t>(sizeof(int32_t)), _stream));
+            Check(ungar_shooting_select(&_dims, &ls, _alphas.data() + begin, count, _theta0, _phi0, _obj0, _slope, _thetaT, _phiT, _objT, _accepted, _active, _status, _rows, _trial,
+                                        (begin > 0 ? UNGAR_SEARCH_NOT_FIRST : 0) | (last ? 0 : UNGAR_SEARCH_NOT_LAST), _unresolved, _stream));
+            begin += count;
+            if (!last && Download<int32_t>(_unresolved, 1)[0] == 0) {  // everybody took one of the first steps (or had stopped): close the search
+                break;
+            }
+        }
         ++_iterations;
     }
 
@@ -289,6 +302,10 @@ class BatchedSoftSQPOptimizer {
         return q;
     }
     void SetStream(void* hipStream) { _stream = hipStream; }
+    /// Offer the first `candidates` step sizes (1, 1/2, ...) on their own and evaluate the remaining ones only if some instance accepted none of
+    /// them -- most iterations of a warm-started MPC take full or half steps, and every candidate costs a pass of the stage functions over all
+    /// nodes.  Costs one 4-byte read-back per iteration; 0 (default) evaluates all candidates at once, without any host decision.
+    void SetFirstLineSearchStage(const index_t candidates) { _firstStage = candidates; }
     /// Stage equality rows: eliminated node by node before the recursion (default; the sequential chain then carries no constraint
     /// block) or kept inside the Riccati recursion as the stage KKT block of every knot (false; same solution, for comparison).
     void EliminateEqualityRowsBeforeTheRecursion(const bool on) { _eliminateEqualities = on; }
@@ -385,6 +402,7 @@ class BatchedSoftSQPOptimizer {
         if (_workspaceDoubles < 0) throw std::invalid_argument("BatchedSoftSQPOptimizer: sizes not supported by the batched QP solver");
         _workspace = Device<real_t>(_workspaceDoubles);
         _status = Device<int32_t>(B);
+        _unresolved = Device<int32_t>(1);
         _active = Device<int32_t>(B);
         _theta0 = Device<real_t>(B);
         _phi0 = Device<real_t>(B);
@@ -448,6 +466,8 @@ class BatchedSoftSQPOptimizer {
     real_t* _er = nullptr;
     int32_t *_status = nullptr, *_active = nullptr, *_pivots = nullptr;
     bool _eliminateEqualities = true;
+    index_t _firstStage = 0;
+    int32_t* _unresolved = nullptr;
     real_t *_theta0 = nullptr, *_phi0 = nullptr, *_obj0 = nullptr, *_slope = nullptr, *_accepted = nullptr, *_thetaT = nullptr, *_phiT = nullptr, *_objT = nullptr;
 };
 
