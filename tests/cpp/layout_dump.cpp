@@ -182,6 +182,11 @@ UNGAR_MVARIABLE_ARRAY(joint_torques, leg_joint_torques, NUM_LEGS);
 UNGAR_BRANCH_MVARIABLE(tau, base_wrench, joint_torques);
 UNGAR_BRANCH_MVARIABLE(qvtau, q, v, tau);
 static_assert(q.Size() == 19 && v.Size() == 18 && tau.Size() == 18 && qvtau.Size() == 55);  // test/rbd/robot.test.cpp:103-106
+// optional lookup (reference mvariable.hpp:90-111): engaged for a variable of the hierarchy, empty otherwise, never an error
+UNGAR_LEAF_MVARIABLE(not_part_of_the_robot, 2);
+static_assert(qvtau.GetOpt(q).has_value() && qvtau.GetOpt(q)->get().Size() == 19 && qvtau.GetOpt(v).value().get().Index() == 19);
+static_assert(qvtau.GetOpt(joint_torques, 2)->get().Index() == qvtau.Get(tau, joint_torques, 2).Index() && qvtau.GetOpt(qvtau)->get().Size() == 55);
+static_assert(!qvtau.GetOpt(not_part_of_the_robot).has_value() && !q.GetOpt(base_twist) && !position.GetOpt(orientation).has_value());
 }  // namespace anymal
 
 #define DUMP_M(expr, label) \

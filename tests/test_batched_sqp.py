@@ -1,9 +1,9 @@
 """Batched soft SQP from C++ on the reference's OCPs AS WRITTEN.
 
-`build/batched_quadrotor_test` and `build/batched_quadruped_test` (tests/cpp/batched_*_test.cpp) are plain C++20 host programs over
-the C ABI.  Each states one of the reference's MPC problems twice through the facade -- whole-horizon, as
-example/mpc/quadrotor.example.cpp:196-291 / quadruped.example.cpp:209-338 do (523 / 1123 decision variables, input-rate coupling,
-480 foot-contact equality rows), and in stage form with the cross-knot quantity carried in the stage state -- and advances
+`build/batched_{quadrotor,rc_car,quadruped}_test` (tests/cpp/batched_*_test.cpp) are plain C++20 host programs over
+the C ABI.  Each states one of the reference's THREE MPC problems twice through the facade -- whole-horizon, as
+example/mpc/quadrotor.example.cpp:196-291 / rc_car.example.cpp:191-285 / quadruped.example.cpp:209-338 do (523 / 246 / 1123 decision
+variables, input-rate coupling, terminal tracking, 480 foot-contact equality rows), and in stage form with the cross-knot quantity carried in the stage state -- and advances
   * >= 1024 perturbed instances (random references, measured states, rotor bounds active or not; random gaits for the quadruped) with
     Ungar::BatchedSoftSQPOptimizer: stage derivatives, QP assembly, Riccati recursion with stage equality rows, stacked backtracking
     search, all on the device;
@@ -19,7 +19,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("problem,batch,compared", [("quadrotor", 1024, 8), ("quadruped", 1024, 8)])
+@pytest.mark.parametrize("problem,batch,compared", [("quadrotor", 1024, 8), ("rc_car", 1024, 8), ("quadruped", 1024, 8)])
 def test_batched_sqp_equals_the_whole_horizon_facade(repo_root, tmp_path, problem, batch, compared):
     exe = os.path.join(repo_root, "build", f"batched_{problem}_test")
     assert os.path.exists(exe), f"{exe} missing: run __graft_entry__.build()"

@@ -150,7 +150,7 @@ def build_cpp_tests():
     hdrs = _tree(inc, os.path.join(CSRC, "tape"), os.path.join(CSRC, "rbd")) + [os.path.join(ROOT, "include", "ungar_amd.h")]
     jobs = []
     for name, link in (("layout_dump", False), ("function_test", True), ("quadrotor_ocp_test", True), ("rbd_test", True), ("optimization_test", False),
-                       ("batched_quadrotor_test", True), ("batched_quadruped_test", True), ("helpers_device_test", True)):
+                       ("batched_quadrotor_test", True), ("batched_quadruped_test", True), ("batched_rc_car_test", True), ("helpers_device_test", True)):
         src = os.path.join(ROOT, "tests", "cpp", f"{name}.cpp")
         exe = os.path.join(BUILD, name)
         if _newer([exe], [src, *hdrs] + ([LIB] if link else [])):

@@ -52,9 +52,16 @@ struct ungar_function {
     // staging buffers for the single-instance host entry points
     double *dIn = nullptr, *dOut = nullptr;
     int64_t dOutSize = 0;
+    // single-instance host calls: pinned input staging, outputs written by the kernel straight into mapped host memory, one private stream
+    double *hIn = nullptr, *hOut = nullptr, *hOutDevice = nullptr;
+    int64_t hOutSize = 0;
+    hipStream_t hostStream = nullptr;
     ~ungar_function() {
         if (dIn) (void)hipFree(dIn);
         if (dOut) (void)hipFree(dOut);
+        if (hIn) (void)hipHostFree(hIn);
+        if (hOut) (void)hipHostFree(hOut);
+        if (hostStream) (void)hipStreamDestroy(hostStream);
         for (hipModule_t mod : modules)
             if (mod) (void)hipModuleUnload(mod);
     }
@@ -105,7 +112,8 @@ struct KeyHasher {
 #endif
 constexpr const char* kCacheFormat = "ungar_amd-cache-2";
 constexpr const char* kArch = "gfx950";
-constexpr std::size_t kBigKernel = 3000;  // statements above which the machine schedulers are switched off (see below)
+constexpr std::size_t kBigKernel = 3000;
+constexpr int64_t kDirectHostResults = 512;  // single-instance host calls: results up to this many doubles are written straight into mapped host memory  // statements above which the machine schedulers are switched off (see below)
 
 std::string ShellQuote(const std::string& s) {
     std::string q = "'";
@@ -630,20 +638,58 @@ int ungar_function_eval_host(ungar_function* fn, int32_t what, const double* xp_
     if (!out_host) return Fail(UNGAR_E_INVALID, "ungar_function_eval_host: null output");
     if (!k) return Fail(UNGAR_E_UNSUPPORTED, "ungar_function_eval_host: kernel not available for function '" + fn->name + "' (derivative not enabled, or made with UNGAR_AMD_COMPILE_ONLY)");
     if (nOut == 0) return UNGAR_OK;
+    // One launch and ONE synchronisation per call: the inputs go through a pinned staging buffer (asynchronous copy on the function's own
+    // stream), the kernel writes its results straight into mapped host memory (posted writes over PCIe; nothing to copy back), and the stream
+    // is awaited once.  (Three blocking steps -- copy in, launch, copy out -- measured 27 us per call; the reference's in-process C call has no
+    // such floor, so this is what a drop-in user of the single-instance API sees first.)  UNGAR_AMD_HOST_CALL_COPIES=1 restores the copies.
+    static const bool copies = std::getenv("UNGAR_AMD_HOST_CALL_COPIES") != nullptr;
     hipError_t e = hipSuccess;
     if (!fn->dIn) e = hipMalloc(&fn->dIn, static_cast<std::size_t>(std::max<int64_t>(nIn, 1)) * sizeof(double));
-    if (e == hipSuccess && fn->dOutSize < nOut) {
+    if (copies) {
+        if (e == hipSuccess && fn->dOutSize < nOut) {
+            if (fn->dOut) (void)hipFree(fn->dOut);
+            e = hipMalloc(&fn->dOut, static_cast<std::size_t>(nOut) * sizeof(double));
+            fn->dOutSize = nOut;
+        }
+        if (e == hipSuccess && nIn > 0) e = hipMemcpy(fn->dIn, xp_host, static_cast<std::size_t>(nIn) * sizeof(double), hipMemcpyHostToDevice);
+        if (e != hipSuccess) return Fail(UNGAR_E_HIP, std::string("ungar_function_eval_host: ") + hipGetErrorString(e));
+        const ungar_operand in{fn->dIn, nIn, 0, 1}, outOp{fn->dOut, nOut, 0, 1};
+        const int rc = LaunchFn(fn, k, "ungar_function_eval_host", &in, &outOp, 1, nullptr);
+        if (rc != UNGAR_OK) return rc;
+        e = hipMemcpy(out_host, fn->dOut, static_cast<std::size_t>(nOut) * sizeof(double), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return Fail(UNGAR_E_HIP, std::string("ungar_function_eval_host: ") + hipGetErrorString(e));
+        return UNGAR_OK;
+    }
+    if (e == hipSuccess && !fn->hostStream) e = hipStreamCreateWithFlags(&fn->hostStream, hipStreamNonBlocking);
+    if (e == hipSuccess && !fn->hIn) e = hipHostMalloc(reinterpret_cast<void**>(&fn->hIn), static_cast<std::size_t>(std::max<int64_t>(nIn, 1)) * sizeof(double), hipHostMallocDefault);
+    if (e == hipSuccess && fn->hOutSize < nOut) {
+        if (fn->hOut) (void)hipHostFree(fn->hOut);
+        fn->hOut = nullptr;
+        e = hipHostMalloc(reinterpret_cast<void**>(&fn->hOut), static_cast<std::size_t>(nOut) * sizeof(double), hipHostMallocMapped);
+        if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void**>(&fn->hOutDevice), fn->hOut, 0);
+        fn->hOutSize = e == hipSuccess ? nOut : 0;
+    }
+    if (e == hipSuccess && nIn > 0) {
+        std::memcpy(fn->hIn, xp_host, static_cast<std::size_t>(nIn) * sizeof(double));
+        e = hipMemcpyAsync(fn->dIn, fn->hIn, static_cast<std::size_t>(nIn) * sizeof(double), hipMemcpyHostToDevice, fn->hostStream);
+    }
+    if (e != hipSuccess) return Fail(UNGAR_E_HIP, std::string("ungar_function_eval_host: ") + hipGetErrorString(e));
+    // small results are written by the kernel into the mapped buffer itself; large ones (a whole-horizon Jacobian: thousands of 8-byte stores of
+    // one lane, each its own PCIe write) go to device memory and come back as one asynchronous copy on the same stream
+    const bool direct = nOut <= kDirectHostResults;
+    if (!direct && fn->dOutSize < nOut) {
         if (fn->dOut) (void)hipFree(fn->dOut);
         e = hipMalloc(&fn->dOut, static_cast<std::size_t>(nOut) * sizeof(double));
-        fn->dOutSize = nOut;
+        fn->dOutSize = e == hipSuccess ? nOut : 0;
+        if (e != hipSuccess) return Fail(UNGAR_E_HIP, std::string("ungar_function_eval_host: ") + hipGetErrorString(e));
     }
-    if (e == hipSuccess && nIn > 0) e = hipMemcpy(fn->dIn, xp_host, static_cast<std::size_t>(nIn) * sizeof(double), hipMemcpyHostToDevice);
-    if (e != hipSuccess) return Fail(UNGAR_E_HIP, std::string("ungar_function_eval_host: ") + hipGetErrorString(e));
-    const ungar_operand in{fn->dIn, nIn, 0, 1}, outOp{fn->dOut, nOut, 0, 1};
-    const int rc = LaunchFn(fn, k, "ungar_function_eval_host", &in, &outOp, 1, nullptr);
+    const ungar_operand in{fn->dIn, nIn, 0, 1}, outOp{direct ? fn->hOutDevice : fn->dOut, nOut, 0, 1};
+    const int rc = LaunchFn(fn, k, "ungar_function_eval_host", &in, &outOp, 1, fn->hostStream);
     if (rc != UNGAR_OK) return rc;
-    e = hipMemcpy(out_host, fn->dOut, static_cast<std::size_t>(nOut) * sizeof(double), hipMemcpyDeviceToHost);
+    if (!direct) e = hipMemcpyAsync(fn->hOut, fn->dOut, static_cast<std::size_t>(nOut) * sizeof(double), hipMemcpyDeviceToHost, fn->hostStream);
+    if (e == hipSuccess) e = hipStreamSynchronize(fn->hostStream);
     if (e != hipSuccess) return Fail(UNGAR_E_HIP, std::string("ungar_function_eval_host: ") + hipGetErrorString(e));
+    std::memcpy(out_host, fn->hOut, static_cast<std::size_t>(nOut) * sizeof(double));
     return UNGAR_OK;
 }
 

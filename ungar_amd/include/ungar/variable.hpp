@@ -129,6 +129,26 @@ struct fixed_string {
 };
 
 // ---- the variable tree ------------------------------------------------------------------------------
+/// Results of Variable::GetOpt.
+template <class V>
+struct VariableReference {
+    V variable;
+    constexpr const V& get() const { return variable; }
+};
+template <class V>
+struct VariableOptional {
+    VariableReference<V> reference;
+    static constexpr bool has_value() { return true; }
+    constexpr explicit operator bool() const { return true; }
+    constexpr const VariableReference<V>& value() const { return reference; }
+    constexpr const VariableReference<V>& operator*() const { return reference; }
+    constexpr const VariableReference<V>* operator->() const { return &reference; }
+};
+struct NoVariable {
+    static constexpr bool has_value() { return false; }
+    constexpr explicit operator bool() const { return false; }
+};
+
 template <fixed_string NAME, index_t SIZE, class... Children>
 class Variable;
 
@@ -240,6 +260,18 @@ class Variable {
     template <class... Args>
     constexpr auto Get(const Args&... args) const {
         return Resolve(*this, args...);
+    }
+    /// Optional lookup (reference mvariable.hpp:90-111 and the GetOpt members of its three m-variable macros): whether `var` lives in this
+    /// hierarchy is a compile-time fact, so the result is either an engaged VariableOptional -- `GetOpt(var, i)->get()` / `.value().get()` is the
+    /// sub-variable, as with the reference's optional of a reference wrapper -- or NoVariable (`has_value()` false), never an error.
+    template <class Target, class... Idx>
+    constexpr auto GetOpt(const Target& target, const Idx... idx) const {
+        if constexpr (Name() == Target::Name() || CountDescendantsNamed<Target::Name()>() == 1) {
+            using Found = decltype(Resolve(*this, target, idx...));
+            return VariableOptional<Found>{VariableReference<Found>{Resolve(*this, target, idx...)}};
+        } else {
+            return NoVariable{};
+        }
     }
     /// Verbose form: X.At<"x">(1)
     template <fixed_string CHILD, class... Idx>
