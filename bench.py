@@ -286,7 +286,10 @@ def main():
     want_cpu = not args.no_cpu_baseline and world == 1 and rank == 0
     from ungar_amd import workloads as W
     model_name = W.WORKLOADS[args.workload][0]
-    native = NativeOracleBuild((model_name, "anymal_ad") if model_name == "anymal" else (model_name,)) if want_cpu else None  # compiles while the GPU runs
+    # compiles while the GPU runs (UNGAR_BENCH_PORTABLE_ORACLE=1: time the prebuilt portable library instead -- the contract test's choice, a native build of the
+    # generated C takes a minute of host time; the JSON line says which one was timed)
+    native = (NativeOracleBuild((model_name, "anymal_ad") if model_name == "anymal" else (model_name,))
+              if want_cpu and os.environ.get("UNGAR_BENCH_PORTABLE_ORACLE") != "1" else None)
 
     import torch
     import ungar_amd
