@@ -389,6 +389,7 @@ typedef struct ungar_shooting_merit_args {
     const double *dZ, *dU;                  /* dZ[batch][N+1][nz], dU[batch][N][nu] */
     double *theta, *phi, *objective, *slope; /* device, one per (stacked) instance; objective / slope may be null */
     int64_t period;
+    int64_t rows_stride;                    /* 0: node-major rows; > 0: unit-fastest rows (ungar_shooting_trial_rows with trial_stride) */
 } ungar_shooting_merit_args;
 int ungar_shooting_merit(const ungar_shooting_merit_args* args, void* stream);
 
@@ -396,7 +397,11 @@ int ungar_shooting_merit(const ungar_shooting_merit_args* args, void* stream);
  * With carry_inputs the carried slots of row k+1 are the trial inputs of row k; otherwise the caller refreshes them with the carry function
  * (output operand = the carried slots of rows 1..N). */
 int ungar_shooting_trial_rows(const ungar_shooting_dims* dims, const double* rows, const double* dZ, const double* dU, const double* alphas, int64_t candidates,
-                              double* trial, void* stream);
+                              double* trial, int64_t trial_stride, void* stream);
+/* trial_stride: 0 = node-major trial rows (like `rows`); > 0 = UNIT-FASTEST: element e of stacked node i = (c * batch + b) * (N+1) + k at
+ * trial[e * trial_stride + i] (trial_stride >= candidates * batch * (N+1)).  The stage functions then read the trial rows with coalesced loads
+ * (ungar_operand {base + offset * trial_stride, instance_stride 1, knot_stride 0, element_stride trial_stride}) and touch only the elements they
+ * use; pass the same stride to ungar_shooting_merit (rows_stride) and ungar_shooting_select (trial_stride). */
 
 /* Backtracking search over the stacked candidates (backtracking_line_search.hpp:116-151) and the iteration bookkeeping of
  * SoftSQPOptimizer::Optimize (soft_sqp.hpp:88-99) per instance: the first acceptable candidate's [c|x|u] is copied into `rows`, accepted[b] = its
@@ -412,7 +417,7 @@ int ungar_shooting_trial_rows(const ungar_shooting_dims* dims, const double* row
 int ungar_shooting_select(const ungar_shooting_dims* dims, const ungar_line_search_parameters* parameters, const double* alphas, int64_t candidates,
                           const double* theta0, const double* phi0, const double* objective0, const double* slope, const double* theta_trial,
                           const double* phi_trial, const double* objective_trial, double* accepted, int32_t* active, const int32_t* status, double* rows, const double* trial,
-                          int32_t stage, int32_t* unresolved, void* stream);
+                          int64_t trial_stride, int32_t stage, int32_t* unresolved, void* stream);
 
 /* ---- device memory for host code that is not compiled with hipcc (the C++20 facade) ------------------------------------------------ */
 int ungar_device_malloc(void** out, int64_t bytes);

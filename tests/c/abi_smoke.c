@@ -42,10 +42,11 @@ int main(void) {
             void* ptr = dummy;
             memset(&asm_args, 0, sizeof asm_args);
             asm_args.dims = dims;
-            bad += ungar_shooting_trial_rows(&dims, dummy, dummy, dummy, alphas, 17, dummy, 0) != UNGAR_E_INVALID;
-            bad += ungar_shooting_trial_rows(&wrong, dummy, dummy, dummy, alphas, 14, dummy, 0) != UNGAR_E_INVALID;
+            bad += ungar_shooting_trial_rows(&dims, dummy, dummy, dummy, alphas, 17, dummy, 0, 0) != UNGAR_E_INVALID;
+            bad += ungar_shooting_trial_rows(&wrong, dummy, dummy, dummy, alphas, 14, dummy, 0, 0) != UNGAR_E_INVALID;
+            bad += ungar_shooting_trial_rows(&dims, dummy, dummy, dummy, alphas, 14, dummy, 5, 0) != UNGAR_E_INVALID; /* stride below the stacked node count */
             bad += ungar_shooting_assemble(&asm_args, 0) != UNGAR_E_INVALID; /* null operands */
-            bad += ungar_shooting_select(&dims, &ls, alphas, 14, 0, dummy, dummy, dummy, dummy, dummy, dummy, dummy, 0, 0, dummy, dummy, 0, 0, 0) != UNGAR_E_INVALID;
+            bad += ungar_shooting_select(&dims, &ls, alphas, 14, 0, dummy, dummy, dummy, dummy, dummy, dummy, dummy, 0, 0, dummy, dummy, 0, 0, 0, 0) != UNGAR_E_INVALID;
             bad += ungar_device_malloc(&ptr, -1) != UNGAR_E_INVALID;
             bad += ungar_device_malloc(&ptr, 0) != UNGAR_OK || ptr != 0;
             bad += ungar_function_forward_zero_nodes(0, &op, &op, 4, 2, 0) != UNGAR_E_INVALID;

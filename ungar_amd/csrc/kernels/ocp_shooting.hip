@@ -299,14 +299,16 @@ __global__ __launch_bounds__(kBlock) void ShootingMeritKernel(const ShootingMeri
     const long long b = a.period > 0 ? s % a.period : s;
     const int lane = static_cast<int>(threadIdx.x), nz = d.nz(), nd = d.nd(), nc = d.nc, nx = d.nx, N = d.N;
     double g2 = 0.0, obj = 0.0, bar = 0.0, slope = 0.0;
-    const double* row0 = RowOf(a.rows, d, s, 0);
+    auto state = [&](int k, int i) {  // x_k[i] of (stacked) instance s
+        return a.rowsStride > 0 ? a.rows[(nc + i) * a.rowsStride + s * (N + 1) + k] : RowOf(a.rows, d, s, k)[nc + i];
+    };
     for (int i = lane; i < nx; i += kBlock) {
-        const double r = row0[nc + i] - a.xm[b * nx + i];
+        const double r = state(0, i) - a.xm[b * nx + i];
         g2 += r * r;
     }
     for (int idx = lane; idx < N * nx; idx += kBlock) {
         const int k = idx / nx, i = idx - k * nx;
-        const double r = RowOf(a.rows, d, s, k + 1)[nc + i] - a.f[(s * (N + 1) + k) * nx + i];
+        const double r = state(k + 1, i) - a.f[(s * (N + 1) + k) * nx + i];
         g2 += r * r;
     }
     if (a.e)
@@ -369,6 +371,45 @@ __global__ __launch_bounds__(256) void ShootingTrialKernel(const ShootingTrialAr
     }
 }
 
+/// The same trial rows UNIT-FASTEST: a workgroup transposes 64 consecutive stacked nodes, 32 elements at a time, through an LDS tile --
+/// row segments are read coalesced (32 consecutive elements of a node per half wavefront), elements are stored coalesced (64 consecutive nodes).
+__global__ __launch_bounds__(256) void ShootingTrialUnitFastestKernel(const ShootingTrialArgs a) {
+    __shared__ double tile[32][65];
+    const ShootingDims& d = a.d;
+    const long long nodes = static_cast<long long>(a.candidates) * d.batch * (d.N + 1);
+    const long long node0 = static_cast<long long>(blockIdx.x) * 64;
+    const int t = static_cast<int>(threadIdx.x), nz = d.nz(), nd = d.nd(), nv = d.nv(), nc = d.nc, N = d.N;
+    for (int j0 = 0; j0 < nv; j0 += 32) {
+        const int jj = t & 31, j = j0 + jj;
+        for (int pass = 0; pass < 8; ++pass) {
+            const int nl = (t >> 5) + 8 * pass;
+            const long long node = node0 + nl;
+            if (node < nodes && j < nv) {
+                const long long s = node / (N + 1);
+                const int k = static_cast<int>(node - s * (N + 1));
+                const long long b = s % d.batch;
+                const double alpha = a.alphas[s / d.batch];
+                double v = RowOf(a.rows, d, b, k)[j];
+                if (j < nc && d.carryInputs) {
+                    if (k > 0) v = fma(alpha, a.dU[(b * N + (k - 1)) * d.nu + j], RowOf(a.rows, d, b, k - 1)[nz + j]);
+                } else if (j < nz) {
+                    v = fma(alpha, a.dZ[(b * (N + 1) + k) * nz + j], v);
+                } else if (j < nd && k < N) {
+                    v = fma(alpha, a.dU[(b * N + k) * d.nu + (j - nz)], v);
+                }
+                tile[jj][nl] = v;
+            }
+        }
+        __syncthreads();
+        const int nl = t & 63;
+        for (int pass = 0; pass < 8; ++pass) {
+            const int row = (t >> 6) + 4 * pass;
+            if (j0 + row < nv && node0 + nl < nodes) a.trial[(j0 + row) * a.trialStride + node0 + nl] = tile[row][nl];
+        }
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void ShootingSelectKernel(const ShootingSelectArgs a) {
     const ShootingDims& d = a.d;
     const long long b = blockIdx.x;
@@ -398,7 +439,7 @@ __global__ __launch_bounds__(kBlock) void ShootingSelectKernel(const ShootingSel
     const int nd = d.nd(), nv = d.nv();
     for (int idx = static_cast<int>(threadIdx.x); idx < (d.N + 1) * nd; idx += kBlock) {
         const int k = idx / nd, j = idx - k * nd;
-        a.rows[(b * (d.N + 1) + k) * nv + j] = a.trial[(from * (d.N + 1) + k) * nv + j];
+        a.rows[(b * (d.N + 1) + k) * nv + j] = a.trialStride > 0 ? a.trial[j * a.trialStride + from * (d.N + 1) + k] : a.trial[(from * (d.N + 1) + k) * nv + j];
     }
     if (threadIdx.x == 0) {
         a.accepted[b] = a.alphas[chosen];
@@ -448,7 +489,8 @@ extern "C" int ungar_amd_launch_shooting_merit(const ShootingMeritArgs* a, void*
 extern "C" int ungar_amd_launch_shooting_trial(const ShootingTrialArgs* a, void* stream) {
     if (a->d.batch <= 0) return 0;
     const long long nodes = static_cast<long long>(a->candidates) * a->d.batch * (a->d.N + 1);
-    hipLaunchKernelGGL(ShootingTrialKernel, dim3(static_cast<unsigned>(nodes)), dim3(a->d.nv() > 64 ? 128 : kBlock), 0, static_cast<hipStream_t>(stream), *a);
+    if (a->trialStride > 0) hipLaunchKernelGGL(ShootingTrialUnitFastestKernel, dim3(static_cast<unsigned>((nodes + 63) / 64)), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
+    else hipLaunchKernelGGL(ShootingTrialKernel, dim3(static_cast<unsigned>(nodes)), dim3(a->d.nv() > 64 ? 128 : kBlock), 0, static_cast<hipStream_t>(stream), *a);
     return static_cast<int>(hipGetLastError());
 }
 

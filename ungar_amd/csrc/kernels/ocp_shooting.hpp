@@ -91,6 +91,7 @@ struct ShootingMeritArgs {
     const double *dZ, *dU;
     double *theta, *phi, *objective, *slope;
     long long period;
+    long long rowsStride = 0;  // 0: node-major rows; > 0: UNIT-FASTEST rows, element e of node i = instance * (N + 1) + knot at rows[e * rowsStride + i]
 };
 
 /// Stacked trial rows: row (c * batch + b, k) = row (b, k) with [c|x|u] += alphas[c] * [dZ; dU]  (k = N: z only), parameters copied;
@@ -102,6 +103,9 @@ struct ShootingTrialArgs {
     double* trial;
     int candidates;
     double alphas[kMaxLineSearchCandidates];
+    // > 0: the trial rows are written UNIT-FASTEST (element e of stacked node i at trial[e * trialStride + i]): the stage functions then read
+    // them with coalesced loads and touch only the elements they use (a node-major row is fetched whole, line by line, by every function)
+    long long trialStride = 0;
 };
 
 /// The backtracking search of backtracking_line_search.hpp:116-151 per instance over the stacked candidates, then the bookkeeping of
@@ -120,6 +124,7 @@ struct ShootingSelectArgs {
     // a call that is not the last one counts the instances it leaves unresolved in *unresolved instead.
     int first, last;
     int* unresolved;
+    long long trialStride;  // layout of `trial` (ShootingTrialArgs)
     const int* status;  // per instance, from the Riccati solve: non-zero = the QP was not solved (the reference asserts there, soft_sqp.hpp:223-230): no step, instance stops
     double* rows;
     const double* trial;

@@ -265,11 +265,13 @@ int ungar_shooting_merit(const ungar_shooting_merit_args* a, void* stream) {
     k.objective = a->objective;
     k.slope = a->slope;
     k.period = a->period;
+    k.rowsStride = a->rows_stride;
+    if (a->rows_stride < 0 || (a->rows_stride > 0 && a->rows_stride < a->dims.batch * (a->dims.horizon + 1))) return Fail(UNGAR_E_INVALID, "ungar_shooting_merit: rows_stride smaller than the number of nodes");
     return Launched(ungar_amd_launch_shooting_merit(&k, stream), "ungar_shooting_merit");
 }
 
 int ungar_shooting_trial_rows(const ungar_shooting_dims* dims, const double* rows, const double* dZ, const double* dU, const double* alphas, int64_t candidates,
-                              double* trial, void* stream) {
+                              double* trial, int64_t trial_stride, void* stream) {
     ShootingTrialArgs k{};
     if (!dims || !ToDims(*dims, &k.d) || !alphas || candidates < 1 || candidates > kMaxLineSearchCandidates)
         return Fail(UNGAR_E_INVALID, "ungar_shooting_trial_rows: bad argument (1 <= candidates <= 16)");
@@ -281,13 +283,15 @@ int ungar_shooting_trial_rows(const ungar_shooting_dims* dims, const double* row
     k.trial = trial;
     k.candidates = static_cast<int>(candidates);
     for (int64_t c = 0; c < candidates; ++c) k.alphas[c] = alphas[c];
+    if (trial_stride < 0 || (trial_stride > 0 && trial_stride < candidates * k.d.batch * (k.d.N + 1))) return Fail(UNGAR_E_INVALID, "ungar_shooting_trial_rows: trial_stride smaller than the number of stacked nodes");
+    k.trialStride = trial_stride;
     return Launched(ungar_amd_launch_shooting_trial(&k, stream), "ungar_shooting_trial_rows");
 }
 
 int ungar_shooting_select(const ungar_shooting_dims* dims, const ungar_line_search_parameters* p, const double* alphas, int64_t candidates, const double* theta0,
                           const double* phi0, const double* objective0, const double* slope, const double* theta_trial, const double* phi_trial,
-                          const double* objective_trial, double* accepted, int32_t* active, const int32_t* status, double* rows, const double* trial, int32_t stage,
-                          int32_t* unresolved, void* stream) {
+                          const double* objective_trial, double* accepted, int32_t* active, const int32_t* status, double* rows, const double* trial, int64_t trial_stride,
+                          int32_t stage, int32_t* unresolved, void* stream) {
     ShootingSelectArgs k{};
     if (!dims || !ToDims(*dims, &k.d) || !p || !alphas || candidates < 1 || candidates > kMaxLineSearchCandidates)
         return Fail(UNGAR_E_INVALID, "ungar_shooting_select: bad argument (1 <= candidates <= 16)");
@@ -314,6 +318,7 @@ int ungar_shooting_select(const ungar_shooting_dims* dims, const ungar_line_sear
     k.first = (stage & UNGAR_SEARCH_NOT_FIRST) ? 0 : 1;
     k.last = (stage & UNGAR_SEARCH_NOT_LAST) ? 0 : 1;
     k.unresolved = unresolved;
+    k.trialStride = trial_stride;
     k.rows = rows;
     k.trial = trial;
     return Launched(ungar_amd_launch_shooting_select(&k, stream), "ungar_shooting_select");

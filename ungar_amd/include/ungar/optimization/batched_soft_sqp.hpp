@@ -26,6 +26,7 @@
 #pragma once
 
 #include <cstdint>
+#include <cstdlib>
 #include <optional>
 #include <stdexcept>
 #include <string>
@@ -106,7 +107,7 @@ class BatchedSoftSQPOptimizer {
             Check(ungar_device_zero(_dZ, Bytes(_batch * (N + 1) * Nz()), _stream));
             Check(ungar_device_zero(_dU, Bytes(_batch * N * _p.inputSize), _stream));
             const real_t one = 1.0;
-            Check(ungar_shooting_trial_rows(&_dims, _rows, _dZ, _dU, &one, 1, _trial, _stream));
+            Check(ungar_shooting_trial_rows(&_dims, _rows, _dZ, _dU, &one, 1, _trial, 0, _stream));
             Check(ungar_device_copy(_rows, _trial, Bytes(RowsSize()), _stream));
         } else {
             CarryValues(_rows, _batch);
@@ -223,12 +224,15 @@ class BatchedSoftSQPOptimizer {
         for (index_t begin = 0; begin < K;) {
             const index_t count = begin == 0 ? stageA : K - begin;
             const bool last = begin + count == K;
-            Check(ungar_shooting_trial_rows(&_dims, _rows, _dZ, _dU, _alphas.data() + begin, count, _trial, _stream));
-            if (_p.carry) CarryValues(_trial, count * B);
-            Evaluate(*_p.dynamics, 0, _trial, _p.StateOffset(), _fT, count * B * (N + 1));
-            Evaluate(*_p.cost, 0, _trial, 0, _lT, count * B * (N + 1));
-            if (_p.inequality) Evaluate(*_p.inequality, 0, _trial, 0, _hT, count * B * (N + 1));
-            if (_p.equality) Evaluate(*_p.equality, 0, _trial, 0, _eT, count * B * (N + 1));
+            // trial rows UNIT-FASTEST (element e of stacked node i at _trial[e * stride + i]): the stage functions read them coalesced and touch
+            // only the elements they use
+            const index_t stride = _trialStride;
+            Check(ungar_shooting_trial_rows(&_dims, _rows, _dZ, _dU, _alphas.data() + begin, count, _trial, stride, _stream));
+            if (_p.carry) CarryValues(_trial, count * B, stride);
+            Evaluate(*_p.dynamics, 0, _trial, _p.StateOffset(), _fT, count * B * (N + 1), stride);
+            Evaluate(*_p.cost, 0, _trial, 0, _lT, count * B * (N + 1), stride);
+            if (_p.inequality) Evaluate(*_p.inequality, 0, _trial, 0, _hT, count * B * (N + 1), stride);
+            if (_p.equality) Evaluate(*_p.equality, 0, _trial, 0, _eT, count * B * (N + 1), stride);
             ungar_shooting_merit_args t = m;
             t.dims.batch = count * B;
             t.rows = _trial;
@@ -242,9 +246,10 @@ class BatchedSoftSQPOptimizer {
             t.phi = _phiT;
             t.objective = _objT;
             t.period = B;
+            t.rows_stride = stride;
             Check(ungar_shooting_merit(&t, _stream));
             if (!last) Check(ungar_device_zero(_unresolved, static_cast<int64_t>(sizeof(int32_t)), _stream));
-            Check(ungar_shooting_select(&_dims, &ls, _alphas.data() + begin, count, _theta0, _phi0, _obj0, _slope, _thetaT, _phiT, _objT, _accepted, _active, _status, _rows, _trial,
+            Check(ungar_shooting_select(&_dims, &ls, _alphas.data() + begin, count, _theta0, _phi0, _obj0, _slope, _thetaT, _phiT, _objT, _accepted, _active, _status, _rows, _trial, stride,
                                         (begin > 0 ? UNGAR_SEARCH_NOT_FIRST : 0) | (last ? 0 : UNGAR_SEARCH_NOT_LAST), _unresolved, _stream));
             begin += count;
             if (!last && Download<int32_t>(_unresolved, 1)[0] == 0) {  // everybody took one of the first steps (or had stopped): close the search
@@ -373,7 +378,8 @@ class BatchedSoftSQPOptimizer {
         if (_p.equality) _pe = UploadPattern(*_p.equality, false);
         _rows = Device<real_t>(nodes * nv);
         _xm = Device<real_t>(B * nx);
-        _trial = Device<real_t>(stacked * nv);
+        _trialStride = _nodeMajorTrialRows ? 0 : ((stacked + 15) / 16 * 16 + 48);  // whole 128-byte segments, off the power-of-two channel strides
+        _trial = Device<real_t>((_trialStride > 0 ? _trialStride : stacked) * nv);
         _f = Device<real_t>(nodes * nx);
         _fJ = Device<real_t>(nodes * _pf.nnz);
         _cJ = _p.carry ? Device<real_t>(nodes * _pc.nnz) : nullptr;
@@ -420,22 +426,25 @@ class BatchedSoftSQPOptimizer {
 
     /// what: 0 value, 1 sparse Jacobian, 2 sparse Hessian of `f` for `count` consecutive node rows starting at `rows`; the function's
     /// variables begin `offset` doubles into each row.
-    void Evaluate(const Autodiff::Function& f, int what, real_t* rows, index_t offset, real_t* out, index_t count) {
+    void Evaluate(const Autodiff::Function& f, int what, real_t* rows, index_t offset, real_t* out, index_t count, index_t unitFastestStride = 0) {
         const index_t nv = _p.RowSize();
         int64_t width = f.DependentVariableSize();
         if (what != 0) {
             const int32_t *r = nullptr, *c = nullptr;
             Check(what == 1 ? ungar_function_jacobian_sparsity(f.Handle(), &r, &c, &width) : ungar_function_hessian_sparsity(f.Handle(), &r, &c, &width));
         }
-        const ungar_operand xp{rows + offset, nv, 0, 1}, y{out, width, 0, 1};
+        const ungar_operand xp = unitFastestStride > 0 ? ungar_operand{rows + offset * unitFastestStride, 1, 0, unitFastestStride} : ungar_operand{rows + offset, nv, 0, 1};
+        const ungar_operand y{out, width, 0, 1};
         Check(what == 0   ? ungar_function_forward_zero_nodes(f.Handle(), &xp, &y, count, 1, _stream)
               : what == 1 ? ungar_function_sparse_jacobian_nodes(f.Handle(), &xp, &y, count, 1, _stream)
                           : ungar_function_sparse_hessian_nodes(f.Handle(), &xp, &y, count, 1, _stream));
     }
     /// c of row k + 1 <- carry(x, u, w, p of row k) for k < N of `instances` consecutive instances (rows in place).
-    void CarryValues(real_t* rows, index_t instances) {
+    void CarryValues(real_t* rows, index_t instances, index_t unitFastestStride = 0) {
         const index_t N = _p.horizon, nv = _p.RowSize();
-        const ungar_operand xp{rows + _p.StateOffset(), (N + 1) * nv, nv, 1}, y{rows + nv, (N + 1) * nv, nv, 1};
+        const ungar_operand xp = unitFastestStride > 0 ? ungar_operand{rows + _p.StateOffset() * unitFastestStride, N + 1, 1, unitFastestStride}
+                                                       : ungar_operand{rows + _p.StateOffset(), (N + 1) * nv, nv, 1};
+        const ungar_operand y = unitFastestStride > 0 ? ungar_operand{rows + 1, N + 1, 1, unitFastestStride} : ungar_operand{rows + nv, (N + 1) * nv, nv, 1};
         Check(ungar_function_forward_zero_nodes(_p.carry->Handle(), &xp, &y, instances * N, N, _stream));
     }
     template <class T>
@@ -467,6 +476,8 @@ class BatchedSoftSQPOptimizer {
     int32_t *_status = nullptr, *_active = nullptr, *_pivots = nullptr;
     bool _eliminateEqualities = true;
     index_t _firstStage = 0;
+    index_t _trialStride = 0;
+    bool _nodeMajorTrialRows = std::getenv("UNGAR_AMD_NODE_MAJOR_TRIAL_ROWS") != nullptr;  // A/B switch (measurement)
     int32_t* _unresolved = nullptr;
     real_t *_theta0 = nullptr, *_phi0 = nullptr, *_obj0 = nullptr, *_slope = nullptr, *_accepted = nullptr, *_thetaT = nullptr, *_phiT = nullptr, *_objT = nullptr;
 };
