@@ -35,8 +35,7 @@ __global__ __launch_bounds__(256) void ShootingAssembleKernel(const ShootingAsse
     const float ndInv = 1.0f / static_cast<float>(nd);  // row of a flat index through a float reciprocal: exact for nd <= 256 (idx + 0.5 is never a multiple of nd)
     double* Wd = lds;                 // nd x nd
     double* gd = Wd + nd * nd;        // nd
-    double* Jh = gd + nd;             // nh x nd
-    double* d1 = Jh + a.nh * nd;      // nh
+    double* d1 = gd + nd;             // nh
     double* d2 = d1 + a.nh;           // nh
     double* ABd = d2 + a.nh;          // nz x nd
     const int ld = nd + 1;            // equality tableau [C | D | e]: row stride
@@ -48,14 +47,13 @@ __global__ __launch_bounds__(256) void ShootingAssembleKernel(const ShootingAsse
     int* used = pivCol + a.ne;        // nu flags
     int* list = used + d.nu;          // max(nd, ne) indices of a support
     int* listSize = list + (nd > a.ne ? nd : a.ne);
-    const int total = nd * nd + nd + a.nh * nd + 2 * a.nh + nz * nd + a.ne * ld;
+    const int total = nd * nd + nd + 2 * a.nh + nz * nd + a.ne * ld;
     for (int i = lane; i < total; i += lanes) lds[i] = 0.0;
     __syncthreads();
     const long long nodeOff = b * (d.N + 1) + k;
     for (int e = lane; e < a.pH.nnz; e += lanes) Wd[a.pH.rows[e] * nd + a.pH.cols[e]] = a.lH[nodeOff * a.pH.nnz + e];
     for (int e = lane; e < a.pg.nnz; e += lanes) gd[a.pg.cols[e]] = a.lg[nodeOff * a.pg.nnz + e];
     if (stage) {
-        for (int e = lane; e < a.ph.nnz; e += lanes) Jh[a.ph.rows[e] * nd + a.ph.cols[e]] = a.hJ[nodeOff * a.ph.nnz + e];
         for (int j = lane; j < a.nh; j += lanes) {
             const double z = -a.h[nodeOff * a.nh + j];
             d1[j] = BarrierD1(a.barrier, z);
@@ -71,22 +69,40 @@ __global__ __launch_bounds__(256) void ShootingAssembleKernel(const ShootingAsse
         for (int e = lane; e < a.pe.nnz; e += lanes) Ed[a.pe.rows[e] * ld + a.pe.cols[e]] = a.eJ[nodeOff * a.pe.nnz + e];
     }
     __syncthreads();
-    // W (barrier terms and regularisation added; kept in LDS, both triangles), w
+    // barrier terms  W += J_h^T diag(b''(-h)) J_h,  w -= J_h^T b'(-h)  straight from the SPARSE inequality Jacobian (28 of 588 entries for the
+    // quadruped's rows: a dense product over every entry of W read 44 k LDS words per node).  Row by row, in order: inside a row the pairs of its
+    // entries hit distinct targets, so plain read-modify-writes suffice and the sums are accumulated in the same order on every run.
+    if (stage && a.nh > 0) {
+        // the lane's entries (one for up to `lanes` non-zeros, the common case) are fetched once; the row loop below touches LDS only
+        const int mine = lane < a.ph.nnz ? lane : -1;
+        const int myRow = mine >= 0 ? a.ph.rows[mine] : -1, myCol = mine >= 0 ? a.ph.cols[mine] : 0;
+        const double myValue = mine >= 0 ? a.hJ[nodeOff * a.ph.nnz + mine] : 0.0;
+        int partners = 0;  // entries of the same row from this one on (columns ascend within a row: upper triangle)
+        if (mine >= 0)
+            for (int e2 = mine; e2 < a.ph.nnz && a.ph.rows[e2] == myRow; ++e2) ++partners;
+        for (int j = 0; j < a.nh; ++j) {
+            if (myRow == j) {
+                gd[myCol] -= d1[j] * myValue;  // d/dz b(-h) = -b'(-h) dh/dz
+                for (int t = 0; t < partners; ++t) Wd[myCol * nd + a.ph.cols[mine + t]] += d2[j] * myValue * a.hJ[nodeOff * a.ph.nnz + mine + t];
+            }
+            for (int e1 = lane + lanes; e1 < a.ph.nnz; e1 += lanes) {  // (patterns with more non-zeros than lanes)
+                if (a.ph.rows[e1] != j) continue;
+                const int c1 = a.ph.cols[e1];
+                const double v1 = a.hJ[nodeOff * a.ph.nnz + e1];
+                gd[c1] -= d1[j] * v1;
+                for (int e2 = e1; e2 < a.ph.nnz && a.ph.rows[e2] == j; ++e2) Wd[c1 * nd + a.ph.cols[e2]] += d2[j] * v1 * a.hJ[nodeOff * a.ph.nnz + e2];
+            }
+            __syncthreads();
+        }
+    }
+    // regularisation, and the lower triangle mirrored (W is kept in LDS with both triangles)
     for (int idx = lane; idx < nd * nd; idx += lanes) {
         const int r = static_cast<int>((static_cast<float>(idx) + 0.5f) * ndInv), c = idx - r * nd;
         if (r > c) continue;
         double acc = Wd[idx];
-        if (stage)
-            for (int j = 0; j < a.nh; ++j) acc += d2[j] * Jh[j * nd + r] * Jh[j * nd + c];
         if (r == c && r >= nc && (stage || r < nz)) acc += a.regularization;  // the reference's 1e-6 I over its decision variables (soft_sqp.hpp:149-151)
         Wd[idx] = acc;
         Wd[c * nd + r] = acc;
-    }
-    for (int c = lane; c < nd; c += lanes) {
-        double acc = gd[c];
-        if (stage)
-            for (int j = 0; j < a.nh; ++j) acc -= d1[j] * Jh[j * nd + c];  // d/dz b(-h) = -b'(-h) dh/dz
-        gd[c] = acc;
     }
     const long long stageOff = b * d.N + k;
     if (stage) {
@@ -457,7 +473,7 @@ extern "C" int ungar_amd_launch_shooting_assemble(const ShootingAssembleArgs* a,
     if (a->d.batch <= 0) return 0;
     const std::size_t nd = static_cast<std::size_t>(a->d.nd()), nz = static_cast<std::size_t>(a->d.nz());
     const std::size_t ne = static_cast<std::size_t>(a->ne), nu = static_cast<std::size_t>(a->d.nu);
-    const std::size_t lds = (nd * nd + nd + static_cast<std::size_t>(a->nh) * nd + 2 * static_cast<std::size_t>(a->nh) + nz * nd + 2 * ne * (nd + 1) + nz + (nd + 1) + 6) * sizeof(double) +
+    const std::size_t lds = (nd * nd + nd + 2 * static_cast<std::size_t>(a->nh) + nz * nd + 2 * ne * (nd + 1) + nz + (nd + 1) + 6) * sizeof(double) +
                             (ne + nu + (nd > ne ? nd : ne) + 2) * sizeof(int) + 16;
     if (lds > 160 * 1024) return static_cast<int>(hipErrorInvalidValue);
     if (lds > 64 * 1024) {
