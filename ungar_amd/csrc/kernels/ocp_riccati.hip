@@ -181,7 +181,7 @@ struct DeviceExec {
     }
     /// H = W + [A|B]^T PAB on and above the diagonal (mirrored), h = w + [A|B]^T t.  W: folded upper triangle (RiccatiFoldedIndex) or
     /// null = in place in H; the upper tiles (column-major) are dealt to the wavefronts in contiguous runs.
-    template <int NX, int NU>
+    template <int NX, int NU, bool FOLDED>
     __device__ __forceinline__ void ProductH(const double* AB, const double* PAB, const double* t, const double* Wfold, const double* wv, double reg, double* H, double* h) {
         constexpr int n = NX + NU, TT = (n + 1 + 15) / 16, tiles = TT * (TT + 1) / 2, CH = (tiles + kWaves - 1) / kWaves, KS = (NX + 3) / 4;
         const int lane = static_cast<int>(threadIdx.x) & 63, li = lane & 15, lk = lane >> 4;
@@ -229,7 +229,7 @@ struct DeviceExec {
 #endif
         // epilogue, tile by tile: the four stage-Hessian / gradient words of the lane's entries are loaded first (clamped addresses, no branches),
         // then added and stored under the lane's conditions -- one LDS round trip per tile instead of one per entry
-        const double* Wsrc = Wfold ? Wfold : H;
+        const double* Wsrc = FOLDED ? Wfold : H;
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
             if (!live[c]) continue;  // uniform over the wavefront
@@ -239,7 +239,7 @@ struct DeviceExec {
             for (int r = 0; r < 4; ++r) {
                 const int row = 16 * ti[c] + lk + 4 * r, rc = row < n ? row : n - 1;
                 const int lo = rc < cc ? rc : cc, hi = rc < cc ? cc : rc;
-                const int at = Wfold ? RiccatiFoldedIndex(n, lo, hi) : lo * n + hi;
+                const int at = FOLDED ? RiccatiFoldedIndex(n, lo, hi) : lo * n + hi;
                 base[r] = col == n ? wv[rc] : Wsrc[at];
             }
 #pragma unroll

@@ -156,7 +156,9 @@ constexpr bool RiccatiExecHasSelfDma() {
 /// Upper triangle (r <= c) of a symmetric n x n matrix folded into a ((n + 1) / 2) x (n + 1) rectangle: row q of the rectangle holds
 /// row q of the triangle (n - q entries) followed by row n - 1 - q (q + 1 entries) -- decodable with one division by n + 1.
 UNGAR_HD inline int RiccatiFoldedIndex(int n, int r, int c) {
-    return r <= n - 1 - r ? r * (n + 1) + (c - r) : (n - 1 - r) * (n + 1) + (n - (n - 1 - r)) + (c - r);
+    // row q = min(r, n - 1 - r) of the rectangle; the second half of a row starts r + 1 words in (branch-free: selects, no jumps)
+    const int mirrored = n - 1 - r, q = r <= mirrored ? r : mirrored;
+    return q * (n + 1) + (c - r) + (r <= mirrored ? 0 : r + 1);
 }
 /// Inverse: index in the rectangle -> r * n + c of the entry it holds, or -1 for the unused tail of the middle row (n odd).
 UNGAR_HD inline int RiccatiFoldedSource(int n, int i) {
@@ -338,7 +340,7 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
                 if (k > 0) dmaAfterPab(k - 1, P);
             }
             const double* Wsrc = foldW ? (foldInP ? Pn : wf) : nullptr;
-            ex.template ProductH<NX, NU>(AB, PAB, t, Wsrc, foldW ? wn : h, a.regularization, H, h);
+            ex.template ProductH<NX, NU, foldW>(AB, PAB, t, Wsrc, foldW ? wn : h, a.regularization, H, h);
         } else if constexpr (NX >= UNGAR_RICCATI_TILE_MIN_NX) {
             // Sizes fixed at compile time: TI x TC register tiles (RiccatiChooseTile; 2 x 4: eight multiply-adds per six LDS reads instead of
             // per sixteen) and no bounds checks inside the product (a tile on the edge reads past its row / matrix into the neighbouring
