@@ -25,7 +25,7 @@ def timeit(fn, reps=10):
     return s.elapsed_time(e) / reps
 
 
-count = 32768
+count = int(sys.argv[1]) if len(sys.argv) > 1 else 32768  # (32 768 nodes are 512 wavefronts of a lane-per-node kernel: half of the 1024 SIMDs idle; pass 81920, 262144, ... for the sweep)
 gen = torch.Generator(device="cuda")
 gen.manual_seed(0)
 out = {}
@@ -51,4 +51,5 @@ for name in ungar_amd.RBD_MODELS:
         r["jac_nnz"], r["jacobian_ms"], r["jacobian_nodes_per_s"] = m.jac_nnz, t, count / t * 1e3
         r["jacobian_GBs_written"] = count * 8 * (m.jac_nnz + m.ny) / t / 1e6
     out[name] = r
+out["nodes"] = count
 print(json.dumps(out))
