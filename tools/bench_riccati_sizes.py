@@ -5,6 +5,7 @@ diagnostic library (tools/make_riccati_clocks.sh, UNGAR_AMD_LIBRARY=...), the sh
   (reference quadrotor, inputs carried), 13+4 N=30, 8+2 N=30 (reference RC car, inputs carried), 6+2 N=30."""
 import ctypes
 import json
+import os
 import sys
 
 import torch
@@ -46,7 +47,7 @@ for nx, nu, N in SIZES:
         e1.record()
         torch.cuda.synchronize()
         times.append(e0.elapsed_time(e1))
-    assert int(out[2].abs().max()) == 0
+    assert int(out[2].abs().max()) == 0 or os.environ.get("UNGAR_BENCH_NO_STATUS_CHECK")  # (timing-only library variants compute garbage)
     line = {"nx": nx, "nu": nu, "N": N, "batch": batch, "ms_median": sorted(times)[len(times) // 2], "ms_min": min(times)}
     flops = N * (2 * nx * nx * n + 2 * nx * n * (n + 1) / 2 + nu ** 3 / 3 + 2 * nu * nu * (nx + 1) + 2 * nx * nx * nu)  # per instance: P[A|B], H (upper), Cholesky, solves, cost-to-go
     byts = 8 * N * (nx * n + n * (n + 1) / 2 + n + nx + 2 * nu * (nx + 1) + 2 * n)  # operands once, gains out and back, steps out
