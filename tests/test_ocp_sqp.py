@@ -367,15 +367,44 @@ def _quadrotor_problem(batch, N, seed, torch):
     return X, U, xm, p_dyn, p_cost, p_ineq
 
 
-def _reference_iteration(X, U, xm, p_dyn, p_cost, p_ineq, dyn, cost, N, k_barrier=100.0, eps=2e-5, mult=1.0):
-    """One iteration of SoftSQPOptimizer::Optimize for ONE instance, numpy + the torch oracle (independent of the product)."""
+def _c_checker_node_jacobian(name, X, U, p):
+    """(f, dense [A|B]) of the nodes (X[k], U[k]) from the oracle's generated C (oracle/_gen; pinned against the torch oracle's golden vectors by
+    tests/test_codegen_c.py): two orders of magnitude faster than torch autograd for the full-body model."""
+    import ctypes
+    from oracle import build_oracle
+    path = build_oracle.lib_path("portable")
+    if not os.path.exists(path):
+        pytest.skip("oracle C library not built: run __graft_entry__.build()")
+    clib = ctypes.CDLL(path)
+    m, nx, nu = X.shape[0], X.shape[1], U.shape[1]
+    nnz = ctypes.c_int.in_dll(clib, f"{name}_jac_nnz").value
+    rows = np.ctypeslib.as_array((ctypes.c_int * nnz).in_dll(clib, f"{name}_jac_row")).astype(np.int64)
+    cols = np.ctypeslib.as_array((ctypes.c_int * nnz).in_dll(clib, f"{name}_jac_col")).astype(np.int64)
+    dp = ctypes.POINTER(ctypes.c_double)
+    loop = getattr(clib, f"{name}_sparse_jacobian_batch_shared")
+    loop.argtypes = [dp] * 6 + [ctypes.c_long, ctypes.c_long]
+    loop.restype = None
+    xh, uh, ph, w0 = np.ascontiguousarray(X), np.ascontiguousarray(U), np.ascontiguousarray(p), np.zeros(1)
+    f, v = np.empty((m, nx)), np.empty((m, nnz))
+    loop(xh.ctypes.data_as(dp), uh.ctypes.data_as(dp), w0.ctypes.data_as(dp), ph.ctypes.data_as(dp), f.ctypes.data_as(dp), v.ctypes.data_as(dp), 0, m)
+    J = np.zeros((m, nx, nx + nu))
+    J[:, rows, cols] = v
+    return f, J
+
+
+def _reference_iteration(X, U, xm, p_dyn, p_cost, p_ineq, dyn, cost, N, k_barrier=100.0, eps=2e-5, mult=1.0, c_checker_jacobian=False):
+    """One iteration of SoftSQPOptimizer::Optimize for ONE instance, numpy + the torch oracle (independent of the product).
+    c_checker_jacobian: node Jacobians from the oracle's generated C instead of torch autograd (the full-body model: 7 s -> 0.1 s per instance)."""
     nx, nu = X.shape[1], U.shape[1]
     n = nx + nu
     w0 = np.zeros((N, 0))
 
     def evaluate(Xc, Uc, derivatives):
         pd, pc = np.tile(p_dyn, (N, 1)), np.tile(p_cost, (N, 1))
-        if derivatives:
+        if derivatives and c_checker_jacobian:
+            f, J = _c_checker_node_jacobian(dyn, Xc[:N], Uc, p_dyn)
+            c, g, H = O.cost_value_gradient_hessian(Xc[:N], Uc, pc, name=cost)
+        elif derivatives:
             f, J = O.node_jacobian(dyn, Xc[:N], Uc, w0, pd)
             c, g, H = O.cost_value_gradient_hessian(Xc[:N], Uc, pc, name=cost)
         else:
@@ -564,8 +593,12 @@ def test_one_sqp_iteration_full_body_quadruped():
         if th0 is None:
             th0 = theta0.copy()
         assert (acc > 0).mean() > 0.9
-        for i in (sample if iteration == 1 else sample[:3]):  # (the torch oracle takes ~7 s per instance and iteration)
-            dX, dU, alpha, Xr, Ur, (theta, phi, slope) = _reference_iteration(Xc[i], Uc[i], xm[i], p_dyn[i], p_cost[i], None, "anymal", "anymal_cost", N)
+        for i in (sample if iteration == 1 else sample[:3]):
+            # node Jacobians by torch autograd (~7 s per instance and iteration) for two instances of the first iteration and one of the second,
+            # by the oracle's generated C for the others
+            independent = i in (sample[:2] if iteration == 1 else sample[:1])
+            dX, dU, alpha, Xr, Ur, (theta, phi, slope) = _reference_iteration(Xc[i], Uc[i], xm[i], p_dyn[i], p_cost[i], None, "anymal", "anymal_cost", N,
+                                                                              c_checker_jacobian=not independent)
             scale = max(1.0, np.abs(dX).max(), np.abs(dU).max())
             assert np.abs(dXd[i] - dX).max() <= 1e-8 * scale and np.abs(dUd[i] - dU).max() <= 1e-8 * scale
             assert abs(theta0[i] - theta) <= 1e-9 * max(1.0, theta) and abs(phi0[i] - phi) <= 1e-9 * max(1.0, abs(phi))
