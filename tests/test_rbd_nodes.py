@@ -149,3 +149,54 @@ def test_batched_quantities_at_scale():
     feet = run("anymal_feet", q).t().reshape(count, 4, 12)
     R = feet[:, :, 3:].reshape(count * 4, 3, 3)
     assert (torch.bmm(R, R.transpose(1, 2)) - torch.eye(3, dtype=torch.float64, device="cuda")).abs().max().item() < 1e-12
+
+
+@pytest.mark.gpu
+def test_joint_torque_jacobians_at_scale_lane_per_leg():
+    """The Jacobian modes of 'anymal_rnea' run the lane-per-leg program (quad_rnea_kernel.hpp): 65 531 configurations (a ragged last wavefront)
+    in one launch, dense block and CSR values; identities that need no oracle -- d tau / d a = M(q) from the CRBA kernel, the values equal the
+    value-only (lane-per-node) kernel's, the CSR values are the dense block gathered through the pattern with exact zeros elsewhere,
+    and J (dq, dv) matches central differences of the value kernel along a random direction at EVERY configuration."""
+    import torch
+    import ungar_amd
+    count = 65531
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(11)
+    r = lambda n: torch.rand((n, count), generator=gen, device="cuda", dtype=torch.float64) * 2 - 1  # noqa: E731
+    quat = torch.randn((4, count), generator=gen, device="cuda", dtype=torch.float64)
+    q = torch.cat((r(3), quat / quat.norm(dim=0, keepdim=True), r(12)))
+    x, a = torch.cat((q, r(18))), r(18)
+    Op = ungar_amd.Operand
+    m = ungar_amd.NodeModel("anymal_rnea")
+    rows, cols = (torch.as_tensor(t.astype(np.int64), device="cuda") for t in m.jacobian_sparsity())
+    y0 = torch.full((18, count), float("nan"), dtype=torch.float64, device="cuda")
+    m.forward_zero(count, Op.soa(x, count), Op.soa(a, count), None, None, Op.soa(y0, count))
+    yd, Jd = torch.full_like(y0, float("nan")), torch.full((18 * 55, count), float("nan"), dtype=torch.float64, device="cuda")
+    m.dense_jacobian(count, Op.soa(x, count), Op.soa(a, count), None, None, Op.soa(yd, count), Op.soa(Jd, count))
+    ys, Js = torch.full_like(y0, float("nan")), torch.full((m.jac_nnz, count), float("nan"), dtype=torch.float64, device="cuda")
+    m.sparse_jacobian(count, Op.soa(x, count), Op.soa(a, count), None, None, Op.soa(ys, count), Op.soa(Js, count))
+    torch.cuda.synchronize()
+    assert torch.isfinite(Jd).all() and torch.isfinite(Js).all()
+    scale = y0.abs().max().item()
+    assert (yd - y0).abs().max().item() <= 1e-12 * scale and (ys - y0).abs().max().item() <= 1e-12 * scale
+    J = Jd.t().reshape(count, 18, 55)
+    # (two instantiations of the same body: the compiler contracts multiply-adds differently around the sinks that differ, so not bit for bit)
+    assert (Js.t() - J[:, rows, cols]).abs().max().item() <= 1e-12 * J.abs().max().item()
+    mask = torch.ones((18, 55), dtype=torch.bool, device="cuda")
+    mask[rows, cols] = False
+    assert (J[:, mask] == 0.0).all()
+    crba = ungar_amd.NodeModel("anymal_crba")
+    M = torch.empty((324, count), dtype=torch.float64, device="cuda")
+    crba.forward_zero(count, Op.soa(q, count), None, None, None, Op.soa(M, count))
+    torch.cuda.synchronize()
+    assert (J[:, :, 37:] - M.t().reshape(count, 18, 18)).abs().max().item() <= 1e-10 * M.abs().max().item()
+    # directional derivative along (dq, dv): the quaternion moves along a direction of R^4 (the node differentiates with respect to its four entries)
+    d = r(37)
+    h = 1e-6
+    yp, ym = torch.empty_like(y0), torch.empty_like(y0)
+    m.forward_zero(count, Op.soa(x + h * d, count), Op.soa(a, count), None, None, Op.soa(yp, count))
+    m.forward_zero(count, Op.soa(x - h * d, count), Op.soa(a, count), None, None, Op.soa(ym, count))
+    torch.cuda.synchronize()
+    fd = ((yp - ym) / (2 * h)).t()
+    jd = torch.bmm(J[:, :, :37], d.t().unsqueeze(2)).squeeze(2)
+    assert (fd - jd).abs().max().item() <= 2e-6 * max(1.0, jd.abs().max().item())

@@ -21,6 +21,7 @@
 #include "../rbd/rnea_crba.hpp"
 #include "../tape/emit.hpp"
 #include "quad_leg_program.hpp"
+#include "quad_rnea_program.hpp"
 
 using namespace ungar_amd;
 using tape::AD;
@@ -444,6 +445,7 @@ int main(int argc, char** argv) {
     int quadPrefetch = 48;            // LDS loads are hoisted this many statements ahead of their first use ...
     bool quadPrefetchAcross = false;  // ... and may cross into the tail of the previous phase
     int quadUniformSlots = 80;  // compact (one copy per quad) LDS slots; budget: quadLdsSlots + quadUniformSlots / 4 <= 80
+    int rneaQuadLdsSlots = 60, rneaQuadUniformSlots = 80;  // LDS home of the lane-per-leg joint-torque program (same budget)
     int quadLdsSlots = 60;  // 64-lane workgroups, four per CU: 160 KiB / 4 / 64 lanes / 8 B
     int rbdLdsSlots = -1;  // >= 0 overrides the per-lane LDS home of the phased rigid-body quantity Jacobians (0 = plain bodies only)
     std::vector<std::string> only;
@@ -459,6 +461,10 @@ int main(int argc, char** argv) {
         else if (a == "--remat-depth" && i + 1 < argc) rematDepth = std::atoi(argv[++i]);
         else if (a == "--prefetch" && i + 1 < argc) prefetch = std::atoi(argv[++i]);
         else if (a == "--quad-lds-slots" && i + 1 < argc) quadLdsSlots = std::atoi(argv[++i]);
+        else if (a == "--rnea-quad-slots" && i + 2 < argc) {
+            rneaQuadLdsSlots = std::atoi(argv[++i]);
+            rneaQuadUniformSlots = std::atoi(argv[++i]);
+        }
         else if (a == "--quad-merge-shared" && i + 1 < argc) quadMergeShared = std::atoi(argv[++i]) != 0;
         else if (a == "--quad-uniform-slots" && i + 1 < argc) quadUniformSlots = std::atoi(argv[++i]);
         else if (a == "--quad-prefetch" && i + 2 < argc) {
@@ -600,6 +606,36 @@ int main(int argc, char** argv) {
         const int slots = rbdLdsSlots >= 0 && s.phasedLdsSlots > 0 ? rbdLdsSlots : s.phasedLdsSlots;
         EmitHip(g, outDir, false, slots, slots > 0 ? 4 : rematConsumers, slots > 0 ? 4 : rematDepth, prefetch, g.jacMode == 2);
         if (!cDir.empty()) EmitC(g, cDir);
+        if (std::string(s.dims.name) == "anymal_rnea") {  // lane-per-leg SPMD program: what the Jacobian modes of this model launch
+            const codegen::QuadProgram qp = codegen::RecordQuadRneaProgram(anymal, g.jac);
+            tape::EmitStats qs;
+            int quadLds = 0, quadUniformUsed = 0;
+            const std::string fn = codegen::EmitQuadProgram(qp, "ValueJacobianQuad", &qs, true, rneaQuadLdsSlots, &quadLds, quadRematConsumers, quadRematDepth, quadPrefetch, rneaQuadUniformSlots, &quadUniformUsed, false);
+            std::ostringstream qo;
+            qo << "// GENERATED by ungar_amd/csrc/codegen (quad_rnea_program.hpp) -- do not edit.\n"
+               << "// ANYmal B joint torques and their derivatives, one lane per leg: " << qs.statements << " statements, " << qs.flops << " flops, "
+               << qs.transcendentals << " transcendentals, " << qs.divisions << " divisions per lane.\n"
+               << "#pragma once\n#ifndef __host__\n#define __host__\n#endif\n#ifndef __device__\n#define __device__\n#endif\n\n"
+               << "namespace ungar_amd::gen::anymal_rnea_quad {\n\n"
+               << "inline constexpr int kNumConstants = " << qp.constants.size() << ";\n"
+               << "inline constexpr int kLdsSlots = " << quadLds << ", kLdsUniformSlots = " << quadUniformUsed << ";\n"
+               << "inline constexpr int kJacNnz = " << g.jac.Nnz() << ";  // entries of the sparse (CSR) output\n"
+               << "// leg constants that differ between legs, [k][leg]; legs in model order (LF, LH, RF, RH)\n";
+            for (int dev = 0; dev < 2; ++dev) {
+                qo << (dev ? "#ifdef __HIPCC__\nstatic __device__ __constant__ double kLegConstantsDev[" : "inline constexpr double kLegConstants[") << std::max<std::size_t>(1, qp.constants.size())
+                   << "][4] = {\n";
+                for (const auto& c : qp.constants) {
+                    char buf[256];
+                    std::snprintf(buf, sizeof buf, "    {%.17g, %.17g, %.17g, %.17g},\n", c[0], c[1], c[2], c[3]);
+                    qo << buf;
+                }
+                qo << (dev ? "};\n#endif\n\n" : "};\n");
+            }
+            qo << fn << "\n}  // namespace ungar_amd::gen::anymal_rnea_quad\n";
+            std::ofstream qf(outDir + "/anymal_rnea_quad_gen.hpp");
+            qf << qo.str();
+            std::fprintf(stderr, "[codegen] anymal_rnea_quad (lane per leg): %zu statements, %zu flops per lane, %zu table constants\n", qs.statements, qs.flops, qp.constants.size());
+        }
     }
     // scalar stage-cost nodes (value + gradient + upper Hessian)
     {

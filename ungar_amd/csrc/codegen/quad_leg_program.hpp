@@ -55,11 +55,10 @@ inline bool IsZeroLit(const AD& a) {
 
 }  // namespace detail
 
-/// Records the leg-lane program for a free-flyer + 4 x (3 revolute) robot.
-inline QuadProgram RecordQuadLegProgram(const rbd::Model& model, const tape::SparseEntries& pattern, int columnsPerPhase = 1,
-                                        bool mergeSharedStores = false) {
-    using namespace rbd;
-    using namespace rbd::detail;
+/// The lane-per-leg programs assume a free-flyer with four structurally identical 3-joint legs off the base (same joint axes, placements that
+/// are pure translations): checked here, the leg-specific numbers go through a constants table.
+inline void CheckFloatingBaseQuadruped(const rbd::Model& model) {
+    using rbd::Joint;
     if (model.NumJoints() != 14 || model.nq != 19 || model.nv != 18) throw std::runtime_error("quad program: expected a free-flyer with 12 revolute joints");
     for (int L = 0; L < 4; ++L)
         for (int j = 0; j < 3; ++j) {
@@ -72,6 +71,43 @@ inline QuadProgram RecordQuadLegProgram(const rbd::Model& model, const tape::Spa
                     if (std::fabs(J.placement.R[static_cast<std::size_t>(r)][static_cast<std::size_t>(c)] - (r == c ? 1.0 : 0.0)) > 1e-14)
                         throw std::runtime_error("quad program: joint placements must be pure translations");
         }
+}
+
+/// Leg constants in the order the programs consume them -- per joint t(3), mass, h(3), I(6 upper) -- as a literal when identical in the four
+/// legs, otherwise as an index into `table` ([k][leg]).
+struct LegConstantRef {
+    bool literal;
+    double value;
+    int index;
+};
+inline std::vector<LegConstantRef> CollectLegConstants(const rbd::Model& model, std::vector<std::array<double, 4>>& table) {
+    using rbd::Joint;
+    std::vector<LegConstantRef> cref;
+    auto addConst = [&](const std::array<double, 4>& v) {
+        if (v[0] == v[1] && v[1] == v[2] && v[2] == v[3]) {
+            cref.push_back({true, v[0], -1});
+        } else {
+            cref.push_back({false, 0.0, static_cast<int>(table.size())});
+            table.push_back(v);
+        }
+    };
+    for (int j = 0; j < 3; ++j) {
+        auto joint = [&](int L) -> const Joint& { return model.joints[static_cast<std::size_t>(2 + 3 * L + j)]; };
+        for (std::size_t k = 0; k < 3; ++k) addConst({joint(0).placement.p[k], joint(1).placement.p[k], joint(2).placement.p[k], joint(3).placement.p[k]});
+        addConst({joint(0).inertia.mass, joint(1).inertia.mass, joint(2).inertia.mass, joint(3).inertia.mass});
+        for (std::size_t k = 0; k < 3; ++k) addConst({joint(0).inertia.h[k], joint(1).inertia.h[k], joint(2).inertia.h[k], joint(3).inertia.h[k]});
+        for (std::size_t r = 0; r < 3; ++r)
+            for (std::size_t c = r; c < 3; ++c) addConst({joint(0).inertia.I[r][c], joint(1).inertia.I[r][c], joint(2).inertia.I[r][c], joint(3).inertia.I[r][c]});
+    }
+    return cref;
+}
+
+/// Records the leg-lane program for a free-flyer + 4 x (3 revolute) robot.
+inline QuadProgram RecordQuadLegProgram(const rbd::Model& model, const tape::SparseEntries& pattern, int columnsPerPhase = 1,
+                                        bool mergeSharedStores = false) {
+    using namespace rbd;
+    using namespace rbd::detail;
+    CheckFloatingBaseQuadruped(model);
 
     QuadProgram P;
     // CSR index of (row, col) in the node's sparse pattern, -1 for structural zeros (sparse output mode)
@@ -94,29 +130,7 @@ inline QuadProgram RecordQuadLegProgram(const rbd::Model& model, const tape::Spa
     // ---- inputs --------------------------------------------------------------------------------------------
     // [0,7) q_b  [7,13) v_b  [13,16) q_L  [16,19) v_L  [19,22) u_L  [22] dt  [23, 23+K) constants  then 9 aux
     constexpr int kQb = 0, kVb = 7, kQl = 13, kVl = 16, kUl = 19, kDt = 22, kConst = 23;
-    // leg constants: per joint t(3), mass, h(3), I(6 upper)  -> literal when identical in all four legs
-    struct CRef {
-        bool literal;
-        double value;
-        int index;
-    };
-    std::vector<CRef> cref;
-    auto addConst = [&](const std::array<double, 4>& v) {
-        if (v[0] == v[1] && v[1] == v[2] && v[2] == v[3]) {
-            cref.push_back({true, v[0], -1});
-        } else {
-            cref.push_back({false, 0.0, static_cast<int>(P.constants.size())});
-            P.constants.push_back(v);
-        }
-    };
-    for (int j = 0; j < 3; ++j) {
-        auto joint = [&](int L) -> const Joint& { return model.joints[static_cast<std::size_t>(2 + 3 * L + j)]; };
-        for (std::size_t k = 0; k < 3; ++k) addConst({joint(0).placement.p[k], joint(1).placement.p[k], joint(2).placement.p[k], joint(3).placement.p[k]});
-        addConst({joint(0).inertia.mass, joint(1).inertia.mass, joint(2).inertia.mass, joint(3).inertia.mass});
-        for (std::size_t k = 0; k < 3; ++k) addConst({joint(0).inertia.h[k], joint(1).inertia.h[k], joint(2).inertia.h[k], joint(3).inertia.h[k]});
-        for (std::size_t r = 0; r < 3; ++r)
-            for (std::size_t c = r; c < 3; ++c) addConst({joint(0).inertia.I[r][c], joint(1).inertia.I[r][c], joint(2).inertia.I[r][c], joint(3).inertia.I[r][c]});
-    }
+    const std::vector<LegConstantRef> cref = CollectLegConstants(model, P.constants);
     const int K = static_cast<int>(P.constants.size());
     const int kAux = kConst + K;  // aux: accb(6), aL(3)
     const int nInputs = kAux + 9;
@@ -136,7 +150,7 @@ inline QuadProgram RecordQuadLegProgram(const rbd::Model& model, const tape::Spa
 
     std::size_t cnext = 0;
     auto C = [&]() -> AD {
-        const CRef& r = cref[cnext++];
+        const LegConstantRef& r = cref[cnext++];
         return r.literal ? AD{r.value} : in[static_cast<std::size_t>(kConst + r.index)];
     };
     const AD dt = in[kDt];

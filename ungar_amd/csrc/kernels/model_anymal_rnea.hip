@@ -1,6 +1,45 @@
 // ungar_amd :: built-in rigid-body quantity node 'anymal_rnea' (SURVEY.md section 8(f) N4): joint torques tau = RNEA(q, v, a) of ANYmal B (rbd/quantities/joint_torques.hpp:42-43) and d tau / d (q, v, a),
-// one lane per configuration, whole batch per launch (body lowered from the tape of csrc/models/rbd_nodes.hpp).
+// whole batch per launch.
+//   value + Jacobian (dense block or CSR values) -> lane-per-leg SPMD program (quad_rnea_kernel.hpp, csrc/codegen/quad_rnea_program.hpp)
+//   value only, or operands beyond 32-bit element offsets / with negative strides -> one lane per configuration (body lowered from the tape of csrc/models/rbd_nodes.hpp)
 #include "../gen/anymal_rnea_gen.hpp"
-#include "node_kernel.hpp"
+#include "../gen/anymal_rnea_quad_gen.hpp"
+#include <cstdlib>
 
-UNGAR_AMD_DEFINE_NODE_MODEL(anymal_rnea, 64)
+#include "quad_rnea_kernel.hpp"
+
+UNGAR_AMD_DEFINE_NODE_TRAITS(anymal_rnea)
+
+namespace ungar_amd::kernels {
+struct AnymalRneaQuadBody {
+    template <class IO>
+    __device__ __forceinline__ void operator()(IO& io) const { gen::anymal_rnea_quad::ValueJacobianQuad<double>(io); }
+};
+}  // namespace ungar_amd::kernels
+
+extern "C" int ungar_amd_launch_anymal_rnea(int mode, const ungar_amd::kernels::NodeLaunch* a, void* stream) {
+    using namespace ungar_amd::kernels;
+    namespace Q = ungar_amd::gen::anymal_rnea_quad;
+    static const bool lanePerNode = getenv("UNGAR_AMD_RNEA_LANE_PER_NODE") != nullptr;  // A/B switch (tools/bench_rbd_nodes.py)
+    const bool jacobian = mode == kModeDenseJacobian || mode == kModeSparseJacobian;
+    const long long entries = mode == kModeDenseJacobian ? 18 * 55 : Q::kJacNnz;
+    if (!jacobian || lanePerNode || a->jac.es < 0 || a->jac.es * entries >= (1LL << 32))
+        return static_cast<int>(LaunchNodeModel<Model_anymal_rnea, 64>(mode, *a, static_cast<hipStream_t>(stream)));
+    if (a->count <= 0) return 0;
+    void* sym = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&sym, HIP_SYMBOL(ungar_amd::gen::anymal_rnea_quad::kLegConstantsDev));
+    if (e != hipSuccess) return static_cast<int>(e);
+    const double(*ctab)[4] = static_cast<const double(*)[4]>(sym);
+    const dim3 grid(static_cast<unsigned>((a->count + 15) / 16)), block(64);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool streaming = UseStreamingStores(*a, mode, entries, 18);
+    const AnymalRneaQuadBody body{};
+    if (mode == kModeDenseJacobian) {
+        if (streaming) hipLaunchKernelGGL((QuadRneaKernel<Q::kLdsSlots, Q::kLdsUniformSlots, false, true, AnymalRneaQuadBody>), grid, block, 0, s, *a, ctab, body);
+        else hipLaunchKernelGGL((QuadRneaKernel<Q::kLdsSlots, Q::kLdsUniformSlots, false, false, AnymalRneaQuadBody>), grid, block, 0, s, *a, ctab, body);
+    } else {
+        if (streaming) hipLaunchKernelGGL((QuadRneaKernel<Q::kLdsSlots, Q::kLdsUniformSlots, true, true, AnymalRneaQuadBody>), grid, block, 0, s, *a, ctab, body);
+        else hipLaunchKernelGGL((QuadRneaKernel<Q::kLdsSlots, Q::kLdsUniformSlots, true, false, AnymalRneaQuadBody>), grid, block, 0, s, *a, ctab, body);
+    }
+    return static_cast<int>(hipGetLastError());
+}
