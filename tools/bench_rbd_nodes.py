@@ -50,6 +50,10 @@ for name in ungar_amd.RBD_MODELS:
         t = timeit(lambda: m.sparse_jacobian(count, Op.soa(x, st), uo, None, Op.per_instance(p, max(m.np, 1), shared=True), Op.soa(f, st), Op.soa(J, st)))
         r["jac_nnz"], r["jacobian_ms"], r["jacobian_nodes_per_s"] = m.jac_nnz, t, count / t * 1e3
         r["jacobian_GBs_written"] = count * 8 * (m.jac_nnz + m.ny) / t / 1e6
+        if name == "anymal_rnea":  # dense block as well (structural zeros written): the other mode of the lane-per-leg program
+            Jd = unit_fastest(m.ny * (m.nx + m.nu), count, torch)
+            t = timeit(lambda: m.dense_jacobian(count, Op.soa(x, st), uo, None, Op.per_instance(p, max(m.np, 1), shared=True), Op.soa(f, st), Op.soa(Jd, st)))
+            r["dense_jacobian_ms"], r["dense_jacobian_GBs_written"] = t, count * 8 * (m.ny * (m.nx + m.nu) + m.ny) / t / 1e6
     out[name] = r
 out["nodes"] = count
 print(json.dumps(out))

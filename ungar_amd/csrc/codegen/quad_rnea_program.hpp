@@ -16,12 +16,15 @@
 // dynamics program, emitted generic over the value type, and pinned in a 4-lane CPU simulator (tests/cpp/quad_rnea_sim.cpp).
 #pragma once
 
+#include <algorithm>
+
 #include "quad_leg_program.hpp"
 
 namespace ungar_amd::codegen {
 
 /// pattern: the sparse pattern of the lane-per-node model 'anymal_rnea' (rows 18 x columns 55): the per-leg CSR indices of the sinks.
-inline QuadProgram RecordQuadRneaProgram(const rbd::Model& model, const tape::SparseEntries& pattern) {
+/// reverse: partials by reverse accumulation (15 local outputs against 25 local inputs), sinks and phases ordered row by row instead of column by column.
+inline QuadProgram RecordQuadRneaProgram(const rbd::Model& model, const tape::SparseEntries& pattern, bool reverse = false) {
     using namespace rbd;
     using namespace rbd::detail;
     CheckFloatingBaseQuadruped(model);
@@ -32,16 +35,17 @@ inline QuadProgram RecordQuadRneaProgram(const rbd::Model& model, const tape::Sp
     for (std::size_t e = 0; e < pattern.Nnz(); ++e) kOf[static_cast<std::size_t>(pattern.row[e] * kCols + pattern.col[e])] = static_cast<int>(e);
     auto kArgs = [&](int rowBase, int rowLegMul, int colBase, int colLegMul, int rot) {
         std::string s;
+        std::array<int, 4> k{};
         for (int L = 0; L < 4; ++L) {
             const int r = rowBase + 3 * rowLegMul * L, c = colBase + 3 * colLegMul * ((L + rot) & 3);
-            s += (L ? ", " : "") + std::to_string(kOf[static_cast<std::size_t>(r * kCols + c)]);
+            k[static_cast<std::size_t>(L)] = kOf[static_cast<std::size_t>(r * kCols + c)];
+            s += (L ? ", " : "") + std::to_string(k[static_cast<std::size_t>(L)]);
+        }
+        if (*std::min_element(k.begin(), k.end()) >= 0) {  // per-leg index pattern k_L - k_0: one per-lane base pointer each in the sparse kernel
+            const std::array<int, 4> delta{0, k[1] - k[0], k[2] - k[0], k[3] - k[0]};
+            if (std::find(P.sparseDeltas.begin(), P.sparseDeltas.end(), delta) == P.sparseDeltas.end()) P.sparseDeltas.push_back(delta);
         }
         return s;
-    };
-    auto inPattern = [&](int rowBase, int rowLegMul, int colBase, int colLegMul, int rot) {
-        bool any = false;
-        for (int L = 0; L < 4; ++L) any = any || kOf[static_cast<std::size_t>((rowBase + 3 * rowLegMul * L) * kCols + colBase + 3 * colLegMul * ((L + rot) & 3))] >= 0;
-        return any;
     };
     // ---- inputs: [0,4) quaternion  [4,10) v_b  [10,16) a_b  [16,19) q_L  [19,22) v_L  [22,25) a_L  then the leg constants -----------------
     constexpr int kQuat = 0, kVb = 4, kAb = 10, kQl = 16, kVl = 19, kAl = 22, kConst = 25;
@@ -147,7 +151,7 @@ inline QuadProgram RecordQuadRneaProgram(const rbd::Model& model, const tape::Sp
     for (const AD& v : fOwn) tIds.push_back(v.Node());
     std::vector<int> dCols;
     for (int k = 0; k < kConst; ++k) dCols.push_back(k);
-    const tape::SparseEntries D = diff.Jacobian(tIds, dCols, 1);  // forward: a column's partials are born together
+    const tape::SparseEntries D = diff.Jacobian(tIds, dCols, reverse ? 2 : 1);  // forward: a column's partials are born together; reverse: a row's
     AD Dm[15][kConst];
     for (std::size_t e = 0; e < D.Nnz(); ++e) Dm[D.row[e]][D.col[e]] = AD::FromId(D.value[e]);
 
@@ -164,36 +168,59 @@ inline QuadProgram RecordQuadRneaProgram(const rbd::Model& model, const tape::Sp
                                          kArgs(6 + k, 1, colBase, colLegMul, rot) + ", %s);"});
     };
     // node-level columns: x = [p 0..2 | quat 3..6 | q_leg 7 + 3 L + k | v_b 19..24 | v_leg 25 + 3 L + k],  u = [a_b 37..42 | a_leg 43 + 3 L + k]
-    // ---- columns owned by this lane's leg ----------------------------------------------------------------------------------------------------------
     const int ownLocal[3] = {kQl, kVl, kAl}, ownNode[3] = {7, 25, 43};
-    for (int kind = 0; kind < 3; ++kind)
-        for (int k = 0; k < 3; ++k) {
-            P.phaseStarts.push_back(P.slots.size());
-            const int lc = ownLocal[kind] + k, colBase = ownNode[kind] + k;
-            for (int r = 0; r < 6; ++r) {
-                const AD v = Dm[3 + r][lc];  // (f_own does not depend on leg variables)
-                checkZero(v, r, 0, colBase, 1, 0);
-                P.slots.push_back({v.Node(), "io.j_base_own(" + std::to_string(r) + ", " + std::to_string(colBase) + ", " + kArgs(r, 0, colBase, 1, 0) + ", %s);"});
-            }
-            for (int kk = 0; kk < 3; ++kk) legSink(Dm[kk][lc], kk, colBase, 1, 0);
-            for (int rot = 1; rot < 4; ++rot)  // the other legs' versions of this column: exact zeros in this leg's rows
-                for (int kk = 0; kk < 3; ++kk) legSink(AD{0.0}, kk, colBase, 1, rot);
-        }
-    // ---- shared columns: quaternion, base twist, base acceleration; position (zeros) ---------------------------------------------------------------
-    auto sharedColumn = [&](int lc, int col) {
-        P.phaseStarts.push_back(P.slots.size());
-        for (int r = 0; r < 6; ++r) {
-            const AD v = lc >= 0 ? Dm[9 + r][lc] + tape::QuadSum(Dm[3 + r][lc]) : AD{0.0};
-            checkZero(v, r, 0, col, 0, 0);
-            P.slots.push_back({v.Node(), "io.j_base_shared(" + std::to_string(r) + ", " + std::to_string(col) + ", " + std::to_string(kOf[static_cast<std::size_t>(r * kCols + col)]) + ", %s);"});
-        }
-        for (int kk = 0; kk < 3; ++kk) legSink(lc >= 0 ? Dm[kk][lc] : AD{0.0}, kk, col, 0, 0);
+    struct SharedCol {
+        int local, node;
     };
-    for (int k = 0; k < 3; ++k) sharedColumn(-1, k);
-    for (int k = 0; k < 4; ++k) sharedColumn(kQuat + k, 3 + k);
-    for (int k = 0; k < 6; ++k) sharedColumn(kVb + k, 19 + k);
-    for (int k = 0; k < 6; ++k) sharedColumn(kAb + k, 37 + k);
-    (void)inPattern;
+    std::vector<SharedCol> shared;
+    for (int k = 0; k < 3; ++k) shared.push_back({-1, k});  // position: zeros
+    for (int k = 0; k < 4; ++k) shared.push_back({kQuat + k, 3 + k});
+    for (int k = 0; k < 6; ++k) shared.push_back({kVb + k, 19 + k});
+    for (int k = 0; k < 6; ++k) shared.push_back({kAb + k, 37 + k});
+    auto baseOwnSink = [&](int r, int lc, int colBase) {
+        const AD v = Dm[3 + r][lc];  // (f_own does not depend on leg variables)
+        checkZero(v, r, 0, colBase, 1, 0);
+        P.slots.push_back({v.Node(), "io.j_base_own(" + std::to_string(r) + ", " + std::to_string(colBase) + ", " + kArgs(r, 0, colBase, 1, 0) + ", %s);"});
+    };
+    auto baseSharedSink = [&](int r, int lc, int col) {
+        const AD v = lc >= 0 ? Dm[9 + r][lc] + tape::QuadSum(Dm[3 + r][lc]) : AD{0.0};
+        checkZero(v, r, 0, col, 0, 0);
+        P.slots.push_back({v.Node(), "io.j_base_shared(" + std::to_string(r) + ", " + std::to_string(col) + ", " + std::to_string(kOf[static_cast<std::size_t>(r * kCols + col)]) + ", %s);"});
+    };
+    if (!reverse) {
+        // ---- columns owned by this lane's leg, then the shared ones: one phase per column ------------------------------------------------------
+        for (int kind = 0; kind < 3; ++kind)
+            for (int k = 0; k < 3; ++k) {
+                P.phaseStarts.push_back(P.slots.size());
+                const int lc = ownLocal[kind] + k, colBase = ownNode[kind] + k;
+                for (int r = 0; r < 6; ++r) baseOwnSink(r, lc, colBase);
+                for (int kk = 0; kk < 3; ++kk) legSink(Dm[kk][lc], kk, colBase, 1, 0);
+                for (int rot = 1; rot < 4; ++rot)  // the other legs' versions of this column: exact zeros in this leg's rows
+                    for (int kk = 0; kk < 3; ++kk) legSink(AD{0.0}, kk, colBase, 1, rot);
+            }
+        for (const SharedCol& sc : shared) {
+            P.phaseStarts.push_back(P.slots.size());
+            for (int r = 0; r < 6; ++r) baseSharedSink(r, sc.local, sc.node);
+            for (int kk = 0; kk < 3; ++kk) legSink(sc.local >= 0 ? Dm[kk][sc.local] : AD{0.0}, kk, sc.node, 0, 0);
+        }
+    } else {
+        // ---- one phase per row of the local function: the leg's torque rows (top of the leg first), then the base rows --------------------------
+        for (int kk = 2; kk >= 0; --kk) {
+            P.phaseStarts.push_back(P.slots.size());
+            for (const SharedCol& sc : shared) legSink(sc.local >= 0 ? Dm[kk][sc.local] : AD{0.0}, kk, sc.node, 0, 0);
+            for (int kind = 0; kind < 3; ++kind)
+                for (int k = 0; k < 3; ++k) {
+                    legSink(Dm[kk][ownLocal[kind] + k], kk, ownNode[kind] + k, 1, 0);
+                    for (int rot = 1; rot < 4; ++rot) legSink(AD{0.0}, kk, ownNode[kind] + k, 1, rot);
+                }
+        }
+        for (int r = 0; r < 6; ++r) {
+            P.phaseStarts.push_back(P.slots.size());
+            for (const SharedCol& sc : shared) baseSharedSink(r, sc.local, sc.node);
+            for (int kind = 0; kind < 3; ++kind)
+                for (int k = 0; k < 3; ++k) baseOwnSink(r, ownLocal[kind] + k, ownNode[kind] + k);
+        }
+    }
 
     std::vector<AD> roots;
     for (const auto& sl : P.slots) roots.push_back(AD::FromId(sl.value));

@@ -38,8 +38,8 @@ extern "C" int ungar_amd_launch_anymal_rnea(int mode, const ungar_amd::kernels::
         if (streaming) hipLaunchKernelGGL((QuadRneaKernel<Q::kLdsSlots, Q::kLdsUniformSlots, false, true, AnymalRneaQuadBody>), grid, block, 0, s, *a, ctab, body);
         else hipLaunchKernelGGL((QuadRneaKernel<Q::kLdsSlots, Q::kLdsUniformSlots, false, false, AnymalRneaQuadBody>), grid, block, 0, s, *a, ctab, body);
     } else {
-        if (streaming) hipLaunchKernelGGL((QuadRneaKernel<Q::kLdsSlots, Q::kLdsUniformSlots, true, true, AnymalRneaQuadBody>), grid, block, 0, s, *a, ctab, body);
-        else hipLaunchKernelGGL((QuadRneaKernel<Q::kLdsSlots, Q::kLdsUniformSlots, true, false, AnymalRneaQuadBody>), grid, block, 0, s, *a, ctab, body);
+        if (streaming) hipLaunchKernelGGL((QuadRneaKernel<Q::kLdsSlots, Q::kLdsUniformSlots, true, true, AnymalRneaQuadBody, Q::SparsePlan>), grid, block, 0, s, *a, ctab, body);
+        else hipLaunchKernelGGL((QuadRneaKernel<Q::kLdsSlots, Q::kLdsUniformSlots, true, false, AnymalRneaQuadBody, Q::SparsePlan>), grid, block, 0, s, *a, ctab, body);
     }
     return static_cast<int>(hipGetLastError());
 }

@@ -12,7 +12,9 @@
 namespace ungar_amd::kernels {
 
 /// SPARSE: the Jacobian operand is the CSR value array of the model's pattern (every sink carries its index per leg, -1 = structural zero).
-template <bool SPARSE, bool STREAM>
+/// PLAN (generated: gen::anymal_rnea_quad::SparsePlan): the distinct per-leg index patterns k_L - k_0 of the sparse sinks; one per-lane base
+/// pointer per pattern makes a sparse store (lane pointer) + (wave-uniform offset) like a dense one (quad_kernel.hpp).
+template <bool SPARSE, bool STREAM, class PLAN = NoSparsePlan>
 struct QuadRneaIO {
     const double* __restrict__ xb;
     const double* __restrict__ ub;
@@ -28,6 +30,7 @@ struct QuadRneaIO {
     const double (*ctab)[4];
     double* lds;
     double* ldsu;
+    double* jS[PLAN::kCount > 0 ? PLAN::kCount : 1];  // sparse mode: per-lane base pointer of every index pattern
 
     __device__ __forceinline__ double qb(int i) const { return xb[i * xe]; }
     __device__ __forceinline__ double vb(int i) const { return xb[(19 + i) * xe]; }
@@ -36,7 +39,11 @@ struct QuadRneaIO {
     __device__ __forceinline__ double vl(int i) const { return xb[(25 + 3 * L + i) * xe]; }
     __device__ __forceinline__ double al(int i) const { return ub[(6 + 3 * L + i) * ue]; }
     __device__ __forceinline__ double c(int k) const { return ctab[k][L]; }
+#ifndef UNGAR_QUAD_NO_PHASE_BARRIER
     __device__ __forceinline__ void phase() const { __builtin_amdgcn_sched_barrier(0); }
+#else
+    __device__ __forceinline__ void phase() const {}
+#endif
     __device__ __forceinline__ void keep(double) const {}
     __device__ __forceinline__ double ld(int slot) const { return lds[slot * 64]; }
     __device__ __forceinline__ void st(int slot, double v) const { lds[slot * 64] = v; }
@@ -55,6 +62,14 @@ struct QuadRneaIO {
     }
     __device__ __forceinline__ void j_sparse(int k0, int k1, int k2, int k3, double v) const {
         if (k0 < 0 && k1 < 0 && k2 < 0 && k3 < 0) return;  // literal arguments: folds away at compile time
+        if (k0 >= 0 && k1 >= 0 && k2 >= 0 && k3 >= 0) {
+#pragma unroll
+            for (int p = 0; p < PLAN::kCount; ++p)  // literal arguments, constexpr table: exactly one branch survives
+                if (k1 - k0 == PLAN::kDeltas[p][1] && k2 - k0 == PLAN::kDeltas[p][2] && k3 - k0 == PLAN::kDeltas[p][3]) {
+                    Put(jS[p] + static_cast<unsigned>(k0) * je, v);
+                    return;
+                }
+        }
         const int k = L == 0 ? k0 : L == 1 ? k1 : L == 2 ? k2 : k3;
         if (k0 >= 0 && k1 >= 0 && k2 >= 0 && k3 >= 0) Put(jb + static_cast<unsigned>(k) * je, v);
         else if (k >= 0) Put(jb + static_cast<unsigned>(k) * je, v);
@@ -78,7 +93,7 @@ struct QuadRneaIO {
 };
 
 /// One wavefront per workgroup, 16 configurations per wavefront.
-template <int LDS_SLOTS, int LDS_USLOTS, bool SPARSE, bool STREAM, class Body>
+template <int LDS_SLOTS, int LDS_USLOTS, bool SPARSE, bool STREAM, class Body, class PLAN = NoSparsePlan>
 __global__ __launch_bounds__(64) void QuadRneaKernel(const NodeLaunch a, const double (*ctab)[4], Body body) {
     __shared__ double lds[(LDS_SLOTS > 0 ? LDS_SLOTS : 1) * 64 + (LDS_USLOTS > 0 ? LDS_USLOTS : 1) * 16];
     const int L = (threadIdx.x >> 2) & 3;
@@ -94,7 +109,7 @@ __global__ __launch_bounds__(64) void QuadRneaKernel(const NodeLaunch a, const d
     double* const jb = a.jac.base + b * a.jac.bs + k * a.jac.ks;
     const long long je = a.jac.es;
     double* const jLeg = jb + 3LL * L * 55 * je;
-    QuadRneaIO<SPARSE, STREAM> io{a.x.base + b * a.x.bs + k * a.x.ks,
+    QuadRneaIO<SPARSE, STREAM, PLAN> io{a.x.base + b * a.x.bs + k * a.x.ks,
                                   a.u.base + b * a.u.bs + k * a.u.ks,
                                   fb,
                                   jb,
@@ -109,7 +124,12 @@ __global__ __launch_bounds__(64) void QuadRneaKernel(const NodeLaunch a, const d
                                   fb ? fb + 3LL * L * a.f.es : nullptr,
                                   ctab,
                                   lds + threadIdx.x,
-                                  lds + (LDS_SLOTS > 0 ? LDS_SLOTS : 1) * 64 + nodeInWave};
+                                  lds + (LDS_SLOTS > 0 ? LDS_SLOTS : 1) * 64 + nodeInWave,
+                                  {}};
+    if constexpr (SPARSE) {
+#pragma unroll
+        for (int p = 0; p < PLAN::kCount; ++p) io.jS[p] = jb + static_cast<long long>(PLAN::kDeltas[p][L]) * je;
+    }
     body(io);
 }
 
