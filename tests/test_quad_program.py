@@ -103,3 +103,28 @@ def test_joint_torque_quad_program_matches_golden(repo_root, rnea_sim):
         mask = np.zeros((18, 55), dtype=bool)
         mask[rows, cols] = True
         assert np.all(J[~mask] == 0.0)
+
+
+def test_inertia_matrix_quad_program_matches_golden(repo_root, tmp_path_factory):
+    """The lane-per-leg program of M(q) and d M / d q (csrc/codegen/quad_crba_program.hpp) in the 4-lane simulator: all 324 entries of M written
+    (zeros between different legs included) and equal to the oracle's fixture; the CSR values of d M / d q, scattered through the per-leg indices of
+    the sinks, cover the model's pattern completely and equal the fixture's dense block gathered through it."""
+    import ungar_amd
+    gen = os.path.join(repo_root, "ungar_amd", "csrc", "gen", "anymal_crba_quad_gen.hpp")
+    if not os.path.exists(gen):
+        pytest.skip("generated inertia-matrix quad program missing: run __graft_entry__.build()")
+    lib = str(tmp_path_factory.mktemp("quad_crba") / "libquad_crba_sim.so")
+    subprocess.run(["g++", "-std=c++20", "-O0", "-shared", "-fPIC", "-I", os.path.dirname(gen), "-o", lib, os.path.join(repo_root, "tests", "cpp", "quad_crba_sim.cpp")], check=True)
+    sim = ctypes.CDLL(lib)
+    g = np.load(f"{repo_root}/tests/golden/rbd_anymal_crba.npz")
+    rows, cols = (a.astype(int) for a in ungar_amd.NodeModel("anymal_crba").jacobian_sparsity())
+    nnz = cols.size
+    dp = ctypes.POINTER(ctypes.c_double)
+    for b in range(g["x"].shape[0]):
+        x = np.ascontiguousarray(g["x"][b])
+        y, Js = np.zeros(324), np.zeros(nnz)
+        sim.anymal_crba_quad_sim(x.ctypes.data_as(dp), y.ctypes.data_as(dp), Js.ctypes.data_as(dp), ctypes.c_int(nnz))
+        assert not np.isnan(y).any() and not np.isnan(Js).any(), "an entry of M or of the pattern was never written"
+        J = g["J"][b].reshape(324, 19)
+        assert np.abs(y - g["y"][b]).max() <= 1e-12 * np.abs(g["y"][b]).max()
+        assert np.abs(Js - J[rows, cols]).max() <= 1e-12 * np.abs(J).max()

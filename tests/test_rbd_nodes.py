@@ -200,3 +200,37 @@ def test_joint_torque_jacobians_at_scale_lane_per_leg():
     fd = ((yp - ym) / (2 * h)).t()
     jd = torch.bmm(J[:, :, :37], d.t().unsqueeze(2)).squeeze(2)
     assert (fd - jd).abs().max().item() <= 2e-6 * max(1.0, jd.abs().max().item())
+
+
+@pytest.mark.gpu
+def test_inertia_matrix_jacobian_at_scale_lane_per_leg():
+    """The CSR Jacobian mode of 'anymal_crba' runs the lane-per-leg program (quad_crba_kernel.hpp): 65 531 configurations in one launch; M equals the
+    value-only (lane-per-node) kernel's, and d M / d q applied to a random direction matches central differences of the value kernel at EVERY configuration."""
+    import torch
+    import ungar_amd
+    count = 65531
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(12)
+    r = lambda n: torch.rand((n, count), generator=gen, device="cuda", dtype=torch.float64) * 2 - 1  # noqa: E731
+    quat = torch.randn((4, count), generator=gen, device="cuda", dtype=torch.float64)
+    q = torch.cat((r(3), quat / quat.norm(dim=0, keepdim=True), r(12)))
+    Op = ungar_amd.Operand
+    m = ungar_amd.NodeModel("anymal_crba")
+    rows, cols = (torch.as_tensor(t.astype(np.int64), device="cuda") for t in m.jacobian_sparsity())
+    M0 = torch.full((324, count), float("nan"), dtype=torch.float64, device="cuda")
+    m.forward_zero(count, Op.soa(q, count), None, None, None, Op.soa(M0, count))
+    M1, Js = torch.full_like(M0, float("nan")), torch.full((m.jac_nnz, count), float("nan"), dtype=torch.float64, device="cuda")
+    m.sparse_jacobian(count, Op.soa(q, count), None, None, None, Op.soa(M1, count), Op.soa(Js, count))
+    torch.cuda.synchronize()
+    assert torch.isfinite(Js).all()
+    assert (M1 - M0).abs().max().item() <= 1e-12 * M0.abs().max().item()
+    d = r(19)
+    h = 1e-6
+    Mp, Mm = torch.empty_like(M0), torch.empty_like(M0)
+    m.forward_zero(count, Op.soa(q + h * d, count), None, None, None, Op.soa(Mp, count))
+    m.forward_zero(count, Op.soa(q - h * d, count), None, None, None, Op.soa(Mm, count))
+    torch.cuda.synchronize()
+    fd = (Mp - Mm) / (2 * h)                       # (324, count)
+    jd = torch.zeros_like(fd)
+    jd.index_add_(0, rows, Js * d[cols])           # sum over the pattern entries of every row
+    assert (fd - jd).abs().max().item() <= 2e-6 * max(1.0, jd.abs().max().item())

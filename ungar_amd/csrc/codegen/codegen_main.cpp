@@ -21,6 +21,7 @@
 #include "../rbd/rnea_crba.hpp"
 #include "../tape/emit.hpp"
 #include "quad_leg_program.hpp"
+#include "quad_crba_program.hpp"
 #include "quad_rnea_program.hpp"
 
 using namespace ungar_amd;
@@ -445,6 +446,7 @@ int main(int argc, char** argv) {
     int quadPrefetch = 48;            // LDS loads are hoisted this many statements ahead of their first use ...
     bool quadPrefetchAcross = false;  // ... and may cross into the tail of the previous phase
     int quadUniformSlots = 80;  // compact (one copy per quad) LDS slots; budget: quadLdsSlots + quadUniformSlots / 4 <= 80
+    int crbaQuadLdsSlots = 40;  // LDS home of the lane-per-leg inertia-matrix program
     bool rneaQuadReverse = true;  // partials of the lane-local function by reverse accumulation, one phase per row (measured: 11 % faster than forward / per column)
     int rneaQuadLdsSlots = 60, rneaQuadUniformSlots = 80;  // LDS home of the lane-per-leg joint-torque program (same budget)
     int quadLdsSlots = 60;  // 64-lane workgroups, four per CU: 160 KiB / 4 / 64 lanes / 8 B
@@ -608,17 +610,22 @@ int main(int argc, char** argv) {
         const int slots = rbdLdsSlots >= 0 && s.phasedLdsSlots > 0 ? rbdLdsSlots : s.phasedLdsSlots;
         EmitHip(g, outDir, false, slots, slots > 0 ? 4 : rematConsumers, slots > 0 ? 4 : rematDepth, prefetch, g.jacMode == 2);
         if (!cDir.empty()) EmitC(g, cDir);
-        if (std::string(s.dims.name) == "anymal_rnea") {  // lane-per-leg SPMD program: what the Jacobian modes of this model launch
-            const codegen::QuadProgram qp = codegen::RecordQuadRneaProgram(anymal, g.jac, rneaQuadReverse);
+        const std::string sname = s.dims.name;
+        if (sname == "anymal_rnea" || sname == "anymal_crba") {  // lane-per-leg SPMD programs: what the Jacobian modes of these models launch
+            const bool rnea = sname == "anymal_rnea";
+            const codegen::QuadProgram qp = rnea ? codegen::RecordQuadRneaProgram(anymal, g.jac, rneaQuadReverse) : codegen::RecordQuadCrbaProgram(anymal, g.jac);
             tape::EmitStats qs;
             int quadLds = 0, quadUniformUsed = 0;
-            const std::string fn = codegen::EmitQuadProgram(qp, "ValueJacobianQuad", &qs, true, rneaQuadLdsSlots, &quadLds, quadRematConsumers, quadRematDepth, quadPrefetch, rneaQuadUniformSlots, &quadUniformUsed, false);
+            const std::string fn = rnea ? codegen::EmitQuadProgram(qp, "ValueJacobianQuad", &qs, true, rneaQuadLdsSlots, &quadLds, quadRematConsumers, quadRematDepth, quadPrefetch, rneaQuadUniformSlots,
+                                                                   &quadUniformUsed, false)
+                                        : codegen::EmitQuadProgram(qp, "ValueJacobianQuad", &qs, true, crbaQuadLdsSlots, &quadLds, quadRematConsumers, quadRematDepth, quadPrefetch, 0, &quadUniformUsed, false);
+            const std::string ns = sname + "_quad";
             std::ostringstream qo;
-            qo << "// GENERATED by ungar_amd/csrc/codegen (quad_rnea_program.hpp) -- do not edit.\n"
-               << "// ANYmal B joint torques and their derivatives, one lane per leg: " << qs.statements << " statements, " << qs.flops << " flops, "
+            qo << "// GENERATED by ungar_amd/csrc/codegen (" << (rnea ? "quad_rnea_program.hpp" : "quad_crba_program.hpp") << ") -- do not edit.\n"
+               << "// ANYmal B " << (rnea ? "joint torques" : "joint-space inertia matrix") << " and derivatives, one lane per leg: " << qs.statements << " statements, " << qs.flops << " flops, "
                << qs.transcendentals << " transcendentals, " << qs.divisions << " divisions per lane.\n"
                << "#pragma once\n#ifndef __host__\n#define __host__\n#endif\n#ifndef __device__\n#define __device__\n#endif\n\n"
-               << "namespace ungar_amd::gen::anymal_rnea_quad {\n\n"
+               << "namespace ungar_amd::gen::" << ns << " {\n\n"
                << "inline constexpr int kNumConstants = " << qp.constants.size() << ";\n"
                << "inline constexpr int kLdsSlots = " << quadLds << ", kLdsUniformSlots = " << quadUniformUsed << ";\n"
                << "inline constexpr int kJacNnz = " << g.jac.Nnz() << ";  // entries of the sparse (CSR) output\n"
@@ -639,10 +646,11 @@ int main(int argc, char** argv) {
                 }
                 qo << (dev ? "};\n#endif\n\n" : "};\n");
             }
-            qo << fn << "\n}  // namespace ungar_amd::gen::anymal_rnea_quad\n";
-            std::ofstream qf(outDir + "/anymal_rnea_quad_gen.hpp");
+            qo << fn << "\n}  // namespace ungar_amd::gen::" << ns << "\n";
+            std::ofstream qf(outDir + "/" + ns + "_gen.hpp");
             qf << qo.str();
-            std::fprintf(stderr, "[codegen] anymal_rnea_quad (lane per leg): %zu statements, %zu flops per lane, %zu table constants\n", qs.statements, qs.flops, qp.constants.size());
+            std::fprintf(stderr, "[codegen] %s (lane per leg): %zu statements, %zu flops per lane, %zu table constants, %zu index patterns\n", ns.c_str(), qs.statements, qs.flops, qp.constants.size(),
+                         qp.sparseDeltas.size());
         }
     }
     // scalar stage-cost nodes (value + gradient + upper Hessian)
