@@ -128,3 +128,30 @@ def test_inertia_matrix_quad_program_matches_golden(repo_root, tmp_path_factory)
         J = g["J"][b].reshape(324, 19)
         assert np.abs(y - g["y"][b]).max() <= 1e-12 * np.abs(g["y"][b]).max()
         assert np.abs(Js - J[rows, cols]).max() <= 1e-12 * np.abs(J).max()
+
+
+def test_centroidal_momentum_quad_program_matches_golden(repo_root, tmp_path_factory):
+    """The lane-per-leg program of h_G and d h_G / d (q, v) (csrc/codegen/quad_centroidal_program.hpp) in the 4-lane simulator (the skeleton of the
+    joint-torque program, 6 x 37): values, the dense block -- quaternion columns included, which are derivatives OFF the unit sphere and pin the
+    cofactor form of the frame change -- and the CSR values through the per-leg indices, against the oracle's fixture."""
+    import ungar_amd
+    gen = os.path.join(repo_root, "ungar_amd", "csrc", "gen", "anymal_centroidal_quad_gen.hpp")
+    if not os.path.exists(gen):
+        pytest.skip("generated centroidal quad program missing: run __graft_entry__.build()")
+    lib = str(tmp_path_factory.mktemp("quad_centroidal") / "libquad_centroidal_sim.so")
+    subprocess.run(["g++", "-std=c++20", "-O0", "-shared", "-fPIC", "-DQUAD_SIM_CENTROIDAL", "-I", os.path.dirname(gen), "-o", lib,
+                    os.path.join(repo_root, "tests", "cpp", "quad_rnea_sim.cpp")], check=True)
+    sim = ctypes.CDLL(lib)
+    g = np.load(f"{repo_root}/tests/golden/rbd_anymal_centroidal.npz")
+    rows, cols = (a.astype(int) for a in ungar_amd.NodeModel("anymal_centroidal").jacobian_sparsity())
+    nnz = cols.size
+    dp = ctypes.POINTER(ctypes.c_double)
+    for b in range(g["x"].shape[0]):
+        x, u = np.ascontiguousarray(g["x"][b]), np.zeros(1)
+        y, J, Js = np.zeros(6), np.zeros((6, 37)), np.zeros(nnz)
+        sim.anymal_rnea_quad_sim(x.ctypes.data_as(dp), u.ctypes.data_as(dp), y.ctypes.data_as(dp), J.ctypes.data_as(dp), Js.ctypes.data_as(dp), ctypes.c_int(nnz))
+        assert not np.isnan(y).any() and not np.isnan(J).any() and not np.isnan(Js).any()
+        Jg = g["J"][b].reshape(6, 37)
+        assert np.abs(y - g["y"][b]).max() <= 1e-12 * np.abs(g["y"][b]).max()
+        assert np.abs(J - Jg).max() <= 1e-12 * np.abs(Jg).max()
+        assert np.array_equal(Js, J[rows, cols])

@@ -234,3 +234,42 @@ def test_inertia_matrix_jacobian_at_scale_lane_per_leg():
     jd = torch.zeros_like(fd)
     jd.index_add_(0, rows, Js * d[cols])           # sum over the pattern entries of every row
     assert (fd - jd).abs().max().item() <= 2e-6 * max(1.0, jd.abs().max().item())
+
+
+@pytest.mark.gpu
+def test_centroidal_momentum_jacobian_at_scale_lane_per_leg():
+    """The Jacobian modes of 'anymal_centroidal' run the lane-per-leg program: 65 531 configurations, dense block and CSR values; the values equal
+    the value-only (lane-per-node) kernel's, and J (dq, dv) matches central differences of the value kernel along a random direction -- the raw
+    quaternion entries included -- at EVERY configuration."""
+    import torch
+    import ungar_amd
+    count = 65531
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(13)
+    r = lambda n: torch.rand((n, count), generator=gen, device="cuda", dtype=torch.float64) * 2 - 1  # noqa: E731
+    quat = torch.randn((4, count), generator=gen, device="cuda", dtype=torch.float64)
+    x = torch.cat((r(3), quat / quat.norm(dim=0, keepdim=True), r(12), r(18)))
+    Op = ungar_amd.Operand
+    m = ungar_amd.NodeModel("anymal_centroidal")
+    rows, cols = (torch.as_tensor(t.astype(np.int64), device="cuda") for t in m.jacobian_sparsity())
+    y0 = torch.full((6, count), float("nan"), dtype=torch.float64, device="cuda")
+    m.forward_zero(count, Op.soa(x, count), None, None, None, Op.soa(y0, count))
+    yd, Jd = torch.full_like(y0, float("nan")), torch.full((6 * 37, count), float("nan"), dtype=torch.float64, device="cuda")
+    m.dense_jacobian(count, Op.soa(x, count), None, None, None, Op.soa(yd, count), Op.soa(Jd, count))
+    ys, Js = torch.full_like(y0, float("nan")), torch.full((m.jac_nnz, count), float("nan"), dtype=torch.float64, device="cuda")
+    m.sparse_jacobian(count, Op.soa(x, count), None, None, None, Op.soa(ys, count), Op.soa(Js, count))
+    torch.cuda.synchronize()
+    assert torch.isfinite(Jd).all() and torch.isfinite(Js).all()
+    scale = y0.abs().max().item()
+    assert (yd - y0).abs().max().item() <= 1e-12 * scale and (ys - y0).abs().max().item() <= 1e-12 * scale
+    J = Jd.t().reshape(count, 6, 37)
+    assert (Js.t() - J[:, rows, cols]).abs().max().item() <= 1e-12 * J.abs().max().item()
+    d = r(37)
+    h = 1e-6
+    yp, ym = torch.empty_like(y0), torch.empty_like(y0)
+    m.forward_zero(count, Op.soa(x + h * d, count), None, None, None, Op.soa(yp, count))
+    m.forward_zero(count, Op.soa(x - h * d, count), None, None, None, Op.soa(ym, count))
+    torch.cuda.synchronize()
+    fd = ((yp - ym) / (2 * h)).t()
+    jd = torch.bmm(J, d.t().unsqueeze(2)).squeeze(2)
+    assert (fd - jd).abs().max().item() <= 2e-6 * max(1.0, jd.abs().max().item())

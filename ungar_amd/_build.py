@@ -64,7 +64,7 @@ def generate(exe: str):
     edit to the generator recompiles just the kernels it affects (a from-scratch library build takes ~6 minutes)."""
     import filecmp
     import shutil
-    outs = [os.path.join(GEN, f"{m}_gen.hpp") for m in MODELS + ("quadrotor_cost", "srbd_cost", "rc_car_cost", "anymal_cost", "anymal_quad", "anymal_rnea_quad", "anymal_crba_quad")] + [os.path.join(ORACLE_GEN, f"{m}_cg.c") for m in C_MODELS]
+    outs = [os.path.join(GEN, f"{m}_gen.hpp") for m in MODELS + ("quadrotor_cost", "srbd_cost", "rc_car_cost", "anymal_cost", "anymal_quad", "anymal_rnea_quad", "anymal_crba_quad", "anymal_centroidal_quad")] + [os.path.join(ORACLE_GEN, f"{m}_cg.c") for m in C_MODELS]
     robot = os.path.join(ROOT, "ungar_amd", "data", "anymal_b.robot")
     stamp = os.path.join(BUILD, "codegen.stamp")
     if _newer(outs + [stamp], [exe, robot]):
@@ -98,8 +98,9 @@ def build_library(jobs: int | None = None):
         deps = [src, kernel_hdr, os.path.join(GEN, f"{m}_gen.hpp")]
         if m == "anymal":
             deps += quad_deps
-        if m in ("anymal_rnea", "anymal_crba"):  # lane-per-leg programs of the joint torques / the inertia matrix
-            deps += [os.path.join(CSRC, "kernels", "quad_kernel.hpp"), os.path.join(CSRC, "kernels", f"quad_{m[7:]}_kernel.hpp"), os.path.join(GEN, f"{m}_quad_gen.hpp")]
+        if m in ("anymal_rnea", "anymal_crba", "anymal_centroidal"):  # lane-per-leg programs of the joint torques / the inertia matrix / the centroidal momentum
+            skeleton = "quad_crba_kernel.hpp" if m == "anymal_crba" else "quad_rnea_kernel.hpp"
+            deps += [os.path.join(CSRC, "kernels", "quad_kernel.hpp"), os.path.join(CSRC, "kernels", skeleton), os.path.join(GEN, f"{m}_quad_gen.hpp")]
         units.append((src, os.path.join(BUILD, f"model_{m}.o"), deps))
     for name in sorted(os.listdir(os.path.join(CSRC, "kernels"))):
         if name.endswith(".hip") and not name.startswith("model_"):

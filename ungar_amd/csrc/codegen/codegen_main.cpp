@@ -21,6 +21,7 @@
 #include "../rbd/rnea_crba.hpp"
 #include "../tape/emit.hpp"
 #include "quad_leg_program.hpp"
+#include "quad_centroidal_program.hpp"
 #include "quad_crba_program.hpp"
 #include "quad_rnea_program.hpp"
 
@@ -611,18 +612,20 @@ int main(int argc, char** argv) {
         EmitHip(g, outDir, false, slots, slots > 0 ? 4 : rematConsumers, slots > 0 ? 4 : rematDepth, prefetch, g.jacMode == 2);
         if (!cDir.empty()) EmitC(g, cDir);
         const std::string sname = s.dims.name;
-        if (sname == "anymal_rnea" || sname == "anymal_crba") {  // lane-per-leg SPMD programs: what the Jacobian modes of these models launch
-            const bool rnea = sname == "anymal_rnea";
-            const codegen::QuadProgram qp = rnea ? codegen::RecordQuadRneaProgram(anymal, g.jac, rneaQuadReverse) : codegen::RecordQuadCrbaProgram(anymal, g.jac);
+        if (sname == "anymal_rnea" || sname == "anymal_crba" || sname == "anymal_centroidal") {  // lane-per-leg SPMD programs: what the Jacobian modes of these models launch
+            const bool rnea = sname == "anymal_rnea", crba = sname == "anymal_crba";
+            const codegen::QuadProgram qp = rnea   ? codegen::RecordQuadRneaProgram(anymal, g.jac, rneaQuadReverse)
+                                            : crba ? codegen::RecordQuadCrbaProgram(anymal, g.jac)
+                                                   : codegen::RecordQuadCentroidalProgram(anymal, g.jac);
             tape::EmitStats qs;
             int quadLds = 0, quadUniformUsed = 0;
-            const std::string fn = rnea ? codegen::EmitQuadProgram(qp, "ValueJacobianQuad", &qs, true, rneaQuadLdsSlots, &quadLds, quadRematConsumers, quadRematDepth, quadPrefetch, rneaQuadUniformSlots,
-                                                                   &quadUniformUsed, false)
-                                        : codegen::EmitQuadProgram(qp, "ValueJacobianQuad", &qs, true, crbaQuadLdsSlots, &quadLds, quadRematConsumers, quadRematDepth, quadPrefetch, 0, &quadUniformUsed, false);
+            const std::string fn = crba ? codegen::EmitQuadProgram(qp, "ValueJacobianQuad", &qs, true, crbaQuadLdsSlots, &quadLds, quadRematConsumers, quadRematDepth, quadPrefetch, 0, &quadUniformUsed, false)
+                                        : codegen::EmitQuadProgram(qp, "ValueJacobianQuad", &qs, true, rneaQuadLdsSlots, &quadLds, quadRematConsumers, quadRematDepth, quadPrefetch, rneaQuadUniformSlots,
+                                                                   &quadUniformUsed, false);
             const std::string ns = sname + "_quad";
             std::ostringstream qo;
-            qo << "// GENERATED by ungar_amd/csrc/codegen (" << (rnea ? "quad_rnea_program.hpp" : "quad_crba_program.hpp") << ") -- do not edit.\n"
-               << "// ANYmal B " << (rnea ? "joint torques" : "joint-space inertia matrix") << " and derivatives, one lane per leg: " << qs.statements << " statements, " << qs.flops << " flops, "
+            qo << "// GENERATED by ungar_amd/csrc/codegen (" << (rnea ? "quad_rnea_program.hpp" : crba ? "quad_crba_program.hpp" : "quad_centroidal_program.hpp") << ") -- do not edit.\n"
+               << "// ANYmal B " << (rnea ? "joint torques" : crba ? "joint-space inertia matrix" : "centroidal momentum") << " and derivatives, one lane per leg: " << qs.statements << " statements, " << qs.flops << " flops, "
                << qs.transcendentals << " transcendentals, " << qs.divisions << " divisions per lane.\n"
                << "#pragma once\n#ifndef __host__\n#define __host__\n#endif\n#ifndef __device__\n#define __device__\n#endif\n\n"
                << "namespace ungar_amd::gen::" << ns << " {\n\n"

@@ -3,6 +3,7 @@
 // quad_kernel.hpp (lane = 4 * leg + node % 4 inside each 16-lane DPP row: the legs of a node meet through row_ror, and 4 adjacent lanes
 // hold the same leg of 4 consecutive nodes, so unit-fastest stores run 32 bytes contiguous).
 //   y (18): rows 0..5 base wrench, 6 + 3 L + k leg torques;   J (18 x 55): columns x = [p | quat | q_leg | v_b | v_leg], u = [a_b | a_leg].
+// The centroidal-momentum program (csrc/codegen/quad_centroidal_program.hpp: 6 base rows x 37 columns of x) runs in the same skeleton.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -14,7 +15,8 @@ namespace ungar_amd::kernels {
 /// SPARSE: the Jacobian operand is the CSR value array of the model's pattern (every sink carries its index per leg, -1 = structural zero).
 /// PLAN (generated: gen::anymal_rnea_quad::SparsePlan): the distinct per-leg index patterns k_L - k_0 of the sparse sinks; one per-lane base
 /// pointer per pattern makes a sparse store (lane pointer) + (wave-uniform offset) like a dense one (quad_kernel.hpp).
-template <bool SPARSE, bool STREAM, class PLAN = NoSparsePlan>
+/// COLS: columns of the node's dense Jacobian block (55 joint torques; 37 centroidal momentum, whose six rows are all base rows).
+template <bool SPARSE, bool STREAM, class PLAN = NoSparsePlan, int COLS = 55>
 struct QuadRneaIO {
     const double* __restrict__ xb;
     const double* __restrict__ ub;
@@ -76,24 +78,24 @@ struct QuadRneaIO {
     }
     __device__ __forceinline__ void j_leg(int rowBase, int colBase, int legMul, int rot, int k0, int k1, int k2, int k3, double v) const {
         if constexpr (SPARSE) j_sparse(k0, k1, k2, k3, v);
-        else Put((legMul ? jLegCol[rot] : jLeg) + static_cast<unsigned>(rowBase * 55 + colBase) * je, v);
+        else Put((legMul ? jLegCol[rot] : jLeg) + static_cast<unsigned>(rowBase * COLS + colBase) * je, v);
     }
     __device__ __forceinline__ void j_base_own(int row, int colBase, int k0, int k1, int k2, int k3, double v) const {
         if constexpr (SPARSE) j_sparse(k0, k1, k2, k3, v);
-        else Put(jOwnCol + static_cast<unsigned>(row * 55 + colBase) * je, v);
+        else Put(jOwnCol + static_cast<unsigned>(row * COLS + colBase) * je, v);
     }
     // shared columns: the four lanes hold the same value and store it to the same address (merged inside the instruction)
     __device__ __forceinline__ void j_base_shared(int row, int col, int k, double v) const {
         if constexpr (SPARSE) {
             if (k >= 0) Put(jb + static_cast<unsigned>(k) * je, v);
         } else {
-            Put(jb + static_cast<unsigned>(row * 55 + col) * je, v);
+            Put(jb + static_cast<unsigned>(row * COLS + col) * je, v);
         }
     }
 };
 
 /// One wavefront per workgroup, 16 configurations per wavefront.
-template <int LDS_SLOTS, int LDS_USLOTS, bool SPARSE, bool STREAM, class Body, class PLAN = NoSparsePlan>
+template <int LDS_SLOTS, int LDS_USLOTS, bool SPARSE, bool STREAM, class Body, class PLAN = NoSparsePlan, int COLS = 55>
 __global__ __launch_bounds__(64) void QuadRneaKernel(const NodeLaunch a, const double (*ctab)[4], Body body) {
     __shared__ double lds[(LDS_SLOTS > 0 ? LDS_SLOTS : 1) * 64 + (LDS_USLOTS > 0 ? LDS_USLOTS : 1) * 16];
     const int L = (threadIdx.x >> 2) & 3;
@@ -108,8 +110,8 @@ __global__ __launch_bounds__(64) void QuadRneaKernel(const NodeLaunch a, const d
     double* const fb = a.f.base ? a.f.base + b * a.f.bs + k * a.f.ks : nullptr;
     double* const jb = a.jac.base + b * a.jac.bs + k * a.jac.ks;
     const long long je = a.jac.es;
-    double* const jLeg = jb + 3LL * L * 55 * je;
-    QuadRneaIO<SPARSE, STREAM, PLAN> io{a.x.base + b * a.x.bs + k * a.x.ks,
+    double* const jLeg = jb + 3LL * L * COLS * je;
+    QuadRneaIO<SPARSE, STREAM, PLAN, COLS> io{a.x.base + b * a.x.bs + k * a.x.ks,
                                   a.u.base + b * a.u.bs + k * a.u.ks,
                                   fb,
                                   jb,
