@@ -33,6 +33,10 @@ cp_if gpurun_out/fp64_peaks.log               profiles/${tag}_fp64_peaks.log
 cp_if gpurun_out/prewarm.log                  profiles/${tag}_prewarm.log
 cp_if gpurun_out/gn_shapes.json                profiles/${tag}_gn_shapes.json
 cp_if gpurun_out/rbd_nodes.json                profiles/${tag}_rbd_nodes.json
+cp_if gpurun_out/rbd_nodes_81920.json          profiles/${tag}_rbd_nodes_81920.json
+cp_if gpurun_out/rbd_nodes_262144.json         profiles/${tag}_rbd_nodes_262144.json
+cp_if gpurun_out/rbd_nodes_lane_per_node.json  profiles/${tag}_rbd_nodes_lane_per_node.json
+cp_if "$(ls gpurun_out/rbd_prof/*/rbd_kernel_stats.csv gpurun_out/rbd_prof/rbd_kernel_stats.csv 2>/dev/null | head -1)" profiles/${tag}_rbd_nodes_kernel_stats.csv
 cp_if gpurun_out/layouts_all.log              profiles/${tag}_layouts_all.log
 cp_if gpurun_out/sqp_anymal.json              profiles/${tag}_sqp_anymal_timing.json
 cp_if gpurun_out/sqp_bench.log                profiles/${tag}_sqp_quadrotor_timing.json

@@ -35,6 +35,10 @@ bash tools/gpu_gn_tiles_profile.sh 2>&1 | tail -24
 tools/_bin/gn_tiles_bench 2>&1 | tail -4 | tee gpurun_out/gn_tiles_ablation.log
 timeout 300 python tools/bench_gn_shapes.py 2>/dev/null | tail -1 > gpurun_out/gn_shapes.json
 timeout 300 python tools/bench_rbd_nodes.py 2>/dev/null | tail -1 > gpurun_out/rbd_nodes.json
+timeout 300 python tools/bench_rbd_nodes.py 81920 2>/dev/null | tail -1 > gpurun_out/rbd_nodes_81920.json
+timeout 300 python tools/bench_rbd_nodes.py 262144 2>/dev/null | tail -1 > gpurun_out/rbd_nodes_262144.json
+UNGAR_AMD_RNEA_LANE_PER_NODE=1 UNGAR_AMD_CRBA_LANE_PER_NODE=1 UNGAR_AMD_CENTROIDAL_LANE_PER_NODE=1 timeout 300 python tools/bench_rbd_nodes.py 2>/dev/null | tail -1 > gpurun_out/rbd_nodes_lane_per_node.json
+rm -rf gpurun_out/rbd_prof; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/rbd_prof -o rbd -- python tools/bench_rbd_nodes.py > /dev/null 2>&1
 for m in anymal quadrotor rc_car; do timeout 300 python tools/bench_layouts.py $m $([ $m = anymal ] && echo 81920 || ([ $m = quadrotor ] && echo 524288 || echo 3276800)) 2>/dev/null | tail -1; done > gpurun_out/layouts_all.log
 tools/_bin/valu_f64_peak 2>&1 | tail -5 | tee gpurun_out/fp64_peaks.log; tools/_bin/mfma_f64_peak 2>&1 | tail -1 | tee -a gpurun_out/fp64_peaks.log
 timeout 300 python tools/bench_layouts.py 2>&1 | tail -3 > gpurun_out/layouts.log
