@@ -310,6 +310,183 @@ struct DeviceExec {
         LdsBarrier();
     }
 
+    // ---- R = H_uu = L D L^T and the gains, BLOCKED, trailing updates on the matrix cores (four-wavefront kernels, NU a multiple of 4) -----------
+    // The column-by-column L D L^T of ocp_riccati.hpp is 2 NU + 1 barrier phases, and four workgroups share a CU: the wall-clock of a phase is
+    // its critical-path instruction count times ~12 cycles, 40 k cycles per knot for NU = 24.  Same factorisation, 4 x 4 blocks:
+    //   P_b  (one phase)  every lane of wavefront 0 factorises the diagonal block itself (registers; redundant work is free, serial
+    //        instructions are not); lanes 0..31, one per ROW from the block down, forward-substitute their four panel entries (unscaled
+    //        columns L d, as the column-wise route stores them), lanes 32.., one per right-hand side, the block's rows of K;
+    //   T_b  (one phase)  R_22 -= (L_21 d) D^-1 (L_21 d)^T and K_2 -= (L_21 d) D^-1 K_b: one v_mfma_f64_16x16x4_f64 per 16 x 16 tile,
+    //        C tile LDS -> accumulator -> LDS (nothing stays in registers across phases);
+    //   backwards  B1_b  x_b = D^-1 y_b - L_bb^T-part (one lane per right-hand side; the scaling of the column-wise route folded in),
+    //              B2_b  K_above -= (L_b,above d)^T x_b on the matrix cores.
+    // 4 NU / 4 - 1 = 23 phases for NU = 24, ~1.5 k critical-path instructions instead of ~3.3 k.  The arithmetic is the L D L^T's (same pivots,
+    // IEEE reciprocals; only the association inside a rank-4 update differs), so the accuracy is the column-wise route's (tests).
+#ifndef UNGAR_RICCATI_NO_BLOCKED_LDLT
+    static constexpr bool kFactorBlocked = BLOCK == 256;
+#else
+    static constexpr bool kFactorBlocked = false;
+#endif
+    /// Returns true if a pivot was not positive (replaced by 1).  K (NU x (NX + 1)) and gainsK (global, same layout) receive [K | kff]; piv: NU
+    /// doubles (reciprocal pivots); the lower triangle of the H_uu block of H is overwritten by the unscaled columns of L.  Closes with a barrier.
+    template <int NX, int NU>
+    __device__ __forceinline__ bool FactorGainsBlocked(double* H, const double* h, double* K, double* piv, double* gainsK) {
+        constexpr int n = NX + NU, nk = NX + 1, STEPS = NU / 4, TCK = (nk + 15) / 16;
+        static_assert(NU % 4 == 0 && NU <= 32 && nk <= 32, "two row tiles of trailing rows; rows and right-hand sides share one wavefront");
+        const int tid = static_cast<int>(threadIdx.x), lane = tid & 63, li = lane & 15, lk = lane >> 4, w = Wave();
+        double* R = H + NX * n + NX;  // R[i][j], j <= i, at R[i * n + j]
+        for (int idx = tid; idx < NU * nk; idx += BLOCK) {
+            const int i = static_cast<int>((static_cast<float>(idx) + 0.5f) * (1.0f / static_cast<float>(nk))), c = idx - i * nk;
+            K[idx] = c < NX ? -H[(NX + i) * n + c] : -h[NX + i];
+        }
+        LdsBarrier();
+        bool bad = false;
+        // L D L^T of the 4 x 4 diagonal block at J0 (lower triangle read): reciprocal pivots and unit-lower entries
+        struct Block {
+            double i0, i1, i2, i3, l10, l20, l21, l30, l31, l32;
+        };
+        auto factorBlock = [&](int J0) {
+            const double* D = R + J0 * n + J0;
+            const double d00 = D[0], d10 = D[n], d11 = D[n + 1], d20 = D[2 * n], d21 = D[2 * n + 1], d22 = D[2 * n + 2], d30 = D[3 * n], d31 = D[3 * n + 1], d32 = D[3 * n + 2],
+                         d33 = D[3 * n + 3];
+            auto reciprocal = [&](double d) {
+                const bool neg = !(d > 0.0);
+                bad = bad || neg;
+                return 1.0 / (neg ? 1.0 : d);
+            };
+            Block B;
+            B.i0 = reciprocal(d00);
+            B.l10 = d10 * B.i0;
+            B.l20 = d20 * B.i0;
+            B.l30 = d30 * B.i0;
+            B.i1 = reciprocal(d11 - d10 * B.l10);
+            const double u21 = d21 - d20 * B.l10, u31 = d31 - d30 * B.l10;
+            B.l21 = u21 * B.i1;
+            B.l31 = u31 * B.i1;
+            B.i2 = reciprocal(d22 - d20 * B.l20 - u21 * B.l21);
+            const double u32 = d32 - d30 * B.l20 - u31 * B.l21;
+            B.l32 = u32 * B.i2;
+            B.i3 = reciprocal(d33 - d30 * B.l30 - u31 * B.l31 - u32 * B.l32);
+            return B;
+        };
+        // one rank-4 update of a 16 x 16 tile of C (leading dimension ldc, rows r0.., columns c0.., valid below rowEnd / colEnd):
+        //   C[r][c] += sum_k A(r, k) B(k, c);  A and B return 0 outside their ranges
+        auto updateTile = [&](double* C, int ldc, int r0, int rowEnd, int c0, int colEnd, auto A, auto Bop) {
+            f64x4 acc;
+            const int col = c0 + li, cc = col < colEnd ? col : colEnd - 1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = r0 + lk + 4 * r, rc = row < rowEnd ? row : rowEnd - 1;
+                acc[r] = C[rc * ldc + cc];
+            }
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A(r0 + li, lk), Bop(lk, c0 + li), acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = r0 + lk + 4 * r;
+                if (row < rowEnd && col < colEnd) C[row * ldc + col] = acc[r];
+            }
+        };
+#pragma nounroll
+        for (int b = 0; b < STEPS; ++b) {
+            const int J0 = 4 * b, i0 = J0 + 4, rest = NU - i0;
+            if (w == 0) {  // P_b: one wavefront (its loads of the diagonal block precede its stores into it in program order)
+                const Block B = factorBlock(J0);
+                const int i = J0 + lane;
+                if (lane < 32 && i < NU) {
+                    double* ri = R + i * n + J0;
+                    const double u0 = ri[0], p1 = ri[1], p2 = ri[2], p3 = ri[3];  // (rows inside the block: entries above the diagonal are never read again)
+                    const double u1 = p1 - u0 * B.l10, u2 = p2 - u0 * B.l20 - u1 * B.l21;
+                    ri[1] = u1;
+                    ri[2] = u2;
+                    ri[3] = p3 - u0 * B.l30 - u1 * B.l31 - u2 * B.l32;
+                } else if (lane >= 32 && lane - 32 < nk) {
+                    double* kc = K + J0 * nk + (lane - 32);
+                    const double y0 = kc[0], y1 = kc[nk] - B.l10 * y0, y2 = kc[2 * nk] - B.l20 * y0 - B.l21 * y1;
+                    kc[nk] = y1;
+                    kc[2 * nk] = y2;
+                    kc[3 * nk] -= B.l30 * y0 + B.l31 * y1 + B.l32 * y2;
+                }
+                if (lane == 0) {
+                    piv[J0] = B.i0;
+                    piv[J0 + 1] = B.i1;
+                    piv[J0 + 2] = B.i2;
+                    piv[J0 + 3] = B.i3;
+                }
+            }
+            LdsBarrier();
+            if (rest > 0) {  // T_b
+                const int TR = (rest + 15) >> 4, nR = TR * (TR + 1) / 2, NT = nR + TR * TCK;
+                auto A = [&](int row, int k) {  // -(L d)[row][J0 + k] / d_(J0 + k)
+                    const int rc = row < NU ? row : NU - 1;
+                    const double v = R[rc * n + J0 + k] * piv[J0 + k];
+                    return row < NU ? -v : 0.0;
+                };
+                for (int t = w; t < NT; t += kWaves) {
+                    if (t < nR) {
+                        const int ti = t == 0 ? 0 : 1, tj = t == 2 ? 1 : 0;
+                        updateTile(R, n, i0 + 16 * ti, NU, i0 + 16 * tj, NU, A, [&](int k, int col) {
+                            const int cc = col < NU ? col : NU - 1;
+                            const double v = R[cc * n + J0 + k];
+                            return col < NU ? v : 0.0;
+                        });
+                    } else {
+                        const int q = t - nR, ti = q / TCK, tc = q - ti * TCK;
+                        updateTile(K, nk, i0 + 16 * ti, NU, 16 * tc, nk, A, [&](int k, int col) {
+                            const int cc = col < nk ? col : nk - 1;
+                            const double v = K[(J0 + k) * nk + cc];
+                            return col < nk ? v : 0.0;
+                        });
+                    }
+                }
+                LdsBarrier();
+            }
+        }
+#pragma nounroll
+        for (int b = STEPS - 1; b >= 0; --b) {
+            const int J0 = 4 * b;
+            if (w == 0 && lane < nk) {  // B1_b
+                const double* D = R + J0 * n + J0;
+                const double u10 = D[n], u20 = D[2 * n], u21 = D[2 * n + 1], u30 = D[3 * n], u31 = D[3 * n + 1], u32 = D[3 * n + 2];
+                double* kc = K + J0 * nk + lane;
+                const double x3 = kc[3 * nk] * piv[J0 + 3];
+                const double x2 = (kc[2 * nk] - u32 * x3) * piv[J0 + 2];
+                const double x1 = (kc[nk] - u21 * x2 - u31 * x3) * piv[J0 + 1];
+                const double x0 = (kc[0] - u10 * x1 - u20 * x2 - u30 * x3) * piv[J0];
+                kc[0] = x0;
+                kc[nk] = x1;
+                kc[2 * nk] = x2;
+                kc[3 * nk] = x3;
+                double* gc = gainsK + J0 * nk + lane;
+                gc[0] = x0;
+                gc[nk] = x1;
+                gc[2 * nk] = x2;
+                gc[3 * nk] = x3;
+            }
+            LdsBarrier();
+            if (J0 > 0) {  // B2_b
+                const int TR = (J0 + 15) >> 4, NT = TR * TCK;
+                for (int t = w; t < NT; t += kWaves) {
+                    const int ti = t / TCK, tc = t - ti * TCK;
+                    updateTile(
+                        K, nk, 16 * ti, J0, 16 * tc, nk,
+                        [&](int row, int k) {  // -(L d)[J0 + k][row]
+                            const int rc = row < J0 ? row : J0 - 1;
+                            const double v = R[(J0 + k) * n + rc];
+                            return row < J0 ? -v : 0.0;
+                        },
+                        [&](int k, int col) {
+                            const int cc = col < nk ? col : nk - 1;
+                            const double v = K[(J0 + k) * nk + cc];
+                            return col < nk ? v : 0.0;
+                        });
+                }
+                LdsBarrier();
+            }
+        }
+        return bad;
+    }
+
+
 #ifdef UNGAR_RICCATI_CLOCKS
     /// Diagnostic build: cycles of the first workgroup's first lane between consecutive marks, summed per mark id
     /// (read back with ungar_amd_debug_riccati_clocks; tools/bench_riccati_phases.py).

@@ -61,6 +61,9 @@
 #define UNGAR_RICCATI_BLOCKED_MIN_NX 24  // blocked Cholesky from this state dimension on: such blocks fit two workgroups per CU by their LDS anyway, so its registers cost
 #endif                                 // no occupancy (13 + 24 runs five workgroups per CU on the rank-one phases: 4.8 ms against 5.7 blocked, r03e)
 
+#ifndef UNGAR_RICCATI_BLOCKED_LDLT_MIN_NU
+#define UNGAR_RICCATI_BLOCKED_LDLT_MIN_NU 16  // input dimension from which the four-wavefront kernels factorise R by the blocked L D L^T with matrix-core trailing updates
+#endif
 #ifndef UNGAR_RICCATI_BLOCK
 #define UNGAR_RICCATI_BLOCK 8  // diagonal block of the blocked Cholesky for input dimensions above 12 (factorised in registers by every lane)
 #endif
@@ -145,6 +148,16 @@ constexpr int RiccatiMatrixCoresFrom() {
     } else {
         return 0;
     }
+}
+
+/// R = H_uu by the BLOCKED L D L^T with trailing updates on the matrix cores (policies with a FactorGainsBlocked member: the four-wavefront device
+/// kernels), for input dimensions that are a multiple of 4 from UNGAR_RICCATI_BLOCKED_LDLT_MIN_NU on.
+template <class Exec, int NX, int NU, int NE>
+constexpr bool RiccatiFactorBlockedOnMatrixCores() {
+    if constexpr (requires { Exec::kFactorBlocked; })
+        return Exec::kFactorBlocked && NX > 0 && NE == 0 && NU >= UNGAR_RICCATI_BLOCKED_LDLT_MIN_NU && NU % 4 == 0 && NU <= 32 && NX + 1 <= 32;
+    else
+        return false;
 }
 
 template <class Exec>
@@ -451,7 +464,10 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
         if constexpr (dma) {
             if (k > 0) dmaAfterH(k - 1);
         }
-        if constexpr (NU > 0 && NU <= 12 && NE == 0) {
+        if constexpr (RiccatiFactorBlockedOnMatrixCores<Exec, NX, NU, NE>()) {
+            // four-wavefront device kernels, 16..36 inputs: the same L D L^T in 4 x 4 blocks, trailing updates on the matrix cores (NU - 1 phases)
+            if (ex.template FactorGainsBlocked<NX, NU>(H, h, K, piv, gains + static_cast<long long>(k) * nu * nk)) failed = failed ? failed : k + 1;
+        } else if constexpr (NU > 0 && NU <= 12 && NE == 0) {
             // Input dimension <= 12 fixed at compile time: every lane factorises R = H_uu = L L^T itself, in registers (NU^3 / 6
             // multiply-adds from NU (NU + 1) / 2 LDS reads), and goes straight on to its right-hand side of
             // [K | kff] = -R^-1 [H_ux | h_u] -- one phase instead of NU + 1 (a barrier and an LDS round trip per Cholesky column).
