@@ -314,8 +314,8 @@ struct DeviceExec {
     // The column-by-column L D L^T of ocp_riccati.hpp is 2 NU + 1 barrier phases, and four workgroups share a CU: the wall-clock of a phase is
     // its critical-path instruction count times ~12 cycles, 40 k cycles per knot for NU = 24.  Same factorisation, 4 x 4 blocks:
     //   P_b  (one phase)  every lane of wavefront 0 factorises the diagonal block itself (registers; redundant work is free, serial
-    //        instructions are not); lanes 0..31, one per ROW from the block down, forward-substitute their four panel entries (unscaled
-    //        columns L d, as the column-wise route stores them), lanes 32.., one per right-hand side, the block's rows of K;
+    //        instructions are not); the first lanes, one per ROW from the block down, forward-substitute their four panel entries (unscaled
+    //        columns L d, as the column-wise route stores them), the lanes after them, one per right-hand side, the block's rows of K;
     //   T_b  (one phase)  R_22 -= (L_21 d) D^-1 (L_21 d)^T and K_2 -= (L_21 d) D^-1 K_b: one v_mfma_f64_16x16x4_f64 per 16 x 16 tile,
     //        C tile LDS -> accumulator -> LDS (nothing stays in registers across phases);
     //   backwards  B1_b  x_b = D^-1 y_b - L_bb^T-part (one lane per right-hand side; the scaling of the column-wise route folded in),
@@ -332,7 +332,8 @@ struct DeviceExec {
     template <int NX, int NU>
     __device__ __forceinline__ bool FactorGainsBlocked(double* H, const double* h, double* K, double* piv, double* gainsK) {
         constexpr int n = NX + NU, nk = NX + 1, STEPS = NU / 4, TCK = (nk + 15) / 16;
-        static_assert(NU % 4 == 0 && NU <= 32 && nk <= 32, "two row tiles of trailing rows; rows and right-hand sides share one wavefront");
+        constexpr int ROWL = (NU + 15) / 16 * 16;  // P_b: rows in lanes 0 .. ROWL - 1, right-hand sides from lane ROWL on
+        static_assert(NU % 4 == 0 && NU <= 32 && ROWL + nk <= 64, "two row tiles of trailing rows; rows and right-hand sides share one wavefront");
         const int tid = static_cast<int>(threadIdx.x), lane = tid & 63, li = lane & 15, lk = lane >> 4, w = Wave();
         double* R = H + NX * n + NX;  // R[i][j], j <= i, at R[i * n + j]
         for (int idx = tid; idx < NU * nk; idx += BLOCK) {
@@ -352,7 +353,14 @@ struct DeviceExec {
             auto reciprocal = [&](double d) {
                 const bool neg = !(d > 0.0);
                 bad = bad || neg;
+#ifdef UNGAR_RICCATI_FAST_RECIPROCAL  // (measurement variant: v_rcp_f64 and two Newton steps instead of the IEEE division)
+                const double x = neg ? 1.0 : d;
+                double r = __builtin_amdgcn_rcp(x);
+                r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+                return __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+#else
                 return 1.0 / (neg ? 1.0 : d);
+#endif
             };
             Block B;
             B.i0 = reciprocal(d00);
@@ -392,15 +400,15 @@ struct DeviceExec {
             if (w == 0) {  // P_b: one wavefront (its loads of the diagonal block precede its stores into it in program order)
                 const Block B = factorBlock(J0);
                 const int i = J0 + lane;
-                if (lane < 32 && i < NU) {
+                if (lane < ROWL && i < NU) {
                     double* ri = R + i * n + J0;
                     const double u0 = ri[0], p1 = ri[1], p2 = ri[2], p3 = ri[3];  // (rows inside the block: entries above the diagonal are never read again)
                     const double u1 = p1 - u0 * B.l10, u2 = p2 - u0 * B.l20 - u1 * B.l21;
                     ri[1] = u1;
                     ri[2] = u2;
                     ri[3] = p3 - u0 * B.l30 - u1 * B.l31 - u2 * B.l32;
-                } else if (lane >= 32 && lane - 32 < nk) {
-                    double* kc = K + J0 * nk + (lane - 32);
+                } else if (lane >= ROWL && lane - ROWL < nk) {
+                    double* kc = K + J0 * nk + (lane - ROWL);
                     const double y0 = kc[0], y1 = kc[nk] - B.l10 * y0, y2 = kc[2 * nk] - B.l20 * y0 - B.l21 * y1;
                     kc[nk] = y1;
                     kc[2 * nk] = y2;

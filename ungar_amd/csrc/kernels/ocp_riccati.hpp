@@ -155,7 +155,7 @@ constexpr int RiccatiMatrixCoresFrom() {
 template <class Exec, int NX, int NU, int NE>
 constexpr bool RiccatiFactorBlockedOnMatrixCores() {
     if constexpr (requires { Exec::kFactorBlocked; })
-        return Exec::kFactorBlocked && NX > 0 && NE == 0 && NU >= UNGAR_RICCATI_BLOCKED_LDLT_MIN_NU && NU % 4 == 0 && NU <= 32 && NX + 1 <= 32;
+        return Exec::kFactorBlocked && NX > 0 && NE == 0 && NU >= UNGAR_RICCATI_BLOCKED_LDLT_MIN_NU && NU % 4 == 0 && NU <= 32 && (NU + 15) / 16 * 16 + NX + 1 <= 64;
     else
         return false;
 }
