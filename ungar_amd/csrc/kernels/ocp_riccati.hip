@@ -139,30 +139,25 @@ struct DeviceExec {
 #pragma unroll
             for (int ti = 0; ti < TR; ++ti) acc[ti] = f64x4{0.0, 0.0, 0.0, 0.0};
             const int col = 16 * tj + li;
-            // operands are loaded unconditionally from clamped addresses and zeroed by a select: no branches between the matrix instructions
+            // operands are loaded unconditionally from clamped addresses: no branches between the matrix instructions.  A padded ROW of A only
+            // feeds the output row of the same index and a padded COLUMN of B only its output column -- neither is stored --, so they need no
+            // zeroing (the clamped addresses keep the reads inside initialised arrays: finite numbers); only a padded k-step must contribute
+            // nothing, and zeroing ONE operand there (the B word, in the last step alone) does it: 8 selects per step fewer on the critical path.
             const double* bBase = col < n ? AB + col : bk;
             const int bStride = col < n ? n : 1;
-            const bool colOk = col <= n;
             int rowC[TR];
-            bool rowOk[TR];
 #pragma unroll
-            for (int ti = 0; ti < TR; ++ti) {
-                rowOk[ti] = 16 * ti + li < NX;
-                rowC[ti] = rowOk[ti] ? 16 * ti + li : NX - 1;
-            }
+            for (int ti = 0; ti < TR; ++ti) rowC[ti] = 16 * ti + li < NX ? 16 * ti + li : NX - 1;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const int kk = 4 * ks + lk;
                 const bool kOk = kk < NX;
                 const int kc = kOk ? kk : NX - 1;
                 const double braw = bBase[kc * bStride];
-                const double bv = (kOk && colOk) ? braw : 0.0;
+                const double bv = kOk ? braw : 0.0;
                 double av[TR];
 #pragma unroll
-                for (int ti = 0; ti < TR; ++ti) {
-                    const double araw = P[kc * NX + rowC[ti]];
-                    av[ti] = (kOk && rowOk[ti]) ? araw : 0.0;
-                }
+                for (int ti = 0; ti < TR; ++ti) av[ti] = P[kc * NX + rowC[ti]];
 #pragma unroll
                 for (int ti = 0; ti < TR; ++ti) acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ti], bv, acc[ti], 0, 0, 0);
             }
@@ -189,7 +184,7 @@ struct DeviceExec {
         f64x4 acc[CH];
         int ti[CH], tj[CH], rowC[CH], bStride[CH];
         const double* bBase[CH];
-        bool rowOk[CH], colOk[CH], live[CH];
+        bool live[CH];
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
             acc[c] = f64x4{0.0, 0.0, 0.0, 0.0};
@@ -203,10 +198,8 @@ struct DeviceExec {
             ti[c] = idx;
             tj[c] = j;
             const int row = 16 * idx + li, col = 16 * j + li;
-            rowOk[c] = live[c] && row < n;
             rowC[c] = row < n ? row : n - 1;
-            colOk[c] = live[c] && col <= n;
-            bBase[c] = col < n ? PAB + col : t;
+            bBase[c] = col < n ? PAB + col : t;  // (columns beyond n + 1 read t too: their output columns are not stored)
             bStride[c] = col < n ? n : 1;
         }
 #pragma unroll
@@ -217,9 +210,9 @@ struct DeviceExec {
             double av[CH], bv[CH];
 #pragma unroll
             for (int c = 0; c < CH; ++c) {
-                const double araw = AB[kc * n + rowC[c]], braw = bBase[c][kc * bStride[c]];
-                av[c] = (kOk && rowOk[c]) ? araw : 0.0;
-                bv[c] = (kOk && colOk[c]) ? braw : 0.0;
+                const double braw = bBase[c][kc * bStride[c]];
+                av[c] = AB[kc * n + rowC[c]];  // (padded rows / columns feed outputs that are not stored; a padded k-step is zeroed in B alone: see ProductPab)
+                bv[c] = kOk ? braw : 0.0;
             }
 #pragma unroll
             for (int c = 0; c < CH; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[c], bv[c], acc[c], 0, 0, 0);
@@ -284,8 +277,8 @@ struct DeviceExec {
                 const double* Hrow = H + (NX + mc) * n;  // row m of H_ux
                 const double* Krow = K + mc * nk;
                 const double a1raw = Hrow[rowC], b1raw = Krow[colC], a2raw = Krow[rowC], b2raw = Hrow[colX];
-                const double a1 = (mOk && row < NX) ? a1raw : 0.0, b1 = (mOk && col < nk) ? b1raw : 0.0;
-                const double a2 = (mOk && row < NX) ? a2raw : 0.0, b2 = (mOk && col < NX) ? b2raw : 0.0;
+                const double a1 = a1raw, b1 = mOk ? b1raw : 0.0;  // (padded rows / columns feed outputs that are not stored: see ProductPab)
+                const double a2 = a2raw, b2 = mOk ? b2raw : 0.0;
                 t1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, t1, 0, 0, 0);
                 t2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, t2, 0, 0, 0);
             }
@@ -378,7 +371,7 @@ struct DeviceExec {
             return B;
         };
         // one rank-4 update of a 16 x 16 tile of C (leading dimension ldc, rows r0.., columns c0.., valid below rowEnd / colEnd):
-        //   C[r][c] += sum_k A(r, k) B(k, c);  A and B return 0 outside their ranges
+        //   C[r][c] += sum_k A(r, k) B(k, c);  A / B clamp their addresses (padded rows / columns feed outputs that are not stored)
         auto updateTile = [&](double* C, int ldc, int r0, int rowEnd, int c0, int colEnd, auto A, auto Bop) {
             f64x4 acc;
             const int col = c0 + li, cc = col < colEnd ? col : colEnd - 1;
@@ -424,25 +417,22 @@ struct DeviceExec {
             LdsBarrier();
             if (rest > 0) {  // T_b
                 const int TR = (rest + 15) >> 4, nR = TR * (TR + 1) / 2, NT = nR + TR * TCK;
-                auto A = [&](int row, int k) {  // -(L d)[row][J0 + k] / d_(J0 + k)
+                auto A = [&](int row, int k) {  // -(L d)[row][J0 + k] / d_(J0 + k)   (a padded row feeds an output row that is not stored)
                     const int rc = row < NU ? row : NU - 1;
-                    const double v = R[rc * n + J0 + k] * piv[J0 + k];
-                    return row < NU ? -v : 0.0;
+                    return -(R[rc * n + J0 + k] * piv[J0 + k]);
                 };
                 for (int t = w; t < NT; t += kWaves) {
                     if (t < nR) {
                         const int ti = t == 0 ? 0 : 1, tj = t == 2 ? 1 : 0;
                         updateTile(R, n, i0 + 16 * ti, NU, i0 + 16 * tj, NU, A, [&](int k, int col) {
                             const int cc = col < NU ? col : NU - 1;
-                            const double v = R[cc * n + J0 + k];
-                            return col < NU ? v : 0.0;
+                            return R[cc * n + J0 + k];
                         });
                     } else {
                         const int q = t - nR, ti = q / TCK, tc = q - ti * TCK;
                         updateTile(K, nk, i0 + 16 * ti, NU, 16 * tc, nk, A, [&](int k, int col) {
                             const int cc = col < nk ? col : nk - 1;
-                            const double v = K[(J0 + k) * nk + cc];
-                            return col < nk ? v : 0.0;
+                            return K[(J0 + k) * nk + cc];
                         });
                     }
                 }
@@ -479,13 +469,11 @@ struct DeviceExec {
                         K, nk, 16 * ti, J0, 16 * tc, nk,
                         [&](int row, int k) {  // -(L d)[J0 + k][row]
                             const int rc = row < J0 ? row : J0 - 1;
-                            const double v = R[(J0 + k) * n + rc];
-                            return row < J0 ? -v : 0.0;
+                            return -R[(J0 + k) * n + rc];
                         },
                         [&](int k, int col) {
                             const int cc = col < nk ? col : nk - 1;
-                            const double v = K[(J0 + k) * nk + cc];
-                            return col < nk ? v : 0.0;
+                            return K[(J0 + k) * nk + cc];
                         });
                 }
                 LdsBarrier();
