@@ -77,6 +77,30 @@ struct DeviceExec {
         }
     }
     __device__ __forceinline__ void Barrier() { LdsBarrier(); }
+    // ---- inner products shared by PARTS adjacent lanes (forward pass): row r of `rows` by lanes PARTS r .. PARTS r + PARTS - 1, partial sums
+    // reduced with DPP quad permutes (register to register), the first lane of the group stores.  Closes with a barrier.
+#ifndef UNGAR_RICCATI_NO_SPLIT_DOTS
+    static constexpr bool kSplitDots = true;
+#else
+    static constexpr bool kSplitDots = false;
+#endif
+    template <int CTRL>
+    static __device__ __forceinline__ double QuadPermute(double v) {
+        int lo = __double2loint(v), hi = __double2hiint(v);
+        lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
+        hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
+        return __hiloint2double(hi, lo);
+    }
+    template <int PARTS, class Term, class Store>
+    __device__ __forceinline__ void SplitDots(int rows, Term term, Store store) {
+        static_assert(PARTS == 2 || PARTS == 4);
+        const int tid = static_cast<int>(threadIdx.x), r = tid / PARTS, part = tid % PARTS;
+        double s = r < rows ? term(r, part) : 0.0;
+        s += QuadPermute<0xB1>(s);                            // quad_perm [1, 0, 3, 2]
+        if constexpr (PARTS == 4) s += QuadPermute<0x4E>(s);  // quad_perm [2, 3, 0, 1]
+        if (r < rows && part == 0) store(r, s);
+        LdsBarrier();
+    }
 
     /// dst[i] <- *addr(i), i < n, 32 doubles per instruction: lane l moves dword l & 1 of element 32 c + l / 2 of chunk c (any element
     /// stride, 8-byte alignment); the LDS side of a copy is (wave-uniform base) + 4 l.  Chunks firstChunk, firstChunk + step, ...

@@ -160,6 +160,17 @@ constexpr bool RiccatiFactorBlockedOnMatrixCores() {
         return false;
 }
 
+/// Lanes that share one inner product of the forward pass (policies with a SplitDots member; 1: one lane per row).
+template <class Exec, int NX, int NU>
+constexpr int RiccatiSplitDotParts() {
+    if constexpr (requires { Exec::kSplitDots; }) {
+        constexpr int rows = NX > NU ? NX : NU;
+        return !Exec::kSplitDots ? 1 : Exec::kLanes >= 4 * rows ? 4 : Exec::kLanes >= 2 * rows ? 2 : 1;
+    } else {
+        return 1;
+    }
+}
+
 template <class Exec>
 constexpr bool RiccatiExecHasSelfDma() {
     if constexpr (requires { Exec::kDmaSelf; }) return Exec::kDmaSelf;
@@ -751,6 +762,45 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
         a.dX.at(inst, 0, i) = dx[i];
     });
     auto forwardKnot = [&](int k, const double* ABk, const double* bkk, const double* gk) {  // gk: [K | kff] of the knot (scratch copy or global)
+        if constexpr (NX > 0 && RiccatiSplitDotParts<Exec, NX, NU>() > 1) {
+            // Policies with SplitDots (the device kernels): a row's inner product is shared by 2 or 4 adjacent lanes and reduced across them -- the two
+            // phases of a knot are dependent multiply-add CHAINS of nx and nx + nu terms on a handful of lanes, and what a phase costs is the length of
+            // its chain (8.0 k of 41 k cycles per knot for 37 + 12).
+            constexpr int PARTS = RiccatiSplitDotParts<Exec, NX, NU>();
+            ex.template SplitDots<PARTS>(
+                nu,
+                [&](int i, int part) {
+                    const double* g = gk + i * nk;
+                    double s = 0.0;
+#pragma unroll 4
+                    for (int m = part; m < nx; m += PARTS) s += g[m] * dx[m];
+                    return s;
+                },
+                [&](int i, double s) {
+                    s += gk[i * nk + nx];
+                    du[i] = s;
+                    a.dU.at(inst, k, i) = s;
+                });
+            ex.template SplitDots<PARTS>(
+                nx,
+                [&](int i, int part) {
+                    double s = 0.0;
+#pragma unroll 4
+                    for (int m = part; m < nx; m += PARTS) s += ABk[i * n + m] * dx[m];
+#pragma unroll 4
+                    for (int m = part; m < nu; m += PARTS) s += ABk[i * n + nx + m] * du[m];
+                    return s;
+                },
+                [&](int i, double s) {
+                    s += bkk[i];
+                    dxn[i] = s;
+                    a.dX.at(inst, k + 1, i) = s;
+                });
+            double* swapx = dx;
+            dx = dxn;
+            dxn = swapx;
+            return;
+        }
         ex.ForEach(nu, [&](int i) {
             const double* g = gk + i * nk;
             double s = g[nx];
