@@ -479,26 +479,28 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
             // four-wavefront device kernels, 16..36 inputs: the same L D L^T in 4 x 4 blocks, trailing updates on the matrix cores (NU - 1 phases)
             if (ex.template FactorGainsBlocked<NX, NU>(H, h, K, piv, gains + static_cast<long long>(k) * nu * nk)) failed = failed ? failed : k + 1;
         } else if constexpr (NU > 0 && NU <= 12 && NE == 0) {
-            // Input dimension <= 12 fixed at compile time: every lane factorises R = H_uu = L L^T itself, in registers (NU^3 / 6
+            // Input dimension <= 12 fixed at compile time: every lane factorises R = H_uu = L D L^T itself, in registers (NU^3 / 6
             // multiply-adds from NU (NU + 1) / 2 LDS reads), and goes straight on to its right-hand side of
             // [K | kff] = -R^-1 [H_ux | h_u] -- one phase instead of NU + 1 (a barrier and an LDS round trip per Cholesky column).
             ex.ForEach(nk, [&](int c) {
-                double L[NU][NU], inv[NU];  // inv[j] = 1 / L[j][j]: one division per column instead of one per entry (a double-precision
-                bool bad = false;           // division is a ~12-instruction dependent sequence)
+                // R = L D L^T with unit L (no square roots: a column's dependent chain is its inner product and ONE division; the Cholesky form
+                // had a square root in front of every division -- 12 of them in sequence for the full-body block)
+                double L[NU][NU], U[NU][NU], inv[NU];  // U = L D (unscaled columns), inv[j] = 1 / d_j
+                bool bad = false;
 #pragma unroll
                 for (int j = 0; j < NU; ++j) {
                     double d = H[(nx + j) * n + nx + j];
 #pragma unroll
-                    for (int m = 0; m < j; ++m) d -= L[j][m] * L[j][m];
+                    for (int m = 0; m < j; ++m) d -= U[j][m] * L[j][m];
                     const bool neg = !(d > 0.0);
                     bad = bad || neg;
-                    L[j][j] = sqrt(neg ? 1.0 : d);
-                    inv[j] = 1.0 / L[j][j];  // (rsqrt + multiply instead: 37 + 12 QP step 4.80 -> 4.76 ms, 13 + 4 0.82 -> 0.87 ms on the same box: dropped)
+                    inv[j] = 1.0 / (neg ? 1.0 : d);
 #pragma unroll
                     for (int i = j + 1; i < NU; ++i) {
                         double sv = H[(nx + i) * n + nx + j];
 #pragma unroll
-                        for (int m = 0; m < j; ++m) sv -= L[i][m] * L[j][m];
+                        for (int m = 0; m < j; ++m) sv -= U[i][m] * L[j][m];
+                        U[i][j] = sv;
                         L[i][j] = sv * inv[j];
                     }
                 }
@@ -509,14 +511,13 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
                     double sv = c < nx ? -H[(nx + i) * n + c] : -h[nx + i];
 #pragma unroll
                     for (int m = 0; m < i; ++m) sv -= L[i][m] * y[m];
-                    y[i] = sv * inv[i];
+                    y[i] = sv;
                 }
 #pragma unroll
-                for (int i = NU - 1; i >= 0; --i) {  // L^T x = y
-                    double sv = y[i];
+                for (int i = NU - 1; i >= 0; --i) {  // L^T x = D^-1 y
+                    double sv = y[i] * inv[i];
 #pragma unroll
                     for (int m = i + 1; m < NU; ++m) sv -= L[m][i] * y[m];
-                    sv *= inv[i];
                     y[i] = sv;
                     K[i * nk + c] = sv;
                     gains[static_cast<long long>(k) * nu * nk + i * nk + c] = sv;
