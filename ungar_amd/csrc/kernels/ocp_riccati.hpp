@@ -263,8 +263,13 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
     constexpr bool foldW = dma, foldInP = dma && nFold <= NX * NX;
     auto foldedSource = [&](int k) {
         return [&a, inst, k, n](int i) {
-            const int src = RiccatiFoldedSource(n, i);
-            return &a.hess.at(inst, k, src < 0 ? 0 : src);
+            // RiccatiFoldedSource without branches (this runs once per copy instruction of every wavefront, on the critical path of the phase that issues
+            // the copies): a word of the rectangle belongs to row q or to row n - 1 - q; the unused tail of the middle row (n odd) copies valid upper entries
+            // of that row, which nobody reads
+            const int q = i / (n + 1), j = i - q * (n + 1);
+            const bool first = j < n - q;
+            const int r = first ? q : n - 1 - q, off = first ? j : j - (n - q);
+            return &a.hess.at(inst, k, r * (n + 1) + off);
         };
     };
 
