@@ -118,6 +118,20 @@ struct DeviceExec {
     __device__ __forceinline__ void DmaFetch(int n, F addr, double* dst) {
         DmaIssue(n, addr, dst, Wave(), kWaves);
     }
+#ifndef UNGAR_RICCATI_NO_WIDE_COPIES
+    /// dst[i] <- src[i], i < n, src contiguous: 128 doubles per instruction (global_load_lds_dwordx4: lane l moves elements 2 l, 2 l + 1 of its chunk;
+    /// dst + 128 c must be 16-byte aligned in LDS), an odd last element by the 4-byte form.  The copies cost ISSUE slots of the phase that requests them
+    /// (address generation, M0, the instruction: ~10 per copy): 15 -> 4 per wavefront and knot for the 37 x 49 block.
+    __device__ __forceinline__ void DmaFetchContiguous(int n, const double* src, double* dst) {
+        const int lane = static_cast<int>(threadIdx.x) & 63, pairs = n >> 1, chunks = (pairs + 63) >> 6;
+        for (int c = Wave(); c < chunks; c += kWaves) {
+            const int pr = (c << 6) + lane;
+            if (pr < pairs) __builtin_amdgcn_global_load_lds(reinterpret_cast<const unsigned*>(src + 2 * pr), (__attribute__((address_space(3))) void*)(dst + (c << 7)), 16, 0, 0);
+        }
+        if ((n & 1) && Wave() == kWaves - 1 && lane < 2)
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const unsigned*>(src + (n - 1)) + lane, (__attribute__((address_space(3))) void*)(dst + (n - 1)), 4, 0, 0);
+    }
+#endif
     __device__ __forceinline__ void DmaWait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     template <class F>
     __device__ __forceinline__ void DmaFetchOne(int owner, int n, F addr, double* dst) {

@@ -316,7 +316,13 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
     };
     [[maybe_unused]] auto dmaAfterH = [&](int k) {  // [A|B]'s once H exists; the gradient (and a folded W outside P) has its own buffer but one copy in flight
         if constexpr (dma) {
-            ex.DmaFetch(nx * n, [&](int idx) { return &a.jac.at(inst, k, idx); }, AB);
+            if constexpr (requires { ex.DmaFetchContiguous(0, static_cast<const double*>(nullptr), AB); }) {
+                // contiguous [A|B] block (element stride 1, what the stage-QP kernels write): 16 bytes per lane and copy instruction, a quarter of the instructions
+                if (a.jac.es == 1) ex.DmaFetchContiguous(nx * n, &a.jac.at(inst, k, 0), AB);
+                else ex.DmaFetch(nx * n, [&](int idx) { return &a.jac.at(inst, k, idx); }, AB);
+            } else {
+                ex.DmaFetch(nx * n, [&](int idx) { return &a.jac.at(inst, k, idx); }, AB);
+            }
             ex.DmaFetch(n, [&](int c) { return &a.grad.at(inst, k, c); }, wn);
             if constexpr (!foldInP) ex.DmaFetch(nFold, foldedSource(k), wf);
         }
