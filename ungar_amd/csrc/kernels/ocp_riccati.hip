@@ -114,9 +114,15 @@ struct DeviceExec {
         }
     }
     static __device__ __forceinline__ int Wave() { return __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6); }
+    /// true: the copies requested next are issued by the wavefronts other than the first (see ocp_riccati.hpp: deferCopies)
+    bool copySpare = false;
+#ifndef UNGAR_RICCATI_NO_DEFERRED_COPIES
+    __device__ __forceinline__ void SetCopyWaves(bool spareOnly) requires(BLOCK > 64) { copySpare = spareOnly; }
+#endif
     template <class F>
     __device__ __forceinline__ void DmaFetch(int n, F addr, double* dst) {
-        DmaIssue(n, addr, dst, Wave(), kWaves);
+        if (!copySpare) DmaIssue(n, addr, dst, Wave(), kWaves);
+        else if (Wave() > 0) DmaIssue(n, addr, dst, Wave() - 1, kWaves - 1);
     }
 #ifndef UNGAR_RICCATI_NO_WIDE_COPIES
     /// dst[i] <- src[i], i < n, src contiguous: 128 doubles per instruction (global_load_lds_dwordx4: lane l moves elements 2 l, 2 l + 1 of its chunk;
@@ -124,7 +130,9 @@ struct DeviceExec {
     /// (address generation, M0, the instruction: ~10 per copy): 15 -> 4 per wavefront and knot for the 37 x 49 block.
     __device__ __forceinline__ void DmaFetchContiguous(int n, const double* src, double* dst) {
         const int lane = static_cast<int>(threadIdx.x) & 63, pairs = n >> 1, chunks = (pairs + 63) >> 6;
-        for (int c = Wave(); c < chunks; c += kWaves) {
+        if (copySpare && Wave() == 0) return;
+        const int first = copySpare ? Wave() - 1 : Wave(), step = copySpare ? kWaves - 1 : kWaves;
+        for (int c = first; c < chunks; c += step) {
             const int pr = (c << 6) + lane;
             if (pr < pairs) __builtin_amdgcn_global_load_lds(reinterpret_cast<const unsigned*>(src + 2 * pr), (__attribute__((address_space(3))) void*)(dst + (c << 7)), 16, 0, 0);
         }

@@ -331,6 +331,12 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
         dmaAfterPab(N - 1, Pn);
         dmaAfterH(N - 1);
     }
+    // Policies with SetCopyWaves (the four-wavefront device kernels): ALL copies of the next knot are requested after the H phase, by the wavefronts
+    // other than the first -- the factorisation that follows keeps the first one busy (its lanes factorise R in registers, or run the panel
+    // phases of the blocked route) while the others wait at a barrier, so the issue slots of the copies (address generation, M0, the instruction:
+    // ~10 per copy, ~100 copies per knot) come off the critical path.  The destinations are free by then and the data is not needed before the next knot.
+    // (Only where the factorisation is the register one: the blocked route uses all wavefronts in its update phases and measured 3 % SLOWER with deferred copies.)
+    constexpr bool deferCopies = dma && NU > 0 && NU <= 12 && NE == 0 && requires { ex.SetCopyWaves(true); };
     RiccatiMark(ex, 0);
     for (int k = N - 1; k >= 0; --k) {
         if constexpr (dma) {
@@ -372,7 +378,9 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
             ex.template ProductPab<NX, NU>(P, AB, bk, p, PAB, t);
             RiccatiMark(ex, 2);  // P [A|B]
             if constexpr (dma) {
-                if (k > 0) dmaAfterPab(k - 1, P);
+                if constexpr (!deferCopies) {
+                    if (k > 0) dmaAfterPab(k - 1, P);
+                }
             }
             const double* Wsrc = foldW ? (foldInP ? Pn : wf) : nullptr;
             ex.template ProductH<NX, NU, foldW>(AB, PAB, t, Wsrc, foldW ? wn : h, a.regularization, H, h);
@@ -409,7 +417,9 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
             });
             RiccatiMark(ex, 2);  // P [A|B]
             if constexpr (dma) {
-                if (k > 0) dmaAfterPab(k - 1, P);  // P retired with the phase above; the folded W_k read below sits in Pn
+                if constexpr (!deferCopies) {
+                    if (k > 0) dmaAfterPab(k - 1, P);  // P retired with the phase above; the folded W_k read below sits in Pn
+                }
             }
             // H = W + AB^T PAB: all tiles (interleaved rows and columns straddle the diagonal); entries r <= c are updated and mirrored
             constexpr RiccatiTile tileH = RiccatiChooseTile(NX + NU, NX + NU, Exec::kLanes);
@@ -484,7 +494,16 @@ UNGAR_HD void RiccatiInstance(const RiccatiArgs& a, long long inst, double* scra
         }
         RiccatiMark(ex, 3);  // H (for the untiled path: both products)
         if constexpr (dma) {
-            if (k > 0) dmaAfterH(k - 1);
+            if constexpr (deferCopies) {
+                if (k > 0) {
+                    ex.SetCopyWaves(true);
+                    dmaAfterPab(k - 1, P);
+                    dmaAfterH(k - 1);
+                    ex.SetCopyWaves(false);
+                }
+            } else {
+                if (k > 0) dmaAfterH(k - 1);
+            }
         }
         if constexpr (RiccatiFactorBlockedOnMatrixCores<Exec, NX, NU, NE>()) {
             // four-wavefront device kernels, 16..36 inputs: the same L D L^T in 4 x 4 blocks, trailing updates on the matrix cores (NU - 1 phases)
