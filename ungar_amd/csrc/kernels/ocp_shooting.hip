@@ -12,6 +12,14 @@
 namespace ungar_amd::kernels {
 namespace {
 
+template <int CTRL>
+__device__ __forceinline__ double QuadPermute(double v) {  // DPP quad_perm: register to register
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+
 constexpr int kBlock = 64;
 
 __device__ __forceinline__ const double* RowOf(const double* rows, const ShootingDims& d, long long b, int k) {
@@ -47,6 +55,14 @@ __global__ __launch_bounds__(256) void ShootingAssembleKernel(const ShootingAsse
     int* used = pivCol + a.ne;        // nu flags
     int* list = used + d.nu;          // max(nd, ne) indices of a support
     int* listSize = list + (nd > a.ne ? nd : a.ne);
+#ifdef UNGAR_SHOOTING_CLOCKS  // diagnostic build (tools/make_shooting_clocks.sh): cycles of the sections of one stage node, printed by its first lane
+    unsigned long long marks[12];
+    int markCount = 0;
+#define UNGAR_SHOOTING_MARK() marks[markCount++] = __builtin_amdgcn_s_memtime()
+#else
+#define UNGAR_SHOOTING_MARK() ((void)0)
+#endif
+    UNGAR_SHOOTING_MARK();
     const int total = nd * nd + nd + 2 * a.nh + nz * nd + a.ne * ld;
     for (int i = lane; i < total; i += lanes) lds[i] = 0.0;
     __syncthreads();
@@ -69,6 +85,7 @@ __global__ __launch_bounds__(256) void ShootingAssembleKernel(const ShootingAsse
         for (int e = lane; e < a.pe.nnz; e += lanes) Ed[a.pe.rows[e] * ld + a.pe.cols[e]] = a.eJ[nodeOff * a.pe.nnz + e];
     }
     __syncthreads();
+    UNGAR_SHOOTING_MARK();  // 1: zeroed images, scattered stage outputs
     // barrier terms  W += J_h^T diag(b''(-h)) J_h,  w -= J_h^T b'(-h)  straight from the SPARSE inequality Jacobian (28 of 588 entries for the
     // quadruped's rows: a dense product over every entry of W read 44 k LDS words per node).  Row by row, in order: inside a row the pairs of its
     // entries hit distinct targets, so plain read-modify-writes suffice and the sums are accumulated in the same order on every run.
@@ -95,6 +112,7 @@ __global__ __launch_bounds__(256) void ShootingAssembleKernel(const ShootingAsse
             __syncthreads();
         }
     }
+    UNGAR_SHOOTING_MARK();  // 2: barrier terms
     // regularisation, and the lower triangle mirrored (W is kept in LDS with both triangles)
     for (int idx = lane; idx < nd * nd; idx += lanes) {
         const int r = static_cast<int>((static_cast<float>(idx) + 0.5f) * ndInv), c = idx - r * nd;
@@ -111,6 +129,7 @@ __global__ __launch_bounds__(256) void ShootingAssembleKernel(const ShootingAsse
         for (int j = lane; j < a.ne; j += lanes) Ed[j * ld + nd] = a.e ? a.e[nodeOff * a.ne + j] : 0.0;
     }
     __syncthreads();
+    UNGAR_SHOOTING_MARK();  // 3: regularisation, mirror, b
     if (stage && a.eliminate && a.ne > 0) {
         /// list <- {c < n : pred(c)} in ascending order, by the first wavefront (no closing barrier)
         auto buildList = [&](int n, auto pred) {
@@ -165,12 +184,15 @@ __global__ __launch_bounds__(256) void ShootingAssembleKernel(const ShootingAsse
                 double* dst = T[cur ^ 1];
                 const int J = nz + j;
                 const double rpiv = 1.0 / src[i * ld + J];
-                for (int idx = lane; idx < a.ne * ld; idx += lanes) {
-                    const int r = static_cast<int>((static_cast<float>(idx) + 0.5f) * ldInv), c = idx - r * ld;
+                // (wavefront -> rows, lane -> column: the scaled pivot-row entry of a column is computed once per lane, a row's multiplier is one broadcast
+                // read, and no index is decoded -- a step is 4 short iterations for 16 rows; the flat index space cost ~35 instructions per item)
+                for (int c = wl; c < ld; c += 64) {
                     const double p = c == J ? 1.0 : src[i * ld + c] * rpiv;  // (the pivot exactly 1, its column exactly 0 elsewhere)
-                    const double v = r == i ? p : (c == J ? 0.0 : src[idx] - src[r * ld + J] * p);
-                    dst[idx] = v;
-                    if (r == i + 1) offer(nextSet, c, v, j);
+                    for (int r = wave; r < a.ne; r += waves) {
+                        const double v = r == i ? p : (c == J ? 0.0 : src[r * ld + c] - src[r * ld + J] * p);
+                        dst[r * ld + c] = v;
+                        if (r == i + 1) offer(nextSet, c, v, j);
+                    }
                 }
                 cur ^= 1;
             } else if (i + 1 < a.ne) {
@@ -182,68 +204,124 @@ __global__ __launch_bounds__(256) void ShootingAssembleKernel(const ShootingAsse
             for (int idx = lane; idx < a.ne * ld; idx += lanes) Ed[idx] = T[1][idx];
             __syncthreads();
         }
+        UNGAR_SHOOTING_MARK();  // 4: Gauss-Jordan
         double* V = vbuf + 6;  // pivots x nd (the second tableau is dead)
         // ---- substitute u_j = -(G_i . [z; u] + g0_i) for ALL pivot rows at once (the reduced rows have zeros in each other's pivot columns):
         //   W'[a][c] = W[a][c] - sum_i (W[a][J_i] G_i[c] + G_i[a] W[J_i][c]) + sum_i G_i[a] V_i[c],   V_i[c] = sum_i' W[J_i][J_i'] G_i'[c]
         // for a, c outside the pivot set (in place: only pivot rows / columns are read besides the entry itself); likewise w, [A|B], b.
+        // On the FP64 matrix cores, over ALL ne rows t (a row without a pivot contributes nothing: its operands are masked): every entry of the flat version
+        // was a dependent chain of 16 x 3 multiply-adds behind index lookups -- 33-58 k of a node's ~120 k cycles; a 16 x 16 tile is 2 x ceil(ne / 4) matrix
+        // instructions.  v_mfma_f64_16x16x4_f64: A[i][k] in lane 16 k + i, B[k][j] in lane 16 k + j, D[(lane >> 4) + 4 r][lane & 15] in element r.
         buildList(a.ne, [&](int r) { return pivCol[r] >= 0; });
         __syncthreads();
         const int pivots = a.eliminate == 2 ? 0 : *listSize;  // (2: measurement only -- rows reduced, substitution skipped)
-        for (int idx = lane; idx < pivots * nd; idx += lanes) {
-            const int t = static_cast<int>((static_cast<float>(idx) + 0.5f) * ndInv), c = idx - t * nd;
-            const int J = nz + pivCol[list[t]];
-            double acc = 0.0;
-            for (int t2 = 0; t2 < pivots; ++t2) acc += Wd[J * nd + nz + pivCol[list[t2]]] * Ed[list[t2] * ld + c];
-            V[idx] = acc;
+        using f64x4 = __attribute__((__vector_size__(4 * sizeof(double)))) double;
+        const int li = wl & 15, lk = wl >> 4, KS = pivots > 0 ? (a.ne + 3) >> 2 : 0, TD = (nd + 15) >> 4, TE = (a.ne + 15) >> 4, TZ = (nz + 15) >> 4;
+        auto pivotColumn = [&](int t) { return t < a.ne ? pivCol[t] : -1; };  // input the row t was solved for, or < 0
+        // the k-steps of this lane's operand rows, looked up once (the same for every tile): up to 64 equality rows (the C ABI's bound)
+        constexpr int kMaxSteps = 16;
+        int stepPivot[kMaxSteps], stepRow[kMaxSteps];
+#pragma unroll
+        for (int ks = 0; ks < kMaxSteps; ++ks) {
+            const int t = 4 * ks + lk;
+            stepPivot[ks] = ks < KS ? pivotColumn(t) : -1;
+            stepRow[ks] = t < a.ne ? t : a.ne - 1;
         }
-        for (int c = lane; c < nd; c += lanes) {  // w + W s,  s = -sum_i e_(J_i) g0_i
-            double acc = gd[c];
-            for (int t = 0; t < pivots; ++t) acc -= Wd[c * nd + nz + pivCol[list[t]]] * Ed[list[t] * ld + nd];
-            prow[c] = acc;
+        // V = W_JJ G  (ne x nd)
+        for (int tile = wave; tile < TE * TD; tile += waves) {
+            const int ti = tile / TD, tj = tile - ti * TD;
+            const int rowA = 16 * ti + li, colB = 16 * tj + li, cB = colB < nd ? colB : nd - 1;
+            const int jA = pivotColumn(rowA);
+            f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < kMaxSteps; ++ks) {
+                if (ks < KS) {  // (uniform; a `break` keeps the loop rolled and the lookup tables in scratch)
+                    const int jt = stepPivot[ks], tc = stepRow[ks];
+                    const double av = Wd[(nz + (jA < 0 ? 0 : jA)) * nd + nz + (jt < 0 ? 0 : jt)], bv = Ed[tc * ld + cB];
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64((jA >= 0 && jt >= 0) ? av : 0.0, bv, acc, 0, 0, 0);
+                }
+            }
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * ti + lk + 4 * r;
+                if (row < a.ne && colB < nd) V[row * nd + colB] = acc[r];
+            }
         }
-        for (int r = lane; r < nz; r += lanes) {
-            double acc = bd[r];
-            for (int t = 0; t < pivots; ++t) acc -= ABd[r * nd + nz + pivCol[list[t]]] * Ed[list[t] * ld + nd];
-            bd[r] = acc;
-        }
+        // the three vector updates: an entry's sum over the pivot rows is shared by the four lanes of a quad (DPP reduction) -- as one lane's loop it was a
+        // chain of `pivots` multiply-adds, each behind three dependent index lookups
+        auto quadSum = [&](int count, auto term, auto store) {  // item i < count: store(i, sum_t term(i, t)); lanes 4 i .. 4 i + 3 share the sum
+            for (int base = 0; base < count; base += lanes >> 2) {
+                const int i = base + (lane >> 2), part = lane & 3;
+                double sv = 0.0;
+                if (i < count)
+                    for (int t = part; t < pivots; t += 4) sv += term(i, t);
+                sv += QuadPermute<0xB1>(sv);  // quad_perm [1, 0, 3, 2]
+                sv += QuadPermute<0x4E>(sv);  // quad_perm [2, 3, 0, 1]
+                if (i < count && part == 0) store(i, sv);
+            }
+        };
+        quadSum(
+            nd, [&](int c, int t) { return Wd[c * nd + nz + pivCol[list[t]]] * Ed[list[t] * ld + nd]; }, [&](int c, double sv) { prow[c] = gd[c] - sv; });  // w + W s,  s = -sum_i e_(J_i) g0_i
+        quadSum(
+            nz, [&](int r, int t) { return ABd[r * nd + nz + pivCol[list[t]]] * Ed[list[t] * ld + nd]; }, [&](int r, double sv) { bd[r] -= sv; });
         __syncthreads();
+        UNGAR_SHOOTING_MARK();  // (substitution: list, V = W_JJ G, w + W s, b)
         auto isPivot = [&](int c) { return c >= nz && used[c - nz] != 0; };
-        // upper triangle r <= c through the folded rectangle ((nd + 1) / 2 rows of nd + 1: row q of the triangle followed by row nd - 1 - q)
-        const int foldRows = (nd + 1) / 2;
-        for (int idx = lane; idx < foldRows * ld; idx += lanes) {
-            const int q = static_cast<int>((static_cast<float>(idx) + 0.5f) * ldInv), jj = idx - q * ld;
-            int r, c;
-            if (jj < nd - q) {
-                r = q;
-                c = q + jj;
+        // W' on and above the diagonal (mirrored) and [A|B]': in place -- the operands are pivot rows / columns, V and G, which nobody writes here
+        const int upper = TD * (TD + 1) / 2;
+        for (int tile = wave; tile < upper + TZ * TD; tile += waves) {
+            const bool hessian = tile < upper;
+            int ti = 0, tj = 0;
+            if (hessian) {  // column-major upper triangle of tiles
+                int idx = tile;
+                while (idx > tj) {
+                    idx -= tj + 1;
+                    ++tj;
+                }
+                ti = idx;
             } else {
-                r = nd - 1 - q;
-                if (r == q) continue;  // unused tail of the middle row (nd odd)
-                c = r + (jj - (nd - q));
+                ti = (tile - upper) / TD;
+                tj = tile - upper - ti * TD;
             }
-            if (isPivot(r) || isPivot(c)) continue;
-            double acc = Wd[r * nd + c];
-            for (int t = 0; t < pivots; ++t) {
-                const int i = list[t], J = nz + pivCol[i];
-                const double gr = Ed[i * ld + r], gc = Ed[i * ld + c];
-                acc += gr * (V[t * nd + c] - Wd[J * nd + c]) - Wd[r * nd + J] * gc;
+            double* C = hessian ? Wd : ABd;
+            const int rows = hessian ? nd : nz;
+            const int rowA = 16 * ti + li, rA = rowA < rows ? rowA : rows - 1, rG = rowA < nd ? rowA : nd - 1;
+            const int colB = 16 * tj + li, cB = colB < nd ? colB : nd - 1;
+            f64x4 acc, acc2 = {0.0, 0.0, 0.0, 0.0};  // (two accumulators: the two products of a k-step do not wait for each other)
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * ti + lk + 4 * r;
+                acc[r] = C[(row < rows ? row : rows - 1) * nd + cB];
             }
-            Wd[r * nd + c] = acc;
-            Wd[c * nd + r] = acc;
+#pragma unroll
+            for (int ks = 0; ks < kMaxSteps; ++ks) {
+                if (ks < KS) {  // (uniform)
+                    const int jt = stepPivot[ks], tc = stepRow[ks], J = nz + (jt < 0 ? 0 : jt);
+                    const double a1 = C[rA * nd + J], b1 = Ed[tc * ld + cB];
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(jt >= 0 ? -a1 : 0.0, b1, acc, 0, 0, 0);  // - W[a][J_t] G_t[c]   /   - [A|B][r][J_t] G_t[c]
+                    if (hessian) {
+                        const double a2 = Ed[tc * ld + rG], b2 = V[tc * nd + cB] - Wd[J * nd + cB];
+                        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(jt >= 0 ? a2 : 0.0, b2, acc2, 0, 0, 0);  // + G_t[a] (V_t[c] - W[J_t][c])
+                    }
+                }
+            }
+            if (colB < nd && !isPivot(colB)) {
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * ti + lk + 4 * r;
+                    acc[r] += acc2[r];
+                    if (hessian) {
+                        if (row <= colB && !isPivot(row)) {
+                            Wd[row * nd + colB] = acc[r];
+                            Wd[colB * nd + row] = acc[r];
+                        }
+                    } else if (row < nz) {
+                        ABd[row * nd + colB] = acc[r];
+                    }
+                }
+            }
         }
-        for (int c = lane; c < nd; c += lanes) {
-            double acc = prow[c];
-            for (int t = 0; t < pivots; ++t) acc -= Ed[list[t] * ld + c] * prow[nz + pivCol[list[t]]];
-            gd[c] = isPivot(c) ? 0.0 : acc;
-        }
-        for (int idx = lane; idx < nz * nd; idx += lanes) {
-            const int r = static_cast<int>((static_cast<float>(idx) + 0.5f) * ndInv), c = idx - r * nd;
-            if (isPivot(c)) continue;
-            double acc = ABd[idx];
-            for (int t = 0; t < pivots; ++t) acc -= ABd[r * nd + nz + pivCol[list[t]]] * Ed[list[t] * ld + c];
-            ABd[idx] = acc;
-        }
+        quadSum(
+            nd, [&](int c, int t) { return Ed[list[t] * ld + c] * prow[nz + pivCol[list[t]]]; }, [&](int c, double sv) { gd[c] = isPivot(c) ? 0.0 : prow[c] - sv; });
         __syncthreads();  // every read of a pivot row / column is done: they become the dummies' identity rows
+        UNGAR_SHOOTING_MARK();  // (substitution: W', [A|B]', w')
         for (int t = wave; t < pivots; t += waves) {
             const int J = nz + pivCol[list[t]];
             for (int c = wl; c < nd; c += 64) {
@@ -258,6 +336,7 @@ __global__ __launch_bounds__(256) void ShootingAssembleKernel(const ShootingAsse
             a.er[stageOff * a.ne + i] = Ed[i * ld + nd];
         }
     }
+    UNGAR_SHOOTING_MARK();  // 5: substitution (with elimination; else 3 again)
     double* W = a.W + nodeOff * nd * nd;
     for (int idx = lane; idx < nd * nd; idx += lanes) {
         const int r = static_cast<int>((static_cast<float>(idx) + 0.5f) * ndInv);
@@ -282,6 +361,15 @@ __global__ __launch_bounds__(256) void ShootingAssembleKernel(const ShootingAsse
             for (int i = lane; i < nz; i += lanes) a.dz0[b * nz + i] = i < nc ? 0.0 : a.xm[b * nx + (i - nc)] - row0[i];
         }
     }
+#ifdef UNGAR_SHOOTING_CLOCKS
+    __syncthreads();
+    UNGAR_SHOOTING_MARK();  // last: results written
+    if (lane == 0 && (node == 1 || node == d.batch * (d.N + 1) / 2 + 1)) {
+        printf("[assemble clocks] node %lld:", node);
+        for (int m = 1; m < markCount; ++m) printf(" %llu", marks[m] - marks[m - 1]);
+        printf("\n");
+    }
+#endif
 }
 
 /// One lane per (stage node, reduced row).
