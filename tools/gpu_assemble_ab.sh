@@ -1,0 +1,32 @@
+#!/usr/bin/env bash
+# A/B of the shooting assembly kernel on the GPU box: wavefront-specialised sections (default) against the generic sections
+# (UNGAR_AMD_ASSEMBLE_GENERIC=1).  Same bits expected: the facade comparison lines and the dumped QP data of both runs are compared;
+# then wall clock at 4096 instances, the kernel split (rocprofv3) and the section clocks.  Outputs under gpurun_out/.
+set -uo pipefail
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+T=build/batched_quadruped_test
+rm -rf /tmp/dumpA /tmp/dumpB; mkdir -p /tmp/dumpA /tmp/dumpB
+timeout 900 $T /tmp/cg_q 1024 8 /tmp/dumpA > gpurun_out/assemble_ab_specialised.log 2>&1; echo "specialised rc $?"
+UNGAR_AMD_ASSEMBLE_GENERIC=1 timeout 900 $T /tmp/cg_q 1024 8 /tmp/dumpB > gpurun_out/assemble_ab_generic.log 2>&1; echo "generic rc $?"
+grep -E "^iteration [12]:|PASS|FAIL" gpurun_out/assemble_ab_specialised.log
+if diff <(grep -E "^iteration" gpurun_out/assemble_ab_specialised.log) <(grep -E "^iteration" gpurun_out/assemble_ab_generic.log) > gpurun_out/assemble_ab_diff.log; then echo "facade comparison lines: identical"; else echo "facade comparison lines DIFFER"; head -5 gpurun_out/assemble_ab_diff.log; fi
+same=0; differ=0
+for f in /tmp/dumpA/*; do if cmp -s "$f" "/tmp/dumpB/$(basename $f)"; then same=$((same+1)); else differ=$((differ+1)); echo "differs: $(basename $f)"; fi; done 2>/dev/null | head -5
+echo "dumped files compared: $(ls /tmp/dumpA | wc -l)"
+for mode in specialised generic; do
+  for rep in 1 2; do
+    if [ $mode = generic ]; then export UNGAR_AMD_ASSEMBLE_GENERIC=1; else unset UNGAR_AMD_ASSEMBLE_GENERIC; fi
+    timeout 900 $T /tmp/cg_q 4096 0 2>&1 | grep -E "timing" | sed "s/^/[$mode] /"
+  done
+done
+unset UNGAR_AMD_ASSEMBLE_GENERIC
+rm -rf gpurun_out/bprof_asm
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/gpurun_out/bprof_asm -o b -- $OLDPWD/$T /tmp/cg_q 4096 0 > /dev/null 2>&1)
+f=$(find gpurun_out/bprof_asm -name "b_kernel_stats.csv" | head -1)
+[ -n "$f" ] && cp "$f" gpurun_out/assemble_ab_kernel_stats.csv && head -8 "$f" | cut -c1-200
+rm -rf gpurun_out/bprof_asm
+if [ -f build/variants/shooting_clocks/libungar_amd.so ]; then
+  LD_LIBRARY_PATH=build/variants/shooting_clocks:${LD_LIBRARY_PATH:-} UNGAR_AMD_LIBRARY=build/variants/shooting_clocks/libungar_amd.so timeout 600 $T /tmp/cg_q 1024 0 2>&1 | grep -E "assemble (clocks|jobs)" | head -24 > gpurun_out/assemble_ab_clocks.log
+  cat gpurun_out/assemble_ab_clocks.log
+fi

@@ -20,7 +20,35 @@ __device__ __forceinline__ double QuadPermute(double v) {  // DPP quad_perm: reg
     return __hiloint2double(hi, lo);
 }
 
+template <int CTRL>
+__device__ __forceinline__ unsigned long long DppU64(unsigned long long v) {  // (bound_ctrl: a lane without a source reads 0, the identity of the max below)
+    int lo = static_cast<int>(v), hi = static_cast<int>(v >> 32);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
+    return (static_cast<unsigned long long>(static_cast<unsigned>(hi)) << 32) | static_cast<unsigned>(lo);
+}
+
+__device__ __forceinline__ unsigned long long ReadLaneU64(unsigned long long v, int sourceLane) {  // sourceLane wave-uniform
+    const int lo = __builtin_amdgcn_readlane(static_cast<int>(v), sourceLane), hi = __builtin_amdgcn_readlane(static_cast<int>(v >> 32), sourceLane);
+    return (static_cast<unsigned long long>(static_cast<unsigned>(hi)) << 32) | static_cast<unsigned>(lo);
+}
+
+__device__ __forceinline__ double ReadLane(double v, int sourceLane) {
+    return __longlong_as_double(static_cast<long long>(ReadLaneU64(static_cast<unsigned long long>(__double_as_longlong(v)), sourceLane)));
+}
+
+/// Largest of the 64 lanes' values, in scalar registers: butterfly inside every 16-lane DPP row (register to register), then the four rows.
+__device__ __forceinline__ unsigned long long WaveMaxU64(unsigned long long v) {
+    auto larger = [](unsigned long long x, unsigned long long y) { return x > y ? x : y; };
+    v = larger(v, DppU64<0xB1>(v));   // quad_perm [1, 0, 3, 2]
+    v = larger(v, DppU64<0x4E>(v));   // quad_perm [2, 3, 0, 1]
+    v = larger(v, DppU64<0x141>(v));  // row_half_mirror
+    v = larger(v, DppU64<0x140>(v));  // row_mirror
+    return larger(larger(ReadLaneU64(v, 0), ReadLaneU64(v, 16)), larger(ReadLaneU64(v, 32), ReadLaneU64(v, 48)));
+}
+
 constexpr int kBlock = 64;
+constexpr int kRegisterRows = 16;  // equality rows of a node the one-wavefront Gauss-Jordan keeps in registers
 
 __device__ __forceinline__ const double* RowOf(const double* rows, const ShootingDims& d, long long b, int k) {
     return rows + (b * (d.N + 1) + k) * static_cast<long long>(d.nv());
@@ -86,51 +114,158 @@ __global__ __launch_bounds__(256) void ShootingAssembleKernel(const ShootingAsse
     }
     __syncthreads();
     UNGAR_SHOOTING_MARK();  // 1: zeroed images, scattered stage outputs
-    // barrier terms  W += J_h^T diag(b''(-h)) J_h,  w -= J_h^T b'(-h)  straight from the SPARSE inequality Jacobian (28 of 588 entries for the
-    // quadruped's rows: a dense product over every entry of W read 44 k LDS words per node).  Row by row, in order: inside a row the pairs of its
-    // entries hit distinct targets, so plain read-modify-writes suffice and the sums are accumulated in the same order on every run.
-    if (stage && a.nh > 0) {
-        // the lane's entries (one for up to `lanes` non-zeros, the common case) are fetched once; the row loop below touches LDS only
-        const int mine = lane < a.ph.nnz ? lane : -1;
-        const int myRow = mine >= 0 ? a.ph.rows[mine] : -1, myCol = mine >= 0 ? a.ph.cols[mine] : 0;
-        const double myValue = mine >= 0 ? a.hJ[nodeOff * a.ph.nnz + mine] : 0.0;
-        int partners = 0;  // entries of the same row from this one on (columns ascend within a row: upper triangle)
-        if (mine >= 0)
-            for (int e2 = mine; e2 < a.ph.nnz && a.ph.rows[e2] == myRow; ++e2) ++partners;
-        for (int j = 0; j < a.nh; ++j) {
-            if (myRow == j) {
-                gd[myCol] -= d1[j] * myValue;  // d/dz b(-h) = -b'(-h) dh/dz
-                for (int t = 0; t < partners; ++t) Wd[myCol * nd + a.ph.cols[mine + t]] += d2[j] * myValue * a.hJ[nodeOff * a.ph.nnz + mine + t];
-            }
-            for (int e1 = lane + lanes; e1 < a.ph.nnz; e1 += lanes) {  // (patterns with more non-zeros than lanes)
-                if (a.ph.rows[e1] != j) continue;
-                const int c1 = a.ph.cols[e1];
-                const double v1 = a.hJ[nodeOff * a.ph.nnz + e1];
-                gd[c1] -= d1[j] * v1;
-                for (int e2 = e1; e2 < a.ph.nnz && a.ph.rows[e2] == j; ++e2) Wd[c1 * nd + a.ph.cols[e2]] += d2[j] * v1 * a.hJ[nodeOff * a.ph.nnz + e2];
-            }
-            __syncthreads();
-        }
-    }
-    UNGAR_SHOOTING_MARK();  // 2: barrier terms
-    // regularisation, and the lower triangle mirrored (W is kept in LDS with both triangles)
-    for (int idx = lane; idx < nd * nd; idx += lanes) {
-        const int r = static_cast<int>((static_cast<float>(idx) + 0.5f) * ndInv), c = idx - r * nd;
-        if (r > c) continue;
-        double acc = Wd[idx];
-        if (r == c && r >= nc && (stage || r < nz)) acc += a.regularization;  // the reference's 1e-6 I over its decision variables (soft_sqp.hpp:149-151)
-        Wd[idx] = acc;
-        Wd[c * nd + r] = acc;
-    }
+    const int elim = a.eliminate & 3;  // (bit 2: measurement switch -- the generic sections below for every node)
     const long long stageOff = b * d.N + k;
-    if (stage) {
-        const double* next = RowOf(a.rows, d, b, k + 1);
-        for (int i = lane; i < nz; i += lanes) bd[i] = i < nc ? 0.0 : a.f[nodeOff * nx + (i - nc)] - next[i];
-        for (int j = lane; j < a.ne; j += lanes) Ed[j * ld + nd] = a.e ? a.e[nodeOff * a.ne + j] : 0.0;
+    // A stage node with few equality rows and a tableau no wider than a wavefront (the quadruped: 16 x 50) runs the next three sections as
+    // INDEPENDENT jobs of single wavefronts, with no workgroup barrier until all are done: the Gauss-Jordan elimination in the registers of
+    // wavefront 0 (16 barrier-separated LDS sweeps before: 35-51 k of a node's ~115 k cycles), the barrier terms + regularisation + mirror in
+    // wavefront 1 (in-order LDS traffic of one wavefront replaces a workgroup barrier per inequality row), the defect b in the others.
+    const bool specialised = stage && elim && a.ne > 0 && a.ne <= kRegisterRows && ld <= 64 && a.ph.nnz <= 64 && waves >= 4 && !(a.eliminate & 4);
+    if (specialised) {
+#ifdef UNGAR_SHOOTING_CLOCKS
+        const unsigned long long jobStart = __builtin_amdgcn_s_memtime();
+#endif
+        if (wave == 0) {
+            // ---- Gauss-Jordan on [C | D | e], lane = column, the rows in registers: the same pivot rule and the same arithmetic as the generic
+            // section below (largest unused input coefficient of the row, compared on the bit pattern with the low byte replaced by 255 - input),
+            // entries exchanged with v_readlane and the two maxima of a step reduced with DPP moves.
+            double t[kRegisterRows];
+#pragma unroll
+            for (int r = 0; r < kRegisterRows; ++r) {
+                double v = 0.0;
+                if (r < a.ne) {
+                    if (wl < nd) v = Ed[r * ld + wl];
+                    else if (wl == nd && a.e) v = a.e[nodeOff * a.ne + r];
+                }
+                t[r] = v;
+            }
+            unsigned long long taken = 0ull;  // inputs that are pivots already (wave-uniform)
+            const int myInput = wl - nz;
+            const bool inputLane = wl >= nz && wl < nd;
+#pragma unroll
+            for (int i = 0; i < kRegisterRows; ++i) {
+                if (i < a.ne) {  // (uniform)
+                    const unsigned long long bits = static_cast<unsigned long long>(__double_as_longlong(fabs(t[i])));
+                    const bool candidate = bits != 0ull && inputLane && !((taken >> (myInput & 63)) & 1ull);
+                    const unsigned long long key = WaveMaxU64(candidate ? (bits & ~0xFFull) | static_cast<unsigned long long>(255 - myInput) : 0ull);
+                    const unsigned long long rowBits = WaveMaxU64(bits);
+                    const double best = __longlong_as_double(static_cast<long long>(key & ~0xFFull)), rowMax = __longlong_as_double(static_cast<long long>(rowBits));
+                    int j = key ? 255 - static_cast<int>(key & 0xFFull) : -1;
+                    if (j >= 0 && best <= 1e-12 * rowMax) j = -2;
+                    if (j == -1 && rowMax > 0.0) j = -2;
+                    if (wl == 0) pivCol[i] = j;
+                    if (j >= 0) {
+                        taken |= 1ull << j;
+                        const int J = nz + j;
+                        const double rpiv = 1.0 / ReadLane(t[i], J);
+                        const double p = wl == J ? 1.0 : t[i] * rpiv;
+#pragma unroll
+                        for (int r = 0; r < kRegisterRows; ++r) {
+                            if (r == i) continue;
+                            const double m = ReadLane(t[r], J);
+                            t[r] = wl == J ? 0.0 : t[r] - m * p;
+                        }
+                        t[i] = p;
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < kRegisterRows; ++r)
+                if (r < a.ne && wl < ld) Ed[r * ld + wl] = t[r];
+            if (wl < d.nu) used[wl] = static_cast<int>((taken >> wl) & 1ull);
+        } else if (wave == 1) {
+            if (a.nh > 0) {
+                const int mine = wl < a.ph.nnz ? wl : -1;
+                const int myRow = mine >= 0 ? a.ph.rows[mine] : -1, myCol = mine >= 0 ? a.ph.cols[mine] : 0;
+                const double myValue = mine >= 0 ? a.hJ[nodeOff * a.ph.nnz + mine] : 0.0;
+                int partners = 0;
+                if (mine >= 0)
+                    for (int e2 = mine; e2 < a.ph.nnz && a.ph.rows[e2] == myRow; ++e2) ++partners;
+                constexpr int kHeld = 4;  // partner values fetched before the row loop (the loop then touches LDS only)
+                double held[kHeld];
+                int heldCol[kHeld];
+#pragma unroll
+                for (int q = 0; q < kHeld; ++q) {
+                    held[q] = q < partners ? a.hJ[nodeOff * a.ph.nnz + mine + q] : 0.0;
+                    heldCol[q] = q < partners ? a.ph.cols[mine + q] : 0;
+                }
+                for (int j = 0; j < a.nh; ++j) {  // row by row, in order (rows share targets): consecutive LDS instructions of ONE wavefront execute in order
+                    if (myRow == j) {
+                        gd[myCol] -= d1[j] * myValue;
+#pragma unroll
+                        for (int q = 0; q < kHeld; ++q)
+                            if (q < partners) Wd[myCol * nd + heldCol[q]] += d2[j] * myValue * held[q];
+                        for (int q = kHeld; q < partners; ++q) Wd[myCol * nd + a.ph.cols[mine + q]] += d2[j] * myValue * a.hJ[nodeOff * a.ph.nnz + mine + q];
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            for (int idx = wl; idx < nd * nd; idx += 64) {
+                const int r = static_cast<int>((static_cast<float>(idx) + 0.5f) * ndInv), c = idx - r * nd;
+                if (r > c) continue;
+                double acc = Wd[idx];
+                if (r == c && r >= nc) acc += a.regularization;
+                Wd[idx] = acc;
+                Wd[c * nd + r] = acc;
+            }
+        } else {
+            const double* next = RowOf(a.rows, d, b, k + 1);
+            for (int i = lane - 128; i < nz; i += lanes - 128) bd[i] = i < nc ? 0.0 : a.f[nodeOff * nx + (i - nc)] - next[i];
+        }
+#ifdef UNGAR_SHOOTING_CLOCKS
+        if (wl == 0 && (node == 1 || node == d.batch * (d.N + 1) / 2 + 1))
+            printf("[assemble jobs] node %lld wavefront %d: %llu cycles\n", node, wave, __builtin_amdgcn_s_memtime() - jobStart);
+#endif
+        __syncthreads();
+        UNGAR_SHOOTING_MARK();  // 2: the three jobs
+        UNGAR_SHOOTING_MARK();  // 3
+    } else {
+        // barrier terms  W += J_h^T diag(b''(-h)) J_h,  w -= J_h^T b'(-h)  straight from the SPARSE inequality Jacobian (28 of 588 entries for the
+        // quadruped's rows: a dense product over every entry of W read 44 k LDS words per node).  Row by row, in order: inside a row the pairs of its
+        // entries hit distinct targets, so plain read-modify-writes suffice and the sums are accumulated in the same order on every run.
+        if (stage && a.nh > 0) {
+            // the lane's entries (one for up to `lanes` non-zeros, the common case) are fetched once; the row loop below touches LDS only
+            const int mine = lane < a.ph.nnz ? lane : -1;
+            const int myRow = mine >= 0 ? a.ph.rows[mine] : -1, myCol = mine >= 0 ? a.ph.cols[mine] : 0;
+            const double myValue = mine >= 0 ? a.hJ[nodeOff * a.ph.nnz + mine] : 0.0;
+            int partners = 0;  // entries of the same row from this one on (columns ascend within a row: upper triangle)
+            if (mine >= 0)
+                for (int e2 = mine; e2 < a.ph.nnz && a.ph.rows[e2] == myRow; ++e2) ++partners;
+            for (int j = 0; j < a.nh; ++j) {
+                if (myRow == j) {
+                    gd[myCol] -= d1[j] * myValue;  // d/dz b(-h) = -b'(-h) dh/dz
+                    for (int t = 0; t < partners; ++t) Wd[myCol * nd + a.ph.cols[mine + t]] += d2[j] * myValue * a.hJ[nodeOff * a.ph.nnz + mine + t];
+                }
+                for (int e1 = lane + lanes; e1 < a.ph.nnz; e1 += lanes) {  // (patterns with more non-zeros than lanes)
+                    if (a.ph.rows[e1] != j) continue;
+                    const int c1 = a.ph.cols[e1];
+                    const double v1 = a.hJ[nodeOff * a.ph.nnz + e1];
+                    gd[c1] -= d1[j] * v1;
+                    for (int e2 = e1; e2 < a.ph.nnz && a.ph.rows[e2] == j; ++e2) Wd[c1 * nd + a.ph.cols[e2]] += d2[j] * v1 * a.hJ[nodeOff * a.ph.nnz + e2];
+                }
+                __syncthreads();
+            }
+        }
+        UNGAR_SHOOTING_MARK();  // 2: barrier terms
+        // regularisation, and the lower triangle mirrored (W is kept in LDS with both triangles)
+        for (int idx = lane; idx < nd * nd; idx += lanes) {
+            const int r = static_cast<int>((static_cast<float>(idx) + 0.5f) * ndInv), c = idx - r * nd;
+            if (r > c) continue;
+            double acc = Wd[idx];
+            if (r == c && r >= nc && (stage || r < nz)) acc += a.regularization;  // the reference's 1e-6 I over its decision variables (soft_sqp.hpp:149-151)
+            Wd[idx] = acc;
+            Wd[c * nd + r] = acc;
+        }
+        if (stage) {
+            const double* next = RowOf(a.rows, d, b, k + 1);
+            for (int i = lane; i < nz; i += lanes) bd[i] = i < nc ? 0.0 : a.f[nodeOff * nx + (i - nc)] - next[i];
+            for (int j = lane; j < a.ne; j += lanes) Ed[j * ld + nd] = a.e ? a.e[nodeOff * a.ne + j] : 0.0;
+        }
+        __syncthreads();
+        UNGAR_SHOOTING_MARK();  // 3: regularisation, mirror, b
     }
-    __syncthreads();
-    UNGAR_SHOOTING_MARK();  // 3: regularisation, mirror, b
-    if (stage && a.eliminate && a.ne > 0) {
+    if (stage && elim && a.ne > 0) {
         /// list <- {c < n : pred(c)} in ascending order, by the first wavefront (no closing barrier)
         auto buildList = [&](int n, auto pred) {
             if (wave == 0) {
@@ -145,64 +280,66 @@ __global__ __launch_bounds__(256) void ShootingAssembleKernel(const ShootingAsse
                 if (wl == 0) *listSize = size;
             }
         };
-        // ---- Gauss-Jordan on the tableau [C | D | e]: one pivot input per active row.  The pivot of a row is its largest unused input
-        // coefficient, found with ONE LDS atomic per lane: for non-negative doubles the bit pattern orders like the value, so
-        // max(bits(|v|) with the low byte replaced by 255 - input) is the largest coefficient up to 2^-44 relative, ties to the lowest input.
-        // Step i reads one tableau and writes the other (no read-after-write inside a step) and, while writing row i + 1, already
-        // collects that row's keys: ONE barrier per step.  Three key sets rotate so that a set is cleared a full step before its reuse.
-        unsigned long long* keys = reinterpret_cast<unsigned long long*>(vbuf);  // set s: [2 s] pivot key, [2 s + 1] bits of the row's largest |entry|
-        double* T[2] = {Ed, vbuf + 6};
-        const float ldInv = 1.0f / static_cast<float>(ld);
-        auto offer = [&](int set, int c, double value, int excluded) {  // entry c of the row whose keys are collected into `set`
-            const unsigned long long bits = static_cast<unsigned long long>(__double_as_longlong(fabs(value)));
-            if (!bits) return;
-            atomicMax(&keys[2 * set + 1], bits);
-            if (c >= nz && c < nd && c - nz != excluded && !used[c - nz]) atomicMax(&keys[2 * set], (bits & ~0xFFull) | static_cast<unsigned long long>(255 - (c - nz)));
-        };
-        for (int j = lane; j < d.nu; j += lanes) used[j] = 0;
-        if (lane < 6) keys[lane] = 0ull;
-        __syncthreads();
-        for (int c = lane; c < ld; c += lanes) offer(0, c, Ed[c], -1);
-        __syncthreads();
-        int cur = 0;
-        for (int i = 0; i < a.ne; ++i) {
-            const double* src = T[cur];
-            const int set = i % 3, nextSet = (i + 1) % 3;
-            const unsigned long long key = keys[2 * set];
-            const double best = __longlong_as_double(static_cast<long long>(key & ~0xFFull)), rowMax = __longlong_as_double(static_cast<long long>(keys[2 * set + 1]));
-            // no usable input coefficient: an identically-zero (or redundant) row takes no pivot; anything else cannot be met by this knot's inputs
-            int j = key ? 255 - static_cast<int>(key & 0xFFull) : -1;
-            if (j >= 0 && best <= 1e-12 * rowMax) j = -2;
-            if (j == -1 && rowMax > 0.0) j = -2;
-            if (lane == 0) {
-                pivCol[i] = j;
-                if (j >= 0) used[j] = 1;  // (readers of this step exclude j themselves; later steps see the flag behind the barrier)
-                keys[2 * ((i + 2) % 3)] = 0ull;
-                keys[2 * ((i + 2) % 3) + 1] = 0ull;
-            }
-            if (j >= 0) {
-                double* dst = T[cur ^ 1];
-                const int J = nz + j;
-                const double rpiv = 1.0 / src[i * ld + J];
-                // (wavefront -> rows, lane -> column: the scaled pivot-row entry of a column is computed once per lane, a row's multiplier is one broadcast
-                // read, and no index is decoded -- a step is 4 short iterations for 16 rows; the flat index space cost ~35 instructions per item)
-                for (int c = wl; c < ld; c += 64) {
-                    const double p = c == J ? 1.0 : src[i * ld + c] * rpiv;  // (the pivot exactly 1, its column exactly 0 elsewhere)
-                    for (int r = wave; r < a.ne; r += waves) {
-                        const double v = r == i ? p : (c == J ? 0.0 : src[r * ld + c] - src[r * ld + J] * p);
-                        dst[r * ld + c] = v;
-                        if (r == i + 1) offer(nextSet, c, v, j);
-                    }
+        if (!specialised) {
+            // ---- Gauss-Jordan on the tableau [C | D | e]: one pivot input per active row.  The pivot of a row is its largest unused input
+            // coefficient, found with ONE LDS atomic per lane: for non-negative doubles the bit pattern orders like the value, so
+            // max(bits(|v|) with the low byte replaced by 255 - input) is the largest coefficient up to 2^-44 relative, ties to the lowest input.
+            // Step i reads one tableau and writes the other (no read-after-write inside a step) and, while writing row i + 1, already
+            // collects that row's keys: ONE barrier per step.  Three key sets rotate so that a set is cleared a full step before its reuse.
+            unsigned long long* keys = reinterpret_cast<unsigned long long*>(vbuf);  // set s: [2 s] pivot key, [2 s + 1] bits of the row's largest |entry|
+            double* T[2] = {Ed, vbuf + 6};
+            const float ldInv = 1.0f / static_cast<float>(ld);
+            auto offer = [&](int set, int c, double value, int excluded) {  // entry c of the row whose keys are collected into `set`
+                const unsigned long long bits = static_cast<unsigned long long>(__double_as_longlong(fabs(value)));
+                if (!bits) return;
+                atomicMax(&keys[2 * set + 1], bits);
+                if (c >= nz && c < nd && c - nz != excluded && !used[c - nz]) atomicMax(&keys[2 * set], (bits & ~0xFFull) | static_cast<unsigned long long>(255 - (c - nz)));
+            };
+            for (int j = lane; j < d.nu; j += lanes) used[j] = 0;
+            if (lane < 6) keys[lane] = 0ull;
+            __syncthreads();
+            for (int c = lane; c < ld; c += lanes) offer(0, c, Ed[c], -1);
+            __syncthreads();
+            int cur = 0;
+            for (int i = 0; i < a.ne; ++i) {
+                const double* src = T[cur];
+                const int set = i % 3, nextSet = (i + 1) % 3;
+                const unsigned long long key = keys[2 * set];
+                const double best = __longlong_as_double(static_cast<long long>(key & ~0xFFull)), rowMax = __longlong_as_double(static_cast<long long>(keys[2 * set + 1]));
+                // no usable input coefficient: an identically-zero (or redundant) row takes no pivot; anything else cannot be met by this knot's inputs
+                int j = key ? 255 - static_cast<int>(key & 0xFFull) : -1;
+                if (j >= 0 && best <= 1e-12 * rowMax) j = -2;
+                if (j == -1 && rowMax > 0.0) j = -2;
+                if (lane == 0) {
+                    pivCol[i] = j;
+                    if (j >= 0) used[j] = 1;  // (readers of this step exclude j themselves; later steps see the flag behind the barrier)
+                    keys[2 * ((i + 2) % 3)] = 0ull;
+                    keys[2 * ((i + 2) % 3) + 1] = 0ull;
                 }
-                cur ^= 1;
-            } else if (i + 1 < a.ne) {
-                for (int c = lane; c < ld; c += lanes) offer(nextSet, c, src[(i + 1) * ld + c], -1);
+                if (j >= 0) {
+                    double* dst = T[cur ^ 1];
+                    const int J = nz + j;
+                    const double rpiv = 1.0 / src[i * ld + J];
+                    // (wavefront -> rows, lane -> column: the scaled pivot-row entry of a column is computed once per lane, a row's multiplier is one broadcast
+                    // read, and no index is decoded -- a step is 4 short iterations for 16 rows; the flat index space cost ~35 instructions per item)
+                    for (int c = wl; c < ld; c += 64) {
+                        const double p = c == J ? 1.0 : src[i * ld + c] * rpiv;  // (the pivot exactly 1, its column exactly 0 elsewhere)
+                        for (int r = wave; r < a.ne; r += waves) {
+                            const double v = r == i ? p : (c == J ? 0.0 : src[r * ld + c] - src[r * ld + J] * p);
+                            dst[r * ld + c] = v;
+                            if (r == i + 1) offer(nextSet, c, v, j);
+                        }
+                    }
+                    cur ^= 1;
+                } else if (i + 1 < a.ne) {
+                    for (int c = lane; c < ld; c += lanes) offer(nextSet, c, src[(i + 1) * ld + c], -1);
+                }
+                __syncthreads();
             }
-            __syncthreads();
-        }
-        if (cur) {  // the reduced rows back where the substitution and the output expect them
-            for (int idx = lane; idx < a.ne * ld; idx += lanes) Ed[idx] = T[1][idx];
-            __syncthreads();
+            if (cur) {  // the reduced rows back where the substitution and the output expect them
+                for (int idx = lane; idx < a.ne * ld; idx += lanes) Ed[idx] = T[1][idx];
+                __syncthreads();
+            }
         }
         UNGAR_SHOOTING_MARK();  // 4: Gauss-Jordan
         double* V = vbuf + 6;  // pivots x nd (the second tableau is dead)
@@ -214,7 +351,7 @@ __global__ __launch_bounds__(256) void ShootingAssembleKernel(const ShootingAsse
         // instructions.  v_mfma_f64_16x16x4_f64: A[i][k] in lane 16 k + i, B[k][j] in lane 16 k + j, D[(lane >> 4) + 4 r][lane & 15] in element r.
         buildList(a.ne, [&](int r) { return pivCol[r] >= 0; });
         __syncthreads();
-        const int pivots = a.eliminate == 2 ? 0 : *listSize;  // (2: measurement only -- rows reduced, substitution skipped)
+        const int pivots = elim == 2 ? 0 : *listSize;  // (2: measurement only -- rows reduced, substitution skipped)
         using f64x4 = __attribute__((__vector_size__(4 * sizeof(double)))) double;
         const int li = wl & 15, lk = wl >> 4, KS = pivots > 0 ? (a.ne + 3) >> 2 : 0, TD = (nd + 15) >> 4, TE = (a.ne + 15) >> 4, TZ = (nz + 15) >> 4;
         auto pivotColumn = [&](int t) { return t < a.ne ? pivCol[t] : -1; };  // input the row t was solved for, or < 0

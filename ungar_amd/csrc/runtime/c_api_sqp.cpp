@@ -216,6 +216,7 @@ int ungar_shooting_assemble(const ungar_shooting_assemble_args* a, void* stream)
     k.E = a->E;
     k.dz0 = a->dz0;
     k.eliminate = a->eliminate_equalities && a->ne > 0 ? (getenv("UNGAR_AMD_ASSEMBLE_SKIP_SUBSTITUTION") ? 2 : 1) : 0;
+    if (k.eliminate && getenv("UNGAR_AMD_ASSEMBLE_GENERIC")) k.eliminate |= 4;  // measurement switch: no wavefront-specialised sections (same bits)
     k.e = a->eq;
     k.er = a->eq_reduced;
     k.pivots = a->eq_pivots;
