@@ -21,12 +21,17 @@ for mode in specialised generic; do
   done
 done
 unset UNGAR_AMD_ASSEMBLE_GENERIC
+for v in entry_lanes mirror_one_wave both; do  # measurement variants (tools/make_shooting_variants.sh)
+  if [ -f build/variants/shooting_$v/libungar_amd.so ]; then
+    for rep in 1 2; do LD_LIBRARY_PATH=build/variants/shooting_$v:${LD_LIBRARY_PATH:-} timeout 900 $T /tmp/cg_q 4096 0 2>&1 | grep -E "timing" | sed "s/^/[variant $v] /"; done
+  fi
+done
 rm -rf gpurun_out/bprof_asm
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/gpurun_out/bprof_asm -o b -- $OLDPWD/$T /tmp/cg_q 4096 0 > /dev/null 2>&1)
 f=$(find gpurun_out/bprof_asm -name "b_kernel_stats.csv" | head -1)
 [ -n "$f" ] && cp "$f" gpurun_out/assemble_ab_kernel_stats.csv && head -8 "$f" | cut -c1-200
 rm -rf gpurun_out/bprof_asm
 if [ -f build/variants/shooting_clocks/libungar_amd.so ]; then
-  LD_LIBRARY_PATH=build/variants/shooting_clocks:${LD_LIBRARY_PATH:-} UNGAR_AMD_LIBRARY=build/variants/shooting_clocks/libungar_amd.so timeout 600 $T /tmp/cg_q 1024 0 2>&1 | grep -E "assemble (clocks|jobs)" | head -24 > gpurun_out/assemble_ab_clocks.log
+  LD_LIBRARY_PATH=build/variants/shooting_clocks:${LD_LIBRARY_PATH:-} UNGAR_AMD_LIBRARY=build/variants/shooting_clocks/libungar_amd.so timeout 600 $T /tmp/cg_q 1024 0 2>&1 | grep -E "assemble clocks" | head -12 > gpurun_out/assemble_ab_clocks.log
   cat gpurun_out/assemble_ab_clocks.log
 fi

@@ -1,0 +1,18 @@
+#!/usr/bin/env bash
+# Measurement variants of the shooting assembly kernel (run here, CPU; needs a finished library build):
+#   build/variants/shooting_<name>/libungar_amd.so for name in  entry_lanes (barrier terms one lane per entry),  mirror_one_wave,  both (= the first
+#   wavefront-specialised version),  clocks (section clocks).  GPU box: LD_LIBRARY_PATH=build/variants/shooting_<name> build/batched_quadruped_test ...
+set -euo pipefail
+cd "$(dirname "$0")/.."
+variant() {  # name, flags
+  local name=$1; shift
+  mkdir -p build/variants/shooting_$name
+  hipcc --offload-arch=gfx950 -O3 -std=c++20 -fPIC -Wno-unused-result "$@" -c ungar_amd/csrc/kernels/ocp_shooting.hip -o build/variants/ocp_shooting_$name.o
+  hipcc --offload-arch=gfx950 -shared -fPIC -o build/variants/shooting_$name/libungar_amd.so $(ls build/*.o | grep -v "/ocp_shooting.o") build/variants/ocp_shooting_$name.o
+  rm -f build/variants/ocp_shooting_$name.o
+  echo built build/variants/shooting_$name/libungar_amd.so
+}
+variant entry_lanes -DUNGAR_ASSEMBLE_ENTRY_LANES
+variant mirror_one_wave -DUNGAR_ASSEMBLE_MIRROR_ONE_WAVE
+variant both -DUNGAR_ASSEMBLE_ENTRY_LANES -DUNGAR_ASSEMBLE_MIRROR_ONE_WAVE
+variant clocks -DUNGAR_SHOOTING_CLOCKS

@@ -20,14 +20,6 @@ __device__ __forceinline__ double QuadPermute(double v) {  // DPP quad_perm: reg
     return __hiloint2double(hi, lo);
 }
 
-template <int CTRL>
-__device__ __forceinline__ unsigned long long DppU64(unsigned long long v) {  // (bound_ctrl: a lane without a source reads 0, the identity of the max below)
-    int lo = static_cast<int>(v), hi = static_cast<int>(v >> 32);
-    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
-    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
-    return (static_cast<unsigned long long>(static_cast<unsigned>(hi)) << 32) | static_cast<unsigned>(lo);
-}
-
 __device__ __forceinline__ unsigned long long ReadLaneU64(unsigned long long v, int sourceLane) {  // sourceLane wave-uniform
     const int lo = __builtin_amdgcn_readlane(static_cast<int>(v), sourceLane), hi = __builtin_amdgcn_readlane(static_cast<int>(v >> 32), sourceLane);
     return (static_cast<unsigned long long>(static_cast<unsigned>(hi)) << 32) | static_cast<unsigned>(lo);
@@ -37,14 +29,65 @@ __device__ __forceinline__ double ReadLane(double v, int sourceLane) {
     return __longlong_as_double(static_cast<long long>(ReadLaneU64(static_cast<unsigned long long>(__double_as_longlong(v)), sourceLane)));
 }
 
-/// Largest of the 64 lanes' values, in scalar registers: butterfly inside every 16-lane DPP row (register to register), then the four rows.
-__device__ __forceinline__ unsigned long long WaveMaxU64(unsigned long long v) {
-    auto larger = [](unsigned long long x, unsigned long long y) { return x > y ? x : y; };
-    v = larger(v, DppU64<0xB1>(v));   // quad_perm [1, 0, 3, 2]
-    v = larger(v, DppU64<0x4E>(v));   // quad_perm [2, 3, 0, 1]
-    v = larger(v, DppU64<0x141>(v));  // row_half_mirror
-    v = larger(v, DppU64<0x140>(v));  // row_mirror
-    return larger(larger(ReadLaneU64(v, 0), ReadLaneU64(v, 16)), larger(ReadLaneU64(v, 32), ReadLaneU64(v, 48)));
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double DppOrZero(double v) {  // lanes without a source (or outside ROW_MASK) read +0.0, the identity of the max below
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double MaxOfNonNegative(double x, double y) {  // the instruction itself: fmax() canonicalises both operands first (two more v_max_f64)
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+
+/// Largest of the 64 lanes' values of TWO quantities at once (the two chains fill each other's issue gaps), left in scalar registers.  The values are bit
+/// patterns of NON-NEGATIVE finite doubles, which order like the doubles: v_max_f64 returns one of its operands unchanged (FP64 denormals are kept), so the
+/// result is the integer maximum -- three instructions per stage instead of five.  Stages: butterfly inside each 16-lane DPP row, then row_bcast:15 /
+/// row_bcast:31 carry the row maxima forward; lane 63 holds the maximum of the wavefront.
+__device__ __forceinline__ void WaveMaxPair(unsigned long long& x, unsigned long long& y) {
+    double u = __longlong_as_double(static_cast<long long>(x)), v = __longlong_as_double(static_cast<long long>(y));
+#define UNGAR_MAX_STAGE(CTRL, ROWS)              \
+    {                                            \
+        const double su = DppOrZero<CTRL, ROWS>(u), sv = DppOrZero<CTRL, ROWS>(v); \
+        u = MaxOfNonNegative(u, su);             \
+        v = MaxOfNonNegative(v, sv);             \
+    }
+    UNGAR_MAX_STAGE(0xB1, 0xF)   // quad_perm [1, 0, 3, 2]
+    UNGAR_MAX_STAGE(0x4E, 0xF)   // quad_perm [2, 3, 0, 1]
+    UNGAR_MAX_STAGE(0x141, 0xF)  // row_half_mirror
+    UNGAR_MAX_STAGE(0x140, 0xF)  // row_mirror: every lane of a row holds the row's maximum
+    UNGAR_MAX_STAGE(0x142, 0xA)  // row_bcast:15 into rows 1 and 3
+    UNGAR_MAX_STAGE(0x143, 0xC)  // row_bcast:31 into rows 2 and 3
+#undef UNGAR_MAX_STAGE
+    x = ReadLaneU64(static_cast<unsigned long long>(__double_as_longlong(u)), 63);
+    y = ReadLaneU64(static_cast<unsigned long long>(__double_as_longlong(v)), 63);
+}
+
+__device__ __forceinline__ int WaveMinInt(int v) {  // smallest of the 64 lanes' values (same stages as above), wave-uniform
+#define UNGAR_MIN_STAGE(CTRL, ROWS) v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, CTRL, ROWS, 0xF, false));
+    UNGAR_MIN_STAGE(0xB1, 0xF)
+    UNGAR_MIN_STAGE(0x4E, 0xF)
+    UNGAR_MIN_STAGE(0x141, 0xF)
+    UNGAR_MIN_STAGE(0x140, 0xF)
+    UNGAR_MIN_STAGE(0x142, 0xA)
+    UNGAR_MIN_STAGE(0x143, 0xC)
+#undef UNGAR_MIN_STAGE
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+__device__ __forceinline__ unsigned WaveOr(unsigned v) {  // bitwise OR of the 64 lanes' values, wave-uniform
+#define UNGAR_OR_STAGE(CTRL, ROWS) v |= static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), CTRL, ROWS, 0xF, true));
+    UNGAR_OR_STAGE(0xB1, 0xF)
+    UNGAR_OR_STAGE(0x4E, 0xF)
+    UNGAR_OR_STAGE(0x141, 0xF)
+    UNGAR_OR_STAGE(0x140, 0xF)
+    UNGAR_OR_STAGE(0x142, 0xA)
+    UNGAR_OR_STAGE(0x143, 0xC)
+#undef UNGAR_OR_STAGE
+    return static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(v), 63));
 }
 
 constexpr int kBlock = 64;
@@ -65,7 +108,7 @@ __global__ __launch_bounds__(256) void ShootingAssembleKernel(const ShootingAsse
     const int k = static_cast<int>(node - b * (d.N + 1));
     if (b >= d.batch) return;
     const int lane = static_cast<int>(threadIdx.x), lanes = static_cast<int>(blockDim.x);
-    const int wave = lane >> 6, wl = lane & 63, waves = lanes >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(lane >> 6), wl = lane & 63, waves = lanes >> 6;  // (the wavefront's index in a scalar register: tile loops and the single-wavefront jobs branch without execution masks)
     const int nz = d.nz(), nd = d.nd(), nc = d.nc, nx = d.nx;
     const bool stage = k < d.N;  // knot N: terminal cost only
     const float ndInv = 1.0f / static_cast<float>(nd);  // row of a flat index through a float reciprocal: exact for nd <= 256 (idx + 0.5 is never a multiple of nd)
@@ -84,6 +127,8 @@ __global__ __launch_bounds__(256) void ShootingAssembleKernel(const ShootingAsse
     int* list = used + d.nu;          // max(nd, ne) indices of a support
     int* listSize = list + (nd > a.ne ? nd : a.ne);
 #ifdef UNGAR_SHOOTING_CLOCKS  // diagnostic build (tools/make_shooting_clocks.sh): cycles of the sections of one stage node, printed by its first lane
+    __shared__ unsigned long long jobCycles[9];  // the single-wavefront jobs: [wavefront], [4] = barrier terms of wavefront 1
+    if (threadIdx.x < 9) jobCycles[threadIdx.x] = 0ull;
     unsigned long long marks[12];
     int markCount = 0;
 #define UNGAR_SHOOTING_MARK() marks[markCount++] = __builtin_amdgcn_s_memtime()
@@ -92,28 +137,7 @@ __global__ __launch_bounds__(256) void ShootingAssembleKernel(const ShootingAsse
 #endif
     UNGAR_SHOOTING_MARK();
     const int total = nd * nd + nd + 2 * a.nh + nz * nd + a.ne * ld;
-    for (int i = lane; i < total; i += lanes) lds[i] = 0.0;
-    __syncthreads();
     const long long nodeOff = b * (d.N + 1) + k;
-    for (int e = lane; e < a.pH.nnz; e += lanes) Wd[a.pH.rows[e] * nd + a.pH.cols[e]] = a.lH[nodeOff * a.pH.nnz + e];
-    for (int e = lane; e < a.pg.nnz; e += lanes) gd[a.pg.cols[e]] = a.lg[nodeOff * a.pg.nnz + e];
-    if (stage) {
-        for (int j = lane; j < a.nh; j += lanes) {
-            const double z = -a.h[nodeOff * a.nh + j];
-            d1[j] = BarrierD1(a.barrier, z);
-            d2[j] = BarrierD2(a.barrier, z);
-        }
-        // [A|B]: function column j over [x|u] is column nc + j of [c|x|u]
-        for (int e = lane; e < a.pf.nnz; e += lanes) ABd[(nc + a.pf.rows[e]) * nd + nc + a.pf.cols[e]] = a.fJ[nodeOff * a.pf.nnz + e];
-        if (d.carryInputs) {
-            for (int r = lane; r < nc; r += lanes) ABd[r * nd + nz + r] = 1.0;
-        } else {
-            for (int e = lane; e < a.pc.nnz; e += lanes) ABd[a.pc.rows[e] * nd + nc + a.pc.cols[e]] = a.cJ[nodeOff * a.pc.nnz + e];
-        }
-        for (int e = lane; e < a.pe.nnz; e += lanes) Ed[a.pe.rows[e] * ld + a.pe.cols[e]] = a.eJ[nodeOff * a.pe.nnz + e];
-    }
-    __syncthreads();
-    UNGAR_SHOOTING_MARK();  // 1: zeroed images, scattered stage outputs
     const int elim = a.eliminate & 3;  // (bit 2: measurement switch -- the generic sections below for every node)
     const long long stageOff = b * d.N + k;
     // A stage node with few equality rows and a tableau no wider than a wavefront (the quadruped: 16 x 50) runs the next three sections as
@@ -121,11 +145,84 @@ __global__ __launch_bounds__(256) void ShootingAssembleKernel(const ShootingAsse
     // wavefront 0 (16 barrier-separated LDS sweeps before: 35-51 k of a node's ~115 k cycles), the barrier terms + regularisation + mirror in
     // wavefront 1 (in-order LDS traffic of one wavefront replaces a workgroup barrier per inequality row), the defect b in the others.
     const bool specialised = stage && elim && a.ne > 0 && a.ne <= kRegisterRows && ld <= 64 && a.ph.nnz <= 64 && waves >= 4 && !(a.eliminate & 4);
+    const int role = wave;  // (rotating the jobs over the wavefronts with the node index -- other SIMDs for co-resident nodes -- measured: no change)
+    // The first entry of every sparse output per lane (all of them, for patterns of up to `lanes` non-zeros) is requested BEFORE the images are zeroed: six
+    // scatter loops one after the other were six exposed round trips to memory (~10 k cycles per node).
+    struct First {
+        int target;  // < 0: none
+        double value;
+    };
+    auto first = [&](const StagePattern& pattern, const double* values, bool wanted, auto targetOf) {
+        First f{-1, 0.0};
+        if (wanted && values && lane < pattern.nnz) {
+            f.target = targetOf(pattern.rows ? pattern.rows[lane] : 0, pattern.cols[lane]);
+            f.value = values[nodeOff * pattern.nnz + lane];
+        }
+        return f;
+    };
+    auto hessianTarget = [&](int r, int c) { return r * nd + c; };
+    auto gradientTarget = [&](int, int c) { return c; };
+    auto dynamicsTarget = [&](int r, int c) { return (nc + r) * nd + nc + c; };
+    auto carryTarget = [&](int r, int c) { return r * nd + nc + c; };
+    auto equalityTarget = [&](int r, int c) { return r * ld + c; };
+    const First fH = first(a.pH, a.lH, true, hessianTarget), fg = first(a.pg, a.lg, true, gradientTarget), ff = first(a.pf, a.fJ, stage, dynamicsTarget),
+                fc = first(a.pc, a.cJ, stage && !d.carryInputs, carryTarget), fe = first(a.pe, a.eJ, stage, equalityTarget);
+    const double hFirst = stage && lane < a.nh ? a.h[nodeOff * a.nh + lane] : 0.0;
+    // (what the single-wavefront jobs of a specialised node start from is requested here as well: the inequality Jacobian entry of each lane of wavefront 1 and
+    // the equality residuals -- a first memory round trip inside a job is on that job's critical path)
+    const bool ownsInequalityEntry = specialised && a.nh > 0 && role == 1 && wl < a.ph.nnz;
+    const int inequalityRow = ownsInequalityEntry ? a.ph.rows[wl] : -1, inequalityColumn = ownsInequalityEntry ? a.ph.cols[wl] : 0;
+    const double inequalityValue = ownsInequalityEntry ? a.hJ[nodeOff * a.ph.nnz + wl] : 0.0;
+    const double residualFirst = specialised && a.e && lane < a.ne ? a.e[nodeOff * a.ne + lane] : 0.0;
+    for (int i = lane; i < total; i += lanes) lds[i] = 0.0;
+    __syncthreads();
+    if (fH.target >= 0) Wd[fH.target] = fH.value;
+    for (int e = lane + lanes; e < a.pH.nnz; e += lanes) Wd[a.pH.rows[e] * nd + a.pH.cols[e]] = a.lH[nodeOff * a.pH.nnz + e];
+    if (fg.target >= 0) gd[fg.target] = fg.value;
+    for (int e = lane + lanes; e < a.pg.nnz; e += lanes) gd[a.pg.cols[e]] = a.lg[nodeOff * a.pg.nnz + e];
+    if (stage) {
+        for (int j = lane; j < a.nh; j += lanes) {
+            const double z = -(j == lane ? hFirst : a.h[nodeOff * a.nh + j]);
+            d1[j] = BarrierD1(a.barrier, z);
+            d2[j] = BarrierD2(a.barrier, z);
+        }
+        // [A|B]: function column j over [x|u] is column nc + j of [c|x|u]
+        if (ff.target >= 0) ABd[ff.target] = ff.value;
+        for (int e = lane + lanes; e < a.pf.nnz; e += lanes) ABd[(nc + a.pf.rows[e]) * nd + nc + a.pf.cols[e]] = a.fJ[nodeOff * a.pf.nnz + e];
+        if (d.carryInputs) {
+            for (int r = lane; r < nc; r += lanes) ABd[r * nd + nz + r] = 1.0;
+        } else {
+            if (fc.target >= 0) ABd[fc.target] = fc.value;
+            for (int e = lane + lanes; e < a.pc.nnz; e += lanes) ABd[a.pc.rows[e] * nd + nc + a.pc.cols[e]] = a.cJ[nodeOff * a.pc.nnz + e];
+        }
+        if (fe.target >= 0) Ed[fe.target] = fe.value;
+        if (specialised && lane < a.ne) Ed[lane * ld + nd] = residualFirst;  // (the generic sections fill this column later)
+        for (int e = lane + lanes; e < a.pe.nnz; e += lanes) Ed[a.pe.rows[e] * ld + a.pe.cols[e]] = a.eJ[nodeOff * a.pe.nnz + e];
+    }
+    __syncthreads();
+    UNGAR_SHOOTING_MARK();  // 1: zeroed images, scattered stage outputs
     if (specialised) {
 #ifdef UNGAR_SHOOTING_CLOCKS
         const unsigned long long jobStart = __builtin_amdgcn_s_memtime();
 #endif
-        if (wave == 0) {
+        // the barrier terms touch W[c1][c2] with c1, c2 >= the smallest column of the inequality Jacobian's pattern: the rows above it are regularised and
+        // mirrored by the wavefronts that have nothing else to do, the rest by wavefront 1 once its terms are in
+#ifdef UNGAR_ASSEMBLE_MIRROR_ONE_WAVE
+        const int firstBarrierColumn = 0;
+#else
+        const int firstBarrierColumn = role == 0 ? 0 : (a.nh > 0 && a.ph.nnz > 0 ? WaveMinInt(wl < a.ph.nnz ? a.ph.cols[wl] : nd) : nd);
+#endif
+        auto regulariseAndMirror = [&](int firstIndex, int lastIndex, int lane0, int step) {
+            for (int idx = firstIndex + lane0; idx < lastIndex; idx += step) {
+                const int r = static_cast<int>((static_cast<float>(idx) + 0.5f) * ndInv), c = idx - r * nd;
+                if (r > c) continue;
+                double acc = Wd[idx];
+                if (r == c && r >= nc) acc += a.regularization;
+                Wd[idx] = acc;
+                Wd[c * nd + r] = acc;
+            }
+        };
+        if (role == 0) {
             // ---- Gauss-Jordan on [C | D | e], lane = column, the rows in registers: the same pivot rule and the same arithmetic as the generic
             // section below (largest unused input coefficient of the row, compared on the bit pattern with the low byte replaced by 255 - input),
             // entries exchanged with v_readlane and the two maxima of a step reduced with DPP moves.
@@ -133,22 +230,30 @@ __global__ __launch_bounds__(256) void ShootingAssembleKernel(const ShootingAsse
 #pragma unroll
             for (int r = 0; r < kRegisterRows; ++r) {
                 double v = 0.0;
-                if (r < a.ne) {
-                    if (wl < nd) v = Ed[r * ld + wl];
-                    else if (wl == nd && a.e) v = a.e[nodeOff * a.ne + r];
-                }
+                if (r < a.ne && wl < ld) v = Ed[r * ld + wl];
                 t[r] = v;
             }
+            // rows that are identically zero now (inactive contacts: half of them on average) stay zero under every update and take no pivot: found once,
+            // their steps are skipped (a step is ~200 dependent instructions of this one wavefront)
+            unsigned nonZeroRows = 0u;
+#pragma unroll
+            for (int r = 0; r < kRegisterRows; ++r) nonZeroRows |= (__double_as_longlong(t[r]) << 1) != 0ll ? 1u << r : 0u;
+            nonZeroRows = WaveOr(nonZeroRows);
+#ifdef UNGAR_SHOOTING_CLOCKS
+            if (wl == 0) jobCycles[8] = __popc(nonZeroRows);
+#endif
             unsigned long long taken = 0ull;  // inputs that are pivots already (wave-uniform)
             const int myInput = wl - nz;
             const bool inputLane = wl >= nz && wl < nd;
 #pragma unroll
             for (int i = 0; i < kRegisterRows; ++i) {
-                if (i < a.ne) {  // (uniform)
+                if (i < a.ne && !((nonZeroRows >> i) & 1u)) {
+                    if (wl == 0) pivCol[i] = -1;
+                } else if (i < a.ne) {  // (uniform)
                     const unsigned long long bits = static_cast<unsigned long long>(__double_as_longlong(fabs(t[i])));
                     const bool candidate = bits != 0ull && inputLane && !((taken >> (myInput & 63)) & 1ull);
-                    const unsigned long long key = WaveMaxU64(candidate ? (bits & ~0xFFull) | static_cast<unsigned long long>(255 - myInput) : 0ull);
-                    const unsigned long long rowBits = WaveMaxU64(bits);
+                    unsigned long long key = candidate ? (bits & ~0xFFull) | static_cast<unsigned long long>(255 - myInput) : 0ull, rowBits = bits;
+                    WaveMaxPair(key, rowBits);
                     const double best = __longlong_as_double(static_cast<long long>(key & ~0xFFull)), rowMax = __longlong_as_double(static_cast<long long>(rowBits));
                     int j = key ? 255 - static_cast<int>(key & 0xFFull) : -1;
                     if (j >= 0 && best <= 1e-12 * rowMax) j = -2;
@@ -163,7 +268,7 @@ __global__ __launch_bounds__(256) void ShootingAssembleKernel(const ShootingAsse
                         for (int r = 0; r < kRegisterRows; ++r) {
                             if (r == i) continue;
                             const double m = ReadLane(t[r], J);
-                            t[r] = wl == J ? 0.0 : t[r] - m * p;
+                            t[r] = t[r] - m * p;  // (lane J: m - m * 1 = +0 exactly, the generic section's literal zero)
                         }
                         t[i] = p;
                     }
@@ -173,53 +278,78 @@ __global__ __launch_bounds__(256) void ShootingAssembleKernel(const ShootingAsse
             for (int r = 0; r < kRegisterRows; ++r)
                 if (r < a.ne && wl < ld) Ed[r * ld + wl] = t[r];
             if (wl < d.nu) used[wl] = static_cast<int>((taken >> wl) & 1ull);
-        } else if (wave == 1) {
+        } else if (role == 1) {
             if (a.nh > 0) {
-                const int mine = wl < a.ph.nnz ? wl : -1;
-                const int myRow = mine >= 0 ? a.ph.rows[mine] : -1, myCol = mine >= 0 ? a.ph.cols[mine] : 0;
-                const double myValue = mine >= 0 ? a.hJ[nodeOff * a.ph.nnz + mine] : 0.0;
-                int partners = 0;
-                if (mine >= 0)
-                    for (int e2 = mine; e2 < a.ph.nnz && a.ph.rows[e2] == myRow; ++e2) ++partners;
-                constexpr int kHeld = 4;  // partner values fetched before the row loop (the loop then touches LDS only)
-                double held[kHeld];
-                int heldCol[kHeld];
-#pragma unroll
-                for (int q = 0; q < kHeld; ++q) {
-                    held[q] = q < partners ? a.hJ[nodeOff * a.ph.nnz + mine + q] : 0.0;
-                    heldCol[q] = q < partners ? a.ph.cols[mine + q] : 0;
-                }
-                for (int j = 0; j < a.nh; ++j) {  // row by row, in order (rows share targets): consecutive LDS instructions of ONE wavefront execute in order
-                    if (myRow == j) {
-                        gd[myCol] -= d1[j] * myValue;
-#pragma unroll
-                        for (int q = 0; q < kHeld; ++q)
-                            if (q < partners) Wd[myCol * nd + heldCol[q]] += d2[j] * myValue * held[q];
-                        for (int q = kHeld; q < partners; ++q) Wd[myCol * nd + a.ph.cols[mine + q]] += d2[j] * myValue * a.hJ[nodeOff * a.ph.nnz + mine + q];
+                const int nnz = a.ph.nnz, mine = wl < nnz ? wl : -1;
+                const int myRow = inequalityRow, myCol = inequalityColumn;
+                const double myValue = inequalityValue;
+                // entries of the same row from this one on (columns ascend within a row: upper triangle; a row's entries are consecutive): the distance to the
+                // row's last entry, from one ballot instead of a loop of dependent loads
+                const int nextRow = __shfl_down(myRow, 1);
+                const unsigned long long rowEnds = __ballot(mine >= 0 && (mine == nnz - 1 || nextRow != myRow));
+                const int partners = mine >= 0 ? __ffsll(static_cast<unsigned long long>(rowEnds >> mine)) : 0;
+                // one lane per PAIR (e1, e2 >= e1) of a row where the pairs fit a wavefront (the quadruped: 28 entries in 12 rows, 46 pairs): a row is then ONE
+                // read-modify-write per lane instead of a chain of `partners` of them.  Pair p of the concatenation over e1 (same targets, same order per target).
+                int pairFirst = -1, pairOffset = 0, pairs = 0;
+#ifndef UNGAR_ASSEMBLE_ENTRY_LANES
+                for (int e1 = 0; e1 < nnz; ++e1) {
+                    const int count = __builtin_amdgcn_readlane(partners, e1);
+                    if (wl >= pairs && wl < pairs + count) {
+                        pairFirst = e1;
+                        pairOffset = wl - pairs;
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
+                    pairs += count;
+                }
+#else
+                pairs = 65;
+#endif
+                if (pairs <= 64) {
+                    const bool havePair = pairFirst >= 0;
+                    // (a pair's entries come from the lanes that hold them)
+                    const int first = havePair ? pairFirst : 0, second = havePair ? pairFirst + pairOffset : 0;
+                    const int pairRowAny = __shfl(myRow, first), c1 = __shfl(myCol, first), c2 = __shfl(myCol, second);
+                    const double v1 = __shfl(myValue, first), v2 = __shfl(myValue, second);
+                    const int pairRow = havePair ? pairRowAny : -1, target = havePair ? c1 * nd + c2 : 0;
+                    // row by row, in order (rows share targets): consecutive LDS instructions of ONE wavefront execute in order.  The two reads of a row are issued
+                    // together, then the two writes -- one LDS round trip per row; the factors of a lane's row are fetched before the loop.
+                    const double d1Mine = myRow >= 0 ? d1[myRow] : 0.0, d2Mine = havePair ? d2[pairRow] : 0.0;
+                    for (int j = 0; j < a.nh; ++j) {
+                        const bool g = myRow == j, w = pairRow == j;
+                        double g0 = 0.0, w0 = 0.0;
+                        if (g) g0 = gd[myCol];
+                        if (w) w0 = Wd[target];
+                        if (g) gd[myCol] = __builtin_fma(-d1Mine, myValue, g0);      // (explicit: left as products, the loop-invariant factors are multiplied out
+                        if (w) Wd[target] = __builtin_fma(d2Mine * v1, v2, w0);  // before the loop and rounded once more than the generic section's fused forms)
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                } else {
+                    for (int j = 0; j < a.nh; ++j) {
+                        if (myRow == j) {
+                            gd[myCol] -= d1[j] * myValue;
+                            for (int q = 0; q < partners; ++q) Wd[myCol * nd + a.ph.cols[mine + q]] += d2[j] * myValue * a.hJ[nodeOff * nnz + mine + q];
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                    }
                 }
             }
-            for (int idx = wl; idx < nd * nd; idx += 64) {
-                const int r = static_cast<int>((static_cast<float>(idx) + 0.5f) * ndInv), c = idx - r * nd;
-                if (r > c) continue;
-                double acc = Wd[idx];
-                if (r == c && r >= nc) acc += a.regularization;
-                Wd[idx] = acc;
-                Wd[c * nd + r] = acc;
-            }
+#ifdef UNGAR_SHOOTING_CLOCKS
+            if (wl == 0) jobCycles[4] = __builtin_amdgcn_s_memtime() - jobStart;
+#endif
+            regulariseAndMirror(firstBarrierColumn * nd, nd * nd, wl, 64);
         } else {
             const double* next = RowOf(a.rows, d, b, k + 1);
-            for (int i = lane - 128; i < nz; i += lanes - 128) bd[i] = i < nc ? 0.0 : a.f[nodeOff * nx + (i - nc)] - next[i];
+            const int helper = (role - 2) * 64 + wl;  // 0 .. 127 over the two wavefronts without a job of their own
+            for (int i = helper; i < nz; i += 128) bd[i] = i < nc ? 0.0 : a.f[nodeOff * nx + (i - nc)] - next[i];
+            regulariseAndMirror(0, firstBarrierColumn * nd, helper, 128);
         }
 #ifdef UNGAR_SHOOTING_CLOCKS
-        if (wl == 0 && (node == 1 || node == d.batch * (d.N + 1) / 2 + 1))
-            printf("[assemble jobs] node %lld wavefront %d: %llu cycles\n", node, wave, __builtin_amdgcn_s_memtime() - jobStart);
+        if (wl == 0) jobCycles[role] = __builtin_amdgcn_s_memtime() - jobStart;
 #endif
         __syncthreads();
-        UNGAR_SHOOTING_MARK();  // 2: the three jobs
-        UNGAR_SHOOTING_MARK();  // 3
+        UNGAR_SHOOTING_MARK();  // 2: the jobs
+        UNGAR_SHOOTING_MARK();  // 3: regularisation, mirror
     } else {
         // barrier terms  W += J_h^T diag(b''(-h)) J_h,  w -= J_h^T b'(-h)  straight from the SPARSE inequality Jacobian (28 of 588 entries for the
         // quadruped's rows: a dense product over every entry of W read 44 k LDS words per node).  Row by row, in order: inside a row the pairs of its
@@ -356,7 +486,7 @@ __global__ __launch_bounds__(256) void ShootingAssembleKernel(const ShootingAsse
         const int li = wl & 15, lk = wl >> 4, KS = pivots > 0 ? (a.ne + 3) >> 2 : 0, TD = (nd + 15) >> 4, TE = (a.ne + 15) >> 4, TZ = (nz + 15) >> 4;
         auto pivotColumn = [&](int t) { return t < a.ne ? pivCol[t] : -1; };  // input the row t was solved for, or < 0
         // the k-steps of this lane's operand rows, looked up once (the same for every tile): up to 64 equality rows (the C ABI's bound)
-        constexpr int kMaxSteps = 16;
+        constexpr int kMaxSteps = 16, kGroup = 4;
         int stepPivot[kMaxSteps], stepRow[kMaxSteps];
 #pragma unroll
         for (int ks = 0; ks < kMaxSteps; ++ks) {
@@ -370,12 +500,21 @@ __global__ __launch_bounds__(256) void ShootingAssembleKernel(const ShootingAsse
             const int rowA = 16 * ti + li, colB = 16 * tj + li, cB = colB < nd ? colB : nd - 1;
             const int jA = pivotColumn(rowA);
             f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+            // (k-steps in groups of four: the operands of a group are requested together and the matrix instructions follow -- one LDS round trip per group
+            // instead of one per step; a step beyond KS inside a group has no pivot and multiplies by zero.  A `break` would keep the loop rolled and the
+            // lookup tables in scratch.)
 #pragma unroll
-            for (int ks = 0; ks < kMaxSteps; ++ks) {
-                if (ks < KS) {  // (uniform; a `break` keeps the loop rolled and the lookup tables in scratch)
-                    const int jt = stepPivot[ks], tc = stepRow[ks];
-                    const double av = Wd[(nz + (jA < 0 ? 0 : jA)) * nd + nz + (jt < 0 ? 0 : jt)], bv = Ed[tc * ld + cB];
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64((jA >= 0 && jt >= 0) ? av : 0.0, bv, acc, 0, 0, 0);
+            for (int g = 0; g < kMaxSteps / kGroup; ++g) {
+                if (g * kGroup < KS) {  // (uniform)
+                    double av[kGroup], bv[kGroup];
+#pragma unroll
+                    for (int q = 0; q < kGroup; ++q) {
+                        const int jt = stepPivot[g * kGroup + q], tc = stepRow[g * kGroup + q];
+                        av[q] = Wd[(nz + (jA < 0 ? 0 : jA)) * nd + nz + (jt < 0 ? 0 : jt)];
+                        bv[q] = Ed[tc * ld + cB];
+                    }
+#pragma unroll
+                    for (int q = 0; q < kGroup; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64((jA >= 0 && stepPivot[g * kGroup + q] >= 0) ? av[q] : 0.0, bv[q], acc, 0, 0, 0);
                 }
             }
             for (int r = 0; r < 4; ++r) {
@@ -385,21 +524,35 @@ __global__ __launch_bounds__(256) void ShootingAssembleKernel(const ShootingAsse
         }
         // the three vector updates: an entry's sum over the pivot rows is shared by the four lanes of a quad (DPP reduction) -- as one lane's loop it was a
         // chain of `pivots` multiply-adds, each behind three dependent index lookups
-        auto quadSum = [&](int count, auto term, auto store) {  // item i < count: store(i, sum_t term(i, t)); lanes 4 i .. 4 i + 3 share the sum
+        // (the pivot rows a lane sums over -- list index t = part, part + 4, ... -- and their pivot inputs are looked up ONCE: inside the sums they were two
+        // dependent LDS reads in front of every product; with them in registers a lane's products are independent and their operands travel together)
+        constexpr int kHeldTerms = 4;
+        int heldRow[kHeldTerms], heldColumn[kHeldTerms];
+#pragma unroll
+        for (int m = 0; m < kHeldTerms; ++m) {
+            const int t = (lane & 3) + 4 * m;
+            heldRow[m] = t < pivots ? list[t] : -1;
+            heldColumn[m] = heldRow[m] >= 0 ? pivCol[heldRow[m]] : 0;
+        }
+        auto quadSum = [&](int count, auto term, auto store) {  // item i < count: store(i, sum_t term(i, row_t, input_t)); lanes 4 i .. 4 i + 3 share the sum
             for (int base = 0; base < count; base += lanes >> 2) {
                 const int i = base + (lane >> 2), part = lane & 3;
                 double sv = 0.0;
-                if (i < count)
-                    for (int t = part; t < pivots; t += 4) sv += term(i, t);
+                if (i < count) {
+#pragma unroll
+                    for (int m = 0; m < kHeldTerms; ++m)
+                        if (heldRow[m] >= 0) sv += term(i, heldRow[m], heldColumn[m]);
+                    for (int t = part + 4 * kHeldTerms; t < pivots; t += 4) sv += term(i, list[t], pivCol[list[t]]);
+                }
                 sv += QuadPermute<0xB1>(sv);  // quad_perm [1, 0, 3, 2]
                 sv += QuadPermute<0x4E>(sv);  // quad_perm [2, 3, 0, 1]
                 if (i < count && part == 0) store(i, sv);
             }
         };
         quadSum(
-            nd, [&](int c, int t) { return Wd[c * nd + nz + pivCol[list[t]]] * Ed[list[t] * ld + nd]; }, [&](int c, double sv) { prow[c] = gd[c] - sv; });  // w + W s,  s = -sum_i e_(J_i) g0_i
+            nd, [&](int c, int row, int input) { return Wd[c * nd + nz + input] * Ed[row * ld + nd]; }, [&](int c, double sv) { prow[c] = gd[c] - sv; });  // w + W s,  s = -sum_i e_(J_i) g0_i
         quadSum(
-            nz, [&](int r, int t) { return ABd[r * nd + nz + pivCol[list[t]]] * Ed[list[t] * ld + nd]; }, [&](int r, double sv) { bd[r] -= sv; });
+            nz, [&](int r, int row, int input) { return ABd[r * nd + nz + input] * Ed[row * ld + nd]; }, [&](int r, double sv) { bd[r] -= sv; });
         __syncthreads();
         UNGAR_SHOOTING_MARK();  // (substitution: list, V = W_JJ G, w + W s, b)
         auto isPivot = [&](int c) { return c >= nz && used[c - nz] != 0; };
@@ -419,6 +572,9 @@ __global__ __launch_bounds__(256) void ShootingAssembleKernel(const ShootingAsse
                 ti = (tile - upper) / TD;
                 tj = tile - upper - ti * TD;
             }
+#ifdef UNGAR_SHOOTING_CLOCKS
+            const unsigned long long tile0 = __builtin_amdgcn_s_memtime();
+#endif
             double* C = hessian ? Wd : ABd;
             const int rows = hessian ? nd : nz;
             const int rowA = 16 * ti + li, rA = rowA < rows ? rowA : rows - 1, rG = rowA < nd ? rowA : nd - 1;
@@ -429,23 +585,41 @@ __global__ __launch_bounds__(256) void ShootingAssembleKernel(const ShootingAsse
                 acc[r] = C[(row < rows ? row : rows - 1) * nd + cB];
             }
 #pragma unroll
-            for (int ks = 0; ks < kMaxSteps; ++ks) {
-                if (ks < KS) {  // (uniform)
-                    const int jt = stepPivot[ks], tc = stepRow[ks], J = nz + (jt < 0 ? 0 : jt);
-                    const double a1 = C[rA * nd + J], b1 = Ed[tc * ld + cB];
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(jt >= 0 ? -a1 : 0.0, b1, acc, 0, 0, 0);  // - W[a][J_t] G_t[c]   /   - [A|B][r][J_t] G_t[c]
-                    if (hessian) {
-                        const double a2 = Ed[tc * ld + rG], b2 = V[tc * nd + cB] - Wd[J * nd + cB];
-                        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(jt >= 0 ? a2 : 0.0, b2, acc2, 0, 0, 0);  // + G_t[a] (V_t[c] - W[J_t][c])
+            for (int g = 0; g < kMaxSteps / kGroup; ++g) {
+                if (g * kGroup < KS) {  // (uniform; groups of four k-steps as above)
+                    double a1[kGroup], b1[kGroup], a2[kGroup], b2[kGroup], b3[kGroup];
+#pragma unroll
+                    for (int q = 0; q < kGroup; ++q) {
+                        const int jt = stepPivot[g * kGroup + q], tc = stepRow[g * kGroup + q], J = nz + (jt < 0 ? 0 : jt);
+                        a1[q] = C[rA * nd + J];
+                        b1[q] = Ed[tc * ld + cB];
+                        if (hessian) {
+                            a2[q] = Ed[tc * ld + rG];
+                            b2[q] = V[tc * nd + cB];
+                            b3[q] = Wd[J * nd + cB];
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < kGroup; ++q) {
+                        const bool pivot = stepPivot[g * kGroup + q] >= 0;
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pivot ? -a1[q] : 0.0, b1[q], acc, 0, 0, 0);  // - W[a][J_t] G_t[c]   /   - [A|B][r][J_t] G_t[c]
+                        if (hessian) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(pivot ? a2[q] : 0.0, b2[q] - b3[q], acc2, 0, 0, 0);  // + G_t[a] (V_t[c] - W[J_t][c])
                     }
                 }
             }
+#ifdef UNGAR_SHOOTING_CLOCKS
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long tile1 = __builtin_amdgcn_s_memtime();
+#endif
+            // (the pivot flags of the four rows are read before the first store: a store to W may alias them for the compiler, which then waits for every flag in turn)
+            bool rowIsPivot[4];
+            for (int r = 0; r < 4; ++r) rowIsPivot[r] = hessian && 16 * ti + lk + 4 * r < nd && isPivot(16 * ti + lk + 4 * r);
             if (colB < nd && !isPivot(colB)) {
                 for (int r = 0; r < 4; ++r) {
                     const int row = 16 * ti + lk + 4 * r;
                     acc[r] += acc2[r];
                     if (hessian) {
-                        if (row <= colB && !isPivot(row)) {
+                        if (row <= colB && !rowIsPivot[r]) {
                             Wd[row * nd + colB] = acc[r];
                             Wd[colB * nd + row] = acc[r];
                         }
@@ -454,9 +628,17 @@ __global__ __launch_bounds__(256) void ShootingAssembleKernel(const ShootingAsse
                     }
                 }
             }
+#ifdef UNGAR_SHOOTING_CLOCKS
+            if (lane == 0) {
+                const unsigned long long tile2 = __builtin_amdgcn_s_memtime();
+                jobCycles[5] += tile1 - tile0;
+                jobCycles[6] += tile2 - tile1;
+                jobCycles[7] += 1;
+            }
+#endif
         }
         quadSum(
-            nd, [&](int c, int t) { return Ed[list[t] * ld + c] * prow[nz + pivCol[list[t]]]; }, [&](int c, double sv) { gd[c] = isPivot(c) ? 0.0 : prow[c] - sv; });
+            nd, [&](int c, int row, int input) { return Ed[row * ld + c] * prow[nz + input]; }, [&](int c, double sv) { gd[c] = isPivot(c) ? 0.0 : prow[c] - sv; });
         __syncthreads();  // every read of a pivot row / column is done: they become the dummies' identity rows
         UNGAR_SHOOTING_MARK();  // (substitution: W', [A|B]', w')
         for (int t = wave; t < pivots; t += waves) {
@@ -502,9 +684,11 @@ __global__ __launch_bounds__(256) void ShootingAssembleKernel(const ShootingAsse
     __syncthreads();
     UNGAR_SHOOTING_MARK();  // last: results written
     if (lane == 0 && (node == 1 || node == d.batch * (d.N + 1) / 2 + 1)) {
-        printf("[assemble clocks] node %lld:", node);
-        for (int m = 1; m < markCount; ++m) printf(" %llu", marks[m] - marks[m - 1]);
-        printf("\n");
+        unsigned long long dt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int m = 1; m < markCount && m <= 10; ++m) dt[m - 1] = marks[m] - marks[m - 1];
+        // (one call per node: the lines of two nodes do not interleave)
+        printf("[assemble clocks] node %lld (%u non-zero equality rows): %llu %llu %llu %llu %llu %llu %llu %llu %llu   jobs: elimination %llu, barrier terms %llu (wavefront 1 in all %llu), defect %llu %llu; wavefront 0: %llu tiles, operands + products %llu, epilogue %llu\n",
+               node, static_cast<unsigned>(jobCycles[8]), dt[0], dt[1], dt[2], dt[3], dt[4], dt[5], dt[6], dt[7], dt[8], jobCycles[0], jobCycles[4], jobCycles[1], jobCycles[2], jobCycles[3], jobCycles[7], jobCycles[5], jobCycles[6]);
     }
 #endif
 }
