@@ -42,6 +42,8 @@ cp_if gpurun_out/sqp_anymal.json              profiles/${tag}_sqp_anymal_timing.
 cp_if gpurun_out/sqp_bench.log                profiles/${tag}_sqp_quadrotor_timing.json
 cp_if gpurun_out/sqp_srbd.json                profiles/${tag}_sqp_srbd_timing.json
 cp_if gpurun_out/riccati_sizes.log            profiles/${tag}_riccati_sizes.log
+cp_if gpurun_out/assemble_ab.log              profiles/${tag}_assemble_ab.log
+cp_if gpurun_out/assemble_ab_kernel_stats.csv profiles/${tag}_assemble_ab_kernel_stats.csv
 cp_if gpurun_out/riccati_sizes_clocks.log     profiles/${tag}_riccati_phase_clocks.log
 cp_if gpurun_out/batched_quadrotor_kernel_stats.csv profiles/${tag}_batched_quadrotor_kernel_stats.csv
 cp_if gpurun_out/batched_quadruped_kernel_stats.csv profiles/${tag}_batched_quadruped_kernel_stats.csv

@@ -51,6 +51,8 @@ echo "== Riccati solve alone (all block sizes) and the C++ batched SQP on the re
 timeout 300 python tools/bench_riccati_sizes.py 4096 2>/dev/null | grep nx | tee gpurun_out/riccati_sizes.log | cut -c1-120
 [ -f build/variants/lib_riccati_clocks.so ] && UNGAR_AMD_LIBRARY=$PWD/build/variants/lib_riccati_clocks.so timeout 300 python tools/bench_riccati_sizes.py 4096 2>/dev/null | grep nx > gpurun_out/riccati_sizes_clocks.log
 bash tools/gpu_batched_sqp_profile.sh 4096 2>&1 | tail -30
+echo "== shooting assembly kernel: wavefront-specialised sections against the generic ones (bits, wall clock, kernel split, section clocks)"
+bash tools/gpu_assemble_ab.sh 2>&1 | grep -vE "^iteration [12] instance" | tail -40 | tee gpurun_out/assemble_ab.log | cut -c1-300
 echo "== rocprofv3 kernel trace + HBM counters (separate passes)"
 rm -rf gpurun_out/prof gpurun_out/pmc1 gpurun_out/pmc2
 B="python bench.py --no-cpu-baseline --no-sub-results"
