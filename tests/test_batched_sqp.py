@@ -31,3 +31,28 @@ def test_batched_sqp_equals_the_whole_horizon_facade(repo_root, tmp_path, proble
     for line in lines:
         moved, total = map(int, re.search(r"(\d+) of (\d+) instances accepted", line).groups())
         assert total == batch and moved >= batch // 2  # the comparison is not vacuous: steps are taken
+
+
+def test_assembly_kernel_sections_give_the_same_bits(repo_root, tmp_path):
+    """The shooting assembly kernel runs stage nodes with few equality rows (the quadruped: 16 x 50 tableau) through wavefront-specialised
+    sections -- Gauss-Jordan elimination in the registers of one wavefront, barrier terms without workgroup barriers -- and
+    everything else, or everything under UNGAR_AMD_ASSEMBLE_GENERIC=1, through the generic sections.  Same pivot rule, same arithmetic:
+    the assembled QP data (AB, b, W, w, reduced equality rows and residuals, printed with 17 digits) and both steps of the compared
+    instances must agree to the last bit, over two SQP iterations."""
+    exe = os.path.join(repo_root, "build", "batched_quadruped_test")
+    assert os.path.exists(exe), f"{exe} missing: run __graft_entry__.build()"
+    dumps = {}
+    for mode in ("specialised", "generic"):
+        env = dict(os.environ)
+        env.pop("UNGAR_AMD_ASSEMBLE_GENERIC", None)
+        if mode == "generic":
+            env["UNGAR_AMD_ASSEMBLE_GENERIC"] = "1"
+        folder = tmp_path / mode
+        folder.mkdir()
+        r = subprocess.run([exe, str(tmp_path / "codegen"), "256", "4", str(folder)], capture_output=True, text=True, timeout=1500, env=env)
+        print(r.stdout[-2000:], r.stderr[-1000:])
+        assert r.returncode == 0 and "PASS batched quadruped SQP (batch 256, 4 compared)" in r.stdout
+        dumps[mode] = {f.name: f.read_bytes() for f in sorted(folder.iterdir())}
+    assert len(dumps["specialised"]) >= 8 and dumps["specialised"].keys() == dumps["generic"].keys()  # 4 instances x 2 iterations
+    for name, data in dumps["specialised"].items():
+        assert len(data) > 100_000 and data == dumps["generic"][name], f"{name}: the two code paths disagree"
