@@ -798,54 +798,31 @@ __global__ __launch_bounds__(256) void ShootingTrialKernel(const ShootingTrialAr
 
 /// The same trial rows UNIT-FASTEST: a workgroup transposes 64 consecutive stacked nodes, 32 elements at a time, through an LDS tile --
 /// row segments are read coalesced (32 consecutive elements of a node per half wavefront), elements are stored coalesced (64 consecutive nodes).
+/// (Decomposing a lane's eight nodes once, ahead of the element loop -- pointers in registers instead of three 64-bit divisions per element -- was measured:
+/// 0.71 -> 0.87 ms per 1.78 M stacked quadruped nodes at 126 registers; the kernel is bound by memory latency and occupancy, not by that arithmetic.)
 __global__ __launch_bounds__(256) void ShootingTrialUnitFastestKernel(const ShootingTrialArgs a) {
     __shared__ double tile[32][65];
     const ShootingDims& d = a.d;
     const long long nodes = static_cast<long long>(a.candidates) * d.batch * (d.N + 1);
     const long long node0 = static_cast<long long>(blockIdx.x) * 64;
     const int t = static_cast<int>(threadIdx.x), nz = d.nz(), nd = d.nd(), nv = d.nv(), nc = d.nc, N = d.N;
-    // the eight nodes a lane reads from (one per pass) are decomposed ONCE -- three 64-bit divisions per node, which the element loop below repeated for
-    // every chunk of 32 elements: 0.72 ms per 1.78 M stacked quadruped nodes, most of it this arithmetic
-    const double* rowOf[8];
-    const double* previousInputs[8];  // u of row k - 1 (carried inputs), or null at k = 0
-    const double* stateStep[8];
-    const double* inputStep[8];       // null at k = N
-    const double* previousInputStep[8];
-    double alphaOf[8];
-#pragma unroll
-    for (int pass = 0; pass < 8; ++pass) {
-        const long long node = node0 + (t >> 5) + 8 * pass;
-        rowOf[pass] = nullptr;
-        previousInputs[pass] = stateStep[pass] = inputStep[pass] = previousInputStep[pass] = nullptr;
-        alphaOf[pass] = 0.0;
-        if (node < nodes) {
-            const long long s = node / (N + 1);
-            const int k = static_cast<int>(node - s * (N + 1));
-            const long long c = s / d.batch, b = s - c * d.batch;
-            alphaOf[pass] = a.alphas[c];
-            rowOf[pass] = RowOf(a.rows, d, b, k);
-            stateStep[pass] = a.dZ + (b * (N + 1) + k) * nz;
-            if (k < N) inputStep[pass] = a.dU + (b * N + k) * d.nu;
-            if (k > 0) {
-                previousInputs[pass] = RowOf(a.rows, d, b, k - 1) + nz;
-                previousInputStep[pass] = a.dU + (b * N + (k - 1)) * d.nu;
-            }
-        }
-    }
     for (int j0 = 0; j0 < nv; j0 += 32) {
         const int jj = t & 31, j = j0 + jj;
-#pragma unroll
         for (int pass = 0; pass < 8; ++pass) {
             const int nl = (t >> 5) + 8 * pass;
-            if (rowOf[pass] && j < nv) {
-                const double alpha = alphaOf[pass];
-                double v = rowOf[pass][j];
+            const long long node = node0 + nl;
+            if (node < nodes && j < nv) {
+                const long long s = node / (N + 1);
+                const int k = static_cast<int>(node - s * (N + 1));
+                const long long b = s % d.batch;
+                const double alpha = a.alphas[s / d.batch];
+                double v = RowOf(a.rows, d, b, k)[j];
                 if (j < nc && d.carryInputs) {
-                    if (previousInputs[pass]) v = fma(alpha, previousInputStep[pass][j], previousInputs[pass][j]);
+                    if (k > 0) v = fma(alpha, a.dU[(b * N + (k - 1)) * d.nu + j], RowOf(a.rows, d, b, k - 1)[nz + j]);
                 } else if (j < nz) {
-                    v = fma(alpha, stateStep[pass][j], v);
-                } else if (j < nd && inputStep[pass]) {
-                    v = fma(alpha, inputStep[pass][j - nz], v);
+                    v = fma(alpha, a.dZ[(b * (N + 1) + k) * nz + j], v);
+                } else if (j < nd && k < N) {
+                    v = fma(alpha, a.dU[(b * N + k) * d.nu + (j - nz)], v);
                 }
                 tile[jj][nl] = v;
             }
