@@ -14,6 +14,12 @@ if diff <(grep -E "^iteration" gpurun_out/assemble_ab_specialised.log) <(grep -E
 same=0; differ=0
 for f in /tmp/dumpA/*; do if cmp -s "$f" "/tmp/dumpB/$(basename $f)"; then same=$((same+1)); else differ=$((differ+1)); echo "differs: $(basename $f)"; fi; done 2>/dev/null | head -5
 echo "dumped files compared: $(ls /tmp/dumpA | wc -l)"
+# the fallback of the barrier terms (one lane per entry: patterns whose pairs do not fit a wavefront) is a measurement variant for this problem: checked against the same dumps
+if [ -f build/variants/shooting_entry_lanes/libungar_amd.so ]; then
+  rm -rf /tmp/dumpC; mkdir -p /tmp/dumpC
+  LD_LIBRARY_PATH=build/variants/shooting_entry_lanes:${LD_LIBRARY_PATH:-} timeout 900 $T /tmp/cg_q 1024 8 /tmp/dumpC > gpurun_out/assemble_ab_entry_lanes.log 2>&1; echo "entry_lanes variant rc $?"
+  bad=0; for f in /tmp/dumpB/*; do cmp -s "$f" "/tmp/dumpC/$(basename $f)" || bad=$((bad+1)); done; echo "entry_lanes variant: $bad of $(ls /tmp/dumpB | wc -l) dumped files differ from the generic sections"
+fi
 for mode in specialised generic; do
   for rep in 1 2; do
     if [ $mode = generic ]; then export UNGAR_AMD_ASSEMBLE_GENERIC=1; else unset UNGAR_AMD_ASSEMBLE_GENERIC; fi
