@@ -27,7 +27,7 @@ for mode in specialised generic; do
   done
 done
 unset UNGAR_AMD_ASSEMBLE_GENERIC
-for v in entry_lanes mirror_one_wave both; do  # measurement variants (tools/make_shooting_variants.sh)
+for v in eu3_k4 eu4_k4 eu3_k2 entry_lanes; do  # measurement variants (tools/make_shooting_variants.sh)
   if [ -f build/variants/shooting_$v/libungar_amd.so ]; then
     for rep in 1 2; do LD_LIBRARY_PATH=build/variants/shooting_$v:${LD_LIBRARY_PATH:-} timeout 900 $T /tmp/cg_q 4096 0 2>&1 | grep -E "timing" | sed "s/^/[variant $v] /"; done
   fi

@@ -16,3 +16,6 @@ variant entry_lanes -DUNGAR_ASSEMBLE_ENTRY_LANES
 variant mirror_one_wave -DUNGAR_ASSEMBLE_MIRROR_ONE_WAVE
 variant both -DUNGAR_ASSEMBLE_ENTRY_LANES -DUNGAR_ASSEMBLE_MIRROR_ONE_WAVE
 variant clocks -DUNGAR_SHOOTING_CLOCKS
+variant eu3_k4 -DUNGAR_ASSEMBLE_WAVES_PER_EU=3 -DUNGAR_ASSEMBLE_K_GROUP=4
+variant eu4_k4 -DUNGAR_ASSEMBLE_WAVES_PER_EU=4 -DUNGAR_ASSEMBLE_K_GROUP=4
+variant eu3_k2 -DUNGAR_ASSEMBLE_WAVES_PER_EU=3 -DUNGAR_ASSEMBLE_K_GROUP=2

@@ -100,7 +100,15 @@ __device__ __forceinline__ const double* RowOf(const double* rows, const Shootin
 /// One workgroup per node (instance, knot <= N).  Sparse values are scattered into dense LDS images first (a dense block is written
 /// to global memory exactly once, coalesced; zero-filling and scattering in global memory would race), then the barrier terms are added
 /// and -- on request -- the stage equality rows eliminated.  Dense loops map (wavefront -> row, lane -> column): no index divisions.
-__global__ __launch_bounds__(256) void ShootingAssembleKernel(const ShootingAssembleArgs a) {
+// Four wavefronts per SIMD: with W packed, four quadruped nodes (34 KB of LDS each) fit a CU, and the register budget has to admit them too (128 per lane: the
+// k-steps of the substitution then go in groups of two).  UNGAR_ASSEMBLE_WAVES_PER_EU / UNGAR_ASSEMBLE_K_GROUP are measurement knobs (tools/make_shooting_variants.sh).
+#ifndef UNGAR_ASSEMBLE_WAVES_PER_EU
+#define UNGAR_ASSEMBLE_WAVES_PER_EU 4
+#endif
+#ifndef UNGAR_ASSEMBLE_K_GROUP
+#define UNGAR_ASSEMBLE_K_GROUP 2
+#endif
+__global__ __launch_bounds__(256, UNGAR_ASSEMBLE_WAVES_PER_EU) void ShootingAssembleKernel(const ShootingAssembleArgs a) {
     extern __shared__ double lds[];
     const ShootingDims& d = a.d;
     const long long node = blockIdx.x;
@@ -112,8 +120,13 @@ __global__ __launch_bounds__(256) void ShootingAssembleKernel(const ShootingAsse
     const int nz = d.nz(), nd = d.nd(), nc = d.nc, nx = d.nx;
     const bool stage = k < d.N;  // knot N: terminal cost only
     const float ndInv = 1.0f / static_cast<float>(nd);  // row of a flat index through a float reciprocal: exact for nd <= 256 (idx + 0.5 is never a multiple of nd)
-    double* Wd = lds;                 // nd x nd
-    double* gd = Wd + nd * nd;        // nd
+    // W lives as its PACKED upper triangle (row r holds columns r .. nd - 1): 9.8 instead of 19.2 KB for the quadruped's 49 x 49, the difference between three and
+    // four nodes per CU for this latency-bound kernel; no mirrored copy to maintain
+    const int nW = nd * (nd + 1) / 2;
+    auto tri = [nd](int r, int c) { return ((r * (2 * nd + 1 - r)) >> 1) + (c - r); };  // r <= c
+    auto sym = [&tri](int r, int c) { return r <= c ? tri(r, c) : tri(c, r); };
+    double* Wd = lds;                 // nd (nd + 1) / 2
+    double* gd = Wd + nW;             // nd
     double* d1 = gd + nd;             // nh
     double* d2 = d1 + a.nh;           // nh
     double* ABd = d2 + a.nh;          // nz x nd
@@ -136,7 +149,7 @@ __global__ __launch_bounds__(256) void ShootingAssembleKernel(const ShootingAsse
 #define UNGAR_SHOOTING_MARK() ((void)0)
 #endif
     UNGAR_SHOOTING_MARK();
-    const int total = nd * nd + nd + 2 * a.nh + nz * nd + a.ne * ld;
+    const int total = nW + nd + 2 * a.nh + nz * nd + a.ne * ld;
     const long long nodeOff = b * (d.N + 1) + k;
     const int elim = a.eliminate & 3;  // (bit 2: measurement switch -- the generic sections below for every node)
     const long long stageOff = b * d.N + k;
@@ -160,7 +173,7 @@ __global__ __launch_bounds__(256) void ShootingAssembleKernel(const ShootingAsse
         }
         return f;
     };
-    auto hessianTarget = [&](int r, int c) { return r * nd + c; };
+    auto hessianTarget = [&](int r, int c) { return r <= c ? tri(r, c) : -1; };  // (Function::Hessian's pattern is upper triangular; anything below the diagonal is ignored, as the mirror did)
     auto gradientTarget = [&](int, int c) { return c; };
     auto dynamicsTarget = [&](int r, int c) { return (nc + r) * nd + nc + c; };
     auto carryTarget = [&](int r, int c) { return r * nd + nc + c; };
@@ -177,7 +190,8 @@ __global__ __launch_bounds__(256) void ShootingAssembleKernel(const ShootingAsse
     for (int i = lane; i < total; i += lanes) lds[i] = 0.0;
     __syncthreads();
     if (fH.target >= 0) Wd[fH.target] = fH.value;
-    for (int e = lane + lanes; e < a.pH.nnz; e += lanes) Wd[a.pH.rows[e] * nd + a.pH.cols[e]] = a.lH[nodeOff * a.pH.nnz + e];
+    for (int e = lane + lanes; e < a.pH.nnz; e += lanes)
+        if (a.pH.rows[e] <= a.pH.cols[e]) Wd[tri(a.pH.rows[e], a.pH.cols[e])] = a.lH[nodeOff * a.pH.nnz + e];
     if (fg.target >= 0) gd[fg.target] = fg.value;
     for (int e = lane + lanes; e < a.pg.nnz; e += lanes) gd[a.pg.cols[e]] = a.lg[nodeOff * a.pg.nnz + e];
     if (stage) {
@@ -212,15 +226,9 @@ __global__ __launch_bounds__(256) void ShootingAssembleKernel(const ShootingAsse
 #else
         const int firstBarrierColumn = role == 0 ? 0 : (a.nh > 0 && a.ph.nnz > 0 ? WaveMinInt(wl < a.ph.nnz ? a.ph.cols[wl] : nd) : nd);
 #endif
-        auto regulariseAndMirror = [&](int firstIndex, int lastIndex, int lane0, int step) {
-            for (int idx = firstIndex + lane0; idx < lastIndex; idx += step) {
-                const int r = static_cast<int>((static_cast<float>(idx) + 0.5f) * ndInv), c = idx - r * nd;
-                if (r > c) continue;
-                double acc = Wd[idx];
-                if (r == c && r >= nc) acc += a.regularization;
-                Wd[idx] = acc;
-                Wd[c * nd + r] = acc;
-            }
+        auto regularise = [&](int firstRow, int lastRow, int lane0, int step) {  // the reference's 1e-6 I over its decision variables (soft_sqp.hpp:149-151)
+            for (int r = firstRow + lane0; r < lastRow; r += step)
+                if (r >= nc) Wd[tri(r, r)] += a.regularization;
         };
         if (role == 0) {
             // ---- Gauss-Jordan on [C | D | e], lane = column, the rows in registers: the same pivot rule and the same arithmetic as the generic
@@ -309,7 +317,7 @@ __global__ __launch_bounds__(256) void ShootingAssembleKernel(const ShootingAsse
                     const int first = havePair ? pairFirst : 0, second = havePair ? pairFirst + pairOffset : 0;
                     const int pairRowAny = __shfl(myRow, first), c1 = __shfl(myCol, first), c2 = __shfl(myCol, second);
                     const double v1 = __shfl(myValue, first), v2 = __shfl(myValue, second);
-                    const int pairRow = havePair ? pairRowAny : -1, target = havePair ? c1 * nd + c2 : 0;
+                    const int pairRow = havePair ? pairRowAny : -1, target = havePair ? tri(c1, c2) : 0;
                     // row by row, in order (rows share targets): consecutive LDS instructions of ONE wavefront execute in order.  The two reads of a row are issued
                     // together, then the two writes -- one LDS round trip per row; the factors of a lane's row are fetched before the loop.
                     const double d1Mine = myRow >= 0 ? d1[myRow] : 0.0, d2Mine = havePair ? d2[pairRow] : 0.0;
@@ -327,7 +335,7 @@ __global__ __launch_bounds__(256) void ShootingAssembleKernel(const ShootingAsse
                     for (int j = 0; j < a.nh; ++j) {
                         if (myRow == j) {
                             gd[myCol] -= d1[j] * myValue;
-                            for (int q = 0; q < partners; ++q) Wd[myCol * nd + a.ph.cols[mine + q]] += d2[j] * myValue * a.hJ[nodeOff * nnz + mine + q];
+                            for (int q = 0; q < partners; ++q) Wd[tri(myCol, a.ph.cols[mine + q])] += d2[j] * myValue * a.hJ[nodeOff * nnz + mine + q];
                         }
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                         __builtin_amdgcn_wave_barrier();
@@ -337,12 +345,12 @@ __global__ __launch_bounds__(256) void ShootingAssembleKernel(const ShootingAsse
 #ifdef UNGAR_SHOOTING_CLOCKS
             if (wl == 0) jobCycles[4] = __builtin_amdgcn_s_memtime() - jobStart;
 #endif
-            regulariseAndMirror(firstBarrierColumn * nd, nd * nd, wl, 64);
+            regularise(firstBarrierColumn, nd, wl, 64);
         } else {
             const double* next = RowOf(a.rows, d, b, k + 1);
             const int helper = (role - 2) * 64 + wl;  // 0 .. 127 over the two wavefronts without a job of their own
             for (int i = helper; i < nz; i += 128) bd[i] = i < nc ? 0.0 : a.f[nodeOff * nx + (i - nc)] - next[i];
-            regulariseAndMirror(0, firstBarrierColumn * nd, helper, 128);
+            regularise(0, firstBarrierColumn, helper, 128);
         }
 #ifdef UNGAR_SHOOTING_CLOCKS
         if (wl == 0) jobCycles[role] = __builtin_amdgcn_s_memtime() - jobStart;
@@ -365,28 +373,22 @@ __global__ __launch_bounds__(256) void ShootingAssembleKernel(const ShootingAsse
             for (int j = 0; j < a.nh; ++j) {
                 if (myRow == j) {
                     gd[myCol] -= d1[j] * myValue;  // d/dz b(-h) = -b'(-h) dh/dz
-                    for (int t = 0; t < partners; ++t) Wd[myCol * nd + a.ph.cols[mine + t]] += d2[j] * myValue * a.hJ[nodeOff * a.ph.nnz + mine + t];
+                    for (int t = 0; t < partners; ++t) Wd[tri(myCol, a.ph.cols[mine + t])] += d2[j] * myValue * a.hJ[nodeOff * a.ph.nnz + mine + t];
                 }
                 for (int e1 = lane + lanes; e1 < a.ph.nnz; e1 += lanes) {  // (patterns with more non-zeros than lanes)
                     if (a.ph.rows[e1] != j) continue;
                     const int c1 = a.ph.cols[e1];
                     const double v1 = a.hJ[nodeOff * a.ph.nnz + e1];
                     gd[c1] -= d1[j] * v1;
-                    for (int e2 = e1; e2 < a.ph.nnz && a.ph.rows[e2] == j; ++e2) Wd[c1 * nd + a.ph.cols[e2]] += d2[j] * v1 * a.hJ[nodeOff * a.ph.nnz + e2];
+                    for (int e2 = e1; e2 < a.ph.nnz && a.ph.rows[e2] == j; ++e2) Wd[tri(c1, a.ph.cols[e2])] += d2[j] * v1 * a.hJ[nodeOff * a.ph.nnz + e2];
                 }
                 __syncthreads();
             }
         }
         UNGAR_SHOOTING_MARK();  // 2: barrier terms
-        // regularisation, and the lower triangle mirrored (W is kept in LDS with both triangles)
-        for (int idx = lane; idx < nd * nd; idx += lanes) {
-            const int r = static_cast<int>((static_cast<float>(idx) + 0.5f) * ndInv), c = idx - r * nd;
-            if (r > c) continue;
-            double acc = Wd[idx];
-            if (r == c && r >= nc && (stage || r < nz)) acc += a.regularization;  // the reference's 1e-6 I over its decision variables (soft_sqp.hpp:149-151)
-            Wd[idx] = acc;
-            Wd[c * nd + r] = acc;
-        }
+        // regularisation: the reference's 1e-6 I over its decision variables (soft_sqp.hpp:149-151)
+        for (int r = lane; r < nd; r += lanes)
+            if (r >= nc && (stage || r < nz)) Wd[tri(r, r)] += a.regularization;
         if (stage) {
             const double* next = RowOf(a.rows, d, b, k + 1);
             for (int i = lane; i < nz; i += lanes) bd[i] = i < nc ? 0.0 : a.f[nodeOff * nx + (i - nc)] - next[i];
@@ -486,7 +488,7 @@ __global__ __launch_bounds__(256) void ShootingAssembleKernel(const ShootingAsse
         const int li = wl & 15, lk = wl >> 4, KS = pivots > 0 ? (a.ne + 3) >> 2 : 0, TD = (nd + 15) >> 4, TE = (a.ne + 15) >> 4, TZ = (nz + 15) >> 4;
         auto pivotColumn = [&](int t) { return t < a.ne ? pivCol[t] : -1; };  // input the row t was solved for, or < 0
         // the k-steps of this lane's operand rows, looked up once (the same for every tile): up to 64 equality rows (the C ABI's bound)
-        constexpr int kMaxSteps = 16, kGroup = 4;
+        constexpr int kMaxSteps = 16, kGroup = UNGAR_ASSEMBLE_K_GROUP;
         int stepPivot[kMaxSteps], stepRow[kMaxSteps];
 #pragma unroll
         for (int ks = 0; ks < kMaxSteps; ++ks) {
@@ -510,7 +512,7 @@ __global__ __launch_bounds__(256) void ShootingAssembleKernel(const ShootingAsse
 #pragma unroll
                     for (int q = 0; q < kGroup; ++q) {
                         const int jt = stepPivot[g * kGroup + q], tc = stepRow[g * kGroup + q];
-                        av[q] = Wd[(nz + (jA < 0 ? 0 : jA)) * nd + nz + (jt < 0 ? 0 : jt)];
+                        av[q] = Wd[sym(nz + (jA < 0 ? 0 : jA), nz + (jt < 0 ? 0 : jt))];
                         bv[q] = Ed[tc * ld + cB];
                     }
 #pragma unroll
@@ -550,7 +552,7 @@ __global__ __launch_bounds__(256) void ShootingAssembleKernel(const ShootingAsse
             }
         };
         quadSum(
-            nd, [&](int c, int row, int input) { return Wd[c * nd + nz + input] * Ed[row * ld + nd]; }, [&](int c, double sv) { prow[c] = gd[c] - sv; });  // w + W s,  s = -sum_i e_(J_i) g0_i
+            nd, [&](int c, int row, int input) { return Wd[sym(c, nz + input)] * Ed[row * ld + nd]; }, [&](int c, double sv) { prow[c] = gd[c] - sv; });  // w + W s,  s = -sum_i e_(J_i) g0_i
         quadSum(
             nz, [&](int r, int row, int input) { return ABd[r * nd + nz + input] * Ed[row * ld + nd]; }, [&](int r, double sv) { bd[r] -= sv; });
         __syncthreads();
@@ -575,14 +577,14 @@ __global__ __launch_bounds__(256) void ShootingAssembleKernel(const ShootingAsse
 #ifdef UNGAR_SHOOTING_CLOCKS
             const unsigned long long tile0 = __builtin_amdgcn_s_memtime();
 #endif
-            double* C = hessian ? Wd : ABd;
             const int rows = hessian ? nd : nz;
             const int rowA = 16 * ti + li, rA = rowA < rows ? rowA : rows - 1, rG = rowA < nd ? rowA : nd - 1;
             const int colB = 16 * tj + li, cB = colB < nd ? colB : nd - 1;
             f64x4 acc, acc2 = {0.0, 0.0, 0.0, 0.0};  // (two accumulators: the two products of a k-step do not wait for each other)
             for (int r = 0; r < 4; ++r) {
                 const int row = 16 * ti + lk + 4 * r;
-                acc[r] = C[(row < rows ? row : rows - 1) * nd + cB];
+                const int rc = row < rows ? row : rows - 1;
+                acc[r] = hessian ? Wd[sym(rc, cB)] : ABd[rc * nd + cB];  // (below the diagonal of a diagonal tile: the transposed entry, computed and not stored)
             }
 #pragma unroll
             for (int g = 0; g < kMaxSteps / kGroup; ++g) {
@@ -591,12 +593,12 @@ __global__ __launch_bounds__(256) void ShootingAssembleKernel(const ShootingAsse
 #pragma unroll
                     for (int q = 0; q < kGroup; ++q) {
                         const int jt = stepPivot[g * kGroup + q], tc = stepRow[g * kGroup + q], J = nz + (jt < 0 ? 0 : jt);
-                        a1[q] = C[rA * nd + J];
+                        a1[q] = hessian ? Wd[sym(rA, J)] : ABd[rA * nd + J];
                         b1[q] = Ed[tc * ld + cB];
                         if (hessian) {
                             a2[q] = Ed[tc * ld + rG];
                             b2[q] = V[tc * nd + cB];
-                            b3[q] = Wd[J * nd + cB];
+                            b3[q] = Wd[sym(J, cB)];
                         }
                     }
 #pragma unroll
@@ -620,8 +622,7 @@ __global__ __launch_bounds__(256) void ShootingAssembleKernel(const ShootingAsse
                     acc[r] += acc2[r];
                     if (hessian) {
                         if (row <= colB && !rowIsPivot[r]) {
-                            Wd[row * nd + colB] = acc[r];
-                            Wd[colB * nd + row] = acc[r];
+                            Wd[tri(row, colB)] = acc[r];
                         }
                     } else if (row < nz) {
                         ABd[row * nd + colB] = acc[r];
@@ -644,8 +645,7 @@ __global__ __launch_bounds__(256) void ShootingAssembleKernel(const ShootingAsse
         for (int t = wave; t < pivots; t += waves) {
             const int J = nz + pivCol[list[t]];
             for (int c = wl; c < nd; c += 64) {
-                Wd[J * nd + c] = c == J ? 1.0 : 0.0;
-                Wd[c * nd + J] = c == J ? 1.0 : 0.0;
+                Wd[sym(J, c)] = c == J ? 1.0 : 0.0;
             }
             for (int r = wl; r < nz; r += 64) ABd[r * nd + J] = 0.0;
         }
@@ -659,7 +659,7 @@ __global__ __launch_bounds__(256) void ShootingAssembleKernel(const ShootingAsse
     double* W = a.W + nodeOff * nd * nd;
     for (int idx = lane; idx < nd * nd; idx += lanes) {
         const int r = static_cast<int>((static_cast<float>(idx) + 0.5f) * ndInv);
-        if (r <= idx - r * nd) W[idx] = Wd[idx];
+        if (r <= idx - r * nd) W[idx] = Wd[tri(r, idx - r * nd)];
     }
     double* w = a.w + nodeOff * nd;
     for (int c = lane; c < nd; c += lanes) w[c] = gd[c];
@@ -884,7 +884,7 @@ extern "C" int ungar_amd_launch_shooting_assemble(const ShootingAssembleArgs* a,
     if (a->d.batch <= 0) return 0;
     const std::size_t nd = static_cast<std::size_t>(a->d.nd()), nz = static_cast<std::size_t>(a->d.nz());
     const std::size_t ne = static_cast<std::size_t>(a->ne), nu = static_cast<std::size_t>(a->d.nu);
-    const std::size_t lds = (nd * nd + nd + 2 * static_cast<std::size_t>(a->nh) + nz * nd + 2 * ne * (nd + 1) + nz + (nd + 1) + 6) * sizeof(double) +
+    const std::size_t lds = (nd * (nd + 1) / 2 + nd + 2 * static_cast<std::size_t>(a->nh) + nz * nd + 2 * ne * (nd + 1) + nz + (nd + 1) + 6) * sizeof(double) +
                             (ne + nu + (nd > ne ? nd : ne) + 2) * sizeof(int) + 16;
     if (lds > 160 * 1024) return static_cast<int>(hipErrorInvalidValue);
     if (lds > 64 * 1024) {
