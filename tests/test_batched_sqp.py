@@ -49,10 +49,10 @@ def test_assembly_kernel_sections_give_the_same_bits(repo_root, tmp_path):
             env["UNGAR_AMD_ASSEMBLE_GENERIC"] = "1"
         folder = tmp_path / mode
         folder.mkdir()
-        r = subprocess.run([exe, str(tmp_path / "codegen"), "256", "4", str(folder)], capture_output=True, text=True, timeout=1500, env=env)
+        r = subprocess.run([exe, str(tmp_path / "codegen"), "256", "3", str(folder)], capture_output=True, text=True, timeout=1500, env=env)
         print(r.stdout[-2000:], r.stderr[-1000:])
-        assert r.returncode == 0 and "PASS batched quadruped SQP (batch 256, 4 compared)" in r.stdout
+        assert r.returncode == 0 and "PASS batched quadruped SQP (batch 256, 3 compared)" in r.stdout
         dumps[mode] = {f.name: f.read_bytes() for f in sorted(folder.iterdir())}
-    assert len(dumps["specialised"]) >= 8 and dumps["specialised"].keys() == dumps["generic"].keys()  # 4 instances x 2 iterations
+    assert len(dumps["specialised"]) >= 6 and dumps["specialised"].keys() == dumps["generic"].keys()  # 3 instances x 2 iterations
     for name, data in dumps["specialised"].items():
         assert len(data) > 100_000 and data == dumps["generic"][name], f"{name}: the two code paths disagree"
