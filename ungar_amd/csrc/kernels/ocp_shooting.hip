@@ -251,6 +251,7 @@ __global__ __launch_bounds__(256, UNGAR_ASSEMBLE_WAVES_PER_EU) void ShootingAsse
             if (wl == 0) jobCycles[8] = __popc(nonZeroRows);
 #endif
             unsigned long long taken = 0ull;  // inputs that are pivots already (wave-uniform)
+            unsigned pivotRows = 0u;          // rows that took a pivot (wave-uniform)
             const int myInput = wl - nz;
             const bool inputLane = wl >= nz && wl < nd;
 #pragma unroll
@@ -269,6 +270,7 @@ __global__ __launch_bounds__(256, UNGAR_ASSEMBLE_WAVES_PER_EU) void ShootingAsse
                     if (wl == 0) pivCol[i] = j;
                     if (j >= 0) {
                         taken |= 1ull << j;
+                        pivotRows |= 1u << i;
                         const int J = nz + j;
                         const double rpiv = 1.0 / ReadLane(t[i], J);
                         const double p = wl == J ? 1.0 : t[i] * rpiv;
@@ -286,6 +288,9 @@ __global__ __launch_bounds__(256, UNGAR_ASSEMBLE_WAVES_PER_EU) void ShootingAsse
             for (int r = 0; r < kRegisterRows; ++r)
                 if (r < a.ne && wl < ld) Ed[r * ld + wl] = t[r];
             if (wl < d.nu) used[wl] = static_cast<int>((taken >> wl) & 1ull);
+            // the ascending list of pivot rows the substitution walks, while the flags are at hand (the generic path builds it behind a barrier of its own)
+            if (wl < a.ne && ((pivotRows >> wl) & 1u)) list[__popc(pivotRows & ((1u << wl) - 1u))] = wl;
+            if (wl == 0) *listSize = __popc(pivotRows);
         } else if (role == 1) {
             if (a.nh > 0) {
                 const int nnz = a.ph.nnz, mine = wl < nnz ? wl : -1;
@@ -481,8 +486,10 @@ __global__ __launch_bounds__(256, UNGAR_ASSEMBLE_WAVES_PER_EU) void ShootingAsse
         // On the FP64 matrix cores, over ALL ne rows t (a row without a pivot contributes nothing: its operands are masked): every entry of the flat version
         // was a dependent chain of 16 x 3 multiply-adds behind index lookups -- 33-58 k of a node's ~120 k cycles; a 16 x 16 tile is 2 x ceil(ne / 4) matrix
         // instructions.  v_mfma_f64_16x16x4_f64: A[i][k] in lane 16 k + i, B[k][j] in lane 16 k + j, D[(lane >> 4) + 4 r][lane & 15] in element r.
-        buildList(a.ne, [&](int r) { return pivCol[r] >= 0; });
-        __syncthreads();
+        if (!specialised) {
+            buildList(a.ne, [&](int r) { return pivCol[r] >= 0; });
+            __syncthreads();
+        }
         const int pivots = elim == 2 ? 0 : *listSize;  // (2: measurement only -- rows reduced, substitution skipped)
         using f64x4 = __attribute__((__vector_size__(4 * sizeof(double)))) double;
         const int li = wl & 15, lk = wl >> 4, KS = pivots > 0 ? (a.ne + 3) >> 2 : 0, TD = (nd + 15) >> 4, TE = (a.ne + 15) >> 4, TZ = (nz + 15) >> 4;
