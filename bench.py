@@ -222,21 +222,25 @@ def roofline(r, jacobian, traffic=None, traffic_source=None):
             "kernel": f"NodeKernel<{r['kernel_model']}, {jacobian} Jacobian>"}
 
 
+def free_port() -> int:
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def launcher_command(gpus: int, argv: list[str], port: int | None = None) -> list[str]:
     """The one-process-per-GPU launch of this file: `python bench.py --gpus N` run directly (no WORLD_SIZE in the environment)
     re-executes itself under torch.distributed.run on 127.0.0.1 -- the same command the driver uses."""
-    import socket
     if port is None:
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            port = sk.getsockname()[1]
+        port = free_port()
     return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
             os.path.abspath(__file__), *argv]
 
 
 def reduce_min_max(value: float, dist=None, device=None) -> tuple[float, float]:
     """(min, max) of a per-rank figure over the ranks."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         return value, value
     import torch
     lo = torch.tensor([value], dtype=torch.float64, device=device)
@@ -282,6 +286,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    # UNGAR_BENCH_FORCE_DIST=1: build the process group even for ONE rank, so that RCCL initialisation, the device-tensor all-reduces
+    # (MAX / SUM / MIN), the barrier and the teardown can be exercised on a single-GPU box (tests/test_sharding.py, -m gpu)
+    force_dist = os.environ.get("UNGAR_BENCH_FORCE_DIST") == "1"
     # the CPU baseline belongs to the single-GPU line (rank 0, N = 1); multi-rank lines say so instead of dropping it silently
     want_cpu = not args.no_cpu_baseline and world == 1 and rank == 0
     from ungar_amd import workloads as W
@@ -298,13 +305,24 @@ def main():
     device_index = local_rank % max(1, torch.cuda.device_count())  # one rank per GPU on a real node; the modulo only matters in the
     torch.cuda.set_device(device_index)                           # single-GPU dry run of the multi-rank control flow (gloo) below
     dist = None
-    if world > 1:
+    if world > 1 or force_dist:
+        import datetime
         import torch.distributed as dist
         backend = os.environ.get("UNGAR_BENCH_BACKEND", "nccl")  # nccl == RCCL on ROCm; "gloo" only for dry runs
+        if backend == "nccl" and world > torch.cuda.device_count():
+            # two RCCL ranks on one device either fail deep inside the communicator set-up or wait for each other: refuse up front
+            raise SystemExit(f"bench.py: the RCCL (nccl) backend needs one GPU per rank -- WORLD_SIZE={world} but {torch.cuda.device_count()} device(s) visible "
+                             f"(rank {rank}); use UNGAR_BENCH_BACKEND=gloo for a dry run of the multi-rank control flow on fewer devices")
+        if world == 1:  # single forced rank: no launcher set the rendezvous variables
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+        limit = datetime.timedelta(seconds=float(os.environ.get("UNGAR_BENCH_DIST_TIMEOUT", "180")))  # a rendezvous that cannot complete fails instead of hanging
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index), timeout=limit)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=limit)
 
     _, N, default_batch = W.WORKLOADS[args.workload]
     if args.batch_per_gpu is not None:  # weak scaling: fixed work per rank
@@ -378,10 +396,19 @@ def main():
             out["cpu_baseline"] = cpu_baseline(model_name, native, args.cpu_seconds)
         elif world > 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = {"skipped": "timed on rank 0 of the single-GPU run only (python bench.py --gpus 1): host cores are shared by the ranks here"}
-        print(json.dumps(out), flush=True)
+        line = json.dumps(out)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # the JSON line is the LAST line of stdout: native libraries (libdrm under RCCL / the HIP runtime) write notices through C stdio, which is fully
+        # buffered on a pipe and would otherwise be flushed after Python's own output, at exit
+        sys.stdout.flush()
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(line, flush=True)
 
 
 if __name__ == "__main__":

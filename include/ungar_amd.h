@@ -26,6 +26,13 @@
 extern "C" {
 #endif
 
+/* ABI version of THIS header.  It changes whenever a struct below grows or an entry point's parameter list changes (4: ungar_ocp_qp with its
+ * equality-row fields, `status` in ungar_ocp_line_search_select / _accept).  ungar_abi_version() returns the version the LIBRARY was built with:
+ * a wrapper compiled against an older header must compare the two before its first call -- a mismatch silently shifts arguments otherwise.
+ * (ungar_amd/__init__.py and Ungar::BatchedSoftSQPOptimizer do.) */
+#define UNGAR_AMD_ABI_VERSION 4
+int32_t ungar_abi_version(void);
+
 #define UNGAR_OK 0
 #define UNGAR_E_INVALID (-1)   /* bad argument (null pointer, negative count, unknown model) */
 #define UNGAR_E_HIP (-2)       /* a HIP runtime call failed; see ungar_last_error() */
@@ -359,8 +366,10 @@ typedef struct ungar_shooting_assemble_args {
      * recursion: Gauss-Jordan on [D | C | e] picks one pivot input per active row, u_j = -(E'_i . [z; u] + e'_i); the substitution turns
      * (AB, b, W, w) into an UNCONSTRAINED stage problem in which u_j is a decoupled dummy, so ungar_ocp_riccati_solve is called with
      * ne = 0 and ungar_shooting_recover_inputs restores the eliminated inputs afterwards.  E then receives the reduced rows E', eq_reduced
-     * (batch x N x ne) their residuals e', eq_pivots (batch x N x ne) the pivot input of every row (-1: row inactive, -2: a row that the
-     * inputs of its knot cannot meet -- reported through `status` by the recover call).  eq: the equality function's values (N+1 knots). */
+     * (batch x N x ne) their residuals e', eq_pivots (batch x N x ne) the pivot input of every row (-1: row inactive -- identically zero, or REDUNDANT: reduced
+     * by the rows before it to rounding noise, i.e. to less than 1e-12 of its own largest original entry, residual included; the reference's OSQP tolerates
+     * such rows too -- and -2: a row that the inputs of its knot cannot meet, e.g. a duplicate row with a different residual -- reported through `status` by
+     * the recover call).  eq: the equality function's values (N+1 knots). */
     int32_t eliminate_equalities;
     int32_t reserved;
     const double* eq;
@@ -372,6 +381,10 @@ int ungar_shooting_assemble(const ungar_shooting_assemble_args* args, void* stre
  * row i with pivot input j; status[b] = -(k+1) for a row that cannot be met (status may be null). */
 int ungar_shooting_recover_inputs(const ungar_shooting_dims* dims, int64_t ne, const double* E, const double* eq_reduced, const int32_t* eq_pivots, const double* dZ,
                                   double* dU, int32_t* status, void* stream);
+
+/* carry_inputs problems (c_{k+1} = u_k): copies the inputs of row k into the carried slots of row k+1 for every k < N, in place, after `rows` was written from
+ * outside (row 0's carried slots stay the caller's: the input applied before the horizon).  quadrotor.example.cpp:222-227 reads u_{k-1} the same way. */
+int ungar_shooting_refresh_carried_inputs(const ungar_shooting_dims* dims, double* rows, void* stream);
 
 /* theta = multiplier * |[x_0 - x_m; x_{k+1} - f_k; e_k]|_2, objective = sum_{k<=N} cost_k, phi = objective + barrier terms, and (cost_grad,
  * dZ, dU given) slope = grad objective . step, per instance (soft_sqp.hpp:68-87).  period > 0: dims.batch counts STACKED trial points

@@ -56,3 +56,123 @@ def test_assembly_kernel_sections_give_the_same_bits(repo_root, tmp_path):
     assert len(dumps["specialised"]) >= 6 and dumps["specialised"].keys() == dumps["generic"].keys()  # 3 instances x 2 iterations
     for name, data in dumps["specialised"].items():
         assert len(data) > 100_000 and data == dumps["generic"][name], f"{name}: the two code paths disagree"
+
+
+def test_line_search_candidates_in_groups_give_the_same_iterates(repo_root, tmp_path):
+    """More candidate steps than one stacked evaluation holds (16; the reference accepts any BacktrackingLineSearch parameters,
+    backtracking_line_search.hpp:56-78) are offered in groups, largest first, an instance taking the first acceptable candidate over all groups.  Pinned
+    with the default 14 candidates in groups of 4 (UNGAR_AMD_STACKED_CANDIDATES): step sizes and iterates must still equal the facade's."""
+    exe = os.path.join(repo_root, "build", "batched_rc_car_test")
+    assert os.path.exists(exe), f"{exe} missing: run __graft_entry__.build()"
+    r = subprocess.run([exe, str(tmp_path / "codegen"), "512", "8"], capture_output=True, text=True, timeout=1500, env={**os.environ, "UNGAR_AMD_STACKED_CANDIDATES": "4"})
+    print(r.stdout[-4000:], r.stderr[-2000:])
+    assert r.returncode == 0 and "PASS batched rc_car SQP (batch 512, 8 compared)" in r.stdout
+
+
+# ---- redundant stage equality rows (ungar_shooting_assemble with eliminate_equalities) ------------------------------------------------------
+import ctypes  # noqa: E402
+
+import numpy as np  # noqa: E402
+
+
+class _Pattern(ctypes.Structure):
+    _fields_ = [("rows", ctypes.c_void_p), ("cols", ctypes.c_void_p), ("nnz", ctypes.c_int64)]
+
+
+class _Dims(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int64) for n in ("nx", "nu", "nc", "nw", "np", "horizon", "batch")] + [("carry_inputs", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+class _BarrierC(ctypes.Structure):
+    _fields_ = [("type", ctypes.c_int32), ("reserved", ctypes.c_int32), ("stiffness", ctypes.c_double), ("epsilon", ctypes.c_double)]
+
+
+class _AssembleArgs(ctypes.Structure):
+    _fields_ = ([("dims", _Dims)] + [(n, ctypes.c_void_p) for n in ("rows", "xm", "f", "f_jac", "carry_jac", "cost_grad", "cost_hes", "h", "h_jac", "eq_jac")] +
+                [(n, _Pattern) for n in ("f_pattern", "carry_pattern", "cost_grad_pattern", "cost_hes_pattern", "h_pattern", "eq_pattern")] +
+                [("nh", ctypes.c_int64), ("ne", ctypes.c_int64), ("barrier", _BarrierC), ("regularization", ctypes.c_double)] +
+                [(n, ctypes.c_void_p) for n in ("AB", "b", "W", "w", "E", "dz0")] + [("eliminate_equalities", ctypes.c_int32), ("reserved", ctypes.c_int32)] +
+                [(n, ctypes.c_void_p) for n in ("eq", "eq_reduced", "eq_pivots")])
+
+
+@pytest.mark.parametrize("nx,nu", [(3, 5), (20, 14)])  # 64 lanes per node (generic sections) / 256 lanes (wavefront-specialised sections, and generic on request)
+def test_redundant_equality_rows_take_no_pivot(nx, nu, monkeypatch):
+    """Two identical stage equality rows (and a third that is a combination of the others): the duplicate reduces to rounding noise (~1e-16 of its entries, not
+    exactly zero) and must be recognised against its ORIGINAL scale -- relative to its own reduced entries the noise would pass as a pivot and 1 / pivot would
+    blow up W, [A|B] and w.  The reduced problem must equal the one assembled from the independent rows alone; a duplicate with a DIFFERENT residual cannot be
+    met and is reported (-2).  Both code paths of the assembly kernel."""
+    import torch
+    import ungar_amd
+    lib = ungar_amd.load_library()
+    lib.ungar_shooting_assemble.argtypes = [ctypes.POINTER(_AssembleArgs), ctypes.c_void_p]
+    N, B, nd = 2, 3, nx + nu
+    rng = np.random.default_rng(7)
+    dev = lambda a, dt=torch.float64: torch.tensor(np.ascontiguousarray(a), dtype=dt, device="cuda")  # noqa: E731
+    nodes = B * (N + 1)
+
+    def dense_pattern(rows, cols):
+        r, c = np.meshgrid(np.arange(rows), np.arange(cols), indexing="ij")
+        return dev(r.ravel(), torch.int32), dev(c.ravel(), torch.int32)
+
+    def upper_pattern(n):
+        r, c = np.triu_indices(n)
+        return dev(r, torch.int32), dev(c, torch.int32)
+
+    base = rng.standard_normal((nodes, 2, nd))  # two independent rows per node
+    mix = rng.standard_normal((nodes, 2))
+    resid = rng.standard_normal((nodes, 2))
+
+    def run(rows_of, resid_of, generic):
+        """rows_of(node) -> (ne, nd) equality Jacobian; returns (pivots, W, AB, w, b, E', e')."""
+        ne = rows_of(0).shape[0]
+        eJ = np.stack([rows_of(i) for i in range(nodes)])
+        ev = np.stack([resid_of(i) for i in range(nodes)])
+        rows = dev(rng.standard_normal((nodes, nd)))
+        L = rng.standard_normal((nodes, nd, nd))
+        H = L @ L.transpose(0, 2, 1) + nd * np.eye(nd)
+        iu = np.triu_indices(nd)
+        keep = {"pf": dense_pattern(nx, nd), "pg": dense_pattern(1, nd), "pH": upper_pattern(nd), "pe": dense_pattern(ne, nd)}
+        t = {"rows": rows, "xm": dev(rng.standard_normal((B, nx))), "f": dev(rng.standard_normal((nodes, nx))), "fJ": dev(rng.standard_normal((nodes, nx * nd))),
+             "lg": dev(rng.standard_normal((nodes, nd))), "lH": dev(H[:, iu[0], iu[1]]), "eJ": dev(eJ.reshape(nodes, -1)), "e": dev(ev),
+             "AB": torch.zeros((B * N, nx * nd), dtype=torch.float64, device="cuda"), "b": torch.zeros((B * N, nx), dtype=torch.float64, device="cuda"),
+             "W": torch.zeros((nodes, nd * nd), dtype=torch.float64, device="cuda"), "w": torch.zeros((nodes, nd), dtype=torch.float64, device="cuda"),
+             "E": torch.zeros((B * N, ne * nd), dtype=torch.float64, device="cuda"), "dz0": torch.zeros((B, nx), dtype=torch.float64, device="cuda"),
+             "er": torch.zeros((B * N, ne), dtype=torch.float64, device="cuda"), "piv": torch.full((B * N, ne), 99, dtype=torch.int32, device="cuda")}
+        a = _AssembleArgs()
+        a.dims = _Dims(nx, nu, 0, 0, 0, N, B, 0, 0)
+        for name, key in (("rows", "rows"), ("xm", "xm"), ("f", "f"), ("f_jac", "fJ"), ("cost_grad", "lg"), ("cost_hes", "lH"), ("eq_jac", "eJ"), ("AB", "AB"), ("b", "b"), ("W", "W"),
+                          ("w", "w"), ("E", "E"), ("dz0", "dz0"), ("eq", "e"), ("eq_reduced", "er"), ("eq_pivots", "piv")):
+            setattr(a, name, t[key].data_ptr())
+        for name, key in (("f_pattern", "pf"), ("cost_grad_pattern", "pg"), ("cost_hes_pattern", "pH"), ("eq_pattern", "pe")):
+            r, c = keep[key]
+            setattr(a, name, _Pattern(r.data_ptr(), c.data_ptr(), r.numel()))
+        a.nh, a.ne, a.regularization, a.eliminate_equalities = 0, ne, 1e-6, 1
+        a.barrier = _BarrierC(0, 0, 100.0, 2e-5)
+        if generic:
+            monkeypatch.setenv("UNGAR_AMD_ASSEMBLE_GENERIC", "1")
+        else:
+            monkeypatch.delenv("UNGAR_AMD_ASSEMBLE_GENERIC", raising=False)
+        assert lib.ungar_shooting_assemble(ctypes.byref(a), None) == 0, lib.ungar_last_error()
+        torch.cuda.synchronize()
+        return {k: t[k].cpu().numpy() for k in ("piv", "W", "AB", "w", "b", "E", "er")}
+
+    for generic in (False, True):
+        rng = np.random.default_rng(11)  # the same random problem data for every call of run() below
+        ref = run(lambda i: base[i], lambda i: resid[i], generic)
+        assert (ref["piv"] >= 0).all()
+        # rows: r0, r1, a copy of r0 (same residual) and a combination of r0 and r1 (combined residual): two redundant rows
+        def with_copies(i):
+            return np.stack([base[i][0], base[i][1], base[i][0], mix[i][0] * base[i][0] + mix[i][1] * base[i][1]])
+        def residuals(i):
+            return np.array([resid[i][0], resid[i][1], resid[i][0], mix[i][0] * resid[i][0] + mix[i][1] * resid[i][1]])
+        rng = np.random.default_rng(11)
+        out = run(with_copies, residuals, generic)
+        assert (out["piv"][:, :2] == ref["piv"]).all() and (out["piv"][:, 2:] == -1).all(), out["piv"]
+        for key in ("W", "AB", "w", "b"):
+            assert np.isfinite(out[key]).all()
+            scale = np.abs(ref[key]).max()
+            assert np.abs(out[key] - ref[key]).max() <= 1e-10 * scale, key  # the redundant rows changed nothing
+        # the duplicate with a DIFFERENT residual cannot be met by any input
+        rng = np.random.default_rng(11)
+        bad = run(with_copies, lambda i: residuals(i) + np.array([0.0, 0.0, 0.5, 0.0]), generic)
+        assert (bad["piv"][:, 2] == -2).all() and (bad["piv"][:, 3] == -1).all() and (bad["piv"][:, :2] == ref["piv"]).all()

@@ -102,3 +102,55 @@ def test_bench_launches_its_own_ranks(repo_root, monkeypatch):
         bench.main()
     assert "WORLD_SIZE=1" in str(stop.value.code)
     assert bench.reduce_min_max(3.5) == (3.5, 3.5)
+
+
+def _run_bench(repo_root, args, env, timeout=600):
+    import subprocess
+    import sys
+    return subprocess.run([sys.executable, os.path.join(repo_root, "bench.py"), *args], cwd=repo_root, capture_output=True, text=True, timeout=timeout,
+                          env={**os.environ, "HSA_ENABLE_IPC_MODE_LEGACY": "0", **env})
+
+
+@pytest.mark.gpu
+def test_bench_runs_under_rccl_at_world_size_one(repo_root):
+    """SURVEY.md section 8(e) on ONE GPU: `bench.py --gpus 1` under init_process_group("nccl", world_size=1, device_id=...) -- RCCL initialisation,
+    the MAX / SUM / MIN all-reduces on DEVICE tensors, the barriers of the timed region and the teardown all execute; the line reports what the
+    process group saw.  (The 2/4/8-GPU runs are the driver's; this is their first contact with RCCL.)"""
+    import json
+    out = _run_bench(repo_root, ["--gpus", "1", "--steps", "10", "--warmup", "2", "--no-cpu-baseline", "--no-sub-results", "--prewarm-seconds", "0.1"],
+                     {"UNGAR_BENCH_FORCE_DIST": "1", "UNGAR_BENCH_BACKEND": "nccl"})
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert out.stdout.strip().splitlines()[-1].startswith("{"), out.stdout[-2000:]  # the JSON line is the last one, whatever the native libraries print
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["backend"] == "nccl" and d["ranks_seen"] == 1 and d["n_gpus"] == 1
+    assert d["config"]["nodes_per_step"] == 4096 * 20 and abs(d["checksum"] - 5033491.53798481) < 1e-3
+    assert d["per_rank_evals_per_s"]["min"] == d["per_rank_evals_per_s"]["max"] > 1e7
+    assert abs(d["value"] - d["config"]["nodes_per_step"] / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+
+
+@pytest.mark.gpu
+def test_two_rccl_ranks_on_one_device_fail_cleanly(repo_root):
+    """`python bench.py --gpus 2` with the RCCL backend where ONE device is visible: every rank exits non-zero with an explanation before any
+    communicator is built (two RCCL ranks on one device would otherwise fail deep inside RCCL or wait for each other); no hang."""
+    import torch as _torch
+    if _torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with a single visible GPU")
+    out = _run_bench(repo_root, ["--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"], {"UNGAR_BENCH_BACKEND": "nccl", "UNGAR_BENCH_DIST_TIMEOUT": "60"}, timeout=300)
+    assert out.returncode != 0
+    assert "needs one GPU per rank" in out.stderr and "WORLD_SIZE=2" in out.stderr
+
+
+def test_forced_process_group_of_one_rank_runs_the_collectives():
+    """The reductions no longer short-cut an initialised group of one rank (gloo here, RCCL in the GPU test above)."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        assert reduce_timing(0.25, 11, dist) == (0.25, 11)
+        assert reduce_sums([1.5, 2], dist) == [1.5, 2.0]
+    finally:
+        dist.destroy_process_group()
+        for k in ("MASTER_ADDR", "MASTER_PORT", "RANK", "WORLD_SIZE"):
+            os.environ.pop(k, None)

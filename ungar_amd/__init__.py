@@ -54,6 +54,9 @@ class _NodeBatch(ctypes.Structure):
 _LIB = None
 
 
+ABI_VERSION = 4  # UNGAR_AMD_ABI_VERSION of include/ungar_amd.h these bindings mirror
+
+
 def load_library() -> ctypes.CDLL:
     """dlopen libungar_amd.so and declare every symbol of include/ungar_amd.h.  Raises loudly if the
     HIP library has not been built (no fallback path exists)."""
@@ -65,6 +68,9 @@ def load_library() -> ctypes.CDLL:
         raise UngarError(f"{path} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
                          "(ungar_amd has no CPU fallback).")
     lib = ctypes.CDLL(path)
+    lib.ungar_abi_version.restype = ctypes.c_int32
+    if lib.ungar_abi_version() != ABI_VERSION:  # the structs below mirror include/ungar_amd.h at this version: a mismatch would shift arguments silently
+        raise UngarError(f"{path} reports ABI version {lib.ungar_abi_version()}, these bindings were written for {ABI_VERSION} (include/ungar_amd.h: UNGAR_AMD_ABI_VERSION)")
     vp, i64p = ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)
     i32pp = ctypes.POINTER(ctypes.POINTER(ctypes.c_int32))
     lib.ungar_model_open.argtypes = [ctypes.c_char_p, ctypes.POINTER(vp)]

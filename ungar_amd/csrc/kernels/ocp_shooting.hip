@@ -135,7 +135,11 @@ __global__ __launch_bounds__(256, UNGAR_ASSEMBLE_WAVES_PER_EU) void ShootingAsse
     double* bd = Ed + a.ne * ld;      // nz
     double* prow = bd + nz;           // nd + 1: w + W s of the substitution
     double* vbuf = prow + nd + 1;     // 6 + ne x (nd + 1): pivot-search keys, the second tableau of the elimination, then W_BB G
-    int* pivCol = reinterpret_cast<int*>(vbuf + 6 + a.ne * ld);  // ne pivot inputs
+    // ne: bit pattern of the largest |entry| of every ORIGINAL equality row (Jacobian entries and residual), collected while the row is scattered.  A row that the
+    // elimination reduces to rounding noise of its original entries (a redundant / linearly dependent row: ~1e-16 of its scale, never exactly zero) is recognised
+    // against this scale -- relative to its own reduced entries the noise would pass as a pivot and 1 / pivot would blow up W, [A|B] and w.
+    unsigned long long* rowScale = reinterpret_cast<unsigned long long*>(vbuf + 6 + a.ne * ld);
+    int* pivCol = reinterpret_cast<int*>(vbuf + 6 + a.ne * ld + a.ne);  // ne pivot inputs
     int* used = pivCol + a.ne;        // nu flags
     int* list = used + d.nu;          // max(nd, ne) indices of a support
     int* listSize = list + (nd > a.ne ? nd : a.ne);
@@ -188,7 +192,12 @@ __global__ __launch_bounds__(256, UNGAR_ASSEMBLE_WAVES_PER_EU) void ShootingAsse
     const double inequalityValue = ownsInequalityEntry ? a.hJ[nodeOff * a.ph.nnz + wl] : 0.0;
     const double residualFirst = specialised && a.e && lane < a.ne ? a.e[nodeOff * a.ne + lane] : 0.0;
     for (int i = lane; i < total; i += lanes) lds[i] = 0.0;
+    for (int i = lane; i < a.ne; i += lanes) rowScale[i] = 0ull;
     __syncthreads();
+    auto offerScale = [&](int row, double value) {  // (non-negative doubles order like their bit patterns)
+        const unsigned long long bits = static_cast<unsigned long long>(__double_as_longlong(fabs(value)));
+        if (bits) atomicMax(&rowScale[row], bits);
+    };
     if (fH.target >= 0) Wd[fH.target] = fH.value;
     for (int e = lane + lanes; e < a.pH.nnz; e += lanes)
         if (a.pH.rows[e] <= a.pH.cols[e]) Wd[tri(a.pH.rows[e], a.pH.cols[e])] = a.lH[nodeOff * a.pH.nnz + e];
@@ -209,9 +218,19 @@ __global__ __launch_bounds__(256, UNGAR_ASSEMBLE_WAVES_PER_EU) void ShootingAsse
             if (fc.target >= 0) ABd[fc.target] = fc.value;
             for (int e = lane + lanes; e < a.pc.nnz; e += lanes) ABd[a.pc.rows[e] * nd + nc + a.pc.cols[e]] = a.cJ[nodeOff * a.pc.nnz + e];
         }
-        if (fe.target >= 0) Ed[fe.target] = fe.value;
-        if (specialised && lane < a.ne) Ed[lane * ld + nd] = residualFirst;  // (the generic sections fill this column later)
-        for (int e = lane + lanes; e < a.pe.nnz; e += lanes) Ed[a.pe.rows[e] * ld + a.pe.cols[e]] = a.eJ[nodeOff * a.pe.nnz + e];
+        if (fe.target >= 0) {
+            Ed[fe.target] = fe.value;
+            if (elim) offerScale(a.pe.rows[lane], fe.value);
+        }
+        if (specialised && lane < a.ne) {
+            Ed[lane * ld + nd] = residualFirst;  // (the generic sections fill this column later)
+            offerScale(lane, residualFirst);
+        }
+        for (int e = lane + lanes; e < a.pe.nnz; e += lanes) {
+            const double v = a.eJ[nodeOff * a.pe.nnz + e];
+            Ed[a.pe.rows[e] * ld + a.pe.cols[e]] = v;
+            if (elim) offerScale(a.pe.rows[e], v);
+        }
     }
     __syncthreads();
     UNGAR_SHOOTING_MARK();  // 1: zeroed images, scattered stage outputs
@@ -250,6 +269,7 @@ __global__ __launch_bounds__(256, UNGAR_ASSEMBLE_WAVES_PER_EU) void ShootingAsse
 #ifdef UNGAR_SHOOTING_CLOCKS
             if (wl == 0) jobCycles[8] = __popc(nonZeroRows);
 #endif
+            const double scaleOfMyRow = wl < a.ne ? __longlong_as_double(static_cast<long long>(rowScale[wl])) : 0.0;  // lane r: original scale of row r
             unsigned long long taken = 0ull;  // inputs that are pivots already (wave-uniform)
             unsigned pivotRows = 0u;          // rows that took a pivot (wave-uniform)
             const int myInput = wl - nz;
@@ -265,8 +285,12 @@ __global__ __launch_bounds__(256, UNGAR_ASSEMBLE_WAVES_PER_EU) void ShootingAsse
                     WaveMaxPair(key, rowBits);
                     const double best = __longlong_as_double(static_cast<long long>(key & ~0xFFull)), rowMax = __longlong_as_double(static_cast<long long>(rowBits));
                     int j = key ? 255 - static_cast<int>(key & 0xFFull) : -1;
-                    if (j >= 0 && best <= 1e-12 * rowMax) j = -2;
-                    if (j == -1 && rowMax > 0.0) j = -2;
+                    if (rowMax <= 1e-12 * ReadLane(scaleOfMyRow, i)) {
+                        j = -1;  // what is left of the row is rounding noise of its original entries: redundant, no pivot (an inconsistent residual is not noise: below)
+                    } else {
+                        if (j >= 0 && best <= 1e-12 * rowMax) j = -2;
+                        if (j == -1 && rowMax > 0.0) j = -2;
+                    }
                     if (wl == 0) pivCol[i] = j;
                     if (j >= 0) {
                         taken |= 1ull << j;
@@ -397,7 +421,11 @@ __global__ __launch_bounds__(256, UNGAR_ASSEMBLE_WAVES_PER_EU) void ShootingAsse
         if (stage) {
             const double* next = RowOf(a.rows, d, b, k + 1);
             for (int i = lane; i < nz; i += lanes) bd[i] = i < nc ? 0.0 : a.f[nodeOff * nx + (i - nc)] - next[i];
-            for (int j = lane; j < a.ne; j += lanes) Ed[j * ld + nd] = a.e ? a.e[nodeOff * a.ne + j] : 0.0;
+            for (int j = lane; j < a.ne; j += lanes) {
+                const double residual = a.e ? a.e[nodeOff * a.ne + j] : 0.0;
+                Ed[j * ld + nd] = residual;
+                if (elim) offerScale(j, residual);
+            }
         }
         __syncthreads();
         UNGAR_SHOOTING_MARK();  // 3: regularisation, mirror, b
@@ -445,8 +473,12 @@ __global__ __launch_bounds__(256, UNGAR_ASSEMBLE_WAVES_PER_EU) void ShootingAsse
                 const double best = __longlong_as_double(static_cast<long long>(key & ~0xFFull)), rowMax = __longlong_as_double(static_cast<long long>(keys[2 * set + 1]));
                 // no usable input coefficient: an identically-zero (or redundant) row takes no pivot; anything else cannot be met by this knot's inputs
                 int j = key ? 255 - static_cast<int>(key & 0xFFull) : -1;
-                if (j >= 0 && best <= 1e-12 * rowMax) j = -2;
-                if (j == -1 && rowMax > 0.0) j = -2;
+                if (rowMax <= 1e-12 * __longlong_as_double(static_cast<long long>(rowScale[i]))) {
+                    j = -1;  // rounding noise of the row's original entries: redundant (same rule as the single-wavefront job above)
+                } else {
+                    if (j >= 0 && best <= 1e-12 * rowMax) j = -2;
+                    if (j == -1 && rowMax > 0.0) j = -2;
+                }
                 if (lane == 0) {
                     pivCol[i] = j;
                     if (j >= 0) used[j] = 1;  // (readers of this step exclude j themselves; later steps see the flag behind the barrier)
@@ -803,6 +835,20 @@ __global__ __launch_bounds__(256) void ShootingTrialKernel(const ShootingTrialAr
     }
 }
 
+/// carry_inputs problems: the carried slots of row k + 1 <- the inputs of row k (k < N), in place; one lane per (instance, knot, input).  Row 0's carried slots
+/// are the caller's.  (What BatchedSoftSQPOptimizer::RefreshCarried needs after the rows were written from outside: a zero-length step through the trial
+/// kernel did the same but cleared the last search direction and went through the trial buffer.)
+__global__ __launch_bounds__(256) void ShootingRefreshCarriedInputsKernel(const ShootingDims d, double* rows) {
+    const long long idx = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (idx >= d.batch * d.N * d.nu) return;
+    const long long node = idx / d.nu;
+    const int i = static_cast<int>(idx - node * d.nu);
+    const long long b = node / d.N;
+    const int k = static_cast<int>(node - b * d.N);
+    double* row = rows + (b * (d.N + 1) + k) * static_cast<long long>(d.nv());
+    row[d.nv() + i] = row[d.nz() + i];  // (reads inputs, writes carried slots of the next row: disjoint elements, no ordering needed)
+}
+
 /// The same trial rows UNIT-FASTEST: a workgroup transposes 64 consecutive stacked nodes, 32 elements at a time, through an LDS tile --
 /// row segments are read coalesced (32 consecutive elements of a node per half wavefront), elements are stored coalesced (64 consecutive nodes).
 /// (Decomposing a lane's eight nodes once, ahead of the element loop -- pointers in registers instead of three 64-bit divisions per element -- was measured:
@@ -891,7 +937,7 @@ extern "C" int ungar_amd_launch_shooting_assemble(const ShootingAssembleArgs* a,
     if (a->d.batch <= 0) return 0;
     const std::size_t nd = static_cast<std::size_t>(a->d.nd()), nz = static_cast<std::size_t>(a->d.nz());
     const std::size_t ne = static_cast<std::size_t>(a->ne), nu = static_cast<std::size_t>(a->d.nu);
-    const std::size_t lds = (nd * (nd + 1) / 2 + nd + 2 * static_cast<std::size_t>(a->nh) + nz * nd + 2 * ne * (nd + 1) + nz + (nd + 1) + 6) * sizeof(double) +
+    const std::size_t lds = (nd * (nd + 1) / 2 + nd + 2 * static_cast<std::size_t>(a->nh) + nz * nd + 2 * ne * (nd + 1) + nz + (nd + 1) + 6 + ne /*row scales*/) * sizeof(double) +
                             (ne + nu + (nd > ne ? nd : ne) + 2) * sizeof(int) + 16;
     if (lds > 160 * 1024) return static_cast<int>(hipErrorInvalidValue);
     if (lds > 64 * 1024) {
@@ -911,6 +957,13 @@ extern "C" int ungar_amd_launch_shooting_recover(const ShootingRecoverArgs* a, v
     const long long items = a->d.batch * a->d.N * a->ne;
     if (items <= 0) return 0;
     hipLaunchKernelGGL(ShootingRecoverKernel, dim3(static_cast<unsigned>((items + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
+    return static_cast<int>(hipGetLastError());
+}
+
+extern "C" int ungar_amd_launch_shooting_refresh_carried_inputs(const ShootingDims* d, double* rows, void* stream) {
+    const long long items = d->batch * d->N * d->nu;
+    if (items <= 0) return 0;
+    hipLaunchKernelGGL(ShootingRefreshCarriedInputsKernel, dim3(static_cast<unsigned>((items + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), *d, rows);
     return static_cast<int>(hipGetLastError());
 }
 

@@ -134,6 +134,7 @@ struct ShootingSelectArgs {
 
 extern "C" int ungar_amd_launch_shooting_assemble(const ungar_amd::kernels::ShootingAssembleArgs* a, void* stream);
 extern "C" int ungar_amd_launch_shooting_recover(const ungar_amd::kernels::ShootingRecoverArgs* a, void* stream);
+extern "C" int ungar_amd_launch_shooting_refresh_carried_inputs(const ungar_amd::kernels::ShootingDims* d, double* rows, void* stream);
 extern "C" int ungar_amd_launch_shooting_merit(const ungar_amd::kernels::ShootingMeritArgs* a, void* stream);
 extern "C" int ungar_amd_launch_shooting_trial(const ungar_amd::kernels::ShootingTrialArgs* a, void* stream);
 extern "C" int ungar_amd_launch_shooting_select(const ungar_amd::kernels::ShootingSelectArgs* a, void* stream);

@@ -399,6 +399,10 @@ const char* ungar_last_error(void) {
     return g_lastError.c_str();
 }
 
+int32_t ungar_abi_version(void) {
+    return UNGAR_AMD_ABI_VERSION;
+}
+
 const char* ungar_version(void) {
     static std::string v = [] {
         int rt = 0;

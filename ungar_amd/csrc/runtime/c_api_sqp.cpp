@@ -240,12 +240,21 @@ int ungar_shooting_recover_inputs(const ungar_shooting_dims* dims, int64_t ne, c
     return Launched(ungar_amd_launch_shooting_recover(&k, stream), "ungar_shooting_recover_inputs");
 }
 
+int ungar_shooting_refresh_carried_inputs(const ungar_shooting_dims* dims, double* rows, void* stream) {
+    ShootingDims d{};
+    if (!dims || !ToDims(*dims, &d) || !d.carryInputs) return Fail(UNGAR_E_INVALID, "ungar_shooting_refresh_carried_inputs: needs the dimensions of a carry_inputs problem");
+    if (d.batch == 0) return UNGAR_OK;
+    if (!rows) return Fail(UNGAR_E_INVALID, "ungar_shooting_refresh_carried_inputs: null rows");
+    return Launched(ungar_amd_launch_shooting_refresh_carried_inputs(&d, rows, stream), "ungar_shooting_refresh_carried_inputs");
+}
+
 int ungar_shooting_merit(const ungar_shooting_merit_args* a, void* stream) {
     ShootingMeritArgs k{};
-    if (!a || !ToDims(a->dims, &k.d) || a->period < 0 || (a->period > 0 && a->dims.batch % a->period != 0) || a->nh < 0 || a->ne < 0)
-        return Fail(UNGAR_E_INVALID, "ungar_shooting_merit: bad dimensions");
+    if (!a || !ToDims(a->dims, &k.d) || a->period < 0 || (a->period > 0 && a->dims.batch % a->period != 0) || a->nh < 0 || a->nh > 256 || a->ne < 0 || a->ne > 64)
+        return Fail(UNGAR_E_INVALID, "ungar_shooting_merit: bad dimensions (nh <= 256, ne <= 64 as in ungar_shooting_assemble)");
     if (k.d.batch == 0) return UNGAR_OK;
     if (!a->rows || !a->xm || !a->f || !a->cost || !a->theta || !a->phi) return Fail(UNGAR_E_INVALID, "ungar_shooting_merit: null argument");
+    if ((a->nh > 0 && !a->h) || (a->ne > 0 && !a->eq)) return Fail(UNGAR_E_INVALID, "ungar_shooting_merit: nh > 0 needs h and ne > 0 needs eq (their terms would be dropped silently)");
     if (a->cost_grad && (BadPattern(a->cost_grad_pattern, a->cost_grad) || !a->dZ || !a->dU || !a->slope)) return Fail(UNGAR_E_INVALID, "ungar_shooting_merit: the slope needs the gradient pattern, dZ, dU and slope");
     k.rows = a->rows;
     k.xm = a->xm;
@@ -299,6 +308,8 @@ int ungar_shooting_select(const ungar_shooting_dims* dims, const ungar_line_sear
     if (k.d.batch == 0) return UNGAR_OK;
     if (!theta0 || !phi0 || !objective0 || !slope || !theta_trial || !phi_trial || !objective_trial || !accepted || !rows || !trial)
         return Fail(UNGAR_E_INVALID, "ungar_shooting_select: null argument");
+    if (trial_stride < 0 || (trial_stride > 0 && trial_stride < candidates * k.d.batch * (k.d.N + 1)))
+        return Fail(UNGAR_E_INVALID, "ungar_shooting_select: trial_stride smaller than the number of stacked nodes");
     k.candidates = static_cast<int>(candidates);
     k.thetaMin = p->theta_min;
     k.thetaMax = p->theta_max;

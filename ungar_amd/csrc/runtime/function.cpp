@@ -110,10 +110,10 @@ struct KeyHasher {
 #ifndef UNGAR_AMD_EMITTER_ID
 #define UNGAR_AMD_EMITTER_ID "unversioned"
 #endif
-constexpr const char* kCacheFormat = "ungar_amd-cache-2";
+constexpr const char* kCacheFormat = "ungar_amd-cache-3";  // bump whenever the emitted kernels' argument list (their ABI) or the meta file changes: 3 = ten-argument kernels (knot stride, direct host results)
 constexpr const char* kArch = "gfx950";
-constexpr std::size_t kBigKernel = 3000;
-constexpr int64_t kDirectHostResults = 512;  // single-instance host calls: results up to this many doubles are written straight into mapped host memory  // statements above which the machine schedulers are switched off (see below)
+constexpr std::size_t kBigKernel = 3000;        // statements above which the machine schedulers are switched off (see below)
+constexpr int64_t kDirectHostResults = 512;  // single-instance host calls: results up to this many doubles are written straight into mapped host memory
 
 std::string ShellQuote(const std::string& s) {
     std::string q = "'";

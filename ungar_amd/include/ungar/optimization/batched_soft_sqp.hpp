@@ -61,8 +61,10 @@ class BatchedSoftSQPOptimizer {
     /// Same parameters as SoftSQPOptimizer (reference soft_sqp.hpp:44-60) plus the number of instances.
     BatchedSoftSQPOptimizer(ShootingProblem problem, const index_t batch, const bool verbose = false, const real_t constraintViolationMultiplier = 1.0,
                             const index_t maxIterations = 10, const real_t stiffness = 100.0, const real_t epsilon = 2e-5,
-                            const RelaxedBarrierType relaxedBarrierType = RelaxedBarrierType::POLY)
-        : _p{std::move(problem)}, _batch{batch}, _verbose{verbose}, _multiplier{constraintViolationMultiplier}, _maxIterations{maxIterations} {
+                            const RelaxedBarrierType relaxedBarrierType = RelaxedBarrierType::POLY, const BacktrackingLineSearch::Parameters& lineSearchParameters = {})
+        : _p{std::move(problem)}, _batch{batch}, _verbose{verbose}, _multiplier{constraintViolationMultiplier}, _maxIterations{maxIterations}, _ls{lineSearchParameters} {
+        if (ungar_abi_version() != UNGAR_AMD_ABI_VERSION)  // this header was compiled against another revision of the C ABI than the library that is loaded
+            throw std::runtime_error("BatchedSoftSQPOptimizer: libungar_amd ABI version " + std::to_string(ungar_abi_version()) + ", header " + std::to_string(UNGAR_AMD_ABI_VERSION));
         _barrier.type = relaxedBarrierType == RelaxedBarrierType::LOG ? UNGAR_BARRIER_LOG : UNGAR_BARRIER_POLY;
         _barrier.reserved = 0;
         _barrier.stiffness = stiffness;
@@ -70,7 +72,8 @@ class BatchedSoftSQPOptimizer {
         Validate();
         _dims = {_p.stateSize, _p.inputSize, _p.carrySize, _p.knotParameterSize, _p.instanceParameterSize, _p.horizon, _batch, _p.carryInputs ? 1 : 0, 0};
         for (real_t alpha = 1.0; alpha >= _ls.alphaMin; alpha *= _ls.gammaAlpha) _alphas.push_back(alpha);  // backtracking_line_search.hpp:116-151
-        if (_alphas.empty() || _alphas.size() > 16) throw std::invalid_argument("BatchedSoftSQPOptimizer: the line search must try between 1 and 16 step sizes");
+        // any BacktrackingLineSearch parameters (backtracking_line_search.hpp:56-78): more than 16 candidate steps are evaluated in groups of 16, largest first
+        if (_alphas.empty()) throw std::invalid_argument("BatchedSoftSQPOptimizer: the line search has no candidate step (alphaMin > 1)");
         Allocate();
     }
     BatchedSoftSQPOptimizer(const BatchedSoftSQPOptimizer&) = delete;
@@ -89,6 +92,7 @@ class BatchedSoftSQPOptimizer {
     /// 1..N are then made consistent with (x, u) of the previous row (row 0's carried slots are the caller's: the quantity measured
     /// before the horizon, e.g. measured foot positions).  All instances become active.
     void SetRows(const real_t* rows, const real_t* measuredStates) {
+        Check(ungar_device_synchronize());  // the uploads below are synchronous copies on the null stream: nothing launched on the user's stream may still read the rows
         Check(ungar_device_upload(_rows, rows, Bytes(RowsSize())));
         Check(ungar_device_upload(_xm, measuredStates, Bytes(_batch * _p.stateSize)));
         RefreshCarried();
@@ -102,13 +106,8 @@ class BatchedSoftSQPOptimizer {
 
     void RefreshCarried() {
         if (_p.carrySize == 0) return;
-        if (_p.carryInputs) {  // a zero-length step through the trial kernel copies u_k into the carried slots of row k + 1
-            const index_t N = _p.horizon;
-            Check(ungar_device_zero(_dZ, Bytes(_batch * (N + 1) * Nz()), _stream));
-            Check(ungar_device_zero(_dU, Bytes(_batch * N * _p.inputSize), _stream));
-            const real_t one = 1.0;
-            Check(ungar_shooting_trial_rows(&_dims, _rows, _dZ, _dU, &one, 1, _trial, 0, _stream));
-            Check(ungar_device_copy(_rows, _trial, Bytes(RowsSize()), _stream));
+        if (_p.carryInputs) {  // u_k into the carried slots of row k + 1, in place (the last search direction and the trial rows are left alone)
+            Check(ungar_shooting_refresh_carried_inputs(&_dims, _rows, _stream));
         } else {
             CarryValues(_rows, _batch);
         }
@@ -219,10 +218,13 @@ class BatchedSoftSQPOptimizer {
         Check(ungar_shooting_merit(&m, _stream));
         // candidate steps, largest first: all at once (no host decision inside the iteration), or in two stages -- the first few, and the rest only
         // if some instance found none of them acceptable (one counter read back per iteration)
+        // (more than kStacked candidates -- a gamma_alpha close to 1 or a tiny alpha_min: the reference accepts any parameters -- go in groups of kStacked, each group
+        // only if some instance has not found its step yet: the same counter)
         const index_t stageA = _firstStage > 0 && _firstStage < K ? _firstStage : K;
         const ungar_line_search_parameters ls{_ls.alphaMin, _ls.thetaMin, _ls.thetaMax, _ls.eta, _ls.gammaPhi, _ls.gammaTheta, _ls.gammaAlpha};
         for (index_t begin = 0; begin < K;) {
-            const index_t count = begin == 0 ? stageA : K - begin;
+            const index_t wanted = begin == 0 ? stageA : K - begin;
+            const index_t count = wanted < kStacked ? wanted : kStacked;
             const bool last = begin + count == K;
             // trial rows UNIT-FASTEST (element e of stacked node i at _trial[e * stride + i]): the stage functions read them coalesced and touch
             // only the elements they use
@@ -317,7 +319,10 @@ class BatchedSoftSQPOptimizer {
     void SetLineSearchParameters(const BacktrackingLineSearch::Parameters& parameters) {
         std::vector<real_t> alphas;
         for (real_t alpha = 1.0; alpha >= parameters.alphaMin; alpha *= parameters.gammaAlpha) alphas.push_back(alpha);
-        if (alphas.size() != _alphas.size()) throw std::invalid_argument("BatchedSoftSQPOptimizer: the number of candidate steps is fixed at construction");
+        const std::size_t cap = static_cast<std::size_t>(kStacked);  // the stacked buffers hold min(candidates at construction, 16) trial points per instance
+        if ((alphas.size() < cap ? alphas.size() : cap) > (_alphas.size() < cap ? _alphas.size() : cap))
+            throw std::invalid_argument("BatchedSoftSQPOptimizer: more candidate steps per stacked evaluation than the buffers allocated at construction hold");
+        if (alphas.empty()) throw std::invalid_argument("BatchedSoftSQPOptimizer: the line search has no candidate step (alphaMin > 1)");
         _ls = parameters;
         _alphas = alphas;
     }
@@ -368,7 +373,8 @@ class BatchedSoftSQPOptimizer {
         return {dr, dc, nnz};
     }
     void Allocate() {
-        const index_t N = _p.horizon, B = _batch, K = static_cast<index_t>(_alphas.size()), nv = _p.RowSize(), nx = _p.stateSize, nu = _p.inputSize, nz = Nz(), nd = nz + nu;
+        const index_t N = _p.horizon, B = _batch, nv = _p.RowSize(), nx = _p.stateSize, nu = _p.inputSize, nz = Nz(), nd = nz + nu;
+        const index_t K = static_cast<index_t>(_alphas.size()) < kStacked ? static_cast<index_t>(_alphas.size()) : kStacked;  // candidates evaluated at once
         const index_t nodes = B * (N + 1), stacked = K * nodes;
         _pf = UploadPattern(*_p.dynamics, false);
         if (_p.carry) _pc = UploadPattern(*_p.carry, false);
@@ -455,6 +461,14 @@ class BatchedSoftSQPOptimizer {
         return host;
     }
 
+    /// Candidates per stacked evaluation: the C ABI's bound of 16 (ungar_shooting_trial_rows / _select), or fewer on request (UNGAR_AMD_STACKED_CANDIDATES:
+    /// the test of the group logic runs the default 14 candidates in groups of 4 and must reproduce the single-group iterates bit for bit).
+    static index_t StackedCandidates() {
+        const char* e = std::getenv("UNGAR_AMD_STACKED_CANDIDATES");
+        const long v = e ? std::atol(e) : 16;
+        return v >= 1 && v <= 16 ? static_cast<index_t>(v) : 16;
+    }
+    const index_t kStacked = StackedCandidates();
     ShootingProblem _p;
     index_t _batch;
     bool _verbose;

@@ -55,7 +55,7 @@ def tile_ranges(instances: int, tile: int = DEFAULT_TILE_INSTANCES) -> list[tupl
 
 def reduce_timing(elapsed_s: float, evals: int, dist=None, device=None) -> tuple[float, int]:
     """(max elapsed over ranks, total evals over ranks).  `dist` = torch.distributed or None."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():  # (an initialised group of ONE rank still runs the collectives: the single-GPU RCCL test)
         return elapsed_s, evals
     import torch
     t = torch.tensor([elapsed_s], dtype=torch.float64, device=device)
@@ -67,7 +67,7 @@ def reduce_timing(elapsed_s: float, evals: int, dist=None, device=None) -> tuple
 
 def reduce_sums(values, dist=None, device=None) -> list[float]:
     """Element-wise SUM over ranks of a short list of floats (evaluation counts, output checksums: SURVEY.md §8(e))."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():  # (an initialised group of ONE rank still runs the collectives: the single-GPU RCCL test)
         return [float(v) for v in values]
     import torch
     t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
