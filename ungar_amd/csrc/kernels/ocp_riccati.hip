@@ -719,8 +719,19 @@ int LaunchRiccati(const RiccatiArgs* a, std::size_t lds, hipStream_t stream) {
 }
 }  // namespace
 
+extern "C" int ungar_amd_launch_riccati_wave(const RiccatiArgs* a, void* stream);  // ocp_riccati_wave.hip: one wavefront per instance, matrices in registers
+
 extern "C" int ungar_amd_launch_riccati(const RiccatiArgs* a, void* stream) {
     if (a->batch <= 0) return 0;
+    {
+        // Default route for the sizes it is instantiated for (the large blocks: 37 + 12, 25 + 24, 13 + 24, no equality rows inside the recursion): the
+        // register-resident one-wavefront kernels.  UNGAR_AMD_RICCATI_VARIANT (any value, e.g. "fixed") keeps the LDS-resident kernels below: the A/B switch.
+        static const bool ldsResident = getenv("UNGAR_AMD_RICCATI_VARIANT") != nullptr;
+        if (!ldsResident) {
+            const int e = ungar_amd_launch_riccati_wave(a, stream);
+            if (e >= 0) return e;
+        }
+    }
     const std::size_t lds = static_cast<std::size_t>(RiccatiScratchDoubles(a->nx, a->nu, a->ne)) * sizeof(double);
     if (lds > 160 * 1024) return static_cast<int>(hipErrorInvalidValue);
     hipStream_t s = static_cast<hipStream_t>(stream);

@@ -1,0 +1,523 @@
+// ungar_amd :: the Riccati recursion of ocp_riccati.hpp with ONE WAVEFRONT PER INSTANCE and every matrix of the recursion in REGISTERS, in the operand /
+// accumulator layouts of v_mfma_f64_16x16x4_f64 (replaces the OSQP call of soft_sqp.hpp:143-158 for shooting structure).
+//
+// Why.  The LDS-resident kernels (ocp_riccati.hip) run one workgroup of four wavefronts per instance: 66-78 KB of LDS per instance keep two workgroups on
+// a CU, every phase ends in a workgroup barrier and costs its critical-path instruction count -- 0.10-0.15 of the roofline for the
+// 37 + 12, 25 + 24 and 13 + 24 blocks.  Here nothing is shared between wavefronts, so there is no barrier at all, and the products feed each other WITHOUT
+// any data movement because of how the matrix instruction lays its operands out over the lanes:
+//     A[i][k] in lane 16 k + i,   B[k][j] in lane 16 k + j,   D[(lane >> 4) + 4 r][lane & 15] in accumulator element r.
+//   * element r of an accumulator tile is rows 4 r .. 4 r + 3 of the tile in exactly the B layout: an accumulator is the B operand of the next product,
+//     k-step by k-step (P [A|B] -> [A|B]^T (P [A|B]));
+//   * the A and the B layout coincide, so the registers that hold [A|B] as B operand of P [A|B] are the A operand ([A|B]^T) of the second product;
+//   * P is symmetric: its accumulator tiles are the A operand of P [A|B] (A[i][k] = P[k][i]).
+// The affine parts ride along in HOMOGENEOUS coordinates -- x_e = [x; 1], P_e = [P p; p^T *], [A|B]_e = [A b B; 0 1 0] -- so that
+//     H_e = W_e + [A|B]_e^T P_e [A|B]_e = [H_xx h_x H_xu; h_x^T * h_u^T; H_ux h_u R]      (one chain of matrix instructions, no separate vector updates),
+//     [K | kff] = -R^-1 [H_ux | h_u],   P_e' = H_e,xx + H_e,xu [K | kff]                    (ocp_riccati.hpp: the same recursion).
+// R is factorised by symmetric elimination without pivoting on the tableau [R | H_ux h_u], lane = column, rows in registers, pivot columns broadcast with
+// v_readlane: the multipliers and pivots of the right-looking L D L^T of ocp_riccati.hpp (a pivot that is not positive is replaced by 1 and reported).
+// LDS (a few KB per wavefront, private to it) is used only to change layouts: accumulator tiles -> tableau columns, gains -> B operand, tile transposes.
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+
+#include "ocp_riccati.hpp"
+
+namespace ungar_amd::kernels {
+namespace {
+
+using f64x4 = __attribute__((__vector_size__(4 * sizeof(double)))) double;
+
+__device__ __forceinline__ double ReadLaneF64(double v, int sourceLane) {  // sourceLane wave-uniform
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), sourceLane), hi = __builtin_amdgcn_readlane(__double2hiint(v), sourceLane);
+    return __hiloint2double(hi, lo);
+}
+
+template <int CTRL>
+__device__ __forceinline__ double QuadPermuteF64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+
+using v2i = __attribute__((__vector_size__(2 * sizeof(int)))) int;
+constexpr int kOutOfRange = static_cast<int>(0x80000000u);  // a lane offset no buffer below reaches (also with a scalar / instruction offset added): the load returns 0
+
+/// Operands are read with MUBUF loads: (wave-uniform resource) + (32-bit lane offset) + (scalar offset).  A lane that has nothing to read passes
+/// kOutOfRange and gets 0 from the range check -- padded rows / columns cost neither a branch nor a select on the loaded value (a select between a load
+/// and a constant is turned into a branch around the load by the compiler, and every such load then waits for its own round trip: measured, 27-54 k
+/// cycles per knot), and one lane register serves every load of a tile pattern, the tile's position being the scalar offset.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t BufferOver(const double* base, int doubles) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(base), 0, doubles * 8, 0x00020000);
+}
+__device__ __forceinline__ double BufferLoad(__amdgpu_buffer_rsrc_t r, int laneOffsetBytes, int scalarOffsetBytes) {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, laneOffsetBytes, scalarOffsetBytes, 0));
+}
+
+/// Prefetch: every lane names one address; the cache line behind it is brought into L2 / the memory-side cache by an LDS-DMA load of four bytes into a
+/// junk area of LDS (`ldsJunk`: LDS byte address of 256 bytes nobody reads).  No destination register, nothing for the compiler to wait for, no count
+/// of ours either: the data is never used -- only the cache line matters.  (The operands of a knot are 34 KB per wavefront and all wavefronts reach the
+/// same point of the recursion together: requested where they are needed, the whole device waits for HBM -- 70 MB per knot of the 37 + 12 problem, 17 us --
+/// and computes afterwards; touched one knot ahead, HBM works during the products.)
+__device__ __forceinline__ void TouchLine(const void* lanePointer, unsigned ldsJunk) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(lanePointer), "s"(ldsJunk) : "memory");
+}
+
+/// LDS traffic of one wavefront needs no barrier, only program order: the hardware executes the LDS instructions of a wavefront in order, the fence keeps
+/// the compiler from moving accesses across.
+__device__ __forceinline__ void WaveLdsFence() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int NX, int NU>
+struct WaveSizes {
+    static constexpr int n = NX + NU, nk = NX + 1;
+    static constexpr int XE = NX + 1;                     // [x; 1]
+    static constexpr int XT = (XE + 15) / 16, UT = (NU + 15) / 16, NT = XT + UT;
+    static constexpr int KX = (XE + 3) / 4, KU = (NU + 3) / 4;  // k-steps over [x; 1] and over u
+    static constexpr int TW = NU + XE;                    // tableau [R | H_ux h_u]: one lane per column
+    static constexpr int TLD = TW | 1;                    // (odd row stride)
+    static constexpr int KLD = XE | 1;                    // gains in LDS: NU rows of [K | kff]
+    static constexpr int PR = 4 * KX, PLD = XE + (XE & 1);  // cost-to-go P_e in LDS: PR rows (the k-steps of a product read whole groups of four), row stride PLD
+    static constexpr int kPDoubles = PR * PLD + 16 * XT;  // (+ what the last rows' reads of a padded column tile run over: finite numbers that only meet zeros)
+    static constexpr int kTableauDoubles = NU * (TLD > KLD ? TLD : KLD);  // the tableau and, after the factorisation, the gains (same storage)
+    static constexpr int kLdsDoubles = kPDoubles + kTableauDoubles + XE + NU + 8 + 32 /*prefetch junk*/;
+    static_assert(TW <= 64, "the tableau of the factorisation needs one lane per column");
+};
+
+/// CLOCKS: diagnostic instantiation (UNGAR_AMD_RICCATI_WAVE_CLOCKS=1) -- the first wavefront prints the cycles it spent in every section.
+template <int NX, int NU, int WAVES_PER_EU, bool CLOCKS = false>
+__global__ __launch_bounds__(64, WAVES_PER_EU) void RiccatiWaveKernel(const RiccatiArgs a) {
+    using S = WaveSizes<NX, NU>;
+    constexpr int n = S::n, nk = S::nk, XE = S::XE, XT = S::XT, UT = S::UT, NT = S::NT, KX = S::KX, KU = S::KU, TW = S::TW, TLD = S::TLD, KLD = S::KLD;
+    extern __shared__ double lds[];
+    const long long inst = blockIdx.x;
+    if (inst >= a.batch) return;
+    const int lane = static_cast<int>(threadIdx.x), lj = lane & 15, lk = lane >> 4;
+    const int N = a.N;
+    constexpr int PR = S::PR, PLD = S::PLD;
+    double* Pl = lds;                 // cost-to-go P_e, symmetric to the last bit, row-major PR x PLD (rows / columns from XE on are zero)
+    double* T = Pl + S::kPDoubles;    // NU x TLD: tableau of the factorisation
+    double* Kb = T;                   // NU x KLD: gains (the tableau is in registers by then)
+    double* dxv = T + S::kTableauDoubles;  // XE: [dx; 1]
+    double* duv = dxv + XE;           // NU
+    double* gains = a.gains + inst * static_cast<long long>(N) * NU * nk;
+    const double reg = a.regularization;
+    const unsigned junk = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(
+        static_cast<int>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) double*)(duv + NU + 8)))));  // 256 bytes behind the vectors
+    // cache lines of the operands of knot k: [A|B] whole (contiguous), of the stage Hessian what lies on or right of the diagonal, row by row in 128-byte steps
+    auto touchKnot = [&](int k) {
+        const char* jacK = reinterpret_cast<const char*>(&a.jac.at(inst, k, 0));
+        constexpr int abBytes = NX * n * 8;
+#pragma unroll
+        for (int i = 0; i < (abBytes + 127) / 128 + 1; i += 64) {
+            const int off = (i + lane) * 128;
+            TouchLine(jacK + (off < abBytes ? off : abBytes - 8), junk);
+        }
+        const char* hessK = reinterpret_cast<const char*>(&a.hess.at(inst, k, 0));
+        constexpr int rowBytes = n * 8, segments = (rowBytes + 127) / 128;
+#pragma unroll
+        for (int i = 0; i < n * segments; i += 64) {
+            const int idx = i + lane, row = idx < n * segments ? idx / segments : n - 1, seg = idx - (idx / segments) * segments;
+            const int within = seg * 128 > row * 8 ? seg * 128 : row * 8;  // (a segment left of the diagonal touches the diagonal's line again)
+            TouchLine(hessK + row * rowBytes + (within < rowBytes ? within : rowBytes - 8), junk);
+        }
+    };
+
+    // lane parts of the byte offsets (the same for every tile): entry (lk, lj) and entry (lj, lk) of a row-major n x n / nx x n block
+    const int vb = (lk * n + lj) * 8, vt = (lj * n + lk) * 8;
+    constexpr int oneTile = NX / 16, oneCol = NX % 16;  // where the homogeneous 1 sits among the x columns
+    // ---- [A b B; 0 1 0] of knot k in the B (= A) operand layout: ab[ks][tj] = entry (4 ks + lk, column lj of tile tj)
+    double ab[KX][NT];
+    auto loadAB = [&](int k) {
+        const __amdgpu_buffer_rsrc_t rsJ = BufferOver(&a.jac.at(inst, k, 0), NX * n), rsB = BufferOver(&a.b.at(inst, k, 0), NX);
+#pragma unroll
+        for (int ks = 0; ks < KX; ++ks) {
+            const bool rowOk = 4 * ks + 3 < NX || 4 * ks + lk < NX;
+#pragma unroll
+            for (int tj = 0; tj < NT; ++tj) {
+                const int col0 = tj < XT ? 16 * tj : 16 * (tj - XT), limit = tj < XT ? NX : NU;
+                const bool colOk = col0 + 15 < limit || col0 + lj < limit;
+                double v = 0.0;
+                if (4 * ks < NX && col0 < limit)  // (compile time: something to load)
+                    v = BufferLoad(rsJ, rowOk && colOk ? vb : kOutOfRange, (4 * ks * n + (tj < XT ? col0 : NX + col0)) * 8);
+                if (tj == oneTile) {  // the column of b and, in row NX, the 1
+                    if (4 * ks < NX) v += BufferLoad(rsB, rowOk && lj == oneCol ? lk * 8 : kOutOfRange, 4 * ks * 8);
+                    if (4 * ks <= NX && NX < 4 * ks + 4) v += lk == NX % 4 && lj == oneCol ? 1.0 : 0.0;
+                }
+                ab[ks][tj] = v;
+            }
+        }
+    };
+
+    // ---- cost-to-go in homogeneous form P_e = [P p; p^T *] in LDS.  It is the A operand of P_e [A|B]_e READ AS ITS OWN TRANSPOSE (A[i][k] = P_e[k][i]: rows
+    // of the array along the lanes), so it must be symmetric to the last bit: what the recursion does to an antisymmetric part is P_a' = -A^T P_a A --
+    // undamped by the feedback, it grows like |A|^(2 k) from a rounding error (measured: 1e-3 after 30 knots).  Every entry on or above the diagonal is
+    // therefore stored twice, at (i, j) and at (j, i).
+    for (int idx = lane; idx < S::kPDoubles; idx += 64) Pl[idx] = 0.0;
+    WaveLdsFence();
+    {
+        const int ldN = a.hessNld > 0 ? a.hessNld : NX;
+        for (int idx = lane; idx < NX * NX; idx += 64) {
+            const int i = idx / NX, j = idx - i * NX;
+            if (i <= j) {
+                const double v = (a.hessN.base ? a.hessN.at(inst, 0, i * ldN + j) : 0.0) + (i == j ? reg : 0.0);
+                Pl[i * PLD + j] = v;
+                Pl[j * PLD + i] = v;
+            }
+        }
+        if (a.gradN.base && lane < NX) {
+            const double v = a.gradN.at(inst, 0, lane);
+            Pl[lane * PLD + NX] = v;
+            Pl[NX * PLD + lane] = v;
+        }
+    }
+    WaveLdsFence();
+
+    // ---- accumulators of H_e: xx on and above the tile diagonal, ux whole, uu on and below the tile diagonal
+    f64x4 Hxx[XT][XT];  // [ti][tj], ti <= tj used
+    f64x4 Hux[UT][XT];
+    f64x4 Huu[UT][UT];  // [tu][tv], tv <= tu used
+    // lane offsets of a DIAGONAL tile of a symmetric block of which the upper triangle is stored: entry (4 r + lk, lj) or its mirror image
+    int vd[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) vd[r] = 8 * (4 * r + lk <= lj ? (4 * r + lk) * n + lj : lj * n + 4 * r + lk);
+    auto loadW = [&](int k) {  // H_e <- W_e of knot k (stage Hessian, stage gradient in the row / column of the homogeneous 1, regularisation on the diagonal)
+        const __amdgpu_buffer_rsrc_t rsW = BufferOver(&a.hess.at(inst, k, 0), n * n), rsG = BufferOver(&a.grad.at(inst, k, 0), n);
+#pragma unroll
+        for (int ti = 0; ti < XT; ++ti)
+#pragma unroll
+            for (int tj = ti; tj < XT; ++tj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rowL = 4 * r + lk;
+                    double v;
+                    if (ti < tj) {  // rows all inside x (16 (XT - 1) <= NX), columns up to NX - 1
+                        const bool colOk = 16 * tj + 15 < NX || 16 * tj + lj < NX;
+                        v = BufferLoad(rsW, colOk ? vb : kOutOfRange, ((16 * ti + 4 * r) * n + 16 * tj) * 8);
+                        if (tj == oneTile) v += BufferLoad(rsG, lj == oneCol ? lk * 8 : kOutOfRange, (16 * ti + 4 * r) * 8);  // W_e[x][1] = w[x]
+                    } else {
+                        const int hi = rowL > lj ? rowL : lj, lo = rowL > lj ? lj : rowL;
+                        const bool ok = 16 * ti + 15 < NX || 16 * ti + hi < NX;
+                        v = BufferLoad(rsW, ok ? vd[r] : kOutOfRange, 16 * ti * (n + 1) * 8) + (ok && rowL == lj ? reg : 0.0);
+                        if (ti == oneTile) v += BufferLoad(rsG, hi == oneCol && lo < oneCol ? lo * 8 : kOutOfRange, 16 * ti * 8);  // row and column of the 1
+                    }
+                    Hxx[ti][tj][r] = v;
+                }
+#pragma unroll
+        for (int tu = 0; tu < UT; ++tu)
+#pragma unroll
+            for (int tx = 0; tx < XT; ++tx)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {  // H_ux[u][x] = W[x][NX + u]
+                    const bool uOk = 16 * tu + 4 * r + 3 < NU || 16 * tu + 4 * r + lk < NU, colOk = 16 * tx + 15 < NX || 16 * tx + lj < NX;
+                    double v = 0.0;
+                    if (16 * tu + 4 * r < NU) {  // (compile time)
+                        v = BufferLoad(rsW, uOk && colOk ? vt : kOutOfRange, (16 * tx * n + NX + 16 * tu + 4 * r) * 8);
+                        if (tx == oneTile) v += BufferLoad(rsG, uOk && lj == oneCol ? lk * 8 : kOutOfRange, (NX + 16 * tu + 4 * r) * 8);
+                    }
+                    Hux[tu][tx][r] = v;
+                }
+#pragma unroll
+        for (int tu = 0; tu < UT; ++tu)
+#pragma unroll
+            for (int tv = 0; tv <= tu; ++tv)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rowL = 4 * r + lk;
+                    double v = 0.0;
+                    if (16 * tu + 4 * r < NU) {  // (compile time; padded input rows / columns stay zero and are never read)
+                        if (tv < tu) {           // R[u][v] = W[NX + v][NX + u], every column v inside u's range
+                            const bool uOk = 16 * tu + 4 * r + 3 < NU || 16 * tu + rowL < NU;
+                            v = BufferLoad(rsW, uOk ? vt : kOutOfRange, ((NX + 16 * tv) * n + NX + 16 * tu + 4 * r) * 8);
+                        } else {
+                            const int hi = rowL > lj ? rowL : lj;
+                            const bool ok = 16 * tu + 15 < NU || 16 * tu + hi < NU;
+                            v = BufferLoad(rsW, ok ? vd[r] : kOutOfRange, (NX + 16 * tu) * (n + 1) * 8) + (ok && rowL == lj ? reg : 0.0);
+                        }
+                    }
+                    Huu[tu][tv][r] = v;
+                }
+    };
+
+    unsigned long long clocks[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last = 0;
+    auto mark = [&](int id) {
+        if constexpr (CLOCKS) {
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            if (id >= 0) clocks[id] += now - last;
+            last = now;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    int failed = 0;
+    loadAB(N - 1);
+    loadW(N - 1);
+    mark(-1);
+    for (int k = N - 1; k >= 0; --k) {
+        // ---- H_e += [A|B]_e^T (P_e [A|B]_e), one column tile of P_e [A|B]_e at a time (its XT accumulators are the B operand of that column's H tiles)
+#pragma unroll
+        for (int tj = 0; tj < NT; ++tj) {
+            f64x4 pab[XT];
+#pragma unroll
+            for (int ti = 0; ti < XT; ++ti) pab[ti] = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < KX; ++ks)
+#pragma unroll
+                for (int ti = 0; ti < XT; ++ti) pab[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(Pl[(4 * ks + lk) * PLD + 16 * ti + lj], ab[ks][tj], pab[ti], 0, 0, 0);
+            if (tj < XT) {
+#pragma unroll
+                for (int ks = 0; ks < KX; ++ks) {
+#pragma unroll
+                    for (int ti = 0; ti <= tj; ++ti) Hxx[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(ab[ks][ti], pab[ks >> 2][ks & 3], Hxx[ti][tj], 0, 0, 0);
+#pragma unroll
+                    for (int tu = 0; tu < UT; ++tu) Hux[tu][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(ab[ks][XT + tu], pab[ks >> 2][ks & 3], Hux[tu][tj], 0, 0, 0);
+                }
+            } else {
+                const int tv = tj - XT;
+#pragma unroll
+                for (int ks = 0; ks < KX; ++ks)
+#pragma unroll
+                    for (int tu = tv; tu < UT; ++tu) Huu[tu][tv] = __builtin_amdgcn_mfma_f64_16x16x4f64(ab[ks][XT + tu], pab[ks >> 2][ks & 3], Huu[tu][tv], 0, 0, 0);
+            }
+        }
+        mark(0);  // products
+        if (k > 0) touchKnot(k - 1);  // (here the registers of [A|B] are free) in flight during the factorisation; requested for real at the end of the knot
+
+        // ---- tableau [R | H_ux h_u] -> LDS (row-major), both triangles of R from the tiles on and below the diagonal
+#pragma unroll
+        for (int tu = 0; tu < UT; ++tu) {
+#pragma unroll
+            for (int tv = 0; tv <= tu; ++tv)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int u = 16 * tu + 4 * r + lk, v = 16 * tv + lj;
+                    if (u < NU && v < NU) {
+                        if (tv < tu || v <= u) T[u * TLD + v] = Huu[tu][tv][r];
+                        if (tv < tu || v < u) T[v * TLD + u] = Huu[tu][tv][r];
+                    }
+                }
+#pragma unroll
+            for (int tx = 0; tx < XT; ++tx)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int u = 16 * tu + 4 * r + lk, c = 16 * tx + lj;
+                    if (u < NU && c < XE) T[u * TLD + NU + c] = Hux[tu][tx][r];
+                }
+        }
+        WaveLdsFence();
+        mark(1);  // tableau to LDS (and the requests of the next [A|B])
+        // ---- symmetric elimination, lane = column: t[i] = row i of [R | -H_ux -h_u]
+        double t[NU];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            const double v = T[i * TLD + (lane < TW ? lane : TW - 1)];
+            t[i] = lane < NU ? v : (lane < TW ? -v : 0.0);
+        }
+        bool bad = false;
+        auto reciprocalOfPivot = [&](double d) {  // a pivot that is not positive is replaced by 1 and reported (ocp_riccati.hpp)
+            const bool neg = !(d > 0.0);
+            bad = bad || neg;
+            return 1.0 / (neg ? 1.0 : d);
+        };
+        double rd = reciprocalOfPivot(ReadLaneF64(t[0], 0));
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+            const double prow = t[j] * rd;  // row j of L^T (unit diagonal) next to its forward-substituted, scaled right-hand sides
+            // the next pivot is final after the first row update: its reciprocal (a long dependent chain) is started at once, beside the other rows' updates
+            if (j + 1 < NU) {
+                t[j + 1] = __builtin_fma(-ReadLaneF64(t[j + 1], j), prow, t[j + 1]);
+                rd = reciprocalOfPivot(ReadLaneF64(t[j + 1], j + 1));
+            }
+#pragma unroll
+            for (int i = j + 2; i < NU; ++i) t[i] = __builtin_fma(-ReadLaneF64(t[i], j), prow, t[i]);
+            t[j] = prow;
+        }
+        if (bad) failed = failed ? failed : k + 1;
+        mark(2);  // forward elimination
+        // back substitution L^T X = Y, column by column: once x_c is final, x_j -= L^T[j][c] x_c for the rows above.  Only the right-hand-side lanes take
+        // part: row c is zeroed elsewhere first (its entries of L^T are not read again), so that the updates need no select and leave L^T intact.
+#pragma unroll
+        for (int c = NU - 1; c > 0; --c) {
+            const double xc = lane >= NU ? t[c] : 0.0;
+#pragma unroll
+            for (int j = 0; j < c; ++j) t[j] = __builtin_fma(-ReadLaneF64(t[j], c), xc, t[j]);
+        }
+        mark(3);  // back substitution
+        // gains: global (forward pass) and LDS (B operand of the cost-to-go update)
+        {
+            double* gk = gains + static_cast<long long>(k) * NU * nk;
+            const int c = lane - NU;
+#pragma unroll
+            for (int i = 0; i < NU; ++i)
+                if (c >= 0 && c < XE) {
+                    gk[i * nk + c] = t[i];
+                    Kb[i * KLD + c] = t[i];
+                }
+        }
+        WaveLdsFence();
+        double kreg[KU][XT];
+#pragma unroll
+        for (int ks = 0; ks < KU; ++ks)
+#pragma unroll
+            for (int tj = 0; tj < XT; ++tj) {
+                const int m = 4 * ks + lk, c = 16 * tj + lj;
+                const double v = Kb[(m < NU ? m : NU - 1) * KLD + (c < XE ? c : XE - 1)];  // (clamped address, then a select between the value and a constant)
+                kreg[ks][tj] = m < NU && c < XE ? v : 0.0;
+            }
+        mark(4);  // gains out and back
+        // ---- P_e' = H_e,xx + (T + T^T) / 2,  T = H_e,xu [K | kff]: both orientations on the matrix cores; what lies on or above the diagonal goes to LDS
+        // twice (see above; the entries below the diagonal of a diagonal tile are computed and dropped)
+#pragma unroll
+        for (int ti = 0; ti < XT; ++ti)
+#pragma unroll
+            for (int tj = ti; tj < XT; ++tj) {
+                f64x4 t1 = f64x4{0.0, 0.0, 0.0, 0.0}, t2 = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int ks = 0; ks < KU; ++ks) {
+                    t1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Hux[ks >> 2][ti][ks & 3], kreg[ks][tj], t1, 0, 0, 0);
+                    t2 = __builtin_amdgcn_mfma_f64_16x16x4f64(kreg[ks][ti], Hux[ks >> 2][tj][ks & 3], t2, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * ti + 4 * r + lk, col = 16 * tj + lj;
+                    const double v = Hxx[ti][tj][r] + 0.5 * (t1[r] + t2[r]);
+                    if (row < XE && col < XE && (ti < tj || row <= col)) {
+                        Pl[row * PLD + col] = v;
+                        Pl[col * PLD + row] = v;
+                    }
+                }
+            }
+        WaveLdsFence();
+        mark(5);  // cost-to-go update
+        if (k > 0) {  // (the registers of [A|B] and H_e are free from here on)
+            loadAB(k - 1);
+            loadW(k - 1);
+        }
+        mark(6);  // requests of the next knot's operands
+    }
+
+    // ---- forward pass: du_k = [K | kff] [dx_k; 1],  dx_(k+1) = [A b B] [dx_k; 1; du_k]; a row's inner product is shared by the four lanes of a quad
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the gains written above are read back below (same wavefront: program order + the fence for the compiler)
+    if (lane < XE) {
+        const double v = lane < NX ? a.dx0.at(inst, 0, lane) : 1.0;
+        dxv[lane] = v;
+        if (lane < NX) a.dX.at(inst, 0, lane) = v;
+    }
+    WaveLdsFence();
+    const int part = lane & 3, q = lane >> 2;  // row q of a round of 16 rows, terms part, part + 4, ...
+    constexpr int XQ = (XE + 3) / 4, UQ = (NU + 3) / 4, RU = (NU + 15) / 16, RX = (NX + 15) / 16;
+    const int vg = (q * nk + part) * 8, vj = (q * n + part) * 8;  // lane parts: entry (q, part) of a row-major NU x nk / NX x n block
+    for (int k = 0; k < N; ++k) {
+        const __amdgpu_buffer_rsrc_t rsK = BufferOver(gains + static_cast<long long>(k) * NU * nk, NU * nk), rsJ = BufferOver(&a.jac.at(inst, k, 0), NX * n),
+                                     rsB = BufferOver(&a.b.at(inst, k, 0), NX);
+        if (k + 1 < N) {  // the next knot's [A|B] and gains
+            const char* jacN = reinterpret_cast<const char*>(&a.jac.at(inst, k + 1, 0));
+            const char* gainsN = reinterpret_cast<const char*>(gains + static_cast<long long>(k + 1) * NU * nk);
+            constexpr int abBytes = NX * n * 8, gBytes = NU * nk * 8;
+#pragma unroll
+            for (int i = 0; i < (abBytes + 127) / 128 + 1; i += 64) TouchLine(jacN + ((i + lane) * 128 < abBytes ? (i + lane) * 128 : abBytes - 8), junk);
+#pragma unroll
+            for (int i = 0; i < (gBytes + 127) / 128 + 1; i += 64) TouchLine(gainsN + ((i + lane) * 128 < gBytes ? (i + lane) * 128 : gBytes - 8), junk);
+        }
+        // every operand of the knot is requested up front (unconditional loads: they travel together)
+        double gv[RU][XQ], av[RX][XQ], bv[RX][UQ], b0[RX];
+#pragma unroll
+        for (int rr = 0; rr < RU; ++rr)
+#pragma unroll
+            for (int m = 0; m < XQ; ++m) {
+                const bool ok = (16 * rr + 15 < NU || 16 * rr + q < NU) && (4 * m + 3 < XE || 4 * m + part < XE);
+                gv[rr][m] = BufferLoad(rsK, ok ? vg : kOutOfRange, (16 * rr * nk + 4 * m) * 8);
+            }
+#pragma unroll
+        for (int rr = 0; rr < RX; ++rr) {
+            const bool rowOk = 16 * rr + 15 < NX || 16 * rr + q < NX;
+#pragma unroll
+            for (int m = 0; m < XQ; ++m) {
+                const bool ok = rowOk && (4 * m + 3 < NX || 4 * m + part < NX);
+                av[rr][m] = 4 * m < NX ? BufferLoad(rsJ, ok ? vj : kOutOfRange, (16 * rr * n + 4 * m) * 8) : 0.0;
+            }
+#pragma unroll
+            for (int m = 0; m < UQ; ++m) {
+                const bool ok = rowOk && (4 * m + 3 < NU || 4 * m + part < NU);
+                bv[rr][m] = BufferLoad(rsJ, ok ? vj : kOutOfRange, (16 * rr * n + NX + 4 * m) * 8);
+            }
+            b0[rr] = BufferLoad(rsB, rowOk && part == 0 ? q * 8 : kOutOfRange, 16 * rr * 8);
+        }
+        double xs[XQ];
+#pragma unroll
+        for (int m = 0; m < XQ; ++m) xs[m] = dxv[part + 4 * m < XE ? part + 4 * m : XE - 1];  // (a term beyond XE has a zero coefficient)
+#pragma unroll
+        for (int rr = 0; rr < RU; ++rr) {
+            const int i = 16 * rr + q;
+            double s = 0.0;
+#pragma unroll
+            for (int m = 0; m < XQ; ++m) s = __builtin_fma(gv[rr][m], xs[m], s);
+            s += QuadPermuteF64<0xB1>(s);
+            s += QuadPermuteF64<0x4E>(s);
+            if (i < NU && part == 0) {
+                duv[i] = s;
+                a.dU.at(inst, k, i) = s;
+            }
+        }
+        WaveLdsFence();
+        double us[UQ];
+#pragma unroll
+        for (int m = 0; m < UQ; ++m) us[m] = duv[part + 4 * m < NU ? part + 4 * m : NU - 1];
+        double next[RX];
+#pragma unroll
+        for (int rr = 0; rr < RX; ++rr) {
+            double s = b0[rr];
+#pragma unroll
+            for (int m = 0; m < XQ; ++m) s = __builtin_fma(av[rr][m], xs[m], s);
+#pragma unroll
+            for (int m = 0; m < UQ; ++m) s = __builtin_fma(bv[rr][m], us[m], s);
+            s += QuadPermuteF64<0xB1>(s);
+            s += QuadPermuteF64<0x4E>(s);
+            next[rr] = s;
+        }
+        WaveLdsFence();  // every lane has read dx_k
+#pragma unroll
+        for (int rr = 0; rr < RX; ++rr) {
+            const int i = 16 * rr + q;
+            if (i < NX && part == 0) {
+                dxv[i] = next[rr];
+                a.dX.at(inst, k + 1, i) = next[rr];
+            }
+        }
+        WaveLdsFence();
+    }
+    mark(7);  // forward pass
+    if (a.status && lane == 0) a.status[inst] = failed;
+    if constexpr (CLOCKS)
+        if (inst == 0 && lane == 0)
+            printf("[riccati wave clocks %d+%d, cycles per knot] products %llu, tableau %llu, elimination %llu, back substitution %llu, gains %llu, cost-to-go %llu, W requests %llu; forward pass %llu per knot\n",
+                   NX, NU, clocks[0] / N, clocks[1] / N, clocks[2] / N, clocks[3] / N, clocks[4] / N, clocks[5] / N, clocks[6] / N, clocks[7] / N);
+}
+
+template <int NX, int NU, int WAVES_PER_EU>
+int LaunchWave(const RiccatiArgs* a, hipStream_t stream) {
+    constexpr std::size_t lds = static_cast<std::size_t>(WaveSizes<NX, NU>::kLdsDoubles) * sizeof(double);
+    static const bool clocks = getenv("UNGAR_AMD_RICCATI_WAVE_CLOCKS") != nullptr;
+    if (clocks) hipLaunchKernelGGL((RiccatiWaveKernel<NX, NU, WAVES_PER_EU, true>), dim3(static_cast<unsigned>(a->batch)), dim3(64), lds, stream, *a);
+    else hipLaunchKernelGGL((RiccatiWaveKernel<NX, NU, WAVES_PER_EU>), dim3(static_cast<unsigned>(a->batch)), dim3(64), lds, stream, *a);
+    return static_cast<int>(hipGetLastError());
+}
+
+}  // namespace
+}  // namespace ungar_amd::kernels
+
+using namespace ungar_amd::kernels;
+
+/// 0 / a HIP error: launched;  -1: no register-resident instantiation for these sizes (the caller falls back to the LDS-resident kernels).
+extern "C" int ungar_amd_launch_riccati_wave(const RiccatiArgs* a, void* stream) {
+    if (a->ne != 0) return -1;
+    if (a->jac.es != 1 || a->b.es != 1 || a->hess.es != 1 || a->grad.es != 1) return -1;  // a knot's operands as contiguous row-major blocks (what the assembly kernels write)
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (a->nx == 37 && a->nu == 12) return LaunchWave<37, 12, 2>(a, s);
+    if (a->nx == 25 && a->nu == 24) return LaunchWave<25, 24, 2>(a, s);
+    if (a->nx == 13 && a->nu == 24) return LaunchWave<13, 24, 2>(a, s);
+    return -1;
+}
