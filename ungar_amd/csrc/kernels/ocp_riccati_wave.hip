@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <type_traits>
 
 #include "ocp_riccati.hpp"
 
@@ -50,6 +51,10 @@ constexpr int kOutOfRange = static_cast<int>(0x80000000u);  // a lane offset no 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t BufferOver(const double* base, int doubles) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(base), 0, doubles * 8, 0x00020000);
 }
+using v4i = __attribute__((__vector_size__(4 * sizeof(int)))) int;
+__device__ __forceinline__ v4i BufferLoad16(__amdgpu_buffer_rsrc_t r, int laneOffsetBytes, int scalarOffsetBytes) {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, laneOffsetBytes, scalarOffsetBytes, 0);
+}
 __device__ __forceinline__ double BufferLoad(__amdgpu_buffer_rsrc_t r, int laneOffsetBytes, int scalarOffsetBytes) {
     return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, laneOffsetBytes, scalarOffsetBytes, 0));
 }
@@ -80,10 +85,10 @@ struct WaveSizes {
     static constexpr int TW = NU + XE;                    // tableau [R | H_ux h_u]: one lane per column
     static constexpr int TLD = TW | 1;                    // (odd row stride)
     static constexpr int KLD = XE | 1;                    // gains in LDS: NU rows of [K | kff]
-    static constexpr int PR = 4 * KX, PLD = XE + (XE & 1);  // cost-to-go P_e in LDS: PR rows (the k-steps of a product read whole groups of four), row stride PLD
-    static constexpr int kPDoubles = PR * PLD + 16 * XT;  // (+ what the last rows' reads of a padded column tile run over: finite numbers that only meet zeros)
-    static constexpr int kTableauDoubles = NU * (TLD > KLD ? TLD : KLD);  // the tableau and, after the factorisation, the gains (same storage)
-    static constexpr int kLdsDoubles = kPDoubles + kTableauDoubles + XE + NU + 8 + 32 /*prefetch junk*/;
+    static constexpr int kAbDoubles = (NX * n + NX + 1) / 2 * 2;  // [A|B] of the knot as it lies in memory, then b (LDS-DMA: 16 bytes per lane)
+    static constexpr int kWDoubles = (n * n + n + 1) / 2 * 2;     // stage Hessian of the knot as it lies in memory (upper triangle meaningful), then the stage gradient
+    static constexpr int kTableauDoubles = NU * (TLD > KLD ? TLD : KLD) > 16 * 17 ? NU * (TLD > KLD ? TLD : KLD) : 16 * 17;  // tableau, then gains, then tile transposes
+    static constexpr int kLdsDoubles = kAbDoubles + kWDoubles + kTableauDoubles + XE + NU + 8;
     static_assert(TW <= 64, "the tableau of the factorisation needs one lane per column");
 };
 
@@ -97,95 +102,124 @@ __global__ __launch_bounds__(64, WAVES_PER_EU) void RiccatiWaveKernel(const Ricc
     if (inst >= a.batch) return;
     const int lane = static_cast<int>(threadIdx.x), lj = lane & 15, lk = lane >> 4;
     const int N = a.N;
-    constexpr int PR = S::PR, PLD = S::PLD;
-    double* Pl = lds;                 // cost-to-go P_e, symmetric to the last bit, row-major PR x PLD (rows / columns from XE on are zero)
-    double* T = Pl + S::kPDoubles;    // NU x TLD: tableau of the factorisation
-    double* Kb = T;                   // NU x KLD: gains (the tableau is in registers by then)
+    double* ABl = lds;                 // NX x n: [A|B] of the knot, row-major as in memory (16-byte aligned: the LDS-DMA writes 16 bytes per lane)
+    double* bl = ABl + NX * n;         // NX: b of the knot
+    double* Wl = lds + S::kAbDoubles;  // n x n: stage Hessian of the knot (upper triangle), row-major as in memory
+    double* gl = Wl + n * n;           // n: stage gradient
+    double* T = Wl + S::kWDoubles;     // NU x TLD: tableau of the factorisation
+    double* Kb = T;                    // NU x KLD: gains (the tableau is in registers by then)
+    double* tr = T;                    // 16 x 17: tile transposes (the gains are in registers by then)
     double* dxv = T + S::kTableauDoubles;  // XE: [dx; 1]
-    double* duv = dxv + XE;           // NU
+    double* duv = dxv + XE;            // NU
     double* gains = a.gains + inst * static_cast<long long>(N) * NU * nk;
     const double reg = a.regularization;
-    const unsigned junk = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(
-        static_cast<int>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) double*)(duv + NU + 8)))));  // 256 bytes behind the vectors
-    // cache lines of the operands of knot k: [A|B] whole (contiguous), of the stage Hessian what lies on or right of the diagonal, row by row in 128-byte steps
-    auto touchKnot = [&](int k) {
-        const char* jacK = reinterpret_cast<const char*>(&a.jac.at(inst, k, 0));
-        constexpr int abBytes = NX * n * 8;
-#pragma unroll
-        for (int i = 0; i < (abBytes + 127) / 128 + 1; i += 64) {
-            const int off = (i + lane) * 128;
-            TouchLine(jacK + (off < abBytes ? off : abBytes - 8), junk);
-        }
-        const char* hessK = reinterpret_cast<const char*>(&a.hess.at(inst, k, 0));
-        constexpr int rowBytes = n * 8, segments = (rowBytes + 127) / 128;
-#pragma unroll
-        for (int i = 0; i < n * segments; i += 64) {
-            const int idx = i + lane, row = idx < n * segments ? idx / segments : n - 1, seg = idx - (idx / segments) * segments;
-            const int within = seg * 128 > row * 8 ? seg * 128 : row * 8;  // (a segment left of the diagonal touches the diagonal's line again)
-            TouchLine(hessK + row * rowBytes + (within < rowBytes ? within : rowBytes - 8), junk);
-        }
-    };
-
-    // lane parts of the byte offsets (the same for every tile): entry (lk, lj) and entry (lj, lk) of a row-major n x n / nx x n block
-    const int vb = (lk * n + lj) * 8, vt = (lj * n + lk) * 8;
     constexpr int oneTile = NX / 16, oneCol = NX % 16;  // where the homogeneous 1 sits among the x columns
-    // ---- [A b B; 0 1 0] of knot k in the B (= A) operand layout: ab[ks][tj] = entry (4 ks + lk, column lj of tile tj)
-    double ab[KX][NT];
-    auto loadAB = [&](int k) {
-        const __amdgpu_buffer_rsrc_t rsJ = BufferOver(&a.jac.at(inst, k, 0), NX * n), rsB = BufferOver(&a.b.at(inst, k, 0), NX);
+
+    // ---- operands of a knot: global -> registers -> LDS, 16 bytes per lane and instruction, one knot ahead.  They are consumed (copied into the operand /
+    // accumulator registers) at the top of their knot; the NEXT knot's are then fetched in NT shares, one per column tile of the products: a share is
+    // requested at the top of its tile and written to LDS at the top of the following one, its round trip to memory in the shadow of the tile's matrix
+    // instructions.  (All wavefronts reach the same point of the recursion together and ask for 34 KB each: requested where they are needed, the device waits
+    // for HBM -- 17 us per knot of the 37 + 12 problem -- and computes afterwards.  The LDS-DMA path needs no staging registers, but its instructions take
+    // 200+ cycles each to issue here, 37 of them per knot: measured, 8 k cycles per knot even between matrix instructions.)
+    constexpr int abBytes = NX * n * 8, wBytes = n * n * 8, abPieces = (abBytes + 1023) / 1024, wPieces = (wBytes + 1023) / 1024, pieces = abPieces + wPieces;
+    // (measured and dropped: all shares requested during the first two column tiles and stored after the last one -- the staging registers of a whole knot,
+    // 136 for 37 + 12, spill: 1.48 -> 2.4 ms)
+    constexpr int kRequestTiles = NT, perTile = (pieces + kRequestTiles - 1) / kRequestTiles;
+    v4i stage[perTile];  // (one share: a tile stores the previous one before it requests its own)
+    double stageB = 0.0, stageG = 0.0;
+    auto requestShare = [&](int k, int tile) {
+        const __amdgpu_buffer_rsrc_t rsJ = BufferOver(&a.jac.at(inst, k, 0), NX * n), rsW = BufferOver(&a.hess.at(inst, k, 0), n * n);
 #pragma unroll
-        for (int ks = 0; ks < KX; ++ks) {
-            const bool rowOk = 4 * ks + 3 < NX || 4 * ks + lk < NX;
-#pragma unroll
-            for (int tj = 0; tj < NT; ++tj) {
-                const int col0 = tj < XT ? 16 * tj : 16 * (tj - XT), limit = tj < XT ? NX : NU;
-                const bool colOk = col0 + 15 < limit || col0 + lj < limit;
-                double v = 0.0;
-                if (4 * ks < NX && col0 < limit)  // (compile time: something to load)
-                    v = BufferLoad(rsJ, rowOk && colOk ? vb : kOutOfRange, (4 * ks * n + (tj < XT ? col0 : NX + col0)) * 8);
-                if (tj == oneTile) {  // the column of b and, in row NX, the 1
-                    if (4 * ks < NX) v += BufferLoad(rsB, rowOk && lj == oneCol ? lk * 8 : kOutOfRange, 4 * ks * 8);
-                    if (4 * ks <= NX && NX < 4 * ks + 4) v += lk == NX % 4 && lj == oneCol ? 1.0 : 0.0;
-                }
-                ab[ks][tj] = v;
-            }
+        for (int i = 0; i < perTile; ++i) {
+            const int p = i * kRequestTiles + tile;
+            if (p < abPieces) stage[i] = BufferLoad16(rsJ, lane * 16, p * 1024);  // (beyond the block: zeros, not stored)
+            else if (p < pieces) stage[i] = BufferLoad16(rsW, lane * 16, (p - abPieces) * 1024);
+        }
+        if (tile == 0) {
+            stageB = BufferLoad(BufferOver(&a.b.at(inst, k, 0), NX), lane * 8, 0);
+            stageG = BufferLoad(BufferOver(&a.grad.at(inst, k, 0), n), lane * 8, 0);
         }
     };
+    auto storeShare = [&](int tile) {
+#pragma unroll
+        for (int i = 0; i < perTile; ++i) {
+            const int p = i * kRequestTiles + tile;
+            if (p >= pieces) continue;
+            const bool first = p < abPieces;
+            const int off = (first ? p : p - abPieces) * 1024 + lane * 16, bytes = first ? abBytes : wBytes;
+            double* dst = (first ? ABl : Wl) + off / 8;
+            if (off + 16 <= bytes) *reinterpret_cast<v4i*>(dst) = stage[i];
+            else if (off + 8 <= bytes) *dst = __hiloint2double(stage[i][1], stage[i][0]);  // an odd number of doubles: the last one
+        }
+        if (tile == 0) {
+            if (lane < NX) bl[lane] = stageB;
+            if (lane < n) gl[lane] = stageG;
+        }
+    };
+    // entry (4 ks + lk, column lj of tile tj) of [A b B; 0 1 0]: the B operand of P_e [A|B]_e and, the two layouts being the same, the A operand ([A|B]_e^T)
+    // of the second product.  Padded rows / columns are masked in the integer domain (a select between a loaded value and a constant would become a branch).
+    auto masked = [](double v, bool keepIt) { return __longlong_as_double(__double_as_longlong(v) & (keepIt ? -1ll : 0ll)); };
+    auto abOperand = [&](int ks, int tj) -> double {
+        const int row = 4 * ks + lk;
+        const bool rowInterior = 4 * ks + 3 < NX;  // (compile time)
+        const int col0 = tj < XT ? 16 * tj : 16 * (tj - XT), limit = tj < XT ? NX : NU, colBase = tj < XT ? col0 : NX + col0;
+        const bool colInterior = col0 + 15 < limit;
+        if (4 * ks > NX) return 0.0;  // (compile time: rows behind the homogeneous 1)
+        const bool rowOk = rowInterior || row < NX, colOk = colInterior || col0 + lj < limit;
+        double v = 0.0;
+        if (4 * ks < NX && col0 < limit) {
+            const double raw = ABl[(rowOk ? row : 0) * n + colBase + (colOk ? lj : 0)];
+            v = rowInterior && colInterior ? raw : masked(raw, rowOk && colOk);
+        }
+        if (tj == oneTile) {
+            if (4 * ks < NX) v += masked(bl[rowOk ? row : 0], rowOk && lj == oneCol);
+            if (4 * ks <= NX && NX < 4 * ks + 4) v += lk == NX % 4 && lj == oneCol ? 1.0 : 0.0;
+        }
+        return v;
+    };
 
-    // ---- cost-to-go in homogeneous form P_e = [P p; p^T *] in LDS.  It is the A operand of P_e [A|B]_e READ AS ITS OWN TRANSPOSE (A[i][k] = P_e[k][i]: rows
-    // of the array along the lanes), so it must be symmetric to the last bit: what the recursion does to an antisymmetric part is P_a' = -A^T P_a A --
-    // undamped by the feedback, it grows like |A|^(2 k) from a rounding error (measured: 1e-3 after 30 knots).  Every entry on or above the diagonal is
-    // therefore stored twice, at (i, j) and at (j, i).
-    for (int idx = lane; idx < S::kPDoubles; idx += 64) Pl[idx] = 0.0;
-    WaveLdsFence();
+    // ---- cost-to-go in homogeneous form P_e = [P p; p^T *], all XT x XT accumulator tiles: P[tr][tc][r] = P_e[16 tr + 4 r + lk][16 tc + lj].  It is the A
+    // operand of P_e [A|B]_e READ AS ITS OWN TRANSPOSE (A[i][k] = P_e[k][i]), so it must be symmetric to the last bit: what the recursion does to an
+    // antisymmetric part is P_a' = -A^T P_a A -- undamped by the feedback, it grows like |A|^(2 k) from a rounding error (measured: 1e-3 after 30 knots).
+    f64x4 P[XT][XT];
     {
         const int ldN = a.hessNld > 0 ? a.hessNld : NX;
-        for (int idx = lane; idx < NX * NX; idx += 64) {
-            const int i = idx / NX, j = idx - i * NX;
-            if (i <= j) {
-                const double v = (a.hessN.base ? a.hessN.at(inst, 0, i * ldN + j) : 0.0) + (i == j ? reg : 0.0);
-                Pl[i * PLD + j] = v;
-                Pl[j * PLD + i] = v;
-            }
-        }
-        if (a.gradN.base && lane < NX) {
-            const double v = a.gradN.at(inst, 0, lane);
-            Pl[lane * PLD + NX] = v;
-            Pl[NX * PLD + lane] = v;
-        }
+#pragma unroll
+        for (int ti = 0; ti < XT; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < XT; ++tj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * ti + 4 * r + lk, col = 16 * tj + lj;
+                    const int lo = row < col ? row : col, hi = row < col ? col : row;
+                    double v = 0.0;
+                    if (hi < NX) {
+                        if (a.hessN.base) v = a.hessN.at(inst, 0, lo * ldN + hi);
+                        if (lo == hi) v += reg;
+                    } else if (hi == NX && lo < NX) {
+                        if (a.gradN.base) v = a.gradN.at(inst, 0, lo);
+                    }
+                    P[ti][tj][r] = v;
+                }
     }
-    WaveLdsFence();
 
     // ---- accumulators of H_e: xx on and above the tile diagonal, ux whole, uu on and below the tile diagonal
     f64x4 Hxx[XT][XT];  // [ti][tj], ti <= tj used
     f64x4 Hux[UT][XT];
     f64x4 Huu[UT][UT];  // [tu][tv], tv <= tu used
-    // lane offsets of a DIAGONAL tile of a symmetric block of which the upper triangle is stored: entry (4 r + lk, lj) or its mirror image
+    // lane parts of the offsets (the same for every tile): entry (lk, lj) and entry (lj, lk) of the row-major n x n block, and the entry of a DIAGONAL
+    // tile of a symmetric block of which the upper triangle is stored: (4 r + lk, lj) or its mirror image
+    const int vb = lk * n + lj, vt = lj * n + lk;
     int vd[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) vd[r] = 8 * (4 * r + lk <= lj ? (4 * r + lk) * n + lj : lj * n + 4 * r + lk);
-    auto loadW = [&](int k) {  // H_e <- W_e of knot k (stage Hessian, stage gradient in the row / column of the homogeneous 1, regularisation on the diagonal)
-        const __amdgpu_buffer_rsrc_t rsW = BufferOver(&a.hess.at(inst, k, 0), n * n), rsG = BufferOver(&a.grad.at(inst, k, 0), n);
+    for (int r = 0; r < 4; ++r) vd[r] = 4 * r + lk <= lj ? (4 * r + lk) * n + lj : lj * n + 4 * r + lk;
+    auto fromLds = [&](const double* block, int index, bool ok) { return masked(block[ok ? index : 0], ok); };
+    double ab[KX][NT];
+    auto takeOperands = [&]() {  // LDS -> registers: [A b B; 0 1 0] in operand layout, H_e <- W_e (stage Hessian, gradient in the row / column of the 1, regularisation)
+#pragma unroll
+        for (int ks = 0; ks < KX; ++ks)
+#pragma unroll
+            for (int tj = 0; tj < NT; ++tj) ab[ks][tj] = abOperand(ks, tj);
 #pragma unroll
         for (int ti = 0; ti < XT; ++ti)
 #pragma unroll
@@ -196,13 +230,15 @@ __global__ __launch_bounds__(64, WAVES_PER_EU) void RiccatiWaveKernel(const Ricc
                     double v;
                     if (ti < tj) {  // rows all inside x (16 (XT - 1) <= NX), columns up to NX - 1
                         const bool colOk = 16 * tj + 15 < NX || 16 * tj + lj < NX;
-                        v = BufferLoad(rsW, colOk ? vb : kOutOfRange, ((16 * ti + 4 * r) * n + 16 * tj) * 8);
-                        if (tj == oneTile) v += BufferLoad(rsG, lj == oneCol ? lk * 8 : kOutOfRange, (16 * ti + 4 * r) * 8);  // W_e[x][1] = w[x]
+                        const double raw = Wl[(16 * ti + 4 * r) * n + 16 * tj + (colOk ? vb : lk * n)];
+                        v = 16 * tj + 15 < NX ? raw : masked(raw, colOk);
+                        if (tj == oneTile) v += fromLds(gl, 16 * ti + rowL, lj == oneCol);  // W_e[x][1] = w[x]
                     } else {
                         const int hi = rowL > lj ? rowL : lj, lo = rowL > lj ? lj : rowL;
                         const bool ok = 16 * ti + 15 < NX || 16 * ti + hi < NX;
-                        v = BufferLoad(rsW, ok ? vd[r] : kOutOfRange, 16 * ti * (n + 1) * 8) + (ok && rowL == lj ? reg : 0.0);
-                        if (ti == oneTile) v += BufferLoad(rsG, hi == oneCol && lo < oneCol ? lo * 8 : kOutOfRange, 16 * ti * 8);  // row and column of the 1
+                        const double raw = Wl[16 * ti * (n + 1) + (ok ? vd[r] : 0)];
+                        v = (16 * ti + 15 < NX ? raw : masked(raw, ok)) + (ok && rowL == lj ? reg : 0.0);
+                        if (ti == oneTile) v += fromLds(gl, 16 * ti + lo, hi == oneCol && lo < oneCol);  // row and column of the 1
                     }
                     Hxx[ti][tj][r] = v;
                 }
@@ -215,8 +251,8 @@ __global__ __launch_bounds__(64, WAVES_PER_EU) void RiccatiWaveKernel(const Ricc
                     const bool uOk = 16 * tu + 4 * r + 3 < NU || 16 * tu + 4 * r + lk < NU, colOk = 16 * tx + 15 < NX || 16 * tx + lj < NX;
                     double v = 0.0;
                     if (16 * tu + 4 * r < NU) {  // (compile time)
-                        v = BufferLoad(rsW, uOk && colOk ? vt : kOutOfRange, (16 * tx * n + NX + 16 * tu + 4 * r) * 8);
-                        if (tx == oneTile) v += BufferLoad(rsG, uOk && lj == oneCol ? lk * 8 : kOutOfRange, (NX + 16 * tu + 4 * r) * 8);
+                        v = fromLds(Wl + 16 * tx * n + NX + 16 * tu + 4 * r, vt, uOk && colOk);
+                        if (tx == oneTile) v += fromLds(gl + NX + 16 * tu + 4 * r, lk, uOk && lj == oneCol);
                     }
                     Hux[tu][tx][r] = v;
                 }
@@ -231,11 +267,11 @@ __global__ __launch_bounds__(64, WAVES_PER_EU) void RiccatiWaveKernel(const Ricc
                     if (16 * tu + 4 * r < NU) {  // (compile time; padded input rows / columns stay zero and are never read)
                         if (tv < tu) {           // R[u][v] = W[NX + v][NX + u], every column v inside u's range
                             const bool uOk = 16 * tu + 4 * r + 3 < NU || 16 * tu + rowL < NU;
-                            v = BufferLoad(rsW, uOk ? vt : kOutOfRange, ((NX + 16 * tv) * n + NX + 16 * tu + 4 * r) * 8);
+                            v = fromLds(Wl + (NX + 16 * tv) * n + NX + 16 * tu + 4 * r, vt, uOk);
                         } else {
                             const int hi = rowL > lj ? rowL : lj;
                             const bool ok = 16 * tu + 15 < NU || 16 * tu + hi < NU;
-                            v = BufferLoad(rsW, ok ? vd[r] : kOutOfRange, (NX + 16 * tu) * (n + 1) * 8) + (ok && rowL == lj ? reg : 0.0);
+                            v = fromLds(Wl + (NX + 16 * tu) * (n + 1), vd[r], ok) + (ok && rowL == lj ? reg : 0.0);
                         }
                     }
                     Huu[tu][tv][r] = v;
@@ -253,20 +289,35 @@ __global__ __launch_bounds__(64, WAVES_PER_EU) void RiccatiWaveKernel(const Ricc
         }
     };
     int failed = 0;
-    loadAB(N - 1);
-    loadW(N - 1);
+#pragma unroll
+    for (int tile = 0; tile < kRequestTiles; ++tile) {
+        requestShare(N - 1, tile);
+        storeShare(tile);
+    }
     mark(-1);
     for (int k = N - 1; k >= 0; --k) {
+        WaveLdsFence();
+        mark(6);  // waiting for the knot's operands
+        takeOperands();
+        WaveLdsFence();  // the buffers are free again: the next knot's operands are requested during the products below and have the rest of the knot to land in
+        mark(1);  // operands LDS -> registers
         // ---- H_e += [A|B]_e^T (P_e [A|B]_e), one column tile of P_e [A|B]_e at a time (its XT accumulators are the B operand of that column's H tiles)
 #pragma unroll
         for (int tj = 0; tj < NT; ++tj) {
+            if (k > 0) {
+                __builtin_amdgcn_sched_barrier(0);  // (the previous tile's matrix instructions stay in front of the stores that wait for its share)
+                if (tj > 0) storeShare(tj - 1);
+                requestShare(k - 1, tj);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             f64x4 pab[XT];
 #pragma unroll
             for (int ti = 0; ti < XT; ++ti) pab[ti] = f64x4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int ks = 0; ks < KX; ++ks)
+            for (int ks = 0; ks < KX; ++ks) {
 #pragma unroll
-                for (int ti = 0; ti < XT; ++ti) pab[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(Pl[(4 * ks + lk) * PLD + 16 * ti + lj], ab[ks][tj], pab[ti], 0, 0, 0);
+                for (int ti = 0; ti < XT; ++ti) pab[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(P[ks >> 2][ti][ks & 3], ab[ks][tj], pab[ti], 0, 0, 0);
+            }
             if (tj < XT) {
 #pragma unroll
                 for (int ks = 0; ks < KX; ++ks) {
@@ -283,8 +334,8 @@ __global__ __launch_bounds__(64, WAVES_PER_EU) void RiccatiWaveKernel(const Ricc
                     for (int tu = tv; tu < UT; ++tu) Huu[tu][tv] = __builtin_amdgcn_mfma_f64_16x16x4f64(ab[ks][XT + tu], pab[ks >> 2][ks & 3], Huu[tu][tv], 0, 0, 0);
             }
         }
+        if (k > 0) storeShare(NT - 1);
         mark(0);  // products
-        if (k > 0) touchKnot(k - 1);  // (here the registers of [A|B] are free) in flight during the factorisation; requested for real at the end of the knot
 
         // ---- tableau [R | H_ux h_u] -> LDS (row-major), both triangles of R from the tiles on and below the diagonal
 #pragma unroll
@@ -308,7 +359,6 @@ __global__ __launch_bounds__(64, WAVES_PER_EU) void RiccatiWaveKernel(const Ricc
                 }
         }
         WaveLdsFence();
-        mark(1);  // tableau to LDS (and the requests of the next [A|B])
         // ---- symmetric elimination, lane = column: t[i] = row i of [R | -H_ux -h_u]
         double t[NU];
 #pragma unroll
@@ -331,8 +381,20 @@ __global__ __launch_bounds__(64, WAVES_PER_EU) void RiccatiWaveKernel(const Ricc
                 t[j + 1] = __builtin_fma(-ReadLaneF64(t[j + 1], j), prow, t[j + 1]);
                 rd = reciprocalOfPivot(ReadLaneF64(t[j + 1], j + 1));
             }
+            // the multipliers of a pivot are read in batches of eight, then applied: one scalar register pair reused for every row made each update wait
+            // for the previous one (two v_readlane, the wait states between a scalar write and its use, the multiply-add: ~30 cycles per row)
 #pragma unroll
-            for (int i = j + 2; i < NU; ++i) t[i] = __builtin_fma(-ReadLaneF64(t[i], j), prow, t[i]);
+            for (int i0 = j + 2; i0 < NU; i0 += 8) {
+                double m[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (i0 + q < NU) m[q] = ReadLaneF64(t[i0 + q], j);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (i0 + q < NU) t[i0 + q] = __builtin_fma(-m[q], prow, t[i0 + q]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             t[j] = prow;
         }
         if (bad) failed = failed ? failed : k + 1;
@@ -343,7 +405,17 @@ __global__ __launch_bounds__(64, WAVES_PER_EU) void RiccatiWaveKernel(const Ricc
         for (int c = NU - 1; c > 0; --c) {
             const double xc = lane >= NU ? t[c] : 0.0;
 #pragma unroll
-            for (int j = 0; j < c; ++j) t[j] = __builtin_fma(-ReadLaneF64(t[j], c), xc, t[j]);
+            for (int j0 = 0; j0 < c; j0 += 8) {
+                double m[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (j0 + q < c) m[q] = ReadLaneF64(t[j0 + q], c);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (j0 + q < c) t[j0 + q] = __builtin_fma(-m[q], xc, t[j0 + q]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         mark(3);  // back substitution
         // gains: global (forward pass) and LDS (B operand of the cost-to-go update)
@@ -364,12 +436,11 @@ __global__ __launch_bounds__(64, WAVES_PER_EU) void RiccatiWaveKernel(const Ricc
 #pragma unroll
             for (int tj = 0; tj < XT; ++tj) {
                 const int m = 4 * ks + lk, c = 16 * tj + lj;
-                const double v = Kb[(m < NU ? m : NU - 1) * KLD + (c < XE ? c : XE - 1)];  // (clamped address, then a select between the value and a constant)
-                kreg[ks][tj] = m < NU && c < XE ? v : 0.0;
+                kreg[ks][tj] = masked(Kb[(m < NU ? m : NU - 1) * KLD + (c < XE ? c : XE - 1)], m < NU && c < XE);
             }
+        WaveLdsFence();
         mark(4);  // gains out and back
-        // ---- P_e' = H_e,xx + (T + T^T) / 2,  T = H_e,xu [K | kff]: both orientations on the matrix cores; what lies on or above the diagonal goes to LDS
-        // twice (see above; the entries below the diagonal of a diagonal tile are computed and dropped)
+        // ---- P_e' = H_e,xx + (T + T^T) / 2,  T = H_e,xu [K | kff]: both orientations on the matrix cores
 #pragma unroll
         for (int ti = 0; ti < XT; ++ti)
 #pragma unroll
@@ -381,22 +452,26 @@ __global__ __launch_bounds__(64, WAVES_PER_EU) void RiccatiWaveKernel(const Ricc
                     t2 = __builtin_amdgcn_mfma_f64_16x16x4f64(kreg[ks][ti], Hux[ks >> 2][tj][ks & 3], t2, 0, 0, 0);
                 }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 16 * ti + 4 * r + lk, col = 16 * tj + lj;
-                    const double v = Hxx[ti][tj][r] + 0.5 * (t1[r] + t2[r]);
-                    if (row < XE && col < XE && (ti < tj || row <= col)) {
-                        Pl[row * PLD + col] = v;
-                        Pl[col * PLD + row] = v;
-                    }
-                }
+                for (int r = 0; r < 4; ++r) P[ti][tj][r] = Hxx[ti][tj][r] + 0.5 * (t1[r] + t2[r]);
             }
-        WaveLdsFence();
-        mark(5);  // cost-to-go update
-        if (k > 0) {  // (the registers of [A|B] and H_e are free from here on)
-            loadAB(k - 1);
-            loadW(k - 1);
-        }
-        mark(6);  // requests of the next knot's operands
+        // symmetric to the last bit (see above): the tiles below the diagonal are the transposes of the ones above, a diagonal tile is averaged with its own
+        // transpose (through LDS, one tile at a time)
+#pragma unroll
+        for (int ti = 0; ti < XT; ++ti)
+#pragma unroll
+            for (int tj = ti; tj < XT; ++tj) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tr[(4 * r + lk) * 17 + lj] = P[ti][tj][r];
+                WaveLdsFence();
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double mirrored = tr[lj * 17 + 4 * r + lk];
+                    if (ti == tj) P[ti][ti][r] = 0.5 * (P[ti][ti][r] + mirrored);
+                    else P[tj][ti][r] = mirrored;
+                }
+                WaveLdsFence();
+            }
+        mark(5);  // cost-to-go update and its transposes
     }
 
     // ---- forward pass: du_k = [K | kff] [dx_k; 1],  dx_(k+1) = [A b B] [dx_k; 1; du_k]; a row's inner product is shared by the four lanes of a quad
@@ -410,26 +485,17 @@ __global__ __launch_bounds__(64, WAVES_PER_EU) void RiccatiWaveKernel(const Ricc
     const int part = lane & 3, q = lane >> 2;  // row q of a round of 16 rows, terms part, part + 4, ...
     constexpr int XQ = (XE + 3) / 4, UQ = (NU + 3) / 4, RU = (NU + 15) / 16, RX = (NX + 15) / 16;
     const int vg = (q * nk + part) * 8, vj = (q * n + part) * 8;  // lane parts: entry (q, part) of a row-major NU x nk / NX x n block
-    for (int k = 0; k < N; ++k) {
+    // the operands of knot k + 1 are requested (into registers) before knot k is computed: one knot of lead instead of a round trip to memory per knot
+    double gvN[RU][XQ], avN[RX][XQ], bvN[RX][UQ], b0N[RX];
+    auto requestForward = [&](int k) {
         const __amdgpu_buffer_rsrc_t rsK = BufferOver(gains + static_cast<long long>(k) * NU * nk, NU * nk), rsJ = BufferOver(&a.jac.at(inst, k, 0), NX * n),
                                      rsB = BufferOver(&a.b.at(inst, k, 0), NX);
-        if (k + 1 < N) {  // the next knot's [A|B] and gains
-            const char* jacN = reinterpret_cast<const char*>(&a.jac.at(inst, k + 1, 0));
-            const char* gainsN = reinterpret_cast<const char*>(gains + static_cast<long long>(k + 1) * NU * nk);
-            constexpr int abBytes = NX * n * 8, gBytes = NU * nk * 8;
-#pragma unroll
-            for (int i = 0; i < (abBytes + 127) / 128 + 1; i += 64) TouchLine(jacN + ((i + lane) * 128 < abBytes ? (i + lane) * 128 : abBytes - 8), junk);
-#pragma unroll
-            for (int i = 0; i < (gBytes + 127) / 128 + 1; i += 64) TouchLine(gainsN + ((i + lane) * 128 < gBytes ? (i + lane) * 128 : gBytes - 8), junk);
-        }
-        // every operand of the knot is requested up front (unconditional loads: they travel together)
-        double gv[RU][XQ], av[RX][XQ], bv[RX][UQ], b0[RX];
 #pragma unroll
         for (int rr = 0; rr < RU; ++rr)
 #pragma unroll
             for (int m = 0; m < XQ; ++m) {
                 const bool ok = (16 * rr + 15 < NU || 16 * rr + q < NU) && (4 * m + 3 < XE || 4 * m + part < XE);
-                gv[rr][m] = BufferLoad(rsK, ok ? vg : kOutOfRange, (16 * rr * nk + 4 * m) * 8);
+                gvN[rr][m] = BufferLoad(rsK, ok ? vg : kOutOfRange, (16 * rr * nk + 4 * m) * 8);
             }
 #pragma unroll
         for (int rr = 0; rr < RX; ++rr) {
@@ -437,15 +503,32 @@ __global__ __launch_bounds__(64, WAVES_PER_EU) void RiccatiWaveKernel(const Ricc
 #pragma unroll
             for (int m = 0; m < XQ; ++m) {
                 const bool ok = rowOk && (4 * m + 3 < NX || 4 * m + part < NX);
-                av[rr][m] = 4 * m < NX ? BufferLoad(rsJ, ok ? vj : kOutOfRange, (16 * rr * n + 4 * m) * 8) : 0.0;
+                avN[rr][m] = 4 * m < NX ? BufferLoad(rsJ, ok ? vj : kOutOfRange, (16 * rr * n + 4 * m) * 8) : 0.0;
             }
 #pragma unroll
             for (int m = 0; m < UQ; ++m) {
                 const bool ok = rowOk && (4 * m + 3 < NU || 4 * m + part < NU);
-                bv[rr][m] = BufferLoad(rsJ, ok ? vj : kOutOfRange, (16 * rr * n + NX + 4 * m) * 8);
+                bvN[rr][m] = BufferLoad(rsJ, ok ? vj : kOutOfRange, (16 * rr * n + NX + 4 * m) * 8);
             }
-            b0[rr] = BufferLoad(rsB, rowOk && part == 0 ? q * 8 : kOutOfRange, 16 * rr * 8);
+            b0N[rr] = BufferLoad(rsB, rowOk && part == 0 ? q * 8 : kOutOfRange, 16 * rr * 8);
         }
+    };
+    requestForward(0);
+    for (int k = 0; k < N; ++k) {
+        double gv[RU][XQ], av[RX][XQ], bv[RX][UQ], b0[RX];
+#pragma unroll
+        for (int rr = 0; rr < RU; ++rr)
+#pragma unroll
+            for (int m = 0; m < XQ; ++m) gv[rr][m] = gvN[rr][m];
+#pragma unroll
+        for (int rr = 0; rr < RX; ++rr) {
+#pragma unroll
+            for (int m = 0; m < XQ; ++m) av[rr][m] = avN[rr][m];
+#pragma unroll
+            for (int m = 0; m < UQ; ++m) bv[rr][m] = bvN[rr][m];
+            b0[rr] = b0N[rr];
+        }
+        if (k + 1 < N) requestForward(k + 1);
         double xs[XQ];
 #pragma unroll
         for (int m = 0; m < XQ; ++m) xs[m] = dxv[part + 4 * m < XE ? part + 4 * m : XE - 1];  // (a term beyond XE has a zero coefficient)
@@ -493,7 +576,7 @@ __global__ __launch_bounds__(64, WAVES_PER_EU) void RiccatiWaveKernel(const Ricc
     if (a.status && lane == 0) a.status[inst] = failed;
     if constexpr (CLOCKS)
         if (inst == 0 && lane == 0)
-            printf("[riccati wave clocks %d+%d, cycles per knot] products %llu, tableau %llu, elimination %llu, back substitution %llu, gains %llu, cost-to-go %llu, W requests %llu; forward pass %llu per knot\n",
+            printf("[riccati wave clocks %d+%d, cycles per knot] products %llu, operands to registers %llu, tableau + elimination %llu, back substitution %llu, gains %llu, cost-to-go %llu, operand wait %llu; forward pass %llu per knot\n",
                    NX, NU, clocks[0] / N, clocks[1] / N, clocks[2] / N, clocks[3] / N, clocks[4] / N, clocks[5] / N, clocks[6] / N, clocks[7] / N);
 }
 
@@ -516,8 +599,8 @@ extern "C" int ungar_amd_launch_riccati_wave(const RiccatiArgs* a, void* stream)
     if (a->ne != 0) return -1;
     if (a->jac.es != 1 || a->b.es != 1 || a->hess.es != 1 || a->grad.es != 1) return -1;  // a knot's operands as contiguous row-major blocks (what the assembly kernels write)
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (a->nx == 37 && a->nu == 12) return LaunchWave<37, 12, 2>(a, s);
-    if (a->nx == 25 && a->nu == 24) return LaunchWave<25, 24, 2>(a, s);
+    if (a->nx == 37 && a->nu == 12) return LaunchWave<37, 12, 1>(a, s);
+    if (a->nx == 25 && a->nu == 24) return LaunchWave<25, 24, 1>(a, s);
     if (a->nx == 13 && a->nu == 24) return LaunchWave<13, 24, 2>(a, s);
     return -1;
 }
