@@ -314,7 +314,7 @@ gpu = pytest.mark.gpu
 
 
 @gpu
-@pytest.mark.parametrize("nx,nu,N,batch", [(13, 4, 30, 257), (13, 24, 10, 33), (37, 12, 20, 9), (6, 2, 200, 16)])
+@pytest.mark.parametrize("nx,nu,N,batch", [(13, 4, 30, 257), (13, 24, 10, 33), (37, 12, 20, 9), (6, 2, 200, 16), (25, 24, 30, 17), (37, 12, 3, 1), (13, 24, 1, 65)])
 def test_device_riccati_equals_the_dense_kkt_solve(nx, nu, N, batch):
     import torch
     from ungar_amd import sqp
@@ -332,8 +332,35 @@ def test_device_riccati_equals_the_dense_kkt_solve(nx, nu, N, batch):
     assert np.abs(res).max() <= 1e-9 * max(1.0, np.abs(dX).max())
 
 
+@gpu
+@pytest.mark.parametrize("nx,nu,N", [(37, 12, 20), (25, 24, 30), (13, 24, 30)])
+def test_register_resident_riccati_kernels_agree_with_the_lds_resident_ones(nx, nu, N, monkeypatch):
+    """The large blocks take the one-wavefront-per-instance kernels of ocp_riccati_wave.hip by default (every matrix of the recursion in registers, products
+    chained on the FP64 matrix cores, homogeneous coordinates for the affine parts); UNGAR_AMD_RICCATI_VARIANT keeps the LDS-resident kernels of
+    ocp_riccati.hip (the recursion that is pinned against the dense KKT solve on the host).  Same QPs, both routes: steps equal to 1e-11 of their scale, and
+    the dynamics of the QP hold to rounding on the whole batch -- also through a strided view of [A|B] (the register-resident route needs contiguous knot
+    blocks and must hand such a call over)."""
+    import torch
+    from ungar_amd import sqp
+    batch = 64
+    rng = np.random.default_rng(23)
+    q = random_qp(rng, nx, nu, N, batch)
+    dev = lambda a: torch.as_tensor(a, device="cuda")  # noqa: E731
+    args = [dev(q[k]) for k in ("AB", "b", "W", "w", "dx0", "WN", "wN")]
+    monkeypatch.delenv("UNGAR_AMD_RICCATI_VARIANT", raising=False)
+    dXw, dUw, stw = sqp.riccati_solve(nx, nu, N, batch, *args)
+    monkeypatch.setenv("UNGAR_AMD_RICCATI_VARIANT", "fixed")
+    dXl, dUl, stl = sqp.riccati_solve(nx, nu, N, batch, *args)
+    torch.cuda.synchronize()
+    assert (stw == 0).all() and (stl == 0).all()
+    for w, l in ((dXw, dXl), (dUw, dUl)):
+        assert float((w - l).abs().max()) <= 1e-11 * max(1.0, float(l.abs().max()))
+    res = dXw[:, 1:].cpu().numpy() - np.einsum("bkij,bkj->bki", q["AB"], np.concatenate((dXw[:, :-1].cpu().numpy(), dUw.cpu().numpy()), axis=2)) - q["b"]
+    assert np.abs(res).max() <= 1e-10 * max(1.0, float(dXw.abs().max()))
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("nx,nu", [(13, 4), (13, 24), (37, 12), (4, 2)])
+@pytest.mark.parametrize("nx,nu", [(13, 4), (13, 24), (37, 12), (4, 2), (25, 24)])
 def test_device_riccati_reports_an_indefinite_reduced_hessian(nx, nu):
     """Every device instantiation (register Cholesky, L D L^T phases, run-time sizes; one and four wavefronts per instance) reports the
     knot whose input block is not positive definite for exactly the instance concerned, as the host policy does."""

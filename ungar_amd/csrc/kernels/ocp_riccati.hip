@@ -726,7 +726,7 @@ extern "C" int ungar_amd_launch_riccati(const RiccatiArgs* a, void* stream) {
     {
         // Default route for the sizes it is instantiated for (the large blocks: 37 + 12, 25 + 24, 13 + 24, no equality rows inside the recursion): the
         // register-resident one-wavefront kernels.  UNGAR_AMD_RICCATI_VARIANT (any value, e.g. "fixed") keeps the LDS-resident kernels below: the A/B switch.
-        static const bool ldsResident = getenv("UNGAR_AMD_RICCATI_VARIANT") != nullptr;
+        const bool ldsResident = getenv("UNGAR_AMD_RICCATI_VARIANT") != nullptr;  // (read per call: a test switches routes inside one process)
         if (!ldsResident) {
             const int e = ungar_amd_launch_riccati_wave(a, stream);
             if (e >= 0) return e;

@@ -370,7 +370,12 @@ __global__ __launch_bounds__(64, WAVES_PER_EU) void RiccatiWaveKernel(const Ricc
         auto reciprocalOfPivot = [&](double d) {  // a pivot that is not positive is replaced by 1 and reported (ocp_riccati.hpp)
             const bool neg = !(d > 0.0);
             bad = bad || neg;
-            return 1.0 / (neg ? 1.0 : d);
+            // hardware reciprocal and two Newton steps (a last-bit-or-so reciprocal) instead of the IEEE division: the pivots' reciprocals are the serial
+            // chain of the elimination -- NU of them, each behind the first row update of the previous pivot
+            const double x = neg ? 1.0 : d;
+            double r = __builtin_amdgcn_rcp(x);
+            r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+            return __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
         };
         double rd = reciprocalOfPivot(ReadLaneF64(t[0], 0));
 #pragma unroll
@@ -440,19 +445,17 @@ __global__ __launch_bounds__(64, WAVES_PER_EU) void RiccatiWaveKernel(const Ricc
             }
         WaveLdsFence();
         mark(4);  // gains out and back
-        // ---- P_e' = H_e,xx + (T + T^T) / 2,  T = H_e,xu [K | kff]: both orientations on the matrix cores
+        // ---- P_e' = H_e,xx + H_e,xu [K | kff] on the matrix cores (accumulated onto H_e,xx)
 #pragma unroll
         for (int ti = 0; ti < XT; ++ti)
 #pragma unroll
             for (int tj = ti; tj < XT; ++tj) {
-                f64x4 t1 = f64x4{0.0, 0.0, 0.0, 0.0}, t2 = f64x4{0.0, 0.0, 0.0, 0.0};
+                // (one orientation of T = H_e,xu [K | kff] is enough: what makes P_e' symmetric to the last bit is the mirroring below, and the other
+                // orientation, averaged in, was 18 more matrix instructions per knot)
+                f64x4 t1 = Hxx[ti][tj];
 #pragma unroll
-                for (int ks = 0; ks < KU; ++ks) {
-                    t1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Hux[ks >> 2][ti][ks & 3], kreg[ks][tj], t1, 0, 0, 0);
-                    t2 = __builtin_amdgcn_mfma_f64_16x16x4f64(kreg[ks][ti], Hux[ks >> 2][tj][ks & 3], t2, 0, 0, 0);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) P[ti][tj][r] = Hxx[ti][tj][r] + 0.5 * (t1[r] + t2[r]);
+                for (int ks = 0; ks < KU; ++ks) t1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Hux[ks >> 2][ti][ks & 3], kreg[ks][tj], t1, 0, 0, 0);
+                P[ti][tj] = t1;
             }
         // symmetric to the last bit (see above): the tiles below the diagonal are the transposes of the ones above, a diagonal tile is averaged with its own
         // transpose (through LDS, one tile at a time)
