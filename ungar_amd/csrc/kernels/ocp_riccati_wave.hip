@@ -366,6 +366,10 @@ __global__ __launch_bounds__(64, WAVES_PER_EU) void RiccatiWaveKernel(const Ricc
             const double v = T[i * TLD + (lane < TW ? lane : TW - 1)];
             t[i] = lane < NU ? v : (lane < TW ? -v : 0.0);
         }
+        // (Measured and dropped for the elimination below: the pivot's reciprocal chain dealt out between the batches of row updates -- no change, the section is
+        // bound by the issue of its ~1100 vector instructions at ~8 cycles each in a lone wavefront, not by that chain; the multipliers broadcast through LDS, the
+        // pivot ROW stored once and read back entry by entry, one LDS instruction + one multiply-add per row update instead of two v_readlane + one -- 9 k -> 17 k
+        // cycles per knot for 24 inputs: a store-to-load round trip per pivot on the critical path of a lone wavefront.)
         bool bad = false;
         auto reciprocalOfPivot = [&](double d) {  // a pivot that is not positive is replaced by 1 and reported (ocp_riccati.hpp)
             const bool neg = !(d > 0.0);
@@ -605,5 +609,8 @@ extern "C" int ungar_amd_launch_riccati_wave(const RiccatiArgs* a, void* stream)
     if (a->nx == 37 && a->nu == 12) return LaunchWave<37, 12, 1>(a, s);
     if (a->nx == 25 && a->nu == 24) return LaunchWave<25, 24, 1>(a, s);
     if (a->nx == 13 && a->nu == 24) return LaunchWave<13, 24, 2>(a, s);
+    // (the small blocks: 13 + 4 takes 0.22 ms per 4096 x 30 knots here against 0.31 LDS-resident; 17 + 4, 8 + 2 and 6 + 2 measured SLOWER -- 0.85 / 0.15 / 0.12
+    // against 0.50 / 0.12 / 0.11 ms -- and stay with ocp_riccati.hip)
+    if (a->nx == 13 && a->nu == 4) return LaunchWave<13, 4, 4>(a, s);
     return -1;
 }
