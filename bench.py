@@ -60,7 +60,7 @@ class NativeOracleBuild:
         return build_oracle.build("portable"), "portable", build_oracle.PORTABLE_FLAGS
 
 
-def cpu_baseline(name, native: NativeOracleBuild | None, seconds=10.0, patience=240.0):
+def cpu_baseline(name, native: NativeOracleBuild | None, seconds=10.0, patience=240.0, light=False):
     """Times the oracle's generated-C Jacobian (stand-in for the reference's CppADCodeGen C; oracle/build_oracle.py):
     (a) single-threaded, one instance per call -- the reference's execution model (function.hpp:216-230) -- median of 5
     sweeps over a bounded sample, for the structured program AND for the taped-ABA program (the route the reference
@@ -100,6 +100,11 @@ def cpu_baseline(name, native: NativeOracleBuild | None, seconds=10.0, patience=
         return {"value": statistics.median(rates), "sweeps": rates, "evals_per_sweep": sample * reps, "nnz": nnz}
 
     structured = single_thread(name)
+    if light:  # the secondary workloads (configs 0-2): one thread, one figure
+        return {"value": structured["value"], "unit": "node Jacobian evals/s", "cores": 1, "kind": "port",
+                "sample": f"median of 5 sweeps x {structured['evals_per_sweep']} single-instance evaluations of the tape-generated C Jacobian ({name}, sparse nnz={structured['nnz']}) "
+                          f"over {sample} seeded nodes, gcc {' '.join(flags)} ({'compiled on this box' if tag == 'native' else 'prebuilt portable library'}), 1 thread",
+                "sweeps": structured["sweeps"]}
     taped = single_thread(name + "_ad") if name == "anymal" else None
     # (b) all host cores: one thread per core, each sweeping its contiguous share in ONE foreign call (ctypes releases the GIL)
     cores = min(64, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))  # bounded: the box may be CPU-throttled
@@ -229,6 +234,121 @@ def free_port() -> int:
         return sk.getsockname()[1]
 
 
+def gn_chain(torch, ungar_amd, reps=30):
+    """BASELINE configs[3], second half: ANYmal node Jacobians (unit-fastest J) -> Gauss-Newton term upper(J^T diag(d) J) (soft_sqp.hpp:257-264 per node), with the
+    contraction on the FP64 matrix cores (ungar_gn_hessian_upper_unit_fastest, v_mfma_f64_16x16x4_f64) and on the FP64 vector ALU (ungar_gn_hessian_upper_tiles) side by
+    side; HIP events on the launch stream, algorithmic bytes = read x, u; write f, J; read J, d; write the upper triangle."""
+    from ungar_amd import workloads as W
+    from ungar_amd.sharding import unit_fastest
+    rows, cols, N, batch = 37, 49, 20, 4096
+    count = N * batch
+    m = ungar_amd.NodeModel("anymal")
+    x0, u0, _, p = W.synth_device_inputs("anymal", count, 0, torch)
+    Op = ungar_amd.Operand
+    def operand(elements, src=None):
+        t = unit_fastest(elements, count, torch)
+        if src is not None:
+            t.copy_(src)
+        return t
+    x, u, f, J = operand(m.nx, x0), operand(m.nu, u0), operand(rows), operand(rows * cols)
+    d = operand(rows, torch.rand((rows, count), device="cuda", dtype=torch.float64))
+    G_valu = operand(cols * cols)
+    G_mfma = torch.zeros((count, cols, cols), dtype=torch.float64, device="cuda")
+    es = J.stride(0)
+    ops = (count, Op.soa(x, es, N), Op.soa(u, es, N), None, Op.per_instance(p, 1, shared=True), Op.soa(f, es, N), Op.soa(J, es, N))
+    jac = lambda: m.dense_jacobian(*ops, knots=N)  # noqa: E731
+    valu = lambda: ungar_amd.gn_hessian_tiles(J, d, G_valu, rows, cols, count, True)  # noqa: E731
+    mfma = lambda: ungar_amd.gn_hessian_unit_fastest(J, d, G_mfma, rows, cols, count)  # noqa: E731
+    def timeit(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(reps):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        return s.elapsed_time(e) / reps
+    upper = cols * (cols + 1) // 2
+    jac_bytes, gn_bytes = count * W.algorithmic_bytes(m.nx, m.nu, None), count * 8 * (rows * cols + rows + upper)
+    t_end = time.perf_counter() + 0.3  # steady-state clocks, as for the headline measurement
+    while time.perf_counter() < t_end:
+        for _ in range(20):
+            jac()
+            valu()
+        torch.cuda.synchronize()
+    t_jac, t_valu, t_mfma = timeit(jac), timeit(valu), timeit(mfma)
+    t_chain_valu, t_chain_mfma = timeit(lambda: (jac(), valu())), timeit(lambda: (jac(), mfma()))
+    iu = torch.triu_indices(cols, cols, device="cuda")
+    agree = float((G_mfma[:, iu[0], iu[1]].T - G_valu.reshape(cols, cols, count)[iu[0], iu[1]]).abs().max() / G_mfma.abs().max())
+    flops = count * 2 * rows * upper  # useful multiply-adds of the upper triangle
+    counters, source = None, None
+    cpath = os.path.join(ROOT, "profiles", "mfma_counters.json")
+    if os.path.exists(cpath):
+        with open(cpath) as fh:
+            table = json.load(fh)
+        counters, source = table.get("gn_hessian_unit_fastest"), table.get("_source")
+    def leg(ms, byts):
+        return {"ms": ms, "algorithmic_GB": byts / 1e9, "frac_of_8TBs": byts / ms / 1e6 / HBM_PEAK_GBS}
+    return {"workload": "anymal node Jacobians -> upper(J^T diag(d) J) per node, N=20 batch=4096 (81920 nodes), unit-fastest J", "reps": reps,
+            "node_jacobian": leg(t_jac, jac_bytes),
+            "contraction_mfma": {**leg(t_mfma, gn_bytes), "useful_TFLOPs": flops / t_mfma / 1e9, "frac_of_fp64_matrix_peak_78.6": flops / t_mfma / 1e9 / 78.6,
+                                 "kernel": "ungar_gn_hessian_upper_unit_fastest (v_mfma_f64_16x16x4_f64)", "mfma_counters": counters, "mfma_counters_source": source},
+            "contraction_valu": {**leg(t_valu, gn_bytes), "useful_TFLOPs": flops / t_valu / 1e9, "kernel": "ungar_gn_hessian_upper_tiles (FP64 vector ALU, LDS-DMA row streaming)"},
+            "chain_mfma": leg(t_chain_mfma, jac_bytes + gn_bytes), "chain_valu": leg(t_chain_valu, jac_bytes + gn_bytes),
+            "max_rel_difference_between_the_two_contractions": agree}
+
+
+def sqp_iterations(batch=4096, timeout=420):
+    """One batched soft-SQP iteration of each reference OCP AS WRITTEN (quadrotor.example.cpp:196-291, rc_car.example.cpp:191-285, quadruped.example.cpp:209-338)
+    through the C++20 driver Ungar::BatchedSoftSQPOptimizer: the prebuilt host programs of tests/cpp (build/batched_*_test, `<folder> <batch> 0` = no facade
+    comparison) time five iterations after two; their stage functions are compiled at run time on first use (not part of the iteration)."""
+    import re
+    import subprocess
+    import tempfile
+    out = {}
+    folder = os.path.join(tempfile.gettempdir(), "ungar_bench_codegen")
+    for problem in ("quadrotor", "rc_car", "quadruped"):
+        exe = os.path.join(ROOT, "build", f"batched_{problem}_test")
+        if not os.path.exists(exe):
+            out[problem] = {"skipped": f"{exe} missing (python -c 'import __graft_entry__ as g; g.build()')"}
+            continue
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run([exe, os.path.join(folder, problem), str(batch), "0"], capture_output=True, text=True, timeout=timeout)
+            m = re.search(r"timing: ([0-9.]+) ms per SQP iteration of (\d+) instances", r.stdout)
+            if r.returncode == 0 and m:
+                ms = float(m.group(1))
+                out[problem] = {"ms_per_iteration": ms, "instances": int(m.group(2)), "instances_per_s": int(m.group(2)) / ms * 1e3, "wall_s_including_jit": time.perf_counter() - t0,
+                                "kernel_split": f"profiles/r04c_batched_{problem}_kernel_stats.csv" if problem != "rc_car" else None}
+            else:
+                out[problem] = {"failed": (r.stdout + r.stderr)[-400:]}
+        except subprocess.TimeoutExpired:
+            out[problem] = {"failed": f"timeout after {timeout} s"}
+    return out
+
+
+def facade_single_instance_latency(timeout=300):
+    """BASELINE configs[0]'s execution model -- ONE instance per call from host memory (function.hpp:216-230) -- through the facade's Function::Jacobian on the quadrotor
+    node (37 inputs -> 118 values): H2D copy, batch-1 launch, D2H copy, synchronise.  PCIe-inclusive; never part of `value`."""
+    import re
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "build", "function_test")
+    if not os.path.exists(exe):
+        return {"skipped": f"{exe} missing"}
+    try:
+        r = subprocess.run([exe, os.path.join(tempfile.gettempdir(), "ungar_bench_codegen", "latency"), "latency"], capture_output=True, text=True, timeout=timeout)
+        m = re.search(r"HOST_CALL_LATENCY_US ([0-9.]+)", r.stdout)
+        if r.returncode == 0 and m:
+            us = float(m.group(1))
+            return {"us_per_call": us, "evals_per_s": 1e6 / us, "what": "Ungar::Autodiff::Function::Jacobian, quadrotor node, single instance, host memory in and out (PCIe-inclusive)"}
+        return {"failed": (r.stdout + r.stderr)[-300:]}
+    except subprocess.TimeoutExpired:
+        return {"failed": f"timeout after {timeout} s"}
+
+
 def launcher_command(gpus: int, argv: list[str], port: int | None = None) -> list[str]:
     """The one-process-per-GPU launch of this file: `python bench.py --gpus N` run directly (no WORLD_SIZE in the environment)
     re-executes itself under torch.distributed.run on 127.0.0.1 -- the same command the driver uses."""
@@ -273,6 +393,7 @@ def main():
                     help="dense [A|B] block (BASELINE metric, default) or the CSR value array of Function::Jacobian (function.hpp:216-230)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sub-results", action="store_true")
+    ap.add_argument("--no-extended-sub-results", action="store_true", help="skip the Gauss-Newton chain, the batched SQP iterations and the single-instance host-call latency")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     args = ap.parse_args()
 
@@ -295,7 +416,7 @@ def main():
     model_name = W.WORKLOADS[args.workload][0]
     # compiles while the GPU runs (UNGAR_BENCH_PORTABLE_ORACLE=1: time the prebuilt portable library instead -- the contract test's choice, a native build of the
     # generated C takes a minute of host time; the JSON line says which one was timed)
-    native = (NativeOracleBuild((model_name, "anymal_ad") if model_name == "anymal" else (model_name,))
+    native = (NativeOracleBuild((model_name, "anymal_ad", "quadrotor", "rc_car") if model_name == "anymal" else (model_name,))
               if want_cpu and os.environ.get("UNGAR_BENCH_PORTABLE_ORACLE") != "1" else None)
 
     import torch
@@ -392,8 +513,14 @@ def main():
                              "unit": "evals/s", "kernel_ms": s["kernel_ms"], "roofline_frac": rl["frac"], "achieved_GBps": rl["achieved"],
                              "algorithmic_bytes_per_eval": s["bytes_per_eval"]})
             out["sub_results"] = subs
+            if not args.no_extended_sub_results:
+                out["gn_chain"] = gn_chain(torch, ungar_amd)
+                out["sqp_iterations"] = sqp_iterations()
+                out["single_instance_host_call"] = facade_single_instance_latency()
         if want_cpu:
             out["cpu_baseline"] = cpu_baseline(model_name, native, args.cpu_seconds)
+            if args.workload == "anymal" and not args.no_sub_results:  # configs[0..2]: the reference's execution model on the secondary workloads
+                out["cpu_baseline"]["sub_results"] = {wl: cpu_baseline(wl, native, min(args.cpu_seconds, 3.0), light=True) for wl in ("quadrotor", "rc_car")}
         elif world > 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = {"skipped": "timed on rank 0 of the single-GPU run only (python bench.py --gpus 1): host cores are shared by the ranks here"}
         line = json.dumps(out)

@@ -275,6 +275,10 @@ static void TestCacheAndEmptyDerivatives(const std::string& folder) {
 int main(int argc, char** argv) {
     const std::string folder = argc > 1 ? argv[1] : "/tmp/ungar_amd_cpp_test";
     try {
+        if (argc > 2 && std::string(argv[2]) == "latency") {  // bench.py: only the single-instance host call (BASELINE config 1's execution model) is timed
+            QuadrotorNodeThroughFacade(folder);
+            return g_failures ? 1 : 0;
+        }
         TestCacheAndEmptyDerivatives(folder);
         TestExponentialMap(folder);
         TestJacobianClosedForm(folder);

@@ -33,3 +33,15 @@ def test_bench_line_has_the_contract_fields(repo_root):
     assert d["value"] / c["value"] > 100, "one GPU against one CPU core"
     assert abs(d["checksum"] - 5033491.53798481) < 1e-3, "synthetic inputs and results are deterministic"
     assert len(d["sub_results"]) == 2 and all(0.3 < s["roofline_frac"] < 1.0 for s in d["sub_results"])
+    # BASELINE configs[3], second half: node Jacobians -> upper(J^T diag(d) J), matrix-core and vector contraction side by side (soft_sqp.hpp:257-264)
+    g = d["gn_chain"]
+    for leg in ("node_jacobian", "contraction_mfma", "contraction_valu", "chain_mfma", "chain_valu"):
+        assert g[leg]["ms"] > 0 and 0.05 < g[leg]["frac_of_8TBs"] < 1.0 and g[leg]["algorithmic_GB"] > 0.5
+    assert g["max_rel_difference_between_the_two_contractions"] < 1e-12 and 0.0 < g["contraction_mfma"]["frac_of_fp64_matrix_peak_78.6"] < 1.0
+    assert g["contraction_mfma"]["mfma_counters"] is None or (g["contraction_mfma"]["mfma_counters"]["cycles_per_mfma"] == 64.0 and "profiles/" in g["contraction_mfma"]["mfma_counters_source"])
+    # one batched SQP iteration of each reference OCP as written, through the C++ driver
+    q = d["sqp_iterations"]
+    assert set(q) == {"quadrotor", "rc_car", "quadruped"} and all(0.05 < q[k]["ms_per_iteration"] < 100.0 and q[k]["instances"] == 4096 for k in q), q
+    # BASELINE configs[0]: the reference's execution model (one instance per call) through the facade, and its CPU stand-ins for the secondary workloads
+    assert 1.0 < d["single_instance_host_call"]["us_per_call"] < 5000.0
+    assert set(c["sub_results"]) == {"quadrotor", "rc_car"} and all(v["cores"] == 1 and v["value"] > 1e5 for v in c["sub_results"].values())
