@@ -23,9 +23,11 @@ def clib(repo_root):
     return ctypes.CDLL(path)
 
 
-@pytest.mark.parametrize("name", MODELS)
-def test_generated_c_matches_golden(repo_root, clib, name):
-    g = np.load(f"{repo_root}/tests/golden/node_{name.replace('_ad', '')}.npz")
+@pytest.mark.parametrize("name,fixture", [(m, None) for m in MODELS] + [("anymal", "node_anymal_256.npz"), ("anymal_ad", "node_anymal_256.npz")])
+def test_generated_c_matches_golden(repo_root, clib, name, fixture):
+    """(node_anymal_256.npz: 256 nodes of the headline model from the independent torch oracle, tests/golden/make_anymal_many.py -- the C checker that the
+    every-node GPU tests compare with is itself pinned at hundreds of nodes, for both the structured and the taped-ABA program)"""
+    g = np.load(f"{repo_root}/tests/golden/{fixture or 'node_' + name.replace('_ad', '') + '.npz'}")
     dims = (ctypes.c_int * 4).in_dll(clib, f"{name}_dims")
     nx, nu, nw, _ = list(dims)
     nnz = ctypes.c_int.in_dll(clib, f"{name}_jac_nnz").value
