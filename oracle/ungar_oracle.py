@@ -156,6 +156,49 @@ def srbd_node(x, u, w, p):
     return torch.cat((pos_n, q_n, pdot_n, om_n))
 
 
+def quadruped_whole_horizon(z, par, N=30):
+    """The reference's quadruped OCP AS WRITTEN, whole horizon (example/mpc/quadruped.example.cpp:209-304): objective value and the 883 equality rows
+    [x_0 - x_m; x_(k+1) - f(x_k, u_k); foot-contact rows] as torch expressions of the decision variables z = (X, U) (1123) and the parameters par = (P, Rho) (948).
+    Variable layout :57-139: x = (position 3, orientation xyzw 4, linear velocity 3, body angular velocity 3), u = 4 x (ground reaction force 3, body-frame foot position 3),
+    p_k = (reference state 13, 4 x (reference contact state 1, body-frame reference foot position 3)), Rho = (step size, mass, moi diagonal 3, 4 x hip position 3, leg length,
+    gravity, friction coefficient, measured state 13, 4 x (measured contact state 1, measured foot position 3))."""
+    nx, nu, npk = 13, 24, 29
+    X = z[:(N + 1) * nx].reshape(N + 1, nx)
+    U = z[(N + 1) * nx:].reshape(N, nu)
+    P = par[:(N + 1) * npk].reshape(N + 1, npk)
+    rho = par[(N + 1) * npk:]
+    dt, mass, moi = rho[0], rho[1], rho[2:5]
+    g0 = rho[18]
+    xm = rho[20:33]
+    measured = rho[33:49].reshape(4, 4)  # (contact state, foot position) per leg
+    node_p = torch.cat((dt.reshape(1), mass.reshape(1), moi, g0.reshape(1)))
+    weights = torch.tensor([0.1, 0.1, 10.0], dtype=torch.float64)
+    value = torch.zeros((), dtype=torch.float64)
+    for k in range(N + 1):  # :215-245
+        ref = P[k, :13]
+        q, qr = X[k, 3:7], ref[3:7]
+        value = value + ((weights * (X[k, 0:3] - ref[0:3])) ** 2).sum() + torch.minimum(((q - qr) ** 2).sum(), ((q + qr) ** 2).sum()) \
+            + ((X[k, 7:10] - ref[7:10]) ** 2).sum() + ((X[k, 10:13] - ref[10:13]) ** 2).sum()
+        if k != N:
+            for i in range(4):
+                f, r = U[k, 6 * i:6 * i + 3], U[k, 6 * i + 3:6 * i + 6]
+                r_ref = P[k, 13 + 4 * i + 1:13 + 4 * i + 4]
+                value = value + ((r - r_ref) ** 2).sum() + 1e-8 * (f ** 2).sum()
+    rows = [X[0] - xm]  # :262-265
+    for k in range(N):  # :268-276
+        contact = torch.stack([P[k, 13 + 4 * i] for i in range(4)])
+        rows.append(X[k + 1] - srbd_node(X[k], U[k], contact, node_p))
+    for k in range(N):  # :278-304
+        for i in range(4):
+            s = P[k, 13 + 4 * i]
+            s_prev = P[k - 1, 13 + 4 * i] if k else measured[i, 0]
+            foot = X[k, 0:3] + quat_rotate(X[k, 3:7], U[k, 6 * i + 3:6 * i + 6])
+            foot_prev = X[k - 1, 0:3] + quat_rotate(X[k - 1, 3:7], U[k - 1, 6 * i + 3:6 * i + 6]) if k else measured[i, 1:4]
+            rows.append(((1.0 - s_prev) * s * foot[2]).reshape(1))
+            rows.append(s_prev * s * (foot - foot_prev))
+    return value, torch.cat(rows)
+
+
 # ----------------------------------------------------------------------------- rigid-body model
 def _rpy(r, p, y):
     cr, sr, cp, sp, cy, sy = math.cos(r), math.sin(r), math.cos(p), math.sin(p), math.cos(y), math.sin(y)

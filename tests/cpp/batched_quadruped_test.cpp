@@ -313,6 +313,27 @@ int main(int argc, char** argv) {
             instances.push_back(data);
         }
 
+        if (compared < 0) {  // `batched_quadruped_test <folder> <batch> -1 <file>`: dump the whole-horizon functions at instance 1 (a random gait) for tests/test_whole_horizon.py
+            const VectorXr& in = instances[static_cast<std::size_t>(batch > 1 ? 1 : 0)];
+            std::ofstream out(dumpFolder);
+            out.precision(17);
+            auto vector = [&](const char* tag, const VectorXr& v) {
+                out << tag << " " << v.size() << "\n";
+                for (index_t i = 0; i < v.size(); ++i) out << v[i] << "\n";
+            };
+            auto sparse = [&](const char* tag, const Autodiff::SparseMatrix& A) {
+                out << tag << " " << A.rows() << " " << A.cols() << " " << A.nonZeros() << "\n";
+                for (index_t r = 0; r < A.rows(); ++r)
+                    for (int k = A.outerIndexPtr()[r]; k < A.outerIndexPtr()[r + 1]; ++k) out << r << " " << A.innerIndexPtr()[k] << " " << A.valuePtr()[k] << "\n";
+            };
+            vector("INPUT", in);
+            vector("OBJ", nlp.objective(in));
+            sparse("OBJ_JAC", nlp.objective.Jacobian(in));
+            vector("EQ", nlp.equalityConstraints(in));
+            sparse("EQ_JAC", nlp.equalityConstraints.Jacobian(in));
+            std::printf("DUMPED %s\n", dumpFolder.c_str());
+            return 0;
+        }
         // ---- node rows
         const index_t nx = x.Size(), nu = u.Size(), nc = previous_feet.Size(), nz = nc + nx, dec = decision_variables.Size();
         std::vector<real_t> rows(static_cast<std::size_t>(batched.RowsSize())), xm(static_cast<std::size_t>(batch * nx));

@@ -191,3 +191,52 @@ def test_objective_value_gradient_and_upper_triangular_hessian(dump):
     assert Hd.shape == (DEC, DEC)
     assert not Hm[np.tril_indices(DEC, -1)].any(), "Hessian must be upper-triangular only (function.hpp:232-235)"
     assert np.abs(Hd - np.triu(H)).max() <= 1e-12 * np.abs(H).max()
+
+
+# ---- the quadruped OCP as written: 883 equality rows incl. the 480 foot-contact rows (quadruped.example.cpp:246-304) and its objective (:209-245) --------
+@pytest.fixture(scope="module")
+def quadruped_dump(repo_root, tmp_path_factory):
+    exe = os.path.join(repo_root, "build", "batched_quadruped_test")
+    assert os.path.exists(exe), "build/batched_quadruped_test missing: run __graft_entry__.build()"
+    d = tmp_path_factory.mktemp("quadruped_ocp")
+    r = subprocess.run([exe, str(d / "codegen"), "4", "-1", str(d / "dump.txt")], capture_output=True, text=True, timeout=1500)
+    print(r.stdout[-2000:], r.stderr[-2000:])
+    assert r.returncode == 0 and "DUMPED" in r.stdout
+    return _parse(str(d / "dump.txt"))
+
+
+def test_quadruped_whole_horizon_functions_against_the_independent_oracle(quadruped_dump):
+    """The whole-horizon equality function (x_0 - x_m, 30 dynamics defects, 480 foot-contact rows that couple knots k and k - 1 through the world positions of the
+    feet) and the objective of the reference's quadruped OCP, evaluated through the facade's Ungar::Autodiff::Function on the GPU at an instance with a random
+    gait (stance, swing, touch-down and lift-off rows all occur), against oracle.ungar_oracle.quadruped_whole_horizon -- a torch restatement that shares no code
+    with the product -- and its autograd Jacobian / gradient: values to 1e-12, every Jacobian entry to 1e-10 of the largest, structural zeros exact.
+    (The batched SQP tests compare the device iteration with the facade's optimiser on THESE functions.)"""
+    dump = quadruped_dump
+    dec, par_n = 1123, 948
+    v = dump["INPUT"]
+    assert v.size == dec + par_n
+    z, par = torch.tensor(v[:dec]), torch.tensor(v[dec:])
+    value, eq = O.quadruped_whole_horizon(z, par)
+    assert eq.shape == (883,) and dump["EQ"].shape == (883,)
+    assert abs(dump["OBJ"][0] - value.item()) <= 1e-12 * abs(value.item())
+    assert np.abs(dump["EQ"] - eq.numpy()).max() <= 1e-12 * max(1.0, np.abs(eq.numpy()).max())
+    contact_rows = eq.numpy()[13 + 390:]
+    assert (contact_rows != 0).sum() > 40 and (contact_rows == 0).sum() > 40  # active and inactive contact rows both occur
+    zg = z.clone().requires_grad_(True)
+    (grad,) = torch.autograd.grad(O.quadruped_whole_horizon(zg, par)[0], zg)
+    g = dump["OBJ_JAC"]
+    assert g.shape == (1, dec) and np.abs(g[0] - grad.numpy()).max() <= 1e-12 * np.abs(grad.numpy()).max()
+    J = torch.autograd.functional.jacobian(lambda zz: O.quadruped_whole_horizon(zz, par)[1], z).numpy()
+    Jd, mask = dump["EQ_JAC"], dump["EQ_JAC_MASK"]
+    assert Jd.shape == (883, dec)
+    assert np.abs(Jd - J).max() <= 1e-10 * np.abs(J).max()
+    assert not (J != 0)[~mask].any(), "an entry the oracle differentiates to non-zero is missing from the structural pattern"
+    # the foot-contact rows couple knots: a stance row of knot k >= 1 has entries in x_k, u_k AND in x_(k-1), u_(k-1)
+    coupled = 0
+    for k in range(1, 30):
+        for i in range(4):
+            row = 13 + 390 + (k * 4 + i) * 4 + 1  # first of the three "sPrev s (pFoot - pFootPrev)" rows
+            if np.any(J[row] != 0):
+                assert np.any(J[row, (k - 1) * 13:k * 13] != 0) and np.any(J[row, k * 13:(k + 1) * 13] != 0)
+                coupled += 1
+    assert coupled > 20
