@@ -31,7 +31,20 @@ fi
 for name in "$@"; do
   src="$ref/example/mpc/${name}.example.cpp"
   [ -f "$src" ] || src="$ref/example/autodiff/${name}.example.cpp"
+  [ -f "$src" ] || src="$ref/example/rbd/${name}.example.cpp"
   [ -f "$src" ] || src="$ref/example/${name}.example.cpp"
+  data=()
+  case "$src" in */example/rbd/*)  # the rbd examples open UNGAR_DATA_FOLDER "/robots/anymal_b_description/robots/anymal.urdf": written from ungar_amd/data/anymal_b.robot
+    python3 "$root/tools/robot_to_urdf.py" "$root/ungar_amd/data/anymal_b.robot" "$root/oracle/_ref/data/robots/anymal_b_description/robots/anymal.urdf"
+    data=(-DUNGAR_DATA_FOLDER='"/root/repo/oracle/_ref/data"')
+    # (they use Eigen expression forms -- toDense().leftCols(), setRandom() on a view -- the built-in algebra does not have: real Eigen only)
+    if [ -n "$eigen" ]; then
+      g++ -std=c++20 -O2 -DUNGAR_AMD_USE_SYSTEM_EIGEN "${data[@]}" -I "$eigen" "${hana[@]}" -I "$root/ungar_amd/include" -o "$root/oracle/_ref/${name}_example_eigen" "$src" \
+          -L "$root/ungar_amd/lib" -lungar_amd -Wl,-rpath,'$ORIGIN/../../ungar_amd/lib' -Wl,-rpath,/opt/rocm/lib
+      echo "built oracle/_ref/${name}_example_eigen (real Eigen 3.4)"
+    fi
+    continue;;
+  esac
   g++ -std=c++20 -O2 "${hana[@]}" -I "$root/ungar_amd/include" -o "$root/oracle/_ref/${name}_example" "$src" \
       -L "$root/ungar_amd/lib" -lungar_amd -Wl,-rpath,'$ORIGIN/../../ungar_amd/lib' -Wl,-rpath,/opt/rocm/lib
   echo "built oracle/_ref/${name}_example"

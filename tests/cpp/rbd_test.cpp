@@ -115,7 +115,14 @@ int main(int argc, char** argv) {
     robot.Compute(qs::frames).At(q);
     EXPECT_TRUE(robot.Model().nframes == static_cast<int>(robot.Get(qs::frames).size()) && robot.Model().existFrame("LF_FOOT") && !robot.Model().existFrame("no_such_frame"));
     {
-        const auto& base = robot.Get(qs::frames)[0];  // the root link sits in the free-flyer joint frame
+        // frame numbering of the reference's model builder: universe, root joint, root link, then (joint, child link) pairs depth first -- the feet of ANYmal B are
+        // frames 12 / 22 / 32 / 42 (test/rbd/robot.test.cpp:49-52, example/rbd/quantity.example.cpp:44-45)
+        EXPECT_TRUE(robot.Model().getFrameId("universe") == 0 && robot.Model().getFrameId("root_joint") == 1 && robot.Model().getFrameId("base") == 2);
+        EXPECT_TRUE(robot.Model().getFrameId("LF_FOOT") == 12 && robot.Model().getFrameId("LH_FOOT") == 22 && robot.Model().getFrameId("RF_FOOT") == 32 &&
+                    robot.Model().getFrameId("RH_FOOT") == 42);
+        const auto& universe = robot.Get(qs::frames)[0];
+        EXPECT_TRUE(universe.translation()[0] == 0.0 && universe.rotation()[0][0] == 1.0 && universe.rotation()[0][1] == 0.0);
+        const auto& base = robot.Get(qs::frames)[2];  // the root link sits in the free-flyer joint frame
         EXPECT_TRUE(std::fabs(base.translation()[0] - q[0]) + std::fabs(base.translation()[1] - q[1]) + std::fabs(base.translation()[2] - q[2]) < 1e-15);
     }
     for (const char* name : {"base", "LF_FOOT", "LH_FOOT", "RF_FOOT", "RH_FOOT", "LF_SHANK"}) {

@@ -103,3 +103,29 @@ def test_quadruped_example_trots_and_tracks(repo_root, tmp_path, variant):
         swing = [f == 0.0 for f in r[8:12]]
         assert swing in ([False, True, False, True], [True, False, True, False]), "trot: one diagonal pair in swing"
         assert sum(r[8:12]) > 150.0  # the stance pair carries the ~25 kg body
+
+
+def test_rbd_quantity_example_runs_on_the_host(repo_root, tmp_path):
+    """example/rbd/quantity.example.cpp (a user-defined quantity with its own evaluator / getter over pinocchio::forwardKinematics / updateFramePlacement, the feet
+    of ANYmal B addressed by frame INDEX 12 / 22 / 32 / 42 and by name: both must give the same pose -- the frame numbering of the reference's model builder):
+    builds unchanged on the real Eigen and runs without a GPU."""
+    exe = os.path.join(repo_root, "oracle", "_ref", "quantity_example_eigen")
+    if not os.path.exists(exe):
+        pytest.skip(f"{exe} not built (needs the reference sources at build time)")
+    out = subprocess.run([exe], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and all(f"Pose of the foot ('{leg}_FOOT')" in out.stdout for leg in ("LF", "LH", "RF", "RH")), (out.stdout + out.stderr)[-2000:]
+
+
+@pytest.mark.gpu
+def test_rbd_robot_example_checks_itself(repo_root, tmp_path):
+    """example/rbd/robot.example.cpp: centre-of-mass acceleration, composite inertia, forward dynamics on the host, then the centroidal momentum as an
+    Autodiff::Function (recorded through Robot<ad_scalar_t>, evaluated on the GPU) compared with the host value by the example itself (UNGAR_ASSERT(ok))."""
+    exe = os.path.join(repo_root, "oracle", "_ref", "robot_example_eigen")
+    if not os.path.exists(exe):
+        pytest.skip(f"{exe} not built (needs the reference sources at build time)")
+    out = subprocess.run([exe], cwd=tmp_path, capture_output=True, text=True, timeout=900, env={**os.environ, "UNGAR_CODEGEN_FOLDER": str(tmp_path)})
+    text = out.stdout + out.stderr
+    assert out.returncode == 0 and "Autodiff Jacobian (6 leftmost columns)" in out.stdout and "mismatch" not in text, text[-3000:]
+    a = [float(v) for v in out.stdout.split("Autodiff function:")[1].split("\n")[1].split()]
+    b = [float(v) for v in out.stdout.split("Ground truth:")[1].split("\n")[1].split()]
+    assert len(a) == 6 and max(abs(x - y) for x, y in zip(a, b)) <= 1e-9 * max(1.0, max(abs(y) for y in b))

@@ -56,3 +56,13 @@ def test_reference_soft_sqp_test_passes_unchanged(repo_root, tmp_path):
     m = re.search(r"\[==========\] (\d+) tests ran", out.stdout)
     _check(out, int(m.group(1)) if m else -1)
     assert m and int(m.group(1)) >= 1
+
+
+@pytest.mark.gpu
+def test_reference_robot_test_passes_unchanged(repo_root, tmp_path):
+    """test/rbd/robot.test.cpp: RobotTest.Constructor (name / nq / nv / njoints of the model against the reference's own builder call, here the facade's
+    pinocchio::urdf::buildModel on ungar_amd's reader) and RobotTest.Autodiff -- ABA recorded through Robot<ad_scalar_t> -> Autodiff::Function with Jacobian,
+    Function::TestFunction / TestJacobian (the same lambda on doubles, second-order finite differences) at 1024 random configurations.  The only reference-held
+    check at the forward-dynamics boundary; with it all 12 TESTs of the reference's 5 test files run unchanged."""
+    assert os.path.exists(os.path.join(repo_root, "oracle", "_ref", "data", "robots", "anymal_b_description", "robots", "anymal.urdf")), "robot description not generated"
+    _check(_run(repo_root, "ref_robot_test_eigen", tmp_path, timeout=1500), 2)

@@ -195,18 +195,22 @@ def build_cpp_tests():
     build_reference_tests()
 
 
-def build_reference_examples(names=("quadrotor", "rc_car", "quadruped", "function", "variable_map", "variable")):
+def build_reference_examples(names=("quadrotor", "rc_car", "quadruped", "function", "variable_map", "variable", "robot", "quantity")):
     """The reference's own example/mpc programs against ungar_amd's headers (oracle/ref_examples):
     only where the reference is present; the binaries land in oracle/_ref and travel to the GPU box."""
     script = os.path.join(ROOT, "oracle", "ref_examples", "build_examples.sh")
     ref = os.environ.get("UNGAR_REFERENCE", "/root/reference")
     todo = []
     for n in names:
-        cands = [os.path.join(ref, "example", sub, f"{n}.example.cpp") for sub in ("mpc", "autodiff", "")]
+        cands = [os.path.join(ref, "example", sub, f"{n}.example.cpp") for sub in ("mpc", "autodiff", "rbd", "")]
         src = next((c for c in cands if os.path.exists(c)), cands[0])
         exes = [os.path.join(ROOT, "oracle", "_ref", f"{n}_example")]
         if os.path.exists(os.path.join(ref, "external", "config", "eigen", "eigen-3.4.0.zip")):
             exes.append(exes[0] + "_eigen")  # second build on the real Eigen the reference bundles
+            if os.sep + "rbd" + os.sep in src:
+                exes = exes[1:]  # the rbd examples use Eigen expression forms the built-in algebra does not have: real Eigen only
+        elif os.sep + "rbd" + os.sep in src:
+            continue
         if os.path.exists(src) and not _newer(exes, [src, LIB, script] + _tree(os.path.join(ROOT, "ungar_amd", "include"))):
             todo.append(n)
     if todo:
@@ -218,17 +222,17 @@ def build_reference_tests():
     (oracle/ref_tests): only where the reference is present; binaries land in oracle/_ref and travel to the GPU box."""
     script = os.path.join(ROOT, "oracle", "ref_tests", "build_ref_tests.sh")
     ref = os.environ.get("UNGAR_REFERENCE", "/root/reference")
-    srcs = [os.path.join(ref, "test", *rel) for rel in (("variable.test.cpp",), ("autodiff", "function.test.cpp"), ("optimization", "soft_sqp.test.cpp"))]
+    srcs = [os.path.join(ref, "test", *rel) for rel in (("variable.test.cpp",), ("autodiff", "function.test.cpp"), ("optimization", "soft_sqp.test.cpp"), ("rbd", "robot.test.cpp"))]
     if not all(os.path.exists(f) for f in srcs):
         return
     exes = [os.path.join(ROOT, "oracle", "_ref", "ref_variable_test")]
     if os.path.exists(os.path.join(ref, "external", "config", "eigen", "eigen-3.4.0.zip")):
-        exes += [os.path.join(ROOT, "oracle", "_ref", f"ref_{n}_test_eigen") for n in ("variable", "function", "soft_sqp")]
+        exes += [os.path.join(ROOT, "oracle", "_ref", f"ref_{n}_test_eigen") for n in ("variable", "function", "soft_sqp", "robot")]
         if os.path.exists(os.path.join(ref, "external", "config", "hana", "hana-boost-1.84.0.zip")) and os.path.exists(os.path.join(ref, "test", "utils", "utils.test.cpp")):
             exes.append(os.path.join(ROOT, "oracle", "_ref", "ref_utils_test_eigen"))
             srcs.append(os.path.join(ref, "test", "utils", "utils.test.cpp"))
     shim = os.path.join(ROOT, "tests", "gtest_shim", "gtest", "gtest.h")
-    if not _newer(exes, srcs + [LIB, script, shim] + _tree(os.path.join(ROOT, "ungar_amd", "include"))):
+    if not _newer(exes, srcs + [LIB, script, shim, os.path.join(ROOT, "ungar_amd", "data", "anymal_b.robot"), os.path.join(ROOT, "tools", "robot_to_urdf.py")] + _tree(os.path.join(ROOT, "ungar_amd", "include"))):
         _run(["bash", script])
 
 

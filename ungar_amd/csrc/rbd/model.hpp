@@ -143,8 +143,10 @@ struct Joint {
     int idxQ = 0, idxV = 0, nq = 0, nv = 0;
 };
 
-/// A named frame rigidly attached to a moving joint: every link of the description (including the links
-/// lumped into their parents through fixed joints, e.g. the feet) gives one.
+/// A named frame rigidly attached to a moving joint (or to the universe): the universe, the root joint, and then every joint and every link of the
+/// description (including the links lumped into their parents through fixed joints, e.g. the feet) in the order of the depth-first traversal -- a joint's
+/// frame right before its child link's --, which is the frame numbering of the reference's model builder (test/rbd/robot.test.cpp:49-52 and
+/// example/rbd/quantity.example.cpp:44-45 name the feet of ANYmal B by their indices 12, 22, 32, 42).
 struct Frame {
     std::string name;
     int joint = 0;        // index into Model::joints of the supporting joint
@@ -154,7 +156,7 @@ struct Frame {
 struct Model {
     std::string name;
     std::vector<Joint> joints;  // joints[0] is the universe
-    std::vector<Frame> frames;  // one per link, in visiting order (root link first)
+    std::vector<Frame> frames;  // universe, root joint, root link, then (joint, child link) pairs in visiting order
     V3 gravity{0.0, 0.0, -9.81};
     int nq = 0, nv = 0;
     int NumJoints() const {
@@ -422,6 +424,8 @@ inline Model BuildModel(const RobotDescription& d) {
     rootJoint.nv = 6;
     rootJoint.inertia = linkInertia(*links.at(root));
     m.joints.push_back(rootJoint);
+    m.frames.push_back({"universe", 0, Placement{}});
+    m.frames.push_back({"root_joint", 1, Placement{}});
     m.frames.push_back({root, 1, Placement{}});
 
     // Depth-first over links in joint-name order; `support` = index of the moving joint carrying
@@ -442,6 +446,7 @@ inline Model BuildModel(const RobotDescription& d) {
                 const RobotDescription::Link& child = *links.at(j->child);
                 if (j->type == "fixed") {
                     m.joints[static_cast<std::size_t>(support)].inertia += inertiaOf(child).Transported(inSupport);
+                    m.frames.push_back({jname, support, inSupport});
                     m.frames.push_back({j->child, support, inSupport});
                     Visit(j->child, support, inSupport);
                 } else if (j->type == "revolute" || j->type == "continuous") {
@@ -454,6 +459,7 @@ inline Model BuildModel(const RobotDescription& d) {
                     nj.nq = nj.nv = 1;
                     nj.inertia = inertiaOf(child);
                     m.joints.push_back(nj);
+                    m.frames.push_back({jname, static_cast<int>(m.joints.size()) - 1, Placement{}});
                     m.frames.push_back({j->child, static_cast<int>(m.joints.size()) - 1, Placement{}});
                     Visit(j->child, static_cast<int>(m.joints.size()) - 1, Placement{});
                 } else {

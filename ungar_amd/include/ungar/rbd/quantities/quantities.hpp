@@ -299,6 +299,10 @@ struct Evaluator<Quantities::frames, S> {
         const auto liMi = rbd::JointPlacements(m, Internal::ToStd<S>(q));
         const int n = m.NumJoints();
         std::vector<rbd::Xform<S>> oMi(static_cast<std::size_t>(n));
+        for (std::size_t r = 0; r < 3; ++r) {  // the universe: identity (its frame is frame 0)
+            oMi[0].p[r] = S{0.0};
+            for (std::size_t c = 0; c < 3; ++c) oMi[0].R[r][c] = S{r == c ? 1.0 : 0.0};
+        }
         for (int i = 1; i < n; ++i) {
             const std::size_t si = static_cast<std::size_t>(i), sp = static_cast<std::size_t>(m.joints[si].parent);
             if (m.joints[si].parent == 0) {

@@ -10,6 +10,8 @@
 #pragma once
 
 #include <array>
+#include <cmath>
+#include <ostream>
 #include <string>
 #include <vector>
 
@@ -24,7 +26,7 @@ struct ModelInfo {
     std::string name;
     int nq = 0, nv = 0, njoints = 0, nframes = 0;
     std::vector<std::string> names;       // joint names, universe first
-    std::vector<std::string> frameNames;  // one per link of the description
+    std::vector<std::string> frameNames;  // universe, root joint, then every joint and link of the description in the reference's frame order (csrc/rbd/model.hpp)
     int getFrameId(const std::string& name) const {
         for (int i = 0; i < nframes; ++i)
             if (frameNames[static_cast<std::size_t>(i)] == name) return i;
@@ -47,13 +49,39 @@ struct Pose {
     const std::array<std::array<S, 3>, 3>& rotation() const {
         return rotationMatrix;
     }
+    /// cf. pinocchio::SE3::isEqual (example/rbd/quantity.example.cpp:209): every entry within `precision`
+    bool isEqual(const Pose& other, const double precision = 1e-12) const {
+        for (std::size_t r = 0; r < 3; ++r) {
+            if (std::abs(static_cast<double>(position[static_cast<index_t>(r)] - other.position[static_cast<index_t>(r)])) > precision) return false;
+            for (std::size_t c = 0; c < 3; ++c)
+                if (std::abs(static_cast<double>(rotationMatrix[r][c] - other.rotationMatrix[r][c])) > precision) return false;
+        }
+        return true;
+    }
+    friend std::ostream& operator<<(std::ostream& os, const Pose& pose) {  // "  R =\n...\n  p = ..." as the reference's logs print an SE3
+        os << "  R =\n";
+        for (std::size_t r = 0; r < 3; ++r) os << "    " << pose.rotationMatrix[r][0] << " " << pose.rotationMatrix[r][1] << " " << pose.rotationMatrix[r][2] << "\n";
+        return os << "  p = " << pose.position[0] << " " << pose.position[1] << " " << pose.position[2];
+    }
+};
+
+/// [linear; angular] momentum about the centre of mass: a 6-vector that also answers to the one member of pinocchio::Force the reference's example
+/// calls on it (example/rbd/robot.example.cpp:127-141: `.toVector_impl()`).
+template <class S>
+struct SpatialMomentum : VectorX<S> {
+    using VectorX<S>::VectorX;
+    using VectorX<S>::operator=;
+    const VectorX<S>& toVector_impl() const {
+        return *this;
+    }
 };
 
 /// Results of the algorithms (field names follow pinocchio::Data).
 template <class S>
 struct Data {
     std::vector<Pose<S>> oMf;  // world placements of Model().frames
-    VectorX<S> ddq, tau, nle, g, hg;
+    VectorX<S> ddq, tau, nle, g;
+    SpatialMomentum<S> hg;
     MatrixX<S> M, Minv, Ag, Ig;
     Vector3<S> com, vcom, acom;
     S kinetic_energy{0.0}, potential_energy{0.0};

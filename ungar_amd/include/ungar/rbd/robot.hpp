@@ -11,23 +11,31 @@
 #include <random>
 #include <string>
 
+#include "../utils/utils.hpp"  // (as the reference's rbd/robot.hpp: user code that includes only this header uses Utils::...)
 #include "quantities/quantities.hpp"
 
 namespace Ungar {
+namespace RBD {
+/// Free-flyer-rooted model of a robot description file (URDF or the `.robot` text form), with what Robot::Model() exposes.
+inline ModelInfo BuildModelInfo(const std::string& descriptionFilename) {
+    namespace rbd = ::ungar_amd::rbd;
+    ModelInfo model;
+    model.impl = rbd::BuildModel(rbd::ReadRobotDescription(descriptionFilename));
+    model.name = model.impl.name;
+    model.nq = model.impl.nq;
+    model.nv = model.impl.nv;
+    model.njoints = model.impl.NumJoints();
+    for (const auto& j : model.impl.joints) model.names.push_back(j.name);
+    for (const auto& f : model.impl.frames) model.frameNames.push_back(f.name);
+    model.nframes = static_cast<int>(model.frameNames.size());
+    return model;
+}
+}  // namespace RBD
 
 template <Concepts::Scalar S = real_t>
 class Robot {
   public:
-    explicit Robot(const std::string& descriptionFilename) : _data{std::make_unique<RBD::Data<S>>()} {
-        namespace rbd = ::ungar_amd::rbd;
-        _model.impl = rbd::BuildModel(rbd::ReadRobotDescription(descriptionFilename));
-        _model.name = _model.impl.name;
-        _model.nq = _model.impl.nq;
-        _model.nv = _model.impl.nv;
-        _model.njoints = _model.impl.NumJoints();
-        for (const auto& j : _model.impl.joints) _model.names.push_back(j.name);
-        for (const auto& f : _model.impl.frames) _model.frameNames.push_back(f.name);
-        _model.nframes = static_cast<int>(_model.frameNames.size());
+    explicit Robot(const std::string& descriptionFilename) : _model{RBD::BuildModelInfo(descriptionFilename)}, _data{std::make_unique<RBD::Data<S>>()} {
     }
     Robot(const Robot& other) : _model{other._model}, _data{std::make_unique<RBD::Data<S>>()} {
     }
@@ -42,6 +50,13 @@ class Robot {
     decltype(auto) Get(auto quantity) {
         auto getter = RBD::Getter<quantity, S>{_model, *_data};
         return getter.Get();
+    }
+    /// Getters with arguments (user-defined quantities, example/rbd/quantity.example.cpp:118-163: a frame by index or by name).
+    template <class... Args>
+        requires(sizeof...(Args) > 0)
+    decltype(auto) Get(auto quantity, Args&&... args) {
+        auto getter = RBD::Getter<quantity, S>{_model, *_data};
+        return getter.Get(std::forward<Args>(args)...);
     }
 
     const RBD::ModelInfo& Model() const {
@@ -101,3 +116,30 @@ class Robot {
 };
 
 }  // namespace Ungar
+
+/// The handful of Pinocchio names the reference's own rbd test and examples spell out (test/rbd/robot.test.cpp:99-107, 118-121;
+/// example/rbd/quantity.example.cpp:86-163), on ungar_amd's model: `pinocchio::Model` is what Robot::Model() returns, `DataTpl` what the evaluators write to.
+namespace pinocchio {
+using Model = ::Ungar::RBD::ModelInfo;
+template <class S>
+using ModelTpl = ::Ungar::RBD::ModelInfo;
+template <class S>
+using DataTpl = ::Ungar::RBD::Data<S>;
+using SE3 = ::Ungar::RBD::Pose<::Ungar::real_t>;
+struct JointModelFreeFlyer {};  // the root joint is always a free-flyer here
+namespace urdf {
+inline Model& buildModel(const std::string& filename, const JointModelFreeFlyer& /*rootJoint*/, Model& model) {
+    model = ::Ungar::RBD::BuildModelInfo(filename);
+    return model;
+}
+}  // namespace urdf
+/// World placements of every frame (the joint placements of pinocchio::forwardKinematics and the frame update in one pass)
+template <class S, class Q>
+inline void forwardKinematics(const ModelTpl<S>& model, DataTpl<S>& data, const Q& q) {
+    ::Ungar::RBD::Evaluator<::Ungar::RBD::Quantities::frames, S>{model, data}.At(q);
+}
+template <class S>
+inline const ::Ungar::RBD::Pose<S>& updateFramePlacement(const ModelTpl<S>& /*model*/, DataTpl<S>& data, const std::size_t frameId) {
+    return data.oMf[frameId];  // (already placed by forwardKinematics above)
+}
+}  // namespace pinocchio

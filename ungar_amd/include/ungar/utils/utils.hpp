@@ -192,6 +192,24 @@ inline bool CompareMatrices(const real_t* a, std::string_view nameA, const real_
     return ok;
 }
 
+/// The reference's form (utils.hpp:1062-1137): two dense matrix / vector expressions of equal shape.
+template <class A, class B>
+    requires requires(const A& a, const B& b) { a.size(); b.size(); a.rows(); b.cols(); }
+inline bool CompareMatrices(const A& a, std::string_view nameA, const B& b, std::string_view nameB, real_t relTol = 1e-2, real_t absTol = 1e-3, bool verbose = true) {
+    if (a.rows() != b.rows() || a.cols() != b.cols()) {
+        if (verbose) std::fprintf(stderr, "[ungar] size mismatch: %.*s is %td x %td, %.*s is %td x %td\n", static_cast<int>(nameA.size()), nameA.data(), static_cast<index_t>(a.rows()),
+                                  static_cast<index_t>(a.cols()), static_cast<int>(nameB.size()), nameB.data(), static_cast<index_t>(b.rows()), static_cast<index_t>(b.cols()));
+        return false;
+    }
+    std::vector<real_t> va(static_cast<std::size_t>(a.size())), vb(static_cast<std::size_t>(b.size()));
+    for (index_t c = 0; c < static_cast<index_t>(a.cols()); ++c)
+        for (index_t r = 0; r < static_cast<index_t>(a.rows()); ++r) {
+            va[static_cast<std::size_t>(c * a.rows() + r)] = a(r, c);
+            vb[static_cast<std::size_t>(c * a.rows() + r)] = b(r, c);
+        }
+    return CompareMatrices(va.data(), nameA, vb.data(), nameB, static_cast<index_t>(va.size()), relTol, absTol, verbose);
+}
+
 /// CamelCase -> snake_case; digits kept, any other non-letter becomes '_' (reference utils.hpp:499-522: "CCWord" -> "cc_word").
 inline std::string ToSnakeCase(std::string_view in) {
     std::string out;

@@ -107,6 +107,10 @@ constexpr auto enumerate(Const<V>) {
     return std::views::iota(static_cast<index_t>(0), V);
 }
 
+/// `range | cast_to<T>` (reference data_types.hpp:393-396): the elements converted to T
+template <class T>
+inline constexpr auto cast_to = std::views::transform([](auto&& el) -> decltype(auto) { return static_cast<T>(std::forward<decltype(el)>(el)); });
+
 template <std::size_t N>
 struct fixed_string {
     constexpr fixed_string(const char (&str)[N]) {  // NOLINT
