@@ -76,6 +76,14 @@ __device__ __forceinline__ void WaveLdsFence() {
     __builtin_amdgcn_wave_barrier();
 }
 
+/// 16-byte pieces (two doubles, counted from the start of the block) of a row-major n x n block that hold at least one entry on or right of the diagonal, row by
+/// row (a piece shared by two rows counts twice: harmless) -- what the recursion reads of a stage Hessian, of which only the upper triangle is meaningful.
+constexpr int UpperTrianglePieces(int n) {
+    int count = 0;
+    for (int r = 0; r < n; ++r) count += ((r * n + n - 1) >> 1) - ((r * n + r) >> 1) + 1;
+    return count;
+}
+
 template <int NX, int NU>
 struct WaveSizes {
     static constexpr int n = NX + NU, nk = NX + 1;
@@ -121,7 +129,24 @@ __global__ __launch_bounds__(64, WAVES_PER_EU) void RiccatiWaveKernel(const Ricc
     // instructions.  (All wavefronts reach the same point of the recursion together and ask for 34 KB each: requested where they are needed, the device waits
     // for HBM -- 17 us per knot of the 37 + 12 problem -- and computes afterwards.  The LDS-DMA path needs no staging registers, but its instructions take
     // 200+ cycles each to issue here, 37 of them per knot: measured, 8 k cycles per knot even between matrix instructions.)
-    constexpr int abBytes = NX * n * 8, wBytes = n * n * 8, abPieces = (abBytes + 1023) / 1024, wPieces = (wBytes + 1023) / 1024, pieces = abPieces + wPieces;
+    // Of the stage Hessian only the upper triangle is fetched (the rest of the block is never read: half the bytes of the largest operand): the 16-byte pieces
+    // that hold an entry on or right of the diagonal, dealt to the lanes in order; a lane's piece offsets are the same for every knot and computed once.
+    constexpr int abBytes = NX * n * 8, wBytes = n * n * 8, abPieces = (abBytes + 1023) / 1024, wPieces = (UpperTrianglePieces(n) + 63) / 64, pieces = abPieces + wPieces;
+    int wOff[wPieces];
+#pragma unroll
+    for (int i = 0; i < wPieces; ++i) wOff[i] = kOutOfRange;
+    {
+        int begin = 0;
+        for (int r = 0; r < n; ++r) {
+            const int first = (r * n + r) >> 1, count = ((r * n + n - 1) >> 1) - first + 1;
+#pragma unroll
+            for (int i = 0; i < wPieces; ++i) {
+                const int q = 64 * i + lane - begin;
+                if (q >= 0 && q < count) wOff[i] = (first + q) * 16;
+            }
+            begin += count;
+        }
+    }
     // (measured and dropped: all shares requested during the first two column tiles and stored after the last one -- the staging registers of a whole knot,
     // 136 for 37 + 12, spill: 1.48 -> 2.4 ms)
     constexpr int kRequestTiles = NT, perTile = (pieces + kRequestTiles - 1) / kRequestTiles;
@@ -133,7 +158,7 @@ __global__ __launch_bounds__(64, WAVES_PER_EU) void RiccatiWaveKernel(const Ricc
         for (int i = 0; i < perTile; ++i) {
             const int p = i * kRequestTiles + tile;
             if (p < abPieces) stage[i] = BufferLoad16(rsJ, lane * 16, p * 1024);  // (beyond the block: zeros, not stored)
-            else if (p < pieces) stage[i] = BufferLoad16(rsW, lane * 16, (p - abPieces) * 1024);
+            else if (p < pieces) stage[i] = BufferLoad16(rsW, wOff[p - abPieces], 0);
         }
         if (tile == 0) {
             stageB = BufferLoad(BufferOver(&a.b.at(inst, k, 0), NX), lane * 8, 0);
@@ -146,10 +171,10 @@ __global__ __launch_bounds__(64, WAVES_PER_EU) void RiccatiWaveKernel(const Ricc
             const int p = i * kRequestTiles + tile;
             if (p >= pieces) continue;
             const bool first = p < abPieces;
-            const int off = (first ? p : p - abPieces) * 1024 + lane * 16, bytes = first ? abBytes : wBytes;
-            double* dst = (first ? ABl : Wl) + off / 8;
-            if (off + 16 <= bytes) *reinterpret_cast<v4i*>(dst) = stage[i];
-            else if (off + 8 <= bytes) *dst = __hiloint2double(stage[i][1], stage[i][0]);  // an odd number of doubles: the last one
+            const int off = first ? p * 1024 + lane * 16 : wOff[p - abPieces], bytes = first ? abBytes : wBytes;  // (a lane without a piece: kOutOfRange < 0, nothing stored)
+            double* dst = (first ? ABl : Wl) + (off >= 0 ? off : 0) / 8;
+            if (off >= 0 && off + 16 <= bytes) *reinterpret_cast<v4i*>(dst) = stage[i];
+            else if (off >= 0 && off + 8 <= bytes) *dst = __hiloint2double(stage[i][1], stage[i][0]);  // an odd number of doubles: the last one
         }
         if (tile == 0) {
             if (lane < NX) bl[lane] = stageB;
