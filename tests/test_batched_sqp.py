@@ -14,6 +14,8 @@ import os
 import re
 import subprocess
 
+import numpy as np
+
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -33,29 +35,58 @@ def test_batched_sqp_equals_the_whole_horizon_facade(repo_root, tmp_path, proble
         assert total == batch and moved >= batch // 2  # the comparison is not vacuous: steps are taken
 
 
-def test_assembly_kernel_sections_give_the_same_bits(repo_root, tmp_path):
-    """The shooting assembly kernel runs stage nodes with few equality rows (the quadruped: 16 x 50 tableau) through wavefront-specialised
-    sections -- Gauss-Jordan elimination in the registers of one wavefront, barrier terms without workgroup barriers -- and
-    everything else, or everything under UNGAR_AMD_ASSEMBLE_GENERIC=1, through the generic sections.  Same pivot rule, same arithmetic:
-    the assembled QP data (AB, b, W, w, reduced equality rows and residuals, printed with 17 digits) and both steps of the compared
-    instances must agree to the last bit, over two SQP iterations."""
+def test_assembly_kernels_agree(repo_root, tmp_path):
+    """Three routes through the shooting assembly: the one-wavefront kernel (quadruped-shaped stage nodes: tiles of W and [A|B] in registers, the linear
+    terms as the homogeneous column of the matrix-core products), the workgroup kernel with its wavefront-specialised sections
+    (UNGAR_AMD_ASSEMBLE_VARIANT=workgroup), and the workgroup kernel's generic sections (UNGAR_AMD_ASSEMBLE_GENERIC=1).  Same pivot
+    rule and the same arithmetic in the two workgroup routes: the assembled QP data (AB, b, W, w, reduced equality rows and residuals, printed with
+    17 digits) and both steps of the compared instances agree to the last bit over two SQP iterations.  The one-wavefront kernel sums w' and b' on
+    the matrix cores in another order: same pivots, data and steps within 1e-9 of each block's largest entry."""
     exe = os.path.join(repo_root, "build", "batched_quadruped_test")
     assert os.path.exists(exe), f"{exe} missing: run __graft_entry__.build()"
     dumps = {}
-    for mode in ("specialised", "generic"):
+    for mode in ("wavefront", "workgroup", "generic"):
         env = dict(os.environ)
         env.pop("UNGAR_AMD_ASSEMBLE_GENERIC", None)
+        env.pop("UNGAR_AMD_ASSEMBLE_VARIANT", None)
         if mode == "generic":
             env["UNGAR_AMD_ASSEMBLE_GENERIC"] = "1"
+        if mode == "workgroup":
+            env["UNGAR_AMD_ASSEMBLE_VARIANT"] = "workgroup"
         folder = tmp_path / mode
         folder.mkdir()
         r = subprocess.run([exe, str(tmp_path / "codegen"), "256", "3", str(folder)], capture_output=True, text=True, timeout=1500, env=env)
         print(r.stdout[-2000:], r.stderr[-1000:])
         assert r.returncode == 0 and "PASS batched quadruped SQP (batch 256, 3 compared)" in r.stdout
         dumps[mode] = {f.name: f.read_bytes() for f in sorted(folder.iterdir())}
-    assert len(dumps["specialised"]) >= 6 and dumps["specialised"].keys() == dumps["generic"].keys()  # 3 instances x 2 iterations
-    for name, data in dumps["specialised"].items():
-        assert len(data) > 100_000 and data == dumps["generic"][name], f"{name}: the two code paths disagree"
+    assert len(dumps["workgroup"]) >= 6 and dumps["workgroup"].keys() == dumps["generic"].keys() == dumps["wavefront"].keys()  # 3 instances x 2 iterations
+    for name, data in dumps["workgroup"].items():
+        assert len(data) > 100_000 and data == dumps["generic"][name], f"{name}: the two workgroup code paths disagree"
+
+    def blocks(data):
+        lines = data.decode().split("\n")
+        N, nz, nu, ne, nc = map(int, lines[0].split())
+        values = np.array([float(x) for x in lines[1:] if x.strip()])
+        nd = nz + nu
+        sizes = [("AB", N * nz * nd), ("b", N * nz), ("W", (N + 1) * nd * nd), ("w", (N + 1) * nd), ("E", N * ne * nd), ("e", (N + 1) * ne), ("dz0", nz), ("dZ", (N + 1) * nz), ("dU", N * nu)]
+        out, at = {}, 0
+        for key, n in sizes:
+            out[key] = values[at:at + n]
+            at += n
+        out["d_facade"] = values[at:]
+        return out
+
+    differs = 0
+    for name, data in dumps["wavefront"].items():
+        mine, theirs = blocks(data), blocks(dumps["workgroup"][name])
+        for key, block in theirs.items():
+            scale = max(float(np.max(np.abs(block))), 1e-300)
+            worst = float(np.max(np.abs(mine[key] - block))) / scale
+            assert worst <= 1e-9, f"{name} {key}: {worst:.3e}"
+            differs += worst > 0.0
+        # the pivot structure is the same: the reduced rows have their exact 0 / 1 entries in the same places
+        assert np.array_equal(mine["E"] == 1.0, theirs["E"] == 1.0) and np.array_equal(mine["E"] == 0.0, theirs["E"] == 0.0), name
+    assert differs > 0  # (the one-wavefront kernel did run: bitwise equality everywhere would mean the workgroup kernel was compared with itself)
 
 
 def test_line_search_candidates_in_groups_give_the_same_iterates(repo_root, tmp_path):

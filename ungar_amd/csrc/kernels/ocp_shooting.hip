@@ -732,6 +732,384 @@ __global__ __launch_bounds__(256, UNGAR_ASSEMBLE_WAVES_PER_EU) void ShootingAsse
 #endif
 }
 
+/// ONE WAVEFRONT per node, for stage problems whose equality tableau fits the lanes (NE <= 16 rows, ND + 1 <= 64 columns: the quadruped's 16 x 50) -- the
+/// workgroup kernel above spends ~9.8 k vector instructions per node, most of them index arithmetic in front of LDS operands that every 16 x 16 tile of the
+/// substitution fetches again (18 tiles x 5 operands x 4 k-steps), and a workgroup barrier between its sections.  Here
+///   * the quadratic and the linear part travel together in HOMOGENEOUS coordinates z_e = [z; 1]:  W_e = [W w; w^T 0],  [A|B]_e = [A|B  b],  G_e = [G | g0] --
+///     the substitution  z = (I - E_J G_e) z_e  is then  W_e' = W_e - W_e[:,J] G_e - G_e^T W_e[J,:] + G_e^T W_JJ G_e,  [A|B]_e' = [A|B]_e - [A|B]_e[:,J] G_e,  with
+///     w' and b' as column ND of the tiles (three separate matrix-vector sections before);
+///   * the tiles of W_e and [A|B]_e live in accumulator registers, and the operands of the products are fetched ONCE per (tile row, k-step): by symmetry
+///     -W_e[:,J] in A layout is also -W_e[J,:] in B layout, and G_e in B layout is also G_e^T in A layout (lane 16 k + i in both);
+///   * V = W_JJ G_e stays in the accumulators it was computed in: element r of a tile is the B operand of k-step r;
+///   * one LDS region holds the packed image of W_e, then -- once its tiles are in registers -- the image of [A|B]_e: 17 KB of LDS per node, two nodes per SIMD;
+///   * results go to memory from the registers (the dummies' identity rows / zero columns are written, never formed).
+/// Same pivot rule, same arithmetic for the reduced rows, the pivots and the tiles of W' and [A|B]' as the kernel above (bitwise); w' and b' are summed by the
+/// matrix cores in a different order (rounding).
+template <int NZ, int NU, int NE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void ShootingAssembleWaveKernel(const ShootingAssembleArgs a) {
+    using f64x4 = __attribute__((__vector_size__(4 * sizeof(double)))) double;
+    constexpr int ND = NZ + NU, NH = ND + 1, LD = ND + 1, TD = (NH + 15) / 16, TZ = (NZ + 15) / 16, KS = (NE + 3) / 4;
+    constexpr int kImage = NH * (NH + 1) / 2 > NZ * NH ? NH * (NH + 1) / 2 : NZ * NH;  // packed W_e, later [A|B]_e (row stride NH)
+    constexpr int kImagePadded = (kImage + 1) & ~1;
+    static_assert(NE <= kRegisterRows && LD <= 64 && TD <= 4, "one wavefront holds the tableau");
+    extern __shared__ double lds[];
+    const ShootingDims& d = a.d;
+    const long long node = blockIdx.x;
+    const long long b = node / (d.N + 1);
+    const int k = static_cast<int>(node - b * (d.N + 1));
+    const int lane = static_cast<int>(threadIdx.x), lj = lane & 15, lk = lane >> 4;
+    const int nc = d.nc, nx = d.nx;
+    const bool stage = k < d.N;
+    double* R = lds;                       // kImagePadded
+    double* Ee = R + kImagePadded;         // NE x LD
+    double* d1 = Ee + NE * LD;             // nh
+    double* d2 = d1 + a.nh;                // nh
+    unsigned long long* rowScale = reinterpret_cast<unsigned long long*>(d2 + a.nh);  // NE
+    int* pivL = reinterpret_cast<int*>(rowScale + NE);                                  // NE
+    auto tri = [](int r, int c) { return ((r * (2 * NH + 1 - r)) >> 1) + (c - r); };  // r <= c < NH
+    auto sym = [&tri](int r, int c) { return r <= c ? tri(r, c) : tri(c, r); };
+    auto fence = [] { asm volatile("" ::: "memory"); };  // (for the compiler: the LDS instructions of one wavefront execute in order)
+    const long long nodeOff = node, stageOff = b * d.N + k;
+    // ---- requests: every sparse value of the node, up to kSlots per lane and output (the launcher checks the patterns against these bounds)
+    constexpr int kSlotsH = 4, kSlotsF = 4, kSlotsC = 2, kSlotsE = 4;
+    struct Entry {
+        int target;  // < 0: none
+        double value;
+    };
+    auto request = [&](const StagePattern& pattern, const double* values, bool wanted, int slot, auto targetOf) {
+        Entry f{-1, 0.0};
+        const int e = lane + 64 * slot;
+        if (wanted && values && slot * 64 < pattern.nnz) {  // (uniform)
+            const int ec = e < pattern.nnz ? e : pattern.nnz - 1;  // (clamped: the loads are unconditional, the lane's entry is dropped below)
+            const int r = pattern.rows ? pattern.rows[ec] : 0, c = pattern.cols[ec];
+            const double v = values[nodeOff * pattern.nnz + ec];
+            f.target = e < pattern.nnz ? targetOf(r, c) : -1;
+            f.value = v;
+        }
+        return f;
+    };
+    auto hessianTarget = [&](int r, int c) { return r <= c ? tri(r, c) : -1; };
+    auto gradientTarget = [&](int, int c) { return tri(c, ND); };
+    auto dynamicsTarget = [&](int r, int c) { return (nc + r) * NH + nc + c; };
+    auto carryTarget = [&](int r, int c) { return r * NH + nc + c; };
+    auto equalityTarget = [&](int r, int c) { return (r << 8) | c; };  // (row kept: its scale is collected with the entry)
+    Entry eH[kSlotsH], eF[kSlotsF], eC[kSlotsC], eE[kSlotsE];
+#pragma unroll
+    for (int s = 0; s < kSlotsH; ++s) eH[s] = request(a.pH, a.lH, true, s, hessianTarget);
+    const Entry eG = request(a.pg, a.lg, true, 0, gradientTarget);
+#pragma unroll
+    for (int s = 0; s < kSlotsE; ++s) eE[s] = request(a.pe, a.eJ, stage, s, equalityTarget);
+    const double residual = stage && a.e && lane < NE ? a.e[nodeOff * NE + lane] : 0.0;
+    const double hMine = stage && lane < a.nh ? a.h[nodeOff * a.nh + lane] : 0.0;
+    const bool ownsInequalityEntry = stage && a.nh > 0 && lane < a.ph.nnz;
+    const int inequalityRow = ownsInequalityEntry ? a.ph.rows[lane] : -1, inequalityColumn = ownsInequalityEntry ? a.ph.cols[lane] : 0;
+    const double inequalityValue = ownsInequalityEntry ? a.hJ[nodeOff * a.ph.nnz + lane] : 0.0;
+#pragma unroll
+    for (int s = 0; s < kSlotsF; ++s) eF[s] = request(a.pf, a.fJ, stage, s, dynamicsTarget);
+#pragma unroll
+    for (int s = 0; s < kSlotsC; ++s) eC[s] = request(a.pc, a.cJ, stage && !d.carryInputs, s, carryTarget);
+    double defect = 0.0;  // lane i < NZ: b[i]
+    if (stage && lane >= nc && lane < NZ) defect = a.f[nodeOff * nx + (lane - nc)] - RowOf(a.rows, d, b, k + 1)[lane];
+    double dz0 = 0.0;
+    if (k == 0 && lane >= nc && lane < NZ) dz0 = a.xm[b * nx + (lane - nc)] - RowOf(a.rows, d, b, 0)[lane];
+    // ---- images
+    const int zeroed = kImagePadded + NE * LD + 2 * a.nh;
+    for (int i = lane; i < zeroed; i += 64) lds[i] = 0.0;
+    if (lane < NE) rowScale[lane] = 0ull;
+    fence();
+#pragma unroll
+    for (int s = 0; s < kSlotsH; ++s)
+        if (eH[s].target >= 0) R[eH[s].target] = eH[s].value;
+    if (eG.target >= 0) R[eG.target] = eG.value;
+    double* W = a.W + nodeOff * ND * ND;
+    double* w = a.w + nodeOff * ND;
+    if (!stage) {  // knot N: the terminal cost as it is (regularised over its state), no dynamics, no rows
+        fence();
+        if (lane >= nc && lane < NZ) R[tri(lane, lane)] += a.regularization;
+        fence();
+        const float ndInv = 1.0f / static_cast<float>(ND);
+        for (int idx = lane; idx < ND * ND; idx += 64) {
+            const int r = static_cast<int>((static_cast<float>(idx) + 0.5f) * ndInv);
+            if (r <= idx - r * ND) W[idx] = R[tri(r, idx - r * ND)];
+        }
+        if (lane < ND) w[lane] = R[tri(lane, ND)];
+        return;
+    }
+    auto offerScale = [&](int row, double value) {  // (non-negative doubles order like their bit patterns)
+        const unsigned long long bits = static_cast<unsigned long long>(__double_as_longlong(fabs(value)));
+        if (bits) atomicMax(&rowScale[row], bits);
+    };
+#pragma unroll
+    for (int s = 0; s < kSlotsE; ++s)
+        if (eE[s].target >= 0) {
+            Ee[(eE[s].target >> 8) * LD + (eE[s].target & 255)] = eE[s].value;
+            offerScale(eE[s].target >> 8, eE[s].value);
+        }
+    if (lane < NE) {
+        Ee[lane * LD + ND] = residual;
+        offerScale(lane, residual);
+    }
+    if (lane < a.nh) {
+        d1[lane] = BarrierD1(a.barrier, -hMine);
+        d2[lane] = BarrierD2(a.barrier, -hMine);
+    }
+    fence();
+    // ---- barrier terms  W += J_h^T diag(b''(-h)) J_h,  w -= J_h^T b'(-h)  from the sparse inequality Jacobian (the single-wavefront job of the kernel above)
+    if (a.nh > 0) {
+        const int nnz = a.ph.nnz, mine = lane < nnz ? lane : -1;
+        const int myRow = inequalityRow, myCol = inequalityColumn;
+        const double myValue = inequalityValue;
+        const int nextRow = __shfl_down(myRow, 1);
+        const unsigned long long rowEnds = __ballot(mine >= 0 && (mine == nnz - 1 || nextRow != myRow));
+        const int partners = mine >= 0 ? __ffsll(static_cast<unsigned long long>(rowEnds >> mine)) : 0;
+        int pairFirst = -1, pairOffset = 0, pairs = 0;
+        for (int e1 = 0; e1 < nnz; ++e1) {
+            const int count = __builtin_amdgcn_readlane(partners, e1);
+            if (lane >= pairs && lane < pairs + count) {
+                pairFirst = e1;
+                pairOffset = lane - pairs;
+            }
+            pairs += count;
+        }
+        if (pairs <= 64) {
+            const bool havePair = pairFirst >= 0;
+            const int first = havePair ? pairFirst : 0, second = havePair ? pairFirst + pairOffset : 0;
+            const int pairRowAny = __shfl(myRow, first), c1 = __shfl(myCol, first), c2 = __shfl(myCol, second);
+            const double v1 = __shfl(myValue, first), v2 = __shfl(myValue, second);
+            const int pairRow = havePair ? pairRowAny : -1, target = havePair ? tri(c1, c2) : 0, gTarget = tri(myCol, ND);
+            const double d1Mine = myRow >= 0 ? d1[myRow] : 0.0, d2Mine = havePair ? d2[pairRow] : 0.0;
+            for (int j = 0; j < a.nh; ++j) {
+                const bool g = myRow == j, ww = pairRow == j;
+                double g0 = 0.0, w0 = 0.0;
+                if (g) g0 = R[gTarget];
+                if (ww) w0 = R[target];
+                if (g) R[gTarget] = __builtin_fma(-d1Mine, myValue, g0);
+                if (ww) R[target] = __builtin_fma(d2Mine * v1, v2, w0);
+                fence();
+                __builtin_amdgcn_wave_barrier();
+            }
+        } else {
+            for (int j = 0; j < a.nh; ++j) {
+                if (myRow == j) {
+                    R[tri(myCol, ND)] -= d1[j] * myValue;
+                    for (int q = 0; q < partners; ++q) R[tri(myCol, a.ph.cols[mine + q])] += d2[j] * myValue * a.hJ[nodeOff * nnz + mine + q];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+    if (lane >= nc && lane < ND) R[tri(lane, lane)] += a.regularization;  // the reference's 1e-6 I over its decision variables (soft_sqp.hpp:149-151)
+    fence();
+    // ---- Gauss-Jordan on [C | D | e], lane = column, the rows in registers (the elimination job of the kernel above, statement by statement)
+    double t[NE];
+#pragma unroll
+    for (int r = 0; r < NE; ++r) t[r] = lane < LD ? Ee[r * LD + lane] : 0.0;
+    unsigned nonZeroRows = 0u;
+#pragma unroll
+    for (int r = 0; r < NE; ++r) nonZeroRows |= (__double_as_longlong(t[r]) << 1) != 0ll ? 1u << r : 0u;
+    nonZeroRows = WaveOr(nonZeroRows);
+    const double scaleOfMyRow = lane < NE ? __longlong_as_double(static_cast<long long>(rowScale[lane])) : 0.0;
+    unsigned long long taken = 0ull;  // inputs that are pivots already (wave-uniform)
+    unsigned pivotRows = 0u;          // rows that took a pivot (wave-uniform)
+    int myPivot = -1;                 // lane i < NE: pivot input of row i
+    const int myInput = lane - NZ;
+    const bool inputLane = lane >= NZ && lane < ND;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        if ((nonZeroRows >> i) & 1u) {  // (uniform; an identically-zero row takes no pivot: -1)
+            const unsigned long long bits = static_cast<unsigned long long>(__double_as_longlong(fabs(t[i])));
+            const bool candidate = bits != 0ull && inputLane && !((taken >> (myInput & 63)) & 1ull);
+            unsigned long long key = candidate ? (bits & ~0xFFull) | static_cast<unsigned long long>(255 - myInput) : 0ull, rowBits = bits;
+            WaveMaxPair(key, rowBits);
+            const double best = __longlong_as_double(static_cast<long long>(key & ~0xFFull)), rowMax = __longlong_as_double(static_cast<long long>(rowBits));
+            int j = key ? 255 - static_cast<int>(key & 0xFFull) : -1;
+            if (rowMax <= 1e-12 * ReadLane(scaleOfMyRow, i)) {
+                j = -1;
+            } else {
+                if (j >= 0 && best <= 1e-12 * rowMax) j = -2;
+                if (j == -1 && rowMax > 0.0) j = -2;
+            }
+            if (lane == i) myPivot = j;
+            if (j >= 0) {
+                taken |= 1ull << j;
+                pivotRows |= 1u << i;
+                const int J = NZ + j;
+                const double rpiv = 1.0 / ReadLane(t[i], J);
+                const double p = lane == J ? 1.0 : t[i] * rpiv;
+#pragma unroll
+                for (int r = 0; r < NE; ++r) {
+                    if (r == i) continue;
+                    const double m = ReadLane(t[r], J);
+                    t[r] = t[r] - m * p;
+                }
+                t[i] = p;
+            }
+        }
+    }
+    // the reduced rows, their residuals and pivots: to memory from the registers, and back to the LDS tableau the operands below are gathered from
+    {
+        double* E = a.E + stageOff * NE * ND;
+#pragma unroll
+        for (int r = 0; r < NE; ++r) {
+            if (lane < ND) E[r * ND + lane] = t[r];
+            if (lane < LD) Ee[r * LD + lane] = t[r];
+            if (lane == ND) a.er[stageOff * NE + r] = t[r];
+        }
+        if (lane < NE) {
+            a.pivots[stageOff * NE + lane] = myPivot;
+            pivL[lane] = myPivot;
+        }
+    }
+    fence();
+    auto isPivot = [&](int c) { return c >= NZ && c < ND && ((taken >> ((c - NZ) & 63)) & 1ull) != 0ull; };
+    auto masked = [](double v, bool keep) { return __longlong_as_double(keep ? __double_as_longlong(v) : 0ll); };
+    // ---- operands, once per (tile row, k-step).  Row t = 4 ks + lk of the tableau, J_t its pivot input (rows without a pivot are masked out)
+    int pivotOfStep[KS];
+    bool stepHasPivot[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int tRow = 4 * ks + lk;
+        stepHasPivot[ks] = tRow < NE && ((pivotRows >> tRow) & 1u) != 0u;
+        const int j = pivL[tRow < NE ? tRow : NE - 1];
+        pivotOfStep[ks] = NZ + (stepHasPivot[ks] ? j : 0);
+    }
+    const bool anyPivot = pivotRows != 0u;
+    double gm[KS][TD];   // G_e in B layout = G_e^T in A layout: row 4 ks + lk, column 16 tj + lj
+    double a1m[TD][KS];  // -W_e[16 ti + lj][J_t] in A layout = -W_e[J_t][16 tj + lj] in B layout
+    double wjj[KS];      // W[J_lj][J_t]
+    const int pivotOfMyRow = NZ + (lj < NE && ((pivotRows >> lj) & 1u) ? pivL[lj < NE ? lj : 0] : 0);
+    const bool myRowHasPivot = lj < NE && ((pivotRows >> lj) & 1u) != 0u;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+        for (int tj = 0; tj < TD; ++tj) {
+            const int col = 16 * tj + lj, tRow = 4 * ks + lk;
+            const bool in = col < LD && stepHasPivot[ks];
+            gm[ks][tj] = masked(Ee[(tRow < NE ? tRow : NE - 1) * LD + (col < LD ? col : LD - 1)], in);
+        }
+#pragma unroll
+        for (int ti = 0; ti < TD; ++ti) {
+            const int row = 16 * ti + lj;
+            const bool in = row < NH && stepHasPivot[ks];
+            a1m[ti][ks] = masked(-R[sym(row < NH ? row : NH - 1, pivotOfStep[ks])], in);
+        }
+        wjj[ks] = masked(R[sym(pivotOfMyRow, pivotOfStep[ks])], myRowHasPivot && stepHasPivot[ks]);
+    }
+    // ---- the tiles of W_e (on and above the diagonal), element r: row 16 ti + lk + 4 r, column 16 tj + lj; below the diagonal of a diagonal tile the transposed entry
+    f64x4 Wt[TD * (TD + 1) / 2];
+#pragma unroll
+    for (int tj = 0; tj < TD; ++tj)
+#pragma unroll
+        for (int ti = 0; ti <= tj; ++ti)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * ti + lk + 4 * r, col = 16 * tj + lj;
+                const bool in = row < NH && col < NH;
+                const int rc = row < NH ? row : NH - 1, cc = col < NH ? col : NH - 1;
+                Wt[tj * (tj + 1) / 2 + ti][r] = masked(R[ti == tj ? sym(rc, cc) : tri(rc, cc)], in);
+            }
+    fence();
+    // ---- the region becomes the image of [A|B]_e = [A|B  b] (row stride NH)
+    for (int i = lane; i < NZ * NH; i += 64) R[i] = 0.0;
+    fence();
+#pragma unroll
+    for (int s = 0; s < kSlotsF; ++s)
+        if (eF[s].target >= 0) R[eF[s].target] = eF[s].value;
+    if (d.carryInputs) {
+        if (lane < nc) R[lane * NH + NZ + lane] = 1.0;
+    } else {
+#pragma unroll
+        for (int s = 0; s < kSlotsC; ++s)
+            if (eC[s].target >= 0) R[eC[s].target] = eC[s].value;
+    }
+    if (lane < NZ) R[lane * NH + ND] = defect;
+    if (k == 0 && lane < NZ) a.dz0[b * NZ + lane] = dz0;
+    fence();
+    // ---- V = W_JJ G_e, then W_e' tile by tile
+    f64x4 Vt[TD];
+#pragma unroll
+    for (int tj = 0; tj < TD; ++tj) Vt[tj] = f64x4{0.0, 0.0, 0.0, 0.0};
+    if (anyPivot) {  // (uniform)
+#pragma unroll
+        for (int tj = 0; tj < TD; ++tj)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) Vt[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(wjj[ks], gm[ks][tj], Vt[tj], 0, 0, 0);
+#pragma unroll
+        for (int tj = 0; tj < TD; ++tj)
+#pragma unroll
+            for (int ti = 0; ti <= tj; ++ti) {
+                f64x4 acc = Wt[tj * (tj + 1) / 2 + ti], acc2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1m[ti][ks], gm[ks][tj], acc, 0, 0, 0);                  // - W[a][J_t] G_t[c]
+                    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(gm[ks][ti], Vt[tj][ks] + a1m[tj][ks], acc2, 0, 0, 0);  // + G_t[a] (V_t[c] - W[J_t][c])
+                }
+                Wt[tj * (tj + 1) / 2 + ti] = acc + acc2;
+            }
+    }
+    // W' and w' to memory; the eliminated inputs are decoupled dummies: identity rows / columns, zero gradient
+    bool rowPivot[TD][4], colPivot[TD];
+#pragma unroll
+    for (int ti = 0; ti < TD; ++ti) {
+        colPivot[ti] = isPivot(16 * ti + lj);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rowPivot[ti][r] = isPivot(16 * ti + lk + 4 * r);
+    }
+#pragma unroll
+    for (int tj = 0; tj < TD; ++tj)
+#pragma unroll
+        for (int ti = 0; ti <= tj; ++ti)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * ti + lk + 4 * r, col = 16 * tj + lj;
+                if (row > col || row >= ND || col > ND) continue;
+                const bool dummy = rowPivot[ti][r] || colPivot[tj];
+                const double v = dummy ? (row == col ? 1.0 : 0.0) : Wt[tj * (tj + 1) / 2 + ti][r];
+                if (col == ND) w[row] = v;
+                else W[row * ND + col] = v;
+            }
+    // ---- [A|B]_e' = [A|B]_e - [A|B]_e[:,J] G_e
+    double aAB[TZ][KS];
+    f64x4 ABt[TZ][TD];
+#pragma unroll
+    for (int ti = 0; ti < TZ; ++ti) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int row = 16 * ti + lj;
+            aAB[ti][ks] = masked(-R[(row < NZ ? row : NZ - 1) * NH + pivotOfStep[ks]], row < NZ && stepHasPivot[ks]);
+        }
+#pragma unroll
+        for (int tj = 0; tj < TD; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * ti + lk + 4 * r, col = 16 * tj + lj;
+                ABt[ti][tj][r] = masked(R[(row < NZ ? row : NZ - 1) * NH + (col < NH ? col : NH - 1)], row < NZ && col < NH);
+            }
+    }
+    if (anyPivot) {
+#pragma unroll
+        for (int ti = 0; ti < TZ; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < TD; ++tj)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) ABt[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(aAB[ti][ks], gm[ks][tj], ABt[ti][tj], 0, 0, 0);
+    }
+    double* AB = a.AB + stageOff * NZ * ND;
+    double* bo = a.b + stageOff * NZ;
+#pragma unroll
+    for (int ti = 0; ti < TZ; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < TD; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * ti + lk + 4 * r, col = 16 * tj + lj;
+                if (row >= NZ || col > ND) continue;
+                if (col == ND) bo[row] = ABt[ti][tj][r];
+                else AB[row * ND + col] = colPivot[tj] ? 0.0 : ABt[ti][tj][r];
+            }
+}
+
 /// One lane per (stage node, reduced row).
 __global__ __launch_bounds__(256) void ShootingRecoverKernel(const ShootingRecoverArgs a) {
     const ShootingDims& d = a.d;
@@ -933,8 +1311,26 @@ __global__ __launch_bounds__(kBlock) void ShootingSelectKernel(const ShootingSel
 
 using namespace ungar_amd::kernels;
 
+namespace {
+/// The one-wavefront kernel for this shape, if the node fits its bounds (0: launched; -1: not applicable, the caller takes the workgroup kernel).
+template <int NZ, int NU, int NE>
+int LaunchAssembleWave(const ShootingAssembleArgs* a, void* stream) {
+    constexpr int ND = NZ + NU, NH = ND + 1, kImage = NH * (NH + 1) / 2 > NZ * NH ? NH * (NH + 1) / 2 : NZ * NH, kImagePadded = (kImage + 1) & ~1;
+    const ShootingDims& d = a->d;
+    if (d.nz() != NZ || d.nu != NU || a->ne != NE || a->eliminate != 1) return -1;
+    if (a->nh > 64 || (a->nh > 0 && a->ph.nnz > 64) || a->pH.nnz > 256 || a->pg.nnz > 64 || a->pf.nnz > 256 || a->pe.nnz > 256 || (!d.carryInputs && a->pc.nnz > 128)) return -1;
+    const std::size_t lds = (kImagePadded + NE * (ND + 1) + 2 * static_cast<std::size_t>(a->nh) + NE) * sizeof(double) + NE * sizeof(int);
+    hipLaunchKernelGGL((ShootingAssembleWaveKernel<NZ, NU, NE>), dim3(static_cast<unsigned>(d.batch * (d.N + 1))), dim3(64), lds, static_cast<hipStream_t>(stream), *a);
+    return 0;
+}
+}  // namespace
+
 extern "C" int ungar_amd_launch_shooting_assemble(const ShootingAssembleArgs* a, void* stream) {
     if (a->d.batch <= 0) return 0;
+    {
+        const char* variant = getenv("UNGAR_AMD_ASSEMBLE_VARIANT");  // "workgroup": the kernel below for every shape (measurement, A/B tests); read per call
+        if (!(variant && variant[0] == 'w') && LaunchAssembleWave<25, 24, 16>(a, stream) == 0) return static_cast<int>(hipGetLastError());
+    }
     const std::size_t nd = static_cast<std::size_t>(a->d.nd()), nz = static_cast<std::size_t>(a->d.nz());
     const std::size_t ne = static_cast<std::size_t>(a->ne), nu = static_cast<std::size_t>(a->d.nu);
     const std::size_t lds = (nd * (nd + 1) / 2 + nd + 2 * static_cast<std::size_t>(a->nh) + nz * nd + 2 * ne * (nd + 1) + nz + (nd + 1) + 6 + ne /*row scales*/) * sizeof(double) +
