@@ -745,7 +745,7 @@ __global__ __launch_bounds__(256, UNGAR_ASSEMBLE_WAVES_PER_EU) void ShootingAsse
 ///   * results go to memory from the registers (the dummies' identity rows / zero columns are written, never formed).
 /// Same pivot rule, same arithmetic for the reduced rows, the pivots and the tiles of W' and [A|B]' as the kernel above (bitwise); w' and b' are summed by the
 /// matrix cores in a different order (rounding).
-template <int NZ, int NU, int NE>
+template <int NZ, int NU, int NE, bool CLOCKS = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void ShootingAssembleWaveKernel(const ShootingAssembleArgs a) {
     using f64x4 = __attribute__((__vector_size__(4 * sizeof(double)))) double;
     constexpr int ND = NZ + NU, NH = ND + 1, LD = ND + 1, TD = (NH + 15) / 16, TZ = (NZ + 15) / 16, KS = (NE + 3) / 4;
@@ -770,53 +770,84 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     auto sym = [&tri](int r, int c) { return r <= c ? tri(r, c) : tri(c, r); };
     auto fence = [] { asm volatile("" ::: "memory"); };  // (for the compiler: the LDS instructions of one wavefront execute in order)
     const long long nodeOff = node, stageOff = b * d.N + k;
+    unsigned long long marks[CLOCKS ? 12 : 1];  // UNGAR_AMD_ASSEMBLE_CLOCKS=1: cycles of the sections of two nodes, printed by their first lane
+    int markCount = 0;
+    auto mark = [&] {
+        if constexpr (CLOCKS) {
+            __builtin_amdgcn_sched_barrier(0);
+            marks[markCount++] = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    mark();
     // ---- requests: every sparse value of the node, up to kSlots per lane and output (the launcher checks the patterns against these bounds)
     constexpr int kSlotsH = 4, kSlotsF = 4, kSlotsC = 2, kSlotsE = 4;
     struct Entry {
         int target;  // < 0: none
         double value;
     };
-    auto request = [&](const StagePattern& pattern, const double* values, bool wanted, int slot, auto targetOf) {
-        Entry f{-1, 0.0};
-        const int e = lane + 64 * slot;
-        if (wanted && values && slot * 64 < pattern.nnz) {  // (uniform)
-            const int ec = e < pattern.nnz ? e : pattern.nnz - 1;  // (clamped: the loads are unconditional, the lane's entry is dropped below)
-            const int r = pattern.rows ? pattern.rows[ec] : 0, c = pattern.cols[ec];
-            const double v = values[nodeOff * pattern.nnz + ec];
-            f.target = e < pattern.nnz ? targetOf(r, c) : -1;
-            f.value = v;
-        }
+    struct Raw {
+        int r, c;
+        double value;
+        bool valid;
+    };
+    // (MUBUF loads against resources of exactly the pattern's size: a lane beyond the pattern -- or a whole output that is absent -- reads zeros from the range
+    // check, unconditionally, and nothing is computed from a loaded value before every request is out.  Written with conditions, every slot became a branch
+    // around its loads with a full wait behind it: 15 round trips to memory in a row, 24-43 k of a node's ~85 k cycles.)
+    auto resourceOver = [](const void* base, int bytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, base ? bytes : 0, 0x00020000); };
+    auto loadInt = [](__amdgpu_buffer_rsrc_t rs, int byteOffset) { return __builtin_amdgcn_raw_buffer_load_b32(rs, byteOffset, 0, 0); };
+    auto loadDouble = [](__amdgpu_buffer_rsrc_t rs, int byteOffset) { return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, byteOffset, 0, 0)); };
+    auto request = [&](const StagePattern& pattern, const double* values, bool wanted, int slot) {
+        const int nnz = wanted && values ? pattern.nnz : 0, e = lane + 64 * slot;
+        Raw f;
+        f.r = loadInt(resourceOver(pattern.rows, nnz * 4), e * 4);
+        f.c = loadInt(resourceOver(pattern.cols, nnz * 4), e * 4);
+        f.value = loadDouble(resourceOver(values ? values + nodeOff * pattern.nnz : nullptr, nnz * 8), e * 8);
+        f.valid = e < nnz;
         return f;
     };
+    auto resolve = [](const Raw& f, auto targetOf) { return Entry{f.valid ? targetOf(f.r, f.c) : -1, f.value}; };
     auto hessianTarget = [&](int r, int c) { return r <= c ? tri(r, c) : -1; };
     auto gradientTarget = [&](int, int c) { return tri(c, ND); };
     auto dynamicsTarget = [&](int r, int c) { return (nc + r) * NH + nc + c; };
     auto carryTarget = [&](int r, int c) { return r * NH + nc + c; };
     auto equalityTarget = [&](int r, int c) { return (r << 8) | c; };  // (row kept: its scale is collected with the entry)
-    Entry eH[kSlotsH], eF[kSlotsF], eC[kSlotsC], eE[kSlotsE];
+    Raw rH[kSlotsH], rF[kSlotsF], rC[kSlotsC], rE[kSlotsE];
 #pragma unroll
-    for (int s = 0; s < kSlotsH; ++s) eH[s] = request(a.pH, a.lH, true, s, hessianTarget);
-    const Entry eG = request(a.pg, a.lg, true, 0, gradientTarget);
+    for (int s = 0; s < kSlotsH; ++s) rH[s] = request(a.pH, a.lH, true, s);
+    const Raw rG = request(a.pg, a.lg, true, 0);
 #pragma unroll
-    for (int s = 0; s < kSlotsE; ++s) eE[s] = request(a.pe, a.eJ, stage, s, equalityTarget);
-    const double residual = stage && a.e && lane < NE ? a.e[nodeOff * NE + lane] : 0.0;
-    const double hMine = stage && lane < a.nh ? a.h[nodeOff * a.nh + lane] : 0.0;
-    const bool ownsInequalityEntry = stage && a.nh > 0 && lane < a.ph.nnz;
-    const int inequalityRow = ownsInequalityEntry ? a.ph.rows[lane] : -1, inequalityColumn = ownsInequalityEntry ? a.ph.cols[lane] : 0;
-    const double inequalityValue = ownsInequalityEntry ? a.hJ[nodeOff * a.ph.nnz + lane] : 0.0;
+    for (int s = 0; s < kSlotsE; ++s) rE[s] = request(a.pe, a.eJ, stage, s);
+    const double residual = loadDouble(resourceOver(a.e ? a.e + nodeOff * NE : nullptr, stage ? NE * 8 : 0), lane * 8);
+    const double hMine = loadDouble(resourceOver(a.h ? a.h + nodeOff * a.nh : nullptr, stage ? a.nh * 8 : 0), lane * 8);
+    const Raw rI = request(a.ph, a.hJ, stage && a.nh > 0, 0);
 #pragma unroll
-    for (int s = 0; s < kSlotsF; ++s) eF[s] = request(a.pf, a.fJ, stage, s, dynamicsTarget);
+    for (int s = 0; s < kSlotsF; ++s) rF[s] = request(a.pf, a.fJ, stage, s);
 #pragma unroll
-    for (int s = 0; s < kSlotsC; ++s) eC[s] = request(a.pc, a.cJ, stage && !d.carryInputs, s, carryTarget);
-    double defect = 0.0;  // lane i < NZ: b[i]
-    if (stage && lane >= nc && lane < NZ) defect = a.f[nodeOff * nx + (lane - nc)] - RowOf(a.rows, d, b, k + 1)[lane];
-    double dz0 = 0.0;
-    if (k == 0 && lane >= nc && lane < NZ) dz0 = a.xm[b * nx + (lane - nc)] - RowOf(a.rows, d, b, 0)[lane];
+    for (int s = 0; s < kSlotsC; ++s) rC[s] = request(a.pc, a.cJ, stage && !d.carryInputs, s);
+    // lane i < NZ: b[i] = [0; f - x_next],  dz0[i] = [0; x_m - x_0]  (a lane below nc reaches before the function's values: out of range, zero)
+    const double fMine = loadDouble(resourceOver(a.f + nodeOff * nx, stage ? nx * 8 : 0), (lane - nc) * 8);
+    const double nextMine = loadDouble(resourceOver(RowOf(a.rows, d, b, stage ? k + 1 : k), stage ? NZ * 8 : 0), lane * 8);
+    const double xmMine = loadDouble(resourceOver(a.xm + b * nx, k == 0 ? nx * 8 : 0), (lane - nc) * 8);
+    const double row0Mine = loadDouble(resourceOver(RowOf(a.rows, d, b, 0), k == 0 ? NZ * 8 : 0), lane * 8);
     // ---- images
     const int zeroed = kImagePadded + NE * LD + 2 * a.nh;
     for (int i = lane; i < zeroed; i += 64) lds[i] = 0.0;
     if (lane < NE) rowScale[lane] = 0ull;
     fence();
+    Entry eH[kSlotsH], eF[kSlotsF], eC[kSlotsC], eE[kSlotsE];
+#pragma unroll
+    for (int s = 0; s < kSlotsH; ++s) eH[s] = resolve(rH[s], hessianTarget);
+    const Entry eG = resolve(rG, gradientTarget);
+#pragma unroll
+    for (int s = 0; s < kSlotsE; ++s) eE[s] = resolve(rE[s], equalityTarget);
+#pragma unroll
+    for (int s = 0; s < kSlotsF; ++s) eF[s] = resolve(rF[s], dynamicsTarget);
+#pragma unroll
+    for (int s = 0; s < kSlotsC; ++s) eC[s] = resolve(rC[s], carryTarget);
+    const int inequalityRow = rI.valid ? rI.r : -1, inequalityColumn = rI.valid ? rI.c : 0;
+    const double inequalityValue = rI.value;
+    const double defect = lane >= nc && lane < NZ ? fMine - nextMine : 0.0, dz0 = lane >= nc && lane < NZ ? xmMine - row0Mine : 0.0;
 #pragma unroll
     for (int s = 0; s < kSlotsH; ++s)
         if (eH[s].target >= 0) R[eH[s].target] = eH[s].value;
@@ -854,6 +885,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         d2[lane] = BarrierD2(a.barrier, -hMine);
     }
     fence();
+    mark();  // 1: requests answered, images zeroed and filled
     // ---- barrier terms  W += J_h^T diag(b''(-h)) J_h,  w -= J_h^T b'(-h)  from the sparse inequality Jacobian (the single-wavefront job of the kernel above)
     if (a.nh > 0) {
         const int nnz = a.ph.nnz, mine = lane < nnz ? lane : -1;
@@ -901,6 +933,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
     if (lane >= nc && lane < ND) R[tri(lane, lane)] += a.regularization;  // the reference's 1e-6 I over its decision variables (soft_sqp.hpp:149-151)
     fence();
+    mark();  // 2: barrier terms, regularisation
     // ---- Gauss-Jordan on [C | D | e], lane = column, the rows in registers (the elimination job of the kernel above, statement by statement)
     double t[NE];
 #pragma unroll
@@ -947,6 +980,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             }
         }
     }
+    mark();  // 3: elimination
     // the reduced rows, their residuals and pivots: to memory from the registers, and back to the LDS tableau the operands below are gathered from
     {
         double* E = a.E + stageOff * NE * ND;
@@ -962,6 +996,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
     }
     fence();
+    mark();  // 4: reduced rows stored
     auto isPivot = [&](int c) { return c >= NZ && c < ND && ((taken >> ((c - NZ) & 63)) & 1ull) != 0ull; };
     auto masked = [](double v, bool keep) { return __longlong_as_double(keep ? __double_as_longlong(v) : 0ll); };
     // ---- operands, once per (tile row, k-step).  Row t = 4 ks + lk of the tableau, J_t its pivot input (rows without a pivot are masked out)
@@ -1010,6 +1045,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 Wt[tj * (tj + 1) / 2 + ti][r] = masked(R[ti == tj ? sym(rc, cc) : tri(rc, cc)], in);
             }
     fence();
+    mark();  // 5: operands and tiles of W_e in registers
     // ---- the region becomes the image of [A|B]_e = [A|B  b] (row stride NH)
     for (int i = lane; i < NZ * NH; i += 64) R[i] = 0.0;
     fence();
@@ -1026,6 +1062,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     if (lane < NZ) R[lane * NH + ND] = defect;
     if (k == 0 && lane < NZ) a.dz0[b * NZ + lane] = dz0;
     fence();
+    mark();  // 6: image of [A|B]_e
     // ---- V = W_JJ G_e, then W_e' tile by tile
     f64x4 Vt[TD];
 #pragma unroll
@@ -1048,6 +1085,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 Wt[tj * (tj + 1) / 2 + ti] = acc + acc2;
             }
     }
+    mark();  // 7: products of W_e'
     // W' and w' to memory; the eliminated inputs are decoupled dummies: identity rows / columns, zero gradient
     bool rowPivot[TD][4], colPivot[TD];
 #pragma unroll
@@ -1069,6 +1107,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 if (col == ND) w[row] = v;
                 else W[row * ND + col] = v;
             }
+    mark();  // 8: W', w' stored
     // ---- [A|B]_e' = [A|B]_e - [A|B]_e[:,J] G_e
     double aAB[TZ][KS];
     f64x4 ABt[TZ][TD];
@@ -1095,6 +1134,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) ABt[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(aAB[ti][ks], gm[ks][tj], ABt[ti][tj], 0, 0, 0);
     }
+    mark();  // 9: tiles and products of [A|B]_e'
     double* AB = a.AB + stageOff * NZ * ND;
     double* bo = a.b + stageOff * NZ;
 #pragma unroll
@@ -1108,6 +1148,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 if (col == ND) bo[row] = ABt[ti][tj][r];
                 else AB[row * ND + col] = colPivot[tj] ? 0.0 : ABt[ti][tj][r];
             }
+    if constexpr (CLOCKS) {
+        __builtin_amdgcn_s_waitcnt(0);
+        mark();  // 10: [A|B]', b' stored
+        if (lane == 0 && (node == 1 || node == d.batch * (d.N + 1) / 2 + 1))
+            printf("[assemble wave clocks] node %lld (%d pivots): requests+images %llu, barrier terms %llu, elimination %llu, rows stored %llu, operands+tiles %llu, [A|B] image %llu, W products %llu, W stored %llu, [A|B] tiles+products %llu, [A|B] stored %llu; total %llu\n",
+                   node, __popc(pivotRows), marks[1] - marks[0], marks[2] - marks[1], marks[3] - marks[2], marks[4] - marks[3], marks[5] - marks[4], marks[6] - marks[5], marks[7] - marks[6], marks[8] - marks[7],
+                   marks[9] - marks[8], marks[10] - marks[9], marks[10] - marks[0]);
+    }
 }
 
 /// One lane per (stage node, reduced row).
@@ -1320,7 +1368,9 @@ int LaunchAssembleWave(const ShootingAssembleArgs* a, void* stream) {
     if (d.nz() != NZ || d.nu != NU || a->ne != NE || a->eliminate != 1) return -1;
     if (a->nh > 64 || (a->nh > 0 && a->ph.nnz > 64) || a->pH.nnz > 256 || a->pg.nnz > 64 || a->pf.nnz > 256 || a->pe.nnz > 256 || (!d.carryInputs && a->pc.nnz > 128)) return -1;
     const std::size_t lds = (kImagePadded + NE * (ND + 1) + 2 * static_cast<std::size_t>(a->nh) + NE) * sizeof(double) + NE * sizeof(int);
-    hipLaunchKernelGGL((ShootingAssembleWaveKernel<NZ, NU, NE>), dim3(static_cast<unsigned>(d.batch * (d.N + 1))), dim3(64), lds, static_cast<hipStream_t>(stream), *a);
+    const char* clocks = getenv("UNGAR_AMD_ASSEMBLE_CLOCKS");
+    if (clocks && clocks[0] == '1') hipLaunchKernelGGL((ShootingAssembleWaveKernel<NZ, NU, NE, true>), dim3(static_cast<unsigned>(d.batch * (d.N + 1))), dim3(64), lds, static_cast<hipStream_t>(stream), *a);
+    else hipLaunchKernelGGL((ShootingAssembleWaveKernel<NZ, NU, NE, false>), dim3(static_cast<unsigned>(d.batch * (d.N + 1))), dim3(64), lds, static_cast<hipStream_t>(stream), *a);
     return 0;
 }
 }  // namespace

@@ -220,7 +220,13 @@ class BatchedSoftSQPOptimizer {
         // if some instance found none of them acceptable (one counter read back per iteration)
         // (more than kStacked candidates -- a gamma_alpha close to 1 or a tiny alpha_min: the reference accepts any parameters -- go in groups of kStacked, each group
         // only if some instance has not found its step yet: the same counter)
-        const index_t stageA = _firstStage > 0 && _firstStage < K ? _firstStage : K;
+        // (_firstStage < 0, the default: the first kAdaptiveFirstStage candidates on their own while that resolves every instance; an iteration in which it
+        // did not is followed by 2, 4, ... 32 iterations that evaluate all candidates at once, then the short first stage is tried again.  The schedule changes
+        // what is evaluated, never which step an instance takes.)
+        const bool adaptive = _firstStage < 0 && K > kAdaptiveFirstStage;
+        const bool staged = _firstStage > 0 ? _firstStage < K : (adaptive && _unstagedIterationsLeft == 0);
+        const index_t stageA = staged ? (_firstStage > 0 ? _firstStage : kAdaptiveFirstStage) : K;
+        if (adaptive && !staged) --_unstagedIterationsLeft;
         const ungar_line_search_parameters ls{_ls.alphaMin, _ls.thetaMin, _ls.thetaMax, _ls.eta, _ls.gammaPhi, _ls.gammaTheta, _ls.gammaAlpha};
         for (index_t begin = 0; begin < K;) {
             const index_t wanted = begin == 0 ? stageA : K - begin;
@@ -253,10 +259,19 @@ class BatchedSoftSQPOptimizer {
             if (!last) Check(ungar_device_zero(_unresolved, static_cast<int64_t>(sizeof(int32_t)), _stream));
             Check(ungar_shooting_select(&_dims, &ls, _alphas.data() + begin, count, _theta0, _phi0, _obj0, _slope, _thetaT, _phiT, _objT, _accepted, _active, _status, _rows, _trial, stride,
                                         (begin > 0 ? UNGAR_SEARCH_NOT_FIRST : 0) | (last ? 0 : UNGAR_SEARCH_NOT_LAST), _unresolved, _stream));
-            begin += count;
-            if (!last && Download<int32_t>(_unresolved, 1)[0] == 0) {  // everybody took one of the first steps (or had stopped): close the search
-                break;
+            if (!last) {
+                const bool resolved = Download<int32_t>(_unresolved, 1)[0] == 0;
+                if (adaptive && staged && begin == 0) {
+                    if (resolved) {
+                        _unstagedBackoff = 2;
+                    } else {
+                        _unstagedIterationsLeft = _unstagedBackoff;
+                        _unstagedBackoff = _unstagedBackoff < 32 ? 2 * _unstagedBackoff : 32;
+                    }
+                }
+                if (resolved) break;  // everybody took one of the first steps (or had stopped): close the search
             }
+            begin += count;
         }
         ++_iterations;
     }
@@ -311,8 +326,13 @@ class BatchedSoftSQPOptimizer {
     void SetStream(void* hipStream) { _stream = hipStream; }
     /// Offer the first `candidates` step sizes (1, 1/2, ...) on their own and evaluate the remaining ones only if some instance accepted none of
     /// them -- most iterations of a warm-started MPC take full or half steps, and every candidate costs a pass of the stage functions over all
-    /// nodes.  Costs one 4-byte read-back per iteration; 0 (default) evaluates all candidates at once, without any host decision.
-    void SetFirstLineSearchStage(const index_t candidates) { _firstStage = candidates; }
+    /// nodes.  Costs one 4-byte read-back per iteration; 0 evaluates all candidates at once, without any host decision; negative (default): the first four
+    /// on their own, backing off to all-at-once iterations (2, 4, ... 32 of them) whenever some instance needed a smaller step.
+    void SetFirstLineSearchStage(const index_t candidates) {
+        _firstStage = candidates;
+        _unstagedIterationsLeft = 0;
+        _unstagedBackoff = 2;
+    }
     /// Stage equality rows: eliminated node by node before the recursion (default; the sequential chain then carries no constraint
     /// block) or kept inside the Riccati recursion as the stage KKT block of every knot (false; same solution, for comparison).
     void EliminateEqualityRowsBeforeTheRecursion(const bool on) { _eliminateEqualities = on; }
@@ -489,7 +509,9 @@ class BatchedSoftSQPOptimizer {
     real_t* _er = nullptr;
     int32_t *_status = nullptr, *_active = nullptr, *_pivots = nullptr;
     bool _eliminateEqualities = true;
-    index_t _firstStage = 0;
+    static constexpr index_t kAdaptiveFirstStage = 4;
+    index_t _firstStage = -1;
+    index_t _unstagedIterationsLeft = 0, _unstagedBackoff = 2;
     index_t _trialStride = 0;
     bool _nodeMajorTrialRows = std::getenv("UNGAR_AMD_NODE_MAJOR_TRIAL_ROWS") != nullptr;  // A/B switch (measurement)
     int32_t* _unresolved = nullptr;
