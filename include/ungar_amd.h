@@ -30,7 +30,7 @@ extern "C" {
  * equality-row fields, `status` in ungar_ocp_line_search_select / _accept).  ungar_abi_version() returns the version the LIBRARY was built with:
  * a wrapper compiled against an older header must compare the two before its first call -- a mismatch silently shifts arguments otherwise.
  * (ungar_amd/__init__.py and Ungar::BatchedSoftSQPOptimizer do.) */
-#define UNGAR_AMD_ABI_VERSION 4
+#define UNGAR_AMD_ABI_VERSION 5
 int32_t ungar_abi_version(void);
 
 #define UNGAR_OK 0
@@ -403,6 +403,8 @@ typedef struct ungar_shooting_merit_args {
     double *theta, *phi, *objective, *slope; /* device, one per (stacked) instance; objective / slope may be null */
     int64_t period;
     int64_t rows_stride;                    /* 0: node-major rows; > 0: unit-fastest rows (ungar_shooting_trial_rows with trial_stride) */
+    const int32_t* instances;               /* period > 0: null, or the device list of ungar_shooting_trial_rows_listed -- stacked point s belongs to instance
+                                             * instances[s % period] (xm, dZ, dU are that instance's) */
 } ungar_shooting_merit_args;
 int ungar_shooting_merit(const ungar_shooting_merit_args* args, void* stream);
 
@@ -411,6 +413,12 @@ int ungar_shooting_merit(const ungar_shooting_merit_args* args, void* stream);
  * (output operand = the carried slots of rows 1..N). */
 int ungar_shooting_trial_rows(const ungar_shooting_dims* dims, const double* rows, const double* dZ, const double* dU, const double* alphas, int64_t candidates,
                               double* trial, int64_t trial_stride, void* stream);
+/* The same for a LISTED subset of the instances -- the later stages of a staged search evaluate the remaining candidates only for the instances the
+ * first ones left unresolved: trial point (c, i), i < listed, is instance instances[i] (device array of instance indices) at c * listed + i.  listed = 0
+ * (instances null): all instances, as above.  Merit terms of the listed points: ungar_shooting_merit with dims.batch = candidates * listed,
+ * period = listed, instances = the list. */
+int ungar_shooting_trial_rows_listed(const ungar_shooting_dims* dims, const double* rows, const double* dZ, const double* dU, const double* alphas, int64_t candidates,
+                                     const int32_t* instances, int64_t listed, double* trial, int64_t trial_stride, void* stream);
 /* trial_stride: 0 = node-major trial rows (like `rows`); > 0 = UNIT-FASTEST: element e of stacked node i = (c * batch + b) * (N+1) + k at
  * trial[e * trial_stride + i] (trial_stride >= candidates * batch * (N+1)).  The stage functions then read the trial rows with coalesced loads
  * (ungar_operand {base + offset * trial_stride, instance_stride 1, knot_stride 0, element_stride trial_stride}) and touch only the elements they
@@ -431,6 +439,14 @@ int ungar_shooting_select(const ungar_shooting_dims* dims, const ungar_line_sear
                           const double* theta0, const double* phi0, const double* objective0, const double* slope, const double* theta_trial,
                           const double* phi_trial, const double* objective_trial, double* accepted, int32_t* active, const int32_t* status, double* rows, const double* trial,
                           int64_t trial_stride, int32_t stage, int32_t* unresolved, void* stream);
+/* The same over a listed subset (instances / listed as in ungar_shooting_trial_rows_listed; the *_trial arrays hold candidates x listed values; theta0 ...
+ * accepted, active, status, rows stay indexed by instance).  next_instances (may be null; device array of dims.batch entries, not `instances`): in a call
+ * that is not the last, the instances left unresolved are written there at the positions the counter *unresolved hands out -- the list of the next call,
+ * *unresolved its length (read it back; the order of the entries is arbitrary, the instances are independent). */
+int ungar_shooting_select_listed(const ungar_shooting_dims* dims, const ungar_line_search_parameters* parameters, const double* alphas, int64_t candidates,
+                                 const double* theta0, const double* phi0, const double* objective0, const double* slope, const double* theta_trial,
+                                 const double* phi_trial, const double* objective_trial, double* accepted, int32_t* active, const int32_t* status, double* rows, const double* trial,
+                                 int64_t trial_stride, int32_t stage, int32_t* unresolved, const int32_t* instances, int64_t listed, int32_t* next_instances, void* stream);
 
 /* ---- device memory for host code that is not compiled with hipcc (the C++20 facade) ------------------------------------------------ */
 int ungar_device_malloc(void** out, int64_t bytes);

@@ -45,6 +45,8 @@ int main(void) {
             bad += ungar_shooting_trial_rows(&dims, dummy, dummy, dummy, alphas, 17, dummy, 0, 0) != UNGAR_E_INVALID;
             bad += ungar_shooting_trial_rows(&wrong, dummy, dummy, dummy, alphas, 14, dummy, 0, 0) != UNGAR_E_INVALID;
             bad += ungar_shooting_trial_rows(&dims, dummy, dummy, dummy, alphas, 14, dummy, 5, 0) != UNGAR_E_INVALID; /* stride below the stacked node count */
+            bad += ungar_shooting_trial_rows_listed(&dims, dummy, dummy, dummy, alphas, 14, 0, 3, dummy, 0, 0) != UNGAR_E_INVALID; /* listed instances without the list */
+            bad += ungar_shooting_trial_rows_listed(&dims, dummy, dummy, dummy, alphas, 14, (const int32_t*)dummy, dims.batch + 1, dummy, 0, 0) != UNGAR_E_INVALID; /* more listed than there are */
             bad += ungar_shooting_assemble(&asm_args, 0) != UNGAR_E_INVALID; /* null operands */
             bad += ungar_shooting_select(&dims, &ls, alphas, 14, 0, dummy, dummy, dummy, dummy, dummy, dummy, dummy, 0, 0, dummy, dummy, 0, 0, 0, 0) != UNGAR_E_INVALID;
             bad += ungar_device_malloc(&ptr, -1) != UNGAR_E_INVALID;

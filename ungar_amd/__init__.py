@@ -54,7 +54,7 @@ class _NodeBatch(ctypes.Structure):
 _LIB = None
 
 
-ABI_VERSION = 4  # UNGAR_AMD_ABI_VERSION of include/ungar_amd.h these bindings mirror
+ABI_VERSION = 5  # UNGAR_AMD_ABI_VERSION of include/ungar_amd.h these bindings mirror
 
 
 def load_library() -> ctypes.CDLL:

@@ -1186,7 +1186,7 @@ __global__ __launch_bounds__(kBlock) void ShootingMeritKernel(const ShootingMeri
     const ShootingDims& d = a.d;
     const long long s = blockIdx.x;
     if (s >= d.batch) return;
-    const long long b = a.period > 0 ? s % a.period : s;
+    const long long b = a.period > 0 ? (a.instances ? a.instances[s % a.period] : s % a.period) : s;
     const int lane = static_cast<int>(threadIdx.x), nz = d.nz(), nd = d.nd(), nc = d.nc, nx = d.nx, N = d.N;
     double g2 = 0.0, obj = 0.0, bar = 0.0, slope = 0.0;
     auto state = [&](int k, int i) {  // x_k[i] of (stacked) instance s
@@ -1239,9 +1239,10 @@ __global__ __launch_bounds__(256) void ShootingTrialKernel(const ShootingTrialAr
     const long long node = blockIdx.x;  // stacked node: (candidate c, instance b, knot k)
     const long long s = node / (d.N + 1);
     const int k = static_cast<int>(node - s * (d.N + 1));
-    if (s >= a.candidates * d.batch) return;
-    const long long b = s % d.batch;
-    const double alpha = a.alphas[s / d.batch];
+    const long long stacked = a.listed > 0 ? a.listed : d.batch;
+    if (s >= a.candidates * stacked) return;
+    const long long b = a.listed > 0 ? a.instances[s % stacked] : s % stacked;
+    const double alpha = a.alphas[s / stacked];
     const int nz = d.nz(), nd = d.nd(), nv = d.nv(), nc = d.nc, N = d.N;
     const double* row = RowOf(a.rows, d, b, k);
     double* out = a.trial + node * nv;
@@ -1282,7 +1283,8 @@ __global__ __launch_bounds__(256) void ShootingRefreshCarriedInputsKernel(const 
 __global__ __launch_bounds__(256) void ShootingTrialUnitFastestKernel(const ShootingTrialArgs a) {
     __shared__ double tile[32][65];
     const ShootingDims& d = a.d;
-    const long long nodes = static_cast<long long>(a.candidates) * d.batch * (d.N + 1);
+    const long long stacked = a.listed > 0 ? a.listed : d.batch;
+    const long long nodes = static_cast<long long>(a.candidates) * stacked * (d.N + 1);
     const long long node0 = static_cast<long long>(blockIdx.x) * 64;
     const int t = static_cast<int>(threadIdx.x), nz = d.nz(), nd = d.nd(), nv = d.nv(), nc = d.nc, N = d.N;
     for (int j0 = 0; j0 < nv; j0 += 32) {
@@ -1293,8 +1295,8 @@ __global__ __launch_bounds__(256) void ShootingTrialUnitFastestKernel(const Shoo
             if (node < nodes && j < nv) {
                 const long long s = node / (N + 1);
                 const int k = static_cast<int>(node - s * (N + 1));
-                const long long b = s % d.batch;
-                const double alpha = a.alphas[s / d.batch];
+                const long long b = a.listed > 0 ? a.instances[s % stacked] : s % stacked;
+                const double alpha = a.alphas[s / stacked];
                 double v = RowOf(a.rows, d, b, k)[j];
                 if (j < nc && d.carryInputs) {
                     if (k > 0) v = fma(alpha, a.dU[(b * N + (k - 1)) * d.nu + j], RowOf(a.rows, d, b, k - 1)[nz + j]);
@@ -1318,8 +1320,9 @@ __global__ __launch_bounds__(256) void ShootingTrialUnitFastestKernel(const Shoo
 
 __global__ __launch_bounds__(kBlock) void ShootingSelectKernel(const ShootingSelectArgs a) {
     const ShootingDims& d = a.d;
-    const long long b = blockIdx.x;
-    if (b >= d.batch) return;
+    const long long slot = blockIdx.x, stacked = a.listed > 0 ? a.listed : d.batch;  // stacked point (c, slot) at c * stacked + slot
+    if (slot >= stacked) return;
+    const long long b = a.listed > 0 ? a.instances[slot] : slot;
     if (a.active && a.active[b] == 0) {  // uniform over the workgroup
         if (threadIdx.x == 0 && a.first) a.accepted[b] = 0.0;
         return;
@@ -1329,19 +1332,20 @@ __global__ __launch_bounds__(kBlock) void ShootingSelectKernel(const ShootingSel
     int chosen = -1;
     const bool solved = !a.status || a.status[b] == 0;
     for (int c = 0; solved && c < a.candidates && chosen < 0; ++c)
-        if (StepAcceptable(theta, phi, slope, a.thetaT[c * d.batch + b], a.phiT[c * d.batch + b], a.alphas[c], a.thetaMin, a.thetaMax, a.eta, a.gammaPhi, a.gammaTheta)) chosen = c;
+        if (StepAcceptable(theta, phi, slope, a.thetaT[c * stacked + slot], a.phiT[c * stacked + slot], a.alphas[c], a.thetaMin, a.thetaMax, a.eta, a.gammaPhi, a.gammaTheta)) chosen = c;
     if (chosen < 0) {
         if (threadIdx.x == 0) {
             a.accepted[b] = 0.0;
             if (a.last || !solved) {
                 if (a.active) a.active[b] = 0;  // the reference's `break` on a rejected step (soft_sqp.hpp:88-90)
             } else if (a.unresolved) {
-                atomicAdd(a.unresolved, 1);
+                const int position = atomicAdd(a.unresolved, 1);
+                if (a.nextInstances) a.nextInstances[position] = static_cast<int>(b);
             }
         }
         return;
     }
-    const long long from = chosen * d.batch + b;
+    const long long from = chosen * stacked + slot;
     const int nd = d.nd(), nv = d.nv();
     for (int idx = static_cast<int>(threadIdx.x); idx < (d.N + 1) * nd; idx += kBlock) {
         const int k = idx / nd, j = idx - k * nd;
@@ -1421,7 +1425,7 @@ extern "C" int ungar_amd_launch_shooting_merit(const ShootingMeritArgs* a, void*
 
 extern "C" int ungar_amd_launch_shooting_trial(const ShootingTrialArgs* a, void* stream) {
     if (a->d.batch <= 0) return 0;
-    const long long nodes = static_cast<long long>(a->candidates) * a->d.batch * (a->d.N + 1);
+    const long long nodes = static_cast<long long>(a->candidates) * (a->listed > 0 ? a->listed : a->d.batch) * (a->d.N + 1);
     if (a->trialStride > 0) hipLaunchKernelGGL(ShootingTrialUnitFastestKernel, dim3(static_cast<unsigned>((nodes + 63) / 64)), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
     else hipLaunchKernelGGL(ShootingTrialKernel, dim3(static_cast<unsigned>(nodes)), dim3(a->d.nv() > 64 ? 128 : kBlock), 0, static_cast<hipStream_t>(stream), *a);
     return static_cast<int>(hipGetLastError());
@@ -1429,6 +1433,6 @@ extern "C" int ungar_amd_launch_shooting_trial(const ShootingTrialArgs* a, void*
 
 extern "C" int ungar_amd_launch_shooting_select(const ShootingSelectArgs* a, void* stream) {
     if (a->d.batch <= 0) return 0;
-    hipLaunchKernelGGL(ShootingSelectKernel, dim3(static_cast<unsigned>(a->d.batch)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), *a);
+    hipLaunchKernelGGL(ShootingSelectKernel, dim3(static_cast<unsigned>(a->listed > 0 ? a->listed : a->d.batch)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), *a);
     return static_cast<int>(hipGetLastError());
 }

@@ -92,6 +92,7 @@ struct ShootingMeritArgs {
     double *theta, *phi, *objective, *slope;
     long long period;
     long long rowsStride = 0;  // 0: node-major rows; > 0: UNIT-FASTEST rows, element e of node i = instance * (N + 1) + knot at rows[e * rowsStride + i]
+    const int* instances = nullptr;  // period > 0: stacked point s belongs to instance instances[s % period] (a LISTED subset of the instances; null: s % period)
 };
 
 /// Stacked trial rows: row (c * batch + b, k) = row (b, k) with [c|x|u] += alphas[c] * [dZ; dU]  (k = N: z only), parameters copied;
@@ -106,6 +107,9 @@ struct ShootingTrialArgs {
     // > 0: the trial rows are written UNIT-FASTEST (element e of stacked node i at trial[e * trialStride + i]): the stage functions then read
     // them with coalesced loads and touch only the elements they use (a node-major row is fetched whole, line by line, by every function)
     long long trialStride = 0;
+    // listed > 0: only the instances instances[0 .. listed) are stacked -- trial point (c, i) is instance instances[i], at c * listed + i
+    const int* instances = nullptr;
+    long long listed = 0;
 };
 
 /// The backtracking search of backtracking_line_search.hpp:116-151 per instance over the stacked candidates, then the bookkeeping of
@@ -128,6 +132,11 @@ struct ShootingSelectArgs {
     const int* status;  // per instance, from the Riccati solve: non-zero = the QP was not solved (the reference asserts there, soft_sqp.hpp:223-230): no step, instance stops
     double* rows;
     const double* trial;
+    // listed > 0: the stacked candidates belong to the instances instances[0 .. listed) (ShootingTrialArgs); nextInstances (may be null): the instances this
+    // call leaves unresolved are appended there, at the positions the counter *unresolved hands out (any order: the instances are independent)
+    const int* instances = nullptr;
+    long long listed = 0;
+    int* nextInstances = nullptr;
 };
 
 }  // namespace ungar_amd::kernels

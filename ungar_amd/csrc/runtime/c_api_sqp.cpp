@@ -275,6 +275,7 @@ int ungar_shooting_merit(const ungar_shooting_merit_args* a, void* stream) {
     k.objective = a->objective;
     k.slope = a->slope;
     k.period = a->period;
+    k.instances = a->period > 0 ? a->instances : nullptr;
     k.rowsStride = a->rows_stride;
     if (a->rows_stride < 0 || (a->rows_stride > 0 && a->rows_stride < a->dims.batch * (a->dims.horizon + 1))) return Fail(UNGAR_E_INVALID, "ungar_shooting_merit: rows_stride smaller than the number of nodes");
     return Launched(ungar_amd_launch_shooting_merit(&k, stream), "ungar_shooting_merit");
@@ -282,10 +283,18 @@ int ungar_shooting_merit(const ungar_shooting_merit_args* a, void* stream) {
 
 int ungar_shooting_trial_rows(const ungar_shooting_dims* dims, const double* rows, const double* dZ, const double* dU, const double* alphas, int64_t candidates,
                               double* trial, int64_t trial_stride, void* stream) {
+    return ungar_shooting_trial_rows_listed(dims, rows, dZ, dU, alphas, candidates, nullptr, 0, trial, trial_stride, stream);
+}
+
+int ungar_shooting_trial_rows_listed(const ungar_shooting_dims* dims, const double* rows, const double* dZ, const double* dU, const double* alphas, int64_t candidates,
+                                     const int32_t* instances, int64_t listed, double* trial, int64_t trial_stride, void* stream) {
     ShootingTrialArgs k{};
     if (!dims || !ToDims(*dims, &k.d) || !alphas || candidates < 1 || candidates > kMaxLineSearchCandidates)
         return Fail(UNGAR_E_INVALID, "ungar_shooting_trial_rows: bad argument (1 <= candidates <= 16)");
+    if (listed < 0 || listed > k.d.batch || (listed > 0) != (instances != nullptr)) return Fail(UNGAR_E_INVALID, "ungar_shooting_trial_rows_listed: 0 <= listed <= batch, with the list exactly when listed > 0");
     if (k.d.batch == 0) return UNGAR_OK;
+    k.instances = instances;
+    k.listed = listed;
     if (!rows || !dZ || !dU || !trial) return Fail(UNGAR_E_INVALID, "ungar_shooting_trial_rows: null argument");
     k.rows = rows;
     k.dZ = dZ;
@@ -293,7 +302,7 @@ int ungar_shooting_trial_rows(const ungar_shooting_dims* dims, const double* row
     k.trial = trial;
     k.candidates = static_cast<int>(candidates);
     for (int64_t c = 0; c < candidates; ++c) k.alphas[c] = alphas[c];
-    if (trial_stride < 0 || (trial_stride > 0 && trial_stride < candidates * k.d.batch * (k.d.N + 1))) return Fail(UNGAR_E_INVALID, "ungar_shooting_trial_rows: trial_stride smaller than the number of stacked nodes");
+    if (trial_stride < 0 || (trial_stride > 0 && trial_stride < candidates * (listed > 0 ? listed : k.d.batch) * (k.d.N + 1))) return Fail(UNGAR_E_INVALID, "ungar_shooting_trial_rows: trial_stride smaller than the number of stacked nodes");
     k.trialStride = trial_stride;
     return Launched(ungar_amd_launch_shooting_trial(&k, stream), "ungar_shooting_trial_rows");
 }
@@ -302,13 +311,27 @@ int ungar_shooting_select(const ungar_shooting_dims* dims, const ungar_line_sear
                           const double* phi0, const double* objective0, const double* slope, const double* theta_trial, const double* phi_trial,
                           const double* objective_trial, double* accepted, int32_t* active, const int32_t* status, double* rows, const double* trial, int64_t trial_stride,
                           int32_t stage, int32_t* unresolved, void* stream) {
+    return ungar_shooting_select_listed(dims, p, alphas, candidates, theta0, phi0, objective0, slope, theta_trial, phi_trial, objective_trial, accepted, active, status, rows, trial, trial_stride,
+                                        stage, unresolved, nullptr, 0, nullptr, stream);
+}
+
+int ungar_shooting_select_listed(const ungar_shooting_dims* dims, const ungar_line_search_parameters* p, const double* alphas, int64_t candidates, const double* theta0,
+                                 const double* phi0, const double* objective0, const double* slope, const double* theta_trial, const double* phi_trial,
+                                 const double* objective_trial, double* accepted, int32_t* active, const int32_t* status, double* rows, const double* trial, int64_t trial_stride,
+                                 int32_t stage, int32_t* unresolved, const int32_t* instances, int64_t listed, int32_t* next_instances, void* stream) {
     ShootingSelectArgs k{};
     if (!dims || !ToDims(*dims, &k.d) || !p || !alphas || candidates < 1 || candidates > kMaxLineSearchCandidates)
         return Fail(UNGAR_E_INVALID, "ungar_shooting_select: bad argument (1 <= candidates <= 16)");
+    if (listed < 0 || listed > k.d.batch || (listed > 0) != (instances != nullptr)) return Fail(UNGAR_E_INVALID, "ungar_shooting_select_listed: 0 <= listed <= batch, with the list exactly when listed > 0");
+    if (next_instances && (!unresolved || !(stage & UNGAR_SEARCH_NOT_LAST))) return Fail(UNGAR_E_INVALID, "ungar_shooting_select_listed: next_instances is filled through the counter `unresolved` of a call that is not the last");
+    if (next_instances && next_instances == instances) return Fail(UNGAR_E_INVALID, "ungar_shooting_select_listed: next_instances must not be the list being read");
     if (k.d.batch == 0) return UNGAR_OK;
+    k.instances = instances;
+    k.listed = listed;
+    k.nextInstances = next_instances;
     if (!theta0 || !phi0 || !objective0 || !slope || !theta_trial || !phi_trial || !objective_trial || !accepted || !rows || !trial)
         return Fail(UNGAR_E_INVALID, "ungar_shooting_select: null argument");
-    if (trial_stride < 0 || (trial_stride > 0 && trial_stride < candidates * k.d.batch * (k.d.N + 1)))
+    if (trial_stride < 0 || (trial_stride > 0 && trial_stride < candidates * (listed > 0 ? listed : k.d.batch) * (k.d.N + 1)))
         return Fail(UNGAR_E_INVALID, "ungar_shooting_select: trial_stride smaller than the number of stacked nodes");
     k.candidates = static_cast<int>(candidates);
     k.thetaMin = p->theta_min;

@@ -216,33 +216,32 @@ class BatchedSoftSQPOptimizer {
         m.slope = _slope;
         m.period = 0;
         Check(ungar_shooting_merit(&m, _stream));
-        // candidate steps, largest first: all at once (no host decision inside the iteration), or in two stages -- the first few, and the rest only
-        // if some instance found none of them acceptable (one counter read back per iteration)
-        // (more than kStacked candidates -- a gamma_alpha close to 1 or a tiny alpha_min: the reference accepts any parameters -- go in groups of kStacked, each group
-        // only if some instance has not found its step yet: the same counter)
-        // (_firstStage < 0, the default: the first kAdaptiveFirstStage candidates on their own while that resolves every instance; an iteration in which it
-        // did not is followed by 2, 4, ... 32 iterations that evaluate all candidates at once, then the short first stage is tried again.  The schedule changes
-        // what is evaluated, never which step an instance takes.)
-        const bool adaptive = _firstStage < 0 && K > kAdaptiveFirstStage;
-        const bool staged = _firstStage > 0 ? _firstStage < K : (adaptive && _unstagedIterationsLeft == 0);
-        const index_t stageA = staged ? (_firstStage > 0 ? _firstStage : kAdaptiveFirstStage) : K;
-        if (adaptive && !staged) --_unstagedIterationsLeft;
+        // candidate steps, largest first, in STAGES: the first few for every instance, the rest only for the instances that accepted none of them -- the
+        // select kernel lists those, the later stages stack (candidates x listed instances) trial points instead of (candidates x all).  Most iterations
+        // of a warm-started MPC take a full or half step: evaluating all 14 default candidates for everybody was 1.1-1.5 ms of the quadruped's iteration.
+        // One 4-byte read-back per stage that leaves somebody unresolved.  The stages change what is evaluated, never which step an instance takes
+        // (backtracking_line_search.hpp:116-151: the first acceptable candidate in descending order).
+        // (more than kStacked candidates at once -- a gamma_alpha close to 1 or a tiny alpha_min: the reference accepts any parameters -- go in groups of kStacked)
+        const index_t stageA = _firstStage > 0 && _firstStage < K ? _firstStage : K;
         const ungar_line_search_parameters ls{_ls.alphaMin, _ls.thetaMin, _ls.thetaMax, _ls.eta, _ls.gammaPhi, _ls.gammaTheta, _ls.gammaAlpha};
+        index_t listed = 0;  // 0: all instances
+        int32_t *list = nullptr, *nextList = _listA;
         for (index_t begin = 0; begin < K;) {
             const index_t wanted = begin == 0 ? stageA : K - begin;
             const index_t count = wanted < kStacked ? wanted : kStacked;
             const bool last = begin + count == K;
+            const index_t stacked = listed > 0 ? listed : B;  // instances with trial points in this stage
             // trial rows UNIT-FASTEST (element e of stacked node i at _trial[e * stride + i]): the stage functions read them coalesced and touch
             // only the elements they use
             const index_t stride = _trialStride;
-            Check(ungar_shooting_trial_rows(&_dims, _rows, _dZ, _dU, _alphas.data() + begin, count, _trial, stride, _stream));
-            if (_p.carry) CarryValues(_trial, count * B, stride);
-            Evaluate(*_p.dynamics, 0, _trial, _p.StateOffset(), _fT, count * B * (N + 1), stride);
-            Evaluate(*_p.cost, 0, _trial, 0, _lT, count * B * (N + 1), stride);
-            if (_p.inequality) Evaluate(*_p.inequality, 0, _trial, 0, _hT, count * B * (N + 1), stride);
-            if (_p.equality) Evaluate(*_p.equality, 0, _trial, 0, _eT, count * B * (N + 1), stride);
+            Check(ungar_shooting_trial_rows_listed(&_dims, _rows, _dZ, _dU, _alphas.data() + begin, count, list, listed, _trial, stride, _stream));
+            if (_p.carry) CarryValues(_trial, count * stacked, stride);
+            Evaluate(*_p.dynamics, 0, _trial, _p.StateOffset(), _fT, count * stacked * (N + 1), stride);
+            Evaluate(*_p.cost, 0, _trial, 0, _lT, count * stacked * (N + 1), stride);
+            if (_p.inequality) Evaluate(*_p.inequality, 0, _trial, 0, _hT, count * stacked * (N + 1), stride);
+            if (_p.equality) Evaluate(*_p.equality, 0, _trial, 0, _eT, count * stacked * (N + 1), stride);
             ungar_shooting_merit_args t = m;
-            t.dims.batch = count * B;
+            t.dims.batch = count * stacked;
             t.rows = _trial;
             t.f = _fT;
             t.cost = _lT;
@@ -253,25 +252,21 @@ class BatchedSoftSQPOptimizer {
             t.theta = _thetaT;
             t.phi = _phiT;
             t.objective = _objT;
-            t.period = B;
+            t.period = stacked;
+            t.instances = list;
             t.rows_stride = stride;
             Check(ungar_shooting_merit(&t, _stream));
             if (!last) Check(ungar_device_zero(_unresolved, static_cast<int64_t>(sizeof(int32_t)), _stream));
-            Check(ungar_shooting_select(&_dims, &ls, _alphas.data() + begin, count, _theta0, _phi0, _obj0, _slope, _thetaT, _phiT, _objT, _accepted, _active, _status, _rows, _trial, stride,
-                                        (begin > 0 ? UNGAR_SEARCH_NOT_FIRST : 0) | (last ? 0 : UNGAR_SEARCH_NOT_LAST), _unresolved, _stream));
-            if (!last) {
-                const bool resolved = Download<int32_t>(_unresolved, 1)[0] == 0;
-                if (adaptive && staged && begin == 0) {
-                    if (resolved) {
-                        _unstagedBackoff = 2;
-                    } else {
-                        _unstagedIterationsLeft = _unstagedBackoff;
-                        _unstagedBackoff = _unstagedBackoff < 32 ? 2 * _unstagedBackoff : 32;
-                    }
-                }
-                if (resolved) break;  // everybody took one of the first steps (or had stopped): close the search
-            }
+            Check(ungar_shooting_select_listed(&_dims, &ls, _alphas.data() + begin, count, _theta0, _phi0, _obj0, _slope, _thetaT, _phiT, _objT, _accepted, _active, _status, _rows, _trial, stride,
+                                               (begin > 0 ? UNGAR_SEARCH_NOT_FIRST : 0) | (last ? 0 : UNGAR_SEARCH_NOT_LAST), _unresolved, list, listed, last ? nullptr : nextList, _stream));
             begin += count;
+            if (!last) {
+                const index_t unresolved = Download<int32_t>(_unresolved, 1)[0];
+                if (unresolved == 0) break;  // everybody took one of the steps offered so far (or had stopped): the search is closed
+                list = nextList;
+                listed = unresolved;
+                nextList = list == _listA ? _listB : _listA;
+            }
         }
         ++_iterations;
     }
@@ -324,15 +319,10 @@ class BatchedSoftSQPOptimizer {
         return q;
     }
     void SetStream(void* hipStream) { _stream = hipStream; }
-    /// Offer the first `candidates` step sizes (1, 1/2, ...) on their own and evaluate the remaining ones only if some instance accepted none of
-    /// them -- most iterations of a warm-started MPC take full or half steps, and every candidate costs a pass of the stage functions over all
-    /// nodes.  Costs one 4-byte read-back per iteration; 0 evaluates all candidates at once, without any host decision; negative (default): the first four
-    /// on their own, backing off to all-at-once iterations (2, 4, ... 32 of them) whenever some instance needed a smaller step.
-    void SetFirstLineSearchStage(const index_t candidates) {
-        _firstStage = candidates;
-        _unstagedIterationsLeft = 0;
-        _unstagedBackoff = 2;
-    }
+    /// Offer the first `candidates` step sizes (1, 1/2, ...) to every instance and evaluate the remaining ones only for the instances that accepted none
+    /// of them (default 2) -- every candidate costs a pass of the stage functions over all nodes of the instances it is offered to.  Costs one 4-byte
+    /// read-back per iteration in which somebody needs a smaller step; 0 evaluates all candidates for everybody at once, without any host decision.
+    void SetFirstLineSearchStage(const index_t candidates) { _firstStage = candidates; }
     /// Stage equality rows: eliminated node by node before the recursion (default; the sequential chain then carries no constraint
     /// block) or kept inside the Riccati recursion as the stage KKT block of every knot (false; same solution, for comparison).
     void EliminateEqualityRowsBeforeTheRecursion(const bool on) { _eliminateEqualities = on; }
@@ -435,6 +425,8 @@ class BatchedSoftSQPOptimizer {
         _workspace = Device<real_t>(_workspaceDoubles);
         _status = Device<int32_t>(B);
         _unresolved = Device<int32_t>(1);
+        _listA = Device<int32_t>(_batch);
+        _listB = Device<int32_t>(_batch);
         _active = Device<int32_t>(B);
         _theta0 = Device<real_t>(B);
         _phi0 = Device<real_t>(B);
@@ -509,9 +501,8 @@ class BatchedSoftSQPOptimizer {
     real_t* _er = nullptr;
     int32_t *_status = nullptr, *_active = nullptr, *_pivots = nullptr;
     bool _eliminateEqualities = true;
-    static constexpr index_t kAdaptiveFirstStage = 4;
-    index_t _firstStage = -1;
-    index_t _unstagedIterationsLeft = 0, _unstagedBackoff = 2;
+    index_t _firstStage = 2;
+    int32_t *_listA = nullptr, *_listB = nullptr;  // instances a stage of the line search left unresolved (read / written alternately)
     index_t _trialStride = 0;
     bool _nodeMajorTrialRows = std::getenv("UNGAR_AMD_NODE_MAJOR_TRIAL_ROWS") != nullptr;  // A/B switch (measurement)
     int32_t* _unresolved = nullptr;
