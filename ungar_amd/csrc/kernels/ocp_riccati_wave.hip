@@ -95,7 +95,13 @@ struct WaveSizes {
     static constexpr int KLD = XE | 1;                    // gains in LDS: NU rows of [K | kff]
     static constexpr int kAbDoubles = (NX * n + NX + 1) / 2 * 2;  // [A|B] of the knot as it lies in memory, then b (LDS-DMA: 16 bytes per lane)
     static constexpr int kWDoubles = (n * n + n + 1) / 2 * 2;     // stage Hessian of the knot as it lies in memory (upper triangle meaningful), then the stage gradient
-    static constexpr int kTableauDoubles = NU * (TLD > KLD ? TLD : KLD) > 16 * 17 ? NU * (TLD > KLD ? TLD : KLD) : 16 * 17;  // tableau, then gains, then tile transposes
+    // The tableau passes from the accumulator tiles to the lanes (one column each) through LDS.  Where the state is one tile wide and the inputs are two
+    // (13 + 24: 23.0 KB of LDS per wavefront = six per CU, three rounds of 4096 instances with the last one two-thirds empty), it goes in two halves of
+    // its rows through a buffer of half the size: 19.3 KB, eight wavefronts per CU, two rounds.
+    static constexpr int kTableauPasses = (NU > 16 && XT == 1) ? 2 : 1;
+    static constexpr int kTableauRows = (NU + kTableauPasses - 1) / kTableauPasses;
+    static constexpr int kMax3(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
+    static constexpr int kTableauDoubles = kMax3(kTableauRows * TLD, NU * KLD, 16 * 17);  // tableau (a pass of it), then gains, then tile transposes
     static constexpr int kLdsDoubles = kAbDoubles + kWDoubles + kTableauDoubles + XE + NU + 8;
     static_assert(TW <= 64, "the tableau of the factorisation needs one lane per column");
 };
@@ -362,34 +368,44 @@ __global__ __launch_bounds__(64, WAVES_PER_EU) void RiccatiWaveKernel(const Ricc
         if (k > 0) storeShare(NT - 1);
         mark(0);  // products
 
-        // ---- tableau [R | H_ux h_u] -> LDS (row-major), both triangles of R from the tiles on and below the diagonal
-#pragma unroll
-        for (int tu = 0; tu < UT; ++tu) {
-#pragma unroll
-            for (int tv = 0; tv <= tu; ++tv)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int u = 16 * tu + 4 * r + lk, v = 16 * tv + lj;
-                    if (u < NU && v < NU) {
-                        if (tv < tu || v <= u) T[u * TLD + v] = Huu[tu][tv][r];
-                        if (tv < tu || v < u) T[v * TLD + u] = Huu[tu][tv][r];
-                    }
-                }
-#pragma unroll
-            for (int tx = 0; tx < XT; ++tx)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int u = 16 * tu + 4 * r + lk, c = 16 * tx + lj;
-                    if (u < NU && c < XE) T[u * TLD + NU + c] = Hux[tu][tx][r];
-                }
-        }
-        WaveLdsFence();
-        // ---- symmetric elimination, lane = column: t[i] = row i of [R | -H_ux -h_u]
+        // ---- tableau [R | H_ux h_u] -> LDS (row-major), both triangles of R from the tiles on and below the diagonal -> lane = column: t[i] = row i of
+        // [R | -H_ux -h_u], the rows in kTableauPasses groups through a buffer of one group
         double t[NU];
 #pragma unroll
-        for (int i = 0; i < NU; ++i) {
-            const double v = T[i * TLD + (lane < TW ? lane : TW - 1)];
-            t[i] = lane < NU ? v : (lane < TW ? -v : 0.0);
+        for (int pass = 0; pass < S::kTableauPasses; ++pass) {
+            constexpr int rows = S::kTableauRows;
+            const int first = pass * rows;
+            auto put = [&](int row, int col, double v) {
+                if (S::kTableauPasses == 1 || (row >= first && row < first + rows)) T[(row - first) * TLD + col] = v;
+            };
+#pragma unroll
+            for (int tu = 0; tu < UT; ++tu) {
+#pragma unroll
+                for (int tv = 0; tv <= tu; ++tv)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int u = 16 * tu + 4 * r + lk, v = 16 * tv + lj;
+                        if (u < NU && v < NU) {
+                            if (tv < tu || v <= u) put(u, v, Huu[tu][tv][r]);
+                            if (tv < tu || v < u) put(v, u, Huu[tu][tv][r]);
+                        }
+                    }
+#pragma unroll
+                for (int tx = 0; tx < XT; ++tx)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int u = 16 * tu + 4 * r + lk, c = 16 * tx + lj;
+                        if (u < NU && c < XE) put(u, NU + c, Hux[tu][tx][r]);
+                    }
+            }
+            WaveLdsFence();
+#pragma unroll
+            for (int i = 0; i < rows; ++i)
+                if (first + i < NU) {
+                    const double v = T[i * TLD + (lane < TW ? lane : TW - 1)];
+                    t[first + i] = lane < NU ? v : (lane < TW ? -v : 0.0);
+                }
+            if (pass + 1 < S::kTableauPasses) WaveLdsFence();
         }
         // (Measured and dropped for the elimination below: the pivot's reciprocal chain dealt out between the batches of row updates -- no change, the section is
         // bound by the issue of its ~1100 vector instructions at ~8 cycles each in a lone wavefront, not by that chain; the multipliers broadcast through LDS, the
