@@ -5,7 +5,7 @@
 set -uo pipefail
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-echo "== pytest -m gpu"; timeout 3000 python -m pytest tests -m gpu -x -q 2>&1 | tail -12 | tee gpurun_out/pytest_gpu.log
+echo "== pytest -m gpu"; timeout 3000 python -m pytest tests -m gpu -x -q --durations=30 2>&1 | tail -50 | tee gpurun_out/pytest_gpu.log
 echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -4 | tee gpurun_out/smoke.log
 echo "== bench"; timeout 900 python bench.py 2>gpurun_out/bench.err | tail -1 > gpurun_out/bench.log; cut -c1-400 gpurun_out/bench.log
 echo "== bench, the driver's command (20 steps, 5 warm-up) with and without the pre-warm"
