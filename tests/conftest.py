@@ -18,3 +18,19 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def repo_root():
     return ROOT
+
+
+@pytest.fixture(scope="session")
+def shared_codegen(tmp_path_factory):
+    """One model-cache folder per name for the whole session: C++ test programs that JIT the SAME functions (the three batched-quadruped tests, the two algebra
+    variants of an example) compile them once -- the cache is keyed by the tape, the derivative orders, the architecture, the ROCm version and the flags
+    (DESIGN section 8 N3), so a program whose tape differs simply compiles its own.  The cold path is still exercised by the first user of every folder, and the
+    cache life cycle has its own tests (tests/test_cpp_facade.py)."""
+    folders = {}
+
+    def folder(name):
+        if name not in folders:
+            folders[name] = tmp_path_factory.mktemp(f"codegen_{name}")
+        return folders[name]
+
+    return folder

@@ -22,10 +22,10 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("problem,batch,compared", [("quadrotor", 1024, 8), ("rc_car", 1024, 8), ("quadruped", 1024, 8)])
-def test_batched_sqp_equals_the_whole_horizon_facade(repo_root, tmp_path, problem, batch, compared):
+def test_batched_sqp_equals_the_whole_horizon_facade(repo_root, shared_codegen, problem, batch, compared):
     exe = os.path.join(repo_root, "build", f"batched_{problem}_test")
     assert os.path.exists(exe), f"{exe} missing: run __graft_entry__.build()"
-    r = subprocess.run([exe, str(tmp_path / "codegen"), str(batch), str(compared)], capture_output=True, text=True, timeout=1500)
+    r = subprocess.run([exe, str(shared_codegen(f"batched_{problem}")), str(batch), str(compared)], capture_output=True, text=True, timeout=1500)
     print(r.stdout[-6000:], r.stderr[-2000:])
     assert r.returncode == 0 and f"PASS batched {problem} SQP (batch {batch}, {compared} compared)" in r.stdout
     lines = [l for l in r.stdout.splitlines() if l.startswith("iteration") and "instances accepted" in l]
@@ -35,7 +35,7 @@ def test_batched_sqp_equals_the_whole_horizon_facade(repo_root, tmp_path, proble
         assert total == batch and moved >= batch // 2  # the comparison is not vacuous: steps are taken
 
 
-def test_assembly_kernels_agree(repo_root, tmp_path):
+def test_assembly_kernels_agree(repo_root, tmp_path, shared_codegen):
     """Three routes through the shooting assembly: the one-wavefront kernel (quadruped-shaped stage nodes: tiles of W and [A|B] in registers, the linear
     terms as the homogeneous column of the matrix-core products), the workgroup kernel with its wavefront-specialised sections
     (UNGAR_AMD_ASSEMBLE_VARIANT=workgroup), and the workgroup kernel's generic sections (UNGAR_AMD_ASSEMBLE_GENERIC=1).  Same pivot
@@ -55,7 +55,7 @@ def test_assembly_kernels_agree(repo_root, tmp_path):
             env["UNGAR_AMD_ASSEMBLE_VARIANT"] = "workgroup"
         folder = tmp_path / mode
         folder.mkdir()
-        r = subprocess.run([exe, str(tmp_path / "codegen"), "256", "3", str(folder)], capture_output=True, text=True, timeout=1500, env=env)
+        r = subprocess.run([exe, str(shared_codegen("batched_quadruped")), "256", "3", str(folder)], capture_output=True, text=True, timeout=1500, env=env)
         print(r.stdout[-2000:], r.stderr[-1000:])
         assert r.returncode == 0 and "PASS batched quadruped SQP (batch 256, 3 compared)" in r.stdout
         dumps[mode] = {f.name: f.read_bytes() for f in sorted(folder.iterdir())}
@@ -89,13 +89,13 @@ def test_assembly_kernels_agree(repo_root, tmp_path):
     assert differs > 0  # (the one-wavefront kernel did run: bitwise equality everywhere would mean the workgroup kernel was compared with itself)
 
 
-def test_line_search_candidates_in_groups_give_the_same_iterates(repo_root, tmp_path):
+def test_line_search_candidates_in_groups_give_the_same_iterates(repo_root, shared_codegen):
     """More candidate steps than one stacked evaluation holds (16; the reference accepts any BacktrackingLineSearch parameters,
     backtracking_line_search.hpp:56-78) are offered in groups, largest first, an instance taking the first acceptable candidate over all groups.  Pinned
     with the default 14 candidates in groups of 4 (UNGAR_AMD_STACKED_CANDIDATES): step sizes and iterates must still equal the facade's."""
     exe = os.path.join(repo_root, "build", "batched_rc_car_test")
     assert os.path.exists(exe), f"{exe} missing: run __graft_entry__.build()"
-    r = subprocess.run([exe, str(tmp_path / "codegen"), "512", "8"], capture_output=True, text=True, timeout=1500, env={**os.environ, "UNGAR_AMD_STACKED_CANDIDATES": "4"})
+    r = subprocess.run([exe, str(shared_codegen("batched_rc_car")), "512", "8"], capture_output=True, text=True, timeout=1500, env={**os.environ, "UNGAR_AMD_STACKED_CANDIDATES": "4"})
     print(r.stdout[-4000:], r.stderr[-2000:])
     assert r.returncode == 0 and "PASS batched rc_car SQP (batch 512, 8 compared)" in r.stdout
 

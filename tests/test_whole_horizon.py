@@ -195,11 +195,11 @@ def test_objective_value_gradient_and_upper_triangular_hessian(dump):
 
 # ---- the quadruped OCP as written: 883 equality rows incl. the 480 foot-contact rows (quadruped.example.cpp:246-304) and its objective (:209-245) --------
 @pytest.fixture(scope="module")
-def quadruped_dump(repo_root, tmp_path_factory):
+def quadruped_dump(repo_root, tmp_path_factory, shared_codegen):
     exe = os.path.join(repo_root, "build", "batched_quadruped_test")
     assert os.path.exists(exe), "build/batched_quadruped_test missing: run __graft_entry__.build()"
     d = tmp_path_factory.mktemp("quadruped_ocp")
-    r = subprocess.run([exe, str(d / "codegen"), "4", "-1", str(d / "dump.txt")], capture_output=True, text=True, timeout=1500)
+    r = subprocess.run([exe, str(shared_codegen("batched_quadruped")), "4", "-1", str(d / "dump.txt")], capture_output=True, text=True, timeout=1500)
     print(r.stdout[-2000:], r.stderr[-2000:])
     assert r.returncode == 0 and "DUMPED" in r.stdout
     return _parse(str(d / "dump.txt"))
@@ -226,7 +226,7 @@ def test_quadruped_whole_horizon_functions_against_the_independent_oracle(quadru
     (grad,) = torch.autograd.grad(O.quadruped_whole_horizon(zg, par)[0], zg)
     g = dump["OBJ_JAC"]
     assert g.shape == (1, dec) and np.abs(g[0] - grad.numpy()).max() <= 1e-12 * np.abs(grad.numpy()).max()
-    J = torch.autograd.functional.jacobian(lambda zz: O.quadruped_whole_horizon(zz, par)[1], z).numpy()
+    J = torch.autograd.functional.jacobian(lambda zz: O.quadruped_whole_horizon(zz, par)[1], z, vectorize=True).numpy()  # (one batched backward pass: 4 s; row by row 100-180 s, same entries)
     Jd, mask = dump["EQ_JAC"], dump["EQ_JAC_MASK"]
     assert Jd.shape == (883, dec)
     assert np.abs(Jd - J).max() <= 1e-10 * np.abs(J).max()

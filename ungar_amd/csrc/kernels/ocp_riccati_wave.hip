@@ -407,6 +407,10 @@ __global__ __launch_bounds__(64, WAVES_PER_EU) void RiccatiWaveKernel(const Ricc
                 }
             if (pass + 1 < S::kTableauPasses) WaveLdsFence();
         }
+        // (Measured and dropped, round 4: per-knot words flagging the inputs an assembly eliminated -- decoupled dummies, 8-12 of the quadruped's 24: zero column of
+        // [A|B], unit row of the Hessian -- so that their row updates and back-substitution columns are skipped behind scalar branches.  Synthetic 25 + 24 with
+        // half the inputs flagged: 1.97 -> 1.93 ms; inside the quadruped iteration 1.98-2.02 -> 2.09 ms.  Skipping the flagged pivots' whole steps costs 40+
+        // registers of control flow: 37 + 12 spills (1.4 -> 3.1 ms).  The section is not bound by those instructions.)
         // (Measured and dropped for the elimination below: the pivot's reciprocal chain dealt out between the batches of row updates -- no change, the section is
         // bound by the issue of its ~1100 vector instructions at ~8 cycles each in a lone wavefront, not by that chain; the multipliers broadcast through LDS, the
         // pivot ROW stored once and read back entry by entry, one LDS instruction + one multiply-add per row update instead of two v_readlane + one -- 9 k -> 17 k

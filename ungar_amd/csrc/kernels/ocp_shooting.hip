@@ -766,6 +766,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     double* d2 = d1 + a.nh;                // nh
     unsigned long long* rowScale = reinterpret_cast<unsigned long long*>(d2 + a.nh);  // NE
     int* pivL = reinterpret_cast<int*>(rowScale + NE);                                  // NE
+    int* pairTable = pivL + NE;                                                         // 64: pairs of inequality-Jacobian entries (barrier terms)
     auto tri = [](int r, int c) { return ((r * (2 * NH + 1 - r)) >> 1) + (c - r); };  // r <= c < NH
     auto sym = [&tri](int r, int c) { return r <= c ? tri(r, c) : tri(c, r); };
     auto fence = [] { asm volatile("" ::: "memory"); };  // (for the compiler: the LDS instructions of one wavefront execute in order)
@@ -894,18 +895,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         const int nextRow = __shfl_down(myRow, 1);
         const unsigned long long rowEnds = __ballot(mine >= 0 && (mine == nnz - 1 || nextRow != myRow));
         const int partners = mine >= 0 ? __ffsll(static_cast<unsigned long long>(rowEnds >> mine)) : 0;
-        int pairFirst = -1, pairOffset = 0, pairs = 0;
-        for (int e1 = 0; e1 < nnz; ++e1) {
-            const int count = __builtin_amdgcn_readlane(partners, e1);
-            if (lane >= pairs && lane < pairs + count) {
-                pairFirst = e1;
-                pairOffset = lane - pairs;
-            }
-            pairs += count;
-        }
+        // one lane per PAIR (e1, e2 >= e1) of a row: pair p of the concatenation over e1.  Entry e1 owns the pairs [before(e1), before(e1) + partners(e1)): a
+        // prefix sum over the lanes (DPP), then every entry writes its index into its pairs' slots of a 64-word LDS table and every pair reads its slot --
+        // a loop over the entries with a v_readlane each was ~2 k cycles of this lone wavefront.
+        int before = partners;
+#define UNGAR_SCAN_STAGE(CTRL, ROWS) before += __builtin_amdgcn_update_dpp(0, before, CTRL, ROWS, 0xF, false);
+        UNGAR_SCAN_STAGE(0x111, 0xF)  // row_shr:1
+        UNGAR_SCAN_STAGE(0x112, 0xF)  // row_shr:2
+        UNGAR_SCAN_STAGE(0x114, 0xF)  // row_shr:4
+        UNGAR_SCAN_STAGE(0x118, 0xF)  // row_shr:8
+        UNGAR_SCAN_STAGE(0x142, 0xA)  // row_bcast:15 into rows 1 and 3
+        UNGAR_SCAN_STAGE(0x143, 0xC)  // row_bcast:31 into rows 2 and 3
+#undef UNGAR_SCAN_STAGE
+        const int pairs = __builtin_amdgcn_readlane(before, 63);
+        before -= partners;  // (exclusive)
         if (pairs <= 64) {
-            const bool havePair = pairFirst >= 0;
-            const int first = havePair ? pairFirst : 0, second = havePair ? pairFirst + pairOffset : 0;
+            for (int q = 0; __ballot(q < partners) != 0ull; ++q)
+                if (q < partners) pairTable[before + q] = mine | (q << 8);
+            fence();
+            const bool havePair = lane < pairs;
+            const int slot = havePair ? pairTable[lane] : 0;
+            const int first = slot & 255, second = first + (slot >> 8);
             const int pairRowAny = __shfl(myRow, first), c1 = __shfl(myCol, first), c2 = __shfl(myCol, second);
             const double v1 = __shfl(myValue, first), v2 = __shfl(myValue, second);
             const int pairRow = havePair ? pairRowAny : -1, target = havePair ? tri(c1, c2) : 0, gTarget = tri(myCol, ND);
@@ -968,13 +978,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 taken |= 1ull << j;
                 pivotRows |= 1u << i;
                 const int J = NZ + j;
-                const double rpiv = 1.0 / ReadLane(t[i], J);
+                // (hardware reciprocal + two Newton steps instead of the IEEE division -- the pivots' reciprocals are the serial chain of the elimination; the
+                // multipliers of a pivot are read in batches, then applied: one scalar register pair reused for every row made each update wait for the previous one)
+                const double pivot = ReadLane(t[i], J);
+                double rpiv = __builtin_amdgcn_rcp(pivot);
+                rpiv = __builtin_fma(__builtin_fma(-pivot, rpiv, 1.0), rpiv, rpiv);
+                rpiv = __builtin_fma(__builtin_fma(-pivot, rpiv, 1.0), rpiv, rpiv);
                 const double p = lane == J ? 1.0 : t[i] * rpiv;
 #pragma unroll
-                for (int r = 0; r < NE; ++r) {
-                    if (r == i) continue;
-                    const double m = ReadLane(t[r], J);
-                    t[r] = t[r] - m * p;
+                for (int r0 = 0; r0 < NE; r0 += 8) {
+                    double m[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        if (r0 + q < NE && r0 + q != i) m[q] = ReadLane(t[r0 + q], J);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        if (r0 + q < NE && r0 + q != i) t[r0 + q] = t[r0 + q] - m[q] * p;  // (lane J: m - m * 1 = +0 exactly)
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 t[i] = p;
             }
@@ -1371,7 +1392,7 @@ int LaunchAssembleWave(const ShootingAssembleArgs* a, void* stream) {
     const ShootingDims& d = a->d;
     if (d.nz() != NZ || d.nu != NU || a->ne != NE || a->eliminate != 1) return -1;
     if (a->nh > 64 || (a->nh > 0 && a->ph.nnz > 64) || a->pH.nnz > 256 || a->pg.nnz > 64 || a->pf.nnz > 256 || a->pe.nnz > 256 || (!d.carryInputs && a->pc.nnz > 128)) return -1;
-    const std::size_t lds = (kImagePadded + NE * (ND + 1) + 2 * static_cast<std::size_t>(a->nh) + NE) * sizeof(double) + NE * sizeof(int);
+    const std::size_t lds = (kImagePadded + NE * (ND + 1) + 2 * static_cast<std::size_t>(a->nh) + NE) * sizeof(double) + (NE + 64) * sizeof(int);
     const char* clocks = getenv("UNGAR_AMD_ASSEMBLE_CLOCKS");
     if (clocks && clocks[0] == '1') hipLaunchKernelGGL((ShootingAssembleWaveKernel<NZ, NU, NE, true>), dim3(static_cast<unsigned>(d.batch * (d.N + 1))), dim3(64), lds, static_cast<hipStream_t>(stream), *a);
     else hipLaunchKernelGGL((ShootingAssembleWaveKernel<NZ, NU, NE, false>), dim3(static_cast<unsigned>(d.batch * (d.N + 1))), dim3(64), lds, static_cast<hipStream_t>(stream), *a);
