@@ -92,7 +92,8 @@ def test_quadruped_example_trots_and_tracks(repo_root, shared_codegen, variant):
     """quadruped.example.cpp (single-rigid-body quadruped, friction cones, contact schedule): the base must
     keep its height and follow the yaw ramp while exactly one diagonal leg pair carries the weight."""
     import math
-    rows = [tuple(map(float, m.groups())) for m in map(QP_LINE.search, _run(repo_root, "quadruped", shared_codegen("quadruped_example"), 1500, variant)  # (one working directory for both algebra variants: the second finds the first one's compiled models).splitlines()) if m]
+    out = _run(repo_root, "quadruped", shared_codegen("quadruped_example"), 1500, variant)  # (one working directory for both algebra variants: the second finds the first one's compiled models)
+    rows = [tuple(map(float, m.groups())) for m in map(QP_LINE.search, out.splitlines()) if m]
     assert len(rows) >= 290
     late = [r for r in rows if r[0] > 5.0]
     assert max(abs(r[2]) for r in late) < 0.1 and max(r[3] for r in late) < 1e-2
