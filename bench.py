@@ -308,7 +308,7 @@ def sqp_iterations(batch=4096, timeout=420):
     import subprocess
     import tempfile
     out = {}
-    folder = os.path.join(tempfile.gettempdir(), "ungar_bench_codegen")
+    folder = os.environ.get("UNGAR_BENCH_CODEGEN") or os.path.join(tempfile.gettempdir(), "ungar_bench_codegen")  # model cache of the run-time stage functions
     for problem in ("quadrotor", "rc_car", "quadruped"):
         exe = os.path.join(ROOT, "build", f"batched_{problem}_test")
         if not os.path.exists(exe):
@@ -316,12 +316,12 @@ def sqp_iterations(batch=4096, timeout=420):
             continue
         t0 = time.perf_counter()
         try:
-            r = subprocess.run([exe, os.path.join(folder, problem), str(batch), "0"], capture_output=True, text=True, timeout=timeout)
+            r = subprocess.run([exe, os.path.join(folder, f"batched_{problem}"), str(batch), "0"], capture_output=True, text=True, timeout=timeout)
             m = re.search(r"timing: ([0-9.]+) ms per SQP iteration of (\d+) instances", r.stdout)
             if r.returncode == 0 and m:
                 ms = float(m.group(1))
                 out[problem] = {"ms_per_iteration": ms, "instances": int(m.group(2)), "instances_per_s": int(m.group(2)) / ms * 1e3, "wall_s_including_jit": time.perf_counter() - t0,
-                                "kernel_split": f"profiles/r04k_batched_{problem}_kernel_stats.csv" if problem != "rc_car" else None}
+                                "kernel_split": f"profiles/r04l_batched_{problem}_kernel_stats.csv"}
             else:
                 out[problem] = {"failed": (r.stdout + r.stderr)[-400:]}
         except subprocess.TimeoutExpired:
@@ -339,7 +339,7 @@ def facade_single_instance_latency(timeout=300):
     if not os.path.exists(exe):
         return {"skipped": f"{exe} missing"}
     try:
-        r = subprocess.run([exe, os.path.join(tempfile.gettempdir(), "ungar_bench_codegen", "latency"), "latency"], capture_output=True, text=True, timeout=timeout)
+        r = subprocess.run([exe, os.path.join(os.environ.get("UNGAR_BENCH_CODEGEN") or os.path.join(tempfile.gettempdir(), "ungar_bench_codegen"), "latency"), "latency"], capture_output=True, text=True, timeout=timeout)
         m = re.search(r"HOST_CALL_LATENCY_US ([0-9.]+)", r.stdout)
         if r.returncode == 0 and m:
             us = float(m.group(1))

@@ -26,11 +26,12 @@ def shared_codegen(tmp_path_factory):
     variants of an example) compile them once -- the cache is keyed by the tape, the derivative orders, the architecture, the ROCm version and the flags
     (DESIGN section 8 N3), so a program whose tape differs simply compiles its own.  The cold path is still exercised by the first user of every folder, and the
     cache life cycle has its own tests (tests/test_cpp_facade.py)."""
-    folders = {}
+    root = tmp_path_factory.mktemp("model_cache")
 
     def folder(name):
-        if name not in folders:
-            folders[name] = tmp_path_factory.mktemp(f"codegen_{name}")
-        return folders[name]
+        path = root / name
+        path.mkdir(exist_ok=True)
+        return path
 
+    folder.root = root  # (bench.py takes it as UNGAR_BENCH_CODEGEN: its SQP legs run the same programs as tests/test_batched_sqp.py, in <root>/batched_<problem>)
     return folder

@@ -35,6 +35,18 @@ def test_batched_sqp_equals_the_whole_horizon_facade(repo_root, shared_codegen, 
         assert total == batch and moved >= batch // 2  # the comparison is not vacuous: steps are taken
 
 
+@pytest.mark.parametrize("problem", ["quadrotor", "rc_car"])
+def test_workgroup_assembly_route_of_the_problems_without_equality_rows(repo_root, shared_codegen, problem):
+    """Stage problems without equality rows whose row fits a wavefront take ShootingAssembleSmallKernel (one wavefront per node) by default -- that is what
+    test_batched_sqp_equals_the_whole_horizon_facade runs; UNGAR_AMD_ASSEMBLE_VARIANT=workgroup keeps them on the workgroup kernel's generic sections (what larger rows
+    take).  Same comparison with the facade's whole-horizon optimiser on that route."""
+    exe = os.path.join(repo_root, "build", f"batched_{problem}_test")
+    assert os.path.exists(exe), f"{exe} missing: run __graft_entry__.build()"
+    r = subprocess.run([exe, str(shared_codegen(f"batched_{problem}")), "512", "4"], capture_output=True, text=True, timeout=1500, env={**os.environ, "UNGAR_AMD_ASSEMBLE_VARIANT": "workgroup"})
+    print(r.stdout[-3000:], r.stderr[-1000:])
+    assert r.returncode == 0 and f"PASS batched {problem} SQP (batch 512, 4 compared)" in r.stdout
+
+
 def test_assembly_kernels_agree(repo_root, tmp_path, shared_codegen):
     """Three routes through the shooting assembly: the one-wavefront kernel (quadruped-shaped stage nodes: tiles of W and [A|B] in registers, the linear
     terms as the homogeneous column of the matrix-core products), the workgroup kernel with its wavefront-specialised sections

@@ -11,9 +11,11 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def test_bench_line_has_the_contract_fields(repo_root):
+def test_bench_line_has_the_contract_fields(repo_root, shared_codegen):
+    # (UNGAR_BENCH_PORTABLE_ORACLE skips the minute-long native build of the CPU baseline; UNGAR_BENCH_CODEGEN: the SQP legs find the stage functions the batched
+    # SQP tests of this session compiled -- a cold bench run compiles them itself, ~60 s of its ~130 s)
     out = subprocess.run([sys.executable, os.path.join(repo_root, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--cpu-seconds", "2"], cwd=repo_root,
-                         capture_output=True, text=True, timeout=900, env={**os.environ, "UNGAR_BENCH_PORTABLE_ORACLE": "1"})  # (skips the minute-long native build of the CPU baseline)
+                         capture_output=True, text=True, timeout=900, env={**os.environ, "UNGAR_BENCH_PORTABLE_ORACLE": "1", "UNGAR_BENCH_CODEGEN": str(shared_codegen.root)})
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads(out.stdout.strip().splitlines()[-1])
     assert d["metric"].startswith("shooting-node Jacobian evals/sec") and d["unit"] == "evals/s" and d["higher_is_better"] is True

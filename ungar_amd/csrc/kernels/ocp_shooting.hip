@@ -1179,6 +1179,160 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
 }
 
+/// ONE WAVEFRONT per node for stage problems WITHOUT equality rows whose differentiated row fits the lanes (nd + 1 <= 64: the quadrotor's 21, the RC car's 12) --
+/// run-time sizes, the same ingredients as the kernel above: every sparse value requested as one batch of range-checked MUBUF loads before anything is computed
+/// from them, dense LDS images (the packed upper triangle of W_e = [W w; w^T 0] and [A|B]_e = [A|B  b]) filled by scatter, the barrier terms as read-modify-writes
+/// of one wavefront (LDS instructions of a wavefront execute in order: no barrier), each dense block written to memory once, coalesced.  The workgroup kernel's
+/// generic sections did the same with a workgroup barrier after every inequality row and loads from global memory inside the row loop: 0.46 ms per
+/// 4096 x 31 quadrotor nodes against 0.18 ms of compulsory traffic.
+__global__ __launch_bounds__(64) void ShootingAssembleSmallKernel(const ShootingAssembleArgs a) {
+    extern __shared__ double lds[];
+    const ShootingDims& d = a.d;
+    const long long node = blockIdx.x;
+    const long long b = node / (d.N + 1);
+    const int k = static_cast<int>(node - b * (d.N + 1));
+    const int lane = static_cast<int>(threadIdx.x);
+    const int nc = d.nc, nx = d.nx, nz = d.nz(), nd = d.nd(), nh1 = nd + 1;  // (column nd: the linear terms)
+    const bool stage = k < d.N;
+    const int nW = nh1 * (nh1 + 1) / 2, nAB = nz * nh1;
+    double* R = lds;                    // packed upper triangle of W_e
+    double* ABi = R + ((nW + 1) & ~1);  // nz x (nd + 1)
+    double* d1 = ABi + ((nAB + 1) & ~1);
+    double* d2 = d1 + a.nh;
+    int* pairTable = reinterpret_cast<int*>(d2 + a.nh);  // 64
+    auto tri = [nh1](int r, int c) { return ((r * (2 * nh1 + 1 - r)) >> 1) + (c - r); };  // r <= c < nd + 1
+    auto fence = [] { asm volatile("" ::: "memory"); };
+    const long long nodeOff = node, stageOff = b * d.N + k;
+    constexpr int kSlotsH = 4, kSlotsF = 4, kSlotsC = 2;
+    struct Raw {
+        int r, c;
+        double value;
+        bool valid;
+    };
+    auto resourceOver = [](const void* base, int bytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, base ? bytes : 0, 0x00020000); };
+    auto loadInt = [](__amdgpu_buffer_rsrc_t rs, int byteOffset) { return __builtin_amdgcn_raw_buffer_load_b32(rs, byteOffset, 0, 0); };
+    auto loadDouble = [](__amdgpu_buffer_rsrc_t rs, int byteOffset) { return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, byteOffset, 0, 0)); };
+    auto request = [&](const StagePattern& pattern, const double* values, bool wanted, int slot) {
+        const int nnz = wanted && values ? pattern.nnz : 0, e = lane + 64 * slot;
+        Raw f;
+        f.r = loadInt(resourceOver(pattern.rows, nnz * 4), e * 4);
+        f.c = loadInt(resourceOver(pattern.cols, nnz * 4), e * 4);
+        f.value = loadDouble(resourceOver(values ? values + nodeOff * pattern.nnz : nullptr, nnz * 8), e * 8);
+        f.valid = e < nnz;
+        return f;
+    };
+    Raw rH[kSlotsH], rF[kSlotsF], rC[kSlotsC];
+#pragma unroll
+    for (int s = 0; s < kSlotsH; ++s) rH[s] = request(a.pH, a.lH, true, s);
+    const Raw rG = request(a.pg, a.lg, true, 0);
+    const double hMine = loadDouble(resourceOver(a.h ? a.h + nodeOff * a.nh : nullptr, stage ? a.nh * 8 : 0), lane * 8);
+    const Raw rI = request(a.ph, a.hJ, stage && a.nh > 0, 0);
+#pragma unroll
+    for (int s = 0; s < kSlotsF; ++s) rF[s] = request(a.pf, a.fJ, stage, s);
+#pragma unroll
+    for (int s = 0; s < kSlotsC; ++s) rC[s] = request(a.pc, a.cJ, stage && !d.carryInputs, s);
+    const double fMine = loadDouble(resourceOver(a.f + nodeOff * nx, stage ? nx * 8 : 0), (lane - nc) * 8);
+    const double nextMine = loadDouble(resourceOver(RowOf(a.rows, d, b, stage ? k + 1 : k), stage ? nz * 8 : 0), lane * 8);
+    const double xmMine = loadDouble(resourceOver(a.xm + b * nx, k == 0 ? nx * 8 : 0), (lane - nc) * 8);
+    const double row0Mine = loadDouble(resourceOver(RowOf(a.rows, d, b, 0), k == 0 ? nz * 8 : 0), lane * 8);
+    // ---- images
+    const int zeroed = ((nW + 1) & ~1) + ((nAB + 1) & ~1) + 2 * a.nh;
+    for (int i = lane; i < zeroed; i += 64) lds[i] = 0.0;
+    fence();
+#pragma unroll
+    for (int s = 0; s < kSlotsH; ++s)
+        if (rH[s].valid && rH[s].r <= rH[s].c) R[tri(rH[s].r, rH[s].c)] = rH[s].value;  // (Function::Hessian's pattern is upper triangular; anything below the diagonal is ignored)
+    if (rG.valid) R[tri(rG.c, nd)] = rG.value;
+    if (stage) {
+#pragma unroll
+        for (int s = 0; s < kSlotsF; ++s)
+            if (rF[s].valid) ABi[(nc + rF[s].r) * nh1 + nc + rF[s].c] = rF[s].value;
+        if (d.carryInputs) {
+            if (lane < nc) ABi[lane * nh1 + nz + lane] = 1.0;
+        } else {
+#pragma unroll
+            for (int s = 0; s < kSlotsC; ++s)
+                if (rC[s].valid) ABi[rC[s].r * nh1 + nc + rC[s].c] = rC[s].value;
+        }
+        if (lane >= nc && lane < nz) ABi[lane * nh1 + nd] = fMine - nextMine;
+        if (lane < a.nh) {
+            d1[lane] = BarrierD1(a.barrier, -hMine);
+            d2[lane] = BarrierD2(a.barrier, -hMine);
+        }
+    }
+    fence();
+    // ---- barrier terms  W += J_h^T diag(b''(-h)) J_h,  w -= J_h^T b'(-h)
+    if (stage && a.nh > 0) {
+        const int nnz = a.ph.nnz, mine = rI.valid ? lane : -1;
+        const int myRow = rI.valid ? rI.r : -1, myCol = rI.valid ? rI.c : 0;
+        const double myValue = rI.value;
+        const int nextRow = __shfl_down(myRow, 1);
+        const unsigned long long rowEnds = __ballot(mine >= 0 && (mine == nnz - 1 || nextRow != myRow));
+        const int partners = mine >= 0 ? __ffsll(static_cast<unsigned long long>(rowEnds >> mine)) : 0;
+        int before = partners;
+#define UNGAR_SCAN_STAGE(CTRL, ROWS) before += __builtin_amdgcn_update_dpp(0, before, CTRL, ROWS, 0xF, false);
+        UNGAR_SCAN_STAGE(0x111, 0xF)
+        UNGAR_SCAN_STAGE(0x112, 0xF)
+        UNGAR_SCAN_STAGE(0x114, 0xF)
+        UNGAR_SCAN_STAGE(0x118, 0xF)
+        UNGAR_SCAN_STAGE(0x142, 0xA)
+        UNGAR_SCAN_STAGE(0x143, 0xC)
+#undef UNGAR_SCAN_STAGE
+        const int pairs = __builtin_amdgcn_readlane(before, 63);
+        before -= partners;
+        if (pairs <= 64) {
+            for (int q = 0; __ballot(q < partners) != 0ull; ++q)
+                if (q < partners) pairTable[before + q] = mine | (q << 8);
+            fence();
+            const bool havePair = lane < pairs;
+            const int slot = havePair ? pairTable[lane] : 0;
+            const int first = slot & 255, second = first + (slot >> 8);
+            const int pairRowAny = __shfl(myRow, first), c1 = __shfl(myCol, first), c2 = __shfl(myCol, second);
+            const double v1 = __shfl(myValue, first), v2 = __shfl(myValue, second);
+            const int pairRow = havePair ? pairRowAny : -1, target = havePair ? tri(c1, c2) : 0, gTarget = tri(myCol, nd);
+            const double d1Mine = myRow >= 0 ? d1[myRow] : 0.0, d2Mine = havePair ? d2[pairRow] : 0.0;
+            for (int j = 0; j < a.nh; ++j) {
+                const bool g = myRow == j, ww = pairRow == j;
+                double g0 = 0.0, w0 = 0.0;
+                if (g) g0 = R[gTarget];
+                if (ww) w0 = R[target];
+                if (g) R[gTarget] = __builtin_fma(-d1Mine, myValue, g0);
+                if (ww) R[target] = __builtin_fma(d2Mine * v1, v2, w0);
+                fence();
+                __builtin_amdgcn_wave_barrier();
+            }
+        } else {
+            for (int j = 0; j < a.nh; ++j) {
+                if (myRow == j) {
+                    R[tri(myCol, nd)] -= d1[j] * myValue;
+                    for (int q = 0; q < partners; ++q) R[tri(myCol, a.ph.cols[mine + q])] += d2[j] * myValue * a.hJ[nodeOff * nnz + mine + q];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+    if (lane >= nc && lane < (stage ? nd : nz)) R[tri(lane, lane)] += a.regularization;  // the reference's 1e-6 I over its decision variables (soft_sqp.hpp:149-151)
+    fence();
+    // ---- results
+    const float ndInv = 1.0f / static_cast<float>(nd);
+    double* W = a.W + nodeOff * nd * nd;
+    for (int idx = lane; idx < nd * nd; idx += 64) {
+        const int r = static_cast<int>((static_cast<float>(idx) + 0.5f) * ndInv), c = idx - r * nd;
+        if (r <= c) W[idx] = R[tri(r, c)];
+    }
+    if (lane < nd) a.w[nodeOff * nd + lane] = R[tri(lane, nd)];
+    if (stage) {
+        double* AB = a.AB + stageOff * nz * nd;
+        for (int idx = lane; idx < nz * nd; idx += 64) {
+            const int r = static_cast<int>((static_cast<float>(idx) + 0.5f) * ndInv);
+            AB[idx] = ABi[r * nh1 + (idx - r * nd)];
+        }
+        if (lane < nz) a.b[stageOff * nz + lane] = ABi[lane * nh1 + nd];
+        if (k == 0 && lane < nz) a.dz0[b * nz + lane] = lane >= nc ? xmMine - row0Mine : 0.0;
+    }
+}
+
 /// One lane per (stage node, reduced row).
 __global__ __launch_bounds__(256) void ShootingRecoverKernel(const ShootingRecoverArgs a) {
     const ShootingDims& d = a.d;
@@ -1400,11 +1554,24 @@ int LaunchAssembleWave(const ShootingAssembleArgs* a, void* stream) {
 }
 }  // namespace
 
+/// The one-wavefront kernel for stage problems without equality rows (0: launched; -1: not applicable).
+static int LaunchAssembleSmall(const ShootingAssembleArgs* a, void* stream) {
+    const ShootingDims& d = a->d;
+    const int nd = d.nd(), nz = d.nz(), nh1 = nd + 1;
+    if (a->ne != 0 || nh1 > 64 || a->nh > 64 || (a->nh > 0 && a->ph.nnz > 64) || a->pH.nnz > 256 || a->pg.nnz > 64 || a->pf.nnz > 256 || (!d.carryInputs && a->pc.nnz > 128)) return -1;
+    const std::size_t lds = ((((nh1 * (nh1 + 1) / 2) + 1) & ~1) + ((nz * nh1 + 1) & ~1) + 2 * static_cast<std::size_t>(a->nh)) * sizeof(double) + 64 * sizeof(int);
+    hipLaunchKernelGGL(ShootingAssembleSmallKernel, dim3(static_cast<unsigned>(d.batch * (d.N + 1))), dim3(64), lds, static_cast<hipStream_t>(stream), *a);
+    return 0;
+}
+
 extern "C" int ungar_amd_launch_shooting_assemble(const ShootingAssembleArgs* a, void* stream) {
     if (a->d.batch <= 0) return 0;
     {
         const char* variant = getenv("UNGAR_AMD_ASSEMBLE_VARIANT");  // "workgroup": the kernel below for every shape (measurement, A/B tests); read per call
-        if (!(variant && variant[0] == 'w') && LaunchAssembleWave<25, 24, 16>(a, stream) == 0) return static_cast<int>(hipGetLastError());
+        if (!(variant && variant[0] == 'w')) {
+            if (LaunchAssembleWave<25, 24, 16>(a, stream) == 0) return static_cast<int>(hipGetLastError());
+            if (LaunchAssembleSmall(a, stream) == 0) return static_cast<int>(hipGetLastError());
+        }
     }
     const std::size_t nd = static_cast<std::size_t>(a->d.nd()), nz = static_cast<std::size_t>(a->d.nz());
     const std::size_t ne = static_cast<std::size_t>(a->ne), nu = static_cast<std::size_t>(a->d.nu);
