@@ -314,7 +314,7 @@ gpu = pytest.mark.gpu
 
 
 @gpu
-@pytest.mark.parametrize("nx,nu,N,batch", [(13, 4, 30, 257), (13, 24, 10, 33), (37, 12, 20, 9), (6, 2, 200, 16), (25, 24, 30, 17), (37, 12, 3, 1), (13, 24, 1, 65)])
+@pytest.mark.parametrize("nx,nu,N,batch", [(13, 4, 30, 257), (13, 24, 10, 33), (37, 12, 20, 9), (6, 2, 200, 16), (25, 24, 30, 17), (37, 12, 3, 1), (13, 24, 1, 65), (17, 4, 30, 70)])
 def test_device_riccati_equals_the_dense_kkt_solve(nx, nu, N, batch):
     import torch
     from ungar_amd import sqp
@@ -333,7 +333,7 @@ def test_device_riccati_equals_the_dense_kkt_solve(nx, nu, N, batch):
 
 
 @gpu
-@pytest.mark.parametrize("nx,nu,N", [(37, 12, 20), (25, 24, 30), (13, 24, 30)])
+@pytest.mark.parametrize("nx,nu,N", [(37, 12, 20), (25, 24, 30), (13, 24, 30), (17, 4, 30), (13, 4, 30)])
 def test_register_resident_riccati_kernels_agree_with_the_lds_resident_ones(nx, nu, N, monkeypatch):
     """The large blocks take the one-wavefront-per-instance kernels of ocp_riccati_wave.hip by default (every matrix of the recursion in registers, products
     chained on the FP64 matrix cores, homogeneous coordinates for the affine parts); UNGAR_AMD_RICCATI_VARIANT keeps the LDS-resident kernels of
@@ -360,7 +360,7 @@ def test_register_resident_riccati_kernels_agree_with_the_lds_resident_ones(nx, 
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nx,nu", [(13, 4), (13, 24), (37, 12), (4, 2), (25, 24)])
+@pytest.mark.parametrize("nx,nu", [(13, 4), (13, 24), (37, 12), (4, 2), (25, 24), (17, 4)])
 def test_device_riccati_reports_an_indefinite_reduced_hessian(nx, nu):
     """Every device instantiation (register Cholesky, L D L^T phases, run-time sizes; one and four wavefronts per instance) reports the
     knot whose input block is not positive definite for exactly the instance concerned, as the host policy does."""

@@ -654,8 +654,10 @@ extern "C" int ungar_amd_launch_riccati_wave(const RiccatiArgs* a, void* stream)
     if (a->nx == 37 && a->nu == 12) return LaunchWave<37, 12, 1>(a, s);
     if (a->nx == 25 && a->nu == 24) return LaunchWave<25, 24, 1>(a, s);
     if (a->nx == 13 && a->nu == 24) return LaunchWave<13, 24, 2>(a, s);
-    // (the small blocks: 13 + 4 takes 0.22 ms per 4096 x 30 knots here against 0.31 LDS-resident; 17 + 4, 8 + 2 and 6 + 2 measured SLOWER -- 0.85 / 0.15 / 0.12
-    // against 0.50 / 0.12 / 0.11 ms -- and stay with ocp_riccati.hip)
+    // (the small blocks: 13 + 4 takes 0.22 ms per 4096 x 30 knots here against 0.31 LDS-resident; 17 + 4 -- two state tiles for 18 columns -- 0.46 against 0.50 at TWO
+    // wavefronts per SIMD (203 registers; asked to fit four it spills and takes 0.85-1.05 ms: operands-to-registers 23 k cycles per knot); 8 + 2 and 6 + 2 measured
+    // slower -- 0.15 / 0.12 against 0.12 / 0.11 ms -- and stay with ocp_riccati.hip)
     if (a->nx == 13 && a->nu == 4) return LaunchWave<13, 4, 4>(a, s);
+    if (a->nx == 17 && a->nu == 4) return LaunchWave<17, 4, 2>(a, s);
     return -1;
 }
