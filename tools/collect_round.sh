@@ -48,3 +48,5 @@ cp_if gpurun_out/riccati_sizes_clocks.log     profiles/${tag}_riccati_phase_cloc
 cp_if gpurun_out/batched_quadrotor_kernel_stats.csv profiles/${tag}_batched_quadrotor_kernel_stats.csv
 cp_if gpurun_out/batched_quadruped_kernel_stats.csv profiles/${tag}_batched_quadruped_kernel_stats.csv
 cat gpurun_out/batched_quadrotor_timing.log gpurun_out/batched_quadruped_timing.log 2>/dev/null | grep timing > profiles/${tag}_batched_sqp_timing.log || true
+cp_if gpurun_out/reference_programs.log     profiles/${tag}_reference_programs.log
+cp_if gpurun_out/quick_sqp.log              profiles/${tag}_quick_sqp.log

@@ -62,3 +62,5 @@ timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpu
 head -2 gpurun_out/prof/anymal_kernel_stats.csv | cut -c1-200
 echo "== SQ counters of the headline kernel"
 bash tools/gpu_pmc_sq.sh anymal 2>&1 | tail -18 | tee gpurun_out/sq_counters.log
+echo "== the reference's own tests and examples: exit codes and wall times"
+bash tools/gpu_reference_programs.sh 2>&1 | tail -30
