@@ -732,6 +732,64 @@ __global__ __launch_bounds__(256, UNGAR_ASSEMBLE_WAVES_PER_EU) void ShootingAsse
 #endif
 }
 
+/// Barrier terms of ONE wavefront's node into the packed image R of W_e (column `last` = the linear terms):  W += J_h^T diag(b''(-h)) J_h,  w -= J_h^T b'(-h),
+/// straight from the sparse inequality Jacobian -- lane e < nnz holds entry e (myRow < 0: none; the entries of a row are consecutive, columns ascending).
+/// One lane per PAIR (e1, e2 >= e1) of a row where the pairs fit a wavefront (the quadruped: 28 entries in 12 rows, 46 pairs): entry e1 owns the pairs
+/// [before(e1), before(e1) + partners(e1)) -- a prefix sum over the lanes (DPP), every entry writes its index into its pairs' slots of a 64-word LDS table and
+/// every pair reads its slot (a loop over the entries with a v_readlane each was ~2 k cycles of this lone wavefront).  Then row by row, in order (rows share
+/// targets): the LDS instructions of one wavefront execute in order, so the next row's reads see these writes without a barrier.
+template <class Tri>
+__device__ __forceinline__ void WaveBarrierTerms(double* R, const Tri& tri, int last, int nh, const double* d1, const double* d2, int* pairTable, int lane, int nnz, int myRow, int myCol,
+                                                 double myValue, const int* patternCols, const double* nodeValues) {
+    auto fence = [] { asm volatile("" ::: "memory"); };
+    const int mine = myRow >= 0 ? lane : -1;
+    const int nextRow = __shfl_down(myRow, 1);
+    const unsigned long long rowEnds = __ballot(mine >= 0 && (mine == nnz - 1 || nextRow != myRow));
+    const int partners = mine >= 0 ? __ffsll(static_cast<unsigned long long>(rowEnds >> mine)) : 0;  // entries of the same row from this one on
+    int before = partners;
+#define UNGAR_SCAN_STAGE(CTRL, ROWS) before += __builtin_amdgcn_update_dpp(0, before, CTRL, ROWS, 0xF, false);
+    UNGAR_SCAN_STAGE(0x111, 0xF)  // row_shr:1
+    UNGAR_SCAN_STAGE(0x112, 0xF)  // row_shr:2
+    UNGAR_SCAN_STAGE(0x114, 0xF)  // row_shr:4
+    UNGAR_SCAN_STAGE(0x118, 0xF)  // row_shr:8
+    UNGAR_SCAN_STAGE(0x142, 0xA)  // row_bcast:15 into rows 1 and 3
+    UNGAR_SCAN_STAGE(0x143, 0xC)  // row_bcast:31 into rows 2 and 3
+#undef UNGAR_SCAN_STAGE
+    const int pairs = __builtin_amdgcn_readlane(before, 63);
+    before -= partners;  // (exclusive)
+    if (pairs <= 64) {
+        for (int q = 0; __ballot(q < partners) != 0ull; ++q)
+            if (q < partners) pairTable[before + q] = mine | (q << 8);
+        fence();
+        const bool havePair = lane < pairs;
+        const int slot = havePair ? pairTable[lane] : 0;
+        const int first = slot & 255, second = first + (slot >> 8);
+        const int pairRowAny = __shfl(myRow, first), c1 = __shfl(myCol, first), c2 = __shfl(myCol, second);
+        const double v1 = __shfl(myValue, first), v2 = __shfl(myValue, second);
+        const int pairRow = havePair ? pairRowAny : -1, target = havePair ? tri(c1, c2) : 0, gTarget = tri(myCol, last);
+        const double d1Mine = myRow >= 0 ? d1[myRow] : 0.0, d2Mine = havePair ? d2[pairRow] : 0.0;
+        for (int j = 0; j < nh; ++j) {
+            const bool g = myRow == j, ww = pairRow == j;
+            double g0 = 0.0, w0 = 0.0;
+            if (g) g0 = R[gTarget];
+            if (ww) w0 = R[target];
+            if (g) R[gTarget] = __builtin_fma(-d1Mine, myValue, g0);
+            if (ww) R[target] = __builtin_fma(d2Mine * v1, v2, w0);
+            fence();
+            __builtin_amdgcn_wave_barrier();
+        }
+    } else {  // (patterns whose pairs do not fit a wavefront: one lane per entry, its partners one after the other)
+        for (int j = 0; j < nh; ++j) {
+            if (myRow == j) {
+                R[tri(myCol, last)] -= d1[j] * myValue;
+                for (int q = 0; q < partners; ++q) R[tri(myCol, patternCols[mine + q])] += d2[j] * myValue * nodeValues[mine + q];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
 /// ONE WAVEFRONT per node, for stage problems whose equality tableau fits the lanes (NE <= 16 rows, ND + 1 <= 64 columns: the quadruped's 16 x 50) -- the
 /// workgroup kernel above spends ~9.8 k vector instructions per node, most of them index arithmetic in front of LDS operands that every 16 x 16 tile of the
 /// substitution fetches again (18 tiles x 5 operands x 4 k-steps), and a workgroup barrier between its sections.  Here
@@ -887,60 +945,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
     fence();
     mark();  // 1: requests answered, images zeroed and filled
-    // ---- barrier terms  W += J_h^T diag(b''(-h)) J_h,  w -= J_h^T b'(-h)  from the sparse inequality Jacobian (the single-wavefront job of the kernel above)
-    if (a.nh > 0) {
-        const int nnz = a.ph.nnz, mine = lane < nnz ? lane : -1;
-        const int myRow = inequalityRow, myCol = inequalityColumn;
-        const double myValue = inequalityValue;
-        const int nextRow = __shfl_down(myRow, 1);
-        const unsigned long long rowEnds = __ballot(mine >= 0 && (mine == nnz - 1 || nextRow != myRow));
-        const int partners = mine >= 0 ? __ffsll(static_cast<unsigned long long>(rowEnds >> mine)) : 0;
-        // one lane per PAIR (e1, e2 >= e1) of a row: pair p of the concatenation over e1.  Entry e1 owns the pairs [before(e1), before(e1) + partners(e1)): a
-        // prefix sum over the lanes (DPP), then every entry writes its index into its pairs' slots of a 64-word LDS table and every pair reads its slot --
-        // a loop over the entries with a v_readlane each was ~2 k cycles of this lone wavefront.
-        int before = partners;
-#define UNGAR_SCAN_STAGE(CTRL, ROWS) before += __builtin_amdgcn_update_dpp(0, before, CTRL, ROWS, 0xF, false);
-        UNGAR_SCAN_STAGE(0x111, 0xF)  // row_shr:1
-        UNGAR_SCAN_STAGE(0x112, 0xF)  // row_shr:2
-        UNGAR_SCAN_STAGE(0x114, 0xF)  // row_shr:4
-        UNGAR_SCAN_STAGE(0x118, 0xF)  // row_shr:8
-        UNGAR_SCAN_STAGE(0x142, 0xA)  // row_bcast:15 into rows 1 and 3
-        UNGAR_SCAN_STAGE(0x143, 0xC)  // row_bcast:31 into rows 2 and 3
-#undef UNGAR_SCAN_STAGE
-        const int pairs = __builtin_amdgcn_readlane(before, 63);
-        before -= partners;  // (exclusive)
-        if (pairs <= 64) {
-            for (int q = 0; __ballot(q < partners) != 0ull; ++q)
-                if (q < partners) pairTable[before + q] = mine | (q << 8);
-            fence();
-            const bool havePair = lane < pairs;
-            const int slot = havePair ? pairTable[lane] : 0;
-            const int first = slot & 255, second = first + (slot >> 8);
-            const int pairRowAny = __shfl(myRow, first), c1 = __shfl(myCol, first), c2 = __shfl(myCol, second);
-            const double v1 = __shfl(myValue, first), v2 = __shfl(myValue, second);
-            const int pairRow = havePair ? pairRowAny : -1, target = havePair ? tri(c1, c2) : 0, gTarget = tri(myCol, ND);
-            const double d1Mine = myRow >= 0 ? d1[myRow] : 0.0, d2Mine = havePair ? d2[pairRow] : 0.0;
-            for (int j = 0; j < a.nh; ++j) {
-                const bool g = myRow == j, ww = pairRow == j;
-                double g0 = 0.0, w0 = 0.0;
-                if (g) g0 = R[gTarget];
-                if (ww) w0 = R[target];
-                if (g) R[gTarget] = __builtin_fma(-d1Mine, myValue, g0);
-                if (ww) R[target] = __builtin_fma(d2Mine * v1, v2, w0);
-                fence();
-                __builtin_amdgcn_wave_barrier();
-            }
-        } else {
-            for (int j = 0; j < a.nh; ++j) {
-                if (myRow == j) {
-                    R[tri(myCol, ND)] -= d1[j] * myValue;
-                    for (int q = 0; q < partners; ++q) R[tri(myCol, a.ph.cols[mine + q])] += d2[j] * myValue * a.hJ[nodeOff * nnz + mine + q];
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-    }
+    // ---- barrier terms  W += J_h^T diag(b''(-h)) J_h,  w -= J_h^T b'(-h)  from the sparse inequality Jacobian
+    if (a.nh > 0) WaveBarrierTerms(R, tri, ND, a.nh, d1, d2, pairTable, lane, a.ph.nnz, inequalityRow, inequalityColumn, inequalityValue, a.ph.cols, a.hJ + nodeOff * a.ph.nnz);
     if (lane >= nc && lane < ND) R[tri(lane, lane)] += a.regularization;  // the reference's 1e-6 I over its decision variables (soft_sqp.hpp:149-151)
     fence();
     mark();  // 2: barrier terms, regularisation
@@ -1262,56 +1268,7 @@ __global__ __launch_bounds__(64) void ShootingAssembleSmallKernel(const Shooting
     }
     fence();
     // ---- barrier terms  W += J_h^T diag(b''(-h)) J_h,  w -= J_h^T b'(-h)
-    if (stage && a.nh > 0) {
-        const int nnz = a.ph.nnz, mine = rI.valid ? lane : -1;
-        const int myRow = rI.valid ? rI.r : -1, myCol = rI.valid ? rI.c : 0;
-        const double myValue = rI.value;
-        const int nextRow = __shfl_down(myRow, 1);
-        const unsigned long long rowEnds = __ballot(mine >= 0 && (mine == nnz - 1 || nextRow != myRow));
-        const int partners = mine >= 0 ? __ffsll(static_cast<unsigned long long>(rowEnds >> mine)) : 0;
-        int before = partners;
-#define UNGAR_SCAN_STAGE(CTRL, ROWS) before += __builtin_amdgcn_update_dpp(0, before, CTRL, ROWS, 0xF, false);
-        UNGAR_SCAN_STAGE(0x111, 0xF)
-        UNGAR_SCAN_STAGE(0x112, 0xF)
-        UNGAR_SCAN_STAGE(0x114, 0xF)
-        UNGAR_SCAN_STAGE(0x118, 0xF)
-        UNGAR_SCAN_STAGE(0x142, 0xA)
-        UNGAR_SCAN_STAGE(0x143, 0xC)
-#undef UNGAR_SCAN_STAGE
-        const int pairs = __builtin_amdgcn_readlane(before, 63);
-        before -= partners;
-        if (pairs <= 64) {
-            for (int q = 0; __ballot(q < partners) != 0ull; ++q)
-                if (q < partners) pairTable[before + q] = mine | (q << 8);
-            fence();
-            const bool havePair = lane < pairs;
-            const int slot = havePair ? pairTable[lane] : 0;
-            const int first = slot & 255, second = first + (slot >> 8);
-            const int pairRowAny = __shfl(myRow, first), c1 = __shfl(myCol, first), c2 = __shfl(myCol, second);
-            const double v1 = __shfl(myValue, first), v2 = __shfl(myValue, second);
-            const int pairRow = havePair ? pairRowAny : -1, target = havePair ? tri(c1, c2) : 0, gTarget = tri(myCol, nd);
-            const double d1Mine = myRow >= 0 ? d1[myRow] : 0.0, d2Mine = havePair ? d2[pairRow] : 0.0;
-            for (int j = 0; j < a.nh; ++j) {
-                const bool g = myRow == j, ww = pairRow == j;
-                double g0 = 0.0, w0 = 0.0;
-                if (g) g0 = R[gTarget];
-                if (ww) w0 = R[target];
-                if (g) R[gTarget] = __builtin_fma(-d1Mine, myValue, g0);
-                if (ww) R[target] = __builtin_fma(d2Mine * v1, v2, w0);
-                fence();
-                __builtin_amdgcn_wave_barrier();
-            }
-        } else {
-            for (int j = 0; j < a.nh; ++j) {
-                if (myRow == j) {
-                    R[tri(myCol, nd)] -= d1[j] * myValue;
-                    for (int q = 0; q < partners; ++q) R[tri(myCol, a.ph.cols[mine + q])] += d2[j] * myValue * a.hJ[nodeOff * nnz + mine + q];
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-    }
+    if (stage && a.nh > 0) WaveBarrierTerms(R, tri, nd, a.nh, d1, d2, pairTable, lane, a.ph.nnz, rI.valid ? rI.r : -1, rI.valid ? rI.c : 0, rI.value, a.ph.cols, a.hJ + nodeOff * a.ph.nnz);
     if (lane >= nc && lane < (stage ? nd : nz)) R[tri(lane, lane)] += a.regularization;  // the reference's 1e-6 I over its decision variables (soft_sqp.hpp:149-151)
     fence();
     // ---- results
