@@ -1419,16 +1419,31 @@ __global__ __launch_bounds__(256) void ShootingTrialUnitFastestKernel(const Shoo
     const long long nodes = static_cast<long long>(a.candidates) * stacked * (d.N + 1);
     const long long node0 = static_cast<long long>(blockIdx.x) * 64;
     const int t = static_cast<int>(threadIdx.x), nz = d.nz(), nd = d.nd(), nv = d.nv(), nc = d.nc, N = d.N;
+    const bool small = nodes < (1ll << 31);
     for (int j0 = 0; j0 < nv; j0 += 32) {
         const int jj = t & 31, j = j0 + jj;
         for (int pass = 0; pass < 8; ++pass) {
             const int nl = (t >> 5) + 8 * pass;
             const long long node = node0 + nl;
             if (node < nodes && j < nv) {
-                const long long s = node / (N + 1);
-                const int k = static_cast<int>(node - s * (N + 1));
-                const long long b = a.listed > 0 ? a.instances[s % stacked] : s % stacked;
-                const double alpha = a.alphas[s / stacked];
+                // (stacked node -> (candidate, instance slot, knot): 32-bit divisions wherever the launch has fewer than 2^31 stacked nodes -- always, in practice;
+                // three 64-bit divisions per element were ~150 of this kernel's instructions per element)
+                long long s, c, i;
+                int k;
+                if (small) {
+                    const unsigned n32 = static_cast<unsigned>(node), s32 = n32 / static_cast<unsigned>(N + 1), c32 = s32 / static_cast<unsigned>(stacked);
+                    k = static_cast<int>(n32 - s32 * static_cast<unsigned>(N + 1));
+                    s = s32;
+                    c = c32;
+                    i = s32 - c32 * static_cast<unsigned>(stacked);
+                } else {
+                    s = node / (N + 1);
+                    k = static_cast<int>(node - s * (N + 1));
+                    c = s / stacked;
+                    i = s - c * stacked;
+                }
+                const long long b = a.listed > 0 ? a.instances[i] : i;
+                const double alpha = a.alphas[c];
                 double v = RowOf(a.rows, d, b, k)[j];
                 if (j < nc && d.carryInputs) {
                     if (k > 0) v = fma(alpha, a.dU[(b * N + (k - 1)) * d.nu + j], RowOf(a.rows, d, b, k - 1)[nz + j]);
