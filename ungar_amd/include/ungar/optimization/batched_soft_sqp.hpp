@@ -22,7 +22,8 @@
 //                 stage derivatives (ungar_function_*_nodes) -> ungar_shooting_assemble -> ungar_ocp_riccati_solve (the exact
 //                 solution of the QP the reference hands to OSQP, stage equality rows included) -> merit terms -> all candidate steps
 //                 of the backtracking search as one stacked batch -> per-instance selection and stopping rule.
-// Host code is plain C++20 over the C ABI (include/ungar_amd.h); no HIP headers, no host round trip inside an iteration.
+// Host code is plain C++20 over the C ABI (include/ungar_amd.h); no HIP headers.  Inside an iteration the host reads back one 4-byte counter per line-search stage that
+// leaves some instance unresolved (SetFirstLineSearchStage(0): none -- all candidate steps for every instance in one stacked evaluation).
 #pragma once
 
 #include <cstdint>
