@@ -219,3 +219,81 @@ def test_redundant_equality_rows_take_no_pivot(nx, nu, monkeypatch):
         rng = np.random.default_rng(11)
         bad = run(with_copies, lambda i: residuals(i) + np.array([0.0, 0.0, 0.5, 0.0]), generic)
         assert (bad["piv"][:, 2] == -2).all() and (bad["piv"][:, 3] == -1).all() and (bad["piv"][:, :2] == ref["piv"]).all()
+
+
+@pytest.mark.parametrize("nx,nu,nh,dense_row", [(13, 4, 8, False), (8, 2, 6, False), (20, 9, 5, True), (30, 12, 14, True)])
+def test_one_wavefront_assembly_of_problems_without_equality_rows_on_random_patterns(nx, nu, nh, dense_row, monkeypatch):
+    """ShootingAssembleSmallKernel (stage problems without equality rows, nd + 1 <= 64) against the workgroup kernel (UNGAR_AMD_ASSEMBLE_VARIANT=workgroup) on random
+    SPARSE patterns -- Hessian, gradient, dynamics Jacobian, inequality Jacobian with rows of one to several entries, and (dense_row) a row whose entry pairs do not
+    fit a wavefront (the one-lane-per-entry fallback of the barrier terms) -- with carried inputs (nc = nu, identity carry).  Every block it writes (upper triangle of W,
+    w, [A|B], b, dz0 for stage and terminal nodes) within 1e-13 of the other route's."""
+    import torch
+    import ungar_amd
+    lib = ungar_amd.load_library()
+    lib.ungar_shooting_assemble.argtypes = [ctypes.POINTER(_AssembleArgs), ctypes.c_void_p]
+    N, B, nc = 3, 5, nu
+    nz, nd = nc + nx, nc + nx + nu
+    rng = np.random.default_rng(5 + nx)
+    dev = lambda a, dt=torch.float64: torch.tensor(np.ascontiguousarray(a), dtype=dt, device="cuda")  # noqa: E731
+    nodes = B * (N + 1)
+
+    def random_pattern(rows, cols, density, upper=False, keep_diagonal=False):
+        mask = rng.random((rows, cols)) < density
+        if upper:
+            mask = np.triu(mask)
+        if keep_diagonal:
+            mask |= np.eye(rows, cols, dtype=bool)
+        r, c = np.nonzero(mask)  # (row-major order: canonical CSR)
+        return r.astype(np.int32), c.astype(np.int32)
+
+    pH = random_pattern(nd, nd, min(0.3, 180.0 / (nd * (nd + 1) / 2)), upper=True, keep_diagonal=True)
+    pg = (np.zeros(nd, dtype=np.int32), np.arange(nd, dtype=np.int32))
+    pf = random_pattern(nx, nx + nu, min(0.5, 200.0 / (nx * (nx + nu))), keep_diagonal=True)  # dynamics over [x | u]
+    assert pH[0].size <= 256 and pf[0].size <= 256 and nd + 1 <= 64  # the bounds of the one-wavefront kernel (beyond them the launcher takes the workgroup kernel)
+    hmask = rng.random((nh, nd)) < 0.08
+    hmask[np.arange(nh), rng.integers(0, nd, nh)] = True  # no empty row
+    if dense_row:
+        hmask[nh // 2, :] = False
+        hmask[nh // 2, rng.choice(nd, 12, replace=False)] = True  # 78 pairs in this row alone
+    # the kernels take up to 64 inequality-Jacobian entries through their single-request path: keep the pattern below that bound
+    while hmask.sum() > 64:
+        r, c = np.nonzero(hmask)
+        pick = rng.integers(0, r.size)
+        if hmask[r[pick]].sum() > 1 and not (dense_row and r[pick] == nh // 2):
+            hmask[r[pick], c[pick]] = False
+    ph = tuple(a.astype(np.int32) for a in np.nonzero(hmask))
+    pats = {k: (dev(v[0], torch.int32), dev(v[1], torch.int32)) for k, v in (("pH", pH), ("pg", pg), ("pf", pf), ("ph", ph))}
+    t = {"rows": dev(rng.standard_normal((nodes, nd + 3))), "xm": dev(rng.standard_normal((B, nx))), "f": dev(rng.standard_normal((nodes, nx))),
+         "fJ": dev(rng.standard_normal((nodes, pf[0].size))), "lg": dev(rng.standard_normal((nodes, nd))), "lH": dev(rng.standard_normal((nodes, pH[0].size))),
+         "h": dev(-np.abs(rng.standard_normal((nodes, nh))) * 0.01), "hJ": dev(rng.standard_normal((nodes, ph[0].size)))}
+
+    def run(workgroup):
+        out = {"AB": torch.full((B * N, nz * nd), 7.0, dtype=torch.float64, device="cuda"), "b": torch.full((B * N, nz), 7.0, dtype=torch.float64, device="cuda"),
+               "W": torch.zeros((nodes, nd * nd), dtype=torch.float64, device="cuda"), "w": torch.full((nodes, nd), 7.0, dtype=torch.float64, device="cuda"),
+               "dz0": torch.full((B, nz), 7.0, dtype=torch.float64, device="cuda")}
+        a = _AssembleArgs()
+        a.dims = _Dims(nx, nu, nc, 3, 0, N, B, 1, 0)  # (three knot parameters behind [c | x | u]: the row stride differs from nd)
+        for name, key in (("rows", "rows"), ("xm", "xm"), ("f", "f"), ("f_jac", "fJ"), ("cost_grad", "lg"), ("cost_hes", "lH"), ("h", "h"), ("h_jac", "hJ")):
+            setattr(a, name, t[key].data_ptr())
+        for name in ("AB", "b", "W", "w", "dz0"):
+            setattr(a, name, out[name].data_ptr())
+        for name, key in (("f_pattern", "pf"), ("cost_grad_pattern", "pg"), ("cost_hes_pattern", "pH"), ("h_pattern", "ph")):
+            r, c = pats[key]
+            setattr(a, name, _Pattern(r.data_ptr(), c.data_ptr(), r.numel()))
+        a.nh, a.ne, a.regularization, a.eliminate_equalities = nh, 0, 1e-6, 0
+        a.barrier = _BarrierC(0, 0, 100.0, 2e-5)
+        if workgroup:
+            monkeypatch.setenv("UNGAR_AMD_ASSEMBLE_VARIANT", "workgroup")
+        else:
+            monkeypatch.delenv("UNGAR_AMD_ASSEMBLE_VARIANT", raising=False)
+        assert lib.ungar_shooting_assemble(ctypes.byref(a), None) == 0, lib.ungar_last_error()
+        torch.cuda.synchronize()
+        res = {k: v.cpu().numpy() for k, v in out.items()}
+        res["W"] = np.triu(res["W"].reshape(nodes, nd, nd))  # (only the upper triangle is written)
+        return res
+
+    mine, theirs = run(False), run(True)
+    assert np.abs(theirs["W"]).max() > 1.0 and np.abs(theirs["AB"]).max() > 0.1 and not (theirs["b"] == 7.0).any()
+    for key in ("W", "w", "AB", "b", "dz0"):
+        scale = np.abs(theirs[key]).max()
+        assert np.abs(mine[key] - theirs[key]).max() <= 1e-13 * scale, key
