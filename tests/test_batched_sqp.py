@@ -297,3 +297,92 @@ def test_one_wavefront_assembly_of_problems_without_equality_rows_on_random_patt
     for key in ("W", "w", "AB", "b", "dz0"):
         scale = np.abs(theirs[key]).max()
         assert np.abs(mine[key] - theirs[key]).max() <= 1e-13 * scale, key
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_one_wavefront_assembly_with_equality_rows_on_random_patterns(seed, monkeypatch):
+    """ShootingAssembleWaveKernel<25, 24, 16> (quadruped-shaped stage nodes: 12 carried + 13 states, 24 inputs, 16 equality rows eliminated per node) against the
+    workgroup kernel on random sparse patterns and values that the quadruped's own data never produce: equality rows with state and input entries in random places,
+    empty rows, an empty row with a residual (cannot be met: -2), rows without input entries, a carry Jacobian, dense-ish inequality rows.  Same pivots; reduced
+    rows, residuals, W and [A|B] to 1e-12 of their scale (the same matrix-core sequences); w and b to 1e-9 (summed in another order)."""
+    import torch
+    import ungar_amd
+    lib = ungar_amd.load_library()
+    lib.ungar_shooting_assemble.argtypes = [ctypes.POINTER(_AssembleArgs), ctypes.c_void_p]
+    nx, nu, nc, nw, ne, nh, N, B = 13, 24, 12, 2, 16, 12, 2, 6
+    nz, nd = nc + nx, nc + nx + nu
+    rng = np.random.default_rng(100 + seed)
+    dev = lambda a, dt=torch.float64: torch.tensor(np.ascontiguousarray(a), dtype=dt, device="cuda")  # noqa: E731
+    nodes = B * (N + 1)
+
+    def pattern_of(mask):
+        r, c = np.nonzero(mask)
+        return r.astype(np.int32), c.astype(np.int32)
+
+    pH = pattern_of(np.triu(rng.random((nd, nd)) < 0.12) | np.eye(nd, dtype=bool))
+    pg = (np.zeros(nd, dtype=np.int32), np.arange(nd, dtype=np.int32))
+    pf = pattern_of((rng.random((nx, nx + nu)) < 0.4) | np.eye(nx, nx + nu, dtype=bool))
+    pc = pattern_of(rng.random((nc, nx + nu)) < 0.2)
+    emask = np.zeros((ne, nd), dtype=bool)
+    for r in range(ne):
+        kind = rng.random()
+        if kind < 0.25:
+            continue  # empty row (an inactive contact)
+        cols = rng.choice(nd, rng.integers(2, 7), replace=False)
+        emask[r, cols] = True
+        if kind < 0.9:
+            emask[r, nz + rng.integers(0, nu)] = True  # at least one input entry (else: a row the inputs cannot meet unless it is zero)
+        else:
+            emask[r, nz:] = False
+    pe = pattern_of(emask)
+    hmask = rng.random((nh, nd)) < 0.05
+    hmask[np.arange(nh), rng.integers(0, nd, nh)] = True
+    ph = pattern_of(hmask)
+    assert pH[0].size <= 256 and pf[0].size <= 256 and pc[0].size <= 128 and pe[0].size <= 256 and ph[0].size <= 64
+    pats = {k: (dev(v[0], torch.int32), dev(v[1], torch.int32)) for k, v in (("pH", pH), ("pg", pg), ("pf", pf), ("pc", pc), ("pe", pe), ("ph", ph))}
+    L = rng.standard_normal((nodes, nd, nd)) * 0.3
+    H = L @ L.transpose(0, 2, 1) + 3.0 * np.eye(nd)
+    ev = rng.standard_normal((nodes, ne))
+    empty = ~emask.any(axis=1)
+    ev[:, empty] = 0.0
+    if empty.any():
+        ev[1, np.flatnonzero(empty)[0]] = 0.3  # node 1: an empty row with a residual
+    t = {"rows": dev(rng.standard_normal((nodes, nd + nw))), "xm": dev(rng.standard_normal((B, nx))), "f": dev(rng.standard_normal((nodes, nx))),
+         "fJ": dev(rng.standard_normal((nodes, pf[0].size))), "cJ": dev(rng.standard_normal((nodes, pc[0].size))), "lg": dev(rng.standard_normal((nodes, nd))),
+         "lH": dev(H[:, pH[0], pH[1]]), "h": dev(-np.abs(rng.standard_normal((nodes, nh))) * 0.01), "hJ": dev(rng.standard_normal((nodes, ph[0].size))),
+         "eJ": dev(rng.standard_normal((nodes, pe[0].size))), "e": dev(ev)}
+
+    def run(workgroup):
+        out = {"AB": torch.zeros((B * N, nz * nd), dtype=torch.float64, device="cuda"), "b": torch.zeros((B * N, nz), dtype=torch.float64, device="cuda"),
+               "W": torch.zeros((nodes, nd * nd), dtype=torch.float64, device="cuda"), "w": torch.zeros((nodes, nd), dtype=torch.float64, device="cuda"),
+               "E": torch.zeros((B * N, ne * nd), dtype=torch.float64, device="cuda"), "dz0": torch.zeros((B, nz), dtype=torch.float64, device="cuda"),
+               "er": torch.zeros((B * N, ne), dtype=torch.float64, device="cuda"), "piv": torch.full((B * N, ne), 99, dtype=torch.int32, device="cuda")}
+        a = _AssembleArgs()
+        a.dims = _Dims(nx, nu, nc, nw, 0, N, B, 0, 0)
+        for name, key in (("rows", "rows"), ("xm", "xm"), ("f", "f"), ("f_jac", "fJ"), ("carry_jac", "cJ"), ("cost_grad", "lg"), ("cost_hes", "lH"), ("h", "h"), ("h_jac", "hJ"),
+                          ("eq_jac", "eJ"), ("eq", "e")):
+            setattr(a, name, t[key].data_ptr())
+        for name, key in (("AB", "AB"), ("b", "b"), ("W", "W"), ("w", "w"), ("E", "E"), ("dz0", "dz0"), ("eq_reduced", "er"), ("eq_pivots", "piv")):
+            setattr(a, name, out[key].data_ptr())
+        for name, key in (("f_pattern", "pf"), ("carry_pattern", "pc"), ("cost_grad_pattern", "pg"), ("cost_hes_pattern", "pH"), ("h_pattern", "ph"), ("eq_pattern", "pe")):
+            r, c = pats[key]
+            setattr(a, name, _Pattern(r.data_ptr(), c.data_ptr(), r.numel()))
+        a.nh, a.ne, a.regularization, a.eliminate_equalities = nh, ne, 1e-6, 1
+        a.barrier = _BarrierC(0, 0, 100.0, 2e-5)
+        if workgroup:
+            monkeypatch.setenv("UNGAR_AMD_ASSEMBLE_VARIANT", "workgroup")
+        else:
+            monkeypatch.delenv("UNGAR_AMD_ASSEMBLE_VARIANT", raising=False)
+        assert lib.ungar_shooting_assemble(ctypes.byref(a), None) == 0, lib.ungar_last_error()
+        torch.cuda.synchronize()
+        res = {k: v.cpu().numpy() for k, v in out.items()}
+        res["W"] = np.triu(res["W"].reshape(nodes, nd, nd))
+        return res
+
+    mine, theirs = run(False), run(True)
+    assert (mine["piv"] == theirs["piv"]).all(), (mine["piv"], theirs["piv"])
+    assert (theirs["piv"] >= 0).sum() > B * N * 4 and (theirs["piv"] == -1).any()  # (pivots were taken, empty rows took none)
+    for key, tol in (("E", 1e-12), ("er", 1e-12), ("W", 1e-12), ("AB", 1e-12), ("w", 1e-9), ("b", 1e-9), ("dz0", 0.0)):
+        assert np.isfinite(mine[key]).all(), key
+        scale = np.abs(theirs[key]).max()
+        assert np.abs(mine[key] - theirs[key]).max() <= tol * scale, (key, np.abs(mine[key] - theirs[key]).max(), scale)
