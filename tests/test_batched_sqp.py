@@ -47,6 +47,18 @@ def test_workgroup_assembly_route_of_the_problems_without_equality_rows(repo_roo
     assert r.returncode == 0 and f"PASS batched {problem} SQP (batch 512, 4 compared)" in r.stdout
 
 
+@pytest.mark.parametrize("first_stage", ["0", "1", "5"])
+def test_line_search_stages_give_the_same_iterates(repo_root, shared_codegen, first_stage):
+    """The candidate steps are offered in stages -- the first few to every instance, the rest to the LISTED instances that accepted none (default: 2 first) -- and the
+    stages must not change which step an instance takes: all candidates at once (0, no read-back), one first, five first; same comparison with the facade's
+    optimiser (step sizes equal to the last bit) as the default schedule in test_batched_sqp_equals_the_whole_horizon_facade."""
+    exe = os.path.join(repo_root, "build", "batched_quadrotor_test")
+    assert os.path.exists(exe), f"{exe} missing: run __graft_entry__.build()"
+    r = subprocess.run([exe, str(shared_codegen("batched_quadrotor")), "512", "6"], capture_output=True, text=True, timeout=1500, env={**os.environ, "UNGAR_TEST_FIRST_STAGE": first_stage})
+    print(r.stdout[-3000:], r.stderr[-1000:])
+    assert r.returncode == 0 and "PASS batched quadrotor SQP (batch 512, 6 compared)" in r.stdout
+
+
 def test_assembly_kernels_agree(repo_root, tmp_path, shared_codegen):
     """Three routes through the shooting assembly: the one-wavefront kernel (quadruped-shaped stage nodes: tiles of W and [A|B] in registers, the linear
     terms as the homogeneous column of the matrix-core products), the workgroup kernel with its wavefront-specialised sections

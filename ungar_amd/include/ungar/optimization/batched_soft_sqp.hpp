@@ -223,12 +223,13 @@ class BatchedSoftSQPOptimizer {
         // One 4-byte read-back per stage that leaves somebody unresolved.  The stages change what is evaluated, never which step an instance takes
         // (backtracking_line_search.hpp:116-151: the first acceptable candidate in descending order).
         // (more than kStacked candidates at once -- a gamma_alpha close to 1 or a tiny alpha_min: the reference accepts any parameters -- go in groups of kStacked)
-        const index_t stageA = _firstStage > 0 && _firstStage < K ? _firstStage : K;
         const ungar_line_search_parameters ls{_ls.alphaMin, _ls.thetaMin, _ls.thetaMax, _ls.eta, _ls.gammaPhi, _ls.gammaTheta, _ls.gammaAlpha};
         index_t listed = 0;  // 0: all instances
         int32_t *list = nullptr, *nextList = _listA;
-        for (index_t begin = 0; begin < K;) {
-            const index_t wanted = begin == 0 ? stageA : K - begin;
+        std::size_t stage = 0;
+        for (index_t begin = 0; begin < K; ++stage) {
+            const index_t left = K - begin, sized = stage < _stages.size() && _stages[stage] > 0 ? _stages[stage] : left;
+            const index_t wanted = sized < left ? sized : left;
             const index_t count = wanted < kStacked ? wanted : kStacked;
             const bool last = begin + count == K;
             const index_t stacked = listed > 0 ? listed : B;  // instances with trial points in this stage
@@ -321,9 +322,12 @@ class BatchedSoftSQPOptimizer {
     }
     void SetStream(void* hipStream) { _stream = hipStream; }
     /// Offer the first `candidates` step sizes (1, 1/2, ...) to every instance and evaluate the remaining ones only for the instances that accepted none
-    /// of them (default 2) -- every candidate costs a pass of the stage functions over all nodes of the instances it is offered to.  Costs one 4-byte
+    /// of them -- every candidate costs a pass of the stage functions over all nodes of the instances it is offered to.  Costs one 4-byte
     /// read-back per iteration in which somebody needs a smaller step; 0 evaluates all candidates for everybody at once, without any host decision.
-    void SetFirstLineSearchStage(const index_t candidates) { _firstStage = candidates; }
+    void SetFirstLineSearchStage(const index_t candidates) { _stages.assign(1, candidates); }
+    /// The general form: stage s offers the next candidates[s] steps (to every instance for s = 0, to the instances still unresolved afterwards), a last stage the
+    /// remaining ones.  Default {2}: 1 and 1/2 for everybody, the rest (down to alphaMin) for those who took neither.
+    void SetLineSearchStages(std::vector<index_t> candidates) { _stages = std::move(candidates); }
     /// Stage equality rows: eliminated node by node before the recursion (default; the sequential chain then carries no constraint
     /// block) or kept inside the Riccati recursion as the stage KKT block of every knot (false; same solution, for comparison).
     void EliminateEqualityRowsBeforeTheRecursion(const bool on) { _eliminateEqualities = on; }
@@ -502,7 +506,7 @@ class BatchedSoftSQPOptimizer {
     real_t* _er = nullptr;
     int32_t *_status = nullptr, *_active = nullptr, *_pivots = nullptr;
     bool _eliminateEqualities = true;
-    index_t _firstStage = 2;
+    std::vector<index_t> _stages{2};  // ({2, 4} measured: no gain -- quadrotor 1.22 -> 1.27 ms, RC car 0.84 -> 0.86: who needs less than 1/2 mostly needs much less)
     int32_t *_listA = nullptr, *_listB = nullptr;  // instances a stage of the line search left unresolved (read / written alternately)
     index_t _trialStride = 0;
     bool _nodeMajorTrialRows = std::getenv("UNGAR_AMD_NODE_MAJOR_TRIAL_ROWS") != nullptr;  // A/B switch (measurement)
