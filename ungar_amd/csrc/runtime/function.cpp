@@ -110,7 +110,7 @@ struct KeyHasher {
 #ifndef UNGAR_AMD_EMITTER_ID
 #define UNGAR_AMD_EMITTER_ID "unversioned"
 #endif
-constexpr const char* kCacheFormat = "ungar_amd-cache-3";  // bump whenever the emitted kernels' argument list (their ABI) or the meta file changes: 3 = ten-argument kernels (knot stride, direct host results)
+constexpr const char* kCacheFormat = "ungar_amd-cache-4";  // bump whenever the emitted kernels' argument list (their ABI) or the meta file changes: 3 = ten-argument kernels (knot stride, direct host results), 4 = consecutive outputs leave in 16-byte stores
 constexpr const char* kArch = "gfx950";
 constexpr std::size_t kBigKernel = 3000;        // statements above which the machine schedulers are switched off (see below)
 constexpr int64_t kDirectHostResults = 512;  // single-instance host calls: results up to this many doubles are written straight into mapped host memory
@@ -239,9 +239,25 @@ std::string EmitKernel(const std::string& kernelName, const tape::Graph& g, int6
     // front keeps ~n values alive from the top of a whole-horizon kernel and made the register allocator
     // the dominant compile cost (objective value kernel, 960 inputs: 21 s -> 2 s, 1 KB of scratch -> none)
     for (int64_t i = 0; i < nIn; ++i) inNames.push_back("in[" + std::to_string(i) + " * xes]");
+    // Outputs are delivered in index order (Emitter::Emit), so consecutive outputs 2 m, 2 m + 1 leave as ONE 16-byte store where the output operand is
+    // contiguous per instance (oes == 1: the node-major sparse Jacobians / Hessians the batched SQP assembles from).  One lane per instance writes its own
+    // run of doubles: every store instruction is 64 separate transactions at L2 whatever its width, and their RATE bounds these kernels (with coalesced
+    // unit-fastest outputs the quadruped's Jacobian kernels take 60 instead of 112 us) -- pairs halve the transactions.  The run of an instance starts at a
+    // multiple of 8 bytes, not of 16: gfx950 under ROCm executes global_store_dwordx4 at any 4-byte-aligned address (SH_MEM_CONFIG alignment mode
+    // "unaligned", what KFD programs for compute queues; tools/unaligned_store_probe.hip checks it on the box).
     std::vector<tape::OutputSlot> slots;
-    for (std::size_t k = 0; k < values.size(); ++k) slots.push_back({values[k], "out[" + std::to_string(k) + " * oes] = %s;"});
+    for (std::size_t k = 0; k < values.size(); ++k) {
+        const std::string ks = std::to_string(k);
+        if (k % 2 == 0 && k + 1 < values.size()) slots.push_back({values[k], "const double o" + ks + " = %s;"});
+        else if (k % 2 == 1) slots.push_back({values[k], "UNGAR_STORE2(" + std::to_string(k - 1) + ", o" + std::to_string(k - 1) + ", %s);"});
+        else slots.push_back({values[k], "out[" + ks + " * oes] = %s;"});
+    }
     std::ostringstream os;
+    os << "#ifndef UNGAR_STORE2\n"
+          "typedef double ungar_d2 __attribute__((ext_vector_type(2)));\n"
+          "#define UNGAR_STORE2(K, A, B) do { if (oes == 1) { ungar_d2 t_; t_.x = (A); t_.y = (B); *reinterpret_cast<ungar_d2*>(out + (K)) = t_; } "
+          "else { out[(K) * oes] = (A); out[((K) + 1) * oes] = (B); } } while (0)\n"
+          "#endif\n";
     // launched with 64-lane workgroups (LaunchFn): tell the compiler, so that it may use the full register file
     os << "extern \"C\" __global__ __launch_bounds__(64) void " << kernelName
        << "(const double* __restrict__ xp, long long xbs, long long xes, double* __restrict__ outBase, long long obs, long long oes, long long "
