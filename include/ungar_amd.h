@@ -408,7 +408,8 @@ typedef struct ungar_shooting_merit_args {
 } ungar_shooting_merit_args;
 int ungar_shooting_merit(const ungar_shooting_merit_args* args, void* stream);
 
-/* trial[c * batch + b][k] = rows[b][k] with [c|x|u] += alphas[c] * [dZ; dU] (parameters copied; `alphas` host array, at most 16 candidates).
+/* trial[c * batch + b][k] = rows[b][k] with [c|x|u] += alphas[c] * [dZ; dU] (parameters copied; `alphas` host array, at most 16 candidates; a step of
+ * exactly 0 copies the rows whatever dZ / dU hold -- how BatchedSoftSQPOptimizer makes the unit-fastest image of the current rows its derivative kernels read).
  * With carry_inputs the carried slots of row k+1 are the trial inputs of row k; otherwise the caller refreshes them with the carry function
  * (output operand = the carried slots of rows 1..N). */
 int ungar_shooting_trial_rows(const ungar_shooting_dims* dims, const double* rows, const double* dZ, const double* dU, const double* alphas, int64_t candidates,

@@ -1388,7 +1388,9 @@ __global__ __launch_bounds__(256) void ShootingTrialKernel(const ShootingTrialAr
     double* out = a.trial + node * nv;
     for (int j = static_cast<int>(threadIdx.x); j < nv; j += static_cast<int>(blockDim.x)) {
         double v = row[j];
-        if (j < nc && d.carryInputs) {
+        if (alpha == 0.0) {  // (a step of length 0 is the row itself, whatever the direction holds)
+            if (j < nc && d.carryInputs && k > 0) v = RowOf(a.rows, d, b, k - 1)[nz + j];
+        } else if (j < nc && d.carryInputs) {
             if (k > 0) {  // the trial input of the previous knot, the same bits the trial row k - 1 holds
                 const double* prev = RowOf(a.rows, d, b, k - 1);
                 v = fma(alpha, a.dU[(b * N + (k - 1)) * d.nu + j], prev[nz + j]);
@@ -1453,7 +1455,9 @@ __global__ __launch_bounds__(256) void ShootingTrialUnitFastestKernel(const Shoo
                 const long long b = a.listed > 0 ? a.instances[i] : i;
                 const double alpha = a.alphas[c];
                 double v = RowOf(a.rows, d, b, k)[j];
-                if (j < nc && d.carryInputs) {
+                if (alpha == 0.0) {  // (a step of length 0 is the row itself, whatever the direction holds -- the unit-fastest image of the current rows)
+                    if (j < nc && d.carryInputs && k > 0) v = RowOf(a.rows, d, b, k - 1)[nz + j];
+                } else if (j < nc && d.carryInputs) {
                     if (k > 0) v = fma(alpha, a.dU[(b * N + (k - 1)) * d.nu + j], RowOf(a.rows, d, b, k - 1)[nz + j]);
                 } else if (j < nz) {
                     v = fma(alpha, a.dZ[(b * (N + 1) + k) * nz + j], v);

@@ -117,20 +117,30 @@ class BatchedSoftSQPOptimizer {
     /// One SQP iteration of every active instance (the body of the reference's loop, soft_sqp.hpp:68-99).
     void Iterate() {
         const index_t N = _p.horizon, B = _batch, K = static_cast<index_t>(_alphas.size());
-        // ---- derivatives at the current rows
-        Evaluate(*_p.dynamics, 0, _rows, _p.StateOffset(), _f, B * (N + 1));
-        Evaluate(*_p.dynamics, 1, _rows, _p.StateOffset(), _fJ, B * (N + 1));
-        if (_p.carry) Evaluate(*_p.carry, 1, _rows, _p.StateOffset(), _cJ, B * (N + 1));
-        Evaluate(*_p.cost, 0, _rows, 0, _l, B * (N + 1));
-        Evaluate(*_p.cost, 1, _rows, 0, _lg, B * (N + 1));
-        Evaluate(*_p.cost, 2, _rows, 0, _lH, B * (N + 1));
+        // ---- derivatives at the current rows.  The stage kernels run one lane per node: they read a unit-fastest image of the rows (the trial-row kernel with
+        // one candidate of step 0 writes it: a copy) with coalesced loads, as they do in the line search -- a node-major row is 64 separate 8-byte
+        // transactions per load instruction
+        real_t* at = _rows;
+        index_t atStride = 0;
+        if (_trialStride > 0 && std::getenv("UNGAR_AMD_NODE_MAJOR_DERIVATIVE_ROWS") == nullptr) {
+            const real_t zero = 0.0;
+            Check(ungar_shooting_trial_rows(&_dims, _rows, _dZ, _dU, &zero, 1, _trial, _trialStride, _stream));
+            at = _trial;
+            atStride = _trialStride;
+        }
+        Evaluate(*_p.dynamics, 0, at, _p.StateOffset(), _f, B * (N + 1), atStride);
+        Evaluate(*_p.dynamics, 1, at, _p.StateOffset(), _fJ, B * (N + 1), atStride);
+        if (_p.carry) Evaluate(*_p.carry, 1, at, _p.StateOffset(), _cJ, B * (N + 1), atStride);
+        Evaluate(*_p.cost, 0, at, 0, _l, B * (N + 1), atStride);
+        Evaluate(*_p.cost, 1, at, 0, _lg, B * (N + 1), atStride);
+        Evaluate(*_p.cost, 2, at, 0, _lH, B * (N + 1), atStride);
         if (_p.inequality) {
-            Evaluate(*_p.inequality, 0, _rows, 0, _h, B * (N + 1));
-            Evaluate(*_p.inequality, 1, _rows, 0, _hJ, B * (N + 1));
+            Evaluate(*_p.inequality, 0, at, 0, _h, B * (N + 1), atStride);
+            Evaluate(*_p.inequality, 1, at, 0, _hJ, B * (N + 1), atStride);
         }
         if (_p.equality) {
-            Evaluate(*_p.equality, 0, _rows, 0, _e, B * (N + 1));
-            Evaluate(*_p.equality, 1, _rows, 0, _eJ, B * (N + 1));
+            Evaluate(*_p.equality, 0, at, 0, _e, B * (N + 1), atStride);
+            Evaluate(*_p.equality, 1, at, 0, _eJ, B * (N + 1), atStride);
         }
         // ---- QP data and solve (soft_sqp.hpp:143-158)
         ungar_shooting_assemble_args a{};
