@@ -231,7 +231,14 @@ std::string DefaultFolder() {
 }
 
 /// Emits one `extern "C" __global__` kernel: lane = instance, strided operands.
+/// UNGAR_AMD_SCALAR_STORES=1 (part of the cache key): every output as its own 8-byte store -- for a platform whose compute queues are not in the unaligned access mode.
+bool PairOutputStores() {
+    const char* e = std::getenv("UNGAR_AMD_SCALAR_STORES");
+    return !(e && e[0] == '1');
+}
+
 std::string EmitKernel(const std::string& kernelName, const tape::Graph& g, int64_t nIn, const std::vector<tape::Id>& values, std::size_t* statements) {
+    const bool pairs = PairOutputStores();
     std::vector<std::string> inNames;
     inNames.reserve(static_cast<std::size_t>(nIn));
     // inputs are spelled as loads at their uses (`in` derives from a __restrict__ parameter, so the compiler
@@ -248,8 +255,8 @@ std::string EmitKernel(const std::string& kernelName, const tape::Graph& g, int6
     std::vector<tape::OutputSlot> slots;
     for (std::size_t k = 0; k < values.size(); ++k) {
         const std::string ks = std::to_string(k);
-        if (k % 2 == 0 && k + 1 < values.size()) slots.push_back({values[k], "const double o" + ks + " = %s;"});
-        else if (k % 2 == 1) slots.push_back({values[k], "UNGAR_STORE2(" + std::to_string(k - 1) + ", o" + std::to_string(k - 1) + ", %s);"});
+        if (pairs && k % 2 == 0 && k + 1 < values.size()) slots.push_back({values[k], "const double o" + ks + " = %s;"});
+        else if (pairs && k % 2 == 1) slots.push_back({values[k], "UNGAR_STORE2(" + std::to_string(k - 1) + ", o" + std::to_string(k - 1) + ", %s);"});
         else slots.push_back({values[k], "out[" + ks + " * oes] = %s;"});
     }
     std::ostringstream os;
@@ -340,6 +347,7 @@ int ungar_function_make(const ungar_tape_node* nodes, int64_t num_nodes, const i
     int jacobianMode = 0;
     if (const char* forced = std::getenv("UNGAR_AMD_JACOBIAN_MODE")) jacobianMode = std::atoi(forced) == 1 ? 1 : std::atoi(forced) == 2 ? 2 : 0;
     key.Int(jacobianMode);
+    key.Int(PairOutputStores() ? 1 : 0);
     key.Int(n);
     key.Int(p);
     key.Int(m);
