@@ -13,13 +13,18 @@ from oracle import ungar_oracle as O
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("variant", ["", "_eigen"])  # "_eigen": the same test built on the real Eigen 3.4 (UNGAR_AMD_USE_SYSTEM_EIGEN)
+# "_eigen": the same test built on the real Eigen 3.4 (UNGAR_AMD_USE_SYSTEM_EIGEN); "scalar": the generated kernels without paired 16-byte output stores
+# (UNGAR_AMD_SCALAR_STORES=1: the other spelling of every output store, same answers required)
+@pytest.mark.parametrize("variant", ["", "_eigen", "scalar"])
 def test_function_facade_on_gpu(repo_root, tmp_path, variant):
+    env = dict(os.environ)
+    if variant == "scalar":
+        variant, env["UNGAR_AMD_SCALAR_STORES"] = "", "1"
     exe = os.path.join(repo_root, "build", "function_test" + variant)
     if variant and not os.path.exists(exe):
         pytest.skip("the real-Eigen build needs the reference's bundled Eigen at build time")
     assert os.path.exists(exe), "build/function_test missing: run __graft_entry__.build()"
-    r = subprocess.run([exe, str(tmp_path / "codegen")], capture_output=True, text=True, timeout=900)
+    r = subprocess.run([exe, str(tmp_path / "codegen")], capture_output=True, text=True, timeout=900, env=env)
     print(r.stdout[-3000:], r.stderr[-2000:])
     assert r.returncode == 0 and "ALL PASSED" in r.stdout
     vals = {}
