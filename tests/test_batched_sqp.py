@@ -233,7 +233,7 @@ def test_redundant_equality_rows_take_no_pivot(nx, nu, monkeypatch):
         assert (bad["piv"][:, 2] == -2).all() and (bad["piv"][:, 3] == -1).all() and (bad["piv"][:, :2] == ref["piv"]).all()
 
 
-@pytest.mark.parametrize("nx,nu,nh,dense_row", [(13, 4, 8, False), (8, 2, 6, False), (20, 9, 5, True), (30, 12, 14, True)])
+@pytest.mark.parametrize("nx,nu,nh,dense_row", [(13, 4, 8, False), (8, 2, 6, False), (20, 9, 5, True), (30, 12, 14, True), (10, 3, 0, False)])
 def test_one_wavefront_assembly_of_problems_without_equality_rows_on_random_patterns(nx, nu, nh, dense_row, monkeypatch):
     """ShootingAssembleSmallKernel (stage problems without equality rows, nd + 1 <= 64) against the workgroup kernel (UNGAR_AMD_ASSEMBLE_VARIANT=workgroup) on random
     SPARSE patterns -- Hessian, gradient, dynamics Jacobian, inequality Jacobian with rows of one to several entries, and (dense_row) a row whose entry pairs do not
