@@ -49,6 +49,13 @@ int main(void) {
             bad += ungar_shooting_trial_rows_listed(&dims, dummy, dummy, dummy, alphas, 14, (const int32_t*)dummy, dims.batch + 1, dummy, 0, 0) != UNGAR_E_INVALID; /* more listed than there are */
             bad += ungar_shooting_assemble(&asm_args, 0) != UNGAR_E_INVALID; /* null operands */
             bad += ungar_shooting_select(&dims, &ls, alphas, 14, 0, dummy, dummy, dummy, dummy, dummy, dummy, dummy, 0, 0, dummy, dummy, 0, 0, 0, 0) != UNGAR_E_INVALID;
+            /* listed variants: a list exactly when listed > 0; the next list is filled through the counter of a call that is not the last, and is not the list being read */
+            bad += ungar_shooting_select_listed(&dims, &ls, alphas, 2, dummy, dummy, dummy, dummy, dummy, dummy, dummy, dummy, 0, 0, dummy, dummy, 0, UNGAR_SEARCH_NOT_LAST,
+                                                (int32_t*)dummy, 0, 3, 0, 0) != UNGAR_E_INVALID;
+            bad += ungar_shooting_select_listed(&dims, &ls, alphas, 2, dummy, dummy, dummy, dummy, dummy, dummy, dummy, dummy, 0, 0, dummy, dummy, 0, 0, (int32_t*)dummy, 0, 0,
+                                                (int32_t*)dummy, 0) != UNGAR_E_INVALID; /* next list in the LAST call */
+            bad += ungar_shooting_select_listed(&dims, &ls, alphas, 2, dummy, dummy, dummy, dummy, dummy, dummy, dummy, dummy, 0, 0, dummy, dummy, 0, UNGAR_SEARCH_NOT_LAST,
+                                                (int32_t*)dummy, (const int32_t*)dummy, 3, (int32_t*)dummy, 0) != UNGAR_E_INVALID; /* next list == list */
             bad += ungar_device_malloc(&ptr, -1) != UNGAR_E_INVALID;
             bad += ungar_device_malloc(&ptr, 0) != UNGAR_OK || ptr != 0;
             bad += ungar_function_forward_zero_nodes(0, &op, &op, 4, 2, 0) != UNGAR_E_INVALID;
