@@ -27,7 +27,8 @@ extern "C" {
 #endif
 
 /* ABI version of THIS header.  It changes whenever a struct below grows or an entry point's parameter list changes (4: ungar_ocp_qp with its
- * equality-row fields, `status` in ungar_ocp_line_search_select / _accept).  ungar_abi_version() returns the version the LIBRARY was built with:
+ * equality-row fields, `status` in ungar_ocp_line_search_select / _accept; 5: `instances` in ungar_shooting_merit_args, the entry points
+ * ungar_shooting_trial_rows_listed / ungar_shooting_select_listed of the staged line search).  ungar_abi_version() returns the version the LIBRARY was built with:
  * a wrapper compiled against an older header must compare the two before its first call -- a mismatch silently shifts arguments otherwise.
  * (ungar_amd/__init__.py and Ungar::BatchedSoftSQPOptimizer do.) */
 #define UNGAR_AMD_ABI_VERSION 5
@@ -526,6 +527,10 @@ int ungar_function_eval_host(ungar_function* fn, int32_t what, const double* xp_
 const char* ungar_last_error(void);
 /* "ungar_amd <version> gfx950 hip <runtime version>" */
 const char* ungar_version(void);
+/* 0: the shipped library.  1: the measurement build (ungar_amd/lib/measurement/libungar_amd.so, same ABI): A/B routes between kernels, per-phase
+ * clocks and experiment knobs selectable through UNGAR_AMD_* / UNGAR_GN_* environment variables (csrc/runtime/measurement.hpp) -- what tools/ and the
+ * agreement tests between two routes load.  The shipped library reads none of them. */
+int32_t ungar_measurement_build(void);
 
 #ifdef __cplusplus
 }

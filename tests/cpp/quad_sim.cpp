@@ -5,6 +5,7 @@
 // factorisation, ownership of rows/columns, rotations -- against the oracle's golden vectors before
 // the same text is compiled for gfx950.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "anymal_quad_gen.hpp"
@@ -89,6 +90,24 @@ struct SimIO {
         for (int l = 0; l < 4; ++l) put(l, rs[l], col, ks[l], vs[l]->v[l]);  // the lane of leg l writes entry l
     }
     void j_base_shared(int row, int colBase, int, int, int k0, int, int, int, const Quad& v) const { put(0, row, colBase, k0, v.v[(row + colBase) & 3]); }
+    // paired sinks (two entries of a column per statement: one 16-byte store on the GPU): here the two entries one after the other
+    void j_leg2(int row, int row2, int colBase, int legMul, int rot_, int k0, int k1, int k2, int k3, int m0, int m1, int m2, int m3, const Quad& v, const Quad& v2) const {
+        if (row2 != row + 18) std::abort();  // the odd lanes' offset of the paired store assumes this distance
+        j_leg(row, colBase, legMul, rot_, k0, k1, k2, k3, v);
+        j_leg(row2, colBase, legMul, rot_, m0, m1, m2, m3, v2);
+    }
+    void j_base_own2(int row, int row2, int colBase, int legMul, int rot_, int k0, int k1, int k2, int k3, int m0, int m1, int m2, int m3, const Quad& v,
+                     const Quad& v2) const {
+        if (row2 != row + 1) std::abort();
+        j_base_own(row, colBase, legMul, rot_, k0, k1, k2, k3, v);
+        j_base_own(row2, colBase, legMul, rot_, m0, m1, m2, m3, v2);
+    }
+    void j_base_shared2(int row, int row2, int colBase, int legMul, int rot_, int k0, int k1, int k2, int k3, int m0, int m1, int m2, int m3, const Quad& v,
+                        const Quad& v2) const {
+        if (row2 != row + 1) std::abort();
+        j_base_shared(row, colBase, legMul, rot_, k0, k1, k2, k3, v);
+        j_base_shared(row2, colBase, legMul, rot_, m0, m1, m2, m3, v2);
+    }
 };
 
 }  // namespace

@@ -77,6 +77,18 @@ struct StoreIO : TimedIOT<TIMED> {
     __device__ __forceinline__ void j_base_shared(int row, int colBase, int, int, int, int, int, int, double v) const {
         put(jb + static_cast<unsigned>(row * 49 + colBase) * je * kMul, v);
     }
+    __device__ __forceinline__ void j_leg2(int row, int row2, int colBase, int legMul, int rot, int, int, int, int, int, int, int, int, double v, double v2) const {
+        j_leg(row, colBase, legMul, rot, 0, 0, 0, 0, v);
+        j_leg(row2, colBase, legMul, rot, 0, 0, 0, 0, v2);
+    }
+    __device__ __forceinline__ void j_base_own2(int row, int row2, int colBase, int, int, int, int, int, int, int, int, int, int, double v, double v2) const {
+        j_base_own(row, colBase, 0, 0, 0, 0, 0, 0, v);
+        j_base_own(row2, colBase, 0, 0, 0, 0, 0, 0, v2);
+    }
+    __device__ __forceinline__ void j_base_shared2(int row, int row2, int colBase, int, int, int, int, int, int, int, int, int, int, double v, double v2) const {
+        j_base_shared(row, colBase, 0, 0, 0, 0, 0, 0, v);
+        j_base_shared(row2, colBase, 0, 0, 0, 0, 0, 0, v2);
+    }
 };
 
 // REMAP: output ADDRESSES as if the lanes of a leg were contiguous (lane = 16 * leg + node): timing only,

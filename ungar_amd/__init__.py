@@ -33,8 +33,15 @@ class UngarError(RuntimeError):
 
 
 def library_path() -> str:
-    """In-tree library; UNGAR_AMD_LIBRARY overrides it (A/B builds of the same ABI)."""
+    """In-tree library; UNGAR_AMD_LIBRARY overrides it (another build of the same ABI, e.g. `measurement_library_path()`)."""
     return os.environ.get("UNGAR_AMD_LIBRARY") or os.path.join(_HERE, "lib", "libungar_amd.so")
+
+
+def measurement_library_path() -> str:
+    """The measurement build of the library (-DUNGAR_AMD_MEASUREMENT, csrc/runtime/measurement.hpp): the only build in which the A/B routes,
+    per-phase clocks and experiment knobs of tools/ can be selected through the environment.  Same ABI; load it by pointing UNGAR_AMD_LIBRARY
+    (Python) or LD_LIBRARY_PATH (the C++ programs) at it."""
+    return os.path.join(_HERE, "lib", "measurement", "libungar_amd.so")
 
 
 class _ModelInfo(ctypes.Structure):
@@ -68,7 +75,10 @@ def load_library() -> ctypes.CDLL:
         raise UngarError(f"{path} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
                          "(ungar_amd has no CPU fallback).")
     lib = ctypes.CDLL(path)
-    lib.ungar_abi_version.restype = ctypes.c_int32
+    try:
+        lib.ungar_abi_version.restype = ctypes.c_int32
+    except AttributeError:
+        raise UngarError(f"{path} predates ABI versioning (no ungar_abi_version): rebuild it with `python -c 'import __graft_entry__ as g; g.build()'`") from None
     if lib.ungar_abi_version() != ABI_VERSION:  # the structs below mirror include/ungar_amd.h at this version: a mismatch would shift arguments silently
         raise UngarError(f"{path} reports ABI version {lib.ungar_abi_version()}, these bindings were written for {ABI_VERSION} (include/ungar_amd.h: UNGAR_AMD_ABI_VERSION)")
     vp, i64p = ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)

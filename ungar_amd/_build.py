@@ -19,6 +19,7 @@ GEN = os.path.join(CSRC, "gen")
 BUILD = os.path.join(ROOT, "build")
 LIBDIR = os.path.join(ROOT, "ungar_amd", "lib")
 LIB = os.path.join(LIBDIR, "libungar_amd.so")
+MEASUREMENT_LIB = os.path.join(LIBDIR, "measurement", "libungar_amd.so")
 ORACLE_GEN = os.path.join(ROOT, "oracle", "_gen")
 RBD_MODELS = ("anymal_rnea", "anymal_crba", "anymal_minv", "anymal_feet", "anymal_centroidal")
 MODELS = ("quadrotor", "rc_car", "srbd", "srbd_ineq", "quadrotor_ineq", "rc_car_ineq", "srbd_feet", "anymal", "anymal_ad", "anymal_reg") + RBD_MODELS
@@ -64,7 +65,7 @@ def generate(exe: str):
     edit to the generator recompiles just the kernels it affects (a from-scratch library build takes ~6 minutes)."""
     import filecmp
     import shutil
-    outs = [os.path.join(GEN, f"{m}_gen.hpp") for m in MODELS + ("quadrotor_cost", "srbd_cost", "rc_car_cost", "anymal_cost", "anymal_quad", "anymal_rnea_quad", "anymal_crba_quad", "anymal_centroidal_quad")] + [os.path.join(ORACLE_GEN, f"{m}_cg.c") for m in C_MODELS]
+    outs = [os.path.join(GEN, f"{m}_gen.hpp") for m in MODELS + ("quadrotor_cost", "srbd_cost", "rc_car_cost", "anymal_cost", "anymal_quad", "anymal_split", "anymal_rnea_quad", "anymal_crba_quad", "anymal_centroidal_quad")] + [os.path.join(ORACLE_GEN, f"{m}_cg.c") for m in C_MODELS]
     robot = os.path.join(ROOT, "ungar_amd", "data", "anymal_b.robot")
     stamp = os.path.join(BUILD, "codegen.stamp")
     if _newer(outs + [stamp], [exe, robot]):
@@ -118,6 +119,8 @@ def build_library(jobs: int | None = None):
     src = os.path.join(CSRC, "runtime", "function.cpp")
     units.append((src, os.path.join(BUILD, "function.o"), [src, abi_hdr] + _tree(os.path.join(CSRC, "tape"))))
 
+    measurement_hdr = os.path.join(CSRC, "runtime", "measurement.hpp")
+    units = [(s_, o_, d_ + [measurement_hdr]) for s_, o_, d_ in units]
     # the two comparison kernels (taped ABA / structured, lane per node: 40-60 k statements in one basic block)
     # spend > 90 % of their compile time in the machine schedulers; without them the from-scratch build drops
     # from 12.7 to ~6 minutes.  The product kernels keep the full pipeline.
@@ -139,10 +142,38 @@ def build_library(jobs: int | None = None):
             _run(["hipcc", *HIPCC_FLAGS, *extra, *(no_sched if os.path.basename(src) in fast else []), "-c", src, "-o", obj])
         return obj
 
+    # Measurement build (csrc/runtime/measurement.hpp): the translation units that read a measurement switch are compiled a second time with
+    # -DUNGAR_AMD_MEASUREMENT; everything else is shared between the two libraries.  ungar_amd/lib/measurement/libungar_amd.so has the same
+    # ABI and is what tools/ and the agreement tests between two kernel routes load; the shipped library contains none of the switches.
+    measurement_dir = os.path.join(BUILD, "measurement")
+    os.makedirs(measurement_dir, exist_ok=True)
+    os.makedirs(os.path.dirname(MEASUREMENT_LIB), exist_ok=True)
+
+    def reads_switches(src):
+        if os.path.basename(src) in ("function.cpp", "c_api.cpp"):  # (function.cpp through tape/emit.hpp; c_api.cpp reports the build flavour)
+            return True
+        text = open(src).read()
+        return "UNGAR_MEASUREMENT_SWITCH" in text or "UNGAR_AMD_MEASUREMENT_BUILD" in text
+
+    measurement_units = [(src, os.path.join(measurement_dir, os.path.basename(obj)), deps) for src, obj, deps in units if reads_switches(src)]
+
+    def compile_measurement_unit(u):
+        src, obj, deps = u
+        if not _newer([obj], deps):
+            extra = [f'-DUNGAR_AMD_EMITTER_ID="{emitter_id}"'] if os.path.basename(src) == "function.cpp" else []
+            _run(["hipcc", *HIPCC_FLAGS, "-DUNGAR_AMD_MEASUREMENT", *extra, "-c", src, "-o", obj])
+        return obj
+
     with ThreadPoolExecutor(max_workers=jobs or min(8, os.cpu_count() or 1)) as pool:
-        objs = list(pool.map(compile_unit, units))
+        futures = [pool.submit(compile_unit, u) for u in units] + [pool.submit(compile_measurement_unit, u) for u in measurement_units]
+        results = [f.result() for f in futures]
+    objs, measurement_objs = results[:len(units)], results[len(units):]
     if not _newer([LIB], objs):
         _run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
+    replaced = {os.path.basename(o) for o in measurement_objs}
+    all_measurement = [o for o in objs if os.path.basename(o) not in replaced] + measurement_objs
+    if not _newer([MEASUREMENT_LIB], all_measurement):
+        _run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", MEASUREMENT_LIB, *all_measurement])
     return LIB
 
 

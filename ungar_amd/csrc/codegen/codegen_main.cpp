@@ -438,11 +438,40 @@ void EmitC(const Generated& g, const std::string& dir) {
 
 }  // namespace
 
+/// The lane-per-leg program split over the two wavefronts of a workgroup (quad_leg_program.hpp: QuadRole): two function templates in
+/// gen/anymal_split_gen.hpp, ProducerQuad (right-hand sides of the columns that need the RNEA tangents) and ConsumerQuad (everything else).
+static void EmitSplitQuad(const rbd::Model& anymal, const tape::SparseEntries& pattern, const std::string& outDir, int producerSlots, int producerUniform,
+                          int consumerSlots, int consumerUniform, int rematConsumers, int rematDepth, int prefetch, bool pairStores) {
+    std::ostringstream so;
+    so << "// GENERATED by ungar_amd/csrc/codegen (quad_leg_program.hpp, split program) -- do not edit.\n"
+       << "#pragma once\n#ifndef __host__\n#define __host__\n#endif\n#ifndef __device__\n#define __device__\n#endif\n\n"
+       << "namespace ungar_amd::gen::anymal_split {\n\n"
+       << "inline constexpr int kMessages = " << codegen::kQuadMessages << ", kMessageItems = " << codegen::kQuadMessageItems << ";\n";
+    for (const codegen::QuadRole role : {codegen::QuadRole::Producer, codegen::QuadRole::Consumer}) {
+        const bool producer = role == codegen::QuadRole::Producer;
+        const codegen::QuadProgram qp = codegen::RecordQuadLegProgram(anymal, pattern, 1, false, role, pairStores);
+        tape::EmitStats qs;
+        int lds = 0, uniformUsed = 0;
+        const std::string fn = codegen::EmitQuadProgram(qp, producer ? "ProducerQuad" : "ConsumerQuad", &qs, true, producer ? producerSlots : consumerSlots, &lds, rematConsumers,
+                                                           rematDepth, prefetch, producer ? producerUniform : consumerUniform, &uniformUsed, false);
+        so << "// " << (producer ? "producer" : "consumer") << ": " << qs.statements << " statements, " << qs.flops << " flops per lane\n"
+           << "inline constexpr int k" << (producer ? "Producer" : "Consumer") << "LdsSlots = " << lds << ", k" << (producer ? "Producer" : "Consumer")
+           << "LdsUniformSlots = " << uniformUsed << ";\n"
+           << fn << "\n";
+        std::fprintf(stderr, "[codegen] anymal_split %s: %zu statements, %zu flops per lane, LDS home %d + %d slots\n", producer ? "producer" : "consumer", qs.statements,
+                     qs.flops, lds, uniformUsed);
+    }
+    so << "}  // namespace ungar_amd::gen::anymal_split\n";
+    std::ofstream sf(outDir + "/anymal_split_gen.hpp");
+    sf << so.str();
+}
+
 int main(int argc, char** argv) {
     std::string outDir, cDir, robot;
     int jacMode = 0, structuredDMode = 1, ldsSlots = 320;
     int rematConsumers = 2, rematDepth = 3, prefetch = 48;
     int quadColumnsPerPhase = 1, quadRematConsumers = 4, quadRematDepth = 4;  // tools/sweep_quad.sh on MI355X
+    bool quadPairStores = false;      // fused program: sinks carry two entries of a column -> one 16-byte store in kernels with paired stores (quad_kernel.hpp: PAIR; tools/quad_split_bench.hip)
     bool quadMergeShared = false;     // four base-row entries of a shared column per store instruction (measured: no gain, 0.347 vs 0.343 ms)
     int quadPrefetch = 48;            // LDS loads are hoisted this many statements ahead of their first use ...
     bool quadPrefetchAcross = false;  // ... and may cross into the tail of the previous phase
@@ -451,6 +480,8 @@ int main(int argc, char** argv) {
     bool rneaQuadReverse = true;  // partials of the lane-local function by reverse accumulation, one phase per row (measured: 11 % faster than forward / per column)
     int rneaQuadLdsSlots = 60, rneaQuadUniformSlots = 80;  // LDS home of the lane-per-leg joint-torque program (same budget)
     int quadLdsSlots = 60;  // 64-lane workgroups, four per CU: 160 KiB / 4 / 64 lanes / 8 B
+    // split program (producer / consumer wavefront of a 128-lane workgroup, two wavefronts per SIMD): LDS homes of the two halves
+    int splitProducerSlots = 24, splitProducerUniform = 12, splitConsumerSlots = 4, splitConsumerUniform = 80;
     int rbdLdsSlots = -1;  // >= 0 overrides the per-lane LDS home of the phased rigid-body quantity Jacobians (0 = plain bodies only)
     std::vector<std::string> only;
     for (int i = 1; i < argc; ++i) {
@@ -470,6 +501,13 @@ int main(int argc, char** argv) {
             rneaQuadLdsSlots = std::atoi(argv[++i]);
             rneaQuadUniformSlots = std::atoi(argv[++i]);
         }
+        else if (a == "--split-slots" && i + 4 < argc) {
+            splitProducerSlots = std::atoi(argv[++i]);
+            splitProducerUniform = std::atoi(argv[++i]);
+            splitConsumerSlots = std::atoi(argv[++i]);
+            splitConsumerUniform = std::atoi(argv[++i]);
+        }
+        else if (a == "--quad-pair-stores" && i + 1 < argc) quadPairStores = std::atoi(argv[++i]) != 0;
         else if (a == "--quad-merge-shared" && i + 1 < argc) quadMergeShared = std::atoi(argv[++i]) != 0;
         else if (a == "--quad-uniform-slots" && i + 1 < argc) quadUniformSlots = std::atoi(argv[++i]);
         else if (a == "--quad-prefetch" && i + 2 < argc) {
@@ -548,7 +586,7 @@ int main(int argc, char** argv) {
                 EmitHip(st, outDir, true, 0);
             }
             if (wanted("anymal")) {  // lane-per-leg SPMD program (dense Jacobian path of the 'anymal' model)
-                const codegen::QuadProgram qp = codegen::RecordQuadLegProgram(anymal, adv.jac, quadColumnsPerPhase, quadMergeShared);
+                const codegen::QuadProgram qp = codegen::RecordQuadLegProgram(anymal, adv.jac, quadColumnsPerPhase, quadMergeShared, codegen::QuadRole::Fused, quadPairStores && !quadMergeShared);
                 tape::EmitStats qs;
                 int quadLds = 0, quadUniformUsed = 0;
                 const std::string fn = codegen::EmitQuadProgram(qp, "ValueJacobianQuad", &qs, true, quadLdsSlots, &quadLds, quadRematConsumers, quadRematDepth, quadPrefetch,
@@ -597,6 +635,8 @@ int main(int argc, char** argv) {
                 std::fprintf(stderr, "[codegen] anymal_quad value only: %zu statements, %zu flops per lane\n", vs.statements, vs.flops);
                 std::ofstream qf(outDir + "/anymal_quad_gen.hpp");
                 qf << qo.str();
+                EmitSplitQuad(anymal, adv.jac, outDir, splitProducerSlots, splitProducerUniform, splitConsumerSlots, splitConsumerUniform, quadRematConsumers, quadRematDepth,
+                              quadPrefetch, true);
                 std::fprintf(stderr, "[codegen] anymal_quad (lane per leg): %zu statements, %zu flops per lane, %zu table constants\n", qs.statements, qs.flops,
                              qp.constants.size());
             }

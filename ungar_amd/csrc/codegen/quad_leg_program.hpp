@@ -41,11 +41,20 @@ struct QuadProgram {
     std::vector<std::size_t> phaseStarts;    // slot indices where a new phase (Jacobian column) begins
     std::vector<std::string> inputNames;     // spelling of every tape input in the generated code
     std::vector<char> inputUniform;          // 1: same value in the four lanes of a quad (base state, dt)
+    std::vector<char> inputLate;             // 1: read where it is used, in every phase that uses it (channel items of the split program)
     // distinct per-leg CSR index patterns (k_L - k_0, L = 0..3) of the per-lane sinks: the sparse kernel keeps
     // one per-lane base pointer per pattern, so that a sparse store costs what a dense one does
     std::vector<std::array<int, 4>> sparseDeltas;
     std::vector<std::array<double, 4>> constants;  // constants[k][leg]
 };
+
+/// The node program as ONE wavefront (Fused), or split over the two wavefronts of a workgroup:
+///   Producer: leg kinematics, bias forces, RNEA tangents -> right-hand sides of the Jacobian columns, handed over through an LDS ring;
+///   Consumer: composite inertias, block-arrow factorisation, solves, integrator chain, result stores.
+/// Each half keeps its state in 256 registers + its share of LDS, so that TWO wavefronts run per SIMD.
+enum class QuadRole { Fused, Producer, Consumer };
+inline constexpr int kQuadMessageItems = 9;   // values per lane and message: r_L(3), r_b(6)
+inline constexpr int kQuadMessages = 13;      // bias forces + 12 columns whose right-hand side needs the RNEA tangents
 
 namespace detail {
 
@@ -104,7 +113,7 @@ inline std::vector<LegConstantRef> CollectLegConstants(const rbd::Model& model, 
 
 /// Records the leg-lane program for a free-flyer + 4 x (3 revolute) robot.
 inline QuadProgram RecordQuadLegProgram(const rbd::Model& model, const tape::SparseEntries& pattern, int columnsPerPhase = 1,
-                                        bool mergeSharedStores = false) {
+                                        bool mergeSharedStores = false, QuadRole role = QuadRole::Fused, bool pairStores = false) {
     using namespace rbd;
     using namespace rbd::detail;
     CheckFloatingBaseQuadruped(model);
@@ -133,7 +142,11 @@ inline QuadProgram RecordQuadLegProgram(const rbd::Model& model, const tape::Spa
     const std::vector<LegConstantRef> cref = CollectLegConstants(model, P.constants);
     const int K = static_cast<int>(P.constants.size());
     const int kAux = kConst + K;  // aux: accb(6), aL(3)
-    const int nInputs = kAux + 9;
+    const int kRecv = kAux + 9;   // split program: items of the producer's messages as the consumer sees them
+    const int nInputs = kRecv + kQuadMessages * kQuadMessageItems;
+    const bool fused = role == QuadRole::Fused, producer = role == QuadRole::Producer, consumer = role == QuadRole::Consumer;
+    if (pairStores && mergeSharedStores) throw std::runtime_error("quad program: paired stores and merged shared stores exclude each other");
+    if (!fused && (columnsPerPhase != 1 || mergeSharedStores)) throw std::runtime_error("quad program: the split program takes one column per phase");
     std::vector<AD> in = tape::Independent(nInputs);
     tape::Graph& g = tape::CurrentGraph();
     for (int i = 0; i < 7; ++i) P.inputNames.push_back("io.qb(" + std::to_string(i) + ")");
@@ -143,8 +156,15 @@ inline QuadProgram RecordQuadLegProgram(const rbd::Model& model, const tape::Spa
     for (int i = 0; i < 3; ++i) P.inputNames.push_back("io.ul(" + std::to_string(i) + ")");
     P.inputNames.push_back("io.dt()");
     for (int i = 0; i < K; ++i) P.inputNames.push_back("io.c(" + std::to_string(i) + ")");
-    for (int i = 0; i < 9; ++i) P.inputNames.push_back("aux_unused");
+    // the producer reads the solved accelerations the consumer hands back: a_b + gamma (6, the same in the four lanes), a_L (3)
+    for (int i = 0; i < 9; ++i) P.inputNames.push_back(producer ? "io.acc(" + std::to_string(i) + ")" : "aux_unused");
+    for (int m = 0; m < kQuadMessages; ++m)
+        for (int i = 0; i < kQuadMessageItems; ++i) P.inputNames.push_back("io.recv(" + std::to_string(m) + ", " + std::to_string(i) + ")");
     P.inputUniform.assign(P.inputNames.size(), 0);
+    P.inputLate.assign(P.inputNames.size(), 0);
+    for (int i = kAux; i < nInputs; ++i) P.inputLate[static_cast<std::size_t>(i)] = 1;
+    if (producer)
+        for (int i = 0; i < 6; ++i) P.inputUniform[static_cast<std::size_t>(kAux + i)] = 1;
     for (int i = 0; i < 13; ++i) P.inputUniform[static_cast<std::size_t>(i)] = 1;  // qb, vb
     P.inputUniform[22] = 1;                                                        // dt
 
@@ -156,6 +176,24 @@ inline QuadProgram RecordQuadLegProgram(const rbd::Model& model, const tape::Spa
     const AD dt = in[kDt];
     std::vector<AD> vb(in.begin() + kVb, in.begin() + kVb + 6);
     std::array<AD, 3> ql{in[kQl], in[kQl + 1], in[kQl + 2]}, vl{in[kVl], in[kVl + 1], in[kVl + 2]}, ul{in[kUl], in[kUl + 1], in[kUl + 2]};
+
+    // ---- hand-over between the two halves of the split program ----------------------------------------------------------
+    // channel(m, i, v): item i of message m.  Fused: the value itself.  Producer: v becomes a send sink of message m.
+    // Consumer: a fresh input standing for the received item (the producer's sub-graph is then unreachable from the
+    // consumer's sinks and is not emitted).  Literal items are not transmitted (both halves record the same graph).
+    std::vector<std::vector<tape::OutputSlot>> sends(static_cast<std::size_t>(kQuadMessages));
+    const tape::Id noValue = g.Constant(0.0);  // value of a sink that only carries a statement (wait / post / done)
+    auto channel = [&](int m, int i, const AD& v, bool uniform) -> AD {
+        if (fused || v.IsLiteral() || g.At(v.Node()).op == tape::Op::Const) return v;
+        if (m < 0 || m >= kQuadMessages || i < 0 || i >= kQuadMessageItems) throw std::logic_error("quad program: channel item out of range");
+        if (producer) {
+            sends[static_cast<std::size_t>(m)].push_back({v.Node(), "io.send(" + std::to_string(m) + ", " + std::to_string(i) + ", %s);"});
+            return v;
+        }
+        const std::size_t slot = static_cast<std::size_t>(kRecv + kQuadMessageItems * m + i);
+        P.inputUniform[slot] = uniform ? 1 : 0;
+        return in[slot];
+    };
 
     // ---- leg kinematics and inertias ---------------------------------------------------------------------------
     std::array<Xform<AD>, 3> X;
@@ -321,8 +359,15 @@ inline QuadProgram RecordQuadLegProgram(const rbd::Model& model, const tape::Spa
     const LegOut h = legRnea(accB0, {AD{0.0}, AD{0.0}, AD{0.0}});
     const Vec6<AD> hbOwn = baseOwnForce(accB0);
     std::vector<AD> rb0(6);
-    for (std::size_t r = 0; r < 6; ++r) rb0[r] = -(hbOwn[r] + tape::QuadSum(h.fb[r]));
-    const Sol acc = solve(rb0, {ul[0] - h.tau[0], ul[1] - h.tau[1], ul[2] - h.tau[2]}, true);
+    std::array<AD, 3> rl0;
+    if (fused) {
+        for (std::size_t r = 0; r < 6; ++r) rb0[r] = -(hbOwn[r] + tape::QuadSum(h.fb[r]));
+        rl0 = {ul[0] - h.tau[0], ul[1] - h.tau[1], ul[2] - h.tau[2]};
+    } else {  // message 0: the leg's bias torques and its summed bias force on the base
+        for (std::size_t r = 0; r < 6; ++r) rb0[r] = -(hbOwn[r] + channel(0, 3 + static_cast<int>(r), tape::QuadSum(h.fb[r]), true));
+        for (std::size_t k = 0; k < 3; ++k) rl0[k] = ul[k] + channel(0, static_cast<int>(k), -h.tau[k], false);
+    }
+    const Sol acc = solve(rb0, rl0, true);
 
     // ---- stage functions on auxiliary inputs: integrator and RNEA at fixed accelerations -----------------------------------
     std::vector<AD> accbAux(in.begin() + kAux, in.begin() + kAux + 6);  // stands for a_b (integrator) / a_b + gamma (RNEA)
@@ -383,7 +428,8 @@ inline QuadProgram RecordQuadLegProgram(const rbd::Model& model, const tape::Spa
         subG.emplace_back(kAux + 6 + static_cast<int>(k), acc.yl[k].Node());
         subD.emplace_back(kAux + 6 + static_cast<int>(k), acc.yl[k].Node());
     }
-    const std::vector<tape::Id> Gv = diff.Substitute(G.value, subG), fv = diff.Substitute(gIds, subG), Dv = diff.Substitute(D.value, subD);
+    // (the producer's auxiliary inputs ARE the accelerations it receives: nothing to substitute there)
+    const std::vector<tape::Id> Gv = diff.Substitute(G.value, subG), fv = diff.Substitute(gIds, subG), Dv = producer ? D.value : diff.Substitute(D.value, subD);
     // dense views of the small sparse blocks
     AD Gm[19][28], Dm[15][12], dGam[3][4];
     for (std::size_t e = 0; e < G.Nnz(); ++e) Gm[G.row[e]][G.col[e]] = AD::FromId(Gv[e]);
@@ -409,6 +455,14 @@ inline QuadProgram RecordQuadLegProgram(const rbd::Model& model, const tape::Spa
         keep(Fb.dinv[i]);
         for (std::size_t j = i + 1; j < 6; ++j) keep(Fb.U[i][j]);
     }
+    if (consumer) {  // the solved accelerations go back to the producer as early as possible: a phase of their own
+        P.phaseStarts.push_back(P.slots.size());
+        P.slots.push_back({noValue, "@begin:io.wait(0);"});
+        for (std::size_t k = 0; k < 6; ++k) P.slots.push_back({(acc.yb[k] + (k < 3 ? gamma[k] : AD{0.0})).Node(), "io.send_acc(" + std::to_string(k) + ", %s);"});
+        for (std::size_t k = 0; k < 3; ++k) P.slots.push_back({acc.yl[k].Node(), "io.send_acc(" + std::to_string(6 + k) + ", %s);"});
+        P.slots.push_back({noValue, "io.post_acc();"});
+        P.slots.push_back({noValue, "io.done(0);"});
+    }
     P.phaseStarts.push_back(P.slots.size());
     for (int i = 0; i < 13; ++i) sinkF(AD::FromId(fv[static_cast<std::size_t>(i)]), "io.f_base(" + std::to_string(baseRowIndex(i)) + ", %s);");
     for (int k = 0; k < 3; ++k) sinkF(AD::FromId(fv[static_cast<std::size_t>(13 + k)]), "io.f_leg(" + std::to_string(7 + k) + ", %s);");
@@ -419,6 +473,7 @@ inline QuadProgram RecordQuadLegProgram(const rbd::Model& model, const tape::Spa
     ///   yb, yl: base / own-leg rows of da/dz for the column;  ownKind: this lane owns the column
     ///   colExpr: how the column index is spelled; baseRows: emit the 13 base rows too
     int columnCounter = 0;
+    int pendingWait = -1;  // consumer: message the next column phase starts by waiting for
     int sharedGroups = 0;  // merged base-row stores of shared columns emitted so far (unique names)
     auto emitColumn = [&](int gLocal, const std::vector<AD>& yb, const std::array<AD, 3>& yl, int colBase, int colLegMul, int rot, bool baseRows,
                           bool sharedColumn) {
@@ -431,13 +486,38 @@ inline QuadProgram RecordQuadLegProgram(const rbd::Model& model, const tape::Spa
             }
         };
         if (baseRows && (columnCounter++ % columnsPerPhase) == 0) P.phaseStarts.push_back(P.slots.size());  // a column + its rotated copies
+        if (baseRows && consumer && pendingWait >= 0) {
+            P.slots.push_back({noValue, "@begin:io.wait(" + std::to_string(pendingWait) + ");"});
+            pendingWait = -1;
+        }
         auto entry = [&](int gr) {  // integrator row gr (0..18) of this column
             AD v = gLocal >= 0 ? Gm[gr][gLocal] : AD{0.0};
             for (int k = 0; k < 6; ++k) v = v + Gm[gr][19 + k] * yb[static_cast<std::size_t>(k)];
             for (int k = 0; k < 3; ++k) v = v + Gm[gr][25 + k] * yl[static_cast<std::size_t>(k)];
             return v;
         };
-        if (baseRows)
+        // pairStores: two entries of a column leave in ONE 16-byte store after a pairwise exchange between the lanes of
+        // neighbouring nodes (quad_kernel.hpp: BufPut2) -- base rows (0,1) (2,3) (4,5) (19,20) (21,22) (23,24), row 6 alone;
+        // leg rows (7 + k, 25 + k).  The sinks carry both entries; an I/O policy without paired stores writes them one by one.
+        if (baseRows && pairStores) {
+            for (int i = 0; i < 13; ++i) {
+                const AD v = entry(i);
+                checkZero(v, baseRowIndex(i), 0);
+                const std::string head = sharedColumn ? "io.j_base_shared" : "io.j_base_own";
+                if (i == 6) {
+                    P.slots.push_back({v.Node(), head + "(" + std::to_string(baseRowIndex(i)) + ", " + colArgs + ", " + kArgs(baseRowIndex(i), 0, colBase, colLegMul, rot) + ", %s);"});
+                    continue;
+                }
+                const AD v2 = entry(i + 1);
+                checkZero(v2, baseRowIndex(i + 1), 0);
+                P.slots.push_back({v.Node(),
+                                   head + "2(" + std::to_string(baseRowIndex(i)) + ", " + std::to_string(baseRowIndex(i + 1)) + ", " + colArgs + ", " +
+                                       kArgs(baseRowIndex(i), 0, colBase, colLegMul, rot) + ", " + kArgs(baseRowIndex(i + 1), 0, colBase, colLegMul, rot) + ", %s, %t);",
+                                   v2.Node()});
+                ++i;
+            }
+        }
+        if (baseRows && !pairStores)
             for (int i = 0; i < 13; ++i) {
                 const AD v = entry(i);
                 checkZero(v, baseRowIndex(i), 0);
@@ -464,6 +544,18 @@ inline QuadProgram RecordQuadLegProgram(const rbd::Model& model, const tape::Spa
                                                  ", " + kArgs(baseRowIndex(i), 0, colBase, colLegMul, rot) + ", %s);"});
             }
         if (baseRows && sharedColumn) sharedGroups += 3;
+        if (pairStores) {
+            for (int k = 0; k < 3; ++k) {
+                const AD v = entry(13 + k), v2 = entry(16 + k);
+                checkZero(v, 7 + k, 1);
+                checkZero(v2, 25 + k, 1);
+                P.slots.push_back({v.Node(),
+                                   "io.j_leg2(" + std::to_string(7 + k) + ", " + std::to_string(25 + k) + ", " + colArgs + ", " + kArgs(7 + k, 1, colBase, colLegMul, rot) + ", " +
+                                       kArgs(25 + k, 1, colBase, colLegMul, rot) + ", %s, %t);",
+                                   v2.Node()});
+            }
+            return;
+        }
         for (int half = 0; half < 2; ++half)
             for (int k = 0; k < 3; ++k) {
                 const int rowBase = (half ? 25 : 7) + k;
@@ -476,48 +568,102 @@ inline QuadProgram RecordQuadLegProgram(const rbd::Model& model, const tape::Spa
     const std::array<AD, 3> zero3{AD{0.0}, AD{0.0}, AD{0.0}};
 
     // ---- columns owned by this lane's leg: q_L, v_L (via D) and u_L ------------------------------------------------------------
-    for (int kind = 0; kind < 3; ++kind)      // 0: q_L, 1: v_L, 2: u_L
-        for (int k = 0; k < 3; ++k) {
-            std::vector<AD> rb(6, AD{0.0});
-            std::array<AD, 3> rl = zero3;
-            if (kind < 2) {
-                const int dc = 3 * kind + k;
-                for (int r = 0; r < 3; ++r) rl[static_cast<std::size_t>(r)] = -Dm[r][dc];
-                for (int r = 0; r < 6; ++r) rb[static_cast<std::size_t>(r)] = -Dm[3 + r][dc];  // fb_own does not depend on leg variables
-            } else {
-                rl[static_cast<std::size_t>(k)] = AD{1.0};
-            }
-            const Sol s = solve(rb, rl, false);
-            const int colBase = (kind == 0 ? 7 : kind == 1 ? 25 : 37) + k;
-            const int gLocal = kind == 0 ? 13 + k : kind == 1 ? 16 + k : -1;
-            emitColumn(gLocal, s.yb, s.yl, colBase, 1, 0, true, false);
-            // the other three legs' versions of this column: their y_b arrives by rotation, only leg rows are ours
-            for (int rot = 1; rot < 4; ++rot) {
-                std::vector<AD> ybr(6);
-                for (std::size_t r = 0; r < 6; ++r) ybr[r] = tape::QuadRot(s.yb[r], rot);
-                emitColumn(-1, ybr, foreignRows(ybr), colBase, 1, rot, false, false);
-            }
+    int nextMessage = 1;
+    std::vector<int> accMessages;  // producer: messages whose right-hand side depends on the solved accelerations
+    auto doneWith = [&](int message) {
+        if (consumer && message >= 0) P.slots.push_back({noValue, "io.done(" + std::to_string(message) + ");"});
+    };
+    auto ownColumn = [&](int kind, int k) {  // 0: q_L, 1: v_L, 2: u_L
+        std::vector<AD> rb(6, AD{0.0});
+        std::array<AD, 3> rl = zero3;
+        int message = -1;
+        if (kind < 2) {
+            const int dc = 3 * kind + k;
+            if (!fused) message = nextMessage++;
+            if (kind == 0) accMessages.push_back(message);
+            for (int r = 0; r < 3; ++r) rl[static_cast<std::size_t>(r)] = channel(message, r, -Dm[r][dc], false);
+            for (int r = 0; r < 6; ++r) rb[static_cast<std::size_t>(r)] = channel(message, 3 + r, -Dm[3 + r][dc], false);  // fb_own does not depend on leg variables
+        } else {
+            rl[static_cast<std::size_t>(k)] = AD{1.0};
         }
+        pendingWait = message;
+        const Sol s = solve(rb, rl, false);
+        const int colBase = (kind == 0 ? 7 : kind == 1 ? 25 : 37) + k;
+        const int gLocal = kind == 0 ? 13 + k : kind == 1 ? 16 + k : -1;
+        emitColumn(gLocal, s.yb, s.yl, colBase, 1, 0, true, false);
+        // the other three legs' versions of this column: their y_b arrives by rotation, only leg rows are ours
+        for (int rot = 1; rot < 4; ++rot) {
+            std::vector<AD> ybr(6);
+            for (std::size_t r = 0; r < 6; ++r) ybr[r] = tape::QuadRot(s.yb[r], rot);
+            emitColumn(-1, ybr, foreignRows(ybr), colBase, 1, rot, false, false);
+        }
+        doneWith(message);
+    };
     // ---- shared columns: base twist (via D, summed over legs), quaternion (closed form), position (none) -------------------------
-    for (int k = 0; k < 6; ++k) {
+    auto twistColumn = [&](int k) {
         const int dc = 6 + k;
+        const int message = fused ? -1 : nextMessage++;
         std::vector<AD> rb(6);
-        for (int r = 0; r < 6; ++r) rb[static_cast<std::size_t>(r)] = -(tape::QuadSum(Dm[3 + r][dc]) + Dm[9 + r][dc]);
-        const Sol s = solve(rb, {-Dm[0][dc], -Dm[1][dc], -Dm[2][dc]}, true);
+        for (int r = 0; r < 6; ++r) rb[static_cast<std::size_t>(r)] = channel(message, 3 + r, -(tape::QuadSum(Dm[3 + r][dc]) + Dm[9 + r][dc]), true);
+        std::array<AD, 3> rl;
+        for (int r = 0; r < 3; ++r) rl[static_cast<std::size_t>(r)] = channel(message, r, -Dm[r][dc], false);
+        pendingWait = message;
+        const Sol s = solve(rb, rl, true);
         emitColumn(7 + k, s.yb, s.yl, 19 + k, 0, 0, true, true);
-    }
-    for (int k = 0; k < 4; ++k) {
+        doneWith(message);
+    };
+    auto quaternionColumn = [&](int k) {
         std::vector<AD> yb(6, AD{0.0});
         for (int r = 0; r < 3; ++r) yb[static_cast<std::size_t>(r)] = -dGam[r][k];
         emitColumn(3 + k, yb, zero3, 3 + k, 0, 0, true, true);
+    };
+    auto positionColumn = [&](int k) { emitColumn(k, zero6, zero3, k, 0, 0, true, true); };
+    if (fused) {
+        for (int kind = 0; kind < 3; ++kind)
+            for (int k = 0; k < 3; ++k) ownColumn(kind, k);
+        for (int k = 0; k < 6; ++k) twistColumn(k);
+        for (int k = 0; k < 4; ++k) quaternionColumn(k);
+        for (int k = 0; k < 3; ++k) positionColumn(k);
+    } else {
+        // Order of the hand-over: the velocity columns first (their tangents do not involve the solved accelerations, so the
+        // producer starts on them while the consumer still factorises), the joint-angle columns last.  The consumer
+        // interleaves the columns it can do on its own, so that it stays a column or two behind the producer.
+        for (int k = 0; k < 3; ++k) {
+            ownColumn(1, k);
+            ownColumn(2, k);
+        }
+        for (int k = 0; k < 6; ++k) {
+            twistColumn(k);
+            if (k < 4) quaternionColumn(k);
+            if (k == 4)
+                for (int j = 0; j < 3; ++j) positionColumn(j);
+        }
+        for (int k = 0; k < 3; ++k) ownColumn(0, k);
+        if (nextMessage != kQuadMessages) throw std::logic_error("quad program: message count");
     }
-    for (int k = 0; k < 3; ++k) emitColumn(k, zero6, zero3, k, 0, 0, true, true);
+    if (producer) {  // one phase per message: [wait for the ring slot / the accelerations] items... post
+        P.slots.clear();
+        P.phaseStarts.clear();
+        for (int m = 0; m < kQuadMessages; ++m) {
+            if (m) P.phaseStarts.push_back(P.slots.size());
+            P.slots.push_back({noValue, "@begin:io.wait_free(" + std::to_string(m) + ");"});
+            if (!accMessages.empty() && m == accMessages.front()) P.slots.push_back({noValue, "@begin:io.wait_acc();"});
+            for (const auto& sl : sends[static_cast<std::size_t>(m)]) P.slots.push_back(sl);
+            P.slots.push_back({noValue, "io.post(" + std::to_string(m) + ");"});
+        }
+    }
 
     // ---- package ---------------------------------------------------------------------------------------------------------------------
     std::vector<AD> roots;
     for (const auto& sl : P.slots) roots.push_back(AD::FromId(sl.value));
+    for (const auto& sl : P.slots)
+        if (sl.value2 != tape::kNoId) roots.push_back(AD::FromId(sl.value2));
     P.tape = tape::MakeTape(roots);
-    for (std::size_t i = 0; i < P.slots.size(); ++i) P.slots[i].value = P.tape.outputs[i];
+    std::size_t second = P.slots.size();
+    for (std::size_t i = 0; i < P.slots.size(); ++i) {
+        P.slots[i].value = P.tape.outputs[i];
+        if (P.slots[i].value2 != tape::kNoId) P.slots[i].value2 = P.tape.outputs[second++];
+    }
     return P;
 }
 
@@ -544,10 +690,12 @@ inline std::string EmitQuadProgram(const QuadProgram& P, const std::string& fnNa
     std::vector<std::string> names(P.inputNames.size());
     std::string prologue;
     for (std::size_t i = 0; i < names.size(); ++i) {
-        names[i] = "in" + std::to_string(i);
-        if (used[i]) prologue += "    const T " + names[i] + " = " + P.inputNames[i] + ";\n";
+        const bool late = i < P.inputLate.size() && P.inputLate[i];
+        names[i] = late ? P.inputNames[i] : "in" + std::to_string(i);
+        if (used[i] && !late) prologue += "    const T " + names[i] + " = " + P.inputNames[i] + ";\n";
     }
     tape::Emitter em{P.tape.graph, names};
+    em.SetRereadInputs(P.inputLate);
     // phases (primal + one per owned / shared column) separated by scheduling barriers, no LDS home:
     // per-lane state fits the register file, the barriers only stop the scheduler from interleaving columns
     std::vector<std::vector<tape::OutputSlot>> phases;

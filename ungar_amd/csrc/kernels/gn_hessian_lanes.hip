@@ -17,6 +17,7 @@
 // not the arithmetic (8.2 of 78.6 TFLOP/s).  A variant staging each row through LDS (one barrier per row, four passes of 8
 // wavefronts) exposed the HBM latency of every row and took 2.5 ms; it was not kept.  This kernel is the one that writes a
 // unit-fastest G, which is what a lane-per-instance consumer wants.  Reference analogue: soft_sqp.hpp:257-264.
+#include "../runtime/measurement.hpp"
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -97,7 +98,7 @@ extern "C" int ungar_amd_launch_gn_hessian_lanes(const double* jac, long long je
     const dim3 grid(static_cast<unsigned>((((waves + 3) / 4 + 7) / 8) * 8)), block(256);  // a multiple of 8: the XCD renumbering is a bijection
     hipStream_t s = static_cast<hipStream_t>(stream);
     static const int unroll = [] {  // tuning knob (tools/bench_gn_hessian.py sweeps it); default = the measured best
-        const char* e = getenv("UNGAR_GN_LANES_UNROLL");
+        const char* e = UNGAR_MEASUREMENT_SWITCH("UNGAR_GN_LANES_UNROLL");
         return e ? atoi(e) : 1;  // measured on MI355X (ANYmal block, 81 920 nodes): 0.90 / 1.13 / 1.24 ms for 1 / 2 / 4 -- occupancy beats unrolling
     }();
 #define UNGAR_GN_LANES_LAUNCH(W, U) \

@@ -21,6 +21,7 @@
 // blocks (11 %).  Budget for 81 920 ANYmal nodes: vector ALU 0.12 ms, LDS 0.03 ms, HBM (2.0 GB) 0.25 ms.
 // Output strides are the caller's, as for the lanes kernel: unit-fastest (16 lanes = 128 contiguous bytes per entry) or
 // node-major.  Reference analogue: soft_sqp.hpp:257-264.
+#include "../runtime/measurement.hpp"
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -507,7 +508,7 @@ extern "C" int ungar_amd_launch_gn_hessian_tiles(const double* jac, long long je
     const int side = (cols + kTile - 1) / kTile, wavesPerGroup = (side * (side + 1) / 2 * kNodes + 63) / 64;
     const long long resident = static_cast<long long>(computeUnits) * (wavesPerGroup >= 5 ? 1 : wavesPerGroup >= 3 ? 2 : 4);
     static const int depth = [] {  // tuning knob: 0 = register-staged pipeline only, 2 / 3 = LDS-DMA pipeline with that many stage buffers
-        const char* e = getenv("UNGAR_GN_TILES_DMA");
+        const char* e = UNGAR_MEASUREMENT_SWITCH("UNGAR_GN_TILES_DMA");
         return e ? atoi(e) : 2;  // measured (81 920 ANYmal nodes): 0.427 ms with 2 buffers, 0.437 with 3; register-staged 0.56
     }();
     const GnTilesCall call{jac, jes, d, des, g, ges, gns, ldg, rows, count, static_cast<hipStream_t>(stream), static_cast<unsigned>(groups < resident ? groups : resident)};

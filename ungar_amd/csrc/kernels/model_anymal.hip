@@ -4,6 +4,7 @@
 //   value only         -> plain lane-per-node body
 //   operands beyond 32-bit element offsets -> structured implicit differentiation, lane-per-node phased
 //                         body with an LDS home (§4.3-4.4)
+#include "../runtime/measurement.hpp"
 #include "../gen/anymal_gen.hpp"
 #include "../gen/anymal_quad_gen.hpp"
 #include <cstdlib>
@@ -35,7 +36,7 @@ extern "C" int ungar_amd_launch_anymal(int mode, const ungar_amd::kernels::NodeL
     // with a negative element stride are left to the lane-per-node kernel
     const bool jacobian = mode == kModeDenseJacobian || mode == kModeSparseJacobian;
     if (jacobian && !QuadOffsetsFit32(*a) && a->jac.es >= 0) return ungar_amd_launch_anymal_quad_wide(mode, a, stream);
-    static const bool laneValue = getenv("UNGAR_AMD_ANYMAL_VALUE_LANE_PER_NODE") != nullptr;  // A/B switch (tools/bench_anymal_value.py)
+    static const bool laneValue = UNGAR_MEASUREMENT_SWITCH("UNGAR_AMD_ANYMAL_VALUE_LANE_PER_NODE") != nullptr;  // A/B switch (tools/bench_anymal_value.py)
     if (mode == kModeValue && !laneValue) {
         if (a->count <= 0 || !a->f.base) return 0;
         void* vsym = nullptr;
@@ -57,7 +58,7 @@ extern "C" int ungar_amd_launch_anymal(int mode, const ungar_amd::kernels::NodeL
     const double(*ctab)[4] = static_cast<const double(*)[4]>(sym);
     const dim3 grid(static_cast<unsigned>((a->count + kBlock / 4 - 1) / (kBlock / 4))), block(kBlock);
     namespace Q = ungar_amd::gen::anymal_quad;
-    static const bool noBuffer = getenv("UNGAR_AMD_NO_BUFFER_STORES") != nullptr;  // A/B switch for the store path (tools/)
+    static const bool noBuffer = UNGAR_MEASUREMENT_SWITCH("UNGAR_AMD_NO_BUFFER_STORES") != nullptr;  // A/B switch for the store path (tools/)
     if (UseStreamingStores(*a, mode, 37 * 49, 37) && QuadBufferStoresApply(*a) && !noBuffer)
         hipLaunchKernelGGL((QuadNodeKernel<kBlock, Q::kLdsSlots, Q::kLdsUniformSlots, false, true, AnymalQuadBody, NoSparsePlan, unsigned, true>), grid, block, 0,
                            static_cast<hipStream_t>(stream), *a, ctab, AnymalQuadBody{});

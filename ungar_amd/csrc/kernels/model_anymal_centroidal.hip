@@ -2,6 +2,7 @@
 // whole batch per launch.
 //   value + Jacobian (dense block or CSR values) -> lane-per-leg SPMD program (quad_rnea_kernel.hpp skeleton, csrc/codegen/quad_centroidal_program.hpp)
 //   value only, or operands beyond 32-bit element offsets / with negative strides -> one lane per configuration (body lowered from the tape of csrc/models/rbd_nodes.hpp)
+#include "../runtime/measurement.hpp"
 #include "../gen/anymal_centroidal_gen.hpp"
 #include "../gen/anymal_centroidal_quad_gen.hpp"
 #include <cstdlib>
@@ -20,7 +21,7 @@ struct AnymalCentroidalQuadBody {
 extern "C" int ungar_amd_launch_anymal_centroidal(int mode, const ungar_amd::kernels::NodeLaunch* a, void* stream) {
     using namespace ungar_amd::kernels;
     namespace Q = ungar_amd::gen::anymal_centroidal_quad;
-    static const bool lanePerNode = getenv("UNGAR_AMD_CENTROIDAL_LANE_PER_NODE") != nullptr;  // A/B switch (tools/bench_rbd_nodes.py)
+    static const bool lanePerNode = UNGAR_MEASUREMENT_SWITCH("UNGAR_AMD_CENTROIDAL_LANE_PER_NODE") != nullptr;  // A/B switch (tools/bench_rbd_nodes.py)
     const bool jacobian = mode == kModeDenseJacobian || mode == kModeSparseJacobian;
     const long long entries = mode == kModeDenseJacobian ? 6 * 37 : Q::kJacNnz;
     if (!jacobian || lanePerNode || a->jac.es < 0 || a->jac.es * entries >= (1LL << 32))

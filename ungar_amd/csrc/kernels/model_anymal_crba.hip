@@ -2,6 +2,7 @@
 // whole batch per launch.
 //   value + CSR Jacobian values -> lane-per-leg SPMD program (quad_crba_kernel.hpp, csrc/codegen/quad_crba_program.hpp)
 //   value only, the dense 324 x 19 block (85 % structural zeros), operands beyond 32-bit element offsets -> one lane per configuration (body lowered from the tape of csrc/models/rbd_nodes.hpp)
+#include "../runtime/measurement.hpp"
 #include "../gen/anymal_crba_gen.hpp"
 #include "../gen/anymal_crba_quad_gen.hpp"
 #include <cstdlib>
@@ -20,7 +21,7 @@ struct AnymalCrbaQuadBody {
 extern "C" int ungar_amd_launch_anymal_crba(int mode, const ungar_amd::kernels::NodeLaunch* a, void* stream) {
     using namespace ungar_amd::kernels;
     namespace Q = ungar_amd::gen::anymal_crba_quad;
-    static const bool lanePerNode = getenv("UNGAR_AMD_CRBA_LANE_PER_NODE") != nullptr;  // A/B switch (tools/bench_rbd_nodes.py)
+    static const bool lanePerNode = UNGAR_MEASUREMENT_SWITCH("UNGAR_AMD_CRBA_LANE_PER_NODE") != nullptr;  // A/B switch (tools/bench_rbd_nodes.py)
     if (mode != kModeSparseJacobian || lanePerNode || a->jac.es < 0 || a->jac.es * static_cast<long long>(Q::kJacNnz) >= (1LL << 32))
         return static_cast<int>(LaunchNodeModel<Model_anymal_crba, 64>(mode, *a, static_cast<hipStream_t>(stream)));
     if (a->count <= 0) return 0;

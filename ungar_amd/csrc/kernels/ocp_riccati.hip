@@ -3,6 +3,7 @@
 // phi = objective + barrier and theta = c |g| of the line search (soft_sqp.hpp:68-87), trial points, and the three-way
 // acceptance test of backtracking_line_search.hpp:116-151.  One 64-lane workgroup (= one wavefront) per MPC instance;
 // instances are independent, so a launch of thousands of them fills the device.
+#include "../runtime/measurement.hpp"
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -726,7 +727,7 @@ extern "C" int ungar_amd_launch_riccati(const RiccatiArgs* a, void* stream) {
     {
         // Default route for the sizes it is instantiated for (the large blocks: 37 + 12, 25 + 24, 13 + 24, no equality rows inside the recursion): the
         // register-resident one-wavefront kernels.  UNGAR_AMD_RICCATI_VARIANT (any value, e.g. "fixed") keeps the LDS-resident kernels below: the A/B switch.
-        const bool ldsResident = getenv("UNGAR_AMD_RICCATI_VARIANT") != nullptr;  // (read per call: a test switches routes inside one process)
+        const bool ldsResident = UNGAR_MEASUREMENT_SWITCH("UNGAR_AMD_RICCATI_VARIANT") != nullptr;  // (read per call: a test switches routes inside one process)
         if (!ldsResident) {
             const int e = ungar_amd_launch_riccati_wave(a, stream);
             if (e >= 0) return e;
@@ -747,8 +748,17 @@ extern "C" int ungar_amd_launch_riccati(const RiccatiArgs* a, void* stream) {
     // Variants of the same recursion (tools/bench_sqp.py): lanes per instance (one or four wavefronts
     // share the entries of every product) and whether the next knot's operands are staged in registers.
     //   "64" / "128" / "256"   one / two / four wavefronts per instance, operands read in place;   "128p" / "256p"   staged
+#if !UNGAR_AMD_MEASUREMENT_BUILD
+    // shipped library: the default route only (the variants below exist in the measurement build, tools/bench_sqp.py)
+    if (a->nx == 13 && a->nu == 4) return LaunchRiccati<64, 4, 5, 13, 4>(a, lds, s);
+    if (a->nx == 6 && a->nu == 2) return LaunchRiccati<64, 1, 1, 6, 2>(a, lds, s);
+    if (a->nx == 13 && a->nu == 24) return LaunchRiccati<256, 0, 0, 13, 24, true, true>(a, lds, s);
+    if (a->nx == 37 && a->nu == 12) return LaunchRiccati<256, 0, 0, 37, 12, true, true>(a, lds, s);
+    (void)ab, (void)w;
+    return LaunchRiccati<64, 0, 0>(a, lds, s);
+#else
     static const std::string variant = [] {
-        const char* e = getenv("UNGAR_AMD_RICCATI_VARIANT");
+        const char* e = UNGAR_MEASUREMENT_SWITCH("UNGAR_AMD_RICCATI_VARIANT");
         return std::string(e ? e : "fixed");
     }();
     // sizes of the reference's three OCPs and of the full-body quadruped, fixed at compile time (default route)
@@ -790,6 +800,7 @@ extern "C" int ungar_amd_launch_riccati(const RiccatiArgs* a, void* stream) {
     if (variant == "256p" && ab <= 768 && w <= 768) return LaunchRiccati<256, 3, 3>(a, lds, s);    // quadrotor, rc_car (n <= 27)
     if (variant == "256p" && ab <= 1792 && w <= 1792) return LaunchRiccati<256, 7, 7>(a, lds, s);  // single-rigid-body quadruped (n <= 42)
     return LaunchRiccati<256, 0, 0>(a, lds, s);
+#endif
 }
 
 extern "C" int ungar_amd_launch_ocp_stage_qp(const StageQpArgs* a, void* stream) {

@@ -16,6 +16,7 @@
 // R is factorised by symmetric elimination without pivoting on the tableau [R | H_ux h_u], lane = column, rows in registers, pivot columns broadcast with
 // v_readlane: the multipliers and pivots of the right-looking L D L^T of ocp_riccati.hpp (a pivot that is not positive is replaced by 1 and reported).
 // LDS (a few KB per wavefront, private to it) is used only to change layouts: accumulator tiles -> tableau columns, gains -> B operand, tile transposes.
+#include "../runtime/measurement.hpp"
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -635,7 +636,7 @@ __global__ __launch_bounds__(64, WAVES_PER_EU) void RiccatiWaveKernel(const Ricc
 template <int NX, int NU, int WAVES_PER_EU>
 int LaunchWave(const RiccatiArgs* a, hipStream_t stream) {
     constexpr std::size_t lds = static_cast<std::size_t>(WaveSizes<NX, NU>::kLdsDoubles) * sizeof(double);
-    static const bool clocks = getenv("UNGAR_AMD_RICCATI_WAVE_CLOCKS") != nullptr;
+    static const bool clocks = UNGAR_MEASUREMENT_SWITCH("UNGAR_AMD_RICCATI_WAVE_CLOCKS") != nullptr;
     if (clocks) hipLaunchKernelGGL((RiccatiWaveKernel<NX, NU, WAVES_PER_EU, true>), dim3(static_cast<unsigned>(a->batch)), dim3(64), lds, stream, *a);
     else hipLaunchKernelGGL((RiccatiWaveKernel<NX, NU, WAVES_PER_EU>), dim3(static_cast<unsigned>(a->batch)), dim3(64), lds, stream, *a);
     return static_cast<int>(hipGetLastError());

@@ -2,6 +2,7 @@
 // QP data from the stage functions' sparse outputs, merit terms, stacked trial rows, and the per-instance line search + iteration
 // bookkeeping of SoftSQPOptimizer::Optimize (reference include/ungar/optimization/soft_sqp.hpp:62-112, 143-158, 247-264;
 // backtracking_line_search.hpp:116-151).  The QP itself is solved by the Riccati kernel (ocp_riccati.hip) on what is assembled here.
+#include "../runtime/measurement.hpp"
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -1531,7 +1532,7 @@ int LaunchAssembleWave(const ShootingAssembleArgs* a, void* stream) {
     if (d.nz() != NZ || d.nu != NU || a->ne != NE || a->eliminate != 1) return -1;
     if (a->nh > 64 || (a->nh > 0 && a->ph.nnz > 64) || a->pH.nnz > 256 || a->pg.nnz > 64 || a->pf.nnz > 256 || a->pe.nnz > 256 || (!d.carryInputs && a->pc.nnz > 128)) return -1;
     const std::size_t lds = (kImagePadded + NE * (ND + 1) + 2 * static_cast<std::size_t>(a->nh) + NE) * sizeof(double) + (NE + 64) * sizeof(int);
-    const char* clocks = getenv("UNGAR_AMD_ASSEMBLE_CLOCKS");
+    const char* clocks = UNGAR_MEASUREMENT_SWITCH("UNGAR_AMD_ASSEMBLE_CLOCKS");
     if (clocks && clocks[0] == '1') hipLaunchKernelGGL((ShootingAssembleWaveKernel<NZ, NU, NE, true>), dim3(static_cast<unsigned>(d.batch * (d.N + 1))), dim3(64), lds, static_cast<hipStream_t>(stream), *a);
     else hipLaunchKernelGGL((ShootingAssembleWaveKernel<NZ, NU, NE, false>), dim3(static_cast<unsigned>(d.batch * (d.N + 1))), dim3(64), lds, static_cast<hipStream_t>(stream), *a);
     return 0;
@@ -1551,7 +1552,7 @@ static int LaunchAssembleSmall(const ShootingAssembleArgs* a, void* stream) {
 extern "C" int ungar_amd_launch_shooting_assemble(const ShootingAssembleArgs* a, void* stream) {
     if (a->d.batch <= 0) return 0;
     {
-        const char* variant = getenv("UNGAR_AMD_ASSEMBLE_VARIANT");  // "workgroup": the kernel below for every shape (measurement, A/B tests); read per call
+        const char* variant = UNGAR_MEASUREMENT_SWITCH("UNGAR_AMD_ASSEMBLE_VARIANT");  // "workgroup": the kernel below for every shape (measurement, A/B tests); read per call
         if (!(variant && variant[0] == 'w')) {
             if (LaunchAssembleWave<25, 24, 16>(a, stream) == 0) return static_cast<int>(hipGetLastError());
             if (LaunchAssembleSmall(a, stream) == 0) return static_cast<int>(hipGetLastError());
@@ -1567,7 +1568,7 @@ extern "C" int ungar_amd_launch_shooting_assemble(const ShootingAssembleArgs* a,
         if (e != hipSuccess) return static_cast<int>(e);
     }
     static const int forcedLanes = [] {
-        const char* e = getenv("UNGAR_AMD_ASSEMBLE_LANES");  // measurement knob: 64 / 128 / 256 lanes per node
+        const char* e = UNGAR_MEASUREMENT_SWITCH("UNGAR_AMD_ASSEMBLE_LANES");  // measurement knob: 64 / 128 / 256 lanes per node
         return e ? atoi(e) : 0;
     }();
     const int lanesPerNode = forcedLanes == 64 || forcedLanes == 128 || forcedLanes == 256 ? forcedLanes : (nd >= 32 ? 256 : kBlock);

@@ -47,8 +47,16 @@ struct NoSparsePlan {
 /// entry-dependent part a scalar register, so a store costs one s_mul_i32 and NO vector-ALU address arithmetic (the
 /// pointer form needs a 64-bit v_lshl_add_u64 per store: 635 of the 14.2 k instructions a lane issues).  Requires the whole
 /// operand to span less than 4 GiB from the first node of the launch (checked by the launcher: 1813 * stride * 8 < 2^32).
-template <bool SPARSE, bool STREAM = false, class PLAN = NoSparsePlan, class OFF = unsigned, bool BUF = false>
+///
+/// PAIR (with BUF): two entries of a column leave in ONE 16-byte store.  The lanes of the partner nodes n, n + 1 (same lane of two
+/// neighbouring 16-lane rows: same leg) swap one value each; the lane of the even node then writes entry e of both nodes, the lane of the
+/// odd node entry e' = e + delta of both nodes (delta = 18 rows for the leg rows 7 + k / 25 + k, one row for the base rows): half the
+/// store instructions, and -- what matters -- 16-byte stores reach 6.1-6.4 TB/s where the 8-byte ones stop at 5.0-5.3
+/// (tools/store_ceiling.hip, profiles/r05a_store_ceiling.log).  Needs consecutive nodes at consecutive addresses and an even node
+/// count (checked by the launcher).
+template <bool SPARSE, bool STREAM = false, class PLAN = NoSparsePlan, class OFF = unsigned, bool BUF = false, bool PAIR = false>
 struct QuadIO {
+    static_assert(!PAIR || (BUF && !SPARSE), "paired stores are a variant of the buffer-store path of the dense block");
     const double* __restrict__ xb;  // node's x (element stride xe)
     const double* __restrict__ ub;
     const double* __restrict__ pb;
@@ -72,6 +80,7 @@ struct QuadIO {
         __amdgpu_buffer_rsrc_t jr;
 #endif
         int vNode, vLeg, vLegCol[4], vOwnCol;
+        int pNode, pLeg, pLegCol[4], pOwnCol;  // PAIR: offsets of the 16-byte stores (odd lanes: the second entry of the pair, one node back)
         unsigned je8;  // element stride in bytes (wave-uniform)
         __host__ __device__ BufferState() {}  // filled in by the kernel when BUF
     } buf;
@@ -108,13 +117,40 @@ struct QuadIO {
     static __device__ __forceinline__ void Put(double* p, double v) {
         StoreResult<STREAM>(p, v);
     }
+    /// Cache policy of the buffer stores (aux operand: 1 = sc0, 2 = nt, 16 = sc1): non-temporal for streaming outputs.
+#if defined(UNGAR_AMD_MEASUREMENT_STORE_AUX)  // tools/quad_split_bench.hip: sweep of the cache-policy bits
+    static constexpr int kStoreAux = UNGAR_AMD_MEASUREMENT_STORE_AUX;
+#else
+    static constexpr int kStoreAux = STREAM ? 2 : 0;
+#endif
     /// Buffer store of entry `e` (wave-uniform) at the lane offset `voff`.
     __device__ __forceinline__ void BufPut(int voff, unsigned e, double v) const {
 #if defined(__HIP_DEVICE_COMPILE__)
         typedef int v2i __attribute__((ext_vector_type(2)));
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, v), buf.jr, voff, static_cast<int>(e * buf.je8), STREAM ? 2 : 0);  // aux 2 = nt
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, v), buf.jr, voff, static_cast<int>(e * buf.je8), kStoreAux);
 #else
         (void)voff, (void)e, (void)v;
+#endif
+    }
+    /// PAIR: entries e (value v) and e + delta (value v2) of this lane's node and of its partner's, one 16-byte store per lane.
+    /// v_permlane16_swap_b32 (gfx950) swaps the odd 16-lane rows of its first operand with the even rows of its second: with the
+    /// partner nodes n, n + 1 in the same lane of rows 2 R / 2 R + 1 (QuadNodeInWave<true>), the even row ends up with (v(n), v(n + 1))
+    /// and the odd row with (v2(n), v2(n + 1)) -- two instructions for the exchange of both 64-bit values, no select, no LDS.
+    __device__ __forceinline__ void BufPut2(int poff, unsigned e, double v, double v2) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        typedef int v4i __attribute__((ext_vector_type(4)));
+        const auto lo = __builtin_amdgcn_permlane16_swap(static_cast<unsigned>(__double2loint(v)), static_cast<unsigned>(__double2loint(v2)), false, false);
+        const auto hi = __builtin_amdgcn_permlane16_swap(static_cast<unsigned>(__double2hiint(v)), static_cast<unsigned>(__double2hiint(v2)), false, false);
+        const v4i q{static_cast<int>(lo[0]), static_cast<int>(hi[0]), static_cast<int>(lo[1]), static_cast<int>(hi[1])};
+        __builtin_amdgcn_raw_buffer_store_b128(q, buf.jr, poff, static_cast<int>(e * buf.je8), kStoreAux);
+        // A store of more than 64 bits fetches its data registers AFTER it has issued; a vector instruction that overwrites one of them in
+        // the next cycles corrupts what is stored.  The compiler pads that hazard only for stores WITHOUT a scalar offset register
+        // (GCNHazardRecognizer: "this hazard only exists if the instruction is not using a register in the soffset field"), which does not
+        // hold on gfx950: with two wavefronts per SIMD the low dword of ~1e-5 of the stored values came out overwritten
+        // (profiles/r05a_store_data_hazard.log).  The statement below keeps the four registers alive across two wait states.
+        asm volatile("s_nop 1" ::"v"(q) : "memory");
+#else
+        (void)poff, (void)e, (void)v, (void)v2;
 #endif
     }
     // base rows / shared columns: all four lanes hold the same value and store it to the same address
@@ -157,6 +193,34 @@ struct QuadIO {
         else
             Put(jOwnCol + static_cast<unsigned>(row * 49 + colBase) * je, v);
     }
+    // paired sinks (quad_leg_program.hpp: pairStores): one 16-byte store with PAIR, otherwise the two entries one by one
+    __device__ __forceinline__ void j_leg2(int row, int row2, int colBase, int legMul, int rot, int k0, int k1, int k2, int k3, int m0, int m1, int m2, int m3, double v,
+                                           double v2) const {
+        if constexpr (PAIR) {
+            BufPut2(legMul ? buf.pLegCol[rot] : buf.pLeg, static_cast<unsigned>(row * 49 + colBase), v, v2);  // row2 = row + 18: folded into the odd lanes' offset
+        } else {
+            j_leg(row, colBase, legMul, rot, k0, k1, k2, k3, v);
+            j_leg(row2, colBase, legMul, rot, m0, m1, m2, m3, v2);
+        }
+    }
+    __device__ __forceinline__ void j_base_own2(int row, int row2, int colBase, int legMul, int rot, int k0, int k1, int k2, int k3, int m0, int m1, int m2, int m3, double v,
+                                                double v2) const {
+        if constexpr (PAIR) {
+            BufPut2(buf.pOwnCol, static_cast<unsigned>(row * 49 + colBase), v, v2);  // row2 = row + 1
+        } else {
+            j_base_own(row, colBase, legMul, rot, k0, k1, k2, k3, v);
+            j_base_own(row2, colBase, legMul, rot, m0, m1, m2, m3, v2);
+        }
+    }
+    __device__ __forceinline__ void j_base_shared2(int row, int row2, int colBase, int legMul, int rot, int k0, int k1, int k2, int k3, int m0, int m1, int m2, int m3,
+                                                   double v, double v2) const {
+        if constexpr (PAIR) {
+            BufPut2(buf.pNode, static_cast<unsigned>(row * 49 + colBase), v, v2);
+        } else {
+            j_base_shared(row, colBase, legMul, rot, k0, k1, k2, k3, v);
+            j_base_shared(row2, colBase, legMul, rot, m0, m1, m2, m3, v2);
+        }
+    }
     /// Four entries of a shared column (same value in the four lanes of a node) in one store instruction:
     /// the lane of leg g writes entry g.
     __device__ __forceinline__ void j_base_shared4(int r0, int r1, int r2, int r3, int col, int k0, int k1, int k2, int k3, double v0, double v1, double v2,
@@ -180,8 +244,38 @@ struct QuadIO {
     }
 };
 
+/// Offsets of the paired stores: the lane of an even node writes entry e of nodes (n, n + 1) at its own offset; the lane of the odd node
+/// n + 1 writes entry e + delta of the same two nodes: one node back, delta entries on (18 rows for the leg rows, one row for the base rows).
+template <class BufferState>
+__device__ __forceinline__ void QuadPairOffsets(BufferState& buf, int lane, long long je) {
+    const bool odd = ((lane >> 4) & 1) != 0;  // QuadNodeInWave<true>: odd nodes in the odd rows
+    const int legDelta = odd ? static_cast<int>(static_cast<unsigned>(18LL * 49 * je - 1) * 8u) : 0;
+    const int baseDelta = odd ? static_cast<int>(static_cast<unsigned>(49LL * je - 1) * 8u) : 0;
+    buf.pLeg = buf.vLeg + legDelta;
+    for (int r = 0; r < 4; ++r) buf.pLegCol[r] = buf.vLegCol[r] + legDelta;
+    buf.pOwnCol = buf.vOwnCol + baseDelta;
+    buf.pNode = buf.vNode + baseDelta;
+}
+
+/// Node of a lane inside its wavefront (16 nodes, lane = 16 * row + 4 * leg + j).
+///   PAIR = false: node = 4 * row + j        -- 4 adjacent lanes hold the same leg of 4 consecutive nodes: 32-byte runs per 8-byte store;
+///   PAIR = true : node = 8 * (row / 2) + 2 * j + row % 2 -- partner nodes (n, n + 1) in the same lane of rows 2 R, 2 R + 1 (what
+///                 v_permlane16_swap exchanges); 4 adjacent lanes then write 64 contiguous bytes per 16-byte store.
+template <bool PAIR>
+__device__ __forceinline__ int QuadNodeInWave(int lane) {
+    return PAIR ? 8 * (lane >> 5) + 2 * (lane & 3) + ((lane >> 4) & 1) : 4 * (lane >> 4) + (lane & 3);
+}
+
+/// True when the nodes of a launch lie at consecutive addresses of the Jacobian operand (unit-fastest layout, knots of an instance
+/// contiguous, instances back to back) and their number is even: what the paired 16-byte stores need.
+inline bool QuadPairStoresApply(const NodeLaunch& a) {
+    if (a.count % 2 != 0) return false;
+    if (a.knots <= 1) return a.jac.bs == 1;
+    return a.jac.ks == 1 && a.jac.bs == a.knots;
+}
+
 /// GEN is the generated namespace (ValueJacobianQuad, kLegConstantsDev).  BLOCK lanes = BLOCK/4 nodes.
-template <int BLOCK, int LDS_SLOTS, int LDS_USLOTS, bool SPARSE, bool STREAM, class Body, class PLAN = NoSparsePlan, class OFF = unsigned, bool BUF = false>
+template <int BLOCK, int LDS_SLOTS, int LDS_USLOTS, bool SPARSE, bool STREAM, class Body, class PLAN = NoSparsePlan, class OFF = unsigned, bool BUF = false, bool PAIR = false>
 #if defined(UNGAR_QUAD_WAVES_PER_EU)  // experiment knob of tools/quad_bench.hip: ask for N resident wavefronts per SIMD (register budget 512 / N)
 #define UNGAR_QUAD_OCCUPANCY __attribute__((amdgpu_waves_per_eu(UNGAR_QUAD_WAVES_PER_EU, UNGAR_QUAD_WAVES_PER_EU)))
 #else
@@ -191,7 +285,7 @@ __global__ __launch_bounds__(BLOCK) UNGAR_QUAD_OCCUPANCY void QuadNodeKernel(con
     static_assert(BLOCK == 64, "the LDS home is laid out for one wavefront per workgroup");
     __shared__ double lds[(LDS_SLOTS > 0 ? LDS_SLOTS : 1) * BLOCK + LDS_USLOTS * (BLOCK / 4)];
     const int L = (threadIdx.x >> 2) & 3;
-    const int nodeInWave = 4 * (threadIdx.x >> 4) + (threadIdx.x & 3);
+    const int nodeInWave = QuadNodeInWave<PAIR>(static_cast<int>(threadIdx.x));
     const long long i = static_cast<long long>(blockIdx.x) * (BLOCK / 4) + nodeInWave;
     if (i >= a.count) return;  // the four lanes of a node leave together
     long long b = i, k = 0;
@@ -203,7 +297,7 @@ __global__ __launch_bounds__(BLOCK) UNGAR_QUAD_OCCUPANCY void QuadNodeKernel(con
     double* const jb = a.jac.base + b * a.jac.bs + k * a.jac.ks;
     const long long je = a.jac.es;
     double* const jLeg = jb + 3LL * L * 49 * je;
-    QuadIO<SPARSE, STREAM, PLAN, OFF, BUF> io{a.x.base + b * a.x.bs + k * a.x.ks,
+    QuadIO<SPARSE, STREAM, PLAN, OFF, BUF, PAIR> io{a.x.base + b * a.x.bs + k * a.x.ks,
               a.u.base + b * a.u.bs + k * a.u.ks,
               a.p.base + b * a.p.bs + k * a.p.ks,
               fb,
@@ -229,6 +323,7 @@ __global__ __launch_bounds__(BLOCK) UNGAR_QUAD_OCCUPANCY void QuadNodeKernel(con
         io.buf.vLeg = static_cast<int>(static_cast<unsigned>(nodeOff + 3LL * L * 49 * je) * 8u);
         for (int r = 0; r < 4; ++r) io.buf.vLegCol[r] = static_cast<int>(static_cast<unsigned>(nodeOff + 3LL * L * 49 * je + 3LL * ((L + r) & 3) * je) * 8u);
         io.buf.vOwnCol = static_cast<int>(static_cast<unsigned>(nodeOff + 3LL * L * je) * 8u);
+        if constexpr (PAIR) QuadPairOffsets(io.buf, static_cast<int>(threadIdx.x), je);
     }
 #endif
     if constexpr (SPARSE) {

@@ -2,6 +2,7 @@
 //
 // Thin by design: argument checking, the model registry, and launches.  No allocation and no
 // synchronisation on the batched entry points.
+#include "measurement.hpp"
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -401,6 +402,10 @@ const char* ungar_last_error(void) {
 
 int32_t ungar_abi_version(void) {
     return UNGAR_AMD_ABI_VERSION;
+}
+
+int32_t ungar_measurement_build(void) {
+    return UNGAR_AMD_MEASUREMENT_BUILD;
 }
 
 const char* ungar_version(void) {

@@ -1,4 +1,5 @@
 // ungar_amd :: C ABI of the batched SQP iteration (include/ungar_amd.h, "batched SQP iteration"): argument checks and launches.
+#include "measurement.hpp"
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -215,8 +216,8 @@ int ungar_shooting_assemble(const ungar_shooting_assemble_args* a, void* stream)
     k.w = a->w;
     k.E = a->E;
     k.dz0 = a->dz0;
-    k.eliminate = a->eliminate_equalities && a->ne > 0 ? (getenv("UNGAR_AMD_ASSEMBLE_SKIP_SUBSTITUTION") ? 2 : 1) : 0;
-    if (k.eliminate && getenv("UNGAR_AMD_ASSEMBLE_GENERIC")) k.eliminate |= 4;  // measurement switch: no wavefront-specialised sections (same bits)
+    k.eliminate = a->eliminate_equalities && a->ne > 0 ? (UNGAR_MEASUREMENT_SWITCH("UNGAR_AMD_ASSEMBLE_SKIP_SUBSTITUTION") ? 2 : 1) : 0;
+    if (k.eliminate && UNGAR_MEASUREMENT_SWITCH("UNGAR_AMD_ASSEMBLE_GENERIC")) k.eliminate |= 4;  // measurement switch: no wavefront-specialised sections (same bits)
     k.e = a->eq;
     k.er = a->eq_reduced;
     k.pivots = a->eq_pivots;

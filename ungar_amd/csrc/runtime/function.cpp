@@ -12,6 +12,7 @@
 //                                       a hit skips derive / emit / compile altogether
 // Kernels map one lane to one problem instance and address operands through strides, so the same
 // code object serves batch = 1 host calls (what Ungar::Autodiff::Function needs) and large batches.
+#include "measurement.hpp"
 #include <hip/hip_runtime.h>
 #include <fcntl.h>
 #include <sys/file.h>
@@ -666,7 +667,7 @@ int ungar_function_eval_host(ungar_function* fn, int32_t what, const double* xp_
     // stream), the kernel writes its results straight into mapped host memory (posted writes over PCIe; nothing to copy back), and the stream
     // is awaited once.  (Three blocking steps -- copy in, launch, copy out -- measured 27 us per call; the reference's in-process C call has no
     // such floor, so this is what a drop-in user of the single-instance API sees first.)  UNGAR_AMD_HOST_CALL_COPIES=1 restores the copies.
-    static const bool copies = std::getenv("UNGAR_AMD_HOST_CALL_COPIES") != nullptr;
+    static const bool copies = UNGAR_MEASUREMENT_SWITCH("UNGAR_AMD_HOST_CALL_COPIES") != nullptr;
     hipError_t e = hipSuccess;
     if (!fn->dIn) e = hipMalloc(&fn->dIn, static_cast<std::size_t>(std::max<int64_t>(nIn, 1)) * sizeof(double));
     if (copies) {

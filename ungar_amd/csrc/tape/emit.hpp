@@ -11,8 +11,11 @@
 // never linked into the product library.
 #pragma once
 
+#include "../runtime/measurement.hpp"
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <sstream>
 #include <string>
 #include <utility>
@@ -27,6 +30,7 @@ namespace ungar_amd::tape {
 struct OutputSlot {
     Id value;
     std::string sink;
+    Id value2 = kNoId;  // second value of a paired sink ("%t" in the statement): two results leaving in one store instruction
 };
 
 /// How input `i` of the tape is spelled in the generated code.
@@ -41,6 +45,13 @@ class Emitter {
     Emitter(const Graph& g, std::vector<std::string> inputExpr) : g_{g}, inputExpr_{std::move(inputExpr)} {
     }
 
+    /// Inputs flagged here are spelled by an expression that is evaluated wherever the value is used, in every phase
+    /// that uses it (the phased emitter never gives them a home of their own): items of an LDS channel between two
+    /// wavefronts, which must not be read before the statement that waits for them.
+    void SetRereadInputs(std::vector<char> flags) {
+        reread_ = std::move(flags);
+    }
+
     /// Emits statements computing every slot, in slot order; each value's not-yet-emitted
     /// dependencies are emitted depth-first immediately before its first use, which keeps live
     /// ranges short (matters on the GPU where the "stack" is the VGPR file).
@@ -49,12 +60,12 @@ class Emitter {
         name_.assign(g_.Size(), -1);
         for (const OutputSlot& s : slots) {
             EmitNode(s.value, os, indent);
-            char buf[64];
-            const std::string v = Ref(s.value);
+            if (s.value2 != kNoId) EmitNode(s.value2, os, indent);
             std::string line = s.sink;
             const std::size_t pos = line.find("%s");
-            if (pos != std::string::npos) line.replace(pos, 2, v);
-            (void)buf;
+            if (pos != std::string::npos) line.replace(pos, 2, Ref(s.value));
+            const std::size_t pos2 = line.find("%t");
+            if (pos2 != std::string::npos && s.value2 != kNoId) line.replace(pos2, 2, Ref(s.value2));
             os << indent << line << "\n";
         }
         return os.str();
@@ -99,7 +110,10 @@ class Emitter {
         std::vector<int> defPhase(n, -1);
         std::vector<std::vector<Id>> order(phases.size());
         for (std::size_t ph = 0; ph < phases.size(); ++ph)
-            for (const OutputSlot& s : phases[ph]) CollectOrder(s.value, static_cast<int>(ph), defPhase, order[ph]);
+            for (const OutputSlot& s : phases[ph]) {
+                CollectOrder(s.value, static_cast<int>(ph), defPhase, order[ph]);
+                if (s.value2 != kNoId) CollectOrder(s.value2, static_cast<int>(ph), defPhase, order[ph]);
+            }
         const std::vector<std::vector<OutputSlot>>& ph_ = phases;
         std::vector<int> consumers(n, 0);
         for (std::size_t ph = 0; ph < ph_.size(); ++ph) {
@@ -119,7 +133,10 @@ class Emitter {
                 use(nd.c);
                 use(nd.d);
             }
-            for (const OutputSlot& s : ph_[ph]) use(s.value);
+            for (const OutputSlot& s : ph_[ph]) {
+                use(s.value);
+                use(s.value2);
+            }
         }
         // ---- stored set: cross-phase values that are not worth recomputing ---------------------------------
         std::vector<char> stored(n, 0);
@@ -129,6 +146,10 @@ class Emitter {
             if (defPhase[i] < 0 || consumers[i] == 0) continue;
             ++crossTotal;
             const Node& nd = g_.At(static_cast<Id>(i));
+            if (IsReread(nd)) {  // re-read from its channel in every consuming phase
+                depth[i] = 1;
+                continue;
+            }
             bool cheap = nd.op != Op::Input && nd.op != Op::Div && nd.op != Op::Sin && nd.op != Op::Cos && nd.op != Op::Sqrt && nd.op != Op::Tan &&
                          nd.op != Op::Atan && nd.op != Op::Atan2 && nd.op != Op::Exp && nd.op != Op::Log && nd.op != Op::Pow && nd.op != Op::Asin &&
                          nd.op != Op::Acos;
@@ -190,6 +211,10 @@ class Emitter {
                 phaseBegin.push_back(all.size());
                 if (ph && !dry) all.push_back({"io.phase();", false, 0});
                 const int iph = static_cast<int>(ph);
+                // sinks spelled "@begin:<statement>" open the phase (waiting for another wavefront's message, ...)
+                if (!dry)
+                    for (const OutputSlot& s : ph_[ph])
+                        if (s.sink.rfind(kBeginTag, 0) == 0) all.push_back({s.sink.substr(std::strlen(kBeginTag)), false, 0});
                 // explicit stack DFS producing statements for `root` in this phase
                 auto produce = [&](Id root) {
                     std::vector<std::pair<Id, int>> stack{{root, 0}};
@@ -263,12 +288,19 @@ class Emitter {
                 };
                 for (Id id : order[ph]) produce(id);
                 for (const OutputSlot& s : ph_[ph]) {
+                    if (s.sink.rfind(kBeginTag, 0) == 0) continue;
                     produce(s.value);
+                    if (s.value2 != kNoId) produce(s.value2);
                     if (!dry) {
                         std::string line = s.sink;
+                        auto spell = [&](Id v) {
+                            const Node& nv = g_.At(v);
+                            return nv.op == Op::Const ? Lit(nv.value) : local[static_cast<std::size_t>(v)];
+                        };
                         const std::size_t pos = line.find("%s");
-                        const Node& nv = g_.At(s.value);
-                        if (pos != std::string::npos) line.replace(pos, 2, nv.op == Op::Const ? Lit(nv.value) : local[static_cast<std::size_t>(s.value)]);
+                        if (pos != std::string::npos) line.replace(pos, 2, spell(s.value));
+                        const std::size_t pos2 = line.find("%t");
+                        if (pos2 != std::string::npos && s.value2 != kNoId) line.replace(pos2, 2, spell(s.value2));
                         lines.emplace_back(line, false);
                     }
                 }
@@ -346,6 +378,14 @@ class Emitter {
                     live -= liveDelta[ph + 1];
                 }
                 slotsUsed = next;
+                if (UNGAR_MEASUREMENT_SWITCH("UNGAR_EMIT_DUMP_LIVE")) {  // codegen diagnostics: live ranges of the stored cross-phase values
+                    std::vector<std::vector<int>> hist(ph_.size(), std::vector<int>(ph_.size(), 0));
+                    for (std::size_t i = 0; i < n; ++i)
+                        if (stored[i] && defPhase[i] >= 0 && lastLoad[i] > defPhase[i]) ++hist[static_cast<std::size_t>(defPhase[i])][static_cast<std::size_t>(lastLoad[i])];
+                    for (std::size_t d = 0; d < ph_.size(); ++d)
+                        for (std::size_t l = 0; l < ph_.size(); ++l)
+                            if (hist[d][l]) std::fprintf(stderr, "[emit-live] defined in phase %zu, last used in phase %zu: %d values\n", d, l, hist[d][l]);
+                }
                 if (uniformSlotsUsed) *uniformSlotsUsed = nextUniform;
                 if (uniformInput && uniformSlots > 0) {
                     std::size_t uniformStatements = 0, total = 0;
@@ -365,6 +405,12 @@ class Emitter {
             }
         }
         return text;
+    }
+
+    static constexpr const char* kBeginTag = "@begin:";
+
+    bool IsReread(const Node& nd) const {
+        return nd.op == Op::Input && static_cast<std::size_t>(nd.a) < reread_.size() && reread_[static_cast<std::size_t>(nd.a)];
     }
 
     static std::size_t CountDefined(const std::vector<int>& defPhase) {
@@ -529,6 +575,7 @@ class Emitter {
 
     const Graph& g_;
     std::vector<std::string> inputExpr_;
+    std::vector<char> reread_;
     std::vector<int> name_;
     int next_ = 0;
     EmitStats stats_;

@@ -124,7 +124,9 @@ class BatchedSoftSqp:
 
     def __init__(self, dynamics: str, cost: str, horizon: int, batch: int, inequality: str | None = None, constraint_violation_multiplier: float = 1.0,
                  stiffness: float = 100.0, epsilon: float = 2e-5, barrier: str = "poly", regularization: float = 1e-6,
-                 line_search: LineSearchParameters | None = None):
+                 line_search: LineSearchParameters | None = None, jacobian_in_place: bool = False):
+        """jacobian_in_place: the Riccati recursion reads a wide unit-fastest [A|B] through its element stride instead of a node-major transpose
+        (identical bits; measured slower, profiles/r03f_jacobian_in_place_ab.log -- kept selectable for that comparison)."""
         import torch
         self.torch = torch
         self.lib = _declare(load_library())
@@ -156,8 +158,7 @@ class BatchedSoftSqp:
         self.status = torch.zeros((B,), dtype=torch.int32, device="cuda")
         self.workspace = z(max(1, self.lib.ungar_ocp_riccati_workspace(nx, nu, N, B)))
         self._stack = None  # buffers of the stacked line search, allocated on first use
-        import os
-        self._transpose_jacobian = os.environ.get("UNGAR_AMD_SQP_JACOBIAN_IN_PLACE") != "1"
+        self._transpose_jacobian = not jacobian_in_place
         self._wide = None   # unit-fastest scratch of a wide dynamics Jacobian (>= 1024 entries per node and no node parameters w)
         if nx * n >= 1024 and self.dyn.nw == 0:
             from .sharding import unit_fastest
@@ -193,7 +194,7 @@ class BatchedSoftSqp:
                                     par(p_dyn, self.dyn), Operand.soa(sf, st, N), Operand.soa(sJ, st, N), knots=N, stream=stream)
             transpose_nodes(sf, self.f, count, nx, (1, st), (nx, 1), stream=stream)
             # [A|B] is transposed into node-major blocks for the Riccati recursion (0.31 ms per 81 920 nodes).  Reading it IN PLACE through the
-            # element stride (the recursion's LDS-DMA copies take 8-byte elements from any address; UNGAR_AMD_SQP_JACOBIAN_IN_PLACE=1, identical
+            # element stride (the recursion's LDS-DMA copies take 8-byte elements from any address; `jacobian_in_place=True`, identical
             # bits) was measured and is slower: every element of a knot then comes from its own cache line, shared only with the same
             # instance's seven neighbouring knots, which the 512 concurrent instances evict before they are used -- QP step 6.29 ms against
             # 4.70 ms through the transpose (profiles/r03f_jacobian_in_place_ab.log).
