@@ -35,3 +35,28 @@ def shared_codegen(tmp_path_factory):
 
     folder.root = root  # (bench.py takes it as UNGAR_BENCH_CODEGEN: its SQP legs run the same programs as tests/test_batched_sqp.py, in <root>/batched_<problem>)
     return folder
+
+
+@pytest.fixture
+def measurement_library():
+    """The measurement build of the library for the duration of one test (csrc/runtime/measurement.hpp): the agreement tests between two kernel routes select
+    the routes through environment variables that only this build reads.  Yields its path (C++ programs: put its folder first in LD_LIBRARY_PATH)."""
+    import ungar_amd
+    path = ungar_amd.measurement_library_path()
+    assert os.path.exists(path), f"{path} missing: run __graft_entry__.build()"
+    ungar_amd.use_library(path)
+    try:
+        assert ungar_amd.load_library().ungar_measurement_build() == 1
+        yield path
+    finally:
+        ungar_amd.use_library(None)
+
+
+def measurement_env(extra=None):
+    """Environment of a C++ test program that must resolve libungar_amd.so to the measurement build (DT_RUNPATH of the programs comes after LD_LIBRARY_PATH)."""
+    import ungar_amd
+    folder = os.path.dirname(ungar_amd.measurement_library_path())
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = folder + (os.pathsep + env["LD_LIBRARY_PATH"] if env.get("LD_LIBRARY_PATH") else "")
+    env.update(extra or {})
+    return env

@@ -130,3 +130,41 @@ def test_reference_side_adapter_compiles_and_reports_sparsity(repo_root, tmp_pat
 @pytest.mark.gpu
 def test_reference_side_adapter_evaluates_closed_forms_on_gpu(repo_root, tmp_path):
     _amd_model_test(repo_root, "gpu", tmp_path)
+
+
+def test_shipped_library_has_no_measurement_switches(repo_root):
+    """A/B routes, per-phase clocks and experiment knobs are read from the environment only in the measurement build (csrc/runtime/measurement.hpp): the shipped
+    library must not even contain their names -- a user environment that happens to carry UNGAR_AMD_ASSEMBLE_SKIP_SUBSTITUTION must not change what is computed.
+    The names are collected from the sources (every UNGAR_MEASUREMENT_SWITCH("...")); the measurement build has them and says so."""
+    import glob
+    import re
+    import ungar_amd
+    names, library_names = set(), set()
+    for path in glob.glob(os.path.join(repo_root, "ungar_amd", "csrc", "**", "*"), recursive=True):
+        if os.path.isfile(path) and path.endswith((".hip", ".cpp", ".hpp")) and os.sep + "gen" + os.sep not in path:
+            found = re.findall(r'UNGAR_MEASUREMENT_SWITCH\("([A-Z0-9_]+)"\)', open(path).read())
+            names.update(found)
+            if os.sep + "tape" + os.sep not in path:  # (the emitter's diagnostics are reached from the code generator, a build tool, not from the library)
+                library_names.update(found)
+    assert len(library_names) >= 15, library_names
+    shipped = open(ungar_amd.library_path(), "rb").read()
+    measurement_path = ungar_amd.measurement_library_path()
+    assert os.path.exists(measurement_path), f"{measurement_path} missing: run __graft_entry__.build()"
+    measurement = open(measurement_path, "rb").read()
+    for name in sorted(names):
+        assert name.encode() not in shipped, f"{name} is readable by the shipped library"
+        assert name not in library_names or name.encode() in measurement, f"{name} missing from the measurement build"
+    # no other getenv of an UNGAR_* name than the documented interface variables
+    interface = {"UNGAR_HIPCC", "UNGAR_CODEGEN_FOLDER", "UNGAR_AMD_SCALAR_STORES", "UNGAR_AMD_JIT_FLAGS", "UNGAR_AMD_JACOBIAN_MODE", "UNGAR_AMD_VERBOSE", "UNGAR_AMD_KEEP_SOURCE",
+                 "UNGAR_AMD_COMPILE_ONLY"}
+    found = set(m.decode() for m in re.findall(rb"UNGAR_[A-Z0-9_]{3,}", shipped))
+    env_like = {n for n in found if n.startswith(("UNGAR_AMD_", "UNGAR_GN_", "UNGAR_HIPCC", "UNGAR_CODEGEN"))}
+    undocumented = {n for n in env_like if n not in interface and not n.startswith(("UNGAR_AMD_EMITTER", "UNGAR_AMD_ABI", "UNGAR_AMD_H_", "UNGAR_AMD_DEFINE"))}
+    integration = open(os.path.join(repo_root, "INTEGRATION.md")).read()
+    for n in sorted(interface):
+        assert n in integration, f"{n} is read by the shipped library but not documented in INTEGRATION.md"
+    assert not undocumented, undocumented
+    lib = ctypes.CDLL(measurement_path)
+    lib.ungar_measurement_build.restype = ctypes.c_int32
+    assert lib.ungar_measurement_build() == 1
+    assert ungar_amd.load_library().ungar_measurement_build() == 0

@@ -17,6 +17,7 @@ import subprocess
 import numpy as np
 
 import pytest
+from conftest import measurement_env
 
 pytestmark = pytest.mark.gpu
 
@@ -42,7 +43,7 @@ def test_workgroup_assembly_route_of_the_problems_without_equality_rows(repo_roo
     take).  Same comparison with the facade's whole-horizon optimiser on that route."""
     exe = os.path.join(repo_root, "build", f"batched_{problem}_test")
     assert os.path.exists(exe), f"{exe} missing: run __graft_entry__.build()"
-    r = subprocess.run([exe, str(shared_codegen(f"batched_{problem}")), "512", "4"], capture_output=True, text=True, timeout=1500, env={**os.environ, "UNGAR_AMD_ASSEMBLE_VARIANT": "workgroup"})
+    r = subprocess.run([exe, str(shared_codegen(f"batched_{problem}")), "512", "4"], capture_output=True, text=True, timeout=1500, env=measurement_env({"UNGAR_AMD_ASSEMBLE_VARIANT": "workgroup"}))
     print(r.stdout[-3000:], r.stderr[-1000:])
     assert r.returncode == 0 and f"PASS batched {problem} SQP (batch 512, 4 compared)" in r.stdout
 
@@ -70,7 +71,7 @@ def test_assembly_kernels_agree(repo_root, tmp_path, shared_codegen):
     assert os.path.exists(exe), f"{exe} missing: run __graft_entry__.build()"
     dumps = {}
     for mode in ("wavefront", "workgroup", "generic"):
-        env = dict(os.environ)
+        env = measurement_env()
         env.pop("UNGAR_AMD_ASSEMBLE_GENERIC", None)
         env.pop("UNGAR_AMD_ASSEMBLE_VARIANT", None)
         if mode == "generic":
@@ -151,7 +152,7 @@ class _AssembleArgs(ctypes.Structure):
 
 
 @pytest.mark.parametrize("nx,nu", [(3, 5), (20, 14)])  # 64 lanes per node (generic sections) / 256 lanes (wavefront-specialised sections, and generic on request)
-def test_redundant_equality_rows_take_no_pivot(nx, nu, monkeypatch):
+def test_redundant_equality_rows_take_no_pivot(nx, nu, monkeypatch, measurement_library):
     """Two identical stage equality rows (and a third that is a combination of the others): the duplicate reduces to rounding noise (~1e-16 of its entries, not
     exactly zero) and must be recognised against its ORIGINAL scale -- relative to its own reduced entries the noise would pass as a pivot and 1 / pivot would
     blow up W, [A|B] and w.  The reduced problem must equal the one assembled from the independent rows alone; a duplicate with a DIFFERENT residual cannot be
@@ -234,7 +235,7 @@ def test_redundant_equality_rows_take_no_pivot(nx, nu, monkeypatch):
 
 
 @pytest.mark.parametrize("nx,nu,nh,dense_row", [(13, 4, 8, False), (8, 2, 6, False), (20, 9, 5, True), (30, 12, 14, True), (10, 3, 0, False)])
-def test_one_wavefront_assembly_of_problems_without_equality_rows_on_random_patterns(nx, nu, nh, dense_row, monkeypatch):
+def test_one_wavefront_assembly_of_problems_without_equality_rows_on_random_patterns(nx, nu, nh, dense_row, monkeypatch, measurement_library):
     """ShootingAssembleSmallKernel (stage problems without equality rows, nd + 1 <= 64) against the workgroup kernel (UNGAR_AMD_ASSEMBLE_VARIANT=workgroup) on random
     SPARSE patterns -- Hessian, gradient, dynamics Jacobian, inequality Jacobian with rows of one to several entries, and (dense_row) a row whose entry pairs do not
     fit a wavefront (the one-lane-per-entry fallback of the barrier terms) -- with carried inputs (nc = nu, identity carry).  Every block it writes (upper triangle of W,
@@ -312,7 +313,7 @@ def test_one_wavefront_assembly_of_problems_without_equality_rows_on_random_patt
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3])
-def test_one_wavefront_assembly_with_equality_rows_on_random_patterns(seed, monkeypatch):
+def test_one_wavefront_assembly_with_equality_rows_on_random_patterns(seed, monkeypatch, measurement_library):
     """ShootingAssembleWaveKernel<25, 24, 16> (quadruped-shaped stage nodes: 12 carried + 13 states, 24 inputs, 16 equality rows eliminated per node) against the
     workgroup kernel on random sparse patterns and values that the quadruped's own data never produce: equality rows with state and input entries in random places,
     empty rows, an empty row with a residual (cannot be met: -2), rows without input entries, a carry Jacobian, dense-ish inequality rows.  Same pivots; reduced

@@ -158,3 +158,71 @@ def test_concurrent_builders_of_the_same_function(tmp_path):
     files = _entry_files(tmp_path, "cache_race")
     assert not [f for f in files if f.endswith(".tmp") or f.endswith(".hip")], files
     assert _make(tmp_path, scale=3.0, name="cache_race")["hit"]
+
+
+def _wide_tape(m):
+    """y_j = (x_j + x_{j+1}) * x_{j+1} + x_j * p0, j < m (n = m + 1, p = 1): 4 m operations -- above the chunk budget of the run-time factory (6000 statements) for m = 1700."""
+    n = m + 1
+    nodes = [Node(INPUT, i, -1, -1, -1, 0, 0.0) for i in range(n + 1)]  # x0..xm, p0 (index n)
+    outs = []
+    for j in range(m):
+        base = len(nodes)
+        nodes += [Node(ADD, j, j + 1, -1, -1, 0, 0.0), Node(MUL, base, j + 1, -1, -1, 0, 0.0), Node(MUL, j, n, -1, -1, 0, 0.0), Node(ADD, base + 1, base + 2, -1, -1, 0, 0.0)]
+        outs.append(base + 3)
+    return (Node * len(nodes))(*nodes), len(nodes), (ctypes.c_int32 * m)(*outs), n
+
+
+def _make_wide(folder, m=1700):
+    lib = ungar_amd.load_library()
+    lib.ungar_function_make.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                        ctypes.c_char_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+    lib.ungar_function_free.argtypes = [ctypes.c_void_p]
+    lib.ungar_function_free.restype = None
+    lib.ungar_function_get_info.argtypes = [ctypes.c_void_p, ctypes.POINTER(Info)]
+    nodes, count, outs, n = _wide_tape(m)
+    fn = ctypes.c_void_p()
+    rc = lib.ungar_function_make(nodes, count, outs, m, n, 1, b"wide_probe", 1, str(folder).encode(), 0, ctypes.byref(fn))  # enabled = NONE (1): value only
+    assert rc == 0, lib.ungar_last_error().decode()
+    info = Info()
+    assert lib.ungar_function_get_info(fn, ctypes.byref(info)) == 0
+    return lib, fn, info, n
+
+
+def test_a_large_body_is_compiled_in_chunks(tmp_path, monkeypatch):
+    """A derivative whose body exceeds the statement budget is cut into chunks of consecutive outputs -- one kernel, one code object and one compiler process per
+    chunk, all started together (the equality-constraint Jacobian of the reference's quadruped OCP: 85 s -> under 10 s of its cold start): the entry lists them
+    (value, value.1, ...) and a second make finds them all."""
+    monkeypatch.setenv("UNGAR_AMD_COMPILE_ONLY", "1")
+    lib, fn, info, _ = _make_wide(tmp_path)
+    assert info.cache_hit == 0
+    lib.ungar_function_free(fn)
+    objects = sorted(f for f in os.listdir(tmp_path / "wide_probe" / "ungar_amd") if f.endswith(".hsaco"))
+    assert len(objects) >= 2 and any(f.endswith("_value.hsaco") for f in objects) and any(f.endswith("_value.1.hsaco") for f in objects), objects
+    meta = next(f for f in os.listdir(tmp_path / "wide_probe" / "ungar_amd") if f.endswith(".meta"))
+    text = open(tmp_path / "wide_probe" / "ungar_amd" / meta).read()
+    assert f"units {len(objects)}" in text and "unit value.1 ungar_fn_forward_zero_c1" in text
+    lib, fn, info, _ = _make_wide(tmp_path)
+    assert info.cache_hit == 1
+    lib.ungar_function_free(fn)
+    os.remove(tmp_path / "wide_probe" / "ungar_amd" / objects[-1])  # a chunk missing: the entry is rebuilt, not half loaded
+    lib, fn, info, _ = _make_wide(tmp_path)
+    assert info.cache_hit == 0
+    lib.ungar_function_free(fn)
+
+
+@pytest.mark.gpu
+def test_chunked_kernels_write_every_output(tmp_path):
+    """The chunks of a large body on the device: every output of the single-instance host call equals the closed form (each chunk writes its own range of the
+    same operand; a chunk that is not launched leaves its range unwritten)."""
+    import numpy as np
+    lib, fn, info, n = _make_wide(tmp_path)
+    lib.ungar_function_eval_host.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
+    rng = np.random.default_rng(3)
+    xp = rng.uniform(-1.0, 1.0, n + 1)
+    y = np.full(info.m, np.nan)
+    assert lib.ungar_function_eval_host(fn, 0, xp.ctypes.data, y.ctypes.data) == 0, lib.ungar_last_error().decode()
+    x, p0 = xp[:n], xp[n]
+    expect = (x[:-1] + x[1:]) * x[1:] + x[:-1] * p0
+    assert not np.isnan(y).any()
+    assert np.abs(y - expect).max() <= 1e-14
+    lib.ungar_function_free(fn)

@@ -334,7 +334,7 @@ def test_device_riccati_equals_the_dense_kkt_solve(nx, nu, N, batch):
 
 @gpu
 @pytest.mark.parametrize("nx,nu,N", [(37, 12, 20), (25, 24, 30), (13, 24, 30), (17, 4, 30), (13, 4, 30)])
-def test_register_resident_riccati_kernels_agree_with_the_lds_resident_ones(nx, nu, N, monkeypatch):
+def test_register_resident_riccati_kernels_agree_with_the_lds_resident_ones(nx, nu, N, monkeypatch, measurement_library):
     """The large blocks take the one-wavefront-per-instance kernels of ocp_riccati_wave.hip by default (every matrix of the recursion in registers, products
     chained on the FP64 matrix cores, homogeneous coordinates for the affine parts); UNGAR_AMD_RICCATI_VARIANT keeps the LDS-resident kernels of
     ocp_riccati.hip (the recursion that is pinned against the dense KKT solve on the host).  Same QPs, both routes: steps equal to 1e-11 of their scale, and

@@ -4,6 +4,8 @@ lane-per-leg value program vs the lane-per-node body (UNGAR_AMD_ANYMAL_VALUE_LAN
 import json
 import os
 import subprocess
+
+MEASUREMENT_LIBRARY = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ungar_amd", "lib", "measurement", "libungar_amd.so")  # the A/B switch exists only there
 import sys
 
 import torch
@@ -43,6 +45,6 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
 else:
     res = {}
     for tag, env in (("lane_per_leg", {}), ("lane_per_node", {"UNGAR_AMD_ANYMAL_VALUE_LANE_PER_NODE": "1"})):
-        r = subprocess.run([sys.executable, __file__, "--child"], env={**os.environ, **env}, capture_output=True, text=True)
+        r = subprocess.run([sys.executable, __file__, "--child"], env={**os.environ, "UNGAR_AMD_LIBRARY": MEASUREMENT_LIBRARY, **env}, capture_output=True, text=True)
         res[tag] = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": r.stderr[-400:]}
     print(json.dumps(res))

@@ -10,6 +10,9 @@ import torch
 
 sys.path.insert(0, ".")
 import ungar_amd  # noqa: E402
+
+if os.environ.get("UNGAR_GN_LANES_UNROLL") or os.environ.get("UNGAR_GN_TILES_DMA"):
+    ungar_amd.use_library(ungar_amd.measurement_library_path())  # the knobs exist only in the measurement build
 from ungar_amd import workloads as W  # noqa: E402
 
 rows, cols, N, batch = 37, 49, 20, 4096

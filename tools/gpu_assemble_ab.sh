@@ -3,6 +3,7 @@
 # its generic sections (UNGAR_AMD_ASSEMBLE_GENERIC=1) -- same bits expected: the facade comparison lines and the dumped QP data of both runs are compared --
 # then wall clock at 4096 instances of these two and of the default route (the one-wavefront kernel of DESIGN 4.12; its agreement with the others within
 # rounding is tests/test_batched_sqp.py::test_assembly_kernels_agree), the kernel split (rocprofv3) and the section clocks.  Outputs under gpurun_out/.
+source "$(dirname "$0")/use_measurement_build.sh"  # the A/B switches below exist only in the measurement build of the library
 set -uo pipefail
 mkdir -p gpurun_out
 export TMPDIR=/tmp

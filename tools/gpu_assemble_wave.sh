@@ -1,6 +1,7 @@
 #!/usr/bin/env bash
 # One-wavefront shooting assembly kernel (default for quadruped-shaped nodes) against the workgroup kernel (UNGAR_AMD_ASSEMBLE_VARIANT=workgroup):
 # facade comparison, dumped QP data (tolerance: tests/test_batched_sqp.py::test_assembly_kernels_agree), wall clock at 4096 instances, kernel split.
+source "$(dirname "$0")/use_measurement_build.sh"  # the A/B switches below exist only in the measurement build of the library
 set -uo pipefail
 mkdir -p gpurun_out
 export TMPDIR=/tmp

@@ -1,5 +1,6 @@
 #!/usr/bin/env bash
 # Section clocks of the one-wavefront assembly kernel (two nodes per launch print their cycles) + SQ counters of the kernel.
+source "$(dirname "$0")/use_measurement_build.sh"  # the A/B switches below exist only in the measurement build of the library
 set -uo pipefail
 mkdir -p gpurun_out
 export TMPDIR=/tmp

@@ -1,6 +1,7 @@
 #!/usr/bin/env bash
 # SQ counters of the shooting assembly kernel (the reference's quadruped OCP, 4096 instances, C++ driver): wavefront-specialised sections and, with
 # UNGAR_AMD_ASSEMBLE_GENERIC=1, the generic ones.  Separate --pmc passes with --kernel-trace only.  Output: gpurun_out/assemble_sq_counters.log
+source "$(dirname "$0")/use_measurement_build.sh"  # the A/B switches below exist only in the measurement build of the library
 set -uo pipefail
 mkdir -p gpurun_out
 export TMPDIR=/tmp

@@ -1,5 +1,6 @@
 #!/usr/bin/env bash
 # Quick loop: facade comparison of the three batched OCPs (1024 instances, 4 compared), timing at 4096 instances, assembly section clocks.
+source "$(dirname "$0")/use_measurement_build.sh"  # the A/B switches below exist only in the measurement build of the library
 set -uo pipefail
 mkdir -p gpurun_out
 export TMPDIR=/tmp

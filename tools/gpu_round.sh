@@ -2,6 +2,7 @@
 # Full round evidence on the GPU box: parity tests, smoke, bench (default line + 2-rank dry run of the config-5 partition), rocprofv3
 # kernel trace + HBM counters for the headline kernel, Gauss-Newton and SQP benches.  Outputs under gpurun_out/
 # (tools/collect_profiles.py and tools/collect_round.sh copy the judged summaries into profiles/).
+source "$(dirname "$0")/use_measurement_build.sh"  # the A/B switches below exist only in the measurement build of the library
 set -uo pipefail
 mkdir -p gpurun_out
 export TMPDIR=/tmp

@@ -24,6 +24,8 @@ import numpy as np
 __all__ = ["NodeModel", "Operand", "gn_hessian", "gn_hessian_lanes", "gn_hessian_tiles", "transpose_nodes", "gn_hessian_unit_fastest", "library_path", "load_library", "UngarError", "MODELS"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+_PATH_OVERRIDE: str | None = None  # use_library()
+_LOADED: dict = {}                 # path -> declared CDLL
 MODELS = ("quadrotor", "rc_car", "srbd", "anymal", "anymal_ad", "anymal_reg")
 RBD_MODELS = ("anymal_rnea", "anymal_crba", "anymal_minv", "anymal_feet", "anymal_centroidal")  # rigid-body quantities as node models
 
@@ -33,8 +35,16 @@ class UngarError(RuntimeError):
 
 
 def library_path() -> str:
-    """In-tree library; UNGAR_AMD_LIBRARY overrides it (another build of the same ABI, e.g. `measurement_library_path()`)."""
-    return os.environ.get("UNGAR_AMD_LIBRARY") or os.path.join(_HERE, "lib", "libungar_amd.so")
+    """In-tree library; `use_library()` / UNGAR_AMD_LIBRARY override it (another build of the same ABI, e.g. `measurement_library_path()`)."""
+    return _PATH_OVERRIDE or os.environ.get("UNGAR_AMD_LIBRARY") or os.path.join(_HERE, "lib", "libungar_amd.so")
+
+
+def use_library(path: str | None) -> None:
+    """Makes `path` (None: back to the default) the library every later `load_library()` returns; libraries already loaded stay loaded and are
+    reused.  For the agreement tests between two kernel routes and for tools/, which need the measurement build for part of a session."""
+    global _PATH_OVERRIDE, _LIB
+    _PATH_OVERRIDE = path
+    _LIB = None
 
 
 def measurement_library_path() -> str:
@@ -71,6 +81,9 @@ def load_library() -> ctypes.CDLL:
     if _LIB is not None:
         return _LIB
     path = library_path()
+    if path in _LOADED:
+        _LIB = _LOADED[path]
+        return _LIB
     if not os.path.exists(path):
         raise UngarError(f"{path} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
                          "(ungar_amd has no CPU fallback).")
@@ -111,7 +124,7 @@ def load_library() -> ctypes.CDLL:
     lib.ungar_ocp_assemble_equality.argtypes = [vp, ctypes.c_int64, ctypes.c_int64] + [ctypes.POINTER(_Operand)] * 6 + [vp]
     lib.ungar_last_error.restype = ctypes.c_char_p
     lib.ungar_version.restype = ctypes.c_char_p
-    _LIB = lib
+    _LIB = _LOADED[path] = lib
     return lib
 
 

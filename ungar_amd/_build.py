@@ -56,7 +56,7 @@ def build_codegen() -> str:
     srcs = _tree(os.path.join(CSRC, "tape"), os.path.join(CSRC, "models"), os.path.join(CSRC, "rbd"), os.path.join(CSRC, "codegen"))
     if not _newer([exe], srcs):
         os.makedirs(BUILD, exist_ok=True)
-        _run(["g++", "-std=c++20", "-O2", "-o", exe, os.path.join(CSRC, "codegen", "codegen_main.cpp")])
+        _run(["g++", "-std=c++20", "-O2", "-DUNGAR_AMD_MEASUREMENT", "-o", exe, os.path.join(CSRC, "codegen", "codegen_main.cpp")])  # (a build tool: its emitter diagnostics stay selectable)
     return exe
 
 

@@ -46,8 +46,11 @@ struct ungar_function {
     int64_t n = 0, p = 0, m = 0;
     uint32_t enabled = 0;
     std::vector<int32_t> jacRows, jacCols, hesRows, hesCols;
-    hipModule_t modules[3] = {nullptr, nullptr, nullptr};  // value, Jacobian, Hessian: one code object each (compiled concurrently)
-    hipFunction_t kValue = nullptr, kJac = nullptr, kHes = nullptr;
+    // value, Jacobian, Hessian: one code object each -- or several, one per CHUNK of consecutive outputs, when the body exceeds kChunkStatements
+    // statements (all compiled concurrently; the chunks of one derivative are launched one after the other on the caller's stream)
+    using Kernels = std::vector<hipFunction_t>;
+    std::vector<hipModule_t> modules;
+    Kernels kValue, kJac, kHes;
     std::string codeObjectPath;
     bool cacheHit = false;
     // staging buffers for the single-instance host entry points
@@ -111,9 +114,14 @@ struct KeyHasher {
 #ifndef UNGAR_AMD_EMITTER_ID
 #define UNGAR_AMD_EMITTER_ID "unversioned"
 #endif
-constexpr const char* kCacheFormat = "ungar_amd-cache-4";  // bump whenever the emitted kernels' argument list (their ABI) or the meta file changes: 3 = ten-argument kernels (knot stride, direct host results), 4 = consecutive outputs leave in 16-byte stores
+constexpr const char* kCacheFormat = "ungar_amd-cache-5";  // bump whenever the emitted kernels' argument list (their ABI) or the meta file changes: 3 = ten-argument kernels (knot stride, direct host results), 4 = consecutive outputs leave in 16-byte stores, 5 = a derivative may consist of several kernels (chunks of consecutive outputs; unit tags "jacobian.3")
 constexpr const char* kArch = "gfx950";
 constexpr std::size_t kBigKernel = 3000;        // statements above which the machine schedulers are switched off (see below)
+// Statements above which a derivative is cut into chunks of consecutive outputs, one kernel and one compiler process each: the compile time of
+// a straight-line body grows faster than its length (the equality-constraint Jacobian of the reference's quadruped OCP, 14 167 outputs in one
+// body: 85 s of the example's 98 s cold start on the MI355X box), and the chunks compile side by side on the host's cores.
+constexpr std::size_t kChunkStatements = 6000;
+constexpr std::size_t kMaxChunks = 64;
 constexpr int64_t kDirectHostResults = 512;  // single-instance host calls: results up to this many doubles are written straight into mapped host memory
 
 std::string ShellQuote(const std::string& s) {
@@ -205,7 +213,7 @@ struct CacheMeta {
         };
         if (!pattern("jac", jacRows, jacCols) || !pattern("hes", hesRows, hesCols)) return false;
         std::size_t count = 0;
-        if (!(is >> word >> count) || word != "units" || count > 3) return false;
+        if (!(is >> word >> count) || word != "units" || count > 3 * kMaxChunks) return false;
         units.resize(count);
         for (Unit& u : units)
             if (!(is >> word >> u.tag >> u.kernel >> u.objectSize >> u.statements) || word != "unit") return false;
@@ -238,7 +246,9 @@ bool PairOutputStores() {
     return !(e && e[0] == '1');
 }
 
-std::string EmitKernel(const std::string& kernelName, const tape::Graph& g, int64_t nIn, const std::vector<tape::Id>& values, std::size_t* statements) {
+/// Outputs [first, last) of `values` (the whole derivative when the body is small enough, one chunk of it otherwise); output k is written at index k whatever the chunk.
+std::string EmitKernel(const std::string& kernelName, const tape::Graph& g, int64_t nIn, const std::vector<tape::Id>& values, std::size_t first, std::size_t last,
+                       std::size_t* statements) {
     const bool pairs = PairOutputStores();
     std::vector<std::string> inNames;
     inNames.reserve(static_cast<std::size_t>(nIn));
@@ -252,17 +262,19 @@ std::string EmitKernel(const std::string& kernelName, const tape::Graph& g, int6
     // run of doubles: every store instruction is 64 separate transactions at L2 whatever its width, and their RATE bounds these kernels (with coalesced
     // unit-fastest outputs the quadruped's Jacobian kernels take 60 instead of 112 us) -- pairs halve the transactions.  The run of an instance starts at a
     // multiple of 8 bytes, not of 16: gfx950 under ROCm executes global_store_dwordx4 at any 4-byte-aligned address (SH_MEM_CONFIG alignment mode
-    // "unaligned", what KFD programs for compute queues; tools/unaligned_store_probe.hip checks it on the box).
+    // "unaligned", what KFD programs for compute queues; tools/unaligned_store_probe.hip checks it on the box).  The vector TYPE is declared with
+    // 8-byte alignment, so the store is defined C++ at every run start and it is the compiler, which knows the target's access mode
+    // (amdhsa: unaligned-access-mode), that emits one dwordx4 store -- or two dwordx2 stores on a target without that mode.
     std::vector<tape::OutputSlot> slots;
-    for (std::size_t k = 0; k < values.size(); ++k) {
+    for (std::size_t k = first; k < last; ++k) {  // (chunks start at even k: the pairs below never straddle two kernels)
         const std::string ks = std::to_string(k);
-        if (pairs && k % 2 == 0 && k + 1 < values.size()) slots.push_back({values[k], "const double o" + ks + " = %s;"});
+        if (pairs && k % 2 == 0 && k + 1 < last) slots.push_back({values[k], "const double o" + ks + " = %s;"});
         else if (pairs && k % 2 == 1) slots.push_back({values[k], "UNGAR_STORE2(" + std::to_string(k - 1) + ", o" + std::to_string(k - 1) + ", %s);"});
         else slots.push_back({values[k], "out[" + ks + " * oes] = %s;"});
     }
     std::ostringstream os;
     os << "#ifndef UNGAR_STORE2\n"
-          "typedef double ungar_d2 __attribute__((ext_vector_type(2)));\n"
+          "typedef double ungar_d2 __attribute__((ext_vector_type(2), aligned(8)));\n"
           "#define UNGAR_STORE2(K, A, B) do { if (oes == 1) { ungar_d2 t_; t_.x = (A); t_.y = (B); *reinterpret_cast<ungar_d2*>(out + (K)) = t_; } "
           "else { out[(K) * oes] = (A); out[((K) + 1) * oes] = (B); } } while (0)\n"
           "#endif\n";
@@ -436,24 +448,54 @@ int ungar_function_make(const ungar_tape_node* nodes, int64_t num_nodes, const i
 
         // ---- HIP source: one translation unit per kernel so that the compiler runs on all of them at once ----
         struct Unit {
-            const char* kernel = nullptr;
-            const char* tag = nullptr;
+            std::string kernel, tag;  // chunk c > 0 of a derivative: kernel "<name>_c<c>", tag "<tag>.<c>"
             const std::vector<tape::Id>* values = nullptr;
+            std::size_t first = 0, last = 0;  // outputs [first, last) of *values
             std::string source, object, tmpObject, log, flags;
             FILE* pipe = nullptr;
             std::size_t statements = 0;
         };
         std::vector<Unit> units;
-        auto unit = [](const char* kernel, const char* tag, const std::vector<tape::Id>* values) {
-            Unit u;
-            u.kernel = kernel;
-            u.tag = tag;
-            u.values = values;
-            return u;
+        // One unit per derivative, or one per chunk of consecutive outputs whose cone (distinct tape nodes it needs) stays below kChunkStatements: greedy over the
+        // outputs in index order, chunk boundaries at even indices; what two chunks share is computed by both.
+        auto addUnits = [&](const char* kernel, const char* tag, const std::vector<tape::Id>& values) {
+            std::vector<std::size_t> starts{0};
+            {
+                std::vector<int> seenIn(g.Size(), -1);
+                std::size_t inChunk = 0;
+                std::vector<tape::Id> stack;
+                for (std::size_t k = 0; k < values.size(); ++k) {
+                    const int chunk = static_cast<int>(starts.size()) - 1;
+                    stack.push_back(values[k]);
+                    while (!stack.empty()) {
+                        const tape::Id id = stack.back();
+                        stack.pop_back();
+                        if (id == tape::kNoId || seenIn[static_cast<std::size_t>(id)] == chunk) continue;
+                        seenIn[static_cast<std::size_t>(id)] = chunk;
+                        const tape::Node& nd = g.At(id);
+                        if (tape::Arity(nd.op) == 0) continue;
+                        ++inChunk;
+                        for (tape::Id o : {nd.a, nd.b, nd.c, nd.d}) stack.push_back(o);
+                    }
+                    if (inChunk > kChunkStatements && k % 2 == 1 && k + 1 < values.size() && starts.size() < kMaxChunks) {
+                        starts.push_back(k + 1);
+                        inChunk = 0;
+                    }
+                }
+            }
+            for (std::size_t c = 0; c < starts.size(); ++c) {
+                Unit u;
+                u.kernel = c ? std::string(kernel) + "_c" + std::to_string(c) : std::string(kernel);
+                u.tag = c ? std::string(tag) + "." + std::to_string(c) : std::string(tag);
+                u.values = &values;
+                u.first = starts[c];
+                u.last = c + 1 < starts.size() ? starts[c + 1] : values.size();
+                units.push_back(std::move(u));
+            }
         };
-        units.push_back(unit("ungar_fn_forward_zero", "value", &valueIds));
-        if (!jac.value.empty()) units.push_back(unit("ungar_fn_sparse_jacobian", "jacobian", &jac.value));
-        if (!hes.value.empty()) units.push_back(unit("ungar_fn_sparse_hessian", "hessian", &hes.value));
+        addUnits("ungar_fn_forward_zero", "value", valueIds);
+        if (!jac.value.empty()) addUnits("ungar_fn_sparse_jacobian", "jacobian", jac.value);
+        if (!hes.value.empty()) addUnits("ungar_fn_sparse_hessian", "hessian", hes.value);
         if (!MakeDirs(dir)) return Fail(UNGAR_E_IO, "cannot create code-generation folder '" + dir + "'");
         // Compile flags.  The machine instruction schedulers (pre- and post-RA) account for > 95 % of the compile
         // time of a large straight-line kernel (a whole-horizon constraint Jacobian of 23 k statements: 64 s -> 6 s
@@ -477,7 +519,7 @@ int ungar_function_make(const ungar_tape_node* nodes, int64_t num_nodes, const i
         };
         for (Unit& u : units) {
             const std::string src = "// generated by ungar_amd (runtime/function.cpp) for function '" + fn->name + "'\n#include <hip/hip_runtime.h>\n\n" +
-                                    EmitKernel(u.kernel, g, n + p, *u.values, &u.statements);
+                                    EmitKernel(u.kernel, g, n + p, *u.values, u.first, u.last, &u.statements);
             u.flags = std::string("--offload-arch=") + kArch + " -std=c++17 " +
                       (custom ? custom : u.statements > kBigKernel ? "-O3 -mllvm -enable-misched=false -mllvm -enable-post-misched=false" : "-O3");
             u.object = base + "_" + u.tag + ".hsaco";
@@ -555,14 +597,19 @@ int ungar_function_make(const ungar_tape_node* nodes, int64_t num_nodes, const i
         *out = fn.release();
         return UNGAR_OK;
     }
-    for (std::size_t k = 0; k < meta.units.size(); ++k) {
+    for (std::size_t k = 0; k < meta.units.size(); ++k) {  // (the chunks of a derivative are listed in output order)
         const CacheMeta::Unit& u = meta.units[k];
         const std::string object = base + "_" + u.tag + ".hsaco";
-        hipFunction_t* handle = u.tag == "value" ? &fn->kValue : u.tag == "jacobian" ? &fn->kJac : &fn->kHes;
-        hipError_t e = hipModuleLoad(&fn->modules[k], object.c_str());
+        const std::string derivative = u.tag.substr(0, u.tag.find('.'));
+        ungar_function::Kernels& handles = derivative == "value" ? fn->kValue : derivative == "jacobian" ? fn->kJac : fn->kHes;
+        hipModule_t module = nullptr;
+        hipError_t e = hipModuleLoad(&module, object.c_str());
         if (e != hipSuccess) return Fail(UNGAR_E_HIP, std::string("hipModuleLoad('") + object + "'): " + hipGetErrorString(e));
-        e = hipModuleGetFunction(handle, fn->modules[k], u.kernel.c_str());
+        fn->modules.push_back(module);
+        hipFunction_t handle = nullptr;
+        e = hipModuleGetFunction(&handle, module, u.kernel.c_str());
         if (e != hipSuccess) return Fail(UNGAR_E_HIP, std::string("hipModuleGetFunction: ") + hipGetErrorString(e));
+        handles.push_back(handle);
     }
     *out = fn.release();
     return UNGAR_OK;
@@ -589,7 +636,7 @@ const char* ungar_function_code_object(const ungar_function* fn) {
 
 int ungar_function_jacobian_sparsity(const ungar_function* fn, const int32_t** rows, const int32_t** cols, int64_t* nnz) {
     if (!fn || !rows || !cols || !nnz) return Fail(UNGAR_E_INVALID, "ungar_function_jacobian_sparsity: null argument");
-    if (!fn->kJac && !(fn->enabled & kEnableJacobian)) return Fail(UNGAR_E_UNSUPPORTED, "function '" + fn->name + "' was made without JACOBIAN");
+    if (fn->kJac.empty() && !(fn->enabled & kEnableJacobian)) return Fail(UNGAR_E_UNSUPPORTED, "function '" + fn->name + "' was made without JACOBIAN");
     *rows = fn->jacRows.data();
     *cols = fn->jacCols.data();
     *nnz = static_cast<int64_t>(fn->jacRows.size());
@@ -605,10 +652,10 @@ int ungar_function_hessian_sparsity(const ungar_function* fn, const int32_t** ro
     return UNGAR_OK;
 }
 
-static int LaunchFn(const ungar_function* fn, hipFunction_t k, const char* what, const ungar_operand* xp, const ungar_operand* out,
+static int LaunchFn(const ungar_function* fn, const ungar_function::Kernels* kernels, const char* what, const ungar_operand* xp, const ungar_operand* out,
                     int64_t batch, void* stream, int64_t knotsPerInstance = 1) {
     if (!fn || !xp || !out) return Fail(UNGAR_E_INVALID, std::string(what) + ": null argument");
-    if (!k) return Fail(UNGAR_E_UNSUPPORTED, std::string(what) + ": kernel not available for function '" + fn->name + "' (derivative not enabled, or made with UNGAR_AMD_COMPILE_ONLY)");
+    if (!kernels || kernels->empty()) return Fail(UNGAR_E_UNSUPPORTED, std::string(what) + ": kernel not available for function '" + fn->name + "' (derivative not enabled, or made with UNGAR_AMD_COMPILE_ONLY)");
     if (batch < 0 || knotsPerInstance < 1) return Fail(UNGAR_E_INVALID, std::string(what) + ": negative batch or knots < 1");
     if (batch == 0) return UNGAR_OK;
     if (!xp->base || !out->base) return Fail(UNGAR_E_INVALID, std::string(what) + ": null operand base");
@@ -618,38 +665,39 @@ static int LaunchFn(const ungar_function* fn, hipFunction_t k, const char* what,
     long long knots = knotsPerInstance, xks = xp->knot_stride, oks = out->knot_stride;
     void* args[] = {&in, &xbs, &xes, &o, &obs, &oes, &b, &knots, &xks, &oks};
     const unsigned block = 64;
-    const hipError_t e = hipModuleLaunchKernel(k, static_cast<unsigned>((batch + block - 1) / block), 1, 1, block, 1, 1, 0,
-                                               static_cast<hipStream_t>(stream), args, nullptr);
-    if (e != hipSuccess) return Fail(UNGAR_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
+    for (hipFunction_t k : *kernels) {  // every chunk of the derivative writes its own outputs of the same operand
+        const hipError_t e = hipModuleLaunchKernel(k, static_cast<unsigned>((batch + block - 1) / block), 1, 1, block, 1, 1, 0, static_cast<hipStream_t>(stream), args, nullptr);
+        if (e != hipSuccess) return Fail(UNGAR_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
+    }
     return UNGAR_OK;
 }
 
 int ungar_function_forward_zero(const ungar_function* fn, const ungar_operand* xp, const ungar_operand* y, int64_t batch, void* stream) {
-    return LaunchFn(fn, fn ? fn->kValue : nullptr, "ungar_function_forward_zero", xp, y, batch, stream);
+    return LaunchFn(fn, fn ? &fn->kValue : nullptr, "ungar_function_forward_zero", xp, y, batch, stream);
 }
 // A derivative that is enabled but structurally empty (Jacobian of a function of the parameters only, Hessian of a
 // linear objective) has no kernel and nothing to write: the reference returns an empty sparse matrix there
 // (function.hpp:216-230, 236-259), so the batched calls succeed without a launch.
 int ungar_function_sparse_jacobian(const ungar_function* fn, const ungar_operand* xp, const ungar_operand* jac, int64_t batch, void* stream) {
     if (fn && xp && jac && batch >= 0 && (fn->enabled & kEnableJacobian) && fn->jacRows.empty()) return UNGAR_OK;
-    return LaunchFn(fn, fn ? fn->kJac : nullptr, "ungar_function_sparse_jacobian", xp, jac, batch, stream);
+    return LaunchFn(fn, fn ? &fn->kJac : nullptr, "ungar_function_sparse_jacobian", xp, jac, batch, stream);
 }
 int ungar_function_sparse_hessian(const ungar_function* fn, const ungar_operand* xp, const ungar_operand* hes, int64_t batch, void* stream) {
     if (fn && xp && hes && batch >= 0 && (fn->enabled & kEnableHessian) && fn->hesRows.empty()) return UNGAR_OK;
-    return LaunchFn(fn, fn ? fn->kHes : nullptr, "ungar_function_sparse_hessian", xp, hes, batch, stream);
+    return LaunchFn(fn, fn ? &fn->kHes : nullptr, "ungar_function_sparse_hessian", xp, hes, batch, stream);
 }
 
 // Shooting nodes: node i = (instance i / knots, knot i % knots) at base + instance * instance_stride + knot * knot_stride.
 int ungar_function_forward_zero_nodes(const ungar_function* fn, const ungar_operand* xp, const ungar_operand* y, int64_t count, int64_t knots, void* stream) {
-    return LaunchFn(fn, fn ? fn->kValue : nullptr, "ungar_function_forward_zero_nodes", xp, y, count, stream, knots);
+    return LaunchFn(fn, fn ? &fn->kValue : nullptr, "ungar_function_forward_zero_nodes", xp, y, count, stream, knots);
 }
 int ungar_function_sparse_jacobian_nodes(const ungar_function* fn, const ungar_operand* xp, const ungar_operand* jac, int64_t count, int64_t knots, void* stream) {
     if (fn && xp && jac && count >= 0 && (fn->enabled & kEnableJacobian) && fn->jacRows.empty()) return UNGAR_OK;
-    return LaunchFn(fn, fn ? fn->kJac : nullptr, "ungar_function_sparse_jacobian_nodes", xp, jac, count, stream, knots);
+    return LaunchFn(fn, fn ? &fn->kJac : nullptr, "ungar_function_sparse_jacobian_nodes", xp, jac, count, stream, knots);
 }
 int ungar_function_sparse_hessian_nodes(const ungar_function* fn, const ungar_operand* xp, const ungar_operand* hes, int64_t count, int64_t knots, void* stream) {
     if (fn && xp && hes && count >= 0 && (fn->enabled & kEnableHessian) && fn->hesRows.empty()) return UNGAR_OK;
-    return LaunchFn(fn, fn ? fn->kHes : nullptr, "ungar_function_sparse_hessian_nodes", xp, hes, count, stream, knots);
+    return LaunchFn(fn, fn ? &fn->kHes : nullptr, "ungar_function_sparse_hessian_nodes", xp, hes, count, stream, knots);
 }
 
 /// Single-instance host call: H2D, batch-1 launch, D2H, on the null stream, synchronous.
@@ -657,11 +705,11 @@ int ungar_function_eval_host(ungar_function* fn, int32_t what, const double* xp_
     if (!fn || !xp_host) return Fail(UNGAR_E_INVALID, "ungar_function_eval_host: null argument");
     const int64_t nIn = fn->n + fn->p;
     const int64_t nOut = what == 0 ? fn->m : what == 1 ? static_cast<int64_t>(fn->jacRows.size()) : static_cast<int64_t>(fn->hesRows.size());
-    hipFunction_t k = what == 0 ? fn->kValue : what == 1 ? fn->kJac : fn->kHes;
+    const ungar_function::Kernels* k = what == 0 ? &fn->kValue : what == 1 ? &fn->kJac : &fn->kHes;
     if (what < 0 || what > 2) return Fail(UNGAR_E_INVALID, "ungar_function_eval_host: what must be 0 (value), 1 (Jacobian) or 2 (Hessian)");
     if (nOut == 0 && what != 0 && (fn->enabled & (what == 1 ? kEnableJacobian : kEnableHessian))) return UNGAR_OK;  // enabled but structurally empty (out_host may be null)
     if (!out_host) return Fail(UNGAR_E_INVALID, "ungar_function_eval_host: null output");
-    if (!k) return Fail(UNGAR_E_UNSUPPORTED, "ungar_function_eval_host: kernel not available for function '" + fn->name + "' (derivative not enabled, or made with UNGAR_AMD_COMPILE_ONLY)");
+    if (k->empty()) return Fail(UNGAR_E_UNSUPPORTED, "ungar_function_eval_host: kernel not available for function '" + fn->name + "' (derivative not enabled, or made with UNGAR_AMD_COMPILE_ONLY)");
     if (nOut == 0) return UNGAR_OK;
     // One launch and ONE synchronisation per call: the inputs go through a pinned staging buffer (asynchronous copy on the function's own
     // stream), the kernel writes its results straight into mapped host memory (posted writes over PCIe; nothing to copy back), and the stream

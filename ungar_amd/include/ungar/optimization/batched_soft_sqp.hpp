@@ -22,8 +22,11 @@
 //                 stage derivatives (ungar_function_*_nodes) -> ungar_shooting_assemble -> ungar_ocp_riccati_solve (the exact
 //                 solution of the QP the reference hands to OSQP, stage equality rows included) -> merit terms -> all candidate steps
 //                 of the backtracking search as one stacked batch -> per-instance selection and stopping rule.
-// Host code is plain C++20 over the C ABI (include/ungar_amd.h); no HIP headers.  Inside an iteration the host reads back one 4-byte counter per line-search stage that
-// leaves some instance unresolved (SetFirstLineSearchStage(0): none -- all candidate steps for every instance in one stacked evaluation).
+// Host code is plain C++20 over the C ABI (include/ungar_amd.h); no HIP headers.
+// HOST SYNCHRONISATION.  By default the line search is STAGED: the first two candidate steps go to every instance; if some instance accepted neither, Iterate()
+// downloads one 4-byte counter (a stream synchronisation) and offers the remaining steps to the listed instances only -- 2.16 -> 1.45 ms per quadrotor iteration.  An
+// iteration is therefore NOT free of host round trips by default (it was before ABI 5): it cannot be captured into a HIP graph as is, and its timing depends on the data.
+// SetFirstLineSearchStage(0) restores the fully asynchronous schedule (all candidate steps for every instance in one stacked evaluation, no read-back).
 #pragma once
 
 #include <cstdint>
@@ -72,9 +75,7 @@ class BatchedSoftSQPOptimizer {
         _barrier.epsilon = epsilon;
         Validate();
         _dims = {_p.stateSize, _p.inputSize, _p.carrySize, _p.knotParameterSize, _p.instanceParameterSize, _p.horizon, _batch, _p.carryInputs ? 1 : 0, 0};
-        for (real_t alpha = 1.0; alpha >= _ls.alphaMin; alpha *= _ls.gammaAlpha) _alphas.push_back(alpha);  // backtracking_line_search.hpp:116-151
-        // any BacktrackingLineSearch parameters (backtracking_line_search.hpp:56-78): more than 16 candidate steps are evaluated in groups of 16, largest first
-        if (_alphas.empty()) throw std::invalid_argument("BatchedSoftSQPOptimizer: the line search has no candidate step (alphaMin > 1)");
+        _alphas = CandidateSteps(_ls);  // backtracking_line_search.hpp:116-151; more than 16 candidate steps are evaluated in groups of 16, largest first
         Allocate();
     }
     BatchedSoftSQPOptimizer(const BatchedSoftSQPOptimizer&) = delete;
@@ -342,14 +343,29 @@ class BatchedSoftSQPOptimizer {
     /// block) or kept inside the Riccati recursion as the stage KKT block of every knot (false; same solution, for comparison).
     void EliminateEqualityRowsBeforeTheRecursion(const bool on) { _eliminateEqualities = on; }
     void SetLineSearchParameters(const BacktrackingLineSearch::Parameters& parameters) {
-        std::vector<real_t> alphas;
-        for (real_t alpha = 1.0; alpha >= parameters.alphaMin; alpha *= parameters.gammaAlpha) alphas.push_back(alpha);
-        const std::size_t cap = static_cast<std::size_t>(kStacked);  // the stacked buffers hold min(candidates at construction, 16) trial points per instance
-        if ((alphas.size() < cap ? alphas.size() : cap) > (_alphas.size() < cap ? _alphas.size() : cap))
+        const std::vector<real_t> alphas = CandidateSteps(parameters);
+        const std::size_t cap = static_cast<std::size_t>(kStacked);
+        // the stacked buffers hold _stackedCapacity = min(candidates at construction, 16) trial points per instance -- compared with what was ALLOCATED, not with the
+        // current list (a call that shrank the list must not make a later call with the original parameters fail)
+        if ((alphas.size() < cap ? alphas.size() : cap) > static_cast<std::size_t>(_stackedCapacity))
             throw std::invalid_argument("BatchedSoftSQPOptimizer: more candidate steps per stacked evaluation than the buffers allocated at construction hold");
-        if (alphas.empty()) throw std::invalid_argument("BatchedSoftSQPOptimizer: the line search has no candidate step (alphaMin > 1)");
         _ls = parameters;
         _alphas = alphas;
+    }
+
+    /// The candidate steps 1, gamma, gamma^2, ... >= alphaMin of the backtracking search (backtracking_line_search.hpp:116-151).  The reference's loop does not end
+    /// for gammaAlpha >= 1 or alphaMin <= 0 (alpha never drops below alphaMin, or underflows to 0 >= 0); here such parameters are refused, and so is a list of more
+    /// than 1024 steps.
+    static std::vector<real_t> CandidateSteps(const BacktrackingLineSearch::Parameters& parameters) {
+        if (!(parameters.gammaAlpha > 0.0 && parameters.gammaAlpha < 1.0) || !(parameters.alphaMin > 0.0))
+            throw std::invalid_argument("BatchedSoftSQPOptimizer: the line search needs 0 < gammaAlpha < 1 and alphaMin > 0");
+        std::vector<real_t> alphas;
+        for (real_t alpha = 1.0; alpha >= parameters.alphaMin; alpha *= parameters.gammaAlpha) {
+            if (alphas.size() == 1024) throw std::invalid_argument("BatchedSoftSQPOptimizer: more than 1024 candidate steps (gammaAlpha too close to 1 for this alphaMin)");
+            alphas.push_back(alpha);
+        }
+        if (alphas.empty()) throw std::invalid_argument("BatchedSoftSQPOptimizer: the line search has no candidate step (alphaMin > 1)");
+        return alphas;
     }
 
   private:
@@ -400,6 +416,7 @@ class BatchedSoftSQPOptimizer {
     void Allocate() {
         const index_t N = _p.horizon, B = _batch, nv = _p.RowSize(), nx = _p.stateSize, nu = _p.inputSize, nz = Nz(), nd = nz + nu;
         const index_t K = static_cast<index_t>(_alphas.size()) < kStacked ? static_cast<index_t>(_alphas.size()) : kStacked;  // candidates evaluated at once
+        _stackedCapacity = K;
         const index_t nodes = B * (N + 1), stacked = K * nodes;
         _pf = UploadPattern(*_p.dynamics, false);
         if (_p.carry) _pc = UploadPattern(*_p.carry, false);
@@ -516,6 +533,7 @@ class BatchedSoftSQPOptimizer {
     real_t* _er = nullptr;
     int32_t *_status = nullptr, *_active = nullptr, *_pivots = nullptr;
     bool _eliminateEqualities = true;
+    index_t _stackedCapacity = 0;  // trial points per instance the stacked buffers were allocated for
     std::vector<index_t> _stages{2};  // ({2, 4} measured: no gain -- quadrotor 1.22 -> 1.27 ms, RC car 0.84 -> 0.86: who needs less than 1/2 mostly needs much less)
     int32_t *_listA = nullptr, *_listB = nullptr;  // instances a stage of the line search left unresolved (read / written alternately)
     index_t _trialStride = 0;
