@@ -268,6 +268,15 @@ typedef struct ungar_ocp_qp {
 } ungar_ocp_qp;
 int64_t ungar_ocp_riccati_workspace(int64_t nx, int64_t nu, int64_t horizon, int64_t batch);
 int ungar_ocp_riccati_solve(const ungar_ocp_qp* qp, void* stream);
+/* Which recursion a QP of these stage sizes runs (ne: equality rows INSIDE the recursion; rows eliminated by ungar_shooting_assemble count as 0):
+ *   0  the LDS-resident kernels, sizes known at run time (any nx + nu <= 256);
+ *   1  the register-resident one-wavefront kernel compiled into the library (the reference's own stage sizes);
+ *   2  the same kernel TEMPLATE instantiated for (nx, nu) by the kernel factory: `hipcc --genco` through the model cache's machinery
+ *      (UNGAR_CODEGEN_FOLDER/ungar_amd_kernels, keyed by the kernel sources, the sizes, the toolchain), occupancy picked from the compiled candidates.
+ * prepare != 0 builds / loads a factory kernel NOW (seconds, once per size and cache folder) instead of inside the first ungar_ocp_riccati_solve; a
+ * factory failure (no compiler on the machine) is reported on stderr once and the call returns 0: the solve then takes the LDS-resident kernels.
+ * Replaces the reference's "any NLPProblem" contract for the QP step (optimization/concepts.hpp:153-262, soft_sqp.hpp:143-158). */
+int ungar_ocp_riccati_route(int64_t nx, int64_t nu, int64_t ne, int32_t prepare);
 
 /* Merit terms of the line search per instance (soft_sqp.hpp:68-87): theta = multiplier * |g|_2, phi = sum of the stage
  * costs (+ terminal) + sum of the barrier over the inequality values; and, when cost_grad and dX are given, the slope
@@ -378,6 +387,11 @@ typedef struct ungar_shooting_assemble_args {
     int32_t* eq_pivots;
 } ungar_shooting_assemble_args;
 int ungar_shooting_assemble(const ungar_shooting_assemble_args* args, void* stream);
+/* Which assembly kernel a stage problem takes (nz = carried + state size, ne stage equality rows eliminated by the call, nh inequality rows):
+ *   0 the workgroup kernel (any size up to the limits of INTEGRATION.md section 5), 1 the one-wavefront kernel compiled into the library (the reference's
+ *   quadruped OCP), 2 the same kernel template instantiated for (nz, nu, ne) by the kernel factory (see ungar_ocp_riccati_route), 3 the run-time-size
+ *   one-wavefront kernel of the problems without equality rows.  prepare != 0 builds / loads a factory kernel now. */
+int ungar_shooting_assemble_route(int64_t nz, int64_t nu, int64_t ne, int64_t nh, int32_t prepare);
 /* After the Riccati solve of a problem assembled with eliminate_equalities: dU[b][k][j] = -(E'_i . [dz_k; du_k] + e'_i) for every reduced
  * row i with pivot input j; status[b] = -(k+1) for a row that cannot be met (status may be null). */
 int ungar_shooting_recover_inputs(const ungar_shooting_dims* dims, int64_t ne, const double* E, const double* eq_reduced, const int32_t* eq_pivots, const double* dZ,

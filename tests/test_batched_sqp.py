@@ -312,9 +312,15 @@ def test_one_wavefront_assembly_of_problems_without_equality_rows_on_random_patt
         assert np.abs(mine[key] - theirs[key]).max() <= 1e-13 * scale, key
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3])
-def test_one_wavefront_assembly_with_equality_rows_on_random_patterns(seed, monkeypatch, measurement_library):
-    """ShootingAssembleWaveKernel<25, 24, 16> (quadruped-shaped stage nodes: 12 carried + 13 states, 24 inputs, 16 equality rows eliminated per node) against the
+# (stage sizes nx, nu, carried, equality rows, inequality rows; expected ungar_shooting_assemble_route): the reference's quadruped shape is compiled into the
+# library (1); every other shape the kernel template fits is instantiated by the kernel factory on first use (2)
+WAVE_SHAPES = [(13, 24, 12, 16, 12, 1), (8, 9, 12, 4, 5, 2), (10, 3, 0, 2, 0, 2), (30, 12, 5, 7, 9, 2)]
+
+
+@pytest.mark.parametrize("seed,shape", [(1, WAVE_SHAPES[0]), (2, WAVE_SHAPES[0]), (3, WAVE_SHAPES[0]), (4, WAVE_SHAPES[1]), (5, WAVE_SHAPES[2]), (6, WAVE_SHAPES[3])])
+def test_one_wavefront_assembly_with_equality_rows_on_random_patterns(seed, shape, monkeypatch, measurement_library):
+    """ShootingAssembleWaveKernel<NZ, NU, NE> -- compiled in for quadruped-shaped stage nodes (12 carried + 13 states, 24 inputs, 16 equality rows eliminated per
+    node), instantiated at run time by the kernel factory for the other shapes (20 + 9 with 4 rows, 10 + 3 with 2 rows and no inequality, 35 + 12 with 7 rows) -- against the
     workgroup kernel on random sparse patterns and values that the quadruped's own data never produce: equality rows with state and input entries in random places,
     empty rows, an empty row with a residual (cannot be met: -2), rows without input entries, a carry Jacobian, dense-ish inequality rows.  Same pivots; reduced
     rows, residuals, W and [A|B] to 1e-12 of their scale (the same matrix-core sequences); w and b to 1e-9 (summed in another order)."""
@@ -322,8 +328,11 @@ def test_one_wavefront_assembly_with_equality_rows_on_random_patterns(seed, monk
     import ungar_amd
     lib = ungar_amd.load_library()
     lib.ungar_shooting_assemble.argtypes = [ctypes.POINTER(_AssembleArgs), ctypes.c_void_p]
-    nx, nu, nc, nw, ne, nh, N, B = 13, 24, 12, 2, 16, 12, 2, 6
+    nx, nu, nc, ne, nh, route = shape
+    nw, N, B = 2, 2, 6
     nz, nd = nc + nx, nc + nx + nu
+    lib.ungar_shooting_assemble_route.argtypes = [ctypes.c_int64] * 4 + [ctypes.c_int32]
+    assert lib.ungar_shooting_assemble_route(nz, nu, ne, nh, 1) == route, lib.ungar_last_error()
     rng = np.random.default_rng(100 + seed)
     dev = lambda a, dt=torch.float64: torch.tensor(np.ascontiguousarray(a), dtype=dt, device="cuda")  # noqa: E731
     nodes = B * (N + 1)
@@ -332,16 +341,16 @@ def test_one_wavefront_assembly_with_equality_rows_on_random_patterns(seed, monk
         r, c = np.nonzero(mask)
         return r.astype(np.int32), c.astype(np.int32)
 
-    pH = pattern_of(np.triu(rng.random((nd, nd)) < 0.12) | np.eye(nd, dtype=bool))
+    pH = pattern_of(np.triu(rng.random((nd, nd)) < min(0.12, 150.0 / (nd * nd))) | np.eye(nd, dtype=bool))
     pg = (np.zeros(nd, dtype=np.int32), np.arange(nd, dtype=np.int32))
-    pf = pattern_of((rng.random((nx, nx + nu)) < 0.4) | np.eye(nx, nx + nu, dtype=bool))
-    pc = pattern_of(rng.random((nc, nx + nu)) < 0.2)
+    pf = pattern_of((rng.random((nx, nx + nu)) < min(0.4, 180.0 / (nx * (nx + nu)))) | np.eye(nx, nx + nu, dtype=bool))  # (the one-wavefront kernels take patterns of up to 256 entries)
+    pc = pattern_of(rng.random((nc, nx + nu)) < 0.2) if nc else (np.zeros(0, dtype=np.int32), np.zeros(0, dtype=np.int32))
     emask = np.zeros((ne, nd), dtype=bool)
     for r in range(ne):
         kind = rng.random()
-        if kind < 0.25:
+        if kind < 0.25 and r > 0:
             continue  # empty row (an inactive contact)
-        cols = rng.choice(nd, rng.integers(2, 7), replace=False)
+        cols = rng.choice(nd, rng.integers(2, min(7, nd)), replace=False)
         emask[r, cols] = True
         if kind < 0.9:
             emask[r, nz + rng.integers(0, nu)] = True  # at least one input entry (else: a row the inputs cannot meet unless it is zero)
@@ -349,7 +358,8 @@ def test_one_wavefront_assembly_with_equality_rows_on_random_patterns(seed, monk
             emask[r, nz:] = False
     pe = pattern_of(emask)
     hmask = rng.random((nh, nd)) < 0.05
-    hmask[np.arange(nh), rng.integers(0, nd, nh)] = True
+    if nh:
+        hmask[np.arange(nh), rng.integers(0, nd, nh)] = True
     ph = pattern_of(hmask)
     assert pH[0].size <= 256 and pf[0].size <= 256 and pc[0].size <= 128 and pe[0].size <= 256 and ph[0].size <= 64
     pats = {k: (dev(v[0], torch.int32), dev(v[1], torch.int32)) for k, v in (("pH", pH), ("pg", pg), ("pf", pf), ("pc", pc), ("pe", pe), ("ph", ph))}
@@ -394,7 +404,7 @@ def test_one_wavefront_assembly_with_equality_rows_on_random_patterns(seed, monk
 
     mine, theirs = run(False), run(True)
     assert (mine["piv"] == theirs["piv"]).all(), (mine["piv"], theirs["piv"])
-    assert (theirs["piv"] >= 0).sum() > B * N * 4 and (theirs["piv"] == -1).any()  # (pivots were taken, empty rows took none)
+    assert (theirs["piv"] >= 0).sum() >= B * N * min(4, ne // 2) and ((theirs["piv"] == -1).any() or not empty.any())  # (pivots were taken, empty rows took none)
     for key, tol in (("E", 1e-12), ("er", 1e-12), ("W", 1e-12), ("AB", 1e-12), ("w", 1e-9), ("b", 1e-9), ("dz0", 0.0)):
         assert np.isfinite(mine[key]).all(), key
         scale = np.abs(theirs[key]).max()

@@ -211,10 +211,11 @@ def test_a_large_body_is_compiled_in_chunks(tmp_path, monkeypatch):
 
 
 @pytest.mark.gpu
-def test_chunked_kernels_write_every_output(tmp_path):
+def test_chunked_kernels_write_every_output(tmp_path, monkeypatch):
     """The chunks of a large body on the device: every output of the single-instance host call equals the closed form (each chunk writes its own range of the
     same operand; a chunk that is not launched leaves its range unwritten)."""
     import numpy as np
+    monkeypatch.delenv("UNGAR_AMD_COMPILE_ONLY", raising=False)  # (this module's other tests stop after publishing the entry)
     lib, fn, info, n = _make_wide(tmp_path)
     lib.ungar_function_eval_host.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
     rng = np.random.default_rng(3)

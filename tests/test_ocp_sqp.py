@@ -333,6 +333,64 @@ def test_device_riccati_equals_the_dense_kkt_solve(nx, nu, N, batch):
 
 
 @gpu
+@pytest.mark.parametrize("nx,nu,N,batch", [(10, 3, 25, 130), (20, 9, 12, 67), (31, 30, 6, 9), (23, 17, 7, 33)])
+def test_register_resident_riccati_for_sizes_the_library_was_not_compiled_for(nx, nu, N, batch, tmp_path, monkeypatch):
+    """The reference's optimiser takes ANY problem (optimization/concepts.hpp:153-262); the register-resident recursion is a template over the stage sizes.  For sizes
+    that are not compiled into the library the kernel factory instantiates it at run time (hipcc --genco, cached under the code-generation folder, occupancy picked
+    from the compiled candidates): the route is reported as 2, the steps equal the dense KKT solve, the dynamics of the QP hold on the whole batch, and a second
+    request finds the entry in the cache folder."""
+    import ctypes
+    import torch
+    import ungar_amd
+    from ungar_amd import sqp
+    monkeypatch.setenv("UNGAR_CODEGEN_FOLDER", str(tmp_path))
+    lib = ungar_amd.load_library()
+    lib.ungar_ocp_riccati_route.argtypes = [ctypes.c_int64] * 3 + [ctypes.c_int32]
+    assert lib.ungar_ocp_riccati_route(nx, nu, 0, 1) == 2, lib.ungar_last_error()
+    entries = sorted(f for f in os.listdir(tmp_path / "ungar_amd_kernels") if f.startswith(f"riccati_wave_{nx}_{nu}_"))
+    assert any(f.endswith(".hsaco") for f in entries) and any(f.endswith(".meta") for f in entries), entries
+    waves, registers, scratch = (int(v) for v in open(tmp_path / "ungar_amd_kernels" / next(f for f in entries if f.endswith(".meta"))).read().split("\n")[1].split()[1:4])
+    assert waves in (1, 2, 4) and scratch == 0 and registers * waves <= 512, (waves, registers, scratch)
+    rng = np.random.default_rng(29)
+    q = random_qp(rng, nx, nu, N, batch)
+    dev = lambda a: torch.as_tensor(a, device="cuda")  # noqa: E731
+    dX, dU, st = sqp.riccati_solve(nx, nu, N, batch, dev(q["AB"]), dev(q["b"]), dev(q["W"]), dev(q["w"]), dev(q["dx0"]), dev(q["WN"]), dev(q["wN"]))
+    torch.cuda.synchronize()
+    assert (st == 0).all()
+    dX, dU = dX.cpu().numpy(), dU.cpu().numpy()
+    for i in sorted({0, batch // 2, batch - 1}):
+        rX, rU = kkt_dense(nx, nu, N, q["AB"][i], q["b"][i], q["Wfull"][i], q["w"][i], q["dx0"][i], 1e-6, q["WN"][i], q["wN"][i])
+        assert np.abs(dX[i] - rX).max() <= 1e-9 * max(1.0, np.abs(rX).max()) and np.abs(dU[i] - rU).max() <= 1e-9 * max(1.0, np.abs(rU).max())
+    res = dX[:, 1:] - np.einsum("bkij,bkj->bki", q["AB"], np.concatenate((dX[:, :-1], dU), axis=2)) - q["b"]
+    assert np.abs(res).max() <= 1e-9 * max(1.0, np.abs(dX).max())
+
+
+def test_kernel_factory_builds_and_caches_without_a_gpu(tmp_path, monkeypatch):
+    """The kernel factory on a build host (UNGAR_AMD_COMPILE_ONLY: hipcc cross-compiles gfx950 without a device): a miss compiles the occupancy candidates side by
+    side and publishes {meta, code object}; the second request is a hit; sizes the template does not fit, or that the LDS-resident kernels serve better, are
+    answered without compiling anything."""
+    import ctypes
+    import ungar_amd
+    monkeypatch.setenv("UNGAR_CODEGEN_FOLDER", str(tmp_path))
+    monkeypatch.setenv("UNGAR_AMD_COMPILE_ONLY", "1")
+    lib = ungar_amd.load_library()
+    lib.ungar_ocp_riccati_route.argtypes = [ctypes.c_int64] * 3 + [ctypes.c_int32]
+    lib.ungar_shooting_assemble_route.argtypes = [ctypes.c_int64] * 4 + [ctypes.c_int32]
+    assert lib.ungar_ocp_riccati_route(37, 12, 0, 1) == 1 and lib.ungar_ocp_riccati_route(6, 2, 0, 1) == 0 and lib.ungar_ocp_riccati_route(40, 30, 0, 1) == 0
+    assert lib.ungar_ocp_riccati_route(13, 4, 3, 1) == 0  # equality rows inside the recursion: the LDS-resident kernels
+    assert not os.path.exists(tmp_path / "ungar_amd_kernels")
+    assert lib.ungar_ocp_riccati_route(11, 5, 0, 1) == 2, lib.ungar_last_error()
+    first = sorted(os.listdir(tmp_path / "ungar_amd_kernels"))
+    assert sum(f.endswith(".hsaco") for f in first) == 1 and not any(".tmp" in f for f in first), first
+    stamp = os.path.getmtime(tmp_path / "ungar_amd_kernels" / next(f for f in first if f.endswith(".hsaco")))
+    assert lib.ungar_ocp_riccati_route(11, 5, 0, 1) == 2
+    assert sorted(os.listdir(tmp_path / "ungar_amd_kernels")) == first and os.path.getmtime(tmp_path / "ungar_amd_kernels" / next(f for f in first if f.endswith(".hsaco"))) == stamp
+    assert lib.ungar_shooting_assemble_route(25, 24, 16, 12, 1) == 1 and lib.ungar_shooting_assemble_route(17, 4, 0, 8, 1) == 3 and lib.ungar_shooting_assemble_route(60, 30, 4, 0, 1) == 0
+    assert lib.ungar_shooting_assemble_route(9, 4, 3, 2, 1) == 2, lib.ungar_last_error()
+    assert any(f.startswith("shooting_assemble_wave_9_4_3_") and f.endswith(".hsaco") for f in os.listdir(tmp_path / "ungar_amd_kernels"))
+
+
+@gpu
 @pytest.mark.parametrize("nx,nu,N", [(37, 12, 20), (25, 24, 30), (13, 24, 30), (17, 4, 30), (13, 4, 30)])
 def test_register_resident_riccati_kernels_agree_with_the_lds_resident_ones(nx, nu, N, monkeypatch, measurement_library):
     """The large blocks take the one-wavefront-per-instance kernels of ocp_riccati_wave.hip by default (every matrix of the recursion in registers, products

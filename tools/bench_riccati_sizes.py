@@ -15,9 +15,14 @@ import ungar_amd  # noqa: E402
 from ungar_amd.sqp import riccati_solve  # noqa: E402
 
 PHASES = ("-", "operands", "P[A|B]", "H", "factor+gains", "cost-to-go", "-", "forward pass")
-SIZES = [(37, 12, 20), (25, 24, 30), (13, 24, 30), (17, 4, 30), (13, 4, 30), (8, 2, 30), (6, 2, 30)]
+SIZES = [(37, 12, 20), (25, 24, 30), (13, 24, 30), (17, 4, 30), (13, 4, 30), (8, 2, 30), (6, 2, 30),
+         (10, 3, 30), (20, 9, 30), (31, 30, 20)]  # the last three: sizes the library is not compiled for -- register-resident kernels from the kernel factory
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-only = sys.argv[2:]  # e.g. 37x12
+only = sys.argv[2:]  # e.g. 37x12; a size that is not in the list (e.g. 12x5) is added with N = 30
+for item in only:
+    nx_, nu_ = (int(v) for v in item.split("x"))
+    if not any((nx_, nu_) == (a, b_) for a, b_, _ in SIZES):
+        SIZES.append((nx_, nu_, 30))
 lib = ungar_amd.load_library()
 clocks = hasattr(lib, "ungar_amd_debug_riccati_clocks")
 buf = (ctypes.c_ulonglong * 8)()
@@ -48,7 +53,9 @@ for nx, nu, N in SIZES:
         torch.cuda.synchronize()
         times.append(e0.elapsed_time(e1))
     assert int(out[2].abs().max()) == 0 or os.environ.get("UNGAR_BENCH_NO_STATUS_CHECK")  # (timing-only library variants compute garbage)
-    line = {"nx": nx, "nu": nu, "N": N, "batch": batch, "ms_median": sorted(times)[len(times) // 2], "ms_min": min(times)}
+    lib.ungar_ocp_riccati_route.argtypes = [ctypes.c_int64] * 3 + [ctypes.c_int32]
+    route = {0: "LDS-resident", 1: "register-resident (compiled in)", 2: "register-resident (kernel factory)"}[lib.ungar_ocp_riccati_route(nx, nu, 0, 0)]
+    line = {"nx": nx, "nu": nu, "N": N, "batch": batch, "route": route, "ms_median": sorted(times)[len(times) // 2], "ms_min": min(times)}
     flops = N * (2 * nx * nx * n + 2 * nx * n * (n + 1) / 2 + nu ** 3 / 3 + 2 * nu * nu * (nx + 1) + 2 * nx * nx * nu)  # per instance: P[A|B], H (upper), Cholesky, solves, cost-to-go
     byts = 8 * N * (nx * n + n * (n + 1) / 2 + n + nx + 2 * nu * (nx + 1) + 2 * n)  # operands once, gains out and back, steps out
     line["GFLOP_per_s"] = batch * flops / (line["ms_min"] * 1e-3) / 1e9

@@ -107,7 +107,7 @@ def build_library(jobs: int | None = None):
         if name.endswith(".hip") and not name.startswith("model_"):
             src = os.path.join(CSRC, "kernels", name)
             sqp_hdrs = [os.path.join(CSRC, "kernels", h) for h in ("ocp_sqp.hpp", "ocp_riccati.hpp", "ocp_barrier.hpp", "ocp_shooting.hpp")]
-            extra = (sqp_hdrs if name.startswith(("ocp_riccati", "ocp_shooting")) else
+            extra = (sqp_hdrs + [os.path.join(CSRC, "kernels", "ocp_riccati_wave_kernel.hpp"), os.path.join(CSRC, "runtime", "kernel_jit.hpp")] if name.startswith(("ocp_riccati", "ocp_shooting")) else
                      [os.path.join(CSRC, "kernels", "ocp_assembly.hpp")] if name.startswith("ocp_assembly") else
                      quad_deps if name.startswith("quad_") else
                      [os.path.join(GEN, f"{name[5:-4]}_cost_gen.hpp"), os.path.join(CSRC, "kernels", "cost_kernel.hpp")] if name.startswith("cost_") else [])
@@ -117,7 +117,9 @@ def build_library(jobs: int | None = None):
     src = os.path.join(CSRC, "runtime", "c_api_sqp.cpp")
     units.append((src, os.path.join(BUILD, "c_api_sqp.o"), [src, abi_hdr] + [os.path.join(CSRC, "kernels", h) for h in ("ocp_sqp.hpp", "ocp_riccati.hpp", "ocp_shooting.hpp")]))
     src = os.path.join(CSRC, "runtime", "function.cpp")
-    units.append((src, os.path.join(BUILD, "function.o"), [src, abi_hdr] + _tree(os.path.join(CSRC, "tape"))))
+    units.append((src, os.path.join(BUILD, "function.o"), [src, abi_hdr, os.path.join(CSRC, "runtime", "jit_common.hpp")] + _tree(os.path.join(CSRC, "tape"))))
+    src = os.path.join(CSRC, "runtime", "kernel_jit.cpp")
+    units.append((src, os.path.join(BUILD, "kernel_jit.o"), [src, abi_hdr, os.path.join(CSRC, "runtime", "jit_common.hpp"), os.path.join(CSRC, "runtime", "kernel_jit.hpp")]))
 
     measurement_hdr = os.path.join(CSRC, "runtime", "measurement.hpp")
     units = [(s_, o_, d_ + [measurement_hdr]) for s_, o_, d_ in units]

@@ -142,6 +142,7 @@ struct ShootingSelectArgs {
 }  // namespace ungar_amd::kernels
 
 extern "C" int ungar_amd_launch_shooting_assemble(const ungar_amd::kernels::ShootingAssembleArgs* a, void* stream);
+extern "C" int ungar_amd_shooting_assemble_route(int nz, int nu, int ne, int nh, int prepare);  // ocp_shooting.hip
 extern "C" int ungar_amd_launch_shooting_recover(const ungar_amd::kernels::ShootingRecoverArgs* a, void* stream);
 extern "C" int ungar_amd_launch_shooting_refresh_carried_inputs(const ungar_amd::kernels::ShootingDims* d, double* rows, void* stream);
 extern "C" int ungar_amd_launch_shooting_merit(const ungar_amd::kernels::ShootingMeritArgs* a, void* stream);

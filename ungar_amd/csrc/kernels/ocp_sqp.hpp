@@ -88,6 +88,7 @@ struct StageQpArgs {
 
 extern "C" int ungar_amd_launch_ocp_stage_qp(const ungar_amd::kernels::StageQpArgs* a, void* stream);
 extern "C" int ungar_amd_launch_riccati(const ungar_amd::kernels::RiccatiArgs* a, void* stream);
+extern "C" int ungar_amd_riccati_route(int nx, int nu, int ne, int prepare);  // ocp_riccati_wave.hip: 0 LDS-resident, 1 register-resident (compiled in), 2 register-resident (kernel factory)
 extern "C" int ungar_amd_launch_ocp_merit(const ungar_amd::kernels::MeritArgs* a, void* stream);
 extern "C" int ungar_amd_launch_ocp_trial(const ungar_amd::kernels::TrialArgs* a, void* stream);
 extern "C" int ungar_amd_launch_ocp_accept(const ungar_amd::kernels::AcceptArgs* a, void* stream);

@@ -96,6 +96,11 @@ int64_t ungar_ocp_riccati_workspace(int64_t nx, int64_t nu, int64_t horizon, int
     return batch * horizon * nu * (nx + 1);
 }
 
+int ungar_ocp_riccati_route(int64_t nx, int64_t nu, int64_t ne, int32_t prepare) {
+    if (nx < 1 || nu < 1 || ne < 0 || nx + nu > 256) return 0;
+    return ungar_amd_riccati_route(static_cast<int>(nx), static_cast<int>(nu), static_cast<int>(ne), prepare);
+}
+
 int ungar_ocp_riccati_solve(const ungar_ocp_qp* q, void* stream) {
     if (!q || BadDims(q->nx, q->nu, q->horizon, q->batch)) return Fail(UNGAR_E_INVALID, "ungar_ocp_riccati_solve: bad dimensions");
     if (q->batch == 0) return UNGAR_OK;
@@ -223,6 +228,11 @@ int ungar_shooting_assemble(const ungar_shooting_assemble_args* a, void* stream)
     k.pivots = a->eq_pivots;
     if (k.eliminate && (!a->eq || !a->eq_reduced || !a->eq_pivots)) return Fail(UNGAR_E_INVALID, "ungar_shooting_assemble: eliminating the equality rows needs eq, eq_reduced and eq_pivots");
     return Launched(ungar_amd_launch_shooting_assemble(&k, stream), "ungar_shooting_assemble");
+}
+
+int ungar_shooting_assemble_route(int64_t nz, int64_t nu, int64_t ne, int64_t nh, int32_t prepare) {
+    if (nz < 1 || nu < 1 || ne < 0 || nh < 0 || nz + nu > 256 || ne > 64) return 0;
+    return ungar_amd_shooting_assemble_route(static_cast<int>(nz), static_cast<int>(nu), static_cast<int>(ne), static_cast<int>(nh), prepare);
 }
 
 int ungar_shooting_recover_inputs(const ungar_shooting_dims* dims, int64_t ne, const double* E, const double* eq_reduced, const int32_t* eq_pivots, const double* dZ, double* dU,

@@ -34,6 +34,7 @@
 
 #include "../../../include/ungar_amd.h"
 #include "../tape/emit.hpp"
+#include "jit_common.hpp"
 
 namespace ungar_amd::runtime {
 int Fail(int code, const std::string& msg);  // c_api.cpp
@@ -74,39 +75,10 @@ struct ungar_function {
 namespace {
 
 using runtime::Fail;
+using namespace runtime::jit;
 
 constexpr uint32_t kEnableJacobian = 1U << 1;  // EnabledDerivatives::JACOBIAN, autodiff/data_types.hpp:95-100
 constexpr uint32_t kEnableHessian = 1U << 2;   // EnabledDerivatives::HESSIAN
-
-std::uint64_t Fnv1a(const void* data, std::size_t n, std::uint64_t h) {
-    const unsigned char* p = static_cast<const unsigned char*>(data);
-    for (std::size_t i = 0; i < n; ++i) {
-        h ^= p[i];
-        h *= 1099511628211ULL;
-    }
-    return h;
-}
-
-/// 128-bit content key: two FNV-1a lanes with different offsets (the second lane also sees the running first lane).
-struct KeyHasher {
-    std::uint64_t a = 1469598103934665603ULL, b = 0x9E3779B97F4A7C15ULL;
-    void Bytes(const void* data, std::size_t n) {
-        a = Fnv1a(data, n, a);
-        b = Fnv1a(data, n, b ^ (a >> 7));
-    }
-    void Str(const std::string& s) {
-        Bytes(s.data(), s.size());
-        Int(static_cast<long long>(s.size()));
-    }
-    void Int(long long v) {
-        Bytes(&v, sizeof v);
-    }
-    std::string Hex() const {
-        char buf[40];
-        std::snprintf(buf, sizeof buf, "%016llx%016llx", static_cast<unsigned long long>(a), static_cast<unsigned long long>(b));
-        return buf;
-    }
-};
 
 // Everything that decides what a cache entry contains, besides the tape itself.  UNGAR_AMD_EMITTER_ID is a hash of the
 // tape engine's sources (csrc/tape/*.hpp, this file) injected by the build (ungar_amd/_build.py): editing the derivative
@@ -115,7 +87,6 @@ struct KeyHasher {
 #define UNGAR_AMD_EMITTER_ID "unversioned"
 #endif
 constexpr const char* kCacheFormat = "ungar_amd-cache-5";  // bump whenever the emitted kernels' argument list (their ABI) or the meta file changes: 3 = ten-argument kernels (knot stride, direct host results), 4 = consecutive outputs leave in 16-byte stores, 5 = a derivative may consist of several kernels (chunks of consecutive outputs; unit tags "jacobian.3")
-constexpr const char* kArch = "gfx950";
 constexpr std::size_t kBigKernel = 3000;        // statements above which the machine schedulers are switched off (see below)
 // Statements above which a derivative is cut into chunks of consecutive outputs, one kernel and one compiler process each: the compile time of
 // a straight-line body grows faster than its length (the equality-constraint Jacobian of the reference's quadruped OCP, 14 167 outputs in one
@@ -123,42 +94,6 @@ constexpr std::size_t kBigKernel = 3000;        // statements above which the ma
 constexpr std::size_t kChunkStatements = 6000;
 constexpr std::size_t kMaxChunks = 64;
 constexpr int64_t kDirectHostResults = 512;  // single-instance host calls: results up to this many doubles are written straight into mapped host memory
-
-std::string ShellQuote(const std::string& s) {
-    std::string q = "'";
-    for (char c : s) {
-        if (c == '\'') q += "'\\''";
-        else q += c;
-    }
-    return q + "'";
-}
-
-bool FileSize(const std::string& path, long long* size) {
-    struct stat st {};
-    if (stat(path.c_str(), &st) != 0) return false;
-    *size = static_cast<long long>(st.st_size);
-    return true;
-}
-
-/// Identity of the toolchain that compiles the kernels: the ROCm release file, else the compiler's own banner.  (NOT
-/// hipRuntimeGetVersion: a process that has PyTorch loaded resolves the HIP runtime to torch's bundled copy, so two
-/// processes on one machine would disagree about the key of the same function.)
-const std::string& ToolchainVersion() {
-    static const std::string version = [] {
-        const char* root = std::getenv("ROCM_PATH");
-        std::ifstream f(std::string(root && *root ? root : "/opt/rocm") + "/.info/version");
-        std::string v;
-        if (f && std::getline(f, v) && !v.empty()) return "rocm-" + v;
-        const char* hipcc = std::getenv("UNGAR_HIPCC");
-        if (FILE* p = popen((std::string(hipcc ? hipcc : "hipcc") + " --version 2>/dev/null").c_str(), "r")) {
-            char buf[256];
-            while (fgets(buf, sizeof buf, p)) v += buf;
-            (void)pclose(p);
-        }
-        return v.empty() ? std::string("unknown-toolchain") : v;
-    }();
-    return version;
-}
 
 /// What a cache entry records besides the code objects: enough to serve every query and launch without the tape.
 struct CacheMeta {
@@ -220,24 +155,6 @@ struct CacheMeta {
         return true;
     }
 };
-
-bool MakeDirs(const std::string& path) {
-    std::string cur;
-    for (std::size_t i = 0; i <= path.size(); ++i) {
-        if (i == path.size() || path[i] == '/') {
-            if (!cur.empty() && mkdir(cur.c_str(), 0777) != 0 && errno != EEXIST) return false;
-        }
-        if (i < path.size()) cur += path[i];
-    }
-    return true;
-}
-
-std::string DefaultFolder() {
-    // reference: UNGAR_CODEGEN_FOLDER else $TMPDIR/ungar_codegen (data_types.hpp:39-41)
-    if (const char* e = std::getenv("UNGAR_CODEGEN_FOLDER")) return e;
-    const char* tmp = std::getenv("TMPDIR");
-    return std::string(tmp ? tmp : "/tmp") + "/ungar_codegen";
-}
 
 /// Emits one `extern "C" __global__` kernel: lane = instance, strided operands.
 /// UNGAR_AMD_SCALAR_STORES=1 (part of the cache key): every output as its own 8-byte store -- for a platform whose compute queues are not in the unaligned access mode.

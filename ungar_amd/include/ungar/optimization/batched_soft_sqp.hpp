@@ -85,6 +85,10 @@ class BatchedSoftSQPOptimizer {
     }
 
     const ShootingProblem& Problem() const { return _p; }
+    /// Kernels the QP step of this problem runs (ungar_ocp_riccati_route / ungar_shooting_assemble_route: 0 run-time-size kernels, 1 compiled into the library,
+    /// 2 instantiated for this problem's sizes by the kernel factory, 3 run-time-size one-wavefront assembly).
+    int RiccatiRoute() const { return _riccatiRoute; }
+    int AssembleRoute() const { return _assembleRoute; }
     index_t Batch() const { return _batch; }
     index_t RowSize() const { return _p.RowSize(); }
     /// Doubles of the host image of all node rows: batch x (horizon + 1) x RowSize(), row (b, k) at ((b (N + 1)) + k) RowSize().
@@ -417,6 +421,10 @@ class BatchedSoftSQPOptimizer {
         const index_t N = _p.horizon, B = _batch, nv = _p.RowSize(), nx = _p.stateSize, nu = _p.inputSize, nz = Nz(), nd = nz + nu;
         const index_t K = static_cast<index_t>(_alphas.size()) < kStacked ? static_cast<index_t>(_alphas.size()) : kStacked;  // candidates evaluated at once
         _stackedCapacity = K;
+        // the QP kernels of this problem's stage sizes: the register-resident Riccati recursion and the one-wavefront assembly kernel are compiled into the library
+        // for the reference's own problems and instantiated by the kernel factory for any other size they fit -- here, once, not inside the first iteration
+        _assembleRoute = ungar_shooting_assemble_route(nz, nu, _eliminateEqualities ? Ne() : 0, Nh(), 1);
+        _riccatiRoute = ungar_ocp_riccati_route(nz, nu, _eliminateEqualities ? 0 : Ne(), 1);
         const index_t nodes = B * (N + 1), stacked = K * nodes;
         _pf = UploadPattern(*_p.dynamics, false);
         if (_p.carry) _pc = UploadPattern(*_p.carry, false);
@@ -533,6 +541,7 @@ class BatchedSoftSQPOptimizer {
     real_t* _er = nullptr;
     int32_t *_status = nullptr, *_active = nullptr, *_pivots = nullptr;
     bool _eliminateEqualities = true;
+    int _assembleRoute = 0, _riccatiRoute = 0;  // ungar_shooting_assemble_route / ungar_ocp_riccati_route of this problem
     index_t _stackedCapacity = 0;  // trial points per instance the stacked buffers were allocated for
     std::vector<index_t> _stages{2};  // ({2, 4} measured: no gain -- quadrotor 1.22 -> 1.27 ms, RC car 0.84 -> 0.86: who needs less than 1/2 mostly needs much less)
     int32_t *_listA = nullptr, *_listB = nullptr;  // instances a stage of the line search left unresolved (read / written alternately)
