@@ -321,12 +321,90 @@ def sqp_iterations(batch=4096, timeout=420):
             if r.returncode == 0 and m:
                 ms = float(m.group(1))
                 out[problem] = {"ms_per_iteration": ms, "instances": int(m.group(2)), "instances_per_s": int(m.group(2)) / ms * 1e3, "wall_s_including_jit": time.perf_counter() - t0,
-                                "kernel_split": f"profiles/r04o_batched_{problem}_kernel_stats.csv" if problem != "rc_car" else "profiles/r04l_batched_rc_car_kernel_stats.csv"}
+                                "kernel_split": f"profiles/r05c_batched_{problem}_kernel_stats.csv"}
+                try:
+                    out[problem]["cpu_baseline"] = sqp_cpu_stand_in(problem)
+                except Exception as e:  # noqa: BLE001 -- the stand-in must never cost the GPU figure
+                    out[problem]["cpu_baseline"] = {"failed": repr(e)[:300]}
             else:
                 out[problem] = {"failed": (r.stdout + r.stderr)[-400:]}
         except subprocess.TimeoutExpired:
             out[problem] = {"failed": f"timeout after {timeout} s"}
     return out
+
+
+def sqp_cpu_stand_in(problem, seconds=3.0):
+    """A CPU figure beside `sqp_iterations`: one soft-SQP iteration of ONE instance on one host core -- the reference's execution model (one instance, one thread,
+    soft_sqp.hpp:143-158) -- composed of its three dominant parts, each timed here on the box's host:
+      N stage Jacobians      the oracle's tape-generated C for the node dynamics (single-instance calls, as in `cpu_baseline`);
+      the QP                 the Riccati recursion of the batched SQP compiled for the host (oracle/build_oracle.py: build_qp_host; stage equality rows inside the recursion
+                             for the quadruped) -- an EXACT structure-exploiting solve where the reference runs OSQP's ADMM iterations on the whole-horizon KKT system;
+      2 x N stage values     the first line-search stage (two candidate steps; the reference evaluates candidates one by one until one is accepted).
+    Cost / barrier terms and the assembly of the QP data are left out (quadratic forms: small next to the parts above), so the figure is a LOWER bound of the port's time.
+    kind "port": none of this is the reference's own code (CppADCodeGen C + OSQP are absent from the image)."""
+    from oracle import build_oracle
+    from oracle import ungar_oracle as O
+    model, nz, nu, ne, N = {"quadrotor": ("quadrotor", 17, 4, 0, 30), "rc_car": ("rc_car", 8, 2, 0, 30), "quadruped": ("srbd", 25, 24, 16, 30)}[problem]
+    lib = ctypes.CDLL(build_oracle.build("portable"))
+    nx, nu_m, nw, _ = O.DIMS[model]
+    sample = 512
+    x, u, w, p = O.synthetic_inputs(model, sample, seed=5)
+    w = w if nw else np.zeros((sample, 1))
+    dp = ctypes.POINTER(ctypes.c_double)
+    ptr = lambda a: a.ctypes.data_as(dp)  # noqa: E731
+    nnz = ctypes.c_int.in_dll(lib, f"{model}_jac_nnz").value
+    fo, jo = np.zeros((sample, nx)), np.zeros((sample, nnz))
+
+    def rate(fn, args):
+        fn.restype = None
+        t0 = time.perf_counter()
+        fn(*args, 0, sample, 1)
+        reps = max(1, int(seconds / 3 / max(time.perf_counter() - t0, 1e-6)))
+        t0 = time.perf_counter()
+        fn(*args, 0, sample, reps)
+        return sample * reps / (time.perf_counter() - t0)
+
+    jac = getattr(lib, f"{model}_sparse_jacobian_batch")
+    jac.argtypes = [dp] * 6 + [ctypes.c_long] * 3
+    val = getattr(lib, f"{model}_forward_zero_batch")
+    val.argtypes = [dp] * 5 + [ctypes.c_long] * 3
+    jac_rate, val_rate = rate(jac, (ptr(x), ptr(u), ptr(w), ptr(p), ptr(fo), ptr(jo))), rate(val, (ptr(x), ptr(u), ptr(w), ptr(p), ptr(fo)))
+    # the QP of one instance: random well-posed data of the problem's stage sizes
+    qp = ctypes.CDLL(build_oracle.build_qp_host())
+    rng = np.random.default_rng(5)
+    batch, n = 16, nz + nu
+    AB = 0.3 * rng.standard_normal((batch, N, nz, n))
+    AB[:, :, :, :nz] += np.eye(nz)
+    L = rng.standard_normal((batch, N, n, n))
+    W = np.ascontiguousarray(np.triu(0.1 * L @ L.transpose(0, 1, 3, 2) + np.eye(n)))
+    LN = rng.standard_normal((batch, nz, nz))
+    WN = np.ascontiguousarray(np.triu(LN @ LN.transpose(0, 2, 1) + np.eye(nz)))
+    b, wv, wN, dx0 = 0.1 * rng.standard_normal((batch, N, nz)), rng.standard_normal((batch, N, n)), rng.standard_normal((batch, nz)), rng.standard_normal((batch, nz))
+    dX, dU, st = np.zeros((batch, N + 1, nz)), np.zeros((batch, N, nu)), np.zeros(batch, dtype=np.int32)
+    ip = st.ctypes.data_as(ctypes.POINTER(ctypes.c_int))
+    if ne:
+        E = np.zeros((batch, N, ne, n))
+        E[:, :, np.arange(ne), nz + np.arange(ne)] = 1.0  # every row pins one input
+        E[:, :, :, :nz] = 0.1 * rng.standard_normal((batch, N, ne, nz))
+        ev = 0.1 * rng.standard_normal((batch, N + 1, ne))
+        call = lambda: qp.riccati_host_solve_eq(0, nz, nu, ne, N, ctypes.c_longlong(batch), ptr(AB), ptr(b), ptr(W), ptr(wv), ptr(WN), 0, ptr(wN), ptr(dx0), ptr(E), ptr(ev),  # noqa: E731
+                                                ctypes.c_double(1e-6), ptr(dX), ptr(dU), ip)
+    else:
+        call = lambda: qp.riccati_host_solve(nz, nu, N, ctypes.c_longlong(batch), ptr(AB), ptr(b), ptr(W), ptr(wv), ptr(WN), ptr(wN), ptr(dx0), ctypes.c_double(1e-6), ptr(dX),  # noqa: E731
+                                             ptr(dU), ip)
+    call()
+    t0, solves = time.perf_counter(), 0
+    while time.perf_counter() - t0 < seconds / 3:
+        call()
+        solves += batch
+    qp_s = (time.perf_counter() - t0) / solves
+    per_instance = N / jac_rate + qp_s + 2 * N / val_rate
+    cores = min(64, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    return {"ms_per_iteration_of_one_instance": per_instance * 1e3, "instances_per_s": 1.0 / per_instance, "cores": 1, "kind": "port",
+            "all_cores_estimate": {"instances_per_s": cores / per_instance, "cores": cores, "note": "instances are independent: one per core, no shared state"},
+            "parts_ms": {"stage_jacobians": N / jac_rate * 1e3, "qp_solve": qp_s * 1e3, "line_search_values": 2 * N / val_rate * 1e3},
+            "sample": f"{model} node C (gcc, portable flags) over {sample} seeded nodes; host Riccati {nz} + {nu}" + (f", {ne} equality rows" if ne else "") + f", N = {N}, {solves} solves; "
+                      "cost / barrier / assembly not included (lower bound); the reference's own CppADCodeGen C + OSQP are absent from the image"}
 
 
 def facade_single_instance_latency(timeout=300):

@@ -199,6 +199,48 @@ def quadruped_whole_horizon(z, par, N=30):
     return value, torch.cat(rows)
 
 
+def quadruped_whole_horizon_inequalities(z, par, N=30):
+    """The 360 inequality rows h <= 0 of the reference's quadruped OCP, whole horizon (example/mpc/quadruped.example.cpp:312-338): per knot k < N and leg i
+    [-s f_z, s |f_xy|~ - mu f_z, s |r - hip_i|~ - leg_length] with s the REFERENCE contact state of (k, i) and |.|~ Utils::ApproximateNorm.  Same layouts as
+    quadruped_whole_horizon."""
+    nx, nu, npk = 13, 24, 29
+    U = z[(N + 1) * nx:].reshape(N, nu)
+    P = par[:(N + 1) * npk].reshape(N + 1, npk)
+    rho = par[(N + 1) * npk:]
+    hips, leg_length, mu = rho[5:17].reshape(4, 3), rho[17], rho[19]
+    rows = []
+    for k in range(N):
+        for i in range(4):
+            s = P[k, 13 + 4 * i]
+            f, r = U[k, 6 * i:6 * i + 3], U[k, 6 * i + 3:6 * i + 6]
+            rows += [-s * f[2], s * approximate_norm(f[:2]) - mu * f[2], s * approximate_norm(r - hips[i]) - leg_length]
+    return torch.stack(rows)
+
+
+def rc_car_whole_horizon(z, par, N=30):
+    """The reference's RC-car OCP AS WRITTEN, whole horizon (example/mpc/rc_car.example.cpp:191-285): objective value, the 186 equality rows
+    [x_0 - x_m; x_(k+1) - f(x_k, u_k)] and the 90 inequality rows [|d_k| - 15, |delta_k| - 15, 0.3 - v_x,k] as torch expressions of z = (X, U) (246) and
+    par = (15 car parameters, 31 reference positions, measured state) (83).  Layout :52-122: x = (position 2, yaw, body linear velocity 2, yaw rate), u = (duty cycle,
+    steering angle)."""
+    nx, nu = 6, 2
+    X = z[:(N + 1) * nx].reshape(N + 1, nx)
+    U = z[(N + 1) * nx:].reshape(N, nu)
+    car = par[:15]
+    ref = par[15:15 + 2 * (N + 1)].reshape(N + 1, 2)
+    xm = par[15 + 2 * (N + 1):15 + 2 * (N + 1) + nx]
+    value = torch.zeros((), dtype=torch.float64)
+    for k in range(N):  # :204-222
+        value = value + ((X[k, 0:2] - ref[k]) ** 2).sum() + 1e-6 * (U[k] ** 2).sum()
+        if k:
+            value = value + 1e-6 * ((U[k] - U[k - 1]) ** 2).sum()
+    value = value + ((X[N, 0:2] - ref[N]) ** 2).sum()  # :224-226
+    eq = [X[0] - xm] + [X[k + 1] - rc_car_node(X[k], U[k], None, car) for k in range(N)]  # :243-263
+    ineq = []
+    for k in range(N):  # :271-282
+        ineq += [torch.abs(U[k, 0]) - 15.0, torch.abs(U[k, 1]) - 15.0, 0.3 - X[k, 3]]
+    return value, torch.cat(eq), torch.stack(ineq)
+
+
 # ----------------------------------------------------------------------------- rigid-body model
 def _rpy(r, p, y):
     cr, sr, cp, sp, cy, sy = math.cos(r), math.sin(r), math.cos(p), math.sin(p), math.cos(y), math.sin(y)

@@ -331,6 +331,9 @@ int main(int argc, char** argv) {
             sparse("OBJ_JAC", nlp.objective.Jacobian(in));
             vector("EQ", nlp.equalityConstraints(in));
             sparse("EQ_JAC", nlp.equalityConstraints.Jacobian(in));
+            sparse("OBJ_HES", nlp.objective.Hessian(in));
+            vector("INEQ", nlp.inequalityConstraints(in));
+            sparse("INEQ_JAC", nlp.inequalityConstraints.Jacobian(in));
             std::printf("DUMPED %s\n", dumpFolder.c_str());
             return 0;
         }

@@ -7,6 +7,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <fstream>
 #include <cstdlib>
 #include <random>
 #include <string>
@@ -230,6 +231,31 @@ int main(int argc, char** argv) {
             instances.push_back(v_.Get());
         }
 
+        if (compared < 0) {  // `batched_rc_car_test <folder> <batch> -1 <file>`: dump the whole-horizon functions of the OCP as written at instance 3 (a car at the minimum-velocity bound) for tests/test_whole_horizon.py
+            const std::string file = argc > 4 ? argv[4] : "";
+            const VectorXr& in = instances[static_cast<std::size_t>(batch > 3 ? 3 : 0)];
+            std::ofstream out(file);
+            out.precision(17);
+            auto vector = [&](const char* tag, const VectorXr& v) {
+                out << tag << " " << v.size() << "\n";
+                for (index_t i = 0; i < v.size(); ++i) out << v[i] << "\n";
+            };
+            auto sparse = [&](const char* tag, const Autodiff::SparseMatrix& A) {
+                out << tag << " " << A.rows() << " " << A.cols() << " " << A.nonZeros() << "\n";
+                for (index_t r = 0; r < A.rows(); ++r)
+                    for (int k = A.outerIndexPtr()[r]; k < A.outerIndexPtr()[r + 1]; ++k) out << r << " " << A.innerIndexPtr()[k] << " " << A.valuePtr()[k] << "\n";
+            };
+            vector("INPUT", in);
+            vector("OBJ", nlp.objective(in));
+            sparse("OBJ_JAC", nlp.objective.Jacobian(in));
+            sparse("OBJ_HES", nlp.objective.Hessian(in));
+            vector("EQ", nlp.equalityConstraints(in));
+            sparse("EQ_JAC", nlp.equalityConstraints.Jacobian(in));
+            vector("INEQ", nlp.inequalityConstraints(in));
+            sparse("INEQ_JAC", nlp.inequalityConstraints.Jacobian(in));
+            std::printf("DUMPED %s\n", file.c_str());
+            return 0;
+        }
         // ---- node rows
         const index_t nx = x.Size(), nu = u.Size(), nz = nx + nu, dec = decision_variables.Size();
         std::vector<real_t> rows(static_cast<std::size_t>(batched.RowsSize())), xm(static_cast<std::size_t>(batch * nx));

@@ -23,9 +23,12 @@ def clib(repo_root):
     return ctypes.CDLL(path)
 
 
-@pytest.mark.parametrize("name,fixture", [(m, None) for m in MODELS] + [("anymal", "node_anymal_256.npz"), ("anymal_ad", "node_anymal_256.npz")])
+@pytest.mark.parametrize("name,fixture", [(m, None) for m in MODELS] + [("anymal", "node_anymal_256.npz"), ("anymal_ad", "node_anymal_256.npz")] +
+                         [("quadrotor", "node_quadrotor_edge.npz"), ("rc_car", "node_rc_car_edge.npz"), ("anymal", "node_anymal_edge.npz"), ("anymal_ad", "node_anymal_edge.npz")])
 def test_generated_c_matches_golden(repo_root, clib, name, fixture):
-    """(node_anymal_256.npz: 256 nodes of the headline model from the independent torch oracle, tests/golden/make_anymal_many.py -- the C checker that the
+    """(node_*_edge.npz: nodes ON the edge cases of the reference's helpers -- omega+ = 0 exactly for ApproximateExponentialMap, stored quaternions of length 1.3 / 0.7,
+    v_x at the bounds with zero slip angles, the robot at rest: tests/golden/make_edge_cases.py.)
+    (node_anymal_256.npz: 256 nodes of the headline model from the independent torch oracle, tests/golden/make_anymal_many.py -- the C checker that the
     every-node GPU tests compare with is itself pinned at hundreds of nodes, for both the structured and the taped-ABA program)"""
     g = np.load(f"{repo_root}/tests/golden/{fixture or 'node_' + name.replace('_ad', '') + '.npz'}")
     dims = (ctypes.c_int * 4).in_dll(clib, f"{name}_dims")

@@ -64,6 +64,19 @@ def test_golden_vectors_256_anymal_nodes(ua, repo_root, name, layout, mode):
     _assert_close(name, f, J, g["f"], g["J"])
 
 
+@pytest.mark.parametrize("name", ["quadrotor", "rc_car", "anymal", "anymal_ad", "anymal_reg"])
+@pytest.mark.parametrize("layout,mode", [("soa", "dense"), ("aos", "sparse")])
+def test_golden_vectors_on_the_edge_cases_of_the_helpers(ua, repo_root, name, layout, mode):
+    """Nodes that sit ON the switching / degenerate points of the reference's helper functions (tests/golden/make_edge_cases.py, generated in the build container from
+    the independent torch oracle): body angular velocity and net torque exactly 0 so that Utils::ApproximateExponentialMap is evaluated at the zero vector
+    (utils.hpp:731-749; test/autodiff/function.test.cpp:40-58 pins that point for the bare helper only), stored quaternions of length 1.3 and 0.7 (the Lie-group
+    integrator does not normalise, quadrotor.example.cpp:184-187), the RC car at v_x = 0.5 / 0.3 with zero slip-angle arguments (rc_car.example.cpp:158-161), ANYmal at
+    rest with the joints at 0 -- through every kernel of the model."""
+    g = np.load(f"{repo_root}/tests/golden/node_{_oracle_name(name)}_edge.npz")
+    f, J = ua.NodeModel(name).evaluate_numpy(g["x"], g["u"], g["w"], g["p"], mode=mode, layout=layout)
+    _assert_close(name, f, J, g["f"], g["J"])
+
+
 @pytest.mark.parametrize("name", MODELS)
 def test_forward_zero_matches_golden(ua, repo_root, name):
     g = np.load(f"{repo_root}/tests/golden/node_{_oracle_name(name)}.npz")

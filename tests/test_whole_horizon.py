@@ -240,3 +240,75 @@ def test_quadruped_whole_horizon_functions_against_the_independent_oracle(quadru
                 assert np.any(J[row, (k - 1) * 13:k * 13] != 0) and np.any(J[row, k * 13:(k + 1) * 13] != 0)
                 coupled += 1
     assert coupled > 20
+
+
+def _check_function(dump, tag, value, jacobian, tol_value=1e-12, tol_jac=1e-10):
+    """Facade values / sparse Jacobian (dump[tag], dump[tag + "_JAC"]) against an oracle value vector and dense Jacobian: entries to tol_jac of the largest, and
+    every entry the oracle differentiates to non-zero present in the structural pattern."""
+    assert dump[tag].shape == value.shape
+    assert np.abs(dump[tag] - value).max() <= tol_value * max(1.0, np.abs(value).max())
+    J, mask = dump[tag + "_JAC"], dump[tag + "_JAC_MASK"]
+    assert J.shape == jacobian.shape
+    assert np.abs(J - jacobian).max() <= tol_jac * max(np.abs(jacobian).max(), 1e-300)
+    assert not (jacobian != 0)[~mask].any(), "an entry the oracle differentiates to non-zero is missing from the structural pattern"
+
+
+def test_quadruped_inequality_rows_and_objective_hessian_against_the_independent_oracle(quadruped_dump):
+    """The other half of the reference's quadruped OCP (quadruped.example.cpp:209-250, 306-338): the 360 inequality rows (unilateral force, friction cone and leg
+    reach through Utils::ApproximateNorm, switched by the reference contact state) with their 360 x 1123 Jacobian, and the UPPER-TRIANGULAR 1123 x 1123 Hessian of
+    the objective (quaternion `min` term included), through the facade's Ungar::Autodiff::Function on the GPU against torch autograd on
+    oracle.ungar_oracle -- a restatement that shares no code with the product."""
+    dump = quadruped_dump
+    dec = 1123
+    v = dump["INPUT"]
+    z, par = torch.tensor(v[:dec]), torch.tensor(v[dec:])
+    h = O.quadruped_whole_horizon_inequalities(z, par)
+    assert h.shape == (360,)
+    Jh = torch.autograd.functional.jacobian(lambda zz: O.quadruped_whole_horizon_inequalities(zz, par), z, vectorize=True).numpy()
+    _check_function(dump, "INEQ", h.numpy(), Jh)
+    swing = (np.abs(dump["INEQ_JAC"]).reshape(120, 3, dec).sum(axis=(1, 2)) == 0) | (np.abs(Jh).reshape(120, 3, dec)[:, 0].sum(axis=1) == 0)
+    assert swing.any() and (~swing).any()  # legs in swing (s = 0: the force rows vanish) and in stance both occur
+    H = torch.autograd.functional.hessian(lambda zz: O.quadruped_whole_horizon(zz, par)[0], z, vectorize=True).numpy()
+    Hd, Hm = dump["OBJ_HES"], dump["OBJ_HES_MASK"]
+    assert Hd.shape == (dec, dec)
+    assert not Hm[np.tril_indices(dec, -1)].any(), "Hessian must be upper-triangular only (function.hpp:232-235)"
+    assert np.abs(Hd - np.triu(H)).max() <= 1e-12 * np.abs(H).max()
+    assert not (np.triu(H) != 0)[~Hm].any()
+
+
+@pytest.fixture(scope="module")
+def rc_car_dump(repo_root, tmp_path_factory, shared_codegen):
+    exe = os.path.join(repo_root, "build", "batched_rc_car_test")
+    assert os.path.exists(exe), "build/batched_rc_car_test missing: run __graft_entry__.build()"
+    d = tmp_path_factory.mktemp("rc_car_ocp")
+    r = subprocess.run([exe, str(shared_codegen("batched_rc_car")), "4", "-1", str(d / "dump.txt")], capture_output=True, text=True, timeout=1500)
+    print(r.stdout[-2000:], r.stderr[-2000:])
+    assert r.returncode == 0 and "DUMPED" in r.stdout
+    return _parse(str(d / "dump.txt"))
+
+
+def test_rc_car_whole_horizon_functions_against_the_independent_oracle(rc_car_dump):
+    """The reference's RC-car OCP as written (rc_car.example.cpp:191-285; Pacejka tyre model, atan / sin chains, Utils::Abs on the inputs, the minimum-velocity row)
+    through the facade's Ungar::Autodiff::Function on the GPU: objective value / gradient / upper-triangular Hessian, the 186 equality rows and the 90 inequality rows
+    with their Jacobians, against torch autograd on oracle.ungar_oracle.rc_car_whole_horizon at an instance that crawls at the 0.3 m/s bound."""
+    dump = rc_car_dump
+    dec, par_n = 246, 83
+    v = dump["INPUT"]
+    assert v.size == dec + par_n
+    z, par = torch.tensor(v[:dec]), torch.tensor(v[dec:])
+    value, eq, ineq = O.rc_car_whole_horizon(z, par)
+    assert eq.shape == (186,) and ineq.shape == (90,)
+    assert abs(dump["OBJ"][0] - value.item()) <= 1e-12 * abs(value.item())
+    zg = z.clone().requires_grad_(True)
+    (grad,) = torch.autograd.grad(O.rc_car_whole_horizon(zg, par)[0], zg)
+    g = dump["OBJ_JAC"]
+    assert g.shape == (1, dec) and np.abs(g[0] - grad.numpy()).max() <= 1e-12 * np.abs(grad.numpy()).max()
+    H = torch.autograd.functional.hessian(lambda zz: O.rc_car_whole_horizon(zz, par)[0], z, vectorize=True).numpy()
+    Hd, Hm = dump["OBJ_HES"], dump["OBJ_HES_MASK"]
+    assert not Hm[np.tril_indices(dec, -1)].any() and np.abs(Hd - np.triu(H)).max() <= 1e-12 * np.abs(H).max()
+    Je = torch.autograd.functional.jacobian(lambda zz: O.rc_car_whole_horizon(zz, par)[1], z, vectorize=True).numpy()
+    _check_function(dump, "EQ", eq.numpy(), Je)
+    Ji = torch.autograd.functional.jacobian(lambda zz: O.rc_car_whole_horizon(zz, par)[2], z, vectorize=True).numpy()
+    _check_function(dump, "INEQ", ineq.numpy(), Ji)
+    assert (np.abs(ineq.numpy()[2::3]) < 0.1).any(), "the instance is meant to sit near the minimum-velocity bound"
+    assert (v[(30 + 1) * 6:dec:2] > 0).any() and (v[(30 + 1) * 6:dec:2] < 0).any()  # both branches of Utils::Abs on the duty cycle
