@@ -5,7 +5,7 @@ set -uo pipefail
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 B=${1:-4096}
-for p in quadrotor quadruped; do
+for p in quadrotor rc_car quadruped; do
   # first run fills the code-object cache (compiles are not part of the iteration)
   timeout 900 build/batched_${p}_test /tmp/cg_$p $B 0 > gpurun_out/batched_${p}_timing.log 2>&1
   grep -E "timing|PASS|FAIL" gpurun_out/batched_${p}_timing.log
