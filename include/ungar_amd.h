@@ -435,6 +435,12 @@ int ungar_shooting_trial_rows(const ungar_shooting_dims* dims, const double* row
  * period = listed, instances = the list. */
 int ungar_shooting_trial_rows_listed(const ungar_shooting_dims* dims, const double* rows, const double* dZ, const double* dU, const double* alphas, int64_t candidates,
                                      const int32_t* instances, int64_t listed, double* trial, int64_t trial_stride, void* stream);
+/* The same for a WINDOW of the row: elements [first_element, first_element + elements) of every stacked row, unit-fastest (trial_stride > 0) at
+ * trial[(e - first_element) * trial_stride + i]; elements = 0 means the whole row.  The variables [0, nc + nx + nu) are all that a candidate step changes; the
+ * parameter part [nc + nx + nu, row size) of the CURRENT rows (candidates = 1, alphas = {0}) is the same for every candidate and is kept as one image per
+ * ungar_function_*_nodes_split call instead of being copied per candidate. */
+int ungar_shooting_trial_elements(const ungar_shooting_dims* dims, const double* rows, const double* dZ, const double* dU, const double* alphas, int64_t candidates,
+                                  const int32_t* instances, int64_t listed, int64_t first_element, int64_t elements, double* trial, int64_t trial_stride, void* stream);
 /* trial_stride: 0 = node-major trial rows (like `rows`); > 0 = UNIT-FASTEST: element e of stacked node i = (c * batch + b) * (N+1) + k at
  * trial[e * trial_stride + i] (trial_stride >= candidates * batch * (N+1)).  The stage functions then read the trial rows with coalesced loads
  * (ungar_operand {base + offset * trial_stride, instance_stride 1, knot_stride 0, element_stride trial_stride}) and touch only the elements they
@@ -531,6 +537,15 @@ int ungar_function_sparse_hessian(const ungar_function* fn, const ungar_operand*
 int ungar_function_forward_zero_nodes(const ungar_function* fn, const ungar_operand* xp, const ungar_operand* y, int64_t count, int64_t knots, void* stream);
 int ungar_function_sparse_jacobian_nodes(const ungar_function* fn, const ungar_operand* xp, const ungar_operand* jac, int64_t count, int64_t knots, void* stream);
 int ungar_function_sparse_hessian_nodes(const ungar_function* fn, const ungar_operand* xp, const ungar_operand* hes, int64_t count, int64_t knots, void* stream);
+/* The same with the independent variables [0, n) and the parameters [n, n + p) through SEPARATE operands, both addressed by (instance = i / knots, knot =
+ * i % knots).  A parameter operand with instance stride 0 serves every instance from one image: the batched SQP evaluates its stage functions at
+ * (candidate step, node) pairs -- instance := candidate, knot := node -- where only the variables differ between candidates, and keeps one unit-fastest
+ * image of the node parameters (ungar_shooting_trial_elements) instead of copying them for every candidate. */
+int ungar_function_forward_zero_nodes_split(const ungar_function* fn, const ungar_operand* x, const ungar_operand* p, const ungar_operand* y, int64_t count, int64_t knots, void* stream);
+int ungar_function_sparse_jacobian_nodes_split(const ungar_function* fn, const ungar_operand* x, const ungar_operand* p, const ungar_operand* jac, int64_t count, int64_t knots,
+                                               void* stream);
+int ungar_function_sparse_hessian_nodes_split(const ungar_function* fn, const ungar_operand* x, const ungar_operand* p, const ungar_operand* hes, int64_t count, int64_t knots,
+                                              void* stream);
 
 /* Single-instance HOST call (what Ungar::Autodiff::Function::operator()/Jacobian/Hessian need):
  * copies xp to the device, launches batch = 1, copies the result back, synchronously.

@@ -192,6 +192,7 @@ int main(int argc, char** argv) {
             std::printf("FAIL row size %td vs %td\n", nv, cost_node.Size());
             return 1;
         }
+        if (const char* groups = std::getenv("UNGAR_AMD_STACKED_CANDIDATES")) BatchedSoftSQPOptimizer::maxStackedCandidates = std::atol(groups);  // (test of the group logic)
         BatchedSoftSQPOptimizer batched{std::move(problem), batch, false, 1.0, 2};
         if (const char* stage = std::getenv("UNGAR_TEST_FIRST_STAGE")) batched.SetFirstLineSearchStage(std::atol(stage));  // staged line search: same iterates
 

@@ -248,6 +248,7 @@ int main(int argc, char** argv) {
             return 1;
         }
         const real_t dt = 1.0 / static_cast<real_t>(N);
+        if (const char* groups = std::getenv("UNGAR_AMD_STACKED_CANDIDATES")) BatchedSoftSQPOptimizer::maxStackedCandidates = std::atol(groups);  // (test of the group logic)
         BatchedSoftSQPOptimizer batched{std::move(problem), batch, false, dt, 2, 1.0, 1.0};  // the example's optimizer settings (:444)
         if (const char* stage = std::getenv("UNGAR_TEST_FIRST_STAGE")) batched.SetFirstLineSearchStage(std::atol(stage));  // staged line search: same iterates
         if (const char* inside = std::getenv("UNGAR_TEST_EQUALITY_ROWS_IN_RECURSION")) batched.EliminateEqualityRowsBeforeTheRecursion(inside[0] != '1');

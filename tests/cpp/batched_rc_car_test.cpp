@@ -187,6 +187,7 @@ int main(int argc, char** argv) {
             return 1;
         }
         const real_t dt = 1.0 / static_cast<real_t>(N);
+        if (const char* groups = std::getenv("UNGAR_AMD_STACKED_CANDIDATES")) BatchedSoftSQPOptimizer::maxStackedCandidates = std::atol(groups);  // (test of the group logic)
         BatchedSoftSQPOptimizer batched{std::move(problem), batch, false, dt, 2, 100.0, 1e-2};  // the example's optimizer settings (:363)
 
         // ---- perturbed instances (parameter values of rc_car.example.cpp:320-352)

@@ -74,6 +74,23 @@ _LIB = None
 ABI_VERSION = 5  # UNGAR_AMD_ABI_VERSION of include/ungar_amd.h these bindings mirror
 
 
+def _share_the_hip_runtime_of_torch() -> None:
+    """PyTorch bundles its own libamdhip64.so (same SONAME as ROCm's) and loads it lazily.  A library dlopen'ed BEFORE that resolves its libamdhip64.so.7 to ROCm's copy
+    through its RUNPATH, torch then brings its own: two HIP runtimes in one process, and whichever initialises second finds no device ("no ROCm-capable device is
+    detected" from the first launch).  Where torch is in the process its copy is therefore loaded first: the dynamic linker reuses it for ours by SONAME, and device
+    memory, streams and events are shared with torch as the bindings assume."""
+    import sys
+    torch = sys.modules.get("torch")
+    if torch is None or not getattr(torch, "__file__", None):
+        return
+    bundled = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(bundled):
+        try:
+            ctypes.CDLL(bundled, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load_library() -> ctypes.CDLL:
     """dlopen libungar_amd.so and declare every symbol of include/ungar_amd.h.  Raises loudly if the
     HIP library has not been built (no fallback path exists)."""
@@ -87,6 +104,7 @@ def load_library() -> ctypes.CDLL:
     if not os.path.exists(path):
         raise UngarError(f"{path} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
                          "(ungar_amd has no CPU fallback).")
+    _share_the_hip_runtime_of_torch()
     lib = ctypes.CDLL(path)
     try:
         lib.ungar_abi_version.restype = ctypes.c_int32

@@ -70,6 +70,10 @@ __device__ __forceinline__ double BufferLoad(__amdgpu_buffer_rsrc_t r, int laneO
 /// same point of the recursion together: requested where they are needed, the whole device waits for HBM -- 70 MB per knot of the 37 + 12 problem, 17 us --
 /// and computes afterwards; touched one knot ahead, HBM works during the products.)
 __device__ __forceinline__ void TouchLine(const void* lanePointer, unsigned ldsJunk) {
+#if defined(UNGAR_RICCATI_NO_TOUCH)  // (A/B of the prefetch through the kernel factory: UNGAR_AMD_JIT_FLAGS="-O3 -DUNGAR_RICCATI_NO_TOUCH")
+    (void)lanePointer, (void)ldsJunk;
+    return;
+#endif
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(lanePointer), "s"(ldsJunk) : "memory");
 }

@@ -901,12 +901,13 @@ __global__ __launch_bounds__(256) void ShootingTrialUnitFastestKernel(const Shoo
     const long long node0 = static_cast<long long>(blockIdx.x) * 64;
     const int t = static_cast<int>(threadIdx.x), nz = d.nz(), nd = d.nd(), nv = d.nv(), nc = d.nc, N = d.N;
     const bool small = nodes < (1ll << 31);
-    for (int j0 = 0; j0 < nv; j0 += 32) {
+    const int first = a.first, end = a.elements > 0 ? a.first + a.elements : nv;  // window of row elements this launch writes
+    for (int j0 = first; j0 < end; j0 += 32) {
         const int jj = t & 31, j = j0 + jj;
         for (int pass = 0; pass < 8; ++pass) {
             const int nl = (t >> 5) + 8 * pass;
             const long long node = node0 + nl;
-            if (node < nodes && j < nv) {
+            if (node < nodes && j < end) {
                 // (stacked node -> (candidate, instance slot, knot): 32-bit divisions wherever the launch has fewer than 2^31 stacked nodes -- always, in practice;
                 // three 64-bit divisions per element were ~150 of this kernel's instructions per element)
                 long long s, c, i;
@@ -942,7 +943,7 @@ __global__ __launch_bounds__(256) void ShootingTrialUnitFastestKernel(const Shoo
         const int nl = t & 63;
         for (int pass = 0; pass < 8; ++pass) {
             const int row = (t >> 6) + 4 * pass;
-            if (j0 + row < nv && node0 + nl < nodes) a.trial[(j0 + row) * a.trialStride + node0 + nl] = tile[row][nl];
+            if (j0 + row < end && node0 + nl < nodes) a.trial[(j0 + row - first) * a.trialStride + node0 + nl] = tile[row][nl];
         }
         __syncthreads();
     }

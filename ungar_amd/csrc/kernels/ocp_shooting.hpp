@@ -110,6 +110,9 @@ struct ShootingTrialArgs {
     // listed > 0: only the instances instances[0 .. listed) are stacked -- trial point (c, i) is instance instances[i], at c * listed + i
     const int* instances = nullptr;
     long long listed = 0;
+    // Unit-fastest image only: the row elements [first, first + elements) are written, at trial[(e - first) * trialStride + i] (elements = 0: the whole row).
+    // [0, nd): the variables -- all a candidate step changes; [nd, nv) with one candidate of length 0: the knot and instance parameters, once per SetRows.
+    int first = 0, elements = 0;
 };
 
 /// The backtracking search of backtracking_line_search.hpp:116-151 per instance over the stacked candidates, then the bookkeeping of

@@ -299,6 +299,11 @@ int ungar_shooting_trial_rows(const ungar_shooting_dims* dims, const double* row
 
 int ungar_shooting_trial_rows_listed(const ungar_shooting_dims* dims, const double* rows, const double* dZ, const double* dU, const double* alphas, int64_t candidates,
                                      const int32_t* instances, int64_t listed, double* trial, int64_t trial_stride, void* stream) {
+    return ungar_shooting_trial_elements(dims, rows, dZ, dU, alphas, candidates, instances, listed, 0, 0, trial, trial_stride, stream);
+}
+
+int ungar_shooting_trial_elements(const ungar_shooting_dims* dims, const double* rows, const double* dZ, const double* dU, const double* alphas, int64_t candidates,
+                                  const int32_t* instances, int64_t listed, int64_t first_element, int64_t elements, double* trial, int64_t trial_stride, void* stream) {
     ShootingTrialArgs k{};
     if (!dims || !ToDims(*dims, &k.d) || !alphas || candidates < 1 || candidates > kMaxLineSearchCandidates)
         return Fail(UNGAR_E_INVALID, "ungar_shooting_trial_rows: bad argument (1 <= candidates <= 16)");
@@ -315,6 +320,10 @@ int ungar_shooting_trial_rows_listed(const ungar_shooting_dims* dims, const doub
     for (int64_t c = 0; c < candidates; ++c) k.alphas[c] = alphas[c];
     if (trial_stride < 0 || (trial_stride > 0 && trial_stride < candidates * (listed > 0 ? listed : k.d.batch) * (k.d.N + 1))) return Fail(UNGAR_E_INVALID, "ungar_shooting_trial_rows: trial_stride smaller than the number of stacked nodes");
     k.trialStride = trial_stride;
+    if (first_element < 0 || elements < 0 || first_element + elements > k.d.nv() || ((first_element > 0 || elements > 0) && trial_stride == 0))
+        return Fail(UNGAR_E_INVALID, "ungar_shooting_trial_elements: the element window must lie inside the row and needs the unit-fastest image (trial_stride > 0)");
+    k.first = static_cast<int>(first_element);
+    k.elements = static_cast<int>(elements);
     return Launched(ungar_amd_launch_shooting_trial(&k, stream), "ungar_shooting_trial_rows");
 }
 

@@ -86,7 +86,7 @@ constexpr uint32_t kEnableHessian = 1U << 2;   // EnabledDerivatives::HESSIAN
 #ifndef UNGAR_AMD_EMITTER_ID
 #define UNGAR_AMD_EMITTER_ID "unversioned"
 #endif
-constexpr const char* kCacheFormat = "ungar_amd-cache-5";  // bump whenever the emitted kernels' argument list (their ABI) or the meta file changes: 3 = ten-argument kernels (knot stride, direct host results), 4 = consecutive outputs leave in 16-byte stores, 5 = a derivative may consist of several kernels (chunks of consecutive outputs; unit tags "jacobian.3")
+constexpr const char* kCacheFormat = "ungar_amd-cache-6";  // bump whenever the emitted kernels' argument list (their ABI) or the meta file changes: 3 = ten-argument kernels (knot stride, direct host results), 4 = consecutive outputs leave in 16-byte stores, 5 = a derivative may consist of several kernels (chunks of consecutive outputs; unit tags "jacobian.3"), 6 = fourteen-argument kernels (the parameters through an operand of their own)
 constexpr std::size_t kBigKernel = 3000;        // statements above which the machine schedulers are switched off (see below)
 // Statements above which a derivative is cut into chunks of consecutive outputs, one kernel and one compiler process each: the compile time of
 // a straight-line body grows faster than its length (the equality-constraint Jacobian of the reference's quadruped OCP, 14 167 outputs in one
@@ -164,8 +164,8 @@ bool PairOutputStores() {
 }
 
 /// Outputs [first, last) of `values` (the whole derivative when the body is small enough, one chunk of it otherwise); output k is written at index k whatever the chunk.
-std::string EmitKernel(const std::string& kernelName, const tape::Graph& g, int64_t nIn, const std::vector<tape::Id>& values, std::size_t first, std::size_t last,
-                       std::size_t* statements) {
+std::string EmitKernel(const std::string& kernelName, const tape::Graph& g, int64_t nIndependent, int64_t nIn, const std::vector<tape::Id>& values, std::size_t first,
+                       std::size_t last, std::size_t* statements) {
     const bool pairs = PairOutputStores();
     std::vector<std::string> inNames;
     inNames.reserve(static_cast<std::size_t>(nIn));
@@ -173,7 +173,11 @@ std::string EmitKernel(const std::string& kernelName, const tape::Graph& g, int6
     // merges repeated loads and places them where they are needed): reading every input into a local up
     // front keeps ~n values alive from the top of a whole-horizon kernel and made the register allocator
     // the dominant compile cost (objective value kernel, 960 inputs: 21 s -> 2 s, 1 KB of scratch -> none)
-    for (int64_t i = 0; i < nIn; ++i) inNames.push_back("in[" + std::to_string(i) + " * xes]");
+    // The parameters [n, n + p) come through an operand of their own (`par`): a caller whose parameters do not change with what it varies in the independent
+    // variables -- the candidate steps of a line search over the same nodes -- keeps ONE image of them instead of a copy per candidate
+    // (ungar_function_*_nodes_split); the one-operand entry points pass par = xp + n * xes with the same strides.
+    for (int64_t i = 0; i < nIn; ++i)
+        inNames.push_back(i < nIndependent ? "in[" + std::to_string(i) + " * xes]" : "par[" + std::to_string(i - nIndependent) + " * pes]");
     // Outputs are delivered in index order (Emitter::Emit), so consecutive outputs 2 m, 2 m + 1 leave as ONE 16-byte store where the output operand is
     // contiguous per instance (oes == 1: the node-major sparse Jacobians / Hessians the batched SQP assembles from).  One lane per instance writes its own
     // run of doubles: every store instruction is 64 separate transactions at L2 whatever its width, and their RATE bounds these kernels (with coalesced
@@ -198,12 +202,13 @@ std::string EmitKernel(const std::string& kernelName, const tape::Graph& g, int6
     // launched with 64-lane workgroups (LaunchFn): tell the compiler, so that it may use the full register file
     os << "extern \"C\" __global__ __launch_bounds__(64) void " << kernelName
        << "(const double* __restrict__ xp, long long xbs, long long xes, double* __restrict__ outBase, long long obs, long long oes, long long "
-          "batch, long long knots, long long xks, long long oks) {\n"
+          "batch, long long knots, long long xks, long long oks, const double* __restrict__ pp, long long pbs, long long pes, long long pks) {\n"
        << "    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;\n"
        << "    if (i >= batch) return;\n"
        // node i = (instance i / knots, knot i % knots): the shooting nodes of a batch of horizons, each instance a strided run of knots
        << "    const long long ib = knots > 1 ? i / knots : i, ik = i - ib * knots;\n"
        << "    const double* __restrict__ in = xp + ib * xbs + ik * xks;\n"
+       << "    const double* __restrict__ par = pp + ib * pbs + ik * pks;\n"
        << "    double* __restrict__ out = outBase + ib * obs + ik * oks;\n";
     tape::Emitter em{g, inNames};
     os << em.Emit(slots) << "}\n\n";
@@ -447,7 +452,7 @@ int ungar_function_make(const ungar_tape_node* nodes, int64_t num_nodes, const i
         };
         for (Unit& u : units) {
             const std::string src = "// generated by ungar_amd (runtime/function.cpp) for function '" + fn->name + "'\n#include <hip/hip_runtime.h>\n\n" +
-                                    EmitKernel(u.kernel, g, n + p, *u.values, u.first, u.last, &u.statements);
+                                    EmitKernel(u.kernel, g, n, n + p, *u.values, u.first, u.last, &u.statements);
             u.flags = std::string("--offload-arch=") + kArch + " -std=c++17 " +
                       (custom ? custom : u.statements > kBigKernel ? "-O3 -mllvm -enable-misched=false -mllvm -enable-post-misched=false" : "-O3");
             u.object = base + "_" + u.tag + ".hsaco";
@@ -581,7 +586,7 @@ int ungar_function_hessian_sparsity(const ungar_function* fn, const int32_t** ro
 }
 
 static int LaunchFn(const ungar_function* fn, const ungar_function::Kernels* kernels, const char* what, const ungar_operand* xp, const ungar_operand* out,
-                    int64_t batch, void* stream, int64_t knotsPerInstance = 1) {
+                    int64_t batch, void* stream, int64_t knotsPerInstance = 1, const ungar_operand* parameters = nullptr) {
     if (!fn || !xp || !out) return Fail(UNGAR_E_INVALID, std::string(what) + ": null argument");
     if (!kernels || kernels->empty()) return Fail(UNGAR_E_UNSUPPORTED, std::string(what) + ": kernel not available for function '" + fn->name + "' (derivative not enabled, or made with UNGAR_AMD_COMPILE_ONLY)");
     if (batch < 0 || knotsPerInstance < 1) return Fail(UNGAR_E_INVALID, std::string(what) + ": negative batch or knots < 1");
@@ -591,7 +596,12 @@ static int LaunchFn(const ungar_function* fn, const ungar_function::Kernels* ker
     long long xbs = xp->instance_stride, xes = xp->element_stride, obs = out->instance_stride, oes = out->element_stride, b = batch;
     double* o = out->base;
     long long knots = knotsPerInstance, xks = xp->knot_stride, oks = out->knot_stride;
-    void* args[] = {&in, &xbs, &xes, &o, &obs, &oes, &b, &knots, &xks, &oks};
+    // parameters: their own operand, or (one-operand entry points) the elements [n, n + p) of xp
+    if (parameters && fn->p > 0 && !parameters->base) return Fail(UNGAR_E_INVALID, std::string(what) + ": null parameter operand");
+    const double* par = parameters ? parameters->base : xp->base + fn->n * xp->element_stride;
+    long long pbs = parameters ? parameters->instance_stride : xp->instance_stride, pes = parameters ? parameters->element_stride : xp->element_stride,
+              pks = parameters ? parameters->knot_stride : xp->knot_stride;
+    void* args[] = {&in, &xbs, &xes, &o, &obs, &oes, &b, &knots, &xks, &oks, &par, &pbs, &pes, &pks};
     const unsigned block = 64;
     for (hipFunction_t k : *kernels) {  // every chunk of the derivative writes its own outputs of the same operand
         const hipError_t e = hipModuleLaunchKernel(k, static_cast<unsigned>((batch + block - 1) / block), 1, 1, block, 1, 1, 0, static_cast<hipStream_t>(stream), args, nullptr);
@@ -626,6 +636,25 @@ int ungar_function_sparse_jacobian_nodes(const ungar_function* fn, const ungar_o
 int ungar_function_sparse_hessian_nodes(const ungar_function* fn, const ungar_operand* xp, const ungar_operand* hes, int64_t count, int64_t knots, void* stream) {
     if (fn && xp && hes && count >= 0 && (fn->enabled & kEnableHessian) && fn->hesRows.empty()) return UNGAR_OK;
     return LaunchFn(fn, fn ? &fn->kHes : nullptr, "ungar_function_sparse_hessian_nodes", xp, hes, count, stream, knots);
+}
+
+// The independent variables [0, n) and the parameters [n, n + p) through separate operands (same node decomposition for both: a parameter operand with instance
+// stride 0 serves every "instance" -- e.g. every candidate step of a line search over the same nodes -- from one image).
+int ungar_function_forward_zero_nodes_split(const ungar_function* fn, const ungar_operand* x, const ungar_operand* p, const ungar_operand* y, int64_t count, int64_t knots, void* stream) {
+    if (!p) return Fail(UNGAR_E_INVALID, "ungar_function_forward_zero_nodes_split: null argument");
+    return LaunchFn(fn, fn ? &fn->kValue : nullptr, "ungar_function_forward_zero_nodes_split", x, y, count, stream, knots, p);
+}
+int ungar_function_sparse_jacobian_nodes_split(const ungar_function* fn, const ungar_operand* x, const ungar_operand* p, const ungar_operand* jac, int64_t count, int64_t knots,
+                                               void* stream) {
+    if (!p) return Fail(UNGAR_E_INVALID, "ungar_function_sparse_jacobian_nodes_split: null argument");
+    if (fn && x && jac && count >= 0 && (fn->enabled & kEnableJacobian) && fn->jacRows.empty()) return UNGAR_OK;
+    return LaunchFn(fn, fn ? &fn->kJac : nullptr, "ungar_function_sparse_jacobian_nodes_split", x, jac, count, stream, knots, p);
+}
+int ungar_function_sparse_hessian_nodes_split(const ungar_function* fn, const ungar_operand* x, const ungar_operand* p, const ungar_operand* hes, int64_t count, int64_t knots,
+                                              void* stream) {
+    if (!p) return Fail(UNGAR_E_INVALID, "ungar_function_sparse_hessian_nodes_split: null argument");
+    if (fn && x && hes && count >= 0 && (fn->enabled & kEnableHessian) && fn->hesRows.empty()) return UNGAR_OK;
+    return LaunchFn(fn, fn ? &fn->kHes : nullptr, "ungar_function_sparse_hessian_nodes_split", x, hes, count, stream, knots, p);
 }
 
 /// Single-instance host call: H2D, batch-1 launch, D2H, on the null stream, synchronous.

@@ -60,6 +60,14 @@ struct ShootingProblem {
     index_t InstanceParameterOffset() const { return carrySize + stateSize + inputSize + knotParameterSize; }
 };
 
+/// Stacked evaluation whose row image holds the VARIABLES only: `candidates` x `nodes` stacked nodes, candidate-major; the parameters of node i of every candidate
+/// at parameters[e * stride + i] (ungar_function_*_nodes_split: instance := candidate, knot := node, parameter instance stride 0).  candidates = 0: whole rows.
+struct ShootingSplitImage {
+    index_t candidates = 0, nodes = 0;
+    real_t* parameters = nullptr;
+    index_t stride = 0;
+};
+
 class BatchedSoftSQPOptimizer {
   public:
     /// Same parameters as SoftSQPOptimizer (reference soft_sqp.hpp:44-60) plus the number of instances.
@@ -84,6 +92,7 @@ class BatchedSoftSQPOptimizer {
         for (void* ptr : _owned) (void)ungar_device_free(ptr);
     }
 
+    inline static index_t maxStackedCandidates = 16;  // read at construction (see StackedCandidates)
     const ShootingProblem& Problem() const { return _p; }
     /// Kernels the QP step of this problem runs (ungar_ocp_riccati_route / ungar_shooting_assemble_route: 0 run-time-size kernels, 1 compiled into the library,
     /// 2 instantiated for this problem's sizes by the kernel factory, 3 run-time-size one-wavefront assembly).
@@ -117,6 +126,16 @@ class BatchedSoftSQPOptimizer {
         } else {
             CarryValues(_rows, _batch);
         }
+        RefreshParameterImage();
+    }
+    /// The knot and instance parameters [w | p] of all node rows as ONE unit-fastest image (element e of node i at _parameters[e * _parameterStride + i]): the
+    /// stage functions read their parameters from it at every candidate step of the line search and at the current point, so the per-iteration images of the rows
+    /// hold the variables [c | x | u] only.  Refreshed with the rows (SetRows, RefreshCarried -- call the latter after writing rows on the device).
+    void RefreshParameterImage() {
+        if (!_parameters) return;
+        const index_t nd = Nz() + _p.inputSize;
+        const real_t zero = 0.0;
+        Check(ungar_shooting_trial_elements(&_dims, _rows, _dZ, _dU, &zero, 1, nullptr, 0, nd, _p.RowSize() - nd, _parameters, _parameterStride, _stream));
     }
 
     /// One SQP iteration of every active instance (the body of the reference's loop, soft_sqp.hpp:68-99).
@@ -127,25 +146,27 @@ class BatchedSoftSQPOptimizer {
         // transactions per load instruction
         real_t* at = _rows;
         index_t atStride = 0;
-        if (_trialStride > 0 && std::getenv("UNGAR_AMD_NODE_MAJOR_DERIVATIVE_ROWS") == nullptr) {
+        ShootingSplitImage split;  // the image holds the variables only, the parameters come from their own image
+        if (_trialStride > 0) {
             const real_t zero = 0.0;
-            Check(ungar_shooting_trial_rows(&_dims, _rows, _dZ, _dU, &zero, 1, _trial, _trialStride, _stream));
+            if (_parameters) split = {1, B * (N + 1), _parameters, _parameterStride};
+            Check(ungar_shooting_trial_elements(&_dims, _rows, _dZ, _dU, &zero, 1, nullptr, 0, 0, split.candidates ? Nz() + _p.inputSize : 0, _trial, _trialStride, _stream));
             at = _trial;
             atStride = _trialStride;
         }
-        Evaluate(*_p.dynamics, 0, at, _p.StateOffset(), _f, B * (N + 1), atStride);
-        Evaluate(*_p.dynamics, 1, at, _p.StateOffset(), _fJ, B * (N + 1), atStride);
-        if (_p.carry) Evaluate(*_p.carry, 1, at, _p.StateOffset(), _cJ, B * (N + 1), atStride);
-        Evaluate(*_p.cost, 0, at, 0, _l, B * (N + 1), atStride);
-        Evaluate(*_p.cost, 1, at, 0, _lg, B * (N + 1), atStride);
-        Evaluate(*_p.cost, 2, at, 0, _lH, B * (N + 1), atStride);
+        Evaluate(*_p.dynamics, 0, at, _p.StateOffset(), _f, B * (N + 1), atStride, split);
+        Evaluate(*_p.dynamics, 1, at, _p.StateOffset(), _fJ, B * (N + 1), atStride, split);
+        if (_p.carry) Evaluate(*_p.carry, 1, at, _p.StateOffset(), _cJ, B * (N + 1), atStride, split);
+        Evaluate(*_p.cost, 0, at, 0, _l, B * (N + 1), atStride, split);
+        Evaluate(*_p.cost, 1, at, 0, _lg, B * (N + 1), atStride, split);
+        Evaluate(*_p.cost, 2, at, 0, _lH, B * (N + 1), atStride, split);
         if (_p.inequality) {
-            Evaluate(*_p.inequality, 0, at, 0, _h, B * (N + 1), atStride);
-            Evaluate(*_p.inequality, 1, at, 0, _hJ, B * (N + 1), atStride);
+            Evaluate(*_p.inequality, 0, at, 0, _h, B * (N + 1), atStride, split);
+            Evaluate(*_p.inequality, 1, at, 0, _hJ, B * (N + 1), atStride, split);
         }
         if (_p.equality) {
-            Evaluate(*_p.equality, 0, at, 0, _e, B * (N + 1), atStride);
-            Evaluate(*_p.equality, 1, at, 0, _eJ, B * (N + 1), atStride);
+            Evaluate(*_p.equality, 0, at, 0, _e, B * (N + 1), atStride, split);
+            Evaluate(*_p.equality, 1, at, 0, _eJ, B * (N + 1), atStride, split);
         }
         // ---- QP data and solve (soft_sqp.hpp:143-158)
         ungar_shooting_assemble_args a{};
@@ -251,12 +272,25 @@ class BatchedSoftSQPOptimizer {
             // trial rows UNIT-FASTEST (element e of stacked node i at _trial[e * stride + i]): the stage functions read them coalesced and touch
             // only the elements they use
             const index_t stride = _trialStride;
-            Check(ungar_shooting_trial_rows_listed(&_dims, _rows, _dZ, _dU, _alphas.data() + begin, count, list, listed, _trial, stride, _stream));
-            if (_p.carry) CarryValues(_trial, count * stacked, stride);
-            Evaluate(*_p.dynamics, 0, _trial, _p.StateOffset(), _fT, count * stacked * (N + 1), stride);
-            Evaluate(*_p.cost, 0, _trial, 0, _lT, count * stacked * (N + 1), stride);
-            if (_p.inequality) Evaluate(*_p.inequality, 0, _trial, 0, _hT, count * stacked * (N + 1), stride);
-            if (_p.equality) Evaluate(*_p.equality, 0, _trial, 0, _eT, count * stacked * (N + 1), stride);
+            // The stacked (candidate, node) pairs of a stage share their parameters across the candidates: only the variables [c | x | u] of the trial points are
+            // written (a third of the RC car's row), the stage functions take the parameters from an image of their own -- the image of all nodes for a stage
+            // over all instances, an image gathered once per stage for the LISTED instances.
+            ShootingSplitImage split;
+            if (_parameters) {
+                split = {count, stacked * (N + 1), _parameters, _parameterStride};
+                if (listed > 0) {
+                    const real_t zero = 0.0;
+                    const index_t nd = Nz() + _p.inputSize;
+                    Check(ungar_shooting_trial_elements(&_dims, _rows, _dZ, _dU, &zero, 1, list, listed, nd, _p.RowSize() - nd, _listedParameters, _parameterStride, _stream));
+                    split.parameters = _listedParameters;
+                }
+            }
+            Check(ungar_shooting_trial_elements(&_dims, _rows, _dZ, _dU, _alphas.data() + begin, count, list, listed, 0, split.candidates ? Nz() + _p.inputSize : 0, _trial, stride, _stream));
+            if (_p.carry) CarryValues(_trial, count * stacked, stride, split);
+            Evaluate(*_p.dynamics, 0, _trial, _p.StateOffset(), _fT, count * stacked * (N + 1), stride, split);
+            Evaluate(*_p.cost, 0, _trial, 0, _lT, count * stacked * (N + 1), stride, split);
+            if (_p.inequality) Evaluate(*_p.inequality, 0, _trial, 0, _hT, count * stacked * (N + 1), stride, split);
+            if (_p.equality) Evaluate(*_p.equality, 0, _trial, 0, _eT, count * stacked * (N + 1), stride, split);
             ungar_shooting_merit_args t = m;
             t.dims.batch = count * stacked;
             t.rows = _trial;
@@ -436,6 +470,11 @@ class BatchedSoftSQPOptimizer {
         _xm = Device<real_t>(B * nx);
         _trialStride = _nodeMajorTrialRows ? 0 : ((stacked + 15) / 16 * 16 + 48);  // whole 128-byte segments, off the power-of-two channel strides
         _trial = Device<real_t>((_trialStride > 0 ? _trialStride : stacked) * nv);
+        if (_trialStride > 0 && nv > nd) {  // one unit-fastest image of the parameter part of the rows
+            _parameterStride = (nodes + 15) / 16 * 16 + 48;
+            _parameters = Device<real_t>(_parameterStride * (nv - nd));
+            _listedParameters = Device<real_t>(_parameterStride * (nv - nd));
+        }
         _f = Device<real_t>(nodes * nx);
         _fJ = Device<real_t>(nodes * _pf.nnz);
         _cJ = _p.carry ? Device<real_t>(nodes * _pc.nnz) : nullptr;
@@ -484,7 +523,7 @@ class BatchedSoftSQPOptimizer {
 
     /// what: 0 value, 1 sparse Jacobian, 2 sparse Hessian of `f` for `count` consecutive node rows starting at `rows`; the function's
     /// variables begin `offset` doubles into each row.
-    void Evaluate(const Autodiff::Function& f, int what, real_t* rows, index_t offset, real_t* out, index_t count, index_t unitFastestStride = 0) {
+    void Evaluate(const Autodiff::Function& f, int what, real_t* rows, index_t offset, real_t* out, index_t count, index_t unitFastestStride = 0, const ShootingSplitImage& split = ShootingSplitImage{}) {
         const index_t nv = _p.RowSize();
         int64_t width = f.DependentVariableSize();
         if (what != 0) {
@@ -492,14 +531,31 @@ class BatchedSoftSQPOptimizer {
             Check(what == 1 ? ungar_function_jacobian_sparsity(f.Handle(), &r, &c, &width) : ungar_function_hessian_sparsity(f.Handle(), &r, &c, &width));
         }
         const ungar_operand xp = unitFastestStride > 0 ? ungar_operand{rows + offset * unitFastestStride, 1, 0, unitFastestStride} : ungar_operand{rows + offset, nv, 0, 1};
+        if (split.candidates > 0 && unitFastestStride > 0) {
+            const index_t nodes = split.nodes;
+            const ungar_operand x{rows + offset * unitFastestStride, nodes, 1, unitFastestStride}, par{split.parameters, 0, 1, split.stride}, ys{out, nodes * width, width, 1};
+            Check(what == 0   ? ungar_function_forward_zero_nodes_split(f.Handle(), &x, &par, &ys, split.candidates * nodes, nodes, _stream)
+                  : what == 1 ? ungar_function_sparse_jacobian_nodes_split(f.Handle(), &x, &par, &ys, split.candidates * nodes, nodes, _stream)
+                              : ungar_function_sparse_hessian_nodes_split(f.Handle(), &x, &par, &ys, split.candidates * nodes, nodes, _stream));
+            return;
+        }
         const ungar_operand y{out, width, 0, 1};
         Check(what == 0   ? ungar_function_forward_zero_nodes(f.Handle(), &xp, &y, count, 1, _stream)
               : what == 1 ? ungar_function_sparse_jacobian_nodes(f.Handle(), &xp, &y, count, 1, _stream)
                           : ungar_function_sparse_hessian_nodes(f.Handle(), &xp, &y, count, 1, _stream));
     }
     /// c of row k + 1 <- carry(x, u, w, p of row k) for k < N of `instances` consecutive instances (rows in place).
-    void CarryValues(real_t* rows, index_t instances, index_t unitFastestStride = 0) {
+    void CarryValues(real_t* rows, index_t instances, index_t unitFastestStride = 0, const ShootingSplitImage& split = ShootingSplitImage{}) {
         const index_t N = _p.horizon, nv = _p.RowSize();
+        if (split.candidates > 0 && unitFastestStride > 0) {  // variables from the image of each candidate, parameters from theirs: one launch per candidate
+            const index_t nodes = split.nodes;
+            for (index_t c = 0; c < split.candidates; ++c) {
+                const ungar_operand x{rows + _p.StateOffset() * unitFastestStride + c * nodes, N + 1, 1, unitFastestStride}, par{split.parameters, N + 1, 1, split.stride},
+                    ys{rows + c * nodes + 1, N + 1, 1, unitFastestStride};
+                Check(ungar_function_forward_zero_nodes_split(_p.carry->Handle(), &x, &par, &ys, nodes / (N + 1) * N, N, _stream));
+            }
+            return;
+        }
         const ungar_operand xp = unitFastestStride > 0 ? ungar_operand{rows + _p.StateOffset() * unitFastestStride, N + 1, 1, unitFastestStride}
                                                        : ungar_operand{rows + _p.StateOffset(), (N + 1) * nv, nv, 1};
         const ungar_operand y = unitFastestStride > 0 ? ungar_operand{rows + 1, N + 1, 1, unitFastestStride} : ungar_operand{rows + nv, (N + 1) * nv, nv, 1};
@@ -513,13 +569,9 @@ class BatchedSoftSQPOptimizer {
         return host;
     }
 
-    /// Candidates per stacked evaluation: the C ABI's bound of 16 (ungar_shooting_trial_rows / _select), or fewer on request (UNGAR_AMD_STACKED_CANDIDATES:
-    /// the test of the group logic runs the default 14 candidates in groups of 4 and must reproduce the single-group iterates bit for bit).
-    static index_t StackedCandidates() {
-        const char* e = std::getenv("UNGAR_AMD_STACKED_CANDIDATES");
-        const long v = e ? std::atol(e) : 16;
-        return v >= 1 && v <= 16 ? static_cast<index_t>(v) : 16;
-    }
+    /// Candidates per stacked evaluation: the C ABI's bound of 16 (ungar_shooting_trial_rows / _select), or fewer when `maxStackedCandidates` says so before the
+    /// optimiser is constructed (the test of the group logic runs the default 14 candidates in groups of 4 and must reproduce the single-group iterates bit for bit).
+    static index_t StackedCandidates() { return maxStackedCandidates >= 1 && maxStackedCandidates <= 16 ? maxStackedCandidates : 16; }
     const index_t kStacked = StackedCandidates();
     ShootingProblem _p;
     index_t _batch;
@@ -533,7 +585,8 @@ class BatchedSoftSQPOptimizer {
     void* _stream = nullptr;
     std::vector<void*> _owned;
     ungar_stage_pattern _pf{}, _pc{}, _pg{}, _pH{}, _ph{}, _pe{};
-    real_t *_rows = nullptr, *_xm = nullptr, *_trial = nullptr;
+    real_t *_rows = nullptr, *_xm = nullptr, *_trial = nullptr, *_parameters = nullptr, *_listedParameters = nullptr;
+    index_t _parameterStride = 0;
     real_t *_f = nullptr, *_fJ = nullptr, *_cJ = nullptr, *_l = nullptr, *_lg = nullptr, *_lH = nullptr, *_h = nullptr, *_hJ = nullptr, *_e = nullptr, *_eJ = nullptr;
     real_t *_fT = nullptr, *_lT = nullptr, *_hT = nullptr, *_eT = nullptr;
     real_t *_AB = nullptr, *_b = nullptr, *_W = nullptr, *_w = nullptr, *_E = nullptr, *_dz0 = nullptr, *_dZ = nullptr, *_dU = nullptr, *_workspace = nullptr;
@@ -546,7 +599,7 @@ class BatchedSoftSQPOptimizer {
     std::vector<index_t> _stages{2};  // ({2, 4} measured: no gain -- quadrotor 1.22 -> 1.27 ms, RC car 0.84 -> 0.86: who needs less than 1/2 mostly needs much less)
     int32_t *_listA = nullptr, *_listB = nullptr;  // instances a stage of the line search left unresolved (read / written alternately)
     index_t _trialStride = 0;
-    bool _nodeMajorTrialRows = std::getenv("UNGAR_AMD_NODE_MAJOR_TRIAL_ROWS") != nullptr;  // A/B switch (measurement)
+    static constexpr bool _nodeMajorTrialRows = false;  // (node-major trial rows: measured in round 4, 1.5-2.6x slower stage functions; the code path stays for the record)
     int32_t* _unresolved = nullptr;
     real_t *_theta0 = nullptr, *_phi0 = nullptr, *_obj0 = nullptr, *_slope = nullptr, *_accepted = nullptr, *_thetaT = nullptr, *_phiT = nullptr, *_objT = nullptr;
 };
