@@ -75,15 +75,23 @@ ABI_VERSION = 5  # UNGAR_AMD_ABI_VERSION of include/ungar_amd.h these bindings m
 
 
 def _share_the_hip_runtime_of_torch() -> None:
-    """PyTorch bundles its own libamdhip64.so (same SONAME as ROCm's) and loads it lazily.  A library dlopen'ed BEFORE that resolves its libamdhip64.so.7 to ROCm's copy
+    """PyTorch bundles its own libamdhip64.so (same SONAME as ROCm's) and loads it when it is imported.  A library dlopen'ed BEFORE that resolves its libamdhip64.so.7 to ROCm's copy
     through its RUNPATH, torch then brings its own: two HIP runtimes in one process, and whichever initialises second finds no device ("no ROCm-capable device is
-    detected" from the first launch).  Where torch is in the process its copy is therefore loaded first: the dynamic linker reuses it for ours by SONAME, and device
+    detected" from the first launch).  Where torch is installed its copy is therefore loaded first (whether or not it has been imported yet): the dynamic linker reuses it for ours by SONAME, and device
     memory, streams and events are shared with torch as the bindings assume."""
+    import importlib.util
     import sys
     torch = sys.modules.get("torch")
-    if torch is None or not getattr(torch, "__file__", None):
+    origin = getattr(torch, "__file__", None)
+    if origin is None:  # not imported (yet): it may be later in this process -- locate it without importing it
+        try:
+            spec = importlib.util.find_spec("torch")
+        except (ImportError, ValueError):
+            spec = None
+        origin = spec.origin if spec is not None else None
+    if not origin:
         return
-    bundled = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    bundled = os.path.join(os.path.dirname(origin), "lib", "libamdhip64.so")
     if os.path.exists(bundled):
         try:
             ctypes.CDLL(bundled, mode=ctypes.RTLD_GLOBAL)

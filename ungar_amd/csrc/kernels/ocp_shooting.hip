@@ -949,6 +949,37 @@ __global__ __launch_bounds__(256) void ShootingTrialUnitFastestKernel(const Shoo
     }
 }
 
+/// The same image for a NARROW window of the row (the variables of the small problems: 8 + 2, 17 + 4): one lane per (element, stacked node), stacked node fastest --
+/// stores coalesced, the 8-byte reads of a row served by the cache lines its neighbours just touched.  (The tile kernel above keeps 32 lanes per node busy only for
+/// windows of 32 elements and more: with 10 elements two thirds of its lanes idle through the read phase -- 83 us per call of the RC car's line search.)
+__global__ __launch_bounds__(256) void ShootingTrialElementsKernel(const ShootingTrialArgs a) {
+    const ShootingDims& d = a.d;
+    const long long stacked = a.listed > 0 ? a.listed : d.batch;
+    const long long nodes = static_cast<long long>(a.candidates) * stacked * (d.N + 1);
+    const int first = a.first, count = (a.elements > 0 ? a.elements : d.nv()), nz = d.nz(), nd = d.nd(), nc = d.nc, N = d.N;
+    const long long idx = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+    if (idx >= nodes * count) return;
+    const int e = static_cast<int>(idx / nodes);
+    const long long node = idx - e * nodes;
+    const int j = first + e;
+    const long long s = node / (N + 1);
+    const int k = static_cast<int>(node - s * (N + 1));
+    const long long c = s / stacked, i = s - c * stacked;
+    const long long b = a.listed > 0 ? a.instances[i] : i;
+    const double alpha = a.alphas[c];
+    double v = RowOf(a.rows, d, b, k)[j];
+    if (alpha == 0.0) {
+        if (j < nc && d.carryInputs && k > 0) v = RowOf(a.rows, d, b, k - 1)[nz + j];
+    } else if (j < nc && d.carryInputs) {
+        if (k > 0) v = fma(alpha, a.dU[(b * N + (k - 1)) * d.nu + j], RowOf(a.rows, d, b, k - 1)[nz + j]);
+    } else if (j < nz) {
+        v = fma(alpha, a.dZ[(b * (N + 1) + k) * nz + j], v);
+    } else if (j < nd && k < N) {
+        v = fma(alpha, a.dU[(b * N + k) * d.nu + (j - nz)], v);
+    }
+    a.trial[e * a.trialStride + node] = v;
+}
+
 __global__ __launch_bounds__(kBlock) void ShootingSelectKernel(const ShootingSelectArgs a) {
     const ShootingDims& d = a.d;
     const long long slot = blockIdx.x, stacked = a.listed > 0 ? a.listed : d.batch;  // stacked point (c, slot) at c * stacked + slot
@@ -1123,7 +1154,10 @@ extern "C" int ungar_amd_launch_shooting_merit(const ShootingMeritArgs* a, void*
 extern "C" int ungar_amd_launch_shooting_trial(const ShootingTrialArgs* a, void* stream) {
     if (a->d.batch <= 0) return 0;
     const long long nodes = static_cast<long long>(a->candidates) * (a->listed > 0 ? a->listed : a->d.batch) * (a->d.N + 1);
-    if (a->trialStride > 0) hipLaunchKernelGGL(ShootingTrialUnitFastestKernel, dim3(static_cast<unsigned>((nodes + 63) / 64)), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
+    const int window = a->elements > 0 ? a->elements : a->d.nv();
+    if (a->trialStride > 0 && window < 32 && nodes * window < (1ll << 40))
+        hipLaunchKernelGGL(ShootingTrialElementsKernel, dim3(static_cast<unsigned>((nodes * window + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
+    else if (a->trialStride > 0) hipLaunchKernelGGL(ShootingTrialUnitFastestKernel, dim3(static_cast<unsigned>((nodes + 63) / 64)), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
     else hipLaunchKernelGGL(ShootingTrialKernel, dim3(static_cast<unsigned>(nodes)), dim3(a->d.nv() > 64 ? 128 : kBlock), 0, static_cast<hipStream_t>(stream), *a);
     return static_cast<int>(hipGetLastError());
 }
