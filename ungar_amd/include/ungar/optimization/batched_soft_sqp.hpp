@@ -120,7 +120,10 @@ class BatchedSoftSQPOptimizer {
     real_t* DeviceMeasuredStates() const { return _xm; }
 
     void RefreshCarried() {
-        if (_p.carrySize == 0) return;
+        if (_p.carrySize == 0) {
+            RefreshParameterImage();
+            return;
+        }
         if (_p.carryInputs) {  // u_k into the carried slots of row k + 1, in place (the last search direction and the trial rows are left alone)
             Check(ungar_shooting_refresh_carried_inputs(&_dims, _rows, _stream));
         } else {
