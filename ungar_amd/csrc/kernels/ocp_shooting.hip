@@ -889,95 +889,57 @@ __global__ __launch_bounds__(256) void ShootingRefreshCarriedInputsKernel(const 
     row[d.nv() + i] = row[d.nz() + i];  // (reads inputs, writes carried slots of the next row: disjoint elements, no ordering needed)
 }
 
-/// The same trial rows UNIT-FASTEST: a workgroup transposes 64 consecutive stacked nodes, 32 elements at a time, through an LDS tile --
-/// row segments are read coalesced (32 consecutive elements of a node per half wavefront), elements are stored coalesced (64 consecutive nodes).
-/// (Decomposing a lane's eight nodes once, ahead of the element loop -- pointers in registers instead of three 64-bit divisions per element -- was measured:
-/// 0.71 -> 0.87 ms per 1.78 M stacked quadruped nodes at 126 registers; the kernel is bound by memory latency and occupancy, not by that arithmetic.)
+/// The same trial rows UNIT-FASTEST: a workgroup transposes 64 consecutive stacked nodes, up to 32 elements at a time, through an LDS tile.  The (node, element)
+/// pairs of a chunk are dealt to the lanes element-fastest, so a chunk of ANY width keeps every lane busy and reads each row segment once, contiguously (the
+/// variables of the small problems are 10 and 25 elements wide); elements are stored coalesced (64 consecutive nodes).  The 64 nodes are decomposed into
+/// (candidate, instance, knot) once per workgroup.
+/// (History: 32 lanes per node whatever the width left two thirds of the lanes idle on a 10-element window; one lane per (element, node) with the element
+/// outermost over the whole launch re-read every row line once per element from L2 -- 84 us per call of the RC car's line search, 39 % of its iteration.)
 __global__ __launch_bounds__(256) void ShootingTrialUnitFastestKernel(const ShootingTrialArgs a) {
-    __shared__ double tile[32][65];
+    constexpr int kLd = 73;  // (9 mod 32: the pairs a wavefront writes in one instruction fall into different banks for the widths that occur)
+    __shared__ double tile[32 * kLd];
+    __shared__ long long nodeInstance[64];
+    __shared__ int nodeKnot[64];
+    __shared__ double nodeAlpha[64];
     const ShootingDims& d = a.d;
     const long long stacked = a.listed > 0 ? a.listed : d.batch;
     const long long nodes = static_cast<long long>(a.candidates) * stacked * (d.N + 1);
     const long long node0 = static_cast<long long>(blockIdx.x) * 64;
     const int t = static_cast<int>(threadIdx.x), nz = d.nz(), nd = d.nd(), nv = d.nv(), nc = d.nc, N = d.N;
-    const bool small = nodes < (1ll << 31);
+    if (t < 64 && node0 + t < nodes) {
+        const long long node = node0 + t, s = node / (N + 1), c = s / stacked, i = s - c * stacked;
+        nodeKnot[t] = static_cast<int>(node - s * (N + 1));
+        nodeInstance[t] = a.listed > 0 ? a.instances[i] : i;
+        nodeAlpha[t] = a.alphas[c];
+    }
+    __syncthreads();
     const int first = a.first, end = a.elements > 0 ? a.first + a.elements : nv;  // window of row elements this launch writes
+    const int live = nodes - node0 < 64 ? static_cast<int>(nodes - node0) : 64;
     for (int j0 = first; j0 < end; j0 += 32) {
-        const int jj = t & 31, j = j0 + jj;
-        for (int pass = 0; pass < 8; ++pass) {
-            const int nl = (t >> 5) + 8 * pass;
-            const long long node = node0 + nl;
-            if (node < nodes && j < end) {
-                // (stacked node -> (candidate, instance slot, knot): 32-bit divisions wherever the launch has fewer than 2^31 stacked nodes -- always, in practice;
-                // three 64-bit divisions per element were ~150 of this kernel's instructions per element)
-                long long s, c, i;
-                int k;
-                if (small) {
-                    const unsigned n32 = static_cast<unsigned>(node), s32 = n32 / static_cast<unsigned>(N + 1), c32 = s32 / static_cast<unsigned>(stacked);
-                    k = static_cast<int>(n32 - s32 * static_cast<unsigned>(N + 1));
-                    s = s32;
-                    c = c32;
-                    i = s32 - c32 * static_cast<unsigned>(stacked);
-                } else {
-                    s = node / (N + 1);
-                    k = static_cast<int>(node - s * (N + 1));
-                    c = s / stacked;
-                    i = s - c * stacked;
-                }
-                const long long b = a.listed > 0 ? a.instances[i] : i;
-                const double alpha = a.alphas[c];
-                double v = RowOf(a.rows, d, b, k)[j];
-                if (alpha == 0.0) {  // (a step of length 0 is the row itself, whatever the direction holds -- the unit-fastest image of the current rows)
-                    if (j < nc && d.carryInputs && k > 0) v = RowOf(a.rows, d, b, k - 1)[nz + j];
-                } else if (j < nc && d.carryInputs) {
-                    if (k > 0) v = fma(alpha, a.dU[(b * N + (k - 1)) * d.nu + j], RowOf(a.rows, d, b, k - 1)[nz + j]);
-                } else if (j < nz) {
-                    v = fma(alpha, a.dZ[(b * (N + 1) + k) * nz + j], v);
-                } else if (j < nd && k < N) {
-                    v = fma(alpha, a.dU[(b * N + k) * d.nu + (j - nz)], v);
-                }
-                tile[jj][nl] = v;
+        const int width = end - j0 < 32 ? end - j0 : 32;
+        for (int f = t; f < live * width; f += 256) {
+            const int nl = f / width, jj = f - nl * width, j = j0 + jj, k = nodeKnot[nl];
+            const long long b = nodeInstance[nl];
+            const double alpha = nodeAlpha[nl];
+            double v = RowOf(a.rows, d, b, k)[j];
+            if (alpha == 0.0) {  // (a step of length 0 is the row itself, whatever the direction holds -- the unit-fastest image of the current rows)
+                if (j < nc && d.carryInputs && k > 0) v = RowOf(a.rows, d, b, k - 1)[nz + j];
+            } else if (j < nc && d.carryInputs) {
+                if (k > 0) v = fma(alpha, a.dU[(b * N + (k - 1)) * d.nu + j], RowOf(a.rows, d, b, k - 1)[nz + j]);
+            } else if (j < nz) {
+                v = fma(alpha, a.dZ[(b * (N + 1) + k) * nz + j], v);
+            } else if (j < nd && k < N) {
+                v = fma(alpha, a.dU[(b * N + k) * d.nu + (j - nz)], v);
             }
+            tile[jj * kLd + nl] = v;
         }
         __syncthreads();
-        const int nl = t & 63;
-        for (int pass = 0; pass < 8; ++pass) {
-            const int row = (t >> 6) + 4 * pass;
-            if (j0 + row < end && node0 + nl < nodes) a.trial[(j0 + row - first) * a.trialStride + node0 + nl] = tile[row][nl];
+        for (int f = t; f < 64 * width; f += 256) {
+            const int row = f >> 6, nl = f & 63;
+            if (nl < live) a.trial[(j0 + row - first) * a.trialStride + node0 + nl] = tile[row * kLd + nl];
         }
         __syncthreads();
     }
-}
-
-/// The same image for a NARROW window of the row (the variables of the small problems: 8 + 2, 17 + 4): one lane per (element, stacked node), stacked node fastest --
-/// stores coalesced, the 8-byte reads of a row served by the cache lines its neighbours just touched.  (The tile kernel above keeps 32 lanes per node busy only for
-/// windows of 32 elements and more: with 10 elements two thirds of its lanes idle through the read phase -- 83 us per call of the RC car's line search.)
-__global__ __launch_bounds__(256) void ShootingTrialElementsKernel(const ShootingTrialArgs a) {
-    const ShootingDims& d = a.d;
-    const long long stacked = a.listed > 0 ? a.listed : d.batch;
-    const long long nodes = static_cast<long long>(a.candidates) * stacked * (d.N + 1);
-    const int first = a.first, count = (a.elements > 0 ? a.elements : d.nv()), nz = d.nz(), nd = d.nd(), nc = d.nc, N = d.N;
-    const long long idx = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
-    if (idx >= nodes * count) return;
-    const int e = static_cast<int>(idx / nodes);
-    const long long node = idx - e * nodes;
-    const int j = first + e;
-    const long long s = node / (N + 1);
-    const int k = static_cast<int>(node - s * (N + 1));
-    const long long c = s / stacked, i = s - c * stacked;
-    const long long b = a.listed > 0 ? a.instances[i] : i;
-    const double alpha = a.alphas[c];
-    double v = RowOf(a.rows, d, b, k)[j];
-    if (alpha == 0.0) {
-        if (j < nc && d.carryInputs && k > 0) v = RowOf(a.rows, d, b, k - 1)[nz + j];
-    } else if (j < nc && d.carryInputs) {
-        if (k > 0) v = fma(alpha, a.dU[(b * N + (k - 1)) * d.nu + j], RowOf(a.rows, d, b, k - 1)[nz + j]);
-    } else if (j < nz) {
-        v = fma(alpha, a.dZ[(b * (N + 1) + k) * nz + j], v);
-    } else if (j < nd && k < N) {
-        v = fma(alpha, a.dU[(b * N + k) * d.nu + (j - nz)], v);
-    }
-    a.trial[e * a.trialStride + node] = v;
 }
 
 __global__ __launch_bounds__(kBlock) void ShootingSelectKernel(const ShootingSelectArgs a) {
@@ -1154,10 +1116,7 @@ extern "C" int ungar_amd_launch_shooting_merit(const ShootingMeritArgs* a, void*
 extern "C" int ungar_amd_launch_shooting_trial(const ShootingTrialArgs* a, void* stream) {
     if (a->d.batch <= 0) return 0;
     const long long nodes = static_cast<long long>(a->candidates) * (a->listed > 0 ? a->listed : a->d.batch) * (a->d.N + 1);
-    const int window = a->elements > 0 ? a->elements : a->d.nv();
-    if (a->trialStride > 0 && window < 32 && nodes * window < (1ll << 40))
-        hipLaunchKernelGGL(ShootingTrialElementsKernel, dim3(static_cast<unsigned>((nodes * window + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
-    else if (a->trialStride > 0) hipLaunchKernelGGL(ShootingTrialUnitFastestKernel, dim3(static_cast<unsigned>((nodes + 63) / 64)), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
+    if (a->trialStride > 0) hipLaunchKernelGGL(ShootingTrialUnitFastestKernel, dim3(static_cast<unsigned>((nodes + 63) / 64)), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
     else hipLaunchKernelGGL(ShootingTrialKernel, dim3(static_cast<unsigned>(nodes)), dim3(a->d.nv() > 64 ? 128 : kBlock), 0, static_cast<hipStream_t>(stream), *a);
     return static_cast<int>(hipGetLastError());
 }
