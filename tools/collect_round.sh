@@ -47,6 +47,9 @@ cp_if gpurun_out/assemble_ab_kernel_stats.csv profiles/${tag}_assemble_ab_kernel
 cp_if gpurun_out/riccati_sizes_clocks.log     profiles/${tag}_riccati_phase_clocks.log
 cp_if gpurun_out/batched_quadrotor_kernel_stats.csv profiles/${tag}_batched_quadrotor_kernel_stats.csv
 cp_if gpurun_out/batched_quadruped_kernel_stats.csv profiles/${tag}_batched_quadruped_kernel_stats.csv
-cat gpurun_out/batched_quadrotor_timing.log gpurun_out/batched_quadruped_timing.log 2>/dev/null | grep timing > profiles/${tag}_batched_sqp_timing.log || true
+cp_if gpurun_out/batched_rc_car_kernel_stats.csv profiles/${tag}_batched_rc_car_kernel_stats.csv
+for p in quadrotor rc_car quadruped; do grep -HE "timing" gpurun_out/batched_${p}_timing.log 2>/dev/null; done > profiles/${tag}_batched_sqp_timing.log || true
+cp_if gpurun_out/split_occupancy.log        profiles/${tag}_split_occupancy.log
+cp_if gpurun_out/user_ocp.log               profiles/${tag}_user_ocp_routes.log
 cp_if gpurun_out/reference_programs.log     profiles/${tag}_reference_programs.log
 cp_if gpurun_out/quick_sqp.log              profiles/${tag}_quick_sqp.log

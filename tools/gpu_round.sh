@@ -2,7 +2,7 @@
 # Full round evidence on the GPU box: parity tests, smoke, bench (default line + 2-rank dry run of the config-5 partition), rocprofv3
 # kernel trace + HBM counters for the headline kernel, Gauss-Newton and SQP benches.  Outputs under gpurun_out/
 # (tools/collect_profiles.py and tools/collect_round.sh copy the judged summaries into profiles/).
-source "$(dirname "$0")/use_measurement_build.sh"  # the A/B switches below exist only in the measurement build of the library
+# Tests, smoke and every bench line run on the SHIPPED library; only the A/B lines (switches that exist in the measurement build alone) load the other one.
 set -uo pipefail
 mkdir -p gpurun_out
 export TMPDIR=/tmp
@@ -38,7 +38,7 @@ timeout 300 python tools/bench_gn_shapes.py 2>/dev/null | tail -1 > gpurun_out/g
 timeout 300 python tools/bench_rbd_nodes.py 2>/dev/null | tail -1 > gpurun_out/rbd_nodes.json
 timeout 300 python tools/bench_rbd_nodes.py 81920 2>/dev/null | tail -1 > gpurun_out/rbd_nodes_81920.json
 timeout 300 python tools/bench_rbd_nodes.py 262144 2>/dev/null | tail -1 > gpurun_out/rbd_nodes_262144.json
-UNGAR_AMD_RNEA_LANE_PER_NODE=1 UNGAR_AMD_CRBA_LANE_PER_NODE=1 UNGAR_AMD_CENTROIDAL_LANE_PER_NODE=1 timeout 300 python tools/bench_rbd_nodes.py 2>/dev/null | tail -1 > gpurun_out/rbd_nodes_lane_per_node.json
+(source tools/use_measurement_build.sh; UNGAR_AMD_RNEA_LANE_PER_NODE=1 UNGAR_AMD_CRBA_LANE_PER_NODE=1 UNGAR_AMD_CENTROIDAL_LANE_PER_NODE=1 timeout 300 python tools/bench_rbd_nodes.py 2>/dev/null | tail -1 > gpurun_out/rbd_nodes_lane_per_node.json)
 rm -rf gpurun_out/rbd_prof; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/rbd_prof -o rbd -- python tools/bench_rbd_nodes.py > /dev/null 2>&1
 for m in anymal quadrotor rc_car; do timeout 300 python tools/bench_layouts.py $m $([ $m = anymal ] && echo 81920 || ([ $m = quadrotor ] && echo 524288 || echo 3276800)) 2>/dev/null | tail -1; done > gpurun_out/layouts_all.log
 tools/_bin/valu_f64_peak 2>&1 | tail -5 | tee gpurun_out/fp64_peaks.log; tools/_bin/mfma_f64_peak 2>&1 | tail -1 | tee -a gpurun_out/fp64_peaks.log
@@ -65,3 +65,7 @@ echo "== SQ counters of the headline kernel"
 bash tools/gpu_pmc_sq.sh anymal 2>&1 | tail -18 | tee gpurun_out/sq_counters.log
 echo "== the reference's own tests and examples: exit codes and wall times"
 bash tools/gpu_reference_programs.sh 2>&1 | tail -30
+echo "== headline kernel: fused (product) against the split producer / consumer program at two wavefronts per SIMD -- resources and SQ wave counters"
+bash tools/gpu_split_occupancy.sh 2>&1 | tail -30
+echo "== user OCPs of stage sizes without prebuilt kernels through the batched driver (kernel factory routes)"
+for s in 10_3_0 20_9_4; do build/batched_user_ocp_test_$s /tmp/cg_user 4096 4 2>&1 | grep -E "routes|^iteration [12]:|PASS|FAIL"; done | tee gpurun_out/user_ocp.log
