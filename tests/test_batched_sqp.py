@@ -249,7 +249,7 @@ def test_redundant_equality_rows_take_no_pivot(nx, nu, monkeypatch, measurement_
         assert (bad["piv"][:, 2] == -2).all() and (bad["piv"][:, 3] == -1).all() and (bad["piv"][:, :2] == ref["piv"]).all()
 
 
-@pytest.mark.parametrize("nx,nu,nh,dense_row", [(13, 4, 8, False), (8, 2, 6, False), (20, 9, 5, True), (30, 12, 14, True), (10, 3, 0, False)])
+@pytest.mark.parametrize("nx,nu,nh,dense_row", [(13, 4, 8, False), (8, 2, 6, False), (6, 1, 3, False), (9, 3, 0, False), (20, 9, 5, True), (30, 12, 14, True), (10, 3, 0, False)])
 def test_one_wavefront_assembly_of_problems_without_equality_rows_on_random_patterns(nx, nu, nh, dense_row, monkeypatch, measurement_library):
     """ShootingAssembleSmallKernel (stage problems without equality rows, nd + 1 <= 64) against the workgroup kernel (UNGAR_AMD_ASSEMBLE_VARIANT=workgroup) on random
     SPARSE patterns -- Hessian, gradient, dynamics Jacobian, inequality Jacobian with rows of one to several entries, and (dense_row) a row whose entry pairs do not
@@ -259,7 +259,7 @@ def test_one_wavefront_assembly_of_problems_without_equality_rows_on_random_patt
     import ungar_amd
     lib = ungar_amd.load_library()
     lib.ungar_shooting_assemble.argtypes = [ctypes.POINTER(_AssembleArgs), ctypes.c_void_p]
-    N, B, nc = 3, 5, nu
+    N, B, nc = 2, 5, nu  # (15 nodes: the last wavefront of the several-nodes-per-wavefront kernel has a group without a node)
     nz, nd = nc + nx, nc + nx + nu
     rng = np.random.default_rng(5 + nx)
     dev = lambda a, dt=torch.float64: torch.tensor(np.ascontiguousarray(a), dtype=dt, device="cuda")  # noqa: E731
@@ -295,7 +295,7 @@ def test_one_wavefront_assembly_of_problems_without_equality_rows_on_random_patt
          "fJ": dev(rng.standard_normal((nodes, pf[0].size))), "lg": dev(rng.standard_normal((nodes, nd))), "lH": dev(rng.standard_normal((nodes, pH[0].size))),
          "h": dev(-np.abs(rng.standard_normal((nodes, nh))) * 0.01), "hJ": dev(rng.standard_normal((nodes, ph[0].size)))}
 
-    def run(workgroup):
+    def run(workgroup, one_node_per_wavefront=False):
         out = {"AB": torch.full((B * N, nz * nd), 7.0, dtype=torch.float64, device="cuda"), "b": torch.full((B * N, nz), 7.0, dtype=torch.float64, device="cuda"),
                "W": torch.zeros((nodes, nd * nd), dtype=torch.float64, device="cuda"), "w": torch.full((nodes, nd), 7.0, dtype=torch.float64, device="cuda"),
                "dz0": torch.full((B, nz), 7.0, dtype=torch.float64, device="cuda")}
@@ -314,6 +314,10 @@ def test_one_wavefront_assembly_of_problems_without_equality_rows_on_random_patt
             monkeypatch.setenv("UNGAR_AMD_ASSEMBLE_VARIANT", "workgroup")
         else:
             monkeypatch.delenv("UNGAR_AMD_ASSEMBLE_VARIANT", raising=False)
+        if one_node_per_wavefront:
+            monkeypatch.setenv("UNGAR_AMD_ASSEMBLE_ONE_NODE_PER_WAVEFRONT", "1")
+        else:
+            monkeypatch.delenv("UNGAR_AMD_ASSEMBLE_ONE_NODE_PER_WAVEFRONT", raising=False)
         assert lib.ungar_shooting_assemble(ctypes.byref(a), None) == 0, lib.ungar_last_error()
         torch.cuda.synchronize()
         res = {k: v.cpu().numpy() for k, v in out.items()}
@@ -321,6 +325,10 @@ def test_one_wavefront_assembly_of_problems_without_equality_rows_on_random_patt
         return res
 
     mine, theirs = run(False), run(True)
+    if nd + 1 <= 16:  # narrow rows: the default route packs four nodes into a wavefront -- same arithmetic in the same order as one node per wavefront
+        single = run(False, one_node_per_wavefront=True)
+        for key in ("W", "w", "AB", "b", "dz0"):
+            assert np.array_equal(mine[key], single[key]), key
     assert np.abs(theirs["W"]).max() > 1.0 and np.abs(theirs["AB"]).max() > 0.1 and not (theirs["b"] == 7.0).any()
     for key in ("W", "w", "AB", "b", "dz0"):
         scale = np.abs(theirs[key]).max()

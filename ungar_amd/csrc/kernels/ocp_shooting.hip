@@ -761,6 +761,135 @@ __global__ __launch_bounds__(64) void ShootingAssembleSmallKernel(const Shooting
     }
 }
 
+/// SEVERAL NODES per wavefront for the narrow stage problems without equality rows: G = 16 lanes per node (nd + 1 <= G: the RC car's 11 columns),
+/// 64 / G nodes per wavefront, each group with its own LDS images.  The kernel above is bound by the number of instructions it issues per node
+/// (~2.5 k SIMD cycles per node whatever the size: 127 us per 4096 x 31 RC-car nodes whose results are 30 us of traffic) and most of its lanes carry nothing
+/// when a row has 11 columns; here one instruction works on four nodes (127 -> 52 us).  Same arithmetic in the same order as the kernel above (bitwise the same results):
+/// sparse values requested first, scatter into the packed image of W_e and the image of [A|B]_e, barrier terms row by row (one lane per entry of the inequality
+/// Jacobian, its partners one after the other), regularisation, every dense block written once.
+template <int G, int SLOTS>  // SLOTS: G-entry batches of a sparse pattern the lanes hold in registers (2, 4, 8)
+__global__ __launch_bounds__(64) void ShootingAssemblePackedKernel(const ShootingAssembleArgs a) {
+    extern __shared__ double lds[];
+    constexpr int kNodes = 64 / G, kSlots = SLOTS, kCarrySlots = SLOTS / 2;
+    const ShootingDims& d = a.d;
+    const int lane = static_cast<int>(threadIdx.x), gl = lane & (G - 1), sub = lane / G;
+    const long long nodes = static_cast<long long>(d.batch) * (d.N + 1), nodeRaw = static_cast<long long>(blockIdx.x) * kNodes + sub;
+    const bool live = nodeRaw < nodes;  // (a group beyond the last node works on the last node once more and stores nothing)
+    const long long node = live ? nodeRaw : nodes - 1;
+    const long long b = node / (d.N + 1);
+    const int k = static_cast<int>(node - b * (d.N + 1));
+    const int nc = d.nc, nx = d.nx, nz = d.nz(), nd = d.nd(), nh1 = nd + 1, nh = a.nh;  // (column nd: the linear terms)
+    const bool stage = k < d.N;
+    const int nW = nh1 * (nh1 + 1) / 2, nAB = nz * nh1;
+    const int perNode = ((nW + 1) & ~1) + ((nAB + 1) & ~1) + 2 * nh;
+    double* R = lds + sub * perNode;    // packed upper triangle of W_e
+    double* ABi = R + ((nW + 1) & ~1);  // nz x (nd + 1)
+    double* d1 = ABi + ((nAB + 1) & ~1);
+    double* d2 = d1 + nh;
+    auto tri = [nh1](int r, int c) { return ((r * (2 * nh1 + 1 - r)) >> 1) + (c - r); };  // r <= c < nd + 1
+    auto fence = [] { asm volatile("" ::: "memory"); };
+    const long long stageOff = b * d.N + k;
+    struct Raw {
+        int r, c;  // r < 0: nothing
+        double value;
+    };
+    auto request = [&](const StagePattern& pattern, const double* values, bool wanted, int slot) {
+        Raw f{-1, 0, 0.0};
+        const int e = gl + G * slot;
+        if (wanted && values && e < pattern.nnz) {
+            f.r = pattern.rows[e];
+            f.c = pattern.cols[e];
+            f.value = values[node * pattern.nnz + e];
+        }
+        return f;
+    };
+    Raw rH[kSlots], rF[kSlots], rC[kCarrySlots];
+#pragma unroll
+    for (int s = 0; s < kSlots; ++s) rH[s] = request(a.pH, a.lH, true, s);
+    const Raw rG = request(a.pg, a.lg, true, 0);
+    const Raw rI = request(a.ph, a.hJ, stage && nh > 0, 0);
+    const double hMine = stage && a.h && gl < nh ? a.h[node * nh + gl] : 0.0;
+#pragma unroll
+    for (int s = 0; s < kSlots; ++s) rF[s] = request(a.pf, a.fJ, stage, s);
+#pragma unroll
+    for (int s = 0; s < kCarrySlots; ++s) rC[s] = request(a.pc, a.cJ, stage && !d.carryInputs, s);
+    const bool stateLane = gl >= nc && gl < nz;
+    const double fMine = stage && stateLane ? a.f[node * nx + (gl - nc)] : 0.0;
+    const double nextMine = stage && gl < nz ? RowOf(a.rows, d, b, k + 1)[gl] : 0.0;
+    const double xmMine = k == 0 && stateLane ? a.xm[b * nx + (gl - nc)] : 0.0;
+    const double row0Mine = k == 0 && gl < nz ? RowOf(a.rows, d, b, 0)[gl] : 0.0;
+    // ---- images
+    for (int i = gl; i < perNode; i += G) R[i] = 0.0;
+    fence();
+#pragma unroll
+    for (int s = 0; s < kSlots; ++s)
+        if (rH[s].r >= 0 && rH[s].r <= rH[s].c) R[tri(rH[s].r, rH[s].c)] = rH[s].value;  // (Function::Hessian's pattern is upper triangular; anything below the diagonal is ignored)
+    if (rG.r >= 0) R[tri(rG.c, nd)] = rG.value;
+    if (stage) {
+#pragma unroll
+        for (int s = 0; s < kSlots; ++s)
+            if (rF[s].r >= 0) ABi[(nc + rF[s].r) * nh1 + nc + rF[s].c] = rF[s].value;
+        if (d.carryInputs) {
+            if (gl < nc) ABi[gl * nh1 + nz + gl] = 1.0;
+        } else {
+#pragma unroll
+            for (int s = 0; s < kCarrySlots; ++s)
+                if (rC[s].r >= 0) ABi[rC[s].r * nh1 + nc + rC[s].c] = rC[s].value;
+        }
+        if (stateLane) ABi[gl * nh1 + nd] = fMine - nextMine;
+        if (gl < nh) {
+            d1[gl] = BarrierD1(a.barrier, -hMine);
+            d2[gl] = BarrierD2(a.barrier, -hMine);
+        }
+    }
+    fence();
+    // ---- barrier terms  W += J_h^T diag(b''(-h)) J_h,  w -= J_h^T b'(-h):  lane e of a group holds entry e of its node's inequality Jacobian (the entries of a row
+    // are consecutive, columns ascending) and owns the pairs (e, e + q) of its row; row by row, in order (rows share targets; LDS instructions of a wavefront execute in order)
+    if (nh > 0) {
+        const int myRow = rI.r, nnz = a.ph.nnz;
+        const int nextRow = __shfl_down(myRow, 1);
+        const unsigned long long rowEnds = __ballot(myRow >= 0 && (gl == nnz - 1 || nextRow != myRow));
+        const int partners = myRow >= 0 ? __ffsll(static_cast<unsigned long long>(rowEnds >> lane)) : 0;  // entries of the same row from this one on (never beyond the group: its last entry ends a row)
+        const double d1Mine = myRow >= 0 ? d1[myRow] : 0.0, d2Mine = myRow >= 0 ? d2[myRow] : 0.0;
+        for (int j = 0; j < nh; ++j) {
+            if (myRow == j) {
+                const int gTarget = tri(rI.c, nd);
+                R[gTarget] = __builtin_fma(-d1Mine, rI.value, R[gTarget]);
+            }
+            for (int q = 0; __ballot(myRow == j && q < partners) != 0ull; ++q) {
+                const int c2 = __shfl(rI.c, lane + q);
+                const double v2 = __shfl(rI.value, lane + q);
+                if (myRow == j && q < partners) {
+                    const int target = tri(rI.c, c2);
+                    R[target] = __builtin_fma(d2Mine * rI.value, v2, R[target]);
+                }
+            }
+            fence();
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (gl >= nc && gl < (stage ? nd : nz)) R[tri(gl, gl)] += a.regularization;  // the reference's 1e-6 I over its decision variables (soft_sqp.hpp:149-151)
+    fence();
+    // ---- results
+    if (!live) return;
+    const float ndInv = 1.0f / static_cast<float>(nd);
+    double* W = a.W + node * nd * nd;
+    for (int idx = gl; idx < nd * nd; idx += G) {
+        const int r = static_cast<int>((static_cast<float>(idx) + 0.5f) * ndInv), c = idx - r * nd;
+        if (r <= c) W[idx] = R[tri(r, c)];
+    }
+    if (gl < nd) a.w[node * nd + gl] = R[tri(gl, nd)];
+    if (stage) {
+        double* AB = a.AB + stageOff * nz * nd;
+        for (int idx = gl; idx < nz * nd; idx += G) {
+            const int r = static_cast<int>((static_cast<float>(idx) + 0.5f) * ndInv);
+            AB[idx] = ABi[r * nh1 + (idx - r * nd)];
+        }
+        if (gl < nz) a.b[stageOff * nz + gl] = ABi[gl * nh1 + nd];
+        if (k == 0 && gl < nz) a.dz0[b * nz + gl] = gl >= nc ? xmMine - row0Mine : 0.0;
+    }
+}
+
 /// FOUR lanes per (stage node, reduced row): lane q of a quad sums the columns q, q + 4, ... of its row, the quad adds up with two DPP moves.  (One lane per row
 /// read its 49 coefficients one after the other, 392 bytes from its neighbour's: 64 separate 8-byte segments per load instruction, 0.29 ms per 4096 x 30 x 16
 /// quadruped rows; four adjacent lanes read 32 consecutive bytes.)
@@ -1055,6 +1184,28 @@ extern "C" int ungar_amd_shooting_assemble_route(int nz, int nu, int ne, int nh,
     return 2;
 }
 
+/// Several nodes per wavefront for the narrow ones of those problems (0: launched; -1: not applicable).
+static int LaunchAssemblePacked(const ShootingAssembleArgs* a, void* stream) {
+    const ShootingDims& d = a->d;
+    const int nd = d.nd(), nz = d.nz(), nh1 = nd + 1;
+    // (rows of up to 16 columns only.  With 32 lanes per node the quadrotor's 26 columns were measured too: 297 against 273 us per 4096 x 31 nodes -- its dense blocks are
+    // 0.9 GB per launch, the loops that write them cost the same number of instructions per node either way and cover 256 instead of 512 contiguous bytes per instruction.)
+    constexpr int G = 16;
+    if (a->ne != 0 || nh1 > G) return -1;
+    if (a->nh > G || (a->nh > 0 && a->ph.nnz > G) || a->pH.nnz > 8 * G || a->pg.nnz > G || a->pf.nnz > 8 * G || (!d.carryInputs && a->pc.nnz > 4 * G)) return -1;
+    const int widest = std::max(std::max(a->pH.nnz, a->pf.nnz), d.carryInputs ? 0 : 2 * a->pc.nnz);
+    const long long nodes = static_cast<long long>(d.batch) * (d.N + 1);
+    const int perWave = 64 / G;
+    const std::size_t lds = static_cast<std::size_t>(perWave) * ((((nh1 * (nh1 + 1) / 2) + 1) & ~1) + ((nz * nh1 + 1) & ~1) + 2 * static_cast<std::size_t>(a->nh)) * sizeof(double);
+    const dim3 grid(static_cast<unsigned>((nodes + perWave - 1) / perWave));
+#define UNGAR_PACKED(SS) hipLaunchKernelGGL((ShootingAssemblePackedKernel<G, SS>), grid, dim3(64), lds, static_cast<hipStream_t>(stream), *a)
+    if (widest <= 2 * G) UNGAR_PACKED(2);
+    else if (widest <= 4 * G) UNGAR_PACKED(4);
+    else UNGAR_PACKED(8);
+#undef UNGAR_PACKED
+    return 0;
+}
+
 /// The one-wavefront kernel for stage problems without equality rows (0: launched; -1: not applicable).
 static int LaunchAssembleSmall(const ShootingAssembleArgs* a, void* stream) {
     const ShootingDims& d = a->d;
@@ -1071,6 +1222,8 @@ extern "C" int ungar_amd_launch_shooting_assemble(const ShootingAssembleArgs* a,
         const char* variant = UNGAR_MEASUREMENT_SWITCH("UNGAR_AMD_ASSEMBLE_VARIANT");  // "workgroup": the kernel below for every shape (measurement, A/B tests); read per call
         if (!(variant && variant[0] == 'w')) {
             if (LaunchAssembleWave<25, 24, 16>(a, stream) == 0) return static_cast<int>(hipGetLastError());
+            const bool onePerWave = UNGAR_MEASUREMENT_SWITCH("UNGAR_AMD_ASSEMBLE_ONE_NODE_PER_WAVEFRONT") != nullptr;  // A/B switch (read per call): the kernel with one node per wavefront for the narrow problems too
+            if (!onePerWave && LaunchAssemblePacked(a, stream) == 0) return static_cast<int>(hipGetLastError());
             if (LaunchAssembleSmall(a, stream) == 0) return static_cast<int>(hipGetLastError());
             if (LaunchAssembleWaveFactory(a, stream) == 0) return static_cast<int>(hipGetLastError());
         }
