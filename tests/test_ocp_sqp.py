@@ -314,7 +314,8 @@ gpu = pytest.mark.gpu
 
 
 @gpu
-@pytest.mark.parametrize("nx,nu,N,batch", [(13, 4, 30, 257), (13, 24, 10, 33), (37, 12, 20, 9), (6, 2, 200, 16), (25, 24, 30, 17), (37, 12, 3, 1), (13, 24, 1, 65), (17, 4, 30, 70)])
+@pytest.mark.parametrize("nx,nu,N,batch", [(13, 4, 30, 257), (13, 24, 10, 33), (37, 12, 20, 9), (6, 2, 200, 16), (25, 24, 30, 17), (37, 12, 3, 1), (13, 24, 1, 65), (17, 4, 30, 70),
+                                           (8, 2, 30, 257), (6, 2, 30, 131), (3, 1, 5, 7), (2, 6, 7, 5), (9, 2, 10, 6), (1, 1, 4, 3)])  # second line: the narrow blocks (LDS-resident kernels, run-time sizes)
 def test_device_riccati_equals_the_dense_kkt_solve(nx, nu, N, batch):
     import torch
     from ungar_amd import sqp
