@@ -28,10 +28,12 @@ extern "C" {
 
 /* ABI version of THIS header.  It changes whenever a struct below grows or an entry point's parameter list changes (4: ungar_ocp_qp with its
  * equality-row fields, `status` in ungar_ocp_line_search_select / _accept; 5: `instances` in ungar_shooting_merit_args, the entry points
- * ungar_shooting_trial_rows_listed / ungar_shooting_select_listed of the staged line search).  ungar_abi_version() returns the version the LIBRARY was built with:
+ * ungar_shooting_trial_rows_listed / ungar_shooting_select_listed of the staged line search; 6: the entry points the C++ driver of round 5 calls --
+ * ungar_shooting_trial_elements, ungar_function_{forward_zero,sparse_jacobian,sparse_hessian}_nodes_split, ungar_ocp_riccati_route, ungar_shooting_assemble_route,
+ * ungar_measurement_build -- so that a driver header never meets a library without them).  ungar_abi_version() returns the version the LIBRARY was built with:
  * a wrapper compiled against an older header must compare the two before its first call -- a mismatch silently shifts arguments otherwise.
  * (ungar_amd/__init__.py and Ungar::BatchedSoftSQPOptimizer do.) */
-#define UNGAR_AMD_ABI_VERSION 5
+#define UNGAR_AMD_ABI_VERSION 6
 int32_t ungar_abi_version(void);
 
 #define UNGAR_OK 0

@@ -71,7 +71,7 @@ class _NodeBatch(ctypes.Structure):
 _LIB = None
 
 
-ABI_VERSION = 5  # UNGAR_AMD_ABI_VERSION of include/ungar_amd.h these bindings mirror
+ABI_VERSION = 6  # UNGAR_AMD_ABI_VERSION of include/ungar_amd.h these bindings mirror
 
 
 def _share_the_hip_runtime_of_torch() -> None:
