@@ -27,8 +27,12 @@ using namespace Ungar;
 #endif
 constexpr index_t NX = USER_NX, NU = USER_NU, NE = USER_NE, N = 12;
 constexpr index_t NH = 2 * NU;                 // input bounds -1.5 <= u_j <= 1.5
-constexpr index_t KNOT = NX + 1 + NE;          // knot parameters: reference state, input weight, right-hand sides of the equality rows
-constexpr index_t INST = 2;                    // instance parameters: step size, gain of the nonlinear term
+#ifndef USER_PARAMETERS
+#define USER_PARAMETERS 1  // 0: the same problem with constant data -- a ShootingProblem WITHOUT knot and instance parameters (its rows are [x | u] alone)
+#endif
+constexpr bool kParameters = USER_PARAMETERS != 0;
+constexpr index_t KNOT = kParameters ? NX + 1 + NE : 0;  // knot parameters: reference state, input weight, right-hand sides of the equality rows
+constexpr index_t INST = kParameters ? 2 : 0;            // instance parameters: step size, gain of the nonlinear term
 constexpr index_t DEC = (N + 1) * NX + N * NU; // whole horizon: z = (X, U)
 constexpr index_t PAR = (N + 1) * KNOT + INST + NX;  // (knot parameters of every knot, instance parameters, measured state)
 
@@ -58,6 +62,23 @@ static ad_scalar_t StageCost(const X& x, const U& u, const P& knot) {
     return value;
 }
 
+struct KnotView {  // the knot parameters at `offset` of v, or the constants that stand for them
+    const VectorXad& v;
+    index_t offset;
+    ad_scalar_t operator[](index_t e) const {
+        if constexpr (kParameters) return v[offset + e];
+        else return ad_scalar_t{e < NX ? 0.5 * std::sin(static_cast<real_t>(e)) : (e == NX ? 0.05 : 0.1 * static_cast<real_t>(e - NX))};
+    }
+};
+static ad_scalar_t StepSize(const VectorXad& v, index_t offset) {
+    if constexpr (kParameters) return v[offset];
+    else return ad_scalar_t{0.08};
+}
+static ad_scalar_t Gain(const VectorXad& v, index_t offset) {
+    if constexpr (kParameters) return v[offset + 1];
+    else return ad_scalar_t{0.3};
+}
+
 struct Slice {  // view of a VectorXad
     const VectorXad& v;
     index_t offset;
@@ -67,14 +88,18 @@ struct Slice {  // view of a VectorXad
 int main(int argc, char** argv) {
     const std::string folder = argc > 1 ? argv[1] : "/tmp/ungar_amd_batched_user";
     const index_t batch = argc > 2 ? std::atol(argv[2]) : 256, compared = argc > 3 ? std::atol(argv[3]) : 4;
-    const std::string tag = "user_" + std::to_string(NX) + "_" + std::to_string(NU) + "_" + std::to_string(NE);
+    const std::string tag = "user_" + std::to_string(NX) + "_" + std::to_string(NU) + "_" + std::to_string(NE) + (kParameters ? "" : "_const");
     try {
         // ---- whole-horizon problem: z = (X, U), parameters = (knot parameters x (N + 1), dt, gain, measured state)
         auto knotOf = [](index_t k) { return DEC + k * KNOT; };
         const index_t instOffset = DEC + (N + 1) * KNOT, measuredOffset = instOffset + INST;
         const auto objective = [&](const VectorXad& v, VectorXad& y) {
             ad_scalar_t value{0.0};
-            for (index_t k = 0; k <= N; ++k) value += StageCost(Slice{v, k * NX}, Slice{v, (N + 1) * NX + (k < N ? k : N - 1) * NU}, Slice{v, knotOf(k)});  // (input weight 0 at knot N)
+            for (index_t k = 0; k < N; ++k) value += StageCost(Slice{v, k * NX}, Slice{v, (N + 1) * NX + k * NU}, KnotView{v, knotOf(k)});
+            {  // knot N: the state part (with parameters: input weight 0 at knot N; without: the inputs of row N are zero)
+                const KnotView knot{v, knotOf(N)};
+                for (index_t i = 0; i < NX; ++i) value += (1.0 + 0.1 * static_cast<real_t>(i)) * (v[N * NX + i] - knot[i]) * (v[N * NX + i] - knot[i]);
+            }
             y.resize(1);
             y << value;
         };
@@ -82,11 +107,11 @@ int main(int argc, char** argv) {
             Autodiff::VectorComposer composer;
             for (index_t i = 0; i < NX; ++i) composer << v[i] - v[measuredOffset + i];
             for (index_t k = 0; k < N; ++k) {
-                const VectorXad next = Dynamics(Slice{v, k * NX}, Slice{v, (N + 1) * NX + k * NU}, v[instOffset], v[instOffset + 1]);
+                const VectorXad next = Dynamics(Slice{v, k * NX}, Slice{v, (N + 1) * NX + k * NU}, StepSize(v, instOffset), Gain(v, instOffset));
                 for (index_t i = 0; i < NX; ++i) composer << v[(k + 1) * NX + i] - next[i];
             }
             for (index_t k = 0; k < N; ++k)
-                for (index_t j = 0; j < NE; ++j) composer << v[(N + 1) * NX + k * NU + j] + 0.3 * v[k * NX + j] - v[knotOf(k) + NX + 1 + j];
+                for (index_t j = 0; j < NE; ++j) composer << v[(N + 1) * NX + k * NU + j] + 0.3 * v[k * NX + j] - KnotView{v, knotOf(k)}[NX + 1 + j];
             y = composer.Compose();
         };
         const auto inequality = [&](const VectorXad& v, VectorXad& y) {
@@ -104,10 +129,10 @@ int main(int argc, char** argv) {
 
         // ---- the same problem in stage form: row = [x | u | knot parameters | instance parameters]
         const index_t nxu = NX + NU, nPar = KNOT + INST;
-        const auto stageDynamics = [&](const VectorXad& v, VectorXad& y) { y = Dynamics(Slice{v, 0}, Slice{v, NX}, v[nxu + KNOT], v[nxu + KNOT + 1]); };
+        const auto stageDynamics = [&](const VectorXad& v, VectorXad& y) { y = Dynamics(Slice{v, 0}, Slice{v, NX}, StepSize(v, nxu + KNOT), Gain(v, nxu + KNOT)); };
         const auto stageCost = [&](const VectorXad& v, VectorXad& y) {
             y.resize(1);
-            y << StageCost(Slice{v, 0}, Slice{v, NX}, Slice{v, nxu});
+            y << StageCost(Slice{v, 0}, Slice{v, NX}, KnotView{v, nxu});
         };
         const auto stageInequality = [&](const VectorXad& v, VectorXad& y) {
             Autodiff::VectorComposer composer;
@@ -119,7 +144,7 @@ int main(int argc, char** argv) {
         };
         const auto stageEquality = [&](const VectorXad& v, VectorXad& y) {
             Autodiff::VectorComposer composer;
-            for (index_t j = 0; j < NE; ++j) composer << v[NX + j] + 0.3 * v[j] - v[nxu + NX + 1 + j];
+            for (index_t j = 0; j < NE; ++j) composer << v[NX + j] + 0.3 * v[j] - KnotView{v, nxu}[NX + 1 + j];
             y = composer.Compose();
         };
         ShootingProblem problem;
@@ -150,15 +175,19 @@ int main(int argc, char** argv) {
             VectorXr v{DEC + PAR};
             v.setZero();
             for (index_t i = 0; i < NX; ++i) v[measuredOffset + i] = 0.3 * normal(rng);
-            v[instOffset] = 0.08 * (1.0 + 0.1 * normal(rng));
-            v[instOffset + 1] = 0.3 * (1.0 + 0.2 * normal(rng));
+            if constexpr (kParameters) {
+                v[instOffset] = 0.08 * (1.0 + 0.1 * normal(rng));
+                v[instOffset + 1] = 0.3 * (1.0 + 0.2 * normal(rng));
+            }
             for (index_t k = 0; k <= N; ++k) {
                 for (index_t i = 0; i < NX; ++i) {
-                    v[knotOf(k) + i] = 0.5 * std::sin(0.3 * static_cast<real_t>(k) + static_cast<real_t>(i)) + 0.05 * normal(rng);
+                    if constexpr (kParameters) v[knotOf(k) + i] = 0.5 * std::sin(0.3 * static_cast<real_t>(k) + static_cast<real_t>(i)) + 0.05 * normal(rng);
                     v[k * NX + i] = v[measuredOffset + i] + 0.05 * normal(rng);
                 }
-                v[knotOf(k) + NX] = k < N ? 0.05 : 0.0;
-                for (index_t j = 0; j < NE; ++j) v[knotOf(k) + NX + 1 + j] = 0.2 * normal(rng);
+                if constexpr (kParameters) {
+                    v[knotOf(k) + NX] = k < N ? 0.05 : 0.0;
+                    for (index_t j = 0; j < NE; ++j) v[knotOf(k) + NX + 1 + j] = 0.2 * normal(rng);
+                }
             }
             for (index_t k = 0; k < N; ++k)
                 for (index_t j = 0; j < NU; ++j) v[(N + 1) * NX + k * NU + j] = (b % 3 == 0 ? 1.45 : 0.3) * normal(rng) * (b % 3 == 0 ? 0.3 : 1.0) + (b % 3 == 0 ? 1.2 : 0.0);  // every third instance near the bound
@@ -170,10 +199,12 @@ int main(int argc, char** argv) {
             for (index_t k = 0; k <= N; ++k) {
                 real_t* row = rows.data() + (b * (N + 1) + k) * nv;
                 for (index_t i = 0; i < NX; ++i) row[i] = v[k * NX + i];
-                for (index_t j = 0; j < NU; ++j) row[NX + j] = v[(N + 1) * NX + (k < N ? k : N - 1) * NU + j];
+                for (index_t j = 0; j < NU; ++j) row[NX + j] = k < N ? v[(N + 1) * NX + k * NU + j] : 0.0;
                 for (index_t i = 0; i < KNOT; ++i) row[nxu + i] = v[knotOf(k) + i];
-                row[nxu + KNOT] = v[instOffset];
-                row[nxu + KNOT + 1] = v[instOffset + 1];
+                if constexpr (kParameters) {
+                    row[nxu + KNOT] = v[instOffset];
+                    row[nxu + KNOT + 1] = v[instOffset + 1];
+                }
             }
             for (index_t i = 0; i < NX; ++i) xm[static_cast<std::size_t>(b * NX + i)] = v[measuredOffset + i];
         }
@@ -259,7 +290,7 @@ int main(int argc, char** argv) {
                         iteration, moved, batch, worstStep, worstIterate, worstAlpha);
         }
         const bool ok = worstStep <= 1e-9 && worstIterate <= 1e-9 && worstAlpha <= 1e-9;
-        std::printf("%s batched user OCP %td + %td, %td equality rows (batch %td, %td compared)\n", ok ? "PASS" : "FAIL", NX, NU, NE, batch, compared);
+        std::printf("%s batched user OCP %td + %td, %td equality rows%s (batch %td, %td compared)\n", ok ? "PASS" : "FAIL", NX, NU, NE, kParameters ? "" : ", no parameters", batch, compared);
         return ok ? 0 : 1;
     } catch (const std::exception& e) {
         std::printf("EXCEPTION %s\n", e.what());

@@ -125,17 +125,17 @@ def test_line_search_candidates_in_groups_give_the_same_iterates(repo_root, shar
     assert r.returncode == 0 and "PASS batched rc_car SQP (batch 512, 8 compared)" in r.stdout
 
 
-@pytest.mark.parametrize("sizes", [(10, 3, 0), (20, 9, 4)], ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("sizes", [(10, 3, 0, ""), (20, 9, 4, ""), (10, 3, 2, "_const")], ids=lambda s: "x".join(map(str, s)))
 def test_user_problems_of_sizes_the_library_was_not_compiled_for(repo_root, shared_codegen, sizes):
     """The reference's optimiser takes ANY problem (optimization/concepts.hpp:153-262).  Two user OCPs whose stage sizes have no prebuilt solver kernels
     (10 + 3; 20 + 9 with 4 stage equality rows) through the batched driver: the program asserts that the register-resident Riccati recursion and the
     one-wavefront assembly INSTANTIATED FOR THE SIZES by the kernel factory ran (RiccatiRoute() == 2; AssembleRoute() == 2, or 3 without equality
     rows), and compares search direction, step size and iterate with the facade's sparse KKT solve of the whole-horizon statement over two iterations
     (<= 1e-9)."""
-    nx, nu, ne = sizes
-    exe = os.path.join(repo_root, "build", f"batched_user_ocp_test_{nx}_{nu}_{ne}")
+    nx, nu, ne, variant = sizes  # variant "_const": the same problem with constant data -- no knot / instance parameters, the rows are [x | u] alone
+    exe = os.path.join(repo_root, "build", f"batched_user_ocp_test_{nx}_{nu}_{ne}{variant}")
     assert os.path.exists(exe), f"{exe} missing: run __graft_entry__.build()"
-    r = subprocess.run([exe, str(shared_codegen(f"batched_user_{nx}_{nu}_{ne}")), "256", "4"], capture_output=True, text=True, timeout=1500)
+    r = subprocess.run([exe, str(shared_codegen(f"batched_user_{nx}_{nu}_{ne}{variant}")), "256", "4"], capture_output=True, text=True, timeout=1500)
     print(r.stdout[-4000:], r.stderr[-2000:])
     assert r.returncode == 0 and f"PASS batched user OCP {nx} + {nu}, {ne} equality rows" in r.stdout
 

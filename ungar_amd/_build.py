@@ -197,11 +197,11 @@ def build_cpp_tests():
         jobs.append(cmd)
     # a user's OCP of stage sizes the library holds no prebuilt solver kernels for (tests/test_batched_sqp.py): two instantiations of one source
     user_src = os.path.join(ROOT, "tests", "cpp", "batched_user_ocp_test.cpp")
-    for nx, nu, ne in ((10, 3, 0), (20, 9, 4)):
-        exe = os.path.join(BUILD, f"batched_user_ocp_test_{nx}_{nu}_{ne}")
+    for nx, nu, ne, parameters in ((10, 3, 0, 1), (20, 9, 4, 1), (10, 3, 2, 0)):  # (the last one: constant problem data -- a ShootingProblem without knot / instance parameters)
+        exe = os.path.join(BUILD, f"batched_user_ocp_test_{nx}_{nu}_{ne}" + ("" if parameters else "_const"))
         if not _newer([exe], [user_src, *hdrs, LIB]):
-            jobs.append(["g++", "-std=c++20", "-O1", f"-DUSER_NX={nx}", f"-DUSER_NU={nu}", f"-DUSER_NE={ne}", "-I", inc, "-o", exe, user_src, "-L", LIBDIR, "-lungar_amd",
-                         "-Wl,-rpath,$ORIGIN/../ungar_amd/lib", "-Wl,-rpath,/opt/rocm/lib"])
+            jobs.append(["g++", "-std=c++20", "-O1", f"-DUSER_NX={nx}", f"-DUSER_NU={nu}", f"-DUSER_NE={ne}", f"-DUSER_PARAMETERS={parameters}", "-I", inc, "-o", exe, user_src, "-L", LIBDIR,
+                         "-lungar_amd", "-Wl,-rpath,$ORIGIN/../ungar_amd/lib", "-Wl,-rpath,/opt/rocm/lib"])
     # reference-side adapter of INTEGRATION.md section 2 (include/ungar_amd_model.hpp): plain C++17, no facade headers
     amd_src, amd_exe = os.path.join(ROOT, "tests", "cpp", "amd_model_test.cpp"), os.path.join(BUILD, "amd_model_test")
     if not _newer([amd_exe], [amd_src, os.path.join(ROOT, "include", "ungar_amd_model.hpp"), os.path.join(ROOT, "include", "ungar_amd.h"), LIB]):
