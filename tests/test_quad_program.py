@@ -206,3 +206,22 @@ def test_split_program_reads_every_message_inside_its_window(repo_root):
         waited = waited or "io.wait_acc()" in line
         assert waited or "io.acc(" not in line, line
     assert waited
+
+
+@pytest.mark.gpu
+def test_split_kernel_on_the_device_equals_the_fused_kernel(repo_root):
+    """The producer / consumer program at TWO wavefronts per SIMD (not the product's route -- it is slower than the fused kernel, whose result
+    stores bound both) on the device: every value and every entry of the 81 920-node launch (BASELINE config 4: 148 520 960 Jacobian entries) against the fused kernel,
+    for the split kernel with 8- and with paired 16-byte stores and for the fused kernel with paired stores; no entry left unwritten; differences at rounding level
+    (the two programs contract some sums in a different order)."""
+    import re
+    exe = os.path.join(repo_root, "build", "variants", "quad_split_bench")
+    assert os.path.exists(exe), f"{exe} missing: run __graft_entry__.build()"
+    r = subprocess.run([exe, "check", "81920"], capture_output=True, text=True, timeout=900)
+    print(r.stdout[-3000:], r.stderr[-1000:])
+    assert r.returncode == 0
+    lines = re.findall(r"check (.+?)\s+vs reference: max \|dJ\| (\S+) \(max \|J\| (\S+)\), max \|df\| (\S+), unwritten (\d+), entries that differ (\d+) of (\d+)", r.stdout)
+    assert len(lines) >= 3 and any(name.startswith("split") for name, *_ in lines), r.stdout[-2000:]
+    for name, dj, scale, df, unwritten, _, entries in lines:
+        assert int(unwritten) == 0 and int(entries) == 1813 * 81920, name
+        assert float(dj) <= 1e-11 * float(scale) and float(df) <= 1e-11, (name, dj, scale, df)

@@ -287,6 +287,12 @@ def build_tools():
         exe = os.path.join(out, name)
         if not _newer([exe], [src, *deps]):
             _run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-result", "-Wno-unused-value", "-o", exe, src])
+    # the headline kernel's producer / consumer program at two wavefronts per SIMD next to the fused kernel: every entry of a launch
+    # compared on the device (tests/test_quad_program.py), timings and counters (tools/gpu_split_occupancy.sh)
+    split_src, split_exe = os.path.join(ROOT, "tools", "quad_split_bench.hip"), os.path.join(BUILD, "variants", "quad_split_bench")
+    split_deps = [split_src, os.path.join(BUILD, "ungar_codegen"), os.path.join(ROOT, "tools", "make_split_bench.sh")] + _tree(os.path.join(CSRC, "kernels"), os.path.join(CSRC, "codegen"), os.path.join(CSRC, "tape"))
+    if not _newer([split_exe], split_deps):
+        _run(["bash", os.path.join(ROOT, "tools", "make_split_bench.sh")])
 
 
 def build_all():
