@@ -162,7 +162,7 @@ int main(int argc, char** argv) {
         BatchedSoftSQPOptimizer batched{std::move(problem), batch, false, multiplier, 2, 100.0, 1e-2};
         std::printf("routes: riccati %d, assembly %d (2: instantiated for these sizes by the kernel factory; 3: run-time-size one-wavefront assembly)\n", batched.RiccatiRoute(),
                     batched.AssembleRoute());
-        if (batched.RiccatiRoute() != 2 || batched.AssembleRoute() != (NE > 0 ? 2 : 3)) {
+        if (!std::getenv("USER_OCP_ANY_ROUTE") && (batched.RiccatiRoute() != 2 || batched.AssembleRoute() != (NE > 0 ? 2 : 3))) {  // (USER_OCP_ANY_ROUTE: soak runs over sizes that take other kernels)
             std::printf("FAIL the register-resident kernels were not taken: %s\n", ungar_last_error());
             return 1;
         }
