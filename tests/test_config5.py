@@ -150,3 +150,21 @@ def test_padded_element_stride_is_bit_identical(ua, mode):
         torch.cuda.synchronize()
         upper = torch.triu(torch.ones((cols, cols), dtype=torch.bool, device="cuda")).reshape(-1)
         assert torch.equal(G[upper][:, :count], G0[upper]) and torch.isnan(G[:, count:]).all() and torch.isnan(G[~upper]).all()
+
+
+@pytest.mark.parametrize("count", [4096 * N, 4090, 34])
+def test_paired_stores_are_bit_identical_to_the_eight_byte_kernel(ua, count):
+    """Where consecutive nodes lie at consecutive addresses and their number is even, the dense ANYmal kernel writes two entries of a column per store instruction
+    (partner nodes exchange one value each with v_permlane16_swap).  An ODD number of nodes takes the kernel with 8-byte stores: the
+    same nodes evaluated as part of an even launch (the headline size; an even count that is not a multiple of a wavefront's 16 nodes; two wavefronts' worth) and as
+    an odd launch must agree bit for bit, and no entry may be left unwritten."""
+    import torch
+    from ungar_amd import workloads as W
+    x, u, _, p = W.synth_device_inputs("anymal", count, 9, torch)
+    f, J = _evaluate(ua, torch, x, u, p, count, knots=1)
+    assert torch.isfinite(f).all() and torch.isfinite(J).all()  # (the outputs start as NaN)
+    odd = count - 1
+    f2, J2 = _evaluate(ua, torch, x[:, :odd].contiguous(), u[:, :odd].contiguous(), p, odd, knots=1)
+    assert torch.equal(f2, f[:, :odd]) and torch.equal(J2, J[:, :odd])
+    f3, J3 = _evaluate(ua, torch, x[:, 1:].contiguous(), u[:, 1:].contiguous(), p, odd, knots=1)  # (shifted by one node: other partners)
+    assert torch.equal(f3, f[:, 1:]) and torch.equal(J3, J[:, 1:])

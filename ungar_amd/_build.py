@@ -76,7 +76,8 @@ def generate(exe: str):
         os.makedirs(d)
     os.makedirs(GEN, exist_ok=True)
     os.makedirs(ORACLE_GEN, exist_ok=True)
-    _run([exe, "--out", tmp_gen, "--c-oracle", tmp_c, "--anymal-robot", robot, "--lds-slots", "320"])
+    # (--quad-pair-stores: the sinks of the lane-per-leg ANYmal program carry two entries of a column -- one 16-byte store in the kernel with paired stores, quad_kernel.hpp: PAIR)
+    _run([exe, "--out", tmp_gen, "--c-oracle", tmp_c, "--anymal-robot", robot, "--lds-slots", "320", "--quad-pair-stores", "1"])
     for src_dir, dst_dir in ((tmp_gen, GEN), (tmp_c, ORACLE_GEN)):
         for name in sorted(os.listdir(src_dir)):
             src, dst = os.path.join(src_dir, name), os.path.join(dst_dir, name)

@@ -59,7 +59,13 @@ extern "C" int ungar_amd_launch_anymal(int mode, const ungar_amd::kernels::NodeL
     const dim3 grid(static_cast<unsigned>((a->count + kBlock / 4 - 1) / (kBlock / 4))), block(kBlock);
     namespace Q = ungar_amd::gen::anymal_quad;
     static const bool noBuffer = UNGAR_MEASUREMENT_SWITCH("UNGAR_AMD_NO_BUFFER_STORES") != nullptr;  // A/B switch for the store path (tools/)
-    if (UseStreamingStores(*a, mode, 37 * 49, 37) && QuadBufferStoresApply(*a) && !noBuffer)
+    static const bool noPairs = UNGAR_MEASUREMENT_SWITCH("UNGAR_AMD_NO_PAIRED_STORES") != nullptr;  // A/B switch: 8-byte stores where the paired 16-byte ones apply
+    // Two entries of a column per store instruction where consecutive nodes lie at consecutive addresses and their number is even (partner nodes exchange one
+    // value each with v_permlane16_swap: DESIGN.md section 4.13 (ii)); bit-identical to the 8-byte kernel below.
+    if (UseStreamingStores(*a, mode, 37 * 49, 37) && QuadBufferStoresApply(*a) && QuadPairStoresApply(*a) && !noBuffer && !noPairs)
+        hipLaunchKernelGGL((QuadNodeKernel<kBlock, Q::kLdsSlots, Q::kLdsUniformSlots, false, true, AnymalQuadBody, NoSparsePlan, unsigned, true, true>), grid, block, 0,
+                           static_cast<hipStream_t>(stream), *a, ctab, AnymalQuadBody{});
+    else if (UseStreamingStores(*a, mode, 37 * 49, 37) && QuadBufferStoresApply(*a) && !noBuffer)
         hipLaunchKernelGGL((QuadNodeKernel<kBlock, Q::kLdsSlots, Q::kLdsUniformSlots, false, true, AnymalQuadBody, NoSparsePlan, unsigned, true>), grid, block, 0,
                            static_cast<hipStream_t>(stream), *a, ctab, AnymalQuadBody{});
     else if (UseStreamingStores(*a, mode, 37 * 49, 37))
