@@ -30,10 +30,11 @@ extern "C" {
  * equality-row fields, `status` in ungar_ocp_line_search_select / _accept; 5: `instances` in ungar_shooting_merit_args, the entry points
  * ungar_shooting_trial_rows_listed / ungar_shooting_select_listed of the staged line search; 6: the entry points the C++ driver of round 5 calls --
  * ungar_shooting_trial_elements, ungar_function_{forward_zero,sparse_jacobian,sparse_hessian}_nodes_split, ungar_ocp_riccati_route, ungar_shooting_assemble_route,
- * ungar_measurement_build -- so that a driver header never meets a library without them).  ungar_abi_version() returns the version the LIBRARY was built with:
+ * ungar_measurement_build -- so that a driver header never meets a library without them; 7: the wave-tile layout of the dense block,
+ * ungar_model_tile_layout / ungar_model_tile_doubles / ungar_model_dense_jacobian_tiles / ungar_tiles_gather).  ungar_abi_version() returns the version the LIBRARY was built with:
  * a wrapper compiled against an older header must compare the two before its first call -- a mismatch silently shifts arguments otherwise.
  * (ungar_amd/__init__.py and Ungar::BatchedSoftSQPOptimizer do.) */
-#define UNGAR_AMD_ABI_VERSION 6
+#define UNGAR_AMD_ABI_VERSION 7
 int32_t ungar_abi_version(void);
 
 #define UNGAR_OK 0
@@ -171,6 +172,40 @@ int ungar_gn_hessian_upper_lanes(const double* jac, int64_t j_es, const double* 
  * (soft_sqp.hpp:257-264). */
 int ungar_gn_hessian_upper_tiles(const double* jac, int64_t j_es, const double* d, int64_t d_es, double* g, int64_t g_es, int64_t g_ns, int64_t ld_g,
                                  int32_t rows, int32_t cols, int64_t count, void* stream);
+
+/* ---- wave tiles: the dense block stored as register images of the wavefronts that compute it --------------------------------
+ * What bounds the widest node kernel ('anymal', 37 x 49) is its result-store path, and the store path wants (a) ONE store instruction =
+ * 1 KiB contiguous and (b) the wavefronts that run at the same time filling one contiguous band together (DESIGN.md sections 3 / 4.5;
+ * profiles/r06a_store_ceiling_*.log: 6.1 TB/s against 5.0-5.4 for every per-entry or per-wavefront layout).  A tile operand is therefore
+ *     [band of `band_tiles` tiles][unit][tile of the band][64 lanes][2 images]
+ * tile = `nodes_per_tile` consecutive nodes (node i = instance * knots + knot); a lane = (leg, node of the tile): lane = 16 * (n / 4) + 4 * leg + n % 4;
+ * an image = one value per lane; unit p = images 2 p and 2 p + 1 side by side per lane (16 bytes per lane, 1 KiB per unit).
+ * Entry (row, col) of the dense block -- row * (nx + nu) + col -- sits in slot 4 * image + leg with entry_of_slot[slot] == entry
+ * (-1: a padding slot, 3 of them); every entry appears exactly once.  Element `slot` of node i:
+ *     t = i / nodes_per_tile, n = i % nodes_per_tile, image = slot / 4, leg = slot % 4, lane = 16 * (n / 4) + 4 * leg + n % 4
+ *     tiles[(((t / band_tiles) * (images / 2) + image / 2) * band_tiles + t % band_tiles) * unit_doubles + 2 * lane + image % 2]
+ * The layout belongs to the MODEL (its generated program decides which entries share a store); only 'anymal' has one.
+ * replaces, for that model, the dense operand of GenericModel::SparseJacobian's values (function.hpp:224-228). */
+typedef struct ungar_tile_layout {
+    int32_t nodes_per_tile;        /* 16 */
+    int32_t band_tiles;            /* 64 */
+    int32_t images;                /* store images per tile (even) */
+    int32_t unit_doubles;          /* 128: two images */
+    int32_t entries;               /* ny * (nx + nu) */
+    int32_t reserved;
+    const int16_t* entry_of_slot;  /* HOST table, 4 * images entries; owned by the library */
+} ungar_tile_layout;
+/* UNGAR_E_UNSUPPORTED for models without a tile program.  Needs no device. */
+int ungar_model_tile_layout(const ungar_model* model, ungar_tile_layout* layout);
+/* Doubles of a tile operand for `count` nodes (whole bands: the last band is padded); < 0 on error. */
+int64_t ungar_model_tile_doubles(const ungar_model* model, int64_t count);
+/* Value (batch->f, may be null) and dense Jacobian of every node of the batch into `tiles` (batch->jac is ignored; tile 0 = nodes 0..15 of the
+ * batch).  Same inputs, same values as ungar_model_dense_jacobian up to the last bit of a few entries (contraction differences between two
+ * compilations of the same program).  replaces GenericModel::SparseJacobian (function.hpp:224-228). */
+int ungar_model_dense_jacobian_tiles(const ungar_model* model, const ungar_node_batch* batch, double* tiles, void* stream);
+/* jac[b * instance_stride + k * knot_stride + entry * element_stride] = tile slot of that entry, for every node (b, k) of `count` nodes with
+ * `knots` knots per instance: a tile operand converted into any strided operand (unit-fastest, node-major, a VariableMap buffer). */
+int ungar_tiles_gather(const ungar_model* model, const double* tiles, int64_t count, int64_t knots, const ungar_operand* jac, void* stream);
 
 /* ---- layout conversion ----------------------------------------------------------------------------------- */
 

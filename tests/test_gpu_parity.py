@@ -242,6 +242,16 @@ def test_full_size_launch_against_the_c_checker_on_every_node(ua, repo_root, nam
     m.dense_jacobian(count, ua.Operand.soa(x, count), ua.Operand.soa(u, count), None, P, ua.Operand.soa(f, count), ua.Operand.soa(J, count))
     torch.cuda.synchronize()
     compare_launch_with_c_checker(name, x, u, p, f, J, count)
+    # The C above is lowered from the product's own tape: a launch-geometry / store-path check.  Against the INDEPENDENT oracle (torch, oracle/ungar_oracle.py) the
+    # same launch is held on 512 nodes spread over it: first and last wavefronts, both sides of the wavefront (64 nodes / 16 for the lane-per-leg kernel), pair
+    # partner, generation (256 CUs x 4 x 64 lanes) and tile boundaries, and random ones.
+    rng = np.random.default_rng(11)
+    edges = np.array([0, 1, 2, 15, 16, 17, 63, 64, 65, 127, 128, 1023, 1024, 1025, 16383, 16384, 16385, 65535, 65536, 65537, count - 65, count - 64, count - 17, count - 16, count - 2, count - 1])
+    sample = np.unique(np.concatenate([edges[edges < count], np.arange(64), count - 1 - np.arange(64), rng.integers(0, count, 600)]))
+    sample = np.sort(rng.permutation(sample)[:512])
+    xs, us = x[:, sample].t().contiguous().cpu().numpy(), u[:, sample].t().contiguous().cpu().numpy()
+    rf, rJ = O.node_jacobian_batched(_oracle_name(name), xs, us, np.zeros((len(sample), O.DIMS[_oracle_name(name)][2])), np.tile(p.cpu().numpy(), (len(sample), 1)))
+    _assert_close(name, f[:, sample].t().cpu().numpy(), J[:, sample].t().cpu().numpy().reshape(len(sample), nx, ncols), rf, rJ)
 
 
 def test_anymal_value_only_program_layouts_and_ragged_counts(ua):

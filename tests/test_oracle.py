@@ -65,6 +65,16 @@ def test_golden_fixtures_are_the_oracle(repo_root, name):
     assert np.array_equal(f, g["f"][sl]) and np.array_equal(J, g["J"][sl])
 
 
+@pytest.mark.parametrize("name", ["quadrotor", "rc_car", "srbd", "anymal"])
+def test_batched_evaluation_of_the_oracle_is_the_oracle(repo_root, name):
+    """node_jacobian_batched (forward mode, vectorised over the batch: what the spread samples of the full-size launches use) against the committed fixtures of
+    node_jacobian (reverse mode, node by node): the same node functions, two differentiation routes."""
+    g = np.load(f"{repo_root}/tests/golden/node_{name}.npz")
+    f, J = O.node_jacobian_batched(name, g["x"], g["u"], g["w"], g["p"])
+    assert np.abs(f - g["f"]).max() <= 1e-12 * max(1.0, np.abs(g["f"]).max())
+    assert np.abs(J - g["J"]).max() <= 1e-12 * np.abs(g["J"]).max()
+
+
 def test_anymal_model_matches_reference_dimensions():
     """test/rbd/robot.test.cpp:103-106 (nq=19, nv=18), SURVEY.md Appendix D (13 moving joints,
     total mass 30.475 kg, leg order LF, LH, RF, RH)."""

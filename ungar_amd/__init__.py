@@ -63,6 +63,11 @@ class _Operand(ctypes.Structure):
                 ("element_stride", ctypes.c_int64)]
 
 
+class _TileLayout(ctypes.Structure):
+    _fields_ = [("nodes_per_tile", ctypes.c_int32), ("band_tiles", ctypes.c_int32), ("images", ctypes.c_int32), ("unit_doubles", ctypes.c_int32),
+                ("entries", ctypes.c_int32), ("reserved", ctypes.c_int32), ("entry_of_slot", ctypes.POINTER(ctypes.c_int16))]
+
+
 class _NodeBatch(ctypes.Structure):
     _fields_ = [("count", ctypes.c_int64), ("knots", ctypes.c_int64), ("x", _Operand), ("u", _Operand), ("w", _Operand),
                 ("p", _Operand), ("f", _Operand), ("jac", _Operand)]
@@ -71,7 +76,7 @@ class _NodeBatch(ctypes.Structure):
 _LIB = None
 
 
-ABI_VERSION = 6  # UNGAR_AMD_ABI_VERSION of include/ungar_amd.h these bindings mirror
+ABI_VERSION = 7  # UNGAR_AMD_ABI_VERSION of include/ungar_amd.h these bindings mirror
 
 
 def _share_the_hip_runtime_of_torch() -> None:
@@ -145,6 +150,11 @@ def load_library() -> ctypes.CDLL:
                                                  ctypes.c_int64, vp]
     lib.ungar_gn_hessian_upper_lanes.argtypes = [vp, ctypes.c_int64, vp, ctypes.c_int64, vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
                                                  ctypes.c_int64, vp]
+    lib.ungar_model_tile_layout.argtypes = [vp, ctypes.POINTER(_TileLayout)]
+    lib.ungar_model_tile_doubles.argtypes = [vp, ctypes.c_int64]
+    lib.ungar_model_tile_doubles.restype = ctypes.c_int64
+    lib.ungar_model_dense_jacobian_tiles.argtypes = [vp, ctypes.POINTER(_NodeBatch), vp, vp]
+    lib.ungar_tiles_gather.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_int64, ctypes.POINTER(_Operand), vp]
     lib.ungar_model_prepare.argtypes = [vp]
     lib.ungar_ocp_equality_sparsity.argtypes = [vp, ctypes.c_int64, vp, vp, i64p]
     lib.ungar_ocp_assemble_equality.argtypes = [vp, ctypes.c_int64, ctypes.c_int64] + [ctypes.POINTER(_Operand)] * 6 + [vp]
@@ -276,6 +286,47 @@ class NodeModel:
         b = self._batch(count, knots, x, u, w, p, f, jac)
         _check(self._lib.ungar_model_dense_jacobian(self._h, ctypes.byref(b), self._stream(stream)))
 
+    # -- wave tiles (include/ungar_amd.h: ungar_tile_layout) -----------------------------------------------------------
+    def tile_layout(self):
+        """dict(nodes_per_tile, band_tiles, images, unit_doubles, entries, entry_of_slot: int16 array of 4 * images) -- needs no device."""
+        l = _TileLayout()
+        _check(self._lib.ungar_model_tile_layout(self._h, ctypes.byref(l)))
+        table = np.ctypeslib.as_array(l.entry_of_slot, shape=(4 * l.images,)).copy()
+        return dict(nodes_per_tile=l.nodes_per_tile, band_tiles=l.band_tiles, images=l.images, unit_doubles=l.unit_doubles, entries=l.entries, entry_of_slot=table)
+
+    def tile_doubles(self, count: int) -> int:
+        n = self._lib.ungar_model_tile_doubles(self._h, count)
+        if n < 0:
+            _check(int(n))
+        return int(n)
+
+    def dense_jacobian_tiles(self, count, x, u, w, p, f, tiles, knots=1, stream=None):
+        """Value into f (may be None) and the dense block of every node into the tile operand `tiles` (1-D float64 CUDA tensor of tile_doubles(count))."""
+        if tiles.numel() < self.tile_doubles(count):
+            raise UngarError(f"tile operand of {tiles.numel()} doubles for {count} nodes: {self.tile_doubles(count)} needed")
+        b = self._batch(count, knots, x, u, w, p, f, None)
+        _check(self._lib.ungar_model_dense_jacobian_tiles(self._h, ctypes.byref(b), ctypes.c_void_p(tiles.data_ptr()), self._stream(stream)))
+
+    def tiles_gather(self, count, tiles, jac, knots=1, stream=None):
+        """Tile operand -> strided dense operand `jac` (device)."""
+        j = jac._c()
+        _check(self._lib.ungar_tiles_gather(self._h, ctypes.c_void_p(tiles.data_ptr()), count, knots, ctypes.byref(j), self._stream(stream)))
+
+    def untile_numpy(self, tiles: np.ndarray, count: int) -> np.ndarray:
+        """Host-side reading of a tile operand through the layout table alone: (count, ny, nx + nu).  Independent of ungar_tiles_gather (tests)."""
+        l = self.tile_layout()
+        i = np.arange(count)
+        t, n = i // l["nodes_per_tile"], i % l["nodes_per_tile"]
+        g, r = t // l["band_tiles"], t % l["band_tiles"]
+        out = np.full((count, l["entries"]), np.nan)
+        for slot, e in enumerate(l["entry_of_slot"]):
+            if e < 0:
+                continue
+            image, leg = slot // 4, slot % 4
+            lane = 16 * (n // 4) + 4 * leg + n % 4
+            out[:, e] = tiles[((g * (l["images"] // 2) + image // 2) * l["band_tiles"] + r) * l["unit_doubles"] + 2 * lane + image % 2]
+        return out.reshape(count, self.ny, self.nx + self.nu)
+
     def sparse_hessian(self, count, x, u, w, p, f, grad, hes, knots=1, stream=None):
         """Scalar (cost) models: value into f, gradient w.r.t. (x, u) into grad (may be None), upper-triangular
         Hessian values (hessian_sparsity order) into hes."""
@@ -326,6 +377,12 @@ class NodeModel:
             t = torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64)
             return (t.t().contiguous() if layout == "soa" else t.contiguous()).to(dev)
 
+        self._tiles_gather_requested = layout == "tiles_gather"
+        tiled = layout in ("tiles", "tiles_gather")  # wave-tile output (dense mode): read on the host through the layout table / gathered on the device
+        if tiled:
+            if mode != "dense":
+                raise UngarError("the wave-tile layout holds the dense block")
+            layout = "soa"
         xt, ut, wt = up(x, self.nx), up(u, self.nu), up(w, self.nw)
         pt = torch.as_tensor(np.ascontiguousarray(p), dtype=torch.float64).to(dev) if self.np else None
         if layout == "soa":
@@ -342,7 +399,16 @@ class NodeModel:
             torch.cuda.synchronize()
             f = ft.cpu().numpy()
             return (f.T.copy() if layout == "soa" else f), None
-        (self.sparse_jacobian if mode == "sparse" else self.dense_jacobian)(*args, mk(jt, nj))
+        if tiled:
+            tiles = torch.full((self.tile_doubles(count),), float("nan"), dtype=torch.float64, device=dev)
+            self.dense_jacobian_tiles(*args, tiles)
+            if gather_on_device := (tiled and nj and layout == "soa" and self._tiles_gather_requested):
+                self.tiles_gather(count, tiles, mk(jt, nj))
+            torch.cuda.synchronize()
+            if not gather_on_device:
+                return ft.cpu().numpy().T.copy(), self.untile_numpy(tiles.cpu().numpy(), count)
+        else:
+            (self.sparse_jacobian if mode == "sparse" else self.dense_jacobian)(*args, mk(jt, nj))
         torch.cuda.synchronize()
         f, j = ft.cpu().numpy(), jt.cpu().numpy()
         if layout == "soa":

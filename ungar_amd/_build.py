@@ -65,7 +65,7 @@ def generate(exe: str):
     edit to the generator recompiles just the kernels it affects (a from-scratch library build takes ~6 minutes)."""
     import filecmp
     import shutil
-    outs = [os.path.join(GEN, f"{m}_gen.hpp") for m in MODELS + ("quadrotor_cost", "srbd_cost", "rc_car_cost", "anymal_cost", "anymal_quad", "anymal_split", "anymal_rnea_quad", "anymal_crba_quad", "anymal_centroidal_quad")] + [os.path.join(ORACLE_GEN, f"{m}_cg.c") for m in C_MODELS]
+    outs = [os.path.join(GEN, f"{m}_gen.hpp") for m in MODELS + ("quadrotor_cost", "srbd_cost", "rc_car_cost", "anymal_cost", "anymal_quad", "anymal_tiles", "anymal_split", "anymal_rnea_quad", "anymal_crba_quad", "anymal_centroidal_quad")] + [os.path.join(ORACLE_GEN, f"{m}_cg.c") for m in C_MODELS]
     robot = os.path.join(ROOT, "ungar_amd", "data", "anymal_b.robot")
     stamp = os.path.join(BUILD, "codegen.stamp")
     if _newer(outs + [stamp], [exe, robot]):
@@ -110,6 +110,7 @@ def build_library(jobs: int | None = None):
             sqp_hdrs = [os.path.join(CSRC, "kernels", h) for h in ("ocp_sqp.hpp", "ocp_riccati.hpp", "ocp_barrier.hpp", "ocp_shooting.hpp")]
             extra = (sqp_hdrs + [os.path.join(CSRC, "kernels", "ocp_riccati_wave_kernel.hpp"), os.path.join(CSRC, "runtime", "kernel_jit.hpp")] if name.startswith(("ocp_riccati", "ocp_shooting")) else
                      [os.path.join(CSRC, "kernels", "ocp_assembly.hpp")] if name.startswith("ocp_assembly") else
+                     quad_deps + [os.path.join(CSRC, "kernels", "quad_tile_kernel.hpp"), os.path.join(GEN, "anymal_tiles_gen.hpp")] if name == "quad_anymal_tiles.hip" else
                      quad_deps if name.startswith("quad_") else
                      [os.path.join(GEN, f"{name[5:-4]}_cost_gen.hpp"), os.path.join(CSRC, "kernels", "cost_kernel.hpp")] if name.startswith("cost_") else [])
             units.append((src, os.path.join(BUILD, name[:-4] + ".o"), [src, kernel_hdr] + extra))

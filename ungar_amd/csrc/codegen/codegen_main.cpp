@@ -479,6 +479,8 @@ int main(int argc, char** argv) {
     int crbaQuadLdsSlots = 40;  // LDS home of the lane-per-leg inertia-matrix program
     bool rneaQuadReverse = true;  // partials of the lane-local function by reverse accumulation, one phase per row (measured: 11 % faster than forward / per column)
     int rneaQuadLdsSlots = 60, rneaQuadUniformSlots = 80;  // LDS home of the lane-per-leg joint-torque program (same budget)
+    bool tileInterleave = true;  // tile program: each store statement right behind the statements that produce its values (stores spread over the phase)
+    int tileLdsSlots = -1, tileUniformSlots = -1;  // tile program: LDS home of its own (-1: as the quad program)
     int quadLdsSlots = 60;  // 64-lane workgroups, four per CU: 160 KiB / 4 / 64 lanes / 8 B
     // split program (producer / consumer wavefront of a 128-lane workgroup, two wavefronts per SIMD): LDS homes of the two halves
     int splitProducerSlots = 24, splitProducerUniform = 12, splitConsumerSlots = 4, splitConsumerUniform = 80;
@@ -508,6 +510,11 @@ int main(int argc, char** argv) {
             splitConsumerUniform = std::atoi(argv[++i]);
         }
         else if (a == "--quad-pair-stores" && i + 1 < argc) quadPairStores = std::atoi(argv[++i]) != 0;
+        else if (a == "--tile-interleave" && i + 1 < argc) tileInterleave = std::atoi(argv[++i]) != 0;
+        else if (a == "--tile-lds-slots" && i + 2 < argc) {
+            tileLdsSlots = std::atoi(argv[++i]);
+            tileUniformSlots = std::atoi(argv[++i]);
+        }
         else if (a == "--quad-merge-shared" && i + 1 < argc) quadMergeShared = std::atoi(argv[++i]) != 0;
         else if (a == "--quad-uniform-slots" && i + 1 < argc) quadUniformSlots = std::atoi(argv[++i]);
         else if (a == "--quad-prefetch" && i + 2 < argc) {
@@ -635,6 +642,45 @@ int main(int argc, char** argv) {
                 std::fprintf(stderr, "[codegen] anymal_quad value only: %zu statements, %zu flops per lane\n", vs.statements, vs.flops);
                 std::ofstream qf(outDir + "/anymal_quad_gen.hpp");
                 qf << qo.str();
+                {  // tile program: the same node program with the Jacobian leaving as register images of the wavefront (quad_leg_program.hpp: tileStores)
+                    const codegen::QuadProgram tp = codegen::RecordQuadLegProgram(anymal, adv.jac, quadColumnsPerPhase, false, codegen::QuadRole::Fused, false, true);
+                    tape::EmitStats ts;
+                    int tileLds = 0, tileUniformUsed = 0;
+                    const std::string tfn = codegen::EmitQuadProgram(tp, "ValueJacobianQuadTiles", &ts, true, tileLdsSlots >= 0 ? tileLdsSlots : quadLdsSlots, &tileLds, quadRematConsumers,
+                                                                        quadRematDepth, quadPrefetch, tileUniformSlots >= 0 ? tileUniformSlots : quadUniformSlots, &tileUniformUsed,
+                                                                        quadPrefetchAcross, tileInterleave);
+                    // the same program with its column phases in another order: the shared columns (few stores per statement) BEFORE the columns owned by
+                    // the legs (many) -- wavefronts running the two orders side by side keep the chip's store traffic even (quad_tile_kernel.hpp)
+                    std::vector<int> orderB{0, 1};
+                    for (int ph = 11; ph < 21; ++ph) orderB.push_back(ph);
+                    for (int ph = 2; ph < 11; ++ph) orderB.push_back(ph);
+                    tape::EmitStats tsB;
+                    int tileLdsB = 0, tileUniformUsedB = 0;
+                    const std::string tfnB = codegen::EmitQuadProgram(tp, "ValueJacobianQuadTilesB", &tsB, true, tileLdsSlots >= 0 ? tileLdsSlots : quadLdsSlots, &tileLdsB, quadRematConsumers,
+                                                                         quadRematDepth, quadPrefetch, tileUniformSlots >= 0 ? tileUniformSlots : quadUniformSlots, &tileUniformUsedB,
+                                                                         quadPrefetchAcross, tileInterleave, &orderB);
+                    tileLds = std::max(tileLds, tileLdsB);
+                    tileUniformUsed = std::max(tileUniformUsed, tileUniformUsedB);
+                    std::ostringstream to;
+                    to << "// GENERATED by ungar_amd/csrc/codegen (quad_leg_program.hpp, tile stores) -- do not edit.\n"
+                       << "// ANYmal B shooting node, one lane per leg, Jacobian stored as register images: " << ts.statements << " statements, " << ts.flops
+                       << " flops per lane.\n"
+                       << "#pragma once\n#ifndef __host__\n#define __host__\n#endif\n#ifndef __device__\n#define __device__\n#endif\n\n"
+                       << "namespace ungar_amd::gen::anymal_tiles {\n\n"
+                       << "inline constexpr int kLdsSlots = " << tileLds << ";\n"
+                       << "inline constexpr int kLdsUniformSlots = " << tileUniformUsed << ";\n"
+                       << "inline constexpr int kImages = " << tp.tileEntries.size() / 4 << ";  // store images per wavefront (two per 16-byte store instruction)\n"
+                       << "// entry (row * 49 + col; -1: padding) held by the lane of leg q in image s: kEntryOfSlot[4 * s + q]\n"
+                       << "inline constexpr short kEntryOfSlot[" << tp.tileEntries.size() << "] = {";
+                    for (std::size_t i = 0; i < tp.tileEntries.size(); ++i) to << (i % 16 ? " " : "\n    ") << tp.tileEntries[i] << ",";
+                    to << "\n};\n#ifdef __HIPCC__\n// device copy of the table (one per translation unit)\nstatic __device__ __constant__ short kEntryOfSlotDev[" << tp.tileEntries.size() << "] = {";
+                    for (std::size_t i = 0; i < tp.tileEntries.size(); ++i) to << (i % 16 ? " " : "\n    ") << tp.tileEntries[i] << ",";
+                    to << "\n};\n#endif\n\n" << tfn << "\n// the shared columns first\n" << tfnB << "\n}  // namespace ungar_amd::gen::anymal_tiles\n";
+                    std::ofstream tf(outDir + "/anymal_tiles_gen.hpp");
+                    tf << to.str();
+                    std::fprintf(stderr, "[codegen] anymal_tiles (lane per leg, tile stores): %zu statements, %zu flops per lane, %zu images\n", ts.statements, ts.flops,
+                                 tp.tileEntries.size() / 4);
+                }
                 EmitSplitQuad(anymal, adv.jac, outDir, splitProducerSlots, splitProducerUniform, splitConsumerSlots, splitConsumerUniform, quadRematConsumers, quadRematDepth,
                               quadPrefetch, true);
                 std::fprintf(stderr, "[codegen] anymal_quad (lane per leg): %zu statements, %zu flops per lane, %zu table constants\n", qs.statements, qs.flops,

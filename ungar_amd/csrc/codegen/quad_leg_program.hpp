@@ -21,10 +21,12 @@
 //   solve(r_b, r_L):  z_L = U_LL^-1 r_L;  y_b = S^-1 (r_b - [sum_L] U_bL z_L);  y_L = U_LL^-T (D_L^-1 z_L - U_bL^T y_b)
 #pragma once
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <stdexcept>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "../models/nodes.hpp"
@@ -46,6 +48,9 @@ struct QuadProgram {
     // one per-lane base pointer per pattern, so that a sparse store costs what a dense one does
     std::vector<std::array<int, 4>> sparseDeltas;
     std::vector<std::array<double, 4>> constants;  // constants[k][leg]
+    // tile program (tileStores): entry (row * 49 + col, -1 = padding) held by lane `leg` in store image `sink`: tileEntries[4 * sink + leg].
+    // Two consecutive images leave in one 16-byte store instruction (io.t_put2), 1 KiB contiguous per wavefront.
+    std::vector<int> tileEntries;
 };
 
 /// The node program as ONE wavefront (Fused), or split over the two wavefronts of a workgroup:
@@ -113,7 +118,7 @@ inline std::vector<LegConstantRef> CollectLegConstants(const rbd::Model& model, 
 
 /// Records the leg-lane program for a free-flyer + 4 x (3 revolute) robot.
 inline QuadProgram RecordQuadLegProgram(const rbd::Model& model, const tape::SparseEntries& pattern, int columnsPerPhase = 1,
-                                        bool mergeSharedStores = false, QuadRole role = QuadRole::Fused, bool pairStores = false) {
+                                        bool mergeSharedStores = false, QuadRole role = QuadRole::Fused, bool pairStores = false, bool tileStores = false) {
     using namespace rbd;
     using namespace rbd::detail;
     CheckFloatingBaseQuadruped(model);
@@ -146,6 +151,7 @@ inline QuadProgram RecordQuadLegProgram(const rbd::Model& model, const tape::Spa
     const int nInputs = kRecv + kQuadMessages * kQuadMessageItems;
     const bool fused = role == QuadRole::Fused, producer = role == QuadRole::Producer, consumer = role == QuadRole::Consumer;
     if (pairStores && mergeSharedStores) throw std::runtime_error("quad program: paired stores and merged shared stores exclude each other");
+    if (tileStores && (pairStores || mergeSharedStores || role != QuadRole::Fused)) throw std::runtime_error("quad program: tile stores are a mode of the fused program of their own");
     if (!fused && (columnsPerPhase != 1 || mergeSharedStores)) throw std::runtime_error("quad program: the split program takes one column per phase");
     std::vector<AD> in = tape::Independent(nInputs);
     tape::Graph& g = tape::CurrentGraph();
@@ -468,6 +474,83 @@ inline QuadProgram RecordQuadLegProgram(const rbd::Model& model, const tape::Spa
     for (int k = 0; k < 3; ++k) sinkF(AD::FromId(fv[static_cast<std::size_t>(13 + k)]), "io.f_leg(" + std::to_string(7 + k) + ", %s);");
     for (int k = 0; k < 3; ++k) sinkF(AD::FromId(fv[static_cast<std::size_t>(16 + k)]), "io.f_leg(" + std::to_string(25 + k) + ", %s);");
 
+    // ---- tile stores (store path of the headline kernel) ------------------------------------------------------
+    // The Jacobian block of the 16 nodes of a wavefront leaves as a sequence of REGISTER IMAGES: image s holds, in the lane of leg q of every
+    // node, entry tileEntries[4 s + q] of that node.  A per-lane result (leg rows, base rows of a column owned by the lane's leg) is an image
+    // as it stands; the base rows of the shared columns are identical in the four lanes of a node, so four of them share one image (lane q
+    // keeps the q-th: io.sel4).  Images leave two at a time (io.t_put2: partner nodes exchange one value each, then ONE 16-byte store
+    // instruction writes 1 KiB contiguous).
+    // Every phase is SELF-CONTAINED -- an even number of complete images -- so that the phases of the program can be emitted in any order
+    // (EmitQuadProgram: phaseOrder; wavefronts running different orders keep the chip's store traffic even).  What a phase lacks is filled
+    // from a pool of LITERAL entries: the three position columns are the identity in the position rows and zero elsewhere (111 entries);
+    // the rest of the pool (+ 3 padding slots) is stored by statements of its own at the top of the program.
+    struct TileImage {
+        std::vector<AD> values;  // 1: per-lane value;  4: lane q keeps values[q]
+    };
+    bool tilePooling = false;  // true while the position columns are recorded: their entries go to the pool
+    std::vector<std::pair<int, double>> tilePool;  // (entry, literal value)
+    bool tileHavePending = false;
+    TileImage tilePending;
+    std::vector<std::pair<int, AD>> tileShared;  // base-row entries of shared columns waiting for an image
+    auto tileImage = [&](TileImage img, const std::array<int, 4>& entries) {
+        const int sink = static_cast<int>(P.tileEntries.size() / 4);
+        for (int q = 0; q < 4; ++q) P.tileEntries.push_back(entries[static_cast<std::size_t>(q)]);
+        if (!tileHavePending) {
+            tilePending = std::move(img);
+            tileHavePending = true;
+            return;
+        }
+        std::vector<tape::Id> ids;
+        auto spell = [&](const TileImage& im) {
+            auto ph = [&](const AD& v) {
+                ids.push_back(v.Node());
+                const std::size_t k = ids.size() - 1;
+                return k == 0 ? std::string("%s") : k == 1 ? std::string("%t") : "%" + std::to_string(k);
+            };
+            if (im.values.size() == 1) return ph(im.values[0]);
+            std::string t = "io.sel4(";
+            for (std::size_t q = 0; q < 4; ++q) t += (q ? ", " : "") + ph(im.values[q]);
+            return t + ")";
+        };
+        const std::string a = spell(tilePending), b = spell(img);
+        tape::OutputSlot slot{ids[0], "io.t_put2(" + std::to_string(sink / 2) + ", " + a + ", " + b + ");", ids[1]};
+        slot.more.assign(ids.begin() + 2, ids.end());
+        P.slots.push_back(std::move(slot));
+        tileHavePending = false;
+    };
+    auto tileSharedEntry = [&](int entry, const AD& v) {
+        tileShared.emplace_back(entry, v);
+        if (tileShared.size() < 4) return;
+        TileImage img;
+        std::array<int, 4> entries{};
+        for (std::size_t q = 0; q < 4; ++q) {
+            img.values.push_back(tileShared[q].second);
+            entries[q] = tileShared[q].first;
+        }
+        tileShared.clear();
+        tileImage(std::move(img), entries);
+    };
+    auto tilePoolEntry = [&]() -> std::pair<int, double> {  // next literal entry, or a padding slot once the pool is empty
+        if (tilePool.empty()) return {-1, 0.0};
+        const std::pair<int, double> e = tilePool.back();
+        tilePool.pop_back();
+        return e;
+    };
+    /// Completes the images of the phase that ends here with literal entries.
+    auto tileClosePhase = [&]() {
+        if (!tileStores) return;
+        while (!tileShared.empty()) {
+            const auto [e, c] = tilePoolEntry();
+            tileSharedEntry(e, AD{c});
+        }
+        if (tileHavePending)
+            for (int q = 0; q < 4; ++q) {
+                const auto [e, c] = tilePoolEntry();
+                tileSharedEntry(e, AD{c});
+            }
+        if (tileHavePending || !tileShared.empty()) throw std::logic_error("quad program: a phase of the tile program is not self-contained");
+    };
+
     /// Emits the Jacobian entries this lane is responsible for, for one column.
     ///   gLocal: index of the column among the lane-local integrator inputs (0..18) or -1
     ///   yb, yl: base / own-leg rows of da/dz for the column;  ownKind: this lane owns the column
@@ -485,7 +568,7 @@ inline QuadProgram RecordQuadLegProgram(const rbd::Model& model, const tape::Spa
                     throw std::runtime_error("quad program: non-zero entry outside the sparsity pattern at (" + std::to_string(r) + "," + std::to_string(c) + ")");
             }
         };
-        if (baseRows && (columnCounter++ % columnsPerPhase) == 0) P.phaseStarts.push_back(P.slots.size());  // a column + its rotated copies
+        if (baseRows && !tilePooling && (columnCounter++ % columnsPerPhase) == 0) P.phaseStarts.push_back(P.slots.size());  // a column + its rotated copies
         if (baseRows && consumer && pendingWait >= 0) {
             P.slots.push_back({noValue, "@begin:io.wait(" + std::to_string(pendingWait) + ");"});
             pendingWait = -1;
@@ -496,6 +579,39 @@ inline QuadProgram RecordQuadLegProgram(const rbd::Model& model, const tape::Spa
             for (int k = 0; k < 3; ++k) v = v + Gm[gr][25 + k] * yl[static_cast<std::size_t>(k)];
             return v;
         };
+        if (tileStores) {
+            if (baseRows)
+                for (int i = 0; i < 13; ++i) {
+                    const AD v = entry(i);
+                    const int row = baseRowIndex(i);
+                    checkZero(v, row, 0);
+                    if (tilePooling) {
+                        if (!v.IsLiteral() && g.At(v.Node()).op != tape::Op::Const) throw std::logic_error("quad program: the position columns are expected to be literals");
+                        tilePool.emplace_back(row * 49 + colBase, v.IsLiteral() ? v.Literal() : g.At(v.Node()).value);
+                    } else if (sharedColumn) {
+                        tileSharedEntry(row * 49 + colBase, v);
+                    } else {  // column owned by the lane's leg: lane q writes (row, colBase + 3 q)
+                        std::array<int, 4> e{};
+                        for (int q = 0; q < 4; ++q) e[static_cast<std::size_t>(q)] = row * 49 + colBase + 3 * colLegMul * ((q + rot) & 3);
+                        tileImage(TileImage{{v}}, e);
+                    }
+                }
+            for (int half = 0; half < 2; ++half)
+                for (int k = 0; k < 3; ++k) {
+                    const int rowBase = (half ? 25 : 7) + k;
+                    const AD v = entry(13 + 3 * half + k);
+                    checkZero(v, rowBase, 1);
+                    std::array<int, 4> e{};
+                    for (int q = 0; q < 4; ++q) e[static_cast<std::size_t>(q)] = (rowBase + 3 * q) * 49 + colBase + 3 * colLegMul * ((q + rot) & 3);
+                    if (tilePooling) {
+                        if (!v.IsLiteral() && g.At(v.Node()).op != tape::Op::Const) throw std::logic_error("quad program: the position columns are expected to be literals");
+                        for (int q = 0; q < 4; ++q) tilePool.emplace_back(e[static_cast<std::size_t>(q)], v.IsLiteral() ? v.Literal() : g.At(v.Node()).value);
+                    } else {
+                        tileImage(TileImage{{v}}, e);
+                    }
+                }
+            return;
+        }
         // pairStores: two entries of a column leave in ONE 16-byte store after a pairwise exchange between the lanes of
         // neighbouring nodes (quad_kernel.hpp: BufPut2) -- base rows (0,1) (2,3) (4,5) (19,20) (21,22) (23,24), row 6 alone;
         // leg rows (7 + k, 25 + k).  The sinks carry both entries; an I/O policy without paired stores writes them one by one.
@@ -598,6 +714,7 @@ inline QuadProgram RecordQuadLegProgram(const rbd::Model& model, const tape::Spa
             emitColumn(-1, ybr, foreignRows(ybr), colBase, 1, rot, false, false);
         }
         doneWith(message);
+        tileClosePhase();
     };
     // ---- shared columns: base twist (via D, summed over legs), quaternion (closed form), position (none) -------------------------
     auto twistColumn = [&](int k) {
@@ -611,19 +728,61 @@ inline QuadProgram RecordQuadLegProgram(const rbd::Model& model, const tape::Spa
         const Sol s = solve(rb, rl, true);
         emitColumn(7 + k, s.yb, s.yl, 19 + k, 0, 0, true, true);
         doneWith(message);
+        tileClosePhase();
     };
     auto quaternionColumn = [&](int k) {
         std::vector<AD> yb(6, AD{0.0});
         for (int r = 0; r < 3; ++r) yb[static_cast<std::size_t>(r)] = -dGam[r][k];
         emitColumn(3 + k, yb, zero3, 3 + k, 0, 0, true, true);
+        tileClosePhase();
     };
     auto positionColumn = [&](int k) { emitColumn(k, zero6, zero3, k, 0, 0, true, true); };
-    if (fused) {
+    if (fused && !tileStores) {
         for (int kind = 0; kind < 3; ++kind)
             for (int k = 0; k < 3; ++k) ownColumn(kind, k);
         for (int k = 0; k < 6; ++k) twistColumn(k);
         for (int k = 0; k < 4; ++k) quaternionColumn(k);
         for (int k = 0; k < 3; ++k) positionColumn(k);
+    } else if (fused) {
+        // tile program: the literal position columns first, into the pool the other phases complete their images from
+        tilePooling = true;
+        for (int k = 0; k < 3; ++k) positionColumn(k);
+        tilePooling = false;
+        for (int kind = 0; kind < 3; ++kind)
+            for (int k = 0; k < 3; ++k) ownColumn(kind, k);
+        for (int k = 0; k < 6; ++k) twistColumn(k);
+        for (int k = 0; k < 4; ++k) quaternionColumn(k);
+        // What is left of the pool leaves through statements at the TOP of the program ("@begin:" sinks of the first phase): a wavefront then has
+        // these bytes in flight while it computes kinematics, composite inertias and the factorisation (17 % of its statements, no other stores).
+        std::vector<tape::OutputSlot> literalSinks;
+        while (!tilePool.empty() || (P.tileEntries.size() / 4) % 2 != 0) {
+            std::string vals[2];
+            for (int half = 0; half < 2; ++half) {
+                std::array<int, 4> e{};
+                std::array<double, 4> c{};
+                for (std::size_t q = 0; q < 4; ++q) std::tie(e[q], c[q]) = tilePoolEntry();
+                for (int q = 0; q < 4; ++q) P.tileEntries.push_back(e[static_cast<std::size_t>(q)]);
+                auto lit = [](double v) {
+                    char buf[40];
+                    std::snprintf(buf, sizeof buf, "%.17g", v);
+                    std::string t = buf;
+                    if (t.find_first_of(".en") == std::string::npos) t += ".0";
+                    return t;
+                };
+                vals[half] = c[0] == c[1] && c[1] == c[2] && c[2] == c[3] ? lit(c[0]) : "io.sel4(" + lit(c[0]) + ", " + lit(c[1]) + ", " + lit(c[2]) + ", " + lit(c[3]) + ")";
+            }
+            literalSinks.push_back({noValue, "@begin:io.t_put2(" + std::to_string(P.tileEntries.size() / 8 - 1) + ", " + vals[0] + ", " + vals[1] + ");"});
+        }
+        P.slots.insert(P.slots.begin(), literalSinks.begin(), literalSinks.end());
+        for (std::size_t& st : P.phaseStarts) st += literalSinks.size();
+        std::vector<char> seen(37 * 49, 0);
+        for (int e : P.tileEntries)
+            if (e >= 0) {
+                if (seen[static_cast<std::size_t>(e)]) throw std::logic_error("quad program: entry stored twice in the tile program");
+                seen[static_cast<std::size_t>(e)] = 1;
+            }
+        for (char c : seen)
+            if (!c) throw std::logic_error("quad program: entry missing from the tile program");
     } else {
         // Order of the hand-over: the velocity columns first (their tangents do not involve the solved accelerations, so the
         // producer starts on them while the consumer still factorises), the joint-angle columns last.  The consumer
@@ -658,26 +817,35 @@ inline QuadProgram RecordQuadLegProgram(const rbd::Model& model, const tape::Spa
     for (const auto& sl : P.slots) roots.push_back(AD::FromId(sl.value));
     for (const auto& sl : P.slots)
         if (sl.value2 != tape::kNoId) roots.push_back(AD::FromId(sl.value2));
+    for (const auto& sl : P.slots)
+        for (tape::Id m : sl.more) roots.push_back(AD::FromId(m));
     P.tape = tape::MakeTape(roots);
     std::size_t second = P.slots.size();
     for (std::size_t i = 0; i < P.slots.size(); ++i) {
         P.slots[i].value = P.tape.outputs[i];
         if (P.slots[i].value2 != tape::kNoId) P.slots[i].value2 = P.tape.outputs[second++];
     }
+    for (auto& sl : P.slots)
+        for (tape::Id& m : sl.more) m = P.tape.outputs[second++];
     return P;
 }
 
 /// Emits `template <class T, class IO> void <fn>(IO& io)` with all values of type T.
 inline std::string EmitQuadProgram(const QuadProgram& P, const std::string& fnName, tape::EmitStats* stats = nullptr, bool usePhases = true,
                                    int ldsSlots = 0, int* ldsSlotsUsed = nullptr, int rematConsumers = 0, int rematDepth = 0, int prefetch = 0,
-                                   int uniformSlots = 0, int* uniformSlotsUsed = nullptr, bool prefetchAcrossPhases = false) {
+                                   int uniformSlots = 0, int* uniformSlotsUsed = nullptr, bool prefetchAcrossPhases = false, bool interleaveSinks = false,
+                                   const std::vector<int>* phaseOrder = nullptr) {
     // inputs are read ONCE into locals (an accessor call per use would be re-issued as a memory load
     // after every store, since the compiler cannot prove the output buffers do not alias them)
     std::vector<char> used(P.inputNames.size(), 0);
     {
         const tape::Graph& g = P.tape.graph;
         std::vector<char> live(g.Size(), 0);
-        for (const auto& sl : P.slots) live[static_cast<std::size_t>(sl.value)] = 1;
+        for (const auto& sl : P.slots) {
+            live[static_cast<std::size_t>(sl.value)] = 1;
+            if (sl.value2 != tape::kNoId) live[static_cast<std::size_t>(sl.value2)] = 1;
+            for (tape::Id m : sl.more) live[static_cast<std::size_t>(m)] = 1;
+        }
         for (std::size_t i = g.Size(); i-- > 0;) {
             if (!live[i]) continue;
             const tape::Node& nd = g.At(static_cast<tape::Id>(i));
@@ -696,6 +864,7 @@ inline std::string EmitQuadProgram(const QuadProgram& P, const std::string& fnNa
     }
     tape::Emitter em{P.tape.graph, names};
     em.SetRereadInputs(P.inputLate);
+    em.SetInterleaveSinks(interleaveSinks);
     // phases (primal + one per owned / shared column) separated by scheduling barriers, no LDS home:
     // per-lane state fits the register file, the barriers only stop the scheduler from interleaving columns
     std::vector<std::vector<tape::OutputSlot>> phases;
@@ -707,6 +876,12 @@ inline std::string EmitQuadProgram(const QuadProgram& P, const std::string& fnNa
             if (st > next) phases.emplace_back(P.slots.begin() + static_cast<std::ptrdiff_t>(next), P.slots.begin() + static_cast<std::ptrdiff_t>(st));
             next = st;
         }
+    }
+    if (phaseOrder) {  // the phases in another order (programs whose phases are self-contained: tile stores)
+        if (phaseOrder->size() != phases.size()) throw std::logic_error("quad program: phase order of " + std::to_string(phaseOrder->size()) + " entries for " + std::to_string(phases.size()) + " phases");
+        std::vector<std::vector<tape::OutputSlot>> permuted;
+        for (int ph : *phaseOrder) permuted.push_back(phases.at(static_cast<std::size_t>(ph)));
+        phases = std::move(permuted);
     }
     int slotsUsed = 0;
     std::string body = usePhases ? em.EmitPhased(phases, ldsSlots, slotsUsed, rematConsumers, rematDepth, prefetch, "    ", &P.inputUniform, uniformSlots, uniformSlotsUsed, prefetchAcrossPhases)

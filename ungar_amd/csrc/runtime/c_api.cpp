@@ -288,6 +288,54 @@ int ungar_gn_hessian_upper_lanes(const double* jac, int64_t j_es, const double* 
     if (err != 0) return Fail(UNGAR_E_HIP, std::string("gn_hessian (lane per node) launch failed: ") + hipGetErrorString(static_cast<hipError_t>(err)));
     return UNGAR_OK;
 }
+extern "C" void ungar_amd_anymal_tile_layout(int* images, const short** entryOfSlot);                                            // quad_anymal_tiles.hip
+extern "C" int ungar_amd_launch_anymal_tiles(const ungar_amd::kernels::NodeLaunch* a, double* tiles, void* stream);
+extern "C" int ungar_amd_launch_anymal_tiles_gather(const double* tiles, const ungar_amd::kernels::OperandView* dst, long long count, long long knots, void* stream);
+namespace {
+constexpr int kTileNodes = 16, kTileBandTiles = 64, kTileUnitDoubles = 128;  // quad_tile_kernel.hpp
+bool HasTiles(const ungar_model* model) {
+    return model && model->name == "anymal";
+}
+}  // namespace
+int ungar_model_tile_layout(const ungar_model* model, ungar_tile_layout* layout) {
+    if (!model || !layout) return Fail(UNGAR_E_INVALID, "ungar_model_tile_layout: null argument");
+    if (!HasTiles(model)) return Fail(UNGAR_E_UNSUPPORTED, "model '" + model->name + "' has no wave-tile program (only 'anymal' has)");
+    int images = 0;
+    const short* table = nullptr;
+    ungar_amd_anymal_tile_layout(&images, &table);
+    *layout = {kTileNodes, kTileBandTiles, images, kTileUnitDoubles, static_cast<int32_t>(model->info.ny * (model->info.nx + model->info.nu)), 0, table};
+    return UNGAR_OK;
+}
+int64_t ungar_model_tile_doubles(const ungar_model* model, int64_t count) {
+    ungar_tile_layout l{};
+    const int rc = ungar_model_tile_layout(model, &l);
+    if (rc != UNGAR_OK) return rc;
+    if (count < 0) return Fail(UNGAR_E_INVALID, "ungar_model_tile_doubles: negative count");
+    const int64_t tiles = (count + l.nodes_per_tile - 1) / l.nodes_per_tile, bands = (tiles + l.band_tiles - 1) / l.band_tiles;
+    return bands * l.band_tiles * (l.images / 2) * l.unit_doubles;
+}
+int ungar_model_dense_jacobian_tiles(const ungar_model* model, const ungar_node_batch* batch, double* tiles, void* stream) {
+    if (!model || !batch || !tiles) return Fail(UNGAR_E_INVALID, "ungar_model_dense_jacobian_tiles: null argument");
+    if (!HasTiles(model)) return Fail(UNGAR_E_UNSUPPORTED, "model '" + model->name + "' has no wave-tile program (only 'anymal' has)");
+    if (batch->count < 0 || batch->knots < 1) return Fail(UNGAR_E_INVALID, "batch.count must be >= 0 and batch.knots >= 1");
+    if (batch->count == 0) return UNGAR_OK;
+    if (batch->count % batch->knots != 0) return Fail(UNGAR_E_INVALID, "batch.count must be a multiple of batch.knots");
+    if (!batch->x.base || !batch->u.base || !batch->p.base) return Fail(UNGAR_E_INVALID, "null input operand for model '" + model->name + "'");
+    const NodeLaunch a{batch->count, batch->knots, View(batch->x), View(batch->u), View(batch->w), View(batch->p), View(batch->f), {}};
+    const int err = ungar_amd_launch_anymal_tiles(&a, tiles, stream);
+    if (err != 0) return Fail(UNGAR_E_HIP, std::string("tile kernel launch failed for model '") + model->name + "': " + hipGetErrorString(static_cast<hipError_t>(err)));
+    return UNGAR_OK;
+}
+int ungar_tiles_gather(const ungar_model* model, const double* tiles, int64_t count, int64_t knots, const ungar_operand* jac, void* stream) {
+    if (!model || !tiles || !jac || !jac->base) return Fail(UNGAR_E_INVALID, "ungar_tiles_gather: null argument");
+    if (!HasTiles(model)) return Fail(UNGAR_E_UNSUPPORTED, "model '" + model->name + "' has no wave-tile program (only 'anymal' has)");
+    if (count < 0 || knots < 1 || count % knots != 0) return Fail(UNGAR_E_INVALID, "ungar_tiles_gather: count must be a non-negative multiple of knots");
+    if (count == 0) return UNGAR_OK;
+    const ungar_amd::kernels::OperandView dst = View(*jac);
+    const int err = ungar_amd_launch_anymal_tiles_gather(tiles, &dst, count, knots, stream);
+    if (err != 0) return Fail(UNGAR_E_HIP, std::string("tile gather launch failed: ") + hipGetErrorString(static_cast<hipError_t>(err)));
+    return UNGAR_OK;
+}
 extern "C" int ungar_amd_launch_transpose_nodes(const double* src, long long sns, long long ses, double* dst, long long dns, long long des, long long count, int elements,
                                                  void* stream);
 int ungar_transpose_nodes(const double* src, int64_t src_node_stride, int64_t src_element_stride, double* dst, int64_t dst_node_stride, int64_t dst_element_stride,

@@ -31,7 +31,18 @@ struct OutputSlot {
     Id value;
     std::string sink;
     Id value2 = kNoId;  // second value of a paired sink ("%t" in the statement): two results leaving in one store instruction
+    std::vector<Id> more;  // further values of a sink that gathers several results ("%2", "%3", ... in the statement, at most eight in all)
 };
+
+/// Replaces "%2".."%9" in a sink statement by the spelling of the slot's further values.
+template <class Spell>
+inline void SpellMoreValues(std::string& line, const OutputSlot& s, Spell&& spell) {
+    for (std::size_t k = 0; k < s.more.size(); ++k) {
+        const std::string tag = "%" + std::to_string(k + 2);
+        const std::size_t pos = line.find(tag);
+        if (pos != std::string::npos) line.replace(pos, tag.size(), spell(s.more[k]));
+    }
+}
 
 /// How input `i` of the tape is spelled in the generated code.
 using InputNamer = std::string (*)(int index, const void* ctx);
@@ -61,11 +72,13 @@ class Emitter {
         for (const OutputSlot& s : slots) {
             EmitNode(s.value, os, indent);
             if (s.value2 != kNoId) EmitNode(s.value2, os, indent);
+            for (Id m : s.more) EmitNode(m, os, indent);
             std::string line = s.sink;
             const std::size_t pos = line.find("%s");
             if (pos != std::string::npos) line.replace(pos, 2, Ref(s.value));
             const std::size_t pos2 = line.find("%t");
             if (pos2 != std::string::npos && s.value2 != kNoId) line.replace(pos2, 2, Ref(s.value2));
+            SpellMoreValues(line, s, [&](Id v) { return Ref(v); });
             os << indent << line << "\n";
         }
         return os.str();
@@ -88,6 +101,8 @@ class Emitter {
     /// `uniformInput` (optional, one flag per tape input) marks inputs whose value is the same in the four
     /// lanes of a quad; values derived only from those (and every QuadSum) are quad-uniform and may live in
     /// one of `uniformSlots` compact slots (io.ldu / io.stu: one copy per quad, a quarter of the LDS bytes).
+    void SetInterleaveSinks(bool on) { interleaveSinks_ = on; }
+
     std::string EmitPhased(const std::vector<std::vector<OutputSlot>>& phases, int ldsSlots, int& slotsUsed, int rematMaxConsumers = 2,
                            int rematMaxDepth = 3, int prefetchDistance = 48, const char* indent = "    ",
                            const std::vector<char>* uniformInput = nullptr, int uniformSlots = 0, int* uniformSlotsUsed = nullptr,
@@ -113,6 +128,7 @@ class Emitter {
             for (const OutputSlot& s : phases[ph]) {
                 CollectOrder(s.value, static_cast<int>(ph), defPhase, order[ph]);
                 if (s.value2 != kNoId) CollectOrder(s.value2, static_cast<int>(ph), defPhase, order[ph]);
+                for (Id m : s.more) CollectOrder(m, static_cast<int>(ph), defPhase, order[ph]);
             }
         const std::vector<std::vector<OutputSlot>>& ph_ = phases;
         std::vector<int> consumers(n, 0);
@@ -136,6 +152,7 @@ class Emitter {
             for (const OutputSlot& s : ph_[ph]) {
                 use(s.value);
                 use(s.value2);
+                for (Id m : s.more) use(m);
             }
         }
         // ---- stored set: cross-phase values that are not worth recomputing ---------------------------------
@@ -286,11 +303,16 @@ class Emitter {
                         }
                     }
                 };
-                for (Id id : order[ph]) produce(id);
+                // default: every value of the phase first, its sinks at the end (the machine scheduler then places the stores); interleaved: each
+                // sink right behind the statements that produce its values, so that result stores are spread over the phase instead of leaving in
+                // one burst at its end (the CU's store path takes 64 bytes per clock: a burst of 18 KiB per wavefront stalls the lone wavefront of a SIMD)
+                if (!interleaveSinks_)
+                    for (Id id : order[ph]) produce(id);
                 for (const OutputSlot& s : ph_[ph]) {
                     if (s.sink.rfind(kBeginTag, 0) == 0) continue;
                     produce(s.value);
                     if (s.value2 != kNoId) produce(s.value2);
+                    for (Id m : s.more) produce(m);
                     if (!dry) {
                         std::string line = s.sink;
                         auto spell = [&](Id v) {
@@ -301,6 +323,7 @@ class Emitter {
                         if (pos != std::string::npos) line.replace(pos, 2, spell(s.value));
                         const std::size_t pos2 = line.find("%t");
                         if (pos2 != std::string::npos && s.value2 != kNoId) line.replace(pos2, 2, spell(s.value2));
+                        SpellMoreValues(line, s, spell);
                         lines.emplace_back(line, false);
                     }
                 }
@@ -576,6 +599,7 @@ class Emitter {
     const Graph& g_;
     std::vector<std::string> inputExpr_;
     std::vector<char> reread_;
+    bool interleaveSinks_ = false;
     std::vector<int> name_;
     int next_ = 0;
     EmitStats stats_;
