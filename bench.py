@@ -151,7 +151,7 @@ def genuine_reference_timing(seconds):
 
 # ------------------------------------------------------------------------------------------------ GPU measurement
 def measure(torch, ungar_amd, workload, instances, total_instances, begin, steps, warmup, jacobian="dense", kernel_model=None, fence=None,
-            seed=0, tile=None, pad_stride=True, prewarm_s=0.0):
+            seed=0, tile=None, pad_stride=True, prewarm_s=0.0, layout="soa"):
     """Times `steps` passes over the node range of instances [begin, begin + instances) of a `total_instances` batch.  The shard
     is stored as [tile][element][node of tile] (ungar_amd.sharding.tile_ranges) and a pass is one launch per tile on one stream.
     Returns per-rank figures (elapsed seconds on the host clock, mean launch duration from HIP events on the launch stream,
@@ -167,6 +167,9 @@ def measure(torch, ungar_amd, workload, instances, total_instances, begin, steps
     jac_len = nx * ncols if jacobian == "dense" else nnz
     Op = ungar_amd.Operand
     launches, outputs = [], []
+    wave_tiles = layout == "tiles"  # dense block as register images of the wavefronts (include/ungar_amd.h: ungar_tile_layout); inputs and f stay unit-fastest
+    if wave_tiles and jacobian != "dense":
+        raise SystemExit("bench.py: the wave-tile layout holds the dense block")
     for b, e in tile_ranges(instances, tile or DEFAULT_TILE_INSTANCES):
         tn = (e - b) * N
         sl = slice(b * N, e * N)
@@ -176,14 +179,16 @@ def measure(torch, ungar_amd, workload, instances, total_instances, begin, steps
                 t.copy_(src)
             return t
         xt, ut, wt = operand(nx, x[:, sl]), operand(nu, u[:, sl]), None if w is None else operand(w.shape[0], w[:, sl])
-        f, J = operand(nx), operand(jac_len)
+        f = operand(nx)
+        # (wave tiles: zero-filled once, so that the padding of the last band -- never written -- does not enter the checksum)
+        J = torch.zeros((m.tile_doubles(tn),), dtype=torch.float64, device="cuda") if wave_tiles else operand(jac_len)
         outputs.append((f, J))
         es = f.stride(0)
         launches.append((tn, Op.soa(xt, es, N), Op.soa(ut, es, N), None if wt is None else Op.soa(wt, es, N), Op.per_instance(p, m.np, shared=True),
-                         Op.soa(f, es, N), Op.soa(J, es, N)))
+                         Op.soa(f, es, N), J if wave_tiles else Op.soa(J, es, N)))
     del x, u, w
     stream = torch.cuda.current_stream().cuda_stream
-    call = m.dense_jacobian if jacobian == "dense" else m.sparse_jacobian
+    call = m.dense_jacobian_tiles if wave_tiles else m.dense_jacobian if jacobian == "dense" else m.sparse_jacobian
 
     def step():
         for ops in launches:
@@ -218,7 +223,7 @@ def measure(torch, ungar_amd, workload, instances, total_instances, begin, steps
     bytes_per_eval = W.algorithmic_bytes(nx, nu, None if jacobian == "dense" else nnz)
     return {"elapsed": elapsed, "kernel_ms": step_ms / len(launches), "step_kernel_ms": step_ms, "launches_per_step": len(launches), "count": count,
             "nodes_per_launch": count / len(launches), "checksum": checksum, "bytes_per_eval": bytes_per_eval, "nx": nx, "nu": nu, "nnz": nnz, "N": N,
-            "kernel_model": kernel_model or model_name}
+            "kernel_model": kernel_model or model_name, "layout": layout}
 
 
 def roofline(r, jacobian, traffic=None, traffic_source=None):
@@ -226,7 +231,26 @@ def roofline(r, jacobian, traffic=None, traffic_source=None):
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "traffic_source": traffic_source, "kernel_ms": r["kernel_ms"], "launches_per_step": r["launches_per_step"], "nodes_per_launch": r["nodes_per_launch"],
             "algorithmic_bytes_per_eval": r["bytes_per_eval"],
-            "kernel": f"NodeKernel<{r['kernel_model']}, {jacobian} Jacobian>"}
+            "kernel": f"NodeKernel<{r['kernel_model']}, {jacobian} Jacobian, {'wave-tile' if r.get('layout') == 'tiles' else 'unit-fastest'} operand>"}
+
+
+def box_store_ceilings(timeout=60):
+    """What THIS box's memory system takes to WRITE the bytes of one headline launch (81 920 nodes x 1813 entries x 8 B = 1.19 GB), measured in this run so that
+    box-to-box spread of the headline is attributable: `store_only_ms` = a store-only kernel with the node kernel's store instructions, lane layout and band
+    interleave (tools/store_ceiling_tiles.hip: band16_nt_64, one wavefront per SIMD), `memset_ms` = hipMemsetAsync over the same bytes."""
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "_bin", "store_ceiling_tiles")
+    if not os.path.exists(exe):
+        return {"unavailable": "tools/_bin/store_ceiling_tiles not built (ungar_amd._build.build_tools)"}
+    out = {}
+    for key, variant in (("store_only_ms", "band16_nt_64"), ("memset_ms", "memset")):
+        try:
+            text = subprocess.run([exe, variant, "100"], capture_output=True, text=True, timeout=timeout).stdout
+            out[key] = float(text.split()[1])
+        except Exception as exc:  # noqa: BLE001 -- a context figure: never fails the line
+            out[key] = None
+            out.setdefault("errors", []).append(f"{variant}: {exc!r}"[:200])
+    return out
 
 
 def free_port() -> int:
@@ -468,7 +492,9 @@ def main():
                     help="A/B switch: element stride of the unit-fastest operands = nodes of the tile (consecutive elements a multiple of 2^17 bytes apart "
                          "for these batch sizes: one memory channel per wavefront) instead of ungar_amd.sharding.padded_stride")
     ap.add_argument("--model", default=None, help="kernel variant of the workload's model (e.g. anymal_ad, anymal_reg)")
-    ap.add_argument("--layout", default="soa", choices=["soa"])
+    ap.add_argument("--layout", default=None, choices=["soa", "tiles"],
+                    help="operand layout of the dense block: `tiles` = register images of the wavefronts in bands (default where the model has a tile program: "
+                         "the anymal workload's dense block), `soa` = unit-fastest [entry][node]")
     ap.add_argument("--jacobian", default="dense", choices=["dense", "sparse"],
                     help="dense [A|B] block (BASELINE metric, default) or the CSR value array of Function::Jacobian (function.hpp:216-230)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -496,8 +522,7 @@ def main():
     model_name = W.WORKLOADS[args.workload][0]
     # compiles while the GPU runs (UNGAR_BENCH_PORTABLE_ORACLE=1: time the prebuilt portable library instead -- the contract test's choice, a native build of the
     # generated C takes a minute of host time; the JSON line says which one was timed)
-    native = (NativeOracleBuild((model_name, "anymal_ad", "quadrotor", "rc_car") if model_name == "anymal" else (model_name,))
-              if want_cpu and os.environ.get("UNGAR_BENCH_PORTABLE_ORACLE") != "1" else None)
+    native = None  # (started AFTER the headline measurement below: four gcc -O3 jobs on multi-MB files must not share the box with the one driver-timed number)
 
     import torch
     import ungar_amd
@@ -540,7 +565,12 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    r = measure(torch, ungar_amd, args.workload, end - begin, total, begin, args.steps, args.warmup, args.jacobian, args.model, fence, tile=args.tile_instances, pad_stride=not args.no_stride_pad, prewarm_s=args.prewarm_seconds)
+    layout = args.layout or ("tiles" if args.workload == "anymal" and args.jacobian == "dense" and args.model in (None, "anymal") else "soa")
+    r = measure(torch, ungar_amd, args.workload, end - begin, total, begin, args.steps, args.warmup, args.jacobian, args.model, fence, tile=args.tile_instances, pad_stride=not args.no_stride_pad, prewarm_s=args.prewarm_seconds, layout=layout)
+    # the host compiles the CPU baseline's C with the reference's JIT flags from here on, next to the secondary GPU measurements (UNGAR_BENCH_PORTABLE_ORACLE=1: time
+    # the prebuilt portable library instead -- the contract test's choice, a native build of the generated C takes a minute of host time; the JSON line says which)
+    if want_cpu and os.environ.get("UNGAR_BENCH_PORTABLE_ORACLE") != "1":
+        native = NativeOracleBuild((model_name, "anymal_ad", "quadrotor", "rc_car") if model_name == "anymal" else (model_name,))
     reduce_device = "cuda" if dist is None or dist.get_backend() == "nccl" else "cpu"
     elapsed, total_evals = reduce_timing(r["elapsed"], r["count"] * args.steps, dist, reduce_device)  # MAX time, SUM evals over ranks
     checksum, nodes_per_step = reduce_sums([r["checksum"], float(r["count"])], dist, reduce_device)  # SUM over ranks
@@ -554,7 +584,7 @@ def main():
         if os.path.exists(tpath) and args.jacobian == "dense" and r["kernel_model"] == model_name:
             with open(tpath) as fh:
                 table = json.load(fh)
-            traffic = table.get(f"{args.workload}:{int(r['nodes_per_launch']) // N}")  # keyed by the instances of one launch
+            traffic = table.get(f"{args.workload}:{int(r['nodes_per_launch']) // N}" + (":tiles" if layout == "tiles" else ""))  # keyed by the instances of one launch (and the layout)
             traffic_source = table.get("_source") if traffic is not None else None  # NOT measured in this run: see profiles/
         out = {
             "metric": "shooting-node Jacobian evals/sec",
@@ -576,13 +606,20 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.workload} shooting-node value + {'dense [A|B]' if args.jacobian == 'dense' else 'sparse (nnz=%d)' % r['nnz']} Jacobian, "
                                    f"nx={r['nx']} nu={r['nu']}, N={N}, batch={total} instances over {world} GPU(s) "
-                                   f"({end - begin} instances = {r['count']} nodes on rank 0 per step), unit-fastest (SoA) device layout in tiles of <= {args.tile_instances or 8192} instances, element stride "
-                                   + ("= nodes of the tile" if args.no_stride_pad else "padded off the 2^17-byte channel stride (sharding.padded_stride)"),
-                       "horizon": N, "total_batch": total, "batch_rank0": end - begin, "nodes_per_step": int(nodes_per_step), "kernel_variant": r["kernel_model"],
+                                   f"({end - begin} instances = {r['count']} nodes on rank 0 per step), "
+                                   + ("dense block in the wave-tile layout (register images of the wavefronts, bands of 64 tiles: include/ungar_amd.h), x / u / f unit-fastest, " if layout == "tiles" else "unit-fastest (SoA) device layout, ")
+                                   + f"one launch per <= {args.tile_instances or 8192} instances, element stride of the unit-fastest operands "
+                                   + ("= nodes of the launch" if args.no_stride_pad else "padded off the 2^17-byte channel stride (sharding.padded_stride)"),
+                       "horizon": N, "total_batch": total, "batch_rank0": end - begin, "nodes_per_step": int(nodes_per_step), "kernel_variant": r["kernel_model"], "layout": layout,
                        "parallelism": f"instance axis partitioned x{world} (shard_range), no data-path collective"},
             "checksum": checksum,
             "roofline": roofline(r, args.jacobian, traffic, traffic_source),
         }
+        if world == 1 and args.workload == "anymal":
+            ceilings = box_store_ceilings()
+            out["roofline"]["box_store_only_ms"], out["roofline"]["box_memset_ms"] = ceilings.get("store_only_ms"), ceilings.get("memset_ms")
+            if "unavailable" in ceilings or "errors" in ceilings:
+                out["roofline"]["box_ceilings_note"] = ceilings.get("unavailable") or ceilings.get("errors")
         if world == 1 and not args.no_sub_results and args.workload == "anymal":
             subs = []
             for wl in ("quadrotor", "rc_car"):  # BASELINE.json configs[1], configs[2]

@@ -29,6 +29,9 @@ def test_bench_line_has_the_contract_fields(repo_root, shared_codegen):
     assert abs(r["achieved"] - r["nodes_per_launch"] * 15192 / (r["kernel_ms"] * 1e-3) / 1e9) <= 1e-6 * r["achieved"]
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.3 < r["frac"] < 1.0
     assert r["kernel_ms"] <= d["ms_per_step"] * 1.001, "the kernel cannot take longer than the step that contains it"
+    # the headline launch writes the dense block in the wave-tile layout, and the line carries the box's own store ceilings measured in the same run
+    assert d["config"]["layout"] == "tiles" and "wave-tile" in r["kernel"]
+    assert 0.1 < r["box_memset_ms"] < r["box_store_only_ms"] < r["kernel_ms"] * 1.05, (r["box_memset_ms"], r["box_store_only_ms"], r["kernel_ms"])
     assert r["traffic"] is None or (0.9 < r["traffic"] / (r["nodes_per_launch"] * 15192) < 1.2 and "profiles/" in r["traffic_source"])
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] == 1 and c["value"] > 1e4 and "sample" in c

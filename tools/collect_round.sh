@@ -4,7 +4,7 @@
 set -euo pipefail
 tag=${1:?tag}
 cd "$(dirname "$0")/.."
-python tools/collect_profiles.py "$tag" anymal:4096
+python tools/collect_profiles.py "$tag" anymal:4096:tiles
 cp_if() { [ -s "$1" ] && cp "$1" "$2" || echo "missing: $1"; }
 cp_if gpurun_out/bench.log                    profiles/bench_${tag}_anymal.json
 cp_if gpurun_out/bench_2rank_gloo.log         profiles/bench_${tag}_config5_2rank_gloo_1gpu.json

@@ -25,24 +25,9 @@ struct Body {
     template <class IO>
     __device__ __forceinline__ void operator()(IO& io) const { Q::ValueJacobianQuad<double>(io); }
 };
-#ifndef TILE_BODY_MODE
-#define TILE_BODY_MODE 2
-#endif
-#ifndef TILE_BODY_SHIFT
-#define TILE_BODY_SHIFT 3
-#endif
-struct TileBody {  // 0: own columns first; 1: shared columns first; 2: both orders, picked by a bit of the workgroup index
+struct TileBody {
     template <class IO>
-    __device__ __forceinline__ void operator()(IO& io) const {
-#if TILE_BODY_MODE == 0
-        T::ValueJacobianQuadTiles<double>(io);
-#elif TILE_BODY_MODE == 1
-        T::ValueJacobianQuadTilesB<double>(io);
-#else
-        if ((blockIdx.x >> TILE_BODY_SHIFT) & 1) T::ValueJacobianQuadTilesB<double>(io);
-        else T::ValueJacobianQuadTiles<double>(io);
-#endif
-    }
+    __device__ __forceinline__ void operator()(IO& io) const { T::ValueJacobianQuadTiles<double>(io); }
 };
 
 // per-phase timestamps (s_memtime) of one lane of every 64th wavefront: where does the time go with the stores on / off?

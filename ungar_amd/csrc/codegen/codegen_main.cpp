@@ -479,6 +479,12 @@ int main(int argc, char** argv) {
     int crbaQuadLdsSlots = 40;  // LDS home of the lane-per-leg inertia-matrix program
     bool rneaQuadReverse = true;  // partials of the lane-local function by reverse accumulation, one phase per row (measured: 11 % faster than forward / per column)
     int rneaQuadLdsSlots = 60, rneaQuadUniformSlots = 80;  // LDS home of the lane-per-leg joint-torque program (same budget)
+    // tile program: its (self-contained) phases in this order (empty = as recorded: 0 kinematics / CRBA / factorisation, 1 value, 2-4 q_L, 5-7 v_L, 8-10 u_L columns of the
+    // four legs, 11-16 base twist, 17-20 quaternion columns).  With one wavefront per SIMD every resident wavefront is in the same phase at the same time, so the ORDER
+    // decides how evenly the chip's store traffic is spread: the densest phases (u_L: 19 KiB of results per 2.9 k cycles of arithmetic) right after the store-free
+    // prefix, each followed by one of the arithmetic-heavy twist columns, the q_L columns (heaviest arithmetic) last beside the quaternion columns.  Measured over
+    // fifteen orders (tools/quad_tile_bench.hip, profiles/r06a_tile_variants5-7.log): 0.2237 ms per 81 920 nodes against 0.238-0.244 as recorded.
+    std::vector<int> tilePhaseOrder{0, 1, 8, 16, 9, 15, 10, 14, 5, 13, 6, 12, 7, 11, 2, 17, 3, 18, 4, 19, 20};
     bool tileInterleave = true;  // tile program: each store statement right behind the statements that produce its values (stores spread over the phase)
     int tileLdsSlots = -1, tileUniformSlots = -1;  // tile program: LDS home of its own (-1: as the quad program)
     int quadLdsSlots = 60;  // 64-lane workgroups, four per CU: 160 KiB / 4 / 64 lanes / 8 B
@@ -511,6 +517,14 @@ int main(int argc, char** argv) {
         }
         else if (a == "--quad-pair-stores" && i + 1 < argc) quadPairStores = std::atoi(argv[++i]) != 0;
         else if (a == "--tile-interleave" && i + 1 < argc) tileInterleave = std::atoi(argv[++i]) != 0;
+        else if (a == "--tile-phase-order" && i + 1 < argc) {
+            tilePhaseOrder.clear();
+            for (const char* c = argv[++i]; *c;) {
+                tilePhaseOrder.push_back(std::atoi(c));
+                while (*c && *c != ',') ++c;
+                if (*c == ',') ++c;
+            }
+        }
         else if (a == "--tile-lds-slots" && i + 2 < argc) {
             tileLdsSlots = std::atoi(argv[++i]);
             tileUniformSlots = std::atoi(argv[++i]);
@@ -648,19 +662,7 @@ int main(int argc, char** argv) {
                     int tileLds = 0, tileUniformUsed = 0;
                     const std::string tfn = codegen::EmitQuadProgram(tp, "ValueJacobianQuadTiles", &ts, true, tileLdsSlots >= 0 ? tileLdsSlots : quadLdsSlots, &tileLds, quadRematConsumers,
                                                                         quadRematDepth, quadPrefetch, tileUniformSlots >= 0 ? tileUniformSlots : quadUniformSlots, &tileUniformUsed,
-                                                                        quadPrefetchAcross, tileInterleave);
-                    // the same program with its column phases in another order: the shared columns (few stores per statement) BEFORE the columns owned by
-                    // the legs (many) -- wavefronts running the two orders side by side keep the chip's store traffic even (quad_tile_kernel.hpp)
-                    std::vector<int> orderB{0, 1};
-                    for (int ph = 11; ph < 21; ++ph) orderB.push_back(ph);
-                    for (int ph = 2; ph < 11; ++ph) orderB.push_back(ph);
-                    tape::EmitStats tsB;
-                    int tileLdsB = 0, tileUniformUsedB = 0;
-                    const std::string tfnB = codegen::EmitQuadProgram(tp, "ValueJacobianQuadTilesB", &tsB, true, tileLdsSlots >= 0 ? tileLdsSlots : quadLdsSlots, &tileLdsB, quadRematConsumers,
-                                                                         quadRematDepth, quadPrefetch, tileUniformSlots >= 0 ? tileUniformSlots : quadUniformSlots, &tileUniformUsedB,
-                                                                         quadPrefetchAcross, tileInterleave, &orderB);
-                    tileLds = std::max(tileLds, tileLdsB);
-                    tileUniformUsed = std::max(tileUniformUsed, tileUniformUsedB);
+                                                                        quadPrefetchAcross, tileInterleave, tilePhaseOrder.empty() ? nullptr : &tilePhaseOrder);
                     std::ostringstream to;
                     to << "// GENERATED by ungar_amd/csrc/codegen (quad_leg_program.hpp, tile stores) -- do not edit.\n"
                        << "// ANYmal B shooting node, one lane per leg, Jacobian stored as register images: " << ts.statements << " statements, " << ts.flops
@@ -675,7 +677,7 @@ int main(int argc, char** argv) {
                     for (std::size_t i = 0; i < tp.tileEntries.size(); ++i) to << (i % 16 ? " " : "\n    ") << tp.tileEntries[i] << ",";
                     to << "\n};\n#ifdef __HIPCC__\n// device copy of the table (one per translation unit)\nstatic __device__ __constant__ short kEntryOfSlotDev[" << tp.tileEntries.size() << "] = {";
                     for (std::size_t i = 0; i < tp.tileEntries.size(); ++i) to << (i % 16 ? " " : "\n    ") << tp.tileEntries[i] << ",";
-                    to << "\n};\n#endif\n\n" << tfn << "\n// the shared columns first\n" << tfnB << "\n}  // namespace ungar_amd::gen::anymal_tiles\n";
+                    to << "\n};\n#endif\n\n" << tfn << "\n}  // namespace ungar_amd::gen::anymal_tiles\n";
                     std::ofstream tf(outDir + "/anymal_tiles_gen.hpp");
                     tf << to.str();
                     std::fprintf(stderr, "[codegen] anymal_tiles (lane per leg, tile stores): %zu statements, %zu flops per lane, %zu images\n", ts.statements, ts.flops,
