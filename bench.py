@@ -197,7 +197,7 @@ def measure(torch, ungar_amd, workload, instances, total_instances, begin, steps
     fence = fence or torch.cuda.synchronize
     # Untimed pre-warm: the clock governor needs a few hundred milliseconds of sustained load to reach the steady-state clocks this
     # FP64-latency-bound kernel runs at (measured: 0.262-0.266 ms per launch right after start, 0.253-0.255 ms after 0.3 s of the
-    # same launches, profiles/r02e_prewarm.log).  It precedes the W warm-up steps; the timed region is exactly `steps` steps.
+    # same launches, profiles/archive/r02e_prewarm.log).  It precedes the W warm-up steps; the timed region is exactly `steps` steps.
     t_end = time.perf_counter() + prewarm_s
     while time.perf_counter() < t_end:
         for _ in range(50):

@@ -289,7 +289,29 @@ int main(int argc, char** argv) {
             std::printf("iteration %d: %td of %td instances accepted a step; worst |d - d_facade| / |d|max = %.3e, worst |x - x_facade| / |x|max = %.3e, worst step-size difference %.3e\n",
                         iteration, moved, batch, worstStep, worstIterate, worstAlpha);
         }
-        const bool ok = worstStep <= 1e-9 && worstIterate <= 1e-9 && worstAlpha <= 1e-9;
+        // Parameters edited ON THE DEVICE between iterations (an MPC loop moving its references): the next Iterate() must see them.  Same rows through SetRows (host
+        // upload) and through DeviceRows() (device-side write after the optimiser took its parameter image of the OLD rows): identical search directions, bit for bit.
+        bool staleOk = true;
+        if constexpr (kParameters) {
+            batched.GetRows(rows.data());
+            std::vector<real_t> moved = rows;
+            for (index_t b = 0; b < batch; ++b)
+                for (index_t k = 0; k <= N; ++k)
+                    for (index_t i = 0; i < NX; ++i) moved[static_cast<std::size_t>((b * (N + 1) + k) * nv + nxu + i)] += 0.25 * std::cos(0.1 * static_cast<real_t>(b + k + i));  // reference states
+            batched.SetRows(moved.data(), xm.data());
+            batched.Iterate();
+            const std::vector<real_t> viaHost = batched.StateSteps();
+            batched.SetRows(rows.data(), xm.data());  // parameter image of the old references
+            if (ungar_device_upload(batched.DeviceRows(), moved.data(), static_cast<int64_t>(moved.size() * sizeof(real_t))) != 0) throw std::runtime_error("upload through DeviceRows failed");
+            batched.Iterate();
+            const std::vector<real_t> viaDevice = batched.StateSteps();
+            batched.SetRows(rows.data(), xm.data());
+            batched.Iterate();
+            const std::vector<real_t> oldReferences = batched.StateSteps();
+            staleOk = viaHost == viaDevice && viaHost != oldReferences;
+            std::printf("%s parameters written through DeviceRows() reach the next iteration (and change it)\n", staleOk ? "ok:" : "FAIL");
+        }
+        const bool ok = worstStep <= 1e-9 && worstIterate <= 1e-9 && worstAlpha <= 1e-9 && staleOk;
         std::printf("%s batched user OCP %td + %td, %td equality rows%s (batch %td, %td compared)\n", ok ? "PASS" : "FAIL", NX, NU, NE, kParameters ? "" : ", no parameters", batch, compared);
         return ok ? 0 : 1;
     } catch (const std::exception& e) {

@@ -9,6 +9,7 @@
 #include <cstring>
 
 #include "anymal_quad_gen.hpp"
+#include "anymal_tiles_gen.hpp"
 
 namespace {
 
@@ -53,6 +54,20 @@ struct SimIO {
     Quad dt() const { return Quad{p[0]}; }
     void phase() const {}
     void keep(const Quad&) const {}
+    Quad fma(const Quad& a, const Quad& b, const Quad& c) const { Quad r; for (int l = 0; l < 4; ++l) r.v[l] = std::fma(a.v[l], b.v[l], c.v[l]); return r; }
+    // tile program: image s holds entry kEntryOfSlot[4 s + l] in lane l; t_put2 stores images 2 p and 2 p + 1; sel4 keeps the l-th of four quad-uniform values in lane l
+    const short* tileTable = nullptr;
+    Quad sel4(const Quad& v0, const Quad& v1, const Quad& v2, const Quad& v3) const { Quad r; r.v[0] = v0.v[0]; r.v[1] = v1.v[1]; r.v[2] = v2.v[2]; r.v[3] = v3.v[3]; return r; }
+    void t_put2(int pair, const Quad& v, const Quad& v2) const {
+        const Quad* vs[2] = {&v, &v2};
+        for (int h = 0; h < 2; ++h)
+            for (int l = 0; l < 4; ++l) {
+                const int e = tileTable[4 * (2 * pair + h) + l];
+                if (e < 0) continue;
+                if (!std::isnan(J[e])) std::abort();  // every entry exactly once
+                J[e] = vs[h]->v[l];
+            }
+    }
     mutable Quad slots[512];
     Quad ld(int s) const { return slots[s]; }
     void st(int s, const Quad& v) const { slots[s] = v; }
@@ -133,4 +148,13 @@ extern "C" void anymal_quad_sim_value(const double* x, const double* u, const do
     double unused[1] = {0.0};
     SimIO io{x, u, p, f, unused};
     ungar_amd::gen::anymal_quad::ValueQuad<Quad>(io);
+}
+
+/// The tile program (quad_leg_program.hpp: tileStores): the same node through register images, read back through the generated slot table.
+extern "C" void anymal_quad_sim_tiles(const double* x, const double* u, const double* p, double* f, double* J) {
+    for (int i = 0; i < 37; ++i) f[i] = NAN;
+    for (int i = 0; i < 37 * 49; ++i) J[i] = NAN;
+    SimIO io{x, u, p, f, J};
+    io.tileTable = ungar_amd::gen::anymal_tiles::kEntryOfSlot;
+    ungar_amd::gen::anymal_tiles::ValueJacobianQuadTiles<Quad>(io);
 }

@@ -18,7 +18,8 @@ def sim(repo_root, tmp_path_factory):
         pytest.skip("generated quad program missing: run __graft_entry__.build()")
     lib = os.path.join(repo_root, "build", "libquad_sim.so")
     src = os.path.join(repo_root, "tests", "cpp", "quad_sim.cpp")
-    if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(gen), os.path.getmtime(src)):
+    tiles = os.path.join(os.path.dirname(gen), "anymal_tiles_gen.hpp")
+    if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(gen), os.path.getmtime(tiles), os.path.getmtime(src)):
         lib = str(tmp_path_factory.mktemp("quad") / "libquad_sim.so")
         subprocess.run(["g++", "-std=c++20", "-O0", "-shared", "-fPIC", "-I", os.path.dirname(gen), "-o", lib, src], check=True)
     return ctypes.CDLL(lib)
@@ -34,6 +35,23 @@ def test_quad_program_matches_golden(repo_root, sim):
         assert not np.isnan(f).any() and not np.isnan(J).any(), "every entry of f and of the dense block must be written by some lane"
         assert np.abs(f - g["f"][b]).max() <= 1e-11 * max(1.0, np.abs(g["f"][b]).max())
         assert np.abs(J - g["J"][b]).max() <= 1e-10 * np.abs(g["J"][b]).max()
+
+
+def test_tile_program_writes_every_entry_once_and_the_same_bits_as_the_unit_fastest_program(repo_root, sim):
+    """The tile program (register images + slot table, phases in another order, literal columns pooled) in the 4-lane simulator: every entry of the dense block
+    written exactly once (the simulator aborts on a second write), equal to the golden vectors, and BIT-IDENTICAL to the unit-fastest program -- the simulator is
+    compiled without contraction, and the two programs are the same expressions: neither the phase order nor the store code changes a rounding there.  (On the GPU
+    the compiler's contraction may pick fma(x, y, z w) in one kernel and fma(z, w, x y) in another: the kernels agree to the last bit or two, tests/test_tiles.py.)"""
+    g = np.load(f"{repo_root}/tests/golden/node_anymal.npz")
+    dp = ctypes.POINTER(ctypes.c_double)
+    for b in range(g["x"].shape[0]):
+        x, u, p = (np.ascontiguousarray(g[k][b]) for k in ("x", "u", "p"))
+        f, J, f2, J2 = np.zeros(37), np.zeros((37, 49)), np.zeros(37), np.zeros((37, 49))
+        sim.anymal_quad_sim_tiles(x.ctypes.data_as(dp), u.ctypes.data_as(dp), p.ctypes.data_as(dp), f.ctypes.data_as(dp), J.ctypes.data_as(dp))
+        sim.anymal_quad_sim(x.ctypes.data_as(dp), u.ctypes.data_as(dp), p.ctypes.data_as(dp), f2.ctypes.data_as(dp), J2.ctypes.data_as(dp))
+        assert not np.isnan(f).any() and not np.isnan(J).any()
+        assert np.abs(J - g["J"][b]).max() <= 1e-10 * np.abs(g["J"][b]).max()
+        assert np.array_equal(f, f2) and np.array_equal(J, J2)
 
 
 def test_value_only_quad_program_matches_golden_and_the_full_program(repo_root, sim):

@@ -36,7 +36,7 @@ struct NodeSpec {
     bool valueOnly = false;  // no Jacobian program (ungar_model_has_sparse_jacobian() == 0)
     int phasedLdsSlots = 0;  // > 0: additionally emit the phased body with this many per-lane LDS home slots
     int jacMode = 0;         // 0 = fewer statements decides; 1 = forward, 2 = reverse accumulation
-    // The three settings above were measured per model on MI355X (tools/run_rbd_variants.sh, profiles/r02k_rbd_variants.log):
+    // The three settings above were measured per model on MI355X (tools/run_rbd_variants.sh, profiles/archive/r02k_rbd_variants.log):
     // phases are Jacobian columns for forward programs and Jacobian rows (one adjoint sweep each) for reverse ones.
 };
 
@@ -479,6 +479,16 @@ int main(int argc, char** argv) {
     int crbaQuadLdsSlots = 40;  // LDS home of the lane-per-leg inertia-matrix program
     bool rneaQuadReverse = true;  // partials of the lane-local function by reverse accumulation, one phase per row (measured: 11 % faster than forward / per column)
     int rneaQuadLdsSlots = 60, rneaQuadUniformSlots = 80;  // LDS home of the lane-per-leg joint-torque program (same budget)
+    // --quad-explicit-fma 1: multiply-adds of the lane-per-leg programs contracted by the generator (Op::Fma, tape::FuseMultiplyAdd) and compiled with contraction off, so
+    // that every kernel a program is instantiated into rounds identically whatever its store code looks like to the compiler's heuristics (with the compiler's own
+    // contraction the instantiations differ in the last bit of ~1e-4 of the entries: `x y + z w` may become fma(x, y, z w) or fma(z, w, x y)).  OFF by default: the
+    // compiler finds ~100 contractions more than the generator's rule and the kernel is 2.5 % faster with them (0.2259-0.2281 against 0.2326 ms,
+    // profiles/r06c_explicit_fma.log); the tests hold kernel variants to 1e-14 of the block scale instead of to the bit.
+    bool quadExplicitFma = false;
+    // unit-fastest program: phases in this order (its paired sinks never cross a phase: any order of the column phases is valid).  As for the tile program below, the
+    // order decides how evenly the store traffic of the lock-stepped wavefronts is spread: the literal position columns (21-23: stores without arithmetic) first, then the
+    // tile program's order.  0.2415-0.2428 ms per 81 920 nodes against 0.2531 as recorded (profiles/r06b_quad_phase_order.log).
+    std::vector<int> quadPhaseOrder{0, 21, 22, 23, 1, 8, 16, 9, 15, 10, 14, 5, 13, 6, 12, 7, 11, 2, 17, 3, 18, 4, 19, 20};
     // tile program: its (self-contained) phases in this order (empty = as recorded: 0 kinematics / CRBA / factorisation, 1 value, 2-4 q_L, 5-7 v_L, 8-10 u_L columns of the
     // four legs, 11-16 base twist, 17-20 quaternion columns).  With one wavefront per SIMD every resident wavefront is in the same phase at the same time, so the ORDER
     // decides how evenly the chip's store traffic is spread: the densest phases (u_L: 19 KiB of results per 2.9 k cycles of arithmetic) right after the store-free
@@ -516,11 +526,13 @@ int main(int argc, char** argv) {
             splitConsumerUniform = std::atoi(argv[++i]);
         }
         else if (a == "--quad-pair-stores" && i + 1 < argc) quadPairStores = std::atoi(argv[++i]) != 0;
+        else if (a == "--quad-explicit-fma" && i + 1 < argc) quadExplicitFma = std::atoi(argv[++i]) != 0;
         else if (a == "--tile-interleave" && i + 1 < argc) tileInterleave = std::atoi(argv[++i]) != 0;
-        else if (a == "--tile-phase-order" && i + 1 < argc) {
-            tilePhaseOrder.clear();
+        else if ((a == "--tile-phase-order" || a == "--quad-phase-order") && i + 1 < argc) {
+            std::vector<int>& order = a == "--tile-phase-order" ? tilePhaseOrder : quadPhaseOrder;
+            order.clear();
             for (const char* c = argv[++i]; *c;) {
-                tilePhaseOrder.push_back(std::atoi(c));
+                order.push_back(std::atoi(c));
                 while (*c && *c != ',') ++c;
                 if (*c == ',') ++c;
             }
@@ -611,7 +623,7 @@ int main(int argc, char** argv) {
                 tape::EmitStats qs;
                 int quadLds = 0, quadUniformUsed = 0;
                 const std::string fn = codegen::EmitQuadProgram(qp, "ValueJacobianQuad", &qs, true, quadLdsSlots, &quadLds, quadRematConsumers, quadRematDepth, quadPrefetch,
-                                                                   quadUniformSlots, &quadUniformUsed, quadPrefetchAcross);
+                                                                   quadUniformSlots, &quadUniformUsed, quadPrefetchAcross, false, quadPhaseOrder.empty() || quadColumnsPerPhase != 1 ? nullptr : &quadPhaseOrder, quadExplicitFma);
                 std::ostringstream qo;
                 qo << "// GENERATED by ungar_amd/csrc/codegen (quad_leg_program.hpp) -- do not edit.\n"
                    << "// ANYmal B shooting node, one lane per leg: " << qs.statements << " statements, " << qs.flops << " flops, "
@@ -650,7 +662,7 @@ int main(int argc, char** argv) {
                 for (const auto& sl : qp.slots)
                     if (sl.sink.rfind("io.f_base(", 0) == 0 || sl.sink.rfind("io.f_leg(", 0) == 0) qv.slots.push_back(sl);
                 tape::EmitStats vs;
-                const std::string fnValue = codegen::EmitQuadProgram(qv, "ValueQuad", &vs, false);
+                const std::string fnValue = codegen::EmitQuadProgram(qv, "ValueQuad", &vs, false, 0, nullptr, 0, 0, 0, 0, nullptr, false, false, nullptr, quadExplicitFma);
                 qo << "};\n#endif\n\n" << fn << "\n// value only: " << vs.statements << " statements, " << vs.flops << " flops per lane\n" << fnValue
                    << "\n}  // namespace ungar_amd::gen::anymal_quad\n";
                 std::fprintf(stderr, "[codegen] anymal_quad value only: %zu statements, %zu flops per lane\n", vs.statements, vs.flops);
@@ -662,7 +674,7 @@ int main(int argc, char** argv) {
                     int tileLds = 0, tileUniformUsed = 0;
                     const std::string tfn = codegen::EmitQuadProgram(tp, "ValueJacobianQuadTiles", &ts, true, tileLdsSlots >= 0 ? tileLdsSlots : quadLdsSlots, &tileLds, quadRematConsumers,
                                                                         quadRematDepth, quadPrefetch, tileUniformSlots >= 0 ? tileUniformSlots : quadUniformSlots, &tileUniformUsed,
-                                                                        quadPrefetchAcross, tileInterleave, tilePhaseOrder.empty() ? nullptr : &tilePhaseOrder);
+                                                                        quadPrefetchAcross, tileInterleave, tilePhaseOrder.empty() ? nullptr : &tilePhaseOrder, quadExplicitFma);
                     std::ostringstream to;
                     to << "// GENERATED by ungar_amd/csrc/codegen (quad_leg_program.hpp, tile stores) -- do not edit.\n"
                        << "// ANYmal B shooting node, one lane per leg, Jacobian stored as register images: " << ts.statements << " statements, " << ts.flops

@@ -834,7 +834,30 @@ inline QuadProgram RecordQuadLegProgram(const rbd::Model& model, const tape::Spa
 inline std::string EmitQuadProgram(const QuadProgram& P, const std::string& fnName, tape::EmitStats* stats = nullptr, bool usePhases = true,
                                    int ldsSlots = 0, int* ldsSlotsUsed = nullptr, int rematConsumers = 0, int rematDepth = 0, int prefetch = 0,
                                    int uniformSlots = 0, int* uniformSlotsUsed = nullptr, bool prefetchAcrossPhases = false, bool interleaveSinks = false,
-                                   const std::vector<int>* phaseOrder = nullptr) {
+                                   const std::vector<int>* phaseOrder = nullptr, bool explicitFma = false) {
+    if (explicitFma) {  // contraction decided here, not by the compiler (tape::FuseMultiplyAdd): the function is compiled with `fp contract(off)`
+        QuadProgram fusedProgram = P;
+        std::vector<tape::Id> roots;
+        for (const auto& sl : P.slots) {
+            roots.push_back(sl.value);
+            if (sl.value2 != tape::kNoId) roots.push_back(sl.value2);
+            for (tape::Id m : sl.more) roots.push_back(m);
+        }
+        tape::FuseMultiplyAdd(P.tape.graph, roots, fusedProgram.tape.graph);
+        std::size_t next = 0;
+        for (auto& sl : fusedProgram.slots) {
+            sl.value = roots[next++];
+            if (sl.value2 != tape::kNoId) sl.value2 = roots[next++];
+            for (tape::Id& m : sl.more) m = roots[next++];
+        }
+        std::string text = EmitQuadProgram(fusedProgram, fnName, stats, usePhases, ldsSlots, ldsSlotsUsed, rematConsumers, rematDepth, prefetch, uniformSlots, uniformSlotsUsed,
+                                           prefetchAcrossPhases, interleaveSinks, phaseOrder, false);
+        const std::string head = "(IO& io) {\n";
+        const std::size_t at = text.find(head);
+        if (at == std::string::npos) throw std::logic_error("quad program: function head not found");
+        text.insert(at + head.size(), "#pragma clang fp contract(off)\n");
+        return text;
+    }
     // inputs are read ONCE into locals (an accessor call per use would be re-issued as a memory load
     // after every store, since the compiler cannot prove the output buffers do not alias them)
     std::vector<char> used(P.inputNames.size(), 0);

@@ -119,7 +119,14 @@ extern "C" int ungar_amd_launch_riccati_wave(const RiccatiArgs* a, void* stream)
     if (!k || !k->function) return -1;
     RiccatiArgs args = *a;
     void* params[] = {&args};
-    const hipError_t e = hipModuleLaunchKernel(k->function, static_cast<unsigned>(a->batch), 1, 1, 64, 1, 1,
-                                               static_cast<unsigned>(RiccatiWaveLdsDoubles(a->nx, a->nu) * sizeof(double)), s, params, nullptr);
+    const unsigned ldsBytes = static_cast<unsigned>(RiccatiWaveLdsDoubles(a->nx, a->nu) * sizeof(double));
+    if (ldsBytes > 64u * 1024u) {  // (60 + 3, 61 + 2, 62 + 1: 65.7-66.8 KB) dynamic LDS beyond 64 KiB has to be asked for
+        const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(k->function), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ldsBytes));
+        if (ea != hipSuccess) {
+            (void)hipGetLastError();
+            return -1;  // the LDS-resident kernels take the solve
+        }
+    }
+    const hipError_t e = hipModuleLaunchKernel(k->function, static_cast<unsigned>(a->batch), 1, 1, 64, 1, 1, ldsBytes, s, params, nullptr);
     return static_cast<int>(e);
 }

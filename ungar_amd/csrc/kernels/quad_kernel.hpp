@@ -98,6 +98,8 @@ struct QuadIO {
     __device__ __forceinline__ void phase() const {}
 #endif
     __device__ __forceinline__ void keep(double) const {}
+    /// a * b + c with one rounding: the generator decides which products are contracted (tape::FuseMultiplyAdd), the program is compiled with contraction off
+    __device__ __forceinline__ double fma(double a, double b, double c) const { return __builtin_fma(a, b, c); }
     __device__ __forceinline__ double ld(int slot) const { return lds[slot * 64]; }
     __device__ __forceinline__ void st(int slot, double v) const { lds[slot * 64] = v; }
     __device__ __forceinline__ double ldu(int slot) const { return ldsu[slot * 16]; }  // same address in the 4 lanes: broadcast

@@ -2,7 +2,7 @@
 //
 // The fused lane-per-leg program (quad_kernel.hpp) keeps ~258 doubles alive per lane: 512 registers + 40 KiB of LDS per
 // wavefront, ONE wavefront per SIMD -- and a lone wavefront issues a v_fma_f64 every 10.2 cycles where two wavefronts issue
-// one every 6.7 (profiles/r04e_quad_cycle_model.md).  Here the program is cut along its data flow into two halves that run
+// one every 6.7 (profiles/archive/r04e_quad_cycle_model.md).  Here the program is cut along its data flow into two halves that run
 // as the two wavefronts of a 128-lane workgroup, each with at most 256 registers and half of the workgroup's 40 KiB:
 //
 //   producer (wavefront 0)                         consumer (wavefront 1)

@@ -14,6 +14,9 @@
 // code object serves batch = 1 host calls (what Ungar::Autodiff::Function needs) and large batches.
 #include "measurement.hpp"
 #include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <chrono>
 #include <fcntl.h>
 #include <sys/file.h>
 #include <sys/stat.h>
@@ -59,6 +62,9 @@ struct ungar_function {
     int64_t dOutSize = 0;
     // single-instance host calls: pinned input staging, outputs written by the kernel straight into mapped host memory, one private stream
     double *hIn = nullptr, *hOut = nullptr, *hOutDevice = nullptr;
+    double* hInDevice = nullptr;                     // device address of hIn (mapped): small inputs are READ by the kernel over the bus, no copy command
+    unsigned long long *hFlag = nullptr, *hFlagDevice = nullptr;  // completion word in mapped host memory, written by the stream behind the kernel, polled by the host
+    unsigned long long hostCalls = 0;
     int64_t hOutSize = 0;
     hipStream_t hostStream = nullptr;
     ~ungar_function() {
@@ -66,6 +72,7 @@ struct ungar_function {
         if (dOut) (void)hipFree(dOut);
         if (hIn) (void)hipHostFree(hIn);
         if (hOut) (void)hipHostFree(hOut);
+        if (hFlag) (void)hipHostFree(hFlag);
         if (hostStream) (void)hipStreamDestroy(hostStream);
         for (hipModule_t mod : modules)
             if (mod) (void)hipModuleUnload(mod);
@@ -93,6 +100,7 @@ constexpr std::size_t kBigKernel = 3000;        // statements above which the ma
 // body: 85 s of the example's 98 s cold start on the MI355X box), and the chunks compile side by side on the host's cores.
 constexpr std::size_t kChunkStatements = 6000;
 constexpr std::size_t kMaxChunks = 64;
+constexpr int64_t kDirectHostInputs = 128;   // single-instance host calls: inputs up to this many doubles are read by the kernel from mapped host memory (no H2D copy command)
 constexpr int64_t kDirectHostResults = 512;  // single-instance host calls: results up to this many doubles are written straight into mapped host memory
 
 /// What a cache entry records besides the code objects: enough to serve every query and launch without the tape.
@@ -691,7 +699,18 @@ int ungar_function_eval_host(ungar_function* fn, int32_t what, const double* xp_
         return UNGAR_OK;
     }
     if (e == hipSuccess && !fn->hostStream) e = hipStreamCreateWithFlags(&fn->hostStream, hipStreamNonBlocking);
-    if (e == hipSuccess && !fn->hIn) e = hipHostMalloc(reinterpret_cast<void**>(&fn->hIn), static_cast<std::size_t>(std::max<int64_t>(nIn, 1)) * sizeof(double), hipHostMallocDefault);
+    if (e == hipSuccess && !fn->hIn) {
+        e = hipHostMalloc(reinterpret_cast<void**>(&fn->hIn), static_cast<std::size_t>(std::max<int64_t>(nIn, 1)) * sizeof(double), hipHostMallocMapped);
+        if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void**>(&fn->hInDevice), fn->hIn, 0);
+    }
+    // Completion: a 64-bit word in mapped host memory that the STREAM writes behind the kernel (hipStreamWriteValue64) and the host polls -- no
+    // hipStreamSynchronize (an interrupt-driven wait costs more than the launch).  A runtime without stream memory operations falls back to the wait.
+    static std::atomic<bool> streamWrites{UNGAR_MEASUREMENT_SWITCH("UNGAR_AMD_HOST_CALL_SYNCHRONIZE") == nullptr};
+    if (e == hipSuccess && !fn->hFlag && streamWrites.load(std::memory_order_relaxed)) {
+        e = hipHostMalloc(reinterpret_cast<void**>(&fn->hFlag), 64, hipHostMallocMapped);
+        if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void**>(&fn->hFlagDevice), fn->hFlag, 0);
+        if (e == hipSuccess) *fn->hFlag = 0;
+    }
     if (e == hipSuccess && fn->hOutSize < nOut) {
         if (fn->hOut) (void)hipHostFree(fn->hOut);
         fn->hOut = nullptr;
@@ -699,9 +718,12 @@ int ungar_function_eval_host(ungar_function* fn, int32_t what, const double* xp_
         if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void**>(&fn->hOutDevice), fn->hOut, 0);
         fn->hOutSize = e == hipSuccess ? nOut : 0;
     }
+    // small inputs: the kernel's one lane reads them from the mapped buffer itself (a handful of bus reads in flight at once); large ones (a whole-horizon
+    // function: hundreds of doubles, one dependent bus read each would dominate) go to device memory by one asynchronous copy on the same stream
+    const bool directIn = nIn <= kDirectHostInputs && fn->hInDevice;
     if (e == hipSuccess && nIn > 0) {
         std::memcpy(fn->hIn, xp_host, static_cast<std::size_t>(nIn) * sizeof(double));
-        e = hipMemcpyAsync(fn->dIn, fn->hIn, static_cast<std::size_t>(nIn) * sizeof(double), hipMemcpyHostToDevice, fn->hostStream);
+        if (!directIn) e = hipMemcpyAsync(fn->dIn, fn->hIn, static_cast<std::size_t>(nIn) * sizeof(double), hipMemcpyHostToDevice, fn->hostStream);
     }
     if (e != hipSuccess) return Fail(UNGAR_E_HIP, std::string("ungar_function_eval_host: ") + hipGetErrorString(e));
     // small results are written by the kernel into the mapped buffer itself; large ones (a whole-horizon Jacobian: thousands of 8-byte stores of
@@ -713,11 +735,28 @@ int ungar_function_eval_host(ungar_function* fn, int32_t what, const double* xp_
         fn->dOutSize = e == hipSuccess ? nOut : 0;
         if (e != hipSuccess) return Fail(UNGAR_E_HIP, std::string("ungar_function_eval_host: ") + hipGetErrorString(e));
     }
-    const ungar_operand in{fn->dIn, nIn, 0, 1}, outOp{direct ? fn->hOutDevice : fn->dOut, nOut, 0, 1};
+    const ungar_operand in{directIn ? fn->hInDevice : fn->dIn, nIn, 0, 1}, outOp{direct ? fn->hOutDevice : fn->dOut, nOut, 0, 1};
     const int rc = LaunchFn(fn, k, "ungar_function_eval_host", &in, &outOp, 1, fn->hostStream);
     if (rc != UNGAR_OK) return rc;
     if (!direct) e = hipMemcpyAsync(fn->hOut, fn->dOut, static_cast<std::size_t>(nOut) * sizeof(double), hipMemcpyDeviceToHost, fn->hostStream);
-    if (e == hipSuccess) e = hipStreamSynchronize(fn->hostStream);
+    bool polled = false;
+    if (e == hipSuccess && fn->hFlag && streamWrites.load(std::memory_order_relaxed)) {
+        const unsigned long long ticket = ++fn->hostCalls;
+        if (hipStreamWriteValue64(fn->hostStream, fn->hFlagDevice, ticket, 0) == hipSuccess) {
+            volatile unsigned long long* flag = fn->hFlag;
+            const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(2);
+            unsigned spins = 0;
+            while (*flag != ticket) {
+                if ((++spins & 0xFFF) == 0 && std::chrono::steady_clock::now() > deadline) break;  // a stuck queue: let the runtime report it through the wait below
+            }
+            polled = *flag == ticket;
+            std::atomic_thread_fence(std::memory_order_acquire);
+        } else {
+            (void)hipGetLastError();
+            streamWrites.store(false, std::memory_order_relaxed);
+        }
+    }
+    if (e == hipSuccess && !polled) e = hipStreamSynchronize(fn->hostStream);
     if (e != hipSuccess) return Fail(UNGAR_E_HIP, std::string("ungar_function_eval_host: ") + hipGetErrorString(e));
     std::memcpy(out_host, fn->hOut, static_cast<std::size_t>(nOut) * sizeof(double));
     return UNGAR_OK;

@@ -44,6 +44,105 @@ inline void SpellMoreValues(std::string& line, const OutputSlot& s, Spell&& spel
     }
 }
 
+/// Rewrites the program rooted at `roots` into `out` with its multiply-adds contracted EXPLICITLY (Op::Fma): a product with exactly one use, that use being a
+/// sum or a difference, is fused into it -- the second operand of the sum first, otherwise the first; a - x y = fma(-x, y, a), x y - b = fma(x, y, -b) (the
+/// negations are source modifiers of the instruction).  Compiled with contraction OFF, the generated code then performs exactly these roundings in every kernel
+/// it is instantiated into, whatever the compiler's own heuristics would have picked next to different store code.  `roots` is remapped in place.
+inline void FuseMultiplyAdd(const Graph& g, std::vector<Id>& roots, Graph& out) {
+    const std::size_t n = g.Size();
+    std::vector<char> live(n, 0);
+    std::vector<int> uses(n, 0);
+    for (Id r : roots) {
+        live[static_cast<std::size_t>(r)] = 1;
+        uses[static_cast<std::size_t>(r)] += 2;  // a value that leaves the program keeps its own name
+    }
+    for (std::size_t i = n; i-- > 0;) {
+        if (!live[i]) continue;
+        const Node& nd = g.At(static_cast<Id>(i));
+        if (nd.op == Op::Input) continue;
+        for (Id o : {nd.a, nd.b, nd.c, nd.d})
+            if (o != kNoId) {
+                live[static_cast<std::size_t>(o)] = 1;
+                ++uses[static_cast<std::size_t>(o)];
+            }
+    }
+    // A product is contracted when EVERY use of it is a sum / difference that takes it as its fused operand (a product used by three sums becomes three
+    // multiply-adds and disappears: what the compiler's own aggressive fusion does, made explicit).  A sum of two candidate products takes its second operand; the
+    // first then stays a product if it has no other taker -- iterated to a fixed point.
+    std::vector<char> candidate(n, 0);
+    std::vector<std::vector<Id>> consumers(n);
+    for (std::size_t i = 0; i < n; ++i) {
+        if (!live[i]) continue;
+        const Node& nd = g.At(static_cast<Id>(i));
+        if (nd.op == Op::Input || nd.op == Op::Const) continue;
+        for (Id o : {nd.a, nd.b, nd.c, nd.d})
+            if (o != kNoId) consumers[static_cast<std::size_t>(o)].push_back(static_cast<Id>(i));
+    }
+    std::vector<char> isRoot(n, 0);
+    for (Id r : roots) isRoot[static_cast<std::size_t>(r)] = 1;
+    for (std::size_t i = 0; i < n; ++i) {
+        if (!live[i] || g.At(static_cast<Id>(i)).op != Op::Mul || isRoot[i] || consumers[i].empty()) continue;
+        bool ok = true;
+        for (Id c : consumers[i]) {
+            const Node& nc = g.At(c);
+            ok = ok && (nc.op == Op::Add || nc.op == Op::Sub) && nc.a != nc.b;
+        }
+        candidate[i] = ok;
+    }
+    std::vector<Id> fused(n, kNoId);    // sum / difference -> the product contracted into it
+    for (bool changed = true; changed;) {
+        changed = false;
+        for (std::size_t i = 0; i < n; ++i) {
+            if (!live[i]) continue;
+            const Node& nd = g.At(static_cast<Id>(i));
+            if (nd.op != Op::Add && nd.op != Op::Sub) continue;
+            if (fused[i] != kNoId && candidate[static_cast<std::size_t>(fused[i])]) continue;
+            fused[i] = candidate[static_cast<std::size_t>(nd.b)] ? nd.b : candidate[static_cast<std::size_t>(nd.a)] ? nd.a : kNoId;
+        }
+        for (std::size_t i = 0; i < n; ++i) {
+            if (!candidate[i]) continue;
+            for (Id c : consumers[i])
+                if (fused[static_cast<std::size_t>(c)] != static_cast<Id>(i)) {
+                    candidate[i] = 0;
+                    changed = true;
+                    break;
+                }
+        }
+    }
+    std::vector<char> absorbed(n, 0);   // products that disappear into their consumers
+    for (std::size_t i = 0; i < n; ++i) {
+        absorbed[i] = candidate[i];
+        if (fused[i] != kNoId && !candidate[static_cast<std::size_t>(fused[i])]) fused[i] = kNoId;
+    }
+    out.Clear();
+    std::vector<Id> map(n, kNoId);
+    int inputs = 0;
+    for (std::size_t i = 0; i < n; ++i)
+        if (g.At(static_cast<Id>(i)).op == Op::Input) inputs = std::max(inputs, g.At(static_cast<Id>(i)).a + 1);
+    std::vector<Id> inputNode(static_cast<std::size_t>(inputs));
+    for (int k = 0; k < inputs; ++k) inputNode[static_cast<std::size_t>(k)] = out.Input();
+    auto at = [&](Id o) { return map[static_cast<std::size_t>(o)]; };
+    for (std::size_t i = 0; i < n; ++i) {
+        if (!live[i] || absorbed[i]) continue;
+        const Node& nd = g.At(static_cast<Id>(i));
+        Id r;
+        if (nd.op == Op::Const) r = out.Constant(nd.value);
+        else if (nd.op == Op::Input) r = inputNode[static_cast<std::size_t>(nd.a)];
+        else if (fused[i] != kNoId) {
+            const Node& m = g.At(fused[i]);
+            const Id x = at(m.a), y = at(m.b);
+            if (nd.op == Op::Add) r = out.Fma(x, y, at(fused[i] == nd.b ? nd.a : nd.b));
+            else if (fused[i] == nd.b) r = out.Fma(out.Unary(Op::Neg, x), y, at(nd.a));  // a - x y
+            else r = out.Fma(x, y, out.Unary(Op::Neg, at(nd.b)));                          // x y - b
+        } else if (IsUnary(nd.op)) r = out.Unary(nd.op, at(nd.a));
+        else if (IsBinary(nd.op)) r = out.Binary(nd.op, at(nd.a), at(nd.b));
+        else if (nd.op == Op::Fma) r = out.Fma(at(nd.a), at(nd.b), at(nd.c));
+        else r = out.Cond(nd.op, at(nd.a), at(nd.b), at(nd.c), at(nd.d));
+        map[i] = r;
+    }
+    for (Id& r : roots) r = at(r);
+}
+
 /// How input `i` of the tape is spelled in the generated code.
 using InputNamer = std::string (*)(int index, const void* ctx);
 
@@ -551,6 +650,7 @@ class Emitter {
             case Op::QuadRot3: return "io.quad_rot3(" + a + ")";
             case Op::Pow: ++stats_.transcendentals; return "pow(" + a + ", " + b + ")";
             case Op::Atan2: ++stats_.transcendentals; return "atan2(" + a + ", " + b + ")";
+            case Op::Fma: stats_.flops += 2; return "io.fma(" + a + ", " + b + ", " + c + ")";
             case Op::CondLt: return "(" + a + " < " + b + " ? " + c + " : " + d + ")";
             case Op::CondLe: return "(" + a + " <= " + b + " ? " + c + " : " + d + ")";
             case Op::CondEq: return "(" + a + " == " + b + " ? " + c + " : " + d + ")";
@@ -587,6 +687,7 @@ class Emitter {
             case Op::QuadRot3: return "io.quad_rot3(" + A() + ")";
             case Op::Pow: ++stats_.transcendentals; return "pow(" + A() + ", " + B() + ")";
             case Op::Atan2: ++stats_.transcendentals; return "atan2(" + A() + ", " + B() + ")";
+            case Op::Fma: stats_.flops += 2; return "io.fma(" + A() + ", " + B() + ", " + Ref(nd.c) + ")";
             case Op::CondLt: return "(" + A() + " < " + B() + " ? " + Ref(nd.c) + " : " + Ref(nd.d) + ")";
             case Op::CondLe: return "(" + A() + " <= " + B() + " ? " + Ref(nd.c) + " : " + Ref(nd.d) + ")";
             case Op::CondEq: return "(" + A() + " == " + B() + " ? " + Ref(nd.c) + " : " + Ref(nd.d) + ")";

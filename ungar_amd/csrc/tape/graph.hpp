@@ -59,10 +59,13 @@ enum class Op : std::uint8_t {
     QuadRot1,  // lane l receives the value of lane (l + 1) & 3 of its quad
     QuadRot2,
     QuadRot3,
+    // a * b + c with ONE rounding.  Never recorded and never differentiated: FuseMultiplyAdd (emit.hpp) rewrites a finished program into it, so that which products
+    // are contracted is decided by the generated source and not by the compiler (the same program then gives the same bits in every kernel it is compiled into).
+    Fma,
 };
 
 inline bool IsQuad(Op op) {
-    return op >= Op::QuadSum;
+    return op >= Op::QuadSum && op <= Op::QuadRot3;
 }
 inline bool IsCond(Op op) {
     return op >= Op::CondLt && op <= Op::CondGt;
@@ -77,6 +80,7 @@ inline int Arity(Op op) {
     if (op == Op::Const || op == Op::Input) return 0;
     if (IsUnary(op)) return 1;
     if (IsBinary(op)) return 2;
+    if (op == Op::Fma) return 3;
     return 4;
 }
 
@@ -261,6 +265,12 @@ class Graph {
             default: break;
         }
         return Intern(op, a, b, kNoId, kNoId);
+    }
+
+    /// a * b + c, fused (no algebraic rewriting: the caller decides what is contracted).
+    Id Fma(Id a, Id b, Id c) {
+        if (a > b) std::swap(a, b);
+        return Intern(Op::Fma, a, b, c, kNoId);
     }
 
     Id Cond(Op op, Id a, Id b, Id c, Id d) {

@@ -115,8 +115,14 @@ class BatchedSoftSQPOptimizer {
         Check(ungar_device_upload(_active, ones.data(), static_cast<int64_t>(ones.size() * sizeof(int32_t))));
     }
     void GetRows(real_t* rows) const { Check(ungar_device_download(rows, _rows, Bytes(RowsSize()))); }
-    /// Device pointer of the node rows (for callers that fill them on the device) -- call RefreshCarried() after writing (x, u).
-    real_t* DeviceRows() const { return _rows; }
+    /// Device pointer of the node rows, for callers that fill them on the device (stream-ordered with Iterate()).  ANY write through it is picked up by the next
+    /// Iterate(): the parameter image the stage functions read ([w | p] of every row) is refreshed from the rows first -- an MPC loop that moves its references or
+    /// parameters on the device between iterations must not optimise against the old ones.  After writing (x, u) of a problem with carried quantities call
+    /// RefreshCarried() (it rewrites the carried slots of rows 1..N, which the caller may not want on every hand-out of the pointer).
+    real_t* DeviceRows() const {
+        _parametersStale = true;
+        return _rows;
+    }
     real_t* DeviceMeasuredStates() const { return _xm; }
 
     void RefreshCarried() {
@@ -135,6 +141,7 @@ class BatchedSoftSQPOptimizer {
     /// stage functions read their parameters from it at every candidate step of the line search and at the current point, so the per-iteration images of the rows
     /// hold the variables [c | x | u] only.  Refreshed with the rows (SetRows, RefreshCarried -- call the latter after writing rows on the device).
     void RefreshParameterImage() {
+        _parametersStale = false;
         if (!_parameters) return;
         const index_t nd = Nz() + _p.inputSize;
         const real_t zero = 0.0;
@@ -144,6 +151,7 @@ class BatchedSoftSQPOptimizer {
     /// One SQP iteration of every active instance (the body of the reference's loop, soft_sqp.hpp:68-99).
     void Iterate() {
         const index_t N = _p.horizon, B = _batch, K = static_cast<index_t>(_alphas.size());
+        if (_parametersStale) RefreshParameterImage();  // the rows were handed out for device-side writes since the image was taken (DeviceRows)
         // ---- derivatives at the current rows.  The stage kernels run one lane per node: they read a unit-fastest image of the rows (the trial-row kernel with
         // one candidate of step 0 writes it: a copy) with coalesced loads, as they do in the line search -- a node-major row is 64 separate 8-byte
         // transactions per load instruction
@@ -462,6 +470,14 @@ class BatchedSoftSQPOptimizer {
         // for the reference's own problems and instantiated by the kernel factory for any other size they fit -- here, once, not inside the first iteration
         _assembleRoute = ungar_shooting_assemble_route(nz, nu, _eliminateEqualities ? Ne() : 0, Nh(), 1);
         _riccatiRoute = ungar_ocp_riccati_route(nz, nu, _eliminateEqualities ? 0 : Ne(), 1);
+        // A route of 0 where the sizes FIT the fast kernels means the kernel factory could not instantiate them on this machine (no hipcc, or the kernel sources
+        // named by UNGAR_AMD_KERNEL_SOURCES are missing): the problem then runs the LDS-resident kernels at about half the rate.  Say so once, here.
+        if (_riccatiRoute == 0 && ungar_ocp_riccati_route(nz, nu, _eliminateEqualities ? 0 : Ne(), 0) == 2)
+            UNGAR_LOG(warn, "BatchedSoftSQPOptimizer: no register-resident Riccati kernel for stage sizes {} + {} on this machine (kernel factory: hipcc / kernel sources missing, see stderr); "
+                            "taking the LDS-resident recursion", nz, nu);
+        if (_assembleRoute == 0 && ungar_shooting_assemble_route(nz, nu, _eliminateEqualities ? Ne() : 0, Nh(), 0) == 2)
+            UNGAR_LOG(warn, "BatchedSoftSQPOptimizer: no one-wavefront assembly kernel for stage sizes {} + {} with {} equality rows on this machine (kernel factory: hipcc / kernel sources "
+                            "missing, see stderr); taking the workgroup kernel", nz, nu, Ne());
         const index_t nodes = B * (N + 1), stacked = K * nodes;
         _pf = UploadPattern(*_p.dynamics, false);
         if (_p.carry) _pc = UploadPattern(*_p.carry, false);
@@ -589,6 +605,7 @@ class BatchedSoftSQPOptimizer {
     std::vector<void*> _owned;
     ungar_stage_pattern _pf{}, _pc{}, _pg{}, _pH{}, _ph{}, _pe{};
     real_t *_rows = nullptr, *_xm = nullptr, *_trial = nullptr, *_parameters = nullptr, *_listedParameters = nullptr;
+    mutable bool _parametersStale = false;  // DeviceRows() handed the rows out since the parameter image was last refreshed
     index_t _parameterStride = 0;
     real_t *_f = nullptr, *_fJ = nullptr, *_cJ = nullptr, *_l = nullptr, *_lg = nullptr, *_lH = nullptr, *_h = nullptr, *_hJ = nullptr, *_e = nullptr, *_eJ = nullptr;
     real_t *_fT = nullptr, *_lT = nullptr, *_hT = nullptr, *_eT = nullptr;

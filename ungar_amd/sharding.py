@@ -18,7 +18,7 @@ def shard_range(total_instances: int, world: int, rank: int) -> tuple[int, int]:
 # a wavefront of the ANYmal kernel keeps 1813 store streams open, one per Jacobian entry: at 65 536 instances x 20 knots in ONE
 # operand the streams are 10.5 MB apart (1813 distinct pages per wavefront) and the kernel drops from 3.2 to 4.1 ns per node;
 # tiles of 4096-8192 instances (element stride <= 1.3 MB) keep the full rate, smaller tiles lose it again to launch tails
-# (tools/bench_tiles.py, profiles/r02b_tile_sweep.json).  A rank therefore stores its shard as [tile][element][node of tile].
+# (tools/bench_tiles.py, profiles/archive/r02b_tile_sweep.json).  A rank therefore stores its shard as [tile][element][node of tile].
 DEFAULT_TILE_INSTANCES = 8192
 
 
@@ -26,7 +26,7 @@ DEFAULT_TILE_INSTANCES = 8192
 # consecutive elements a multiple of 2^17 bytes apart (4096 instances x 20 knots x 8 B = 5 x 2^17), so all 1813 store streams
 # of a wavefront -- and all Jacobian rows a Gauss-Newton workgroup reads -- fall on the SAME memory channel.  Padding the
 # stride by a few 128-byte segments rotates them over the channels: ANYmal node Jacobians 0.30-0.31 -> 0.25 ms per 81 920 nodes,
-# the Gauss-Newton kernel 0.53 -> 0.45 ms (tools/bench_stride_pad.py, profiles/r02e_stride_pad.json).  Any pad >= 32 nodes
+# the Gauss-Newton kernel 0.53 -> 0.45 ms (tools/bench_stride_pad.py, profiles/archive/r02e_stride_pad.json).  Any pad >= 32 nodes
 # (256 B) recovers the node kernel; the contraction additionally prefers an odd number of segments.
 def padded_stride(nodes: int) -> int:
     """Element stride (in doubles) for a unit-fastest operand of `nodes` nodes: a multiple of 16 nodes (128-byte segments stay

@@ -126,7 +126,7 @@ class BatchedSoftSqp:
                  stiffness: float = 100.0, epsilon: float = 2e-5, barrier: str = "poly", regularization: float = 1e-6,
                  line_search: LineSearchParameters | None = None, jacobian_in_place: bool = False):
         """jacobian_in_place: the Riccati recursion reads a wide unit-fastest [A|B] through its element stride instead of a node-major transpose
-        (identical bits; measured slower, profiles/r03f_jacobian_in_place_ab.log -- kept selectable for that comparison)."""
+        (identical bits; measured slower, profiles/archive/r03f_jacobian_in_place_ab.log -- kept selectable for that comparison)."""
         import torch
         self.torch = torch
         self.lib = _declare(load_library())
@@ -197,7 +197,7 @@ class BatchedSoftSqp:
             # element stride (the recursion's LDS-DMA copies take 8-byte elements from any address; `jacobian_in_place=True`, identical
             # bits) was measured and is slower: every element of a knot then comes from its own cache line, shared only with the same
             # instance's seven neighbouring knots, which the 512 concurrent instances evict before they are used -- QP step 6.29 ms against
-            # 4.70 ms through the transpose (profiles/r03f_jacobian_in_place_ab.log).
+            # 4.70 ms through the transpose (profiles/archive/r03f_jacobian_in_place_ab.log).
             if self._transpose_jacobian:
                 transpose_nodes(sJ, self.J, count, nx * n, (1, st), (nx * n, 1), stream=stream)
         elif derivatives:
