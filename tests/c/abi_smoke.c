@@ -8,6 +8,23 @@ int main(void) {
     int rc = ungar_model_open("quadrotor_cost", &m);
     ungar_model_info info;
     if (rc == UNGAR_OK && ungar_model_get_info(m, &info) == UNGAR_OK) printf("%s nx=%lld ny=%lld hes_nnz=%lld version=%s\n", ungar_model_name(m), (long long)info.nx, (long long)info.ny, (long long)info.hes_nnz, ungar_version());
+    {   /* wave tiles (ABI 7): a model without a tile program says so; the layout of 'anymal' is a host-side query */
+        ungar_tile_layout layout;
+        ungar_model* q = 0;
+        double dummy[2] = {0, 0};
+        ungar_node_batch nb;
+        memset(&nb, 0, sizeof nb);
+        if (ungar_model_tile_layout(m, &layout) != UNGAR_E_UNSUPPORTED || ungar_model_tile_doubles(m, 16) >= 0) return 40;
+        if (ungar_model_open("anymal", &q) != UNGAR_OK) return 41;
+        if (ungar_model_tile_layout(q, &layout) != UNGAR_OK || layout.nodes_per_tile != 16 || layout.band_tiles != 64 || layout.images % 2 != 0 || layout.entries != 37 * 49 ||
+            !layout.entry_of_slot || ungar_model_tile_doubles(q, 17) != (int64_t)64 * (layout.images / 2) * layout.unit_doubles)
+            return 42;
+        if (ungar_model_dense_jacobian_tiles(q, &nb, 0, 0) != UNGAR_E_INVALID || ungar_model_dense_jacobian_tiles(q, 0, dummy, 0) != UNGAR_E_INVALID) return 43; /* null operand */
+        nb.count = 5; nb.knots = 2;
+        if (ungar_model_dense_jacobian_tiles(q, &nb, dummy, 0) != UNGAR_E_INVALID) return 44; /* count not a multiple of knots */
+        if (ungar_tiles_gather(q, dummy, 4, 1, 0, 0) != UNGAR_E_INVALID || ungar_tiles_gather(q, dummy, 5, 2, (const ungar_operand*)&nb.jac, 0) != UNGAR_E_INVALID) return 45;
+        ungar_model_close(q);
+    }
     ungar_model_close(m);
     if (rc != UNGAR_OK) return rc;
     /* Error behaviour of the batched entry points: arguments are validated before anything touches a device, so a bad call returns

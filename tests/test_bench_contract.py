@@ -47,6 +47,7 @@ def test_bench_line_has_the_contract_fields(repo_root, shared_codegen):
     # one batched SQP iteration of each reference OCP as written, through the C++ driver
     q = d["sqp_iterations"]
     assert set(q) == {"quadrotor", "rc_car", "quadruped"} and all(0.05 < q[k]["ms_per_iteration"] < 100.0 and q[k]["instances"] == 4096 for k in q), q
+    assert all(q[k]["cpu_baseline"]["all_cores"]["instances_per_s"] > 0 and "threads" in q[k]["cpu_baseline"]["all_cores"]["measured"] for k in q), "the all-core CPU figure is measured"
     # BASELINE configs[0]: the reference's execution model (one instance per call) through the facade, and its CPU stand-ins for the secondary workloads
     assert 1.0 < d["single_instance_host_call"]["us_per_call"] < 5000.0
     assert set(c["sub_results"]) == {"quadrotor", "rc_car"} and all(v["cores"] == 1 and v["value"] > 1e5 for v in c["sub_results"].values())

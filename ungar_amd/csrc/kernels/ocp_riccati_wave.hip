@@ -22,6 +22,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <map>
+#include <tuple>
 #include <mutex>
 #include <string>
 #include <utility>
@@ -54,9 +55,11 @@ namespace {
 const ungar_amd::runtime::JitKernel* FactoryKernel(int nx, int nu) {
     // (asked once per size and process: the factory keys an entry by the CONTENT of the kernel sources, which it reads -- not something to do per launch)
     static std::mutex mutex;
-    static std::map<std::pair<int, int>, const ungar_amd::runtime::JitKernel*> known;
+    static std::map<std::tuple<int, int, int>, const ungar_amd::runtime::JitKernel*> known;  // per (shape, device): a code object is loaded into one device's context
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) device = 0;
     std::lock_guard<std::mutex> guard(mutex);
-    if (auto it = known.find({nx, nu}); it != known.end()) return it->second;
+    if (auto it = known.find({nx, nu, device}); it != known.end()) return it->second;
     const std::size_t lds = static_cast<std::size_t>(RiccatiWaveLdsDoubles(nx, nu)) * sizeof(double);
     ungar_amd::runtime::KernelRequest rq;
     rq.name = "riccati_wave_" + std::to_string(nx) + "_" + std::to_string(nu);
@@ -74,8 +77,9 @@ const ungar_amd::runtime::JitKernel* FactoryKernel(int nx, int nu) {
         reported = true;
     }
     // an instantiation that needs scratch memory even with the whole register file (tableaus near 64 columns) is not kept: the LDS-resident kernels serve that size
+    const bool transient = !k;  // a failed build (compiler missing just now, disk full) is asked again next time; a kernel that needs scratch is a property of the size
     if (k && k->scratchBytes > 0) k = nullptr;
-    known[{nx, nu}] = k;
+    if (!transient) known[{nx, nu, device}] = k;
     return k;
 }
 

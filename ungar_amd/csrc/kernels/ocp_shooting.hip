@@ -1136,9 +1136,11 @@ int LaunchAssembleWave(const ShootingAssembleArgs* a, void* stream) {
 /// compiler on the machine -- reported once, the workgroup kernel takes over).
 static const ungar_amd::runtime::JitKernel* FactoryAssembleWave(int nz, int nu, int ne) {
     static std::mutex mutex;  // (asked once per shape and process: the factory reads the kernel sources to key the entry)
-    static std::map<std::tuple<int, int, int>, const ungar_amd::runtime::JitKernel*> known;
+    static std::map<std::tuple<int, int, int, int>, const ungar_amd::runtime::JitKernel*> known;  // per (shape, device): a code object is loaded into one device's context
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) device = 0;
     std::lock_guard<std::mutex> guard(mutex);
-    if (auto it = known.find({nz, nu, ne}); it != known.end()) return it->second;
+    if (auto it = known.find({nz, nu, ne, device}); it != known.end()) return it->second;
     ungar_amd::runtime::KernelRequest rq;
     rq.name = "shooting_assemble_wave_" + std::to_string(nz) + "_" + std::to_string(nu) + "_" + std::to_string(ne);
     rq.kernel = "ungar_shooting_assemble_wave";
@@ -1152,7 +1154,7 @@ static const ungar_amd::runtime::JitKernel* FactoryAssembleWave(int nz, int nu, 
         if (!reported) std::fprintf(stderr, "[ungar_amd] one-wavefront assembly kernel %d + %d, %d rows not available (%s): the workgroup kernel takes over\n", nz, nu, ne, ungar_last_error());
         reported = true;
     }
-    known[{nz, nu, ne}] = k;
+    if (k) known[{nz, nu, ne, device}] = k;  // (a failed build is asked again next time)
     return k;
 }
 
@@ -1171,7 +1173,7 @@ static int LaunchAssembleWaveFactory(const ShootingAssembleArgs* a, void* stream
     void* params[] = {&args};
     const hipError_t e = hipModuleLaunchKernel(k->function, static_cast<unsigned>(d.batch * (d.N + 1)), 1, 1, 64, 1, 1,
                                                static_cast<unsigned>(ShootingAssembleWaveLds(d.nz(), d.nu, a->ne, a->nh)), static_cast<hipStream_t>(stream), params, nullptr);
-    return e == hipSuccess ? 0 : -1;
+    return static_cast<int>(e);  // a launch error is the caller's to report, not a reason to take the slow route silently
 }
 
 /// Which assembly kernel a stage problem of this shape takes: 0 workgroup kernel, 1 one-wavefront kernel compiled into the library, 2 one-wavefront kernel from the
@@ -1225,7 +1227,8 @@ extern "C" int ungar_amd_launch_shooting_assemble(const ShootingAssembleArgs* a,
             const bool onePerWave = UNGAR_MEASUREMENT_SWITCH("UNGAR_AMD_ASSEMBLE_ONE_NODE_PER_WAVEFRONT") != nullptr;  // A/B switch (read per call): the kernel with one node per wavefront for the narrow problems too
             if (!onePerWave && LaunchAssemblePacked(a, stream) == 0) return static_cast<int>(hipGetLastError());
             if (LaunchAssembleSmall(a, stream) == 0) return static_cast<int>(hipGetLastError());
-            if (LaunchAssembleWaveFactory(a, stream) == 0) return static_cast<int>(hipGetLastError());
+            if (const int rc = LaunchAssembleWaveFactory(a, stream); rc == 0) return static_cast<int>(hipGetLastError());
+            else if (rc > 0) return rc;  // a HIP error of the launch itself (-1: no factory kernel for this shape: the workgroup kernel below)
         }
     }
     const std::size_t nd = static_cast<std::size_t>(a->d.nd()), nz = static_cast<std::size_t>(a->d.nz());

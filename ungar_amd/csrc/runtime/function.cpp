@@ -33,6 +33,7 @@
 #include <memory>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../../include/ungar_amd.h"
@@ -458,7 +459,24 @@ int ungar_function_make(const ungar_tape_node* nodes, int64_t num_nodes, const i
                 if (!u.tmpObject.empty()) (void)std::remove(u.tmpObject.c_str());
             }
         };
+        // Compilers run concurrently, in WAVES of at most UNGAR_AMD_JIT_JOBS (default: the host's hardware threads): a function whose three derivatives are cut into
+        // 64 chunks each would otherwise start 192 hipcc processes at once -- well over a gigabyte each at -O3 -- and an out-of-memory kill reads as a compile error.
+        std::size_t maxJobs = std::max(1u, std::thread::hardware_concurrency());
+        if (const char* jobs = std::getenv("UNGAR_AMD_JIT_JOBS")) maxJobs = static_cast<std::size_t>(std::max(1L, std::atol(jobs)));
+        std::string failure;
+        auto reap = [&](Unit& u) {
+            if (!u.pipe) return;
+            char buf[512];
+            while (fgets(buf, sizeof buf, u.pipe)) u.log += buf;
+            const int st = pclose(u.pipe);
+            u.pipe = nullptr;
+            const int rc = WIFEXITED(st) ? WEXITSTATUS(st) : -1;
+            if (rc != 0) failure += "hipcc failed (" + std::to_string(rc) + ") for the " + u.tag + " kernel of function '" + fn->name + "':\n" + u.log;
+        };
+        std::size_t started = 0, reaped = 0;
         for (Unit& u : units) {
+            if (started - reaped >= maxJobs) reap(units[reaped++]);  // the oldest running compiler finishes before the next one starts
+            ++started;
             const std::string src = "// generated by ungar_amd (runtime/function.cpp) for function '" + fn->name + "'\n#include <hip/hip_runtime.h>\n\n" +
                                     EmitKernel(u.kernel, g, n, n + p, *u.values, u.first, u.last, &u.statements);
             u.flags = std::string("--offload-arch=") + kArch + " -std=c++17 " +
@@ -477,21 +495,13 @@ int ungar_function_make(const ungar_tape_node* nodes, int64_t num_nodes, const i
                 }
             }
             const std::string cmd = std::string(hipcc ? hipcc : "hipcc") + " " + u.flags + " --genco -o " + ShellQuote(u.tmpObject) + " " + ShellQuote(u.source) + " 2>&1";
-            u.pipe = popen(cmd.c_str(), "r");  // all compilers start now and run concurrently
+            u.pipe = popen(cmd.c_str(), "r");
             if (!u.pipe) {
                 cleanup();
                 return Fail(UNGAR_E_COMPILE, "cannot start hipcc for function '" + fn->name + "'");
             }
         }
-        std::string failure;
-        for (Unit& u : units) {
-            char buf[512];
-            while (fgets(buf, sizeof buf, u.pipe)) u.log += buf;
-            const int st = pclose(u.pipe);
-            u.pipe = nullptr;
-            const int rc = WIFEXITED(st) ? WEXITSTATUS(st) : -1;
-            if (rc != 0) failure += "hipcc failed (" + std::to_string(rc) + ") for the " + u.tag + " kernel of function '" + fn->name + "':\n" + u.log;
-        }
+        for (Unit& u : units) reap(u);
         if (!failure.empty()) {
             cleanup();
             return Fail(UNGAR_E_COMPILE, failure);

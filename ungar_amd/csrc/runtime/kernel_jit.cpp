@@ -50,9 +50,9 @@ bool HashIncludes(const std::string& text, const std::string& folder, const std:
             content = ReadFile(path, &ok);
             if (ok) break;
         }
-        if (!ok) {
-            *missing = name;
-            return false;
+        if (!ok) {  // an include inside a comment or a disabled #if block, or a system-style header on the compiler's own path: not part of the key
+            if (missing->empty()) *missing = name;
+            continue;
         }
         char resolved[4096];
         const std::string canonical = realpath(path.c_str(), resolved) ? std::string(resolved) : path;
@@ -127,14 +127,18 @@ const JitKernel* GetKernel(const KernelRequest& rq) {
     {
         std::set<std::string> seen;
         std::string missing;
-        if (!HashIncludes(rq.source, root, root, seen, key, &missing)) {
-            Fail(UNGAR_E_IO, "kernel factory: header '" + missing + "' of kernel '" + rq.name + "' not found under " + root);
-            return nullptr;
-        }
+        (void)HashIncludes(rq.source, root, root, seen, key, &missing);  // (a header that is really missing fails the compile below, with the compiler's message)
     }
     const std::string keyHex = key.Hex();
+    // the code object is loaded into the CURRENT device's context: the in-process entry carries the device (the on-disk entry is shared)
+    int device = 0;
+    if (!std::getenv("UNGAR_AMD_COMPILE_ONLY") && hipGetDevice(&device) != hipSuccess) {
+        (void)hipGetLastError();
+        device = 0;
+    }
+    const std::string processKey = rq.name + keyHex + "@" + std::to_string(device);
     std::lock_guard<std::mutex> guard(g_mutex);
-    if (auto it = g_kernels.find(rq.name + keyHex); it != g_kernels.end()) return it->second.get();
+    if (auto it = g_kernels.find(processKey); it != g_kernels.end()) return it->second.get();
 
     const std::string dir = DefaultFolder() + "/ungar_amd_kernels";
     const std::string base = dir + "/" + rq.name + "_" + keyHex, object = base + ".hsaco", metaPath = base + ".meta";
@@ -259,7 +263,7 @@ const JitKernel* GetKernel(const KernelRequest& rq) {
         }
     }
     const JitKernel* out = kernel.get();
-    g_kernels[rq.name + keyHex] = std::move(kernel);
+    g_kernels[processKey] = std::move(kernel);
     return out;
 }
 
