@@ -31,7 +31,8 @@ extern "C" {
  * ungar_shooting_trial_rows_listed / ungar_shooting_select_listed of the staged line search; 6: the entry points the C++ driver of round 5 calls --
  * ungar_shooting_trial_elements, ungar_function_{forward_zero,sparse_jacobian,sparse_hessian}_nodes_split, ungar_ocp_riccati_route, ungar_shooting_assemble_route,
  * ungar_measurement_build -- so that a driver header never meets a library without them; 7: the wave-tile layout of the dense block,
- * ungar_model_tile_layout / ungar_model_tile_doubles / ungar_model_dense_jacobian_tiles / ungar_tiles_gather).  ungar_abi_version() returns the version the LIBRARY was built with:
+ * ungar_model_tile_layout / ungar_model_tile_doubles / ungar_model_dense_jacobian_tiles / ungar_tiles_gather; ungar_function_get_tape, `value_stride` in
+ * ungar_shooting_merit_args).  ungar_abi_version() returns the version the LIBRARY was built with:
  * a wrapper compiled against an older header must compare the two before its first call -- a mismatch silently shifts arguments otherwise.
  * (ungar_amd/__init__.py and Ungar::BatchedSoftSQPOptimizer do.) */
 #define UNGAR_AMD_ABI_VERSION 7
@@ -457,6 +458,8 @@ typedef struct ungar_shooting_merit_args {
     int64_t rows_stride;                    /* 0: node-major rows; > 0: unit-fastest rows (ungar_shooting_trial_rows with trial_stride) */
     const int32_t* instances;               /* period > 0: null, or the device list of ungar_shooting_trial_rows_listed -- stacked point s belongs to instance
                                              * instances[s % period] (xm, dZ, dU are that instance's) */
+    int64_t value_stride;                   /* 0: f, cost, h, eq are dense arrays of nx / 1 / nh / ne values per node; > 0: all four point INTO one array of
+                                             * value_stride doubles per node (the output of one function that evaluates them together) */
 } ungar_shooting_merit_args;
 int ungar_shooting_merit(const ungar_shooting_merit_args* args, void* stream);
 
@@ -556,6 +559,10 @@ int ungar_function_make(const ungar_tape_node* nodes, int64_t num_nodes, const i
 void ungar_function_free(ungar_function* fn);
 int ungar_function_get_info(const ungar_function* fn, ungar_function_info* info);
 const char* ungar_function_code_object(const ungar_function* fn);
+/* The tape `fn` was made from, as the caller passed it (owned by `fn`; outputs: info.m node indices; folder: the model-cache folder it was made in, may be null).
+ * What a caller needs to make ONE function out of several over shared inputs -- BatchedSoftSQPOptimizer evaluates the values of all stage functions of a
+ * shooting problem at the trial points of the line search in one launch this way.  No reference counterpart (CppAD's ADFun keeps its operation sequence too). */
+int ungar_function_get_tape(const ungar_function* fn, const ungar_tape_node** nodes, int64_t* num_nodes, const int32_t** outputs, const char** folder);
 /* replaces GenericModel::JacobianSparsity / HessianSparsity(0, ...) (function.hpp:98-105, 135-145). */
 int ungar_function_jacobian_sparsity(const ungar_function* fn, const int32_t** rows, const int32_t** cols, int64_t* nnz);
 int ungar_function_hessian_sparsity(const ungar_function* fn, const int32_t** rows, const int32_t** cols, int64_t* nnz);

@@ -147,16 +147,20 @@ int main(int argc, char** argv) {
             for (index_t j = 0; j < NE; ++j) composer << v[NX + j] + 0.3 * v[j] - KnotView{v, nxu}[NX + 1 + j];
             y = composer.Compose();
         };
-        ShootingProblem problem;
-        problem.horizon = N;
-        problem.stateSize = NX;
-        problem.inputSize = NU;
-        problem.knotParameterSize = KNOT;
-        problem.instanceParameterSize = INST;
-        problem.dynamics.emplace(Autodiff::MakeFunction({stageDynamics, nxu, nPar, tag + "_stage_dyn", EnabledDerivatives::JACOBIAN, folder}, false));
-        problem.cost.emplace(Autodiff::MakeFunction({stageCost, nxu, nPar, tag + "_stage_cost", EnabledDerivatives::ALL, folder}, false));
-        problem.inequality.emplace(Autodiff::MakeFunction({stageInequality, nxu, nPar, tag + "_stage_ineq", EnabledDerivatives::JACOBIAN, folder}, false));
-        if constexpr (NE > 0) problem.equality.emplace(Autodiff::MakeFunction({stageEquality, nxu, nPar, tag + "_stage_eq", EnabledDerivatives::JACOBIAN, folder}, false));
+        const auto MakeProblem = [&]() {
+            ShootingProblem problem;
+            problem.horizon = N;
+            problem.stateSize = NX;
+            problem.inputSize = NU;
+            problem.knotParameterSize = KNOT;
+            problem.instanceParameterSize = INST;
+            problem.dynamics.emplace(Autodiff::MakeFunction({stageDynamics, nxu, nPar, tag + "_stage_dyn", EnabledDerivatives::JACOBIAN, folder}, false));
+            problem.cost.emplace(Autodiff::MakeFunction({stageCost, nxu, nPar, tag + "_stage_cost", EnabledDerivatives::ALL, folder}, false));
+            problem.inequality.emplace(Autodiff::MakeFunction({stageInequality, nxu, nPar, tag + "_stage_ineq", EnabledDerivatives::JACOBIAN, folder}, false));
+            if constexpr (NE > 0) problem.equality.emplace(Autodiff::MakeFunction({stageEquality, nxu, nPar, tag + "_stage_eq", EnabledDerivatives::JACOBIAN, folder}, false));
+            return problem;
+        };
+        ShootingProblem problem = MakeProblem();
         const index_t nv = problem.RowSize();
         const real_t multiplier = 0.1;
         BatchedSoftSQPOptimizer batched{std::move(problem), batch, false, multiplier, 2, 100.0, 1e-2};
@@ -311,7 +315,29 @@ int main(int argc, char** argv) {
             staleOk = viaHost == viaDevice && viaHost != oldReferences;
             std::printf("%s parameters written through DeviceRows() reach the next iteration (and change it)\n", staleOk ? "ok:" : "FAIL");
         }
-        const bool ok = worstStep <= 1e-9 && worstIterate <= 1e-9 && worstAlpha <= 1e-9 && staleOk;
+        // The values at the trial points come from ONE function stitched from the stage functions' tapes (BatchedSoftSQPOptimizer::BuildStageValues); evaluated one by
+        // one instead (fuseStageValues = false) the same rows must take the same steps.
+        bool fusedOk = batched.StageValuesFused();
+        {
+            batched.GetRows(rows.data());
+            batched.SetRows(rows.data(), xm.data());
+            batched.Iterate();
+            const std::vector<real_t> alphaFused = batched.AcceptedStepSizes();
+            std::vector<real_t> rowsFused(rows.size());
+            batched.GetRows(rowsFused.data());
+            BatchedSoftSQPOptimizer::fuseStageValues = false;
+            BatchedSoftSQPOptimizer plain{MakeProblem(), batch, false, multiplier, 2, 100.0, 1e-2};
+            BatchedSoftSQPOptimizer::fuseStageValues = true;
+            plain.SetRows(rows.data(), xm.data());
+            plain.Iterate();
+            std::vector<real_t> rowsPlain(rows.size());
+            plain.GetRows(rowsPlain.data());
+            real_t worst = 0.0;
+            for (std::size_t i = 0; i < rowsPlain.size(); ++i) worst = std::max(worst, std::abs(rowsPlain[i] - rowsFused[i]));
+            fusedOk = fusedOk && !plain.StageValuesFused() && alphaFused == plain.AcceptedStepSizes() && worst <= 1e-12;
+            std::printf("%s stage values in one launch: same step sizes, iterates within %.1e of the stage functions evaluated one by one\n", fusedOk ? "ok:" : "FAIL", worst);
+        }
+        const bool ok = worstStep <= 1e-9 && worstIterate <= 1e-9 && worstAlpha <= 1e-9 && staleOk && fusedOk;
         std::printf("%s batched user OCP %td + %td, %td equality rows%s (batch %td, %td compared)\n", ok ? "PASS" : "FAIL", NX, NU, NE, kParameters ? "" : ", no parameters", batch, compared);
         return ok ? 0 : 1;
     } catch (const std::exception& e) {

@@ -10,6 +10,8 @@ cp_if gpurun_out/bench.log                    profiles/bench_${tag}_anymal.json
 cp_if gpurun_out/bench_2rank_gloo.log         profiles/bench_${tag}_config5_2rank_gloo_1gpu.json
 cp_if gpurun_out/bench_config5_1gpu.log       profiles/bench_${tag}_config5_1gpu.json
 cp_if gpurun_out/bench_config5_shard_of_8.log profiles/bench_${tag}_config5_shard_of_8.json
+cp_if gpurun_out/bench_anymal_unit_fastest.log profiles/bench_${tag}_anymal_unit_fastest.json
+cp_if gpurun_out/tiles_gather.json            profiles/${tag}_tiles_gather.json
 cp_if gpurun_out/bench_srbd.log               profiles/bench_${tag}_srbd.json
 cp_if gpurun_out/bench_anymal_sparse.log      profiles/bench_${tag}_anymal_sparse.json
 cp_if gpurun_out/bench_anymal_reg.log         profiles/bench_${tag}_anymal_reg.json

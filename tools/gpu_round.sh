@@ -15,10 +15,12 @@ echo "== bench, 2 ranks sharing the device over gloo: control flow of the config
 UNGAR_BENCH_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 20 --warmup 3 2>gpurun_out/bench2.err | tail -1 > gpurun_out/bench_2rank_gloo.log
 timeout 600 python bench.py --total-batch 65536 --steps 20 --warmup 3 --no-cpu-baseline --no-sub-results 2>&1 | tail -1 > gpurun_out/bench_config5_1gpu.log
 timeout 600 python bench.py --total-batch 8192 --steps 50 --warmup 3 --no-cpu-baseline --no-sub-results 2>&1 | tail -1 > gpurun_out/bench_config5_shard_of_8.log
+timeout 300 python bench.py --layout soa --steps 50 --warmup 3 --no-cpu-baseline --no-sub-results 2>&1 | tail -1 > gpurun_out/bench_anymal_unit_fastest.log
+timeout 300 python tools/bench_tiles_gather.py 2>/dev/null | tail -1 | tee gpurun_out/tiles_gather.json | cut -c1-500
 for w in srbd; do timeout 300 python bench.py --workload $w --steps 50 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/bench_$w.log; done
 timeout 300 python bench.py --jacobian sparse --steps 50 --warmup 3 --no-cpu-baseline --no-sub-results 2>&1 | tail -1 > gpurun_out/bench_anymal_sparse.log
 for m in anymal_reg anymal_ad; do timeout 300 python bench.py --model $m --steps 20 --warmup 3 --no-cpu-baseline --no-sub-results 2>&1 | tail -1 > gpurun_out/bench_$m.log; done
-for f in bench_2rank_gloo bench_config5_1gpu bench_config5_shard_of_8 bench_srbd bench_anymal_sparse bench_anymal_reg bench_anymal_ad; do python - "$f" <<'PY'
+for f in bench_anymal_unit_fastest bench_2rank_gloo bench_config5_1gpu bench_config5_shard_of_8 bench_srbd bench_anymal_sparse bench_anymal_reg bench_anymal_ad; do python - "$f" <<'PY'
 import json, sys
 try:
     d = json.loads(open(f"gpurun_out/{sys.argv[1]}.log").read())

@@ -938,20 +938,20 @@ __global__ __launch_bounds__(kBlock) void ShootingMeritKernel(const ShootingMeri
     }
     for (int idx = lane; idx < N * nx; idx += kBlock) {
         const int k = idx / nx, i = idx - k * nx;
-        const double r = state(k + 1, i) - a.f[(s * (N + 1) + k) * nx + i];
+        const double r = state(k + 1, i) - a.f[(s * (N + 1) + k) * (a.valueStride > 0 ? a.valueStride : nx) + i];
         g2 += r * r;
     }
     if (a.e)
         for (int idx = lane; idx < N * a.ne; idx += kBlock) {
             const int k = idx / a.ne, j = idx - k * a.ne;
-            const double r = a.e[(s * (N + 1) + k) * a.ne + j];
+            const double r = a.e[(s * (N + 1) + k) * (a.valueStride > 0 ? a.valueStride : a.ne) + j];
             g2 += r * r;
         }
-    for (int k = lane; k <= N; k += kBlock) obj += a.l[s * (N + 1) + k];
+    for (int k = lane; k <= N; k += kBlock) obj += a.l[(s * (N + 1) + k) * (a.valueStride > 0 ? a.valueStride : 1)];
     if (a.h)
         for (int idx = lane; idx < N * a.nh; idx += kBlock) {
             const int k = idx / a.nh, j = idx - k * a.nh;
-            bar += Barrier(a.barrier, -a.h[(s * (N + 1) + k) * a.nh + j]);
+            bar += Barrier(a.barrier, -a.h[(s * (N + 1) + k) * (a.valueStride > 0 ? a.valueStride : a.nh) + j]);
         }
     const bool wantSlope = a.lg && a.dZ && a.slope;
     if (wantSlope)

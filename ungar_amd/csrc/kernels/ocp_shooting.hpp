@@ -93,6 +93,7 @@ struct ShootingMeritArgs {
     long long period;
     long long rowsStride = 0;  // 0: node-major rows; > 0: UNIT-FASTEST rows, element e of node i = instance * (N + 1) + knot at rows[e * rowsStride + i]
     const int* instances = nullptr;  // period > 0: stacked point s belongs to instance instances[s % period] (a LISTED subset of the instances; null: s % period)
+    long long valueStride = 0;       // 0: f, l, h, e dense per node (nx / 1 / nh / ne); > 0: all four point into one array of valueStride doubles per node
 };
 
 /// Stacked trial rows: row (c * batch + b, k) = row (b, k) with [c|x|u] += alphas[c] * [dZ; dU]  (k = N: z only), parameters copied;

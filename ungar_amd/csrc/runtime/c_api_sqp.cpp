@@ -288,6 +288,9 @@ int ungar_shooting_merit(const ungar_shooting_merit_args* a, void* stream) {
     k.period = a->period;
     k.instances = a->period > 0 ? a->instances : nullptr;
     k.rowsStride = a->rows_stride;
+    k.valueStride = a->value_stride;
+    if (a->value_stride < 0 || (a->value_stride > 0 && a->value_stride < a->dims.nx + 1 + a->nh + a->ne))
+        return Fail(UNGAR_E_INVALID, "ungar_shooting_merit: value_stride smaller than the values of a node (nx + 1 + nh + ne)");
     if (a->rows_stride < 0 || (a->rows_stride > 0 && a->rows_stride < a->dims.batch * (a->dims.horizon + 1))) return Fail(UNGAR_E_INVALID, "ungar_shooting_merit: rows_stride smaller than the number of nodes");
     return Launched(ungar_amd_launch_shooting_merit(&k, stream), "ungar_shooting_merit");
 }

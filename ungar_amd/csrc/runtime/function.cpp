@@ -57,6 +57,11 @@ struct ungar_function {
     std::vector<hipModule_t> modules;
     Kernels kValue, kJac, kHes;
     std::string codeObjectPath;
+    // the tape as the caller recorded it (ungar_function_get_tape): what a caller needs to build ONE function out of several -- the stage values of a shooting
+    // problem evaluated in a single launch (ungar/optimization/batched_soft_sqp.hpp)
+    std::vector<ungar_tape_node> tapeNodes;
+    std::vector<int32_t> tapeOutputs;
+    std::string folder;
     bool cacheHit = false;
     // staging buffers for the single-instance host entry points
     double *dIn = nullptr, *dOut = nullptr;
@@ -307,6 +312,9 @@ int ungar_function_make(const ungar_tape_node* nodes, int64_t num_nodes, const i
 
     auto fn = std::make_unique<ungar_function>();
     fn->name = name;
+    fn->tapeNodes.assign(nodes, nodes + num_nodes);
+    fn->tapeOutputs.assign(outputs, outputs + m);
+    fn->folder = folder ? folder : "";
     fn->n = n;
     fn->p = p;
     fn->m = m;
@@ -578,6 +586,15 @@ int ungar_function_get_info(const ungar_function* fn, ungar_function_info* info)
     info->jac_nnz = static_cast<int64_t>(fn->jacRows.size());
     info->hes_nnz = static_cast<int64_t>(fn->hesRows.size());
     info->cache_hit = fn->cacheHit ? 1 : 0;
+    return UNGAR_OK;
+}
+
+int ungar_function_get_tape(const ungar_function* fn, const ungar_tape_node** nodes, int64_t* num_nodes, const int32_t** outputs, const char** folder) {
+    if (!fn || !nodes || !num_nodes || !outputs) return Fail(UNGAR_E_INVALID, "ungar_function_get_tape: null argument");
+    *nodes = fn->tapeNodes.data();
+    *num_nodes = static_cast<int64_t>(fn->tapeNodes.size());
+    *outputs = fn->tapeOutputs.data();
+    if (folder) *folder = fn->folder.c_str();
     return UNGAR_OK;
 }
 

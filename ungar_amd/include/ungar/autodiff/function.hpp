@@ -233,10 +233,26 @@ class FunctionFactory {
             const tape::Node& nd = g.At(static_cast<tape::Id>(i));
             nodes[i] = {static_cast<int32_t>(nd.op), nd.a, nd.b, nd.c, nd.d, 0, nd.value};
         }
-        ungar_function* raw = nullptr;
         const std::string folder = bp.folder.string();
+        return MakeFromTape(nodes, outputs, bp.independentVariableSize, bp.parameterSize, bp.name, bp.enabledDerivatives, folder, recompileLibraries);
+    }
+
+    /// A function from a tape that is already recorded (C-ABI node format): what Make ends in, and how several functions over shared inputs become ONE
+    /// (ungar_function_get_tape; ungar/optimization/batched_soft_sqp.hpp evaluates all stage values of a shooting problem in one launch that way).
+    static Function MakeFromTape(const std::vector<ungar_tape_node>& nodes, const std::vector<int32_t>& outputs, const index_t independentVariableSize,
+                                 const index_t parameterSize, const std::string& name, const EnabledDerivatives enabledDerivatives, const std::string& folder,
+                                 const bool recompileLibraries = false) {
+        struct {
+            index_t independentVariableSize, parameterSize;
+            EnabledDerivatives enabledDerivatives;
+        } bp{independentVariableSize, parameterSize, enabledDerivatives};
+        struct {
+            index_t n;
+            index_t size() const { return n; }
+        } y{static_cast<index_t>(outputs.size())};
+        ungar_function* raw = nullptr;
         Function::Check(ungar_function_make(nodes.data(), static_cast<int64_t>(nodes.size()), outputs.data(), y.size(), bp.independentVariableSize,
-                                            bp.parameterSize, bp.name.c_str(), static_cast<uint32_t>(bp.enabledDerivatives), folder.c_str(),
+                                            bp.parameterSize, name.c_str(), static_cast<uint32_t>(bp.enabledDerivatives), folder.c_str(),
                                             recompileLibraries ? 1 : 0, &raw));
         Function f;
         f._fn.reset(raw);

@@ -93,6 +93,8 @@ class BatchedSoftSQPOptimizer {
     }
 
     inline static index_t maxStackedCandidates = 16;  // read at construction (see StackedCandidates)
+    inline static bool fuseStageValues = true;        // read at construction: the values of all stage functions at the trial points in one launch (BuildStageValues)
+    bool StageValuesFused() const { return _stageValues.has_value(); }
     const ShootingProblem& Problem() const { return _p; }
     /// Kernels the QP step of this problem runs (ungar_ocp_riccati_route / ungar_shooting_assemble_route: 0 run-time-size kernels, 1 compiled into the library,
     /// 2 instantiated for this problem's sizes by the kernel factory, 3 run-time-size one-wavefront assembly).
@@ -298,10 +300,14 @@ class BatchedSoftSQPOptimizer {
             }
             Check(ungar_shooting_trial_elements(&_dims, _rows, _dZ, _dU, _alphas.data() + begin, count, list, listed, 0, split.candidates ? Nz() + _p.inputSize : 0, _trial, stride, _stream));
             if (_p.carry) CarryValues(_trial, count * stacked, stride, split);
-            Evaluate(*_p.dynamics, 0, _trial, _p.StateOffset(), _fT, count * stacked * (N + 1), stride, split);
-            Evaluate(*_p.cost, 0, _trial, 0, _lT, count * stacked * (N + 1), stride, split);
-            if (_p.inequality) Evaluate(*_p.inequality, 0, _trial, 0, _hT, count * stacked * (N + 1), stride, split);
-            if (_p.equality) Evaluate(*_p.equality, 0, _trial, 0, _eT, count * stacked * (N + 1), stride, split);
+            if (_stageValues) {
+                Evaluate(*_stageValues, 0, _trial, 0, _fT, count * stacked * (N + 1), stride, split);
+            } else {
+                Evaluate(*_p.dynamics, 0, _trial, _p.StateOffset(), _fT, count * stacked * (N + 1), stride, split);
+                Evaluate(*_p.cost, 0, _trial, 0, _lT, count * stacked * (N + 1), stride, split);
+                if (_p.inequality) Evaluate(*_p.inequality, 0, _trial, 0, _hT, count * stacked * (N + 1), stride, split);
+                if (_p.equality) Evaluate(*_p.equality, 0, _trial, 0, _eT, count * stacked * (N + 1), stride, split);
+            }
             ungar_shooting_merit_args t = m;
             t.dims.batch = count * stacked;
             t.rows = _trial;
@@ -309,6 +315,7 @@ class BatchedSoftSQPOptimizer {
             t.cost = _lT;
             t.h = _hT;
             t.eq = _eT;
+            t.value_stride = _stageValues ? _valueWidth : 0;
             t.cost_grad = nullptr;
             t.slope = nullptr;
             t.theta = _thetaT;
@@ -504,10 +511,23 @@ class BatchedSoftSQPOptimizer {
         _hJ = _p.inequality ? Device<real_t>(nodes * _ph.nnz) : nullptr;
         _e = _p.equality ? Device<real_t>(nodes * Ne()) : nullptr;
         _eJ = _p.equality ? Device<real_t>(nodes * _pe.nnz) : nullptr;
-        _fT = Device<real_t>(stacked * nx);
-        _lT = Device<real_t>(stacked);
-        _hT = _p.inequality ? Device<real_t>(stacked * Nh()) : nullptr;
-        _eT = _p.equality ? Device<real_t>(stacked * Ne()) : nullptr;
+        // Values at the trial points of the line search: ONE function of the whole row that evaluates [f | cost | h | e] together -- the stage functions'
+        // tapes stitched onto shared inputs (ungar_function_get_tape) and compiled like any other function -- so that a search stage is one value launch instead
+        // of up to four (these kernels are launch-bound: ~10 us each whatever they compute).  Its output is one array of _valueWidth doubles per node;
+        // the merit kernel reads the four parts through `value_stride`.
+        BuildStageValues();
+        if (_stageValues) {
+            _valueWidth = nx + 1 + Nh() + Ne();
+            _fT = Device<real_t>(stacked * _valueWidth);
+            _lT = _fT + nx;
+            _hT = _p.inequality ? _lT + 1 : nullptr;
+            _eT = _p.equality ? _lT + 1 + Nh() : nullptr;
+        } else {
+            _fT = Device<real_t>(stacked * nx);
+            _lT = Device<real_t>(stacked);
+            _hT = _p.inequality ? Device<real_t>(stacked * Nh()) : nullptr;
+            _eT = _p.equality ? Device<real_t>(stacked * Ne()) : nullptr;
+        }
         _AB = Device<real_t>(B * N * nz * nd);
         _b = Device<real_t>(B * N * nz);
         _W = Device<real_t>(nodes * nd * nd);
@@ -542,6 +562,53 @@ class BatchedSoftSQPOptimizer {
 
     /// what: 0 value, 1 sparse Jacobian, 2 sparse Hessian of `f` for `count` consecutive node rows starting at `rows`; the function's
     /// variables begin `offset` doubles into each row.
+    /// Stitches the tapes of the stage functions onto the inputs of ONE function of the whole row ([c | x | u] independent, [w | p] parameters): input i of a stage
+    /// function that reads the row from element `offset` on is input offset + i of the row.  Outputs [f (nx) | cost (1) | h (nh) | e (ne)].  Value only.
+    /// inline static bool fuseStageValues = false switches it off (A/B, tests).
+    void BuildStageValues() {
+        if (!fuseStageValues || _trialStride <= 0) return;
+        struct Member {
+            const Autodiff::Function* f;
+            index_t offset;
+        };
+        std::vector<Member> members{{&*_p.dynamics, _p.StateOffset()}, {&*_p.cost, 0}};
+        if (_p.inequality) members.push_back({&*_p.inequality, 0});
+        if (_p.equality) members.push_back({&*_p.equality, 0});
+        const index_t nv = _p.RowSize(), nd = Nz() + _p.inputSize;
+        std::vector<ungar_tape_node> nodes;
+        std::vector<int32_t> outputs;
+        std::string folder, name = "stage_values";
+        for (const Member& mem : members) {
+            const ungar_tape_node* src = nullptr;
+            const int32_t* out = nullptr;
+            const char* dir = nullptr;
+            int64_t count = 0;
+            Check(ungar_function_get_tape(mem.f->Handle(), &src, &count, &out, &dir));
+            if (mem.offset + mem.f->IndependentVariableSize() + mem.f->ParameterSize() != nv) return;  // a stage function that does not read the row to its end: one by one
+            if (folder.empty() && dir) folder = dir;
+            const int32_t base = static_cast<int32_t>(nodes.size());
+            for (int64_t i = 0; i < count; ++i) {
+                ungar_tape_node nd = src[i];
+                if (nd.op == 1) {  // input: index into the row
+                    nd.a += static_cast<int32_t>(mem.offset);
+                } else if (nd.op != 0) {
+                    const int ar = nd.op <= 5 || nd.op == 18 || nd.op == 19 ? 2 : nd.op <= 17 ? 1 : 4;  // include/ungar_amd.h: op codes of ungar_tape_node
+                    nd.a += base;
+                    if (ar >= 2) nd.b += base;
+                    if (ar == 4) {
+                        nd.c += base;
+                        nd.d += base;
+                    }
+                }
+                nodes.push_back(nd);
+            }
+            for (index_t j = 0; j < mem.f->DependentVariableSize(); ++j) outputs.push_back(base + out[j]);
+            name += "_" + std::to_string(count);
+        }
+        if (static_cast<index_t>(outputs.size()) != _p.stateSize + 1 + Nh() + Ne()) return;
+        _stageValues.emplace(Autodiff::FunctionFactory::MakeFromTape(nodes, outputs, nd, nv - nd, name, EnabledDerivatives::NONE, folder));
+    }
+
     void Evaluate(const Autodiff::Function& f, int what, real_t* rows, index_t offset, real_t* out, index_t count, index_t unitFastestStride = 0, const ShootingSplitImage& split = ShootingSplitImage{}) {
         const index_t nv = _p.RowSize();
         int64_t width = f.DependentVariableSize();
@@ -609,6 +676,8 @@ class BatchedSoftSQPOptimizer {
     index_t _parameterStride = 0;
     real_t *_f = nullptr, *_fJ = nullptr, *_cJ = nullptr, *_l = nullptr, *_lg = nullptr, *_lH = nullptr, *_h = nullptr, *_hJ = nullptr, *_e = nullptr, *_eJ = nullptr;
     real_t *_fT = nullptr, *_lT = nullptr, *_hT = nullptr, *_eT = nullptr;
+    std::optional<Autodiff::Function> _stageValues;  // [f | cost | h | e] of a row in one function (BuildStageValues); empty: the stage functions one by one
+    index_t _valueWidth = 0;
     real_t *_AB = nullptr, *_b = nullptr, *_W = nullptr, *_w = nullptr, *_E = nullptr, *_dz0 = nullptr, *_dZ = nullptr, *_dU = nullptr, *_workspace = nullptr;
     int64_t _workspaceDoubles = 0;
     real_t* _er = nullptr;
