@@ -347,7 +347,7 @@ def sqp_iterations(batch=4096, timeout=420):
             if r.returncode == 0 and m:
                 ms = float(m.group(1))
                 out[problem] = {"ms_per_iteration": ms, "instances": int(m.group(2)), "instances_per_s": int(m.group(2)) / ms * 1e3, "wall_s_including_jit": time.perf_counter() - t0,
-                                "kernel_split": f"profiles/r05p_batched_{problem}_kernel_stats.csv"}
+                                "kernel_split": f"profiles/r06z_batched_{problem}_kernel_stats.csv"}
                 try:
                     out[problem]["cpu_baseline"] = sqp_cpu_stand_in(problem)
                 except Exception as e:  # noqa: BLE001 -- the stand-in must never cost the GPU figure
