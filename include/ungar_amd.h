@@ -591,10 +591,16 @@ int ungar_function_sparse_jacobian_nodes_split(const ungar_function* fn, const u
 int ungar_function_sparse_hessian_nodes_split(const ungar_function* fn, const ungar_operand* x, const ungar_operand* p, const ungar_operand* hes, int64_t count, int64_t knots,
                                               void* stream);
 
-/* Single-instance HOST call (what Ungar::Autodiff::Function::operator()/Jacobian/Hessian need):
- * copies xp to the device, launches batch = 1, copies the result back, synchronously.
- * what: 0 value (m doubles), 1 Jacobian values (jac_nnz), 2 Hessian values (hes_nnz). */
+/* Single-instance HOST call (what Ungar::Autodiff::Function::operator()/Jacobian/Hessian need -- reference function.hpp:206-259, an in-process C call there):
+ * xp_host in, the result in out_host, synchronously.  what: 0 value (m doubles), 1 Jacobian values (jac_nnz), 2 Hessian values (hes_nnz).
+ * Node-sized functions (n + p <= 128 inputs, <= 512 results) are served by a RESIDENT kernel: one lane that stays on the device between calls, is handed a
+ * call through a word of mapped host memory and answers through another -- no launch per call.  It is launched by the first call and returns by itself once
+ * nobody has called for UNGAR_AMD_HOST_CALL_RESIDENT_US microseconds (default 100; 0: never resident) or 50 ms after its launch; while it is there, a
+ * device-wide synchronisation waits for at most that long.  Larger functions: one launch per call on a private stream, operands through pinned / mapped
+ * host buffers.  Not re-entrant per function (the reference's Function is not either). */
 int ungar_function_eval_host(ungar_function* fn, int32_t what, const double* xp_host, double* out_host);
+/* 1: single-instance host calls of this derivative (what as above) are served by the resident kernel; 0: one launch per call. */
+int32_t ungar_function_host_call_resident(const ungar_function* fn, int32_t what);
 
 /* ---- diagnostics ------------------------------------------------------------------------------ */
 const char* ungar_last_error(void);

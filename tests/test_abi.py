@@ -156,7 +156,7 @@ def test_shipped_library_has_no_measurement_switches(repo_root):
         assert name not in library_names or name.encode() in measurement, f"{name} missing from the measurement build"
     # no other getenv of an UNGAR_* name than the documented interface variables
     interface = {"UNGAR_HIPCC", "UNGAR_CODEGEN_FOLDER", "UNGAR_AMD_SCALAR_STORES", "UNGAR_AMD_JIT_FLAGS", "UNGAR_AMD_JACOBIAN_MODE", "UNGAR_AMD_VERBOSE", "UNGAR_AMD_KEEP_SOURCE",
-                 "UNGAR_AMD_COMPILE_ONLY", "UNGAR_AMD_KERNEL_SOURCES", "UNGAR_AMD_JIT_JOBS"}
+                 "UNGAR_AMD_COMPILE_ONLY", "UNGAR_AMD_KERNEL_SOURCES", "UNGAR_AMD_JIT_JOBS", "UNGAR_AMD_HOST_CALL_RESIDENT_US"}
     found = set(m.decode() for m in re.findall(rb"UNGAR_[A-Z0-9_]{3,}", shipped))
     env_like = {n for n in found if n.startswith(("UNGAR_AMD_", "UNGAR_GN_", "UNGAR_HIPCC", "UNGAR_CODEGEN"))}
     undocumented = {n for n in env_like if n not in interface and not n.startswith(("UNGAR_AMD_EMITTER", "UNGAR_AMD_ABI", "UNGAR_AMD_H_", "UNGAR_AMD_DEFINE"))}

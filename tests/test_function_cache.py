@@ -227,3 +227,125 @@ def test_chunked_kernels_write_every_output(tmp_path, monkeypatch):
     assert not np.isnan(y).any()
     assert np.abs(y - expect).max() <= 1e-14
     lib.ungar_function_free(fn)
+
+
+def _make_loaded(folder, scale=1.0, name="resident_probe"):
+    lib = ungar_amd.load_library()
+    lib.ungar_function_make.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                        ctypes.c_char_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+    lib.ungar_function_free.argtypes = [ctypes.c_void_p]
+    lib.ungar_function_free.restype = None
+    lib.ungar_function_eval_host.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
+    lib.ungar_function_host_call_resident.argtypes = [ctypes.c_void_p, ctypes.c_int32]
+    lib.ungar_function_host_call_resident.restype = ctypes.c_int32
+    nodes, count, outs = _tape(scale)
+    fn = ctypes.c_void_p()
+    rc = lib.ungar_function_make(nodes, count, outs, 1, 3, 1, name.encode(), 6, str(folder).encode(), 0, ctypes.byref(fn))
+    assert rc == 0, lib.ungar_last_error().decode()
+    return lib, fn
+
+
+def _closed_forms(xp, scale):
+    """y = scale (x0^2 + x1^2 + x2^2) p0 + sin x0: value, Jacobian over x (dense row), upper Hessian entries keyed by (row, col)."""
+    import numpy as np
+    x, p0 = xp[:3], xp[3]
+    value = scale * float(x @ x) * p0 + np.sin(x[0])
+    jac = 2.0 * scale * p0 * x
+    jac[0] += np.cos(x[0])
+    hes = {(i, i): 2.0 * scale * p0 for i in range(3)}
+    hes[(0, 0)] -= np.sin(x[0])
+    return value, jac, hes
+
+
+def _resident_calls(folder, rounds=3000):
+    """value, Jacobian and Hessian of two node-sized functions through the single-instance host call, fresh inputs every call, against the closed forms."""
+    import numpy as np
+    lib, fn = _make_loaded(folder, 1.0)
+    lib2, fn2 = _make_loaded(folder, 2.5, name="resident_probe_b")
+    assert [lib.ungar_function_host_call_resident(fn, w) for w in (0, 1, 2)] == [1, 1, 1]
+    i32pp = ctypes.POINTER(ctypes.POINTER(ctypes.c_int32))
+    lib.ungar_function_jacobian_sparsity.argtypes = [ctypes.c_void_p, i32pp, i32pp, ctypes.POINTER(ctypes.c_int64)]
+    lib.ungar_function_hessian_sparsity.argtypes = [ctypes.c_void_p, i32pp, i32pp, ctypes.POINTER(ctypes.c_int64)]
+
+    def pattern(query, f):
+        rows, cols, nnz = ctypes.POINTER(ctypes.c_int32)(), ctypes.POINTER(ctypes.c_int32)(), ctypes.c_int64()
+        assert query(f, ctypes.byref(rows), ctypes.byref(cols), ctypes.byref(nnz)) == 0
+        return [(rows[k], cols[k]) for k in range(nnz.value)]
+
+    jac_pattern, hes_pattern = pattern(lib.ungar_function_jacobian_sparsity, fn), pattern(lib.ungar_function_hessian_sparsity, fn)
+    rng = np.random.default_rng(11)
+
+    def check(f, scale, what):
+        xp = rng.uniform(-2.0, 2.0, 4)
+        out = np.full(max(1, len(jac_pattern), len(hes_pattern)), np.nan)
+        assert lib.ungar_function_eval_host(f, what, xp.ctypes.data, out.ctypes.data) == 0, lib.ungar_last_error().decode()
+        value, jac, hes = _closed_forms(xp, scale)
+        if what == 0:
+            assert abs(out[0] - value) <= 1e-13 * (1.0 + abs(value))
+        elif what == 1:
+            for k, (_, c) in enumerate(jac_pattern):
+                assert abs(out[k] - jac[c]) <= 1e-13 * (1.0 + abs(jac[c])), (k, out[k], jac[c])
+        else:
+            for k, rc in enumerate(hes_pattern):
+                assert abs(out[k] - hes.get(rc, 0.0)) <= 1e-13 * (1.0 + abs(hes.get(rc, 0.0))), (rc, out[k])
+
+    for i in range(rounds):  # back to back: the kernels stay
+        check(fn, 1.0, i % 3)
+    for i in range(12):  # further apart than the idle time: launched again each time
+        time.sleep(0.002)
+        check(fn, 1.0, i % 3)
+    for i in range(rounds // 5):  # two functions in turn, six kernels alive
+        check(fn if i % 2 else fn2, 1.0 if i % 2 else 2.5, (i // 2) % 3)
+    t0 = time.perf_counter()
+    xp, out = rng.uniform(-1.0, 1.0, 4), np.zeros(4)
+    for _ in range(2000):
+        lib.ungar_function_eval_host(fn, 1, xp.ctypes.data, out.ctypes.data)
+    per_call_us = (time.perf_counter() - t0) / 2000 * 1e6
+    print(f"resident single-instance Jacobian through ctypes: {per_call_us:.2f} us per call")
+    lib.ungar_function_free(fn)
+    lib2.ungar_function_free(fn2)
+    import torch
+    torch.cuda.synchronize()  # nothing is left running
+
+
+@pytest.mark.gpu
+def test_single_instance_host_calls_through_the_resident_kernel(tmp_path, monkeypatch):
+    """Node-sized functions answer single-instance host calls from a kernel that stays on the device (ungar_amd.h: ungar_function_eval_host): value, Jacobian and
+    Hessian interleaved over thousands of calls with fresh inputs each equal their closed forms -- every call reads ITS inputs, not an earlier call's -- and so do
+    calls spaced further apart than the kernel's idle time (it has returned in between and is launched again) and calls on two functions in turn."""
+    monkeypatch.delenv("UNGAR_AMD_COMPILE_ONLY", raising=False)
+    monkeypatch.delenv("UNGAR_AMD_HOST_CALL_RESIDENT_US", raising=False)
+    _resident_calls(tmp_path)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("route", ["doorbell in host memory", "no resident kernel"])
+def test_single_instance_host_calls_on_the_other_routes(tmp_path, route):
+    """The same calls where the device does not expose its memory to the host (doorbell and inputs in mapped host memory: forced through the measurement build),
+    and with the resident kernel switched off (UNGAR_AMD_HOST_CALL_RESIDENT_US=0: one launch per call)."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k != "UNGAR_AMD_COMPILE_ONLY"}
+    program = "import sys; sys.path.insert(0, 'tests'); import test_function_cache as t; t._resident_calls(sys.argv[1], 600)"
+    if route == "doorbell in host memory":
+        env["UNGAR_AMD_LIBRARY"] = ungar_amd.measurement_library_path()
+        env["UNGAR_AMD_HOST_CALL_NO_APERTURE"] = "1"
+    else:
+        env["UNGAR_AMD_HOST_CALL_RESIDENT_US"] = "0"
+        program = program.replace("t._resident_calls(sys.argv[1], 600)", "t._resident_calls_without(sys.argv[1])")
+    r = subprocess.run([sys.executable, "-c", program, str(tmp_path)], cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def _resident_calls_without(folder):
+    """UNGAR_AMD_HOST_CALL_RESIDENT_US=0: the library reports no resident kernel, and the calls (one launch each) give the same results."""
+    import numpy as np
+    lib, fn = _make_loaded(folder, 1.0)
+    assert [lib.ungar_function_host_call_resident(fn, w) for w in (0, 1, 2)] == [0, 0, 0]
+    rng = np.random.default_rng(5)
+    for _ in range(200):
+        xp, out = rng.uniform(-2.0, 2.0, 4), np.full(1, np.nan)
+        assert lib.ungar_function_eval_host(fn, 0, xp.ctypes.data, out.ctypes.data) == 0
+        value, _, _ = _closed_forms(xp, 1.0)
+        assert abs(out[0] - value) <= 1e-13 * (1.0 + abs(value))
+    lib.ungar_function_free(fn)

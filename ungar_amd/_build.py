@@ -284,7 +284,7 @@ def build_tools():
     out = os.path.join(ROOT, "tools", "_bin")
     os.makedirs(out, exist_ok=True)
     kernel = os.path.join(CSRC, "kernels", "gn_hessian_tiles.hip")
-    for name, deps in (("gn_tiles_bench", [kernel]), ("valu_f64_peak", []), ("mfma_f64_peak", []), ("store_ceiling_tiles", []), ("store_issue_cost", [])):
+    for name, deps in (("gn_tiles_bench", [kernel]), ("valu_f64_peak", []), ("mfma_f64_peak", []), ("store_ceiling_tiles", []), ("store_issue_cost", []), ("resident_pingpong", [])):
         src = os.path.join(ROOT, "tools", f"{name}.hip")
         exe = os.path.join(out, name)
         if not _newer([exe], [src, *deps]):

@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <immintrin.h>
 #include <chrono>
 #include <fcntl.h>
 #include <sys/file.h>
@@ -73,7 +74,31 @@ struct ungar_function {
     unsigned long long hostCalls = 0;
     int64_t hOutSize = 0;
     hipStream_t hostStream = nullptr;
+    // RESIDENT single-instance kernels (value, Jacobian, Hessian: `<kernel>_serve` of the same code object, EmitKernel): a wavefront that stays on the device
+    // between host calls, is handed a call through a doorbell word and answers through a word of mapped host memory -- no launch per call.
+    // answers: two 64-bit words per derivative in mapped host memory -- [0] last ticket answered, [1] generation of the last launch that has returned.
+    // The doorbell and the inputs live in device memory that the host writes through the PCIe aperture where the device exposes all of its memory (large BAR):
+    // the wavefront then polls and fetches locally (3.2 against 5.0 us per round trip); in mapped host memory otherwise.
+    struct Resident {
+        hipFunction_t kernel = nullptr;
+        unsigned long long *answers = nullptr, *answersDevice = nullptr;
+        unsigned long long tickets = 0, generation = 0;  // generation of the launch that may still be running (0: never launched)
+        hipStream_t stream = nullptr;                    // its own: the function's other launches do not queue behind a kernel that is waiting for calls
+    } resident[3];
+    void* aperture = nullptr;     // device memory written by the host: inputs at 0, the doorbell of derivative w at 2048 + 64 w (null: mapped host memory instead)
+    unsigned long long* rings = nullptr;  // doorbells in mapped host memory (no aperture): word 8 w
+    unsigned long long* ringsDevice = nullptr;
+    bool residentReady = false;
     ~ungar_function() {
+        for (Resident& r : resident) {
+            if (r.stream) {
+                (void)hipStreamSynchronize(r.stream);  // (a resident kernel returns by itself once nobody calls; it reads the buffers freed below)
+                (void)hipStreamDestroy(r.stream);
+            }
+            if (r.answers) (void)hipHostFree(r.answers);
+        }
+        if (aperture) (void)hipFree(aperture);
+        if (rings) (void)hipHostFree(rings);
         if (dIn) (void)hipFree(dIn);
         if (dOut) (void)hipFree(dOut);
         if (hIn) (void)hipHostFree(hIn);
@@ -178,8 +203,9 @@ bool PairOutputStores() {
 }
 
 /// Outputs [first, last) of `values` (the whole derivative when the body is small enough, one chunk of it otherwise); output k is written at index k whatever the chunk.
+/// serve: the code object also gets the resident single-instance kernel `<kernelName>_serve` (below).
 std::string EmitKernel(const std::string& kernelName, const tape::Graph& g, int64_t nIndependent, int64_t nIn, const std::vector<tape::Id>& values, std::size_t first,
-                       std::size_t last, std::size_t* statements) {
+                       std::size_t last, std::size_t* statements, bool serve) {
     const bool pairs = PairOutputStores();
     std::vector<std::string> inNames;
     inNames.reserve(static_cast<std::size_t>(nIn));
@@ -225,8 +251,59 @@ std::string EmitKernel(const std::string& kernelName, const tape::Graph& g, int6
        << "    const double* __restrict__ par = pp + ib * pbs + ik * pks;\n"
        << "    double* __restrict__ out = outBase + ib * obs + ik * oks;\n";
     tape::Emitter em{g, inNames};
-    os << em.Emit(slots) << "}\n\n";
+    const std::string body = em.Emit(slots);
+    os << body << "}\n\n";
     if (statements) *statements = em.Stats().statements;
+    if (serve) {
+        // The RESIDENT form of the same body for single-instance calls from host memory (ungar_function_eval_host): ONE wavefront that stays on the device between
+        // calls.  The host announces call t by writing t into *ring behind the inputs; the wavefront fetches the inputs with one request (lane i reads input i),
+        // runs the body out of LDS in all 64 lanes alike -- the statements are scalar code: uniform LDS reads, the same cost as one lane -- writes the results with
+        // coalesced stores and answers t in answers[0] behind them (system-scope acquire / release around the call).  Measured (tools/resident_pingpong.hip): the
+        // round trip alone 5.0 us with the doorbell in host memory, 3.2 us with it in device memory the host writes through the PCIe aperture; one lane that
+        // reads its inputs where the statements use them pays a bus round trip per use, +5 us on 37 inputs.  The wavefront returns when nobody has called for
+        // `idle` ticks of the 100 MHz wall clock, or `life` ticks after it started (every device-wide synchronisation waits for it), and records the generation of
+        // its launch in answers[1] so that the host knows to launch again.
+        const std::size_t nOut = last - first;
+        os << "extern \"C\" __global__ __launch_bounds__(64) void " << kernelName
+           << "_serve(const double* hostIn, double* hostOut, unsigned long long* ring, unsigned long long* answers, unsigned long long served, unsigned long long generation, "
+              "unsigned long long idle, unsigned long long life) {\n"
+           << "    __shared__ __attribute__((aligned(16))) double arguments[" << std::max<int64_t>(nIn, 1) << "];\n"
+           << "    __shared__ __attribute__((aligned(16))) double results[" << std::max<std::size_t>(nOut, 1) << "];\n"
+           << "    const long long xes = 1, pes = 1, oes = 1;\n"
+           << "    const int lane = threadIdx.x;\n"
+           << "    if (blockIdx.x != 0) return;\n"
+           << "    const unsigned long long born = wall_clock64();\n"
+           << "    unsigned long long since = born;\n"
+           << "    for (;;) {\n"
+           << "        const unsigned long long asked = __shfl(__hip_atomic_load(ring, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), 0);  // (one address for the 64 lanes: one request)\n"
+           << "        if (asked == served) {\n"
+           << "            if (wall_clock64() - since > idle) break;\n"
+           << "            continue;\n"
+           << "        }\n"
+           << "        __atomic_thread_fence(__ATOMIC_ACQUIRE);\n"
+           << "        const double* from = hostIn;\n"
+           << "        double* to = hostOut;\n"
+           << "        asm volatile(\"\" : \"+v\"(from), \"+v\"(to) : : \"memory\");  // (this call's inputs: nothing read through an earlier copy of the pointer is reused)\n"
+           << "        for (int i = lane; i < " << nIn << "; i += 64) arguments[i] = from[i];\n"
+           << "        __syncthreads();\n"
+           << "        {\n"
+           << "            const double* __restrict__ in = arguments;\n"
+           << "            const double* __restrict__ par = arguments + " << nIndependent << ";\n"
+           << "            double* __restrict__ out = results;\n"
+           << body
+           << "        }\n"
+           << "        __syncthreads();\n"
+           << "        for (int k = lane; k < " << nOut << "; k += 64) to[k] = results[k];\n"
+           << "        __atomic_thread_fence(__ATOMIC_RELEASE);\n"
+           << "        __syncthreads();\n"
+           << "        if (lane == 0) __hip_atomic_store(answers, asked, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);\n"
+           << "        served = asked;\n"
+           << "        since = wall_clock64();\n"
+           << "        if (since - born > life) break;\n"
+           << "    }\n"
+           << "    if (lane == 0) __hip_atomic_store(answers + 1, generation, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);\n"
+           << "}\n\n";
+    }
     return os.str();
 }
 
@@ -486,7 +563,9 @@ int ungar_function_make(const ungar_tape_node* nodes, int64_t num_nodes, const i
             if (started - reaped >= maxJobs) reap(units[reaped++]);  // the oldest running compiler finishes before the next one starts
             ++started;
             const std::string src = "// generated by ungar_amd (runtime/function.cpp) for function '" + fn->name + "'\n#include <hip/hip_runtime.h>\n\n" +
-                                    EmitKernel(u.kernel, g, n, n + p, *u.values, u.first, u.last, &u.statements);
+                                    EmitKernel(u.kernel, g, n, n + p, *u.values, u.first, u.last, &u.statements,
+                                               /* a whole derivative whose operands the single-instance host call keeps in mapped host memory */
+                                               u.first == 0 && u.last == u.values->size() && n + p <= kDirectHostInputs && static_cast<int64_t>(u.values->size()) <= kDirectHostResults);
             u.flags = std::string("--offload-arch=") + kArch + " -std=c++17 " +
                       (custom ? custom : u.statements > kBigKernel ? "-O3 -mllvm -enable-misched=false -mllvm -enable-post-misched=false" : "-O3");
             u.object = base + "_" + u.tag + ".hsaco";
@@ -569,6 +648,11 @@ int ungar_function_make(const ungar_tape_node* nodes, int64_t num_nodes, const i
         e = hipModuleGetFunction(&handle, module, u.kernel.c_str());
         if (e != hipSuccess) return Fail(UNGAR_E_HIP, std::string("hipModuleGetFunction: ") + hipGetErrorString(e));
         handles.push_back(handle);
+        if (u.tag == derivative && n + p <= kDirectHostInputs) {  // (one kernel for the whole derivative: it may come with its resident form)
+            hipFunction_t serve = nullptr;
+            if (hipModuleGetFunction(&serve, module, (u.kernel + "_serve").c_str()) == hipSuccess) fn->resident[derivative == "value" ? 0 : derivative == "jacobian" ? 1 : 2].kernel = serve;
+            else (void)hipGetLastError();
+        }
     }
     *out = fn.release();
     return UNGAR_OK;
@@ -692,7 +776,15 @@ int ungar_function_sparse_hessian_nodes_split(const ungar_function* fn, const un
     return LaunchFn(fn, fn ? &fn->kHes : nullptr, "ungar_function_sparse_hessian_nodes_split", x, hes, count, stream, knots, p);
 }
 
-/// Single-instance host call: H2D, batch-1 launch, D2H, on the null stream, synchronous.
+int32_t ungar_function_host_call_resident(const ungar_function* fn, int32_t what) {
+    if (!fn || what < 0 || what > 2 || !fn->resident[what].kernel) return 0;
+    const char* v = std::getenv("UNGAR_AMD_HOST_CALL_RESIDENT_US");
+    if (v && std::atol(v) <= 0) return 0;
+    const int64_t nOut = what == 0 ? fn->m : what == 1 ? static_cast<int64_t>(fn->jacRows.size()) : static_cast<int64_t>(fn->hesRows.size());
+    return fn->n + fn->p <= kDirectHostInputs && nOut > 0 && nOut <= kDirectHostResults ? 1 : 0;
+}
+
+/// Single-instance host call (ungar_amd.h): the resident kernel for node-sized functions, one launch on a private stream otherwise.
 int ungar_function_eval_host(ungar_function* fn, int32_t what, const double* xp_host, double* out_host) {
     if (!fn || !xp_host) return Fail(UNGAR_E_INVALID, "ungar_function_eval_host: null argument");
     const int64_t nIn = fn->n + fn->p;
@@ -739,11 +831,15 @@ int ungar_function_eval_host(ungar_function* fn, int32_t what, const double* xp_
         if (e == hipSuccess) *fn->hFlag = 0;
     }
     if (e == hipSuccess && fn->hOutSize < nOut) {
+        // sized once for the largest of the three results: a resident kernel of another derivative keeps the address it was launched with
+        const int64_t largest = std::max<int64_t>({fn->m, static_cast<int64_t>(fn->jacRows.size()), static_cast<int64_t>(fn->hesRows.size()), nOut});
+        for (ungar_function::Resident& r : fn->resident)
+            if (r.stream && fn->hOut) (void)hipStreamSynchronize(r.stream);
         if (fn->hOut) (void)hipHostFree(fn->hOut);
         fn->hOut = nullptr;
-        e = hipHostMalloc(reinterpret_cast<void**>(&fn->hOut), static_cast<std::size_t>(nOut) * sizeof(double), hipHostMallocMapped);
+        e = hipHostMalloc(reinterpret_cast<void**>(&fn->hOut), static_cast<std::size_t>(largest) * sizeof(double), hipHostMallocMapped);
         if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void**>(&fn->hOutDevice), fn->hOut, 0);
-        fn->hOutSize = e == hipSuccess ? nOut : 0;
+        fn->hOutSize = e == hipSuccess ? largest : 0;
     }
     // small inputs: the kernel's one lane reads them from the mapped buffer itself (a handful of bus reads in flight at once); large ones (a whole-horizon
     // function: hundreds of doubles, one dependent bus read each would dominate) go to device memory by one asynchronous copy on the same stream
@@ -756,6 +852,81 @@ int ungar_function_eval_host(ungar_function* fn, int32_t what, const double* xp_
     // small results are written by the kernel into the mapped buffer itself; large ones (a whole-horizon Jacobian: thousands of 8-byte stores of
     // one lane, each its own PCIe write) go to device memory and come back as one asynchronous copy on the same stream
     const bool direct = nOut <= kDirectHostResults;
+    // ---- node-sized functions: the RESIDENT kernel (EmitKernel).  A call is a ticket written into mapped host memory and an answer polled from it -- two bus
+    // crossings and the body, no launch, no HIP call at all while the kernel is there.  It is launched on the first call and again whenever the previous launch
+    // has returned (nobody called for UNGAR_AMD_HOST_CALL_RESIDENT_US microseconds -- default 200, 0: never resident -- or it reached its 50 ms life).
+    static const long residentUs = [] {
+        const char* v = std::getenv("UNGAR_AMD_HOST_CALL_RESIDENT_US");
+        return v ? std::max(0L, std::atol(v)) : 100L;
+    }();
+    ungar_function::Resident& r = fn->resident[what];
+    if (r.kernel && residentUs > 0 && directIn && direct) {
+        if (!fn->residentReady) {  // once per function: where the doorbells and the inputs live
+            int device = 0, largeBar = 0;
+            const bool hostMemoryOnly = UNGAR_MEASUREMENT_SWITCH("UNGAR_AMD_HOST_CALL_NO_APERTURE") != nullptr;  // (the route of a device without a large BAR, for the tests)
+            if (!hostMemoryOnly && hipGetDevice(&device) == hipSuccess && hipDeviceGetAttribute(&largeBar, hipDeviceAttributeIsLargeBar, device) == hipSuccess && largeBar == 1) {
+                if (hipExtMallocWithFlags(&fn->aperture, 4096, hipDeviceMallocFinegrained) != hipSuccess || hipMemset(fn->aperture, 0, 4096) != hipSuccess ||
+                    hipDeviceSynchronize() != hipSuccess) {
+                    (void)hipGetLastError();
+                    if (fn->aperture) (void)hipFree(fn->aperture);
+                    fn->aperture = nullptr;
+                }
+            } else {
+                (void)hipGetLastError();
+            }
+            if (!fn->aperture) {
+                e = hipHostMalloc(reinterpret_cast<void**>(&fn->rings), 256, hipHostMallocMapped);
+                if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void**>(&fn->ringsDevice), fn->rings, 0);
+                if (e != hipSuccess) return Fail(UNGAR_E_HIP, std::string("ungar_function_eval_host: ") + hipGetErrorString(e));
+                std::memset(fn->rings, 0, 256);
+            }
+            fn->residentReady = true;
+        }
+        if (!r.answers) {
+            e = hipHostMalloc(reinterpret_cast<void**>(&r.answers), 64, hipHostMallocMapped);
+            if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void**>(&r.answersDevice), r.answers, 0);
+            if (e == hipSuccess) e = hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking);
+            if (e != hipSuccess) return Fail(UNGAR_E_HIP, std::string("ungar_function_eval_host: ") + hipGetErrorString(e));
+            r.answers[0] = r.answers[1] = 0;
+        }
+        volatile unsigned long long* answers = r.answers;
+        const unsigned long long ticket = ++r.tickets;
+        unsigned long long* ring = fn->aperture ? reinterpret_cast<unsigned long long*>(static_cast<char*>(fn->aperture) + 2048 + 64 * what) : fn->rings + 8 * what;
+        if (fn->aperture) {  // write-combined stores: the inputs are pushed out before the doorbell, the doorbell at once
+            std::memcpy(fn->aperture, xp_host, static_cast<std::size_t>(nIn) * sizeof(double));
+            _mm_sfence();
+            *static_cast<volatile unsigned long long*>(ring) = ticket;
+            _mm_sfence();
+        } else {
+            __atomic_store_n(ring, ticket, __ATOMIC_RELEASE);  // (the inputs were written into the mapped buffer above)
+        }
+        auto launch = [&]() -> hipError_t {
+            const double* in = fn->aperture ? static_cast<const double*>(fn->aperture) : fn->hInDevice;
+            double* outDevice = fn->hOutDevice;
+            unsigned long long* ringDevice = fn->aperture ? ring : fn->ringsDevice + 8 * what;
+            unsigned long long* answersDevice = r.answersDevice;
+            unsigned long long served = ticket - 1, generation = ++r.generation, idle = static_cast<unsigned long long>(residentUs) * 100ull, life = 5000000ull;  // 100 MHz
+            void* args[] = {&in, &outDevice, &ringDevice, &answersDevice, &served, &generation, &idle, &life};
+            return hipModuleLaunchKernel(r.kernel, 1, 1, 1, 64, 1, 1, 0, r.stream, args, nullptr);
+        };
+        if (r.generation == 0 || answers[1] == r.generation) e = launch();
+        const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(2);
+        unsigned spins = 0;
+        while (e == hipSuccess && answers[0] != ticket) {
+            if (answers[1] == r.generation) {  // the launch returned: before this ticket was seen (launch again), or right behind its answer
+                std::atomic_thread_fence(std::memory_order_acquire);
+                if (answers[0] == ticket) break;
+                e = launch();
+            } else if ((++spins & 0xFFF) == 0 && std::chrono::steady_clock::now() > deadline) {
+                r.kernel = nullptr;  // (the launches of the stream path from now on)
+                return Fail(UNGAR_E_HIP, "ungar_function_eval_host: the resident kernel of function '" + fn->name + "' did not answer within 2 s");
+            }
+        }
+        if (e != hipSuccess) return Fail(UNGAR_E_HIP, std::string("ungar_function_eval_host: ") + hipGetErrorString(e));
+        std::atomic_thread_fence(std::memory_order_acquire);
+        std::memcpy(out_host, fn->hOut, static_cast<std::size_t>(nOut) * sizeof(double));
+        return UNGAR_OK;
+    }
     if (!direct && fn->dOutSize < nOut) {
         if (fn->dOut) (void)hipFree(fn->dOut);
         e = hipMalloc(&fn->dOut, static_cast<std::size_t>(nOut) * sizeof(double));
