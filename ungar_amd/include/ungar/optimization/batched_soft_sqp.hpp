@@ -275,9 +275,16 @@ class BatchedSoftSQPOptimizer {
         const ungar_line_search_parameters ls{_ls.alphaMin, _ls.thetaMin, _ls.thetaMax, _ls.eta, _ls.gammaPhi, _ls.gammaTheta, _ls.gammaAlpha};
         index_t listed = 0;  // 0: all instances
         int32_t *list = nullptr, *nextList = _listA;
+        // Where most instances go on to the later stages anyway (a cold start, a problem whose full steps are rarely acceptable: nine tenths of 4096 RC-car
+        // instances in every iteration), the first stage buys nothing and costs its launches and a read-back: after such an iteration the following ones offer all
+        // candidates to everybody at once, and every eighth iteration looks again.  What is evaluated changes, never which step an instance takes.
+        static const std::vector<index_t> allAtOnce;
+        const bool probing = !_adaptiveStages || !_mostGoOn || _sinceProbe >= 8;
+        const std::vector<index_t>& stages = probing ? _stages : allAtOnce;
+        _sinceProbe = probing ? 0 : _sinceProbe + 1;
         std::size_t stage = 0;
         for (index_t begin = 0; begin < K; ++stage) {
-            const index_t left = K - begin, sized = stage < _stages.size() && _stages[stage] > 0 ? _stages[stage] : left;
+            const index_t left = K - begin, sized = stage < stages.size() && stages[stage] > 0 ? stages[stage] : left;
             const index_t wanted = sized < left ? sized : left;
             const index_t count = wanted < kStacked ? wanted : kStacked;
             const bool last = begin + count == K;
@@ -331,6 +338,7 @@ class BatchedSoftSQPOptimizer {
             begin += count;
             if (!last) {
                 const index_t unresolved = Download<int32_t>(_unresolved, 1)[0];
+                if (stage == 0) _mostGoOn = 3 * unresolved > 2 * B;
                 if (unresolved == 0) break;  // everybody took one of the steps offered so far (or had stopped): the search is closed
                 list = nextList;
                 listed = unresolved;
@@ -391,10 +399,20 @@ class BatchedSoftSQPOptimizer {
     /// Offer the first `candidates` step sizes (1, 1/2, ...) to every instance and evaluate the remaining ones only for the instances that accepted none
     /// of them -- every candidate costs a pass of the stage functions over all nodes of the instances it is offered to.  Costs one 4-byte
     /// read-back per iteration in which somebody needs a smaller step; 0 evaluates all candidates for everybody at once, without any host decision.
-    void SetFirstLineSearchStage(const index_t candidates) { _stages.assign(1, candidates); }
+    void SetFirstLineSearchStage(const index_t candidates) {
+        _stages.assign(1, candidates);
+        _adaptiveStages = false;
+    }
     /// The general form: stage s offers the next candidates[s] steps (to every instance for s = 0, to the instances still unresolved afterwards), a last stage the
     /// remaining ones.  Default {2}: 1 and 1/2 for everybody, the rest (down to alphaMin) for those who took neither.
-    void SetLineSearchStages(std::vector<index_t> candidates) { _stages = std::move(candidates); }
+    void SetLineSearchStages(std::vector<index_t> candidates) {
+        _stages = std::move(candidates);
+        _adaptiveStages = false;
+    }
+    /// Default on: an iteration whose first stage left more than two thirds of the instances unresolved is followed by iterations that offer all candidates to
+    /// everybody at once (no first stage, no read-back), every eighth of which runs the stages again to see whether that is still so.  Setting the stages by hand
+    /// switches it off.
+    void SetAdaptiveLineSearchStages(const bool on) { _adaptiveStages = on; }
     /// Stage equality rows: eliminated node by node before the recursion (default; the sequential chain then carries no constraint
     /// block) or kept inside the Riccati recursion as the stage KKT block of every knot (false; same solution, for comparison).
     void EliminateEqualityRowsBeforeTheRecursion(const bool on) { _eliminateEqualities = on; }
@@ -685,6 +703,8 @@ class BatchedSoftSQPOptimizer {
     bool _eliminateEqualities = true;
     int _assembleRoute = 0, _riccatiRoute = 0;  // ungar_shooting_assemble_route / ungar_ocp_riccati_route of this problem
     index_t _stackedCapacity = 0;  // trial points per instance the stacked buffers were allocated for
+    bool _adaptiveStages = true, _mostGoOn = false;
+    index_t _sinceProbe = 0;
     std::vector<index_t> _stages{2};  // ({2, 4} measured: no gain -- quadrotor 1.22 -> 1.27 ms, RC car 0.84 -> 0.86: who needs less than 1/2 mostly needs much less)
     int32_t *_listA = nullptr, *_listB = nullptr;  // instances a stage of the line search left unresolved (read / written alternately)
     index_t _trialStride = 0;
