@@ -1018,54 +1018,88 @@ __global__ __launch_bounds__(256) void ShootingRefreshCarriedInputsKernel(const 
     row[d.nv() + i] = row[d.nz() + i];  // (reads inputs, writes carried slots of the next row: disjoint elements, no ordering needed)
 }
 
-/// The same trial rows UNIT-FASTEST: a workgroup transposes 64 consecutive stacked nodes, up to 32 elements at a time, through an LDS tile.  The (node, element)
-/// pairs of a chunk are dealt to the lanes element-fastest, so a chunk of ANY width keeps every lane busy and reads each row segment once, contiguously (the
-/// variables of the small problems are 10 and 25 elements wide); elements are stored coalesced (64 consecutive nodes).  The 64 nodes are decomposed into
-/// (candidate, instance, knot) once per workgroup.
-/// (History: 32 lanes per node whatever the width left two thirds of the lanes idle on a 10-element window; one lane per (element, node) with the element
-/// outermost over the whole launch re-read every row line once per element from L2 -- 84 us per call of the RC car's line search, 39 % of its iteration.)
+/// The same trial rows UNIT-FASTEST: a workgroup takes 64 consecutive nodes (instance, knot) of the (listed) instances and writes their elements for ALL the
+/// candidates of the call -- row and direction are read once, up to 16 elements at a time, into two LDS tiles (the (node, element) pairs of a chunk dealt to the
+/// lanes element-fastest: a chunk of any width keeps every lane busy and reads each row segment once, contiguously), then every candidate's values leave as
+/// fma(alpha_c, direction, value), 64 consecutive nodes per element: coalesced.  The 64 nodes are decomposed into (instance, knot) once per workgroup.
+/// (History: one workgroup per 64 STACKED nodes (candidate, instance, knot) read row and direction again for every candidate and lived for ~2.5 loads per lane
+/// behind a prologue of 64-bit divisions: 95 us for the 142 MB of 14 candidates x 4096 RC-car instances, 1.5 TB/s.  Before that: 32 lanes per node whatever the
+/// width left two thirds of the lanes idle on a 10-element window; one lane per (element, node) with the element outermost over the whole launch re-read every
+/// row line once per element from L2.)
 __global__ __launch_bounds__(256) void ShootingTrialUnitFastestKernel(const ShootingTrialArgs a) {
-    constexpr int kLd = 73;  // (9 mod 32: the pairs a wavefront writes in one instruction fall into different banks for the widths that occur)
-    __shared__ double tile[32 * kLd];
+    constexpr int kLd = 73, kChunk = 16;  // (9 mod 32: the pairs a wavefront writes in one instruction fall into different banks for the widths that occur)
+    __shared__ double value[kChunk * kLd], direction[kChunk * kLd];
     __shared__ long long nodeInstance[64];
     __shared__ int nodeKnot[64];
-    __shared__ double nodeAlpha[64];
     const ShootingDims& d = a.d;
     const long long stacked = a.listed > 0 ? a.listed : d.batch;
-    const long long nodes = static_cast<long long>(a.candidates) * stacked * (d.N + 1);
+    const long long nodes = stacked * (d.N + 1);  // nodes of ONE candidate; candidate c of node i at stacked node c * nodes + i
     const long long node0 = static_cast<long long>(blockIdx.x) * 64;
     const int t = static_cast<int>(threadIdx.x), nz = d.nz(), nd = d.nd(), nv = d.nv(), nc = d.nc, N = d.N;
     if (t < 64 && node0 + t < nodes) {
-        const long long node = node0 + t, s = node / (N + 1), c = s / stacked, i = s - c * stacked;
-        nodeKnot[t] = static_cast<int>(node - s * (N + 1));
+        const long long node = node0 + t, i = node / (N + 1);
+        nodeKnot[t] = static_cast<int>(node - i * (N + 1));
         nodeInstance[t] = a.listed > 0 ? a.instances[i] : i;
-        nodeAlpha[t] = a.alphas[c];
     }
     __syncthreads();
     const int first = a.first, end = a.elements > 0 ? a.first + a.elements : nv;  // window of row elements this launch writes
     const int live = nodes - node0 < 64 ? static_cast<int>(nodes - node0) : 64;
-    for (int j0 = first; j0 < end; j0 += 32) {
-        const int width = end - j0 < 32 ? end - j0 : 32;
-        for (int f = t; f < live * width; f += 256) {
+    const int chunks = (end - first + kChunk - 1) / kChunk, perChunk = chunks > 0 ? (end - first + chunks - 1) / chunks : kChunk;  // (49 elements: 13 + 12 + 12 + 12, not 16 + 16 + 16 + 1)
+    for (int j0 = first; j0 < end; j0 += perChunk) {
+        const int width = end - j0 < perChunk ? end - j0 : perChunk;
+        // (64 nodes x at most 16 elements over 256 lanes: four trips, all their requests in front of the first use -- a trip per round trip to memory made a
+        // pass take 10 us with the whole device doing the same)
+        double v[4], step[4];
+        bool has[4];
+        const int pairs = live * width;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int f = t + 256 * u < pairs ? t + 256 * u : pairs - 1;
             const int nl = f / width, jj = f - nl * width, j = j0 + jj, k = nodeKnot[nl];
             const long long b = nodeInstance[nl];
-            const double alpha = nodeAlpha[nl];
-            double v = RowOf(a.rows, d, b, k)[j];
-            if (alpha == 0.0) {  // (a step of length 0 is the row itself, whatever the direction holds -- the unit-fastest image of the current rows)
-                if (j < nc && d.carryInputs && k > 0) v = RowOf(a.rows, d, b, k - 1)[nz + j];
-            } else if (j < nc && d.carryInputs) {
-                if (k > 0) v = fma(alpha, a.dU[(b * N + (k - 1)) * d.nu + j], RowOf(a.rows, d, b, k - 1)[nz + j]);
+            const bool carried = j < nc && d.carryInputs;
+            const double* from = carried && k > 0 ? RowOf(a.rows, d, b, k - 1) + nz + j : RowOf(a.rows, d, b, k) + j;
+            const double* along = nullptr;  // (parameters, the last knot's input slots, the carried slots of knot 0: copied)
+            if (carried) {
+                if (k > 0) along = a.dU + (b * N + (k - 1)) * d.nu + j;  // the trial input of the previous knot, the same bits the trial row k - 1 holds
             } else if (j < nz) {
-                v = fma(alpha, a.dZ[(b * (N + 1) + k) * nz + j], v);
+                along = a.dZ + (b * (N + 1) + k) * nz + j;
             } else if (j < nd && k < N) {
-                v = fma(alpha, a.dU[(b * N + k) * d.nu + (j - nz)], v);
+                along = a.dU + (b * N + k) * d.nu + (j - nz);
             }
-            tile[jj * kLd + nl] = v;
+            v[u] = *from;
+            step[u] = *(along ? along : from);  // (one request whatever the element is)
+            has[u] = along != nullptr;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int f = t + 256 * u;
+            if (f < pairs) {
+                const int nl = f / width, jj = f - nl * width;
+                value[jj * kLd + nl] = v[u];
+                direction[jj * kLd + nl] = has[u] ? step[u] : 0.0;
+            }
         }
         __syncthreads();
-        for (int f = t; f < 64 * width; f += 256) {
-            const int row = f >> 6, nl = f & 63;
-            if (nl < live) a.trial[(j0 + row - first) * a.trialStride + node0 + nl] = tile[row * kLd + nl];
+        // this workgroup's candidates: blockIdx.y, blockIdx.y + gridDim.y, ... (a launch over few nodes -- the listed instances of a later stage -- spreads its
+        // candidates over workgroups instead: one workgroup writing 12 candidates one after the other was 27 us of nothing but its own latency)
+        double tv[4], ts[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int f = t + 256 * u < 64 * width ? t + 256 * u : 0;
+            tv[u] = value[(f >> 6) * kLd + (f & 63)];
+            ts[u] = direction[(f >> 6) * kLd + (f & 63)];
+        }
+        for (int c = static_cast<int>(blockIdx.y); c < a.candidates; c += static_cast<int>(gridDim.y)) {
+            const double alpha = a.alphas[c];
+            double* out = a.trial + c * nodes + node0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int f = t + 256 * u, row = f >> 6, nl = f & 63;
+                // (a step of length 0 is the row itself, whatever the direction holds -- the unit-fastest image of the current rows)
+                // (no direction: tile entry 0, the value as it is -- its sign of zero included)
+                if (f < 64 * width && nl < live) out[(j0 + row - first) * a.trialStride + nl] = alpha == 0.0 || ts[u] == 0.0 ? tv[u] : fma(alpha, ts[u], tv[u]);
+            }
         }
         __syncthreads();
     }
@@ -1122,9 +1156,21 @@ __global__ __launch_bounds__(kBlock * kSelectWaves) void ShootingSelectKernel(co
     if (chosen < 0) return;
     const long long from = chosen * stacked + slot;
     const int nd = d.nd(), nv = d.nv();
-    for (int idx = lane; idx < (d.N + 1) * nd; idx += kBlock) {
-        const int k = idx / nd, j = idx - k * nd;
-        a.rows[(b * (d.N + 1) + k) * nv + j] = a.trialStride > 0 ? a.trial[j * a.trialStride + from * (d.N + 1) + k] : a.trial[(from * (d.N + 1) + k) * nv + j];
+    // the chosen trial row back into the rows, four trips' loads in front of their stores (rows and trial may alias as far as the compiler knows: written
+    // plainly, every trip waits for its own round trip -- 24 in a row for the quadruped's 31 x 49 variables)
+    const int total = (d.N + 1) * nd;
+    for (int base = lane; base < total; base += 4 * kBlock) {
+        double v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = base + u * kBlock < total ? base + u * kBlock : total - 1, k = idx / nd, j = idx - k * nd;
+            v[u] = a.trialStride > 0 ? a.trial[j * a.trialStride + from * (d.N + 1) + k] : a.trial[(from * (d.N + 1) + k) * nv + j];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = base + u * kBlock, k = idx / nd, j = idx - k * nd;
+            if (idx < total) a.rows[(b * (d.N + 1) + k) * nv + j] = v[u];
+        }
     }
     if (lane == 0) {
         a.accepted[b] = a.alphas[chosen];
@@ -1294,7 +1340,13 @@ extern "C" int ungar_amd_launch_shooting_merit(const ShootingMeritArgs* a, void*
 extern "C" int ungar_amd_launch_shooting_trial(const ShootingTrialArgs* a, void* stream) {
     if (a->d.batch <= 0) return 0;
     const long long nodes = static_cast<long long>(a->candidates) * (a->listed > 0 ? a->listed : a->d.batch) * (a->d.N + 1);
-    if (a->trialStride > 0) hipLaunchKernelGGL(ShootingTrialUnitFastestKernel, dim3(static_cast<unsigned>((nodes + 63) / 64)), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
+    if (a->trialStride > 0) {
+        // as many candidates per workgroup as possible -- they share the reads of row and direction -- once there are four workgroups per CU (measured on 1984
+        // groups of nodes: two candidates in two workgroups each 77 us, in one 52 us; three groups of candidates 40 us, one 35 us)
+        const long long groupsOfNodes = (nodes / a->candidates + 63) / 64, wanted = (1024 + groupsOfNodes - 1) / groupsOfNodes;
+        const unsigned candidateGroups = static_cast<unsigned>(wanted < a->candidates ? wanted : a->candidates);
+        hipLaunchKernelGGL(ShootingTrialUnitFastestKernel, dim3(static_cast<unsigned>(groupsOfNodes), candidateGroups), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
+    }
     else hipLaunchKernelGGL(ShootingTrialKernel, dim3(static_cast<unsigned>(nodes)), dim3(a->d.nv() > 64 ? 128 : kBlock), 0, static_cast<hipStream_t>(stream), *a);
     return static_cast<int>(hipGetLastError());
 }
