@@ -484,7 +484,7 @@ def facade_single_instance_latency(timeout=300):
         m = re.search(r"HOST_CALL_LATENCY_US ([0-9.]+)", r.stdout)
         if r.returncode == 0 and m:
             us = float(m.group(1))
-            return {"us_per_call": us, "evals_per_s": 1e6 / us, "what": "Ungar::Autodiff::Function::Jacobian, quadrotor node, single instance, host memory in and out (PCIe-inclusive)"}
+            return {"us_per_call": us, "evals_per_s": 1e6 / us, "what": "Ungar::Autodiff::Function::Jacobian, quadrotor node, single instance, host memory in and out (PCIe-inclusive); node-sized functions are served by a wavefront resident on the device between calls (include/ungar_amd.h: ungar_function_eval_host)"}
         return {"failed": (r.stdout + r.stderr)[-300:]}
     except subprocess.TimeoutExpired:
         return {"failed": f"timeout after {timeout} s"}

@@ -55,3 +55,5 @@ cp_if gpurun_out/split_occupancy.log        profiles/${tag}_split_occupancy.log
 cp_if gpurun_out/user_ocp.log               profiles/${tag}_user_ocp_routes.log
 cp_if gpurun_out/reference_programs.log     profiles/${tag}_reference_programs.log
 cp_if gpurun_out/quick_sqp.log              profiles/${tag}_quick_sqp.log
+cp_if gpurun_out/host_call.log              profiles/${tag}_host_call.log
+cp_if gpurun_out/resident_pingpong.log      profiles/${tag}_resident_pingpong.log

@@ -71,3 +71,6 @@ echo "== headline kernel: fused (product) against the split producer / consumer 
 bash tools/gpu_split_occupancy.sh 2>&1 | tail -30
 echo "== user OCPs of stage sizes without prebuilt kernels through the batched driver (kernel factory routes)"
 for s in 10_3_0 20_9_4; do build/batched_user_ocp_test_$s /tmp/cg_user 4096 4 2>&1 | grep -E "routes|^iteration [12]:|PASS|FAIL"; done | tee gpurun_out/user_ocp.log
+echo "== single-instance host call: Function::Jacobian of the quadrotor node (resident wavefront; one launch per call with UNGAR_AMD_HOST_CALL_RESIDENT_US=0), the bare round trip"
+{ for i in 1 2 3; do timeout 120 build/function_test /tmp/cg_lat latency 2>&1 | grep HOST_CALL; done; echo "UNGAR_AMD_HOST_CALL_RESIDENT_US=0:"; UNGAR_AMD_HOST_CALL_RESIDENT_US=0 timeout 120 build/function_test /tmp/cg_lat latency 2>&1 | grep HOST_CALL; } | tee gpurun_out/host_call.log
+timeout 120 tools/_bin/resident_pingpong 2>&1 | tee gpurun_out/resident_pingpong.log
