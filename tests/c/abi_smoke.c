@@ -76,6 +76,8 @@ int main(void) {
             bad += ungar_device_malloc(&ptr, -1) != UNGAR_E_INVALID;
             bad += ungar_device_malloc(&ptr, 0) != UNGAR_OK || ptr != 0;
             bad += ungar_function_forward_zero_nodes(0, &op, &op, 4, 2, 0) != UNGAR_E_INVALID;
+            bad += ungar_function_host_call_resident(0, 1) != 0; /* no function: no resident kernel */
+            bad += ungar_function_eval_host(0, 0, dummy, dummy) != UNGAR_E_INVALID;
         }
         bad += ungar_last_error()[0] == 0;
         printf("argument checks: %d unexpected\n", bad);
