@@ -518,6 +518,11 @@ int ungar_device_download(void* dst_host, const void* src_device, int64_t bytes)
 int ungar_device_zero(void* dst_device, int64_t bytes, void* stream);
 int ungar_device_copy(void* dst_device, const void* src_device, int64_t bytes, void* stream);  /* stream-ordered */
 int ungar_device_synchronize(void);
+/* A few bytes (<= 64) of device memory as they are after everything `stream` has been given so far: an asynchronous copy into pinned host memory and a
+ * completion word the stream writes behind it, which the host polls -- the read-back of a count between two launches of a loop (the unresolved instances of
+ * a line-search stage) without a device-wide, interrupt-driven wait (50 us against ~15 around 4 bytes).  Falls back to hipStreamSynchronize where the runtime has
+ * no stream memory operations. */
+int ungar_device_read_polled(void* dst_host, const void* src_device, int64_t bytes, void* stream);
 
 /* ---- run-time function factory (any recorded function, not only the built-in node models) ----- */
 

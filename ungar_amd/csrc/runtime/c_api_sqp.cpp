@@ -2,7 +2,10 @@
 #include "measurement.hpp"
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <chrono>
 #include <cstdint>
+#include <cstring>
 #include <cstdlib>
 #include <string>
 
@@ -422,6 +425,51 @@ int ungar_device_copy(void* dst, const void* src, int64_t bytes, void* stream) {
     if (bytes == 0) return UNGAR_OK;
     const hipError_t e = hipMemcpyAsync(dst, src, static_cast<std::size_t>(bytes), hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return Fail(UNGAR_E_HIP, std::string("ungar_device_copy: ") + hipGetErrorString(e));
+    return UNGAR_OK;
+}
+int ungar_device_read_polled(void* dst, const void* src, int64_t bytes, void* stream) {
+    if (bytes < 0 || bytes > 64 || (bytes > 0 && (!dst || !src))) return Fail(UNGAR_E_INVALID, "ungar_device_read_polled: bad argument (at most 64 bytes)");
+    if (bytes == 0) return UNGAR_OK;
+    struct Staging {  // per host thread, for the life of the process
+        unsigned char* data = nullptr;
+        unsigned long long *flag = nullptr, *flagDevice = nullptr;
+        unsigned long long tickets = 0;
+        bool streamWrites = true;
+    };
+    static thread_local Staging st;
+    hipError_t e = hipSuccess;
+    if (!st.data) {
+        void* block = nullptr;
+        e = hipHostMalloc(&block, 128, hipHostMallocMapped);
+        if (e == hipSuccess) {
+            st.data = static_cast<unsigned char*>(block);
+            st.flag = reinterpret_cast<unsigned long long*>(st.data + 64);
+            *st.flag = 0;
+            e = hipHostGetDevicePointer(reinterpret_cast<void**>(&st.flagDevice), st.flag, 0);
+        }
+        if (e != hipSuccess) return Fail(UNGAR_E_HIP, std::string("ungar_device_read_polled: ") + hipGetErrorString(e));
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    e = hipMemcpyAsync(st.data, src, static_cast<std::size_t>(bytes), hipMemcpyDeviceToHost, s);
+    bool polled = false;
+    if (e == hipSuccess && st.streamWrites) {
+        const unsigned long long ticket = ++st.tickets;
+        if (hipStreamWriteValue64(s, st.flagDevice, ticket, 0) == hipSuccess) {
+            volatile unsigned long long* flag = st.flag;
+            const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(2);
+            unsigned spins = 0;
+            while (*flag != ticket)
+                if ((++spins & 0xFFF) == 0 && std::chrono::steady_clock::now() > deadline) break;  // a stuck queue: the wait below reports it
+            polled = *flag == ticket;
+            std::atomic_thread_fence(std::memory_order_acquire);
+        } else {
+            (void)hipGetLastError();
+            st.streamWrites = false;
+        }
+    }
+    if (e == hipSuccess && !polled) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return Fail(UNGAR_E_HIP, std::string("ungar_device_read_polled: ") + hipGetErrorString(e));
+    std::memcpy(dst, st.data, static_cast<std::size_t>(bytes));
     return UNGAR_OK;
 }
 int ungar_device_synchronize(void) {
