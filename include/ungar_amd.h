@@ -591,6 +591,11 @@ int ungar_function_sparse_hessian_nodes(const ungar_function* fn, const ungar_op
  * (candidate step, node) pairs -- instance := candidate, knot := node -- where only the variables differ between candidates, and keeps one unit-fastest
  * image of the node parameters (ungar_shooting_trial_elements) instead of copying them for every candidate. */
 int ungar_function_forward_zero_nodes_split(const ungar_function* fn, const ungar_operand* x, const ungar_operand* p, const ungar_operand* y, int64_t count, int64_t knots, void* stream);
+/* The same with a parameter operand of `parameter_instances` instances that instance i reads at index i % parameter_instances: candidate steps stacked
+ * INSTANCE-wise (instance := candidate x instance, knot := knot < knots) over one image of the instances' parameters -- the carried quantities of the trial
+ * points of a line search, which exist for the knots 0 .. N - 1 of N + 1 only, in one launch instead of one per candidate. */
+int ungar_function_forward_zero_nodes_periodic(const ungar_function* fn, const ungar_operand* x, const ungar_operand* p, int64_t parameter_instances, const ungar_operand* y,
+                                               int64_t count, int64_t knots, void* stream);
 int ungar_function_sparse_jacobian_nodes_split(const ungar_function* fn, const ungar_operand* x, const ungar_operand* p, const ungar_operand* jac, int64_t count, int64_t knots,
                                                void* stream);
 int ungar_function_sparse_hessian_nodes_split(const ungar_function* fn, const ungar_operand* x, const ungar_operand* p, const ungar_operand* hes, int64_t count, int64_t knots,

@@ -124,7 +124,7 @@ constexpr uint32_t kEnableHessian = 1U << 2;   // EnabledDerivatives::HESSIAN
 #ifndef UNGAR_AMD_EMITTER_ID
 #define UNGAR_AMD_EMITTER_ID "unversioned"
 #endif
-constexpr const char* kCacheFormat = "ungar_amd-cache-6";  // bump whenever the emitted kernels' argument list (their ABI) or the meta file changes: 3 = ten-argument kernels (knot stride, direct host results), 4 = consecutive outputs leave in 16-byte stores, 5 = a derivative may consist of several kernels (chunks of consecutive outputs; unit tags "jacobian.3"), 6 = fourteen-argument kernels (the parameters through an operand of their own)
+constexpr const char* kCacheFormat = "ungar_amd-cache-7";  // bump whenever the emitted kernels' argument list (their ABI) or the meta file changes: 3 = ten-argument kernels (knot stride, direct host results), 4 = consecutive outputs leave in 16-byte stores, 5 = a derivative may consist of several kernels (chunks of consecutive outputs; unit tags "jacobian.3"), 6 = fourteen-argument kernels (the parameters through an operand of their own), 7 = fifteen arguments (period of the parameter operand's instance index) + the resident single-instance kernel
 constexpr std::size_t kBigKernel = 3000;        // statements above which the machine schedulers are switched off (see below)
 // Statements above which a derivative is cut into chunks of consecutive outputs, one kernel and one compiler process each: the compile time of
 // a straight-line body grows faster than its length (the equality-constraint Jacobian of the reference's quadruped OCP, 14 167 outputs in one
@@ -242,13 +242,15 @@ std::string EmitKernel(const std::string& kernelName, const tape::Graph& g, int6
     // launched with 64-lane workgroups (LaunchFn): tell the compiler, so that it may use the full register file
     os << "extern \"C\" __global__ __launch_bounds__(64) void " << kernelName
        << "(const double* __restrict__ xp, long long xbs, long long xes, double* __restrict__ outBase, long long obs, long long oes, long long "
-          "batch, long long knots, long long xks, long long oks, const double* __restrict__ pp, long long pbs, long long pes, long long pks) {\n"
+          "batch, long long knots, long long xks, long long oks, const double* __restrict__ pp, long long pbs, long long pes, long long pks, long long pmod) {\n"
        << "    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;\n"
        << "    if (i >= batch) return;\n"
        // node i = (instance i / knots, knot i % knots): the shooting nodes of a batch of horizons, each instance a strided run of knots
        << "    const long long ib = knots > 1 ? i / knots : i, ik = i - ib * knots;\n"
        << "    const double* __restrict__ in = xp + ib * xbs + ik * xks;\n"
-       << "    const double* __restrict__ par = pp + ib * pbs + ik * pks;\n"
+       // (pmod > 0: the parameter operand holds pmod instances and instance ib reads number ib % pmod -- the candidates of a line search stacked instance-wise
+       // over one image of the instances' parameters, ungar_function_forward_zero_nodes_periodic)
+       << "    const double* __restrict__ par = pp + (pmod > 0 ? ib % pmod : ib) * pbs + ik * pks;\n"
        << "    double* __restrict__ out = outBase + ib * obs + ik * oks;\n";
     tape::Emitter em{g, inNames};
     const std::string body = em.Emit(slots);
@@ -705,10 +707,10 @@ int ungar_function_hessian_sparsity(const ungar_function* fn, const int32_t** ro
 }
 
 static int LaunchFn(const ungar_function* fn, const ungar_function::Kernels* kernels, const char* what, const ungar_operand* xp, const ungar_operand* out,
-                    int64_t batch, void* stream, int64_t knotsPerInstance = 1, const ungar_operand* parameters = nullptr) {
+                    int64_t batch, void* stream, int64_t knotsPerInstance = 1, const ungar_operand* parameters = nullptr, int64_t parameterPeriod = 0) {
     if (!fn || !xp || !out) return Fail(UNGAR_E_INVALID, std::string(what) + ": null argument");
     if (!kernels || kernels->empty()) return Fail(UNGAR_E_UNSUPPORTED, std::string(what) + ": kernel not available for function '" + fn->name + "' (derivative not enabled, or made with UNGAR_AMD_COMPILE_ONLY)");
-    if (batch < 0 || knotsPerInstance < 1) return Fail(UNGAR_E_INVALID, std::string(what) + ": negative batch or knots < 1");
+    if (batch < 0 || knotsPerInstance < 1 || parameterPeriod < 0) return Fail(UNGAR_E_INVALID, std::string(what) + ": negative batch, knots < 1 or a negative period");
     if (batch == 0) return UNGAR_OK;
     if (!xp->base || !out->base) return Fail(UNGAR_E_INVALID, std::string(what) + ": null operand base");
     const double* in = xp->base;
@@ -720,7 +722,8 @@ static int LaunchFn(const ungar_function* fn, const ungar_function::Kernels* ker
     const double* par = parameters ? parameters->base : xp->base + fn->n * xp->element_stride;
     long long pbs = parameters ? parameters->instance_stride : xp->instance_stride, pes = parameters ? parameters->element_stride : xp->element_stride,
               pks = parameters ? parameters->knot_stride : xp->knot_stride;
-    void* args[] = {&in, &xbs, &xes, &o, &obs, &oes, &b, &knots, &xks, &oks, &par, &pbs, &pes, &pks};
+    long long pmod = parameterPeriod;
+    void* args[] = {&in, &xbs, &xes, &o, &obs, &oes, &b, &knots, &xks, &oks, &par, &pbs, &pes, &pks, &pmod};
     const unsigned block = 64;
     for (hipFunction_t k : *kernels) {  // every chunk of the derivative writes its own outputs of the same operand
         const hipError_t e = hipModuleLaunchKernel(k, static_cast<unsigned>((batch + block - 1) / block), 1, 1, block, 1, 1, 0, static_cast<hipStream_t>(stream), args, nullptr);
@@ -762,6 +765,11 @@ int ungar_function_sparse_hessian_nodes(const ungar_function* fn, const ungar_op
 int ungar_function_forward_zero_nodes_split(const ungar_function* fn, const ungar_operand* x, const ungar_operand* p, const ungar_operand* y, int64_t count, int64_t knots, void* stream) {
     if (!p) return Fail(UNGAR_E_INVALID, "ungar_function_forward_zero_nodes_split: null argument");
     return LaunchFn(fn, fn ? &fn->kValue : nullptr, "ungar_function_forward_zero_nodes_split", x, y, count, stream, knots, p);
+}
+int ungar_function_forward_zero_nodes_periodic(const ungar_function* fn, const ungar_operand* x, const ungar_operand* p, int64_t parameter_instances, const ungar_operand* y,
+                                               int64_t count, int64_t knots, void* stream) {
+    if (!p || parameter_instances < 1) return Fail(UNGAR_E_INVALID, "ungar_function_forward_zero_nodes_periodic: null parameter operand or fewer than one parameter instance");
+    return LaunchFn(fn, fn ? &fn->kValue : nullptr, "ungar_function_forward_zero_nodes_periodic", x, y, count, stream, knots, p, parameter_instances);
 }
 int ungar_function_sparse_jacobian_nodes_split(const ungar_function* fn, const ungar_operand* x, const ungar_operand* p, const ungar_operand* jac, int64_t count, int64_t knots,
                                                void* stream) {

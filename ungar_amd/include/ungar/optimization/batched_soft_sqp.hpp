@@ -653,13 +653,14 @@ class BatchedSoftSQPOptimizer {
     /// c of row k + 1 <- carry(x, u, w, p of row k) for k < N of `instances` consecutive instances (rows in place).
     void CarryValues(real_t* rows, index_t instances, index_t unitFastestStride = 0, const ShootingSplitImage& split = ShootingSplitImage{}) {
         const index_t N = _p.horizon, nv = _p.RowSize();
-        if (split.candidates > 0 && unitFastestStride > 0) {  // variables from the image of each candidate, parameters from theirs: one launch per candidate
-            const index_t nodes = split.nodes;
-            for (index_t c = 0; c < split.candidates; ++c) {
-                const ungar_operand x{rows + _p.StateOffset() * unitFastestStride + c * nodes, N + 1, 1, unitFastestStride}, par{split.parameters, N + 1, 1, split.stride},
-                    ys{rows + c * nodes + 1, N + 1, 1, unitFastestStride};
-                Check(ungar_function_forward_zero_nodes_split(_p.carry->Handle(), &x, &par, &ys, nodes / (N + 1) * N, N, _stream));
-            }
+        if (split.candidates > 0 && unitFastestStride > 0) {
+            // variables from the stacked image (candidate c of instance i is stacked instance c * instances + i: one run of instances of N + 1 knots each), parameters
+            // from the one image of the instances: instance index modulo their number -- one launch (one per candidate was 12 launches of a few microseconds each in
+            // every later stage of the quadruped's line search)
+            const index_t nodes = split.nodes, perCandidate = nodes / (N + 1);
+            const ungar_operand x{rows + _p.StateOffset() * unitFastestStride, N + 1, 1, unitFastestStride}, par{split.parameters, N + 1, 1, split.stride},
+                ys{rows + 1, N + 1, 1, unitFastestStride};
+            Check(ungar_function_forward_zero_nodes_periodic(_p.carry->Handle(), &x, &par, perCandidate, &ys, split.candidates * perCandidate * N, N, _stream));
             return;
         }
         const ungar_operand xp = unitFastestStride > 0 ? ungar_operand{rows + _p.StateOffset() * unitFastestStride, N + 1, 1, unitFastestStride}
