@@ -1188,11 +1188,10 @@ namespace {
 /// The one-wavefront kernel for this shape, if the node fits its bounds (0: launched; -1: not applicable, the caller takes the workgroup kernel).
 template <int NZ, int NU, int NE>
 int LaunchAssembleWave(const ShootingAssembleArgs* a, void* stream) {
-    constexpr int ND = NZ + NU, NH = ND + 1, kImage = NH * (NH + 1) / 2 > NZ * NH ? NH * (NH + 1) / 2 : NZ * NH, kImagePadded = (kImage + 1) & ~1;
     const ShootingDims& d = a->d;
     if (d.nz() != NZ || d.nu != NU || a->ne != NE || a->eliminate != 1) return -1;
     if (a->nh > 64 || (a->nh > 0 && a->ph.nnz > 64) || a->pH.nnz > 256 || a->pg.nnz > 64 || a->pf.nnz > 256 || a->pe.nnz > 256 || (!d.carryInputs && a->pc.nnz > 128)) return -1;
-    const std::size_t lds = (kImagePadded + NE * (ND + 1) + 2 * static_cast<std::size_t>(a->nh) + NE) * sizeof(double) + (NE + 64) * sizeof(int);
+    const std::size_t lds = ShootingAssembleWaveLds(NZ, NU, NE, a->nh);
     const char* clocks = UNGAR_MEASUREMENT_SWITCH("UNGAR_AMD_ASSEMBLE_CLOCKS");
     if (clocks && clocks[0] == '1') hipLaunchKernelGGL((ShootingAssembleWaveKernel<NZ, NU, NE, true>), dim3(static_cast<unsigned>(d.batch * (d.N + 1))), dim3(64), lds, static_cast<hipStream_t>(stream), *a);
     else hipLaunchKernelGGL((ShootingAssembleWaveKernel<NZ, NU, NE, false>), dim3(static_cast<unsigned>(d.batch * (d.N + 1))), dim3(64), lds, static_cast<hipStream_t>(stream), *a);
@@ -1215,7 +1214,7 @@ static const ungar_amd::runtime::JitKernel* FactoryAssembleWave(int nz, int nu, 
     rq.source = "#include \"kernels/ocp_shooting_wave_kernel.hpp\"\n"
                 "extern \"C\" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(%W%, %W%))) void ungar_shooting_assemble_wave(const ungar_amd::kernels::ShootingAssembleArgs a) {\n"
                 "    ungar_amd::kernels::ShootingAssembleWaveBody<" + std::to_string(nz) + ", " + std::to_string(nu) + ", " + std::to_string(ne) + ">(a);\n}\n";
-    rq.occupancies = {1, 2, 4};
+    rq.occupancies = {1, 2, 3, 4};
     const ungar_amd::runtime::JitKernel* k = ungar_amd::runtime::GetKernel(rq);
     if (!k) {
         static bool reported = false;

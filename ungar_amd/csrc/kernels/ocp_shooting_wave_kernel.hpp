@@ -66,6 +66,20 @@ __device__ __forceinline__ void WaveMaxPair(unsigned long long& x, unsigned long
     y = ReadLaneU64(static_cast<unsigned long long>(__double_as_longlong(v)), 63);
 }
 
+/// The same for ONE quantity (the kernel with three nodes per SIMD: its issue gaps belong to the other wavefronts).
+__device__ __forceinline__ unsigned long long WaveMaxKey(unsigned long long x) {
+    double u = __longlong_as_double(static_cast<long long>(x));
+#define UNGAR_MAX_STAGE(CTRL, ROWS) u = MaxOfNonNegative(u, DppOrZero<CTRL, ROWS>(u));
+    UNGAR_MAX_STAGE(0xB1, 0xF)   // quad_perm [1, 0, 3, 2]
+    UNGAR_MAX_STAGE(0x4E, 0xF)   // quad_perm [2, 3, 0, 1]
+    UNGAR_MAX_STAGE(0x141, 0xF)  // row_half_mirror
+    UNGAR_MAX_STAGE(0x140, 0xF)  // row_mirror: every lane of a row holds the row's maximum
+    UNGAR_MAX_STAGE(0x142, 0xA)  // row_bcast:15 into rows 1 and 3
+    UNGAR_MAX_STAGE(0x143, 0xC)  // row_bcast:31 into rows 2 and 3
+#undef UNGAR_MAX_STAGE
+    return ReadLaneU64(static_cast<unsigned long long>(__double_as_longlong(u)), 63);
+}
+
 __device__ __forceinline__ int WaveMinInt(int v) {  // smallest of the 64 lanes' values (same stages as above), wave-uniform
 #define UNGAR_MIN_STAGE(CTRL, ROWS) v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, CTRL, ROWS, 0xF, false));
     UNGAR_MIN_STAGE(0xB1, 0xF)
@@ -155,16 +169,27 @@ __device__ __forceinline__ void WaveBarrierTerms(double* R, const Tri& tri, int 
     }
 }
 
+/// Doubles of the one LDS region: the tableau [E | e], packed W_e (with its homogeneous row), [A|B]_e -- whichever is largest.
+constexpr int ShootingAssembleWaveImage(int nz, int nu, int ne) {
+    const int nd = nz + nu, nh = nd + 1, tri = nh * (nh + 1) / 2, ab = nz * nh, tableau = ne * nh;
+    return tri > ab ? (tri > tableau ? tri : tableau) : (ab > tableau ? ab : tableau);
+}
+
 /// ONE WAVEFRONT per node, for stage problems whose equality tableau fits the lanes (NE <= 16 rows, ND + 1 <= 64 columns: the quadruped's 16 x 50) -- the
 /// workgroup kernel above spends ~9.8 k vector instructions per node, most of them index arithmetic in front of LDS operands that every 16 x 16 tile of the
 /// substitution fetches again (18 tiles x 5 operands x 4 k-steps), and a workgroup barrier between its sections.  Here
 ///   * the quadratic and the linear part travel together in HOMOGENEOUS coordinates z_e = [z; 1]:  W_e = [W w; w^T 0],  [A|B]_e = [A|B  b],  G_e = [G | g0] --
 ///     the substitution  z = (I - E_J G_e) z_e  is then  W_e' = W_e - W_e[:,J] G_e - G_e^T W_e[J,:] + G_e^T W_JJ G_e,  [A|B]_e' = [A|B]_e - [A|B]_e[:,J] G_e,  with
 ///     w' and b' as column ND of the tiles (three separate matrix-vector sections before);
-///   * the tiles of W_e and [A|B]_e live in accumulator registers, and the operands of the products are fetched ONCE per (tile row, k-step): by symmetry
-///     -W_e[:,J] in A layout is also -W_e[J,:] in B layout, and G_e in B layout is also G_e^T in A layout (lane 16 k + i in both);
+///   * the operands of the products are fetched ONCE per (tile row, k-step): by symmetry -W_e[:,J] in A layout is also -W_e[J,:] in B layout, and G_e in B layout
+///     is also G_e^T in A layout (lane 16 k + i in both);
 ///   * V = W_JJ G_e stays in the accumulators it was computed in: element r of a tile is the B operand of k-step r;
-///   * one LDS region holds the packed image of W_e, then -- once its tiles are in registers -- the image of [A|B]_e: 17 KB of LDS per node, two nodes per SIMD;
+///   * ONE LDS region holds, one after the other, the tableau [C | D | e] (scatter target of the sparse equality Jacobian; the elimination itself runs in
+///     registers), the reduced tableau (from which G_e is gathered into operand layout), the packed image of W_e (cost Hessian, barrier terms, regularisation;
+///     its tiles are fetched one at a time in front of their matrix instructions and go to memory from the accumulators) and the image of [A|B]_e:
+///     10.9 KB of LDS and <= 168 registers per node, THREE nodes per SIMD (the serial chains of a lone wavefront -- elimination, barrier terms -- leave the SIMD
+///     idle nine cycles in ten: the kernel's rate follows the number of resident wavefronts; with the tableau in a region of its own and every tile of W_e in
+///     registers before the region changed hands it was 17 KB, 256 registers, two per SIMD);
 ///   * results go to memory from the registers (the dummies' identity rows / zero columns are written, never formed).
 /// Same pivot rule, same arithmetic for the reduced rows, the pivots and the tiles of W' and [A|B]' as the kernel above (bitwise); w' and b' are summed by the
 /// matrix cores in a different order (rounding).
@@ -172,7 +197,7 @@ template <int NZ, int NU, int NE, bool CLOCKS = false>
 __device__ __forceinline__ void ShootingAssembleWaveBody(const ShootingAssembleArgs& a) {
     using f64x4 = __attribute__((__vector_size__(4 * sizeof(double)))) double;
     constexpr int ND = NZ + NU, NH = ND + 1, LD = ND + 1, TD = (NH + 15) / 16, TZ = (NZ + 15) / 16, KS = (NE + 3) / 4;
-    constexpr int kImage = NH * (NH + 1) / 2 > NZ * NH ? NH * (NH + 1) / 2 : NZ * NH;  // packed W_e, later [A|B]_e (row stride NH)
+    constexpr int kImage = ShootingAssembleWaveImage(NZ, NU, NE);  // the tableau, packed W_e, [A|B]_e (row stride NH): whichever is largest
     constexpr int kImagePadded = (kImage + 1) & ~1;
     static_assert(NE <= kRegisterRows && LD <= 64 && TD <= 4, "one wavefront holds the tableau");
     extern __shared__ double lds[];
@@ -184,8 +209,7 @@ __device__ __forceinline__ void ShootingAssembleWaveBody(const ShootingAssembleA
     const int nc = d.nc, nx = d.nx;
     const bool stage = k < d.N;
     double* R = lds;                       // kImagePadded
-    double* Ee = R + kImagePadded;         // NE x LD
-    double* d1 = Ee + NE * LD;             // nh
+    double* d1 = R + kImagePadded;         // nh
     double* d2 = d1 + a.nh;                // nh
     unsigned long long* rowScale = reinterpret_cast<unsigned long long*>(d2 + a.nh);  // NE
     int* pivL = reinterpret_cast<int*>(rowScale + NE);                                  // NE
@@ -216,8 +240,8 @@ __device__ __forceinline__ void ShootingAssembleWaveBody(const ShootingAssembleA
         bool valid;
     };
     // (MUBUF loads against resources of exactly the pattern's size: a lane beyond the pattern -- or a whole output that is absent -- reads zeros from the range
-    // check, unconditionally, and nothing is computed from a loaded value before every request is out.  Written with conditions, every slot became a branch
-    // around its loads with a full wait behind it: 15 round trips to memory in a row, 24-43 k of a node's ~85 k cycles.)
+    // check, unconditionally, and nothing is computed from a loaded value before every request of its batch is out.  Written with conditions, every slot became a
+    // branch around its loads with a full wait behind it: 15 round trips to memory in a row, 24-43 k of a node's ~85 k cycles.)
     auto resourceOver = [](const void* base, int bytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, base ? bytes : 0, 0x00020000); };
     auto loadInt = [](__amdgpu_buffer_rsrc_t rs, int byteOffset) { return __builtin_amdgcn_raw_buffer_load_b32(rs, byteOffset, 0, 0); };
     auto loadDouble = [](__amdgpu_buffer_rsrc_t rs, int byteOffset) { return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, byteOffset, 0, 0)); };
@@ -235,49 +259,155 @@ __device__ __forceinline__ void ShootingAssembleWaveBody(const ShootingAssembleA
     auto gradientTarget = [&](int, int c) { return tri(c, ND); };
     auto dynamicsTarget = [&](int r, int c) { return (nc + r) * NH + nc + c; };
     auto carryTarget = [&](int r, int c) { return r * NH + nc + c; };
-    auto equalityTarget = [&](int r, int c) { return (r << 8) | c; };  // (row kept: its scale is collected with the entry)
-    Raw rH[kSlotsH], rF[kSlotsF], rC[kSlotsC], rE[kSlotsE];
-#pragma unroll
-    for (int s = 0; s < kSlotsH; ++s) rH[s] = request(a.pH, a.lH, true, s);
-    const Raw rG = request(a.pg, a.lg, true, 0);
+    auto equalityTarget = [&](int r, int c) { return r * LD + c; };
+    // first batch: what the tableau, the image of W_e and the vectors need (the dynamics' values are asked for when the image of W_e has gone to memory: held
+    // from here on, they were 24 registers across the sections that need the most)
+    Raw rH[kSlotsH], rE[kSlotsE];
 #pragma unroll
     for (int s = 0; s < kSlotsE; ++s) rE[s] = request(a.pe, a.eJ, stage, s);
     const double residual = loadDouble(resourceOver(a.e ? a.e + nodeOff * NE : nullptr, stage ? NE * 8 : 0), lane * 8);
+#pragma unroll
+    for (int s = 0; s < kSlotsH; ++s) rH[s] = request(a.pH, a.lH, true, s);
+    const Raw rG = request(a.pg, a.lg, true, 0);
     const double hMine = loadDouble(resourceOver(a.h ? a.h + nodeOff * a.nh : nullptr, stage ? a.nh * 8 : 0), lane * 8);
     const Raw rI = request(a.ph, a.hJ, stage && a.nh > 0, 0);
-#pragma unroll
-    for (int s = 0; s < kSlotsF; ++s) rF[s] = request(a.pf, a.fJ, stage, s);
-#pragma unroll
-    for (int s = 0; s < kSlotsC; ++s) rC[s] = request(a.pc, a.cJ, stage && !d.carryInputs, s);
-    // lane i < NZ: b[i] = [0; f - x_next],  dz0[i] = [0; x_m - x_0]  (a lane below nc reaches before the function's values: out of range, zero)
-    const double fMine = loadDouble(resourceOver(a.f + nodeOff * nx, stage ? nx * 8 : 0), (lane - nc) * 8);
-    const double nextMine = loadDouble(resourceOver(RowOf(a.rows, d, b, stage ? k + 1 : k), stage ? NZ * 8 : 0), lane * 8);
+    // lane i < NZ: dz0[i] = [0; x_m - x_0]  (a lane below nc reaches before the values: out of range, zero)
     const double xmMine = loadDouble(resourceOver(a.xm + b * nx, k == 0 ? nx * 8 : 0), (lane - nc) * 8);
     const double row0Mine = loadDouble(resourceOver(RowOf(a.rows, d, b, 0), k == 0 ? NZ * 8 : 0), lane * 8);
-    // ---- images
-    const int zeroed = kImagePadded + NE * LD + 2 * a.nh;
-    for (int i = lane; i < zeroed; i += 64) lds[i] = 0.0;
-    if (lane < NE) rowScale[lane] = 0ull;
-    fence();
-    Entry eH[kSlotsH], eF[kSlotsF], eC[kSlotsC], eE[kSlotsE];
-#pragma unroll
-    for (int s = 0; s < kSlotsH; ++s) eH[s] = resolve(rH[s], hessianTarget);
-    const Entry eG = resolve(rG, gradientTarget);
-#pragma unroll
-    for (int s = 0; s < kSlotsE; ++s) eE[s] = resolve(rE[s], equalityTarget);
-#pragma unroll
-    for (int s = 0; s < kSlotsF; ++s) eF[s] = resolve(rF[s], dynamicsTarget);
-#pragma unroll
-    for (int s = 0; s < kSlotsC; ++s) eC[s] = resolve(rC[s], carryTarget);
-    const int inequalityRow = rI.valid ? rI.r : -1, inequalityColumn = rI.valid ? rI.c : 0;
-    const double inequalityValue = rI.value;
-    const double defect = lane >= nc && lane < NZ ? fMine - nextMine : 0.0, dz0 = lane >= nc && lane < NZ ? xmMine - row0Mine : 0.0;
-#pragma unroll
-    for (int s = 0; s < kSlotsH; ++s)
-        if (eH[s].target >= 0) R[eH[s].target] = eH[s].value;
-    if (eG.target >= 0) R[eG.target] = eG.value;
     double* W = a.W + nodeOff * ND * ND;
     double* w = a.w + nodeOff * ND;
+    auto masked = [](double v, bool keep) { return __longlong_as_double(keep ? __double_as_longlong(v) : 0ll); };
+    // ---- the tableau [C | D | e] in the region, then in registers: Gauss-Jordan, lane = column (the elimination job of the kernel above, statement by statement)
+    unsigned long long taken = 0ull;  // inputs that are pivots already (wave-uniform)
+    unsigned pivotRows = 0u;          // rows that took a pivot (wave-uniform)
+    double gm[KS][TD];                // G_e in B layout = G_e^T in A layout: row 4 ks + lk, column 16 tj + lj
+    bool stepHasPivot[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        stepHasPivot[ks] = false;
+#pragma unroll
+        for (int tj = 0; tj < TD; ++tj) gm[ks][tj] = 0.0;
+    }
+    if (stage) {
+        for (int i = lane; i < NE * LD; i += 64) R[i] = 0.0;
+        if (lane < NE) rowScale[lane] = 0ull;
+        fence();
+        auto offerScale = [&](int row, double value) {  // (non-negative doubles order like their bit patterns)
+            const unsigned long long bits = static_cast<unsigned long long>(__double_as_longlong(fabs(value)));
+            if (bits) atomicMax(&rowScale[row], bits);
+        };
+#pragma unroll
+        for (int s = 0; s < kSlotsE; ++s)
+            if (rE[s].valid) {
+                R[equalityTarget(rE[s].r, rE[s].c)] = rE[s].value;
+                offerScale(rE[s].r, rE[s].value);
+            }
+        if (lane < NE) {
+            R[lane * LD + ND] = residual;
+            offerScale(lane, residual);
+        }
+        fence();
+        double t[NE];
+#pragma unroll
+        for (int r = 0; r < NE; ++r) t[r] = lane < LD ? R[r * LD + lane] : 0.0;
+        mark();  // 1: first requests answered, tableau in registers
+        unsigned nonZeroRows = 0u;
+#pragma unroll
+        for (int r = 0; r < NE; ++r) nonZeroRows |= (__double_as_longlong(t[r]) << 1) != 0ll ? 1u << r : 0u;
+        nonZeroRows = WaveOr(nonZeroRows);
+        const double scaleOfMyRow = lane < NE ? __longlong_as_double(static_cast<long long>(rowScale[lane])) : 0.0;
+        int myPivot = -1;  // lane i < NE: pivot input of row i
+        const int myInput = lane - NZ;
+        const bool inputLane = lane >= NZ && lane < ND;
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            if ((nonZeroRows >> i) & 1u) {  // (uniform; an identically-zero row takes no pivot: -1)
+                // (the largest entry of the row decides in three places; each is a question every lane answers for its own entry -- x -> 1e-12 x rounds monotonically,
+                // so  best <= 1e-12 max_l |t_l|  is  best <= 1e-12 |t_l| for some l -- and one reduction over the lanes, 20 vector instructions, is left of two)
+                const double magnitude = fabs(t[i]);
+                const unsigned long long bits = static_cast<unsigned long long>(__double_as_longlong(magnitude));
+                const bool candidate = bits != 0ull && inputLane && !((taken >> (myInput & 63)) & 1ull);
+                const unsigned long long key = WaveMaxKey(candidate ? (bits & ~0xFFull) | static_cast<unsigned long long>(255 - myInput) : 0ull);
+                const double best = __longlong_as_double(static_cast<long long>(key & ~0xFFull));
+                int j = key ? 255 - static_cast<int>(key & 0xFFull) : -1;
+                if (__ballot(magnitude > 1e-12 * ReadLane(scaleOfMyRow, i)) == 0ull) {  // row maximum <= 1e-12 x the scale of the row as it was given
+                    j = -1;
+                } else {
+                    if (j >= 0 && __ballot(best <= 1e-12 * magnitude) != 0ull) j = -2;
+                    if (j == -1 && __ballot(bits != 0ull) != 0ull) j = -2;
+                }
+                if (lane == i) myPivot = j;
+                if (j >= 0) {
+                    taken |= 1ull << j;
+                    pivotRows |= 1u << i;
+                    const int J = NZ + j;
+                    // (hardware reciprocal + two Newton steps instead of the IEEE division -- the pivots' reciprocals are the serial chain of the elimination; the
+                    // multipliers of a pivot -- column J of the tableau, 16 registers of lane J -- reach the lanes through the LDS crossbar (ds_bpermute), in batches:
+                    // as v_readlane pairs they were 30 of a pivot's 137 vector instructions, and the vector unit is what three resident wavefronts compete for)
+                    const double pivot = ReadLane(t[i], J);
+                    double rpiv = __builtin_amdgcn_rcp(pivot);
+                    rpiv = __builtin_fma(__builtin_fma(-pivot, rpiv, 1.0), rpiv, rpiv);
+                    rpiv = __builtin_fma(__builtin_fma(-pivot, rpiv, 1.0), rpiv, rpiv);
+                    const double p = lane == J ? 1.0 : t[i] * rpiv;
+#pragma unroll
+                    for (int r0 = 0; r0 < NE; r0 += 8) {
+                        double m[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q)
+                            if (r0 + q < NE && r0 + q != i) m[q] = __shfl(t[r0 + q], J);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int q = 0; q < 8; ++q)
+                            if (r0 + q < NE && r0 + q != i) t[r0 + q] = t[r0 + q] - m[q] * p;  // (lane J: m - m * 1 = +0 exactly)
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    t[i] = p;
+                }
+            }
+        }
+        mark();  // 2: elimination
+        // the reduced rows, their residuals and pivots: to memory from the registers, and back to the region the operand G_e is gathered from
+        double* E = a.E + stageOff * NE * ND;
+#pragma unroll
+        for (int r = 0; r < NE; ++r) {
+            if (lane < ND) E[r * ND + lane] = t[r];
+            if (lane < LD) R[r * LD + lane] = t[r];
+            if (lane == ND) a.er[stageOff * NE + r] = t[r];
+        }
+        if (lane < NE) {
+            a.pivots[stageOff * NE + lane] = myPivot;
+            pivL[lane] = myPivot;
+        }
+        fence();
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {  // row t = 4 ks + lk of the tableau (rows without a pivot are masked out)
+            const int tRow = 4 * ks + lk;
+            stepHasPivot[ks] = tRow < NE && ((pivotRows >> tRow) & 1u) != 0u;
+#pragma unroll
+            for (int tj = 0; tj < TD; ++tj) {
+                const int col = 16 * tj + lj;
+                gm[ks][tj] = masked(R[(tRow < NE ? tRow : NE - 1) * LD + (col < LD ? col : LD - 1)], col < LD && stepHasPivot[ks]);
+            }
+        }
+        fence();
+        mark();  // 3: reduced rows stored, G_e in operand layout
+    }
+    // ---- the region becomes the packed image of W_e
+    for (int i = lane; i < kImagePadded; i += 64) R[i] = 0.0;
+    if (stage && lane < a.nh) {
+        d1[lane] = BarrierD1(a.barrier, -hMine);
+        d2[lane] = BarrierD2(a.barrier, -hMine);
+    }
+    fence();
+#pragma unroll
+    for (int s = 0; s < kSlotsH; ++s) {
+        const Entry e = resolve(rH[s], hessianTarget);
+        if (e.target >= 0) R[e.target] = e.value;
+    }
+    {
+        const Entry e = resolve(rG, gradientTarget);
+        if (e.target >= 0) R[e.target] = e.value;
+    }
     if (!stage) {  // knot N: the terminal cost as it is (regularised over its state), no dynamics, no rows
         fence();
         if (lane >= nc && lane < NZ) R[tri(lane, lane)] += a.regularization;
@@ -290,131 +420,33 @@ __device__ __forceinline__ void ShootingAssembleWaveBody(const ShootingAssembleA
         if (lane < ND) w[lane] = R[tri(lane, ND)];
         return;
     }
-    auto offerScale = [&](int row, double value) {  // (non-negative doubles order like their bit patterns)
-        const unsigned long long bits = static_cast<unsigned long long>(__double_as_longlong(fabs(value)));
-        if (bits) atomicMax(&rowScale[row], bits);
-    };
-#pragma unroll
-    for (int s = 0; s < kSlotsE; ++s)
-        if (eE[s].target >= 0) {
-            Ee[(eE[s].target >> 8) * LD + (eE[s].target & 255)] = eE[s].value;
-            offerScale(eE[s].target >> 8, eE[s].value);
-        }
-    if (lane < NE) {
-        Ee[lane * LD + ND] = residual;
-        offerScale(lane, residual);
-    }
-    if (lane < a.nh) {
-        d1[lane] = BarrierD1(a.barrier, -hMine);
-        d2[lane] = BarrierD2(a.barrier, -hMine);
-    }
+    const int inequalityRow = rI.valid ? rI.r : -1, inequalityColumn = rI.valid ? rI.c : 0;
+    const double inequalityValue = rI.value;
+    const double dz0 = lane >= nc && lane < NZ ? xmMine - row0Mine : 0.0;
+    if (k == 0 && lane < NZ) a.dz0[b * NZ + lane] = dz0;
     fence();
-    mark();  // 1: requests answered, images zeroed and filled
+    mark();  // 4: image of W_e filled
     // ---- barrier terms  W += J_h^T diag(b''(-h)) J_h,  w -= J_h^T b'(-h)  from the sparse inequality Jacobian
     if (a.nh > 0) WaveBarrierTerms(R, tri, ND, a.nh, d1, d2, pairTable, lane, a.ph.nnz, inequalityRow, inequalityColumn, inequalityValue, a.ph.cols, a.hJ + nodeOff * a.ph.nnz);
     if (lane >= nc && lane < ND) R[tri(lane, lane)] += a.regularization;  // the reference's 1e-6 I over its decision variables (soft_sqp.hpp:149-151)
     fence();
-    mark();  // 2: barrier terms, regularisation
-    // ---- Gauss-Jordan on [C | D | e], lane = column, the rows in registers (the elimination job of the kernel above, statement by statement)
-    double t[NE];
-#pragma unroll
-    for (int r = 0; r < NE; ++r) t[r] = lane < LD ? Ee[r * LD + lane] : 0.0;
-    unsigned nonZeroRows = 0u;
-#pragma unroll
-    for (int r = 0; r < NE; ++r) nonZeroRows |= (__double_as_longlong(t[r]) << 1) != 0ll ? 1u << r : 0u;
-    nonZeroRows = WaveOr(nonZeroRows);
-    const double scaleOfMyRow = lane < NE ? __longlong_as_double(static_cast<long long>(rowScale[lane])) : 0.0;
-    unsigned long long taken = 0ull;  // inputs that are pivots already (wave-uniform)
-    unsigned pivotRows = 0u;          // rows that took a pivot (wave-uniform)
-    int myPivot = -1;                 // lane i < NE: pivot input of row i
-    const int myInput = lane - NZ;
-    const bool inputLane = lane >= NZ && lane < ND;
-#pragma unroll
-    for (int i = 0; i < NE; ++i) {
-        if ((nonZeroRows >> i) & 1u) {  // (uniform; an identically-zero row takes no pivot: -1)
-            const unsigned long long bits = static_cast<unsigned long long>(__double_as_longlong(fabs(t[i])));
-            const bool candidate = bits != 0ull && inputLane && !((taken >> (myInput & 63)) & 1ull);
-            unsigned long long key = candidate ? (bits & ~0xFFull) | static_cast<unsigned long long>(255 - myInput) : 0ull, rowBits = bits;
-            WaveMaxPair(key, rowBits);
-            const double best = __longlong_as_double(static_cast<long long>(key & ~0xFFull)), rowMax = __longlong_as_double(static_cast<long long>(rowBits));
-            int j = key ? 255 - static_cast<int>(key & 0xFFull) : -1;
-            if (rowMax <= 1e-12 * ReadLane(scaleOfMyRow, i)) {
-                j = -1;
-            } else {
-                if (j >= 0 && best <= 1e-12 * rowMax) j = -2;
-                if (j == -1 && rowMax > 0.0) j = -2;
-            }
-            if (lane == i) myPivot = j;
-            if (j >= 0) {
-                taken |= 1ull << j;
-                pivotRows |= 1u << i;
-                const int J = NZ + j;
-                // (hardware reciprocal + two Newton steps instead of the IEEE division -- the pivots' reciprocals are the serial chain of the elimination; the
-                // multipliers of a pivot are read in batches, then applied: one scalar register pair reused for every row made each update wait for the previous one)
-                const double pivot = ReadLane(t[i], J);
-                double rpiv = __builtin_amdgcn_rcp(pivot);
-                rpiv = __builtin_fma(__builtin_fma(-pivot, rpiv, 1.0), rpiv, rpiv);
-                rpiv = __builtin_fma(__builtin_fma(-pivot, rpiv, 1.0), rpiv, rpiv);
-                const double p = lane == J ? 1.0 : t[i] * rpiv;
-#pragma unroll
-                for (int r0 = 0; r0 < NE; r0 += 8) {
-                    double m[8];
-#pragma unroll
-                    for (int q = 0; q < 8; ++q)
-                        if (r0 + q < NE && r0 + q != i) m[q] = ReadLane(t[r0 + q], J);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int q = 0; q < 8; ++q)
-                        if (r0 + q < NE && r0 + q != i) t[r0 + q] = t[r0 + q] - m[q] * p;  // (lane J: m - m * 1 = +0 exactly)
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                t[i] = p;
-            }
-        }
-    }
-    mark();  // 3: elimination
-    // the reduced rows, their residuals and pivots: to memory from the registers, and back to the LDS tableau the operands below are gathered from
-    {
-        double* E = a.E + stageOff * NE * ND;
-#pragma unroll
-        for (int r = 0; r < NE; ++r) {
-            if (lane < ND) E[r * ND + lane] = t[r];
-            if (lane < LD) Ee[r * LD + lane] = t[r];
-            if (lane == ND) a.er[stageOff * NE + r] = t[r];
-        }
-        if (lane < NE) {
-            a.pivots[stageOff * NE + lane] = myPivot;
-            pivL[lane] = myPivot;
-        }
-    }
-    fence();
-    mark();  // 4: reduced rows stored
+    mark();  // 5: barrier terms, regularisation
     auto isPivot = [&](int c) { return c >= NZ && c < ND && ((taken >> ((c - NZ) & 63)) & 1ull) != 0ull; };
-    auto masked = [](double v, bool keep) { return __longlong_as_double(keep ? __double_as_longlong(v) : 0ll); };
-    // ---- operands, once per (tile row, k-step).  Row t = 4 ks + lk of the tableau, J_t its pivot input (rows without a pivot are masked out)
+    // ---- operands out of the image, once per (tile row, k-step): J_t the pivot input of row t = 4 ks + lk
     int pivotOfStep[KS];
-    bool stepHasPivot[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         const int tRow = 4 * ks + lk;
-        stepHasPivot[ks] = tRow < NE && ((pivotRows >> tRow) & 1u) != 0u;
         const int j = pivL[tRow < NE ? tRow : NE - 1];
         pivotOfStep[ks] = NZ + (stepHasPivot[ks] ? j : 0);
     }
     const bool anyPivot = pivotRows != 0u;
-    double gm[KS][TD];   // G_e in B layout = G_e^T in A layout: row 4 ks + lk, column 16 tj + lj
     double a1m[TD][KS];  // -W_e[16 ti + lj][J_t] in A layout = -W_e[J_t][16 tj + lj] in B layout
     double wjj[KS];      // W[J_lj][J_t]
     const int pivotOfMyRow = NZ + (lj < NE && ((pivotRows >> lj) & 1u) ? pivL[lj < NE ? lj : 0] : 0);
     const bool myRowHasPivot = lj < NE && ((pivotRows >> lj) & 1u) != 0u;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-#pragma unroll
-        for (int tj = 0; tj < TD; ++tj) {
-            const int col = 16 * tj + lj, tRow = 4 * ks + lk;
-            const bool in = col < LD && stepHasPivot[ks];
-            gm[ks][tj] = masked(Ee[(tRow < NE ? tRow : NE - 1) * LD + (col < LD ? col : LD - 1)], in);
-        }
 #pragma unroll
         for (int ti = 0; ti < TD; ++ti) {
             const int row = 16 * ti + lj;
@@ -423,62 +455,26 @@ __device__ __forceinline__ void ShootingAssembleWaveBody(const ShootingAssembleA
         }
         wjj[ks] = masked(R[sym(pivotOfMyRow, pivotOfStep[ks])], myRowHasPivot && stepHasPivot[ks]);
     }
-    // ---- the tiles of W_e (on and above the diagonal), element r: row 16 ti + lk + 4 r, column 16 tj + lj; below the diagonal of a diagonal tile the transposed entry
-    f64x4 Wt[TD * (TD + 1) / 2];
+    // ---- V = W_JJ G_e; the B operand of the second product of a tile is V_t[c] - W[J_t][c]
+    double vb[TD][KS];
+    {
+        f64x4 Vt[TD];
 #pragma unroll
-    for (int tj = 0; tj < TD; ++tj)
+        for (int tj = 0; tj < TD; ++tj) Vt[tj] = f64x4{0.0, 0.0, 0.0, 0.0};
+        if (anyPivot) {  // (uniform)
 #pragma unroll
-        for (int ti = 0; ti <= tj; ++ti)
+            for (int tj = 0; tj < TD; ++tj)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 16 * ti + lk + 4 * r, col = 16 * tj + lj;
-                const bool in = row < NH && col < NH;
-                const int rc = row < NH ? row : NH - 1, cc = col < NH ? col : NH - 1;
-                Wt[tj * (tj + 1) / 2 + ti][r] = masked(R[ti == tj ? sym(rc, cc) : tri(rc, cc)], in);
-            }
-    fence();
-    mark();  // 5: operands and tiles of W_e in registers
-    // ---- the region becomes the image of [A|B]_e = [A|B  b] (row stride NH)
-    for (int i = lane; i < NZ * NH; i += 64) R[i] = 0.0;
-    fence();
-#pragma unroll
-    for (int s = 0; s < kSlotsF; ++s)
-        if (eF[s].target >= 0) R[eF[s].target] = eF[s].value;
-    if (d.carryInputs) {
-        if (lane < nc) R[lane * NH + NZ + lane] = 1.0;
-    } else {
-#pragma unroll
-        for (int s = 0; s < kSlotsC; ++s)
-            if (eC[s].target >= 0) R[eC[s].target] = eC[s].value;
-    }
-    if (lane < NZ) R[lane * NH + ND] = defect;
-    if (k == 0 && lane < NZ) a.dz0[b * NZ + lane] = dz0;
-    fence();
-    mark();  // 6: image of [A|B]_e
-    // ---- V = W_JJ G_e, then W_e' tile by tile
-    f64x4 Vt[TD];
-#pragma unroll
-    for (int tj = 0; tj < TD; ++tj) Vt[tj] = f64x4{0.0, 0.0, 0.0, 0.0};
-    if (anyPivot) {  // (uniform)
+                for (int ks = 0; ks < KS; ++ks) Vt[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(wjj[ks], gm[ks][tj], Vt[tj], 0, 0, 0);
+        }
 #pragma unroll
         for (int tj = 0; tj < TD; ++tj)
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) Vt[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(wjj[ks], gm[ks][tj], Vt[tj], 0, 0, 0);
-#pragma unroll
-        for (int tj = 0; tj < TD; ++tj)
-#pragma unroll
-            for (int ti = 0; ti <= tj; ++ti) {
-                f64x4 acc = Wt[tj * (tj + 1) / 2 + ti], acc2 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1m[ti][ks], gm[ks][tj], acc, 0, 0, 0);                  // - W[a][J_t] G_t[c]
-                    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(gm[ks][ti], Vt[tj][ks] + a1m[tj][ks], acc2, 0, 0, 0);  // + G_t[a] (V_t[c] - W[J_t][c])
-                }
-                Wt[tj * (tj + 1) / 2 + ti] = acc + acc2;
-            }
+            for (int ks = 0; ks < KS; ++ks) vb[tj][ks] = Vt[tj][ks] + a1m[tj][ks];
     }
-    mark();  // 7: products of W_e'
-    // W' and w' to memory; the eliminated inputs are decoupled dummies: identity rows / columns, zero gradient
+    mark();  // 6: operands, V
+    // ---- W_e' tile by tile (on and above the diagonal; element r: row 16 ti + lk + 4 r, column 16 tj + lj; below the diagonal of a diagonal tile the transposed
+    // entry): out of the image, through the matrix cores, to memory.  The eliminated inputs are decoupled dummies: identity rows / columns, zero gradient.
     bool rowPivot[TD][4], colPivot[TD];
 #pragma unroll
     for (int ti = 0; ti < TD; ++ti) {
@@ -489,17 +485,64 @@ __device__ __forceinline__ void ShootingAssembleWaveBody(const ShootingAssembleA
 #pragma unroll
     for (int tj = 0; tj < TD; ++tj)
 #pragma unroll
-        for (int ti = 0; ti <= tj; ++ti)
+        for (int ti = 0; ti <= tj; ++ti) {
+            f64x4 acc, acc2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * ti + lk + 4 * r, col = 16 * tj + lj;
+                const bool in = row < NH && col < NH;
+                const int rc = row < NH ? row : NH - 1, cc = col < NH ? col : NH - 1;
+                acc[r] = masked(R[ti == tj ? sym(rc, cc) : tri(rc, cc)], in);
+            }
+            if (anyPivot) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1m[ti][ks], gm[ks][tj], acc, 0, 0, 0);   // - W[a][J_t] G_t[c]
+                    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(gm[ks][ti], vb[tj][ks], acc2, 0, 0, 0);  // + G_t[a] (V_t[c] - W[J_t][c])
+                }
+                acc = acc + acc2;
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 16 * ti + lk + 4 * r, col = 16 * tj + lj;
                 if (row > col || row >= ND || col > ND) continue;
                 const bool dummy = rowPivot[ti][r] || colPivot[tj];
-                const double v = dummy ? (row == col ? 1.0 : 0.0) : Wt[tj * (tj + 1) / 2 + ti][r];
+                const double v = dummy ? (row == col ? 1.0 : 0.0) : acc[r];
                 if (col == ND) w[row] = v;
                 else W[row * ND + col] = v;
             }
-    mark();  // 8: W', w' stored
+        }
+    mark();  // 7: W', w' stored
+    // ---- second batch of requests; the region becomes the image of [A|B]_e = [A|B  b] (row stride NH)
+    fence();
+    Raw rF[kSlotsF], rC[kSlotsC];
+#pragma unroll
+    for (int s = 0; s < kSlotsF; ++s) rF[s] = request(a.pf, a.fJ, true, s);
+#pragma unroll
+    for (int s = 0; s < kSlotsC; ++s) rC[s] = request(a.pc, a.cJ, !d.carryInputs, s);
+    // lane i < NZ: b[i] = [0; f - x_next]
+    const double fMine = loadDouble(resourceOver(a.f + nodeOff * nx, nx * 8), (lane - nc) * 8);
+    const double nextMine = loadDouble(resourceOver(RowOf(a.rows, d, b, k + 1), NZ * 8), lane * 8);
+    fence();
+    for (int i = lane; i < NZ * NH; i += 64) R[i] = 0.0;
+    fence();
+#pragma unroll
+    for (int s = 0; s < kSlotsF; ++s) {
+        const Entry e = resolve(rF[s], dynamicsTarget);
+        if (e.target >= 0) R[e.target] = e.value;
+    }
+    if (d.carryInputs) {
+        if (lane < nc) R[lane * NH + NZ + lane] = 1.0;
+    } else {
+#pragma unroll
+        for (int s = 0; s < kSlotsC; ++s) {
+            const Entry e = resolve(rC[s], carryTarget);
+            if (e.target >= 0) R[e.target] = e.value;
+        }
+    }
+    if (lane < NZ) R[lane * NH + ND] = lane >= nc ? fMine - nextMine : 0.0;
+    fence();
+    mark();  // 8: image of [A|B]_e
     // ---- [A|B]_e' = [A|B]_e - [A|B]_e[:,J] G_e
     double aAB[TZ][KS];
     f64x4 ABt[TZ][TD];
@@ -544,22 +587,25 @@ __device__ __forceinline__ void ShootingAssembleWaveBody(const ShootingAssembleA
         __builtin_amdgcn_s_waitcnt(0);
         mark();  // 10: [A|B]', b' stored
         if (lane == 0 && (node == 1 || node == d.batch * (d.N + 1) / 2 + 1))
-            printf("[assemble wave clocks] node %lld (%d pivots): requests+images %llu, barrier terms %llu, elimination %llu, rows stored %llu, operands+tiles %llu, [A|B] image %llu, W products %llu, W stored %llu, [A|B] tiles+products %llu, [A|B] stored %llu; total %llu\n",
+            printf("[assemble wave clocks] node %lld (%d pivots): requests+tableau %llu, elimination %llu, rows stored+G_e %llu, W image %llu, barrier terms %llu, operands+V %llu, W tiles: products+stores %llu, [A|B] requests+image %llu, [A|B] tiles+products %llu, [A|B] stored %llu; total %llu\n",
                    node, __popc(pivotRows), marks[1] - marks[0], marks[2] - marks[1], marks[3] - marks[2], marks[4] - marks[3], marks[5] - marks[4], marks[6] - marks[5], marks[7] - marks[6], marks[8] - marks[7],
                    marks[9] - marks[8], marks[10] - marks[9], marks[10] - marks[0]);
     }
 }
 
+#ifndef UNGAR_ASSEMBLE_WAVE_EU
+#define UNGAR_ASSEMBLE_WAVE_EU 3  // (measurement knob: tools/make_shooting_variants.sh)
+#endif
 template <int NZ, int NU, int NE, bool CLOCKS = false>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void ShootingAssembleWaveKernel(const ShootingAssembleArgs a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(UNGAR_ASSEMBLE_WAVE_EU, UNGAR_ASSEMBLE_WAVE_EU))) void ShootingAssembleWaveKernel(const ShootingAssembleArgs a) {
     ShootingAssembleWaveBody<NZ, NU, NE, CLOCKS>(a);
 }
 
 /// Sizes the template can be instantiated for (the tableau [E | e] and the homogeneous row of W_e in one wavefront) and its dynamic LDS.
 constexpr bool ShootingAssembleWaveFits(int nz, int nu, int ne) { return ne >= 1 && ne <= kRegisterRows && nz >= 1 && nu >= 1 && nz + nu + 1 <= 64; }
 constexpr std::size_t ShootingAssembleWaveLds(int nz, int nu, int ne, int nh) {
-    const int nd = nz + nu, NH = nd + 1, image = NH * (NH + 1) / 2 > nz * NH ? NH * (NH + 1) / 2 : nz * NH, padded = (image + 1) & ~1;
-    return (static_cast<std::size_t>(padded) + static_cast<std::size_t>(ne) * (nd + 1) + 2 * static_cast<std::size_t>(nh) + static_cast<std::size_t>(ne)) * sizeof(double) + (static_cast<std::size_t>(ne) + 64) * sizeof(int);
+    const int padded = (ShootingAssembleWaveImage(nz, nu, ne) + 1) & ~1;
+    return (static_cast<std::size_t>(padded) + 2 * static_cast<std::size_t>(nh) + static_cast<std::size_t>(ne)) * sizeof(double) + (static_cast<std::size_t>(ne) + 64) * sizeof(int);
 }
 
 }  // namespace
