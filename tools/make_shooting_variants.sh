@@ -19,3 +19,4 @@ variant clocks -DUNGAR_SHOOTING_CLOCKS
 variant eu3_k4 -DUNGAR_ASSEMBLE_WAVES_PER_EU=3 -DUNGAR_ASSEMBLE_K_GROUP=4
 variant eu4_k4 -DUNGAR_ASSEMBLE_WAVES_PER_EU=4 -DUNGAR_ASSEMBLE_K_GROUP=4
 variant eu3_k2 -DUNGAR_ASSEMBLE_WAVES_PER_EU=3 -DUNGAR_ASSEMBLE_K_GROUP=2
+variant wave_eu2 -DUNGAR_ASSEMBLE_WAVE_EU=2  # the one-wavefront kernel held at two nodes per SIMD (its code at three: 10.9 KB of LDS, <= 168 registers)

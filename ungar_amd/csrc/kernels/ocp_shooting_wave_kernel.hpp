@@ -482,10 +482,25 @@ __device__ __forceinline__ void ShootingAssembleWaveBody(const ShootingAssembleA
 #pragma unroll
         for (int r = 0; r < 4; ++r) rowPivot[ti][r] = isPivot(16 * ti + lk + 4 * r);
     }
+    Raw rF[kSlotsF], rC[kSlotsC];
+    double fMine = 0.0, nextMine = 0.0;
 #pragma unroll
-    for (int tj = 0; tj < TD; ++tj)
+    for (int ti = 0; ti < TD; ++ti)  // (tile row by tile row: neighbouring tiles write neighbouring pieces of the same rows of W')
 #pragma unroll
-        for (int ti = 0; ti <= tj; ++ti) {
+        for (int tj = ti; tj < TD; ++tj) {
+            if (tj == TD - 1 && ti == (TD > 2 ? TD - 2 : 0)) {
+                // second batch of requests, in front of the last two tiles: the operands of the earlier tile rows and columns are dead by now, and the round trip to
+                // memory (2-3 k cycles) is over when the image of [A|B]_e is filled
+                fence();
+#pragma unroll
+                for (int s = 0; s < kSlotsF; ++s) rF[s] = request(a.pf, a.fJ, true, s);
+#pragma unroll
+                for (int s = 0; s < kSlotsC; ++s) rC[s] = request(a.pc, a.cJ, !d.carryInputs, s);
+                // lane i < NZ: b[i] = [0; f - x_next]
+                fMine = loadDouble(resourceOver(a.f + nodeOff * nx, nx * 8), (lane - nc) * 8);
+                nextMine = loadDouble(resourceOver(RowOf(a.rows, d, b, k + 1), NZ * 8), lane * 8);
+                fence();
+            }
             f64x4 acc, acc2 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -513,16 +528,7 @@ __device__ __forceinline__ void ShootingAssembleWaveBody(const ShootingAssembleA
             }
         }
     mark();  // 7: W', w' stored
-    // ---- second batch of requests; the region becomes the image of [A|B]_e = [A|B  b] (row stride NH)
-    fence();
-    Raw rF[kSlotsF], rC[kSlotsC];
-#pragma unroll
-    for (int s = 0; s < kSlotsF; ++s) rF[s] = request(a.pf, a.fJ, true, s);
-#pragma unroll
-    for (int s = 0; s < kSlotsC; ++s) rC[s] = request(a.pc, a.cJ, !d.carryInputs, s);
-    // lane i < NZ: b[i] = [0; f - x_next]
-    const double fMine = loadDouble(resourceOver(a.f + nodeOff * nx, nx * 8), (lane - nc) * 8);
-    const double nextMine = loadDouble(resourceOver(RowOf(a.rows, d, b, k + 1), NZ * 8), lane * 8);
+    // ---- the region becomes the image of [A|B]_e = [A|B  b] (row stride NH)
     fence();
     for (int i = lane; i < NZ * NH; i += 64) R[i] = 0.0;
     fence();
