@@ -45,6 +45,9 @@ cp_if gpurun_out/sqp_bench.log                profiles/${tag}_sqp_quadrotor_timi
 cp_if gpurun_out/sqp_srbd.json                profiles/${tag}_sqp_srbd_timing.json
 cp_if gpurun_out/riccati_sizes.log            profiles/${tag}_riccati_sizes.log
 cp_if gpurun_out/assemble_ab.log              profiles/${tag}_assemble_ab.log
+cp_if gpurun_out/assemble_occupancy.log       profiles/${tag}_assemble_occupancy.log
+cp_if gpurun_out/assemble_occupancy_kernel_stats.csv profiles/${tag}_assemble_occupancy_kernel_stats.csv
+cp_if gpurun_out/assemble_wave_sq_counters.log profiles/${tag}_assemble_wave_sq_counters.log
 cp_if gpurun_out/assemble_ab_kernel_stats.csv profiles/${tag}_assemble_ab_kernel_stats.csv
 cp_if gpurun_out/riccati_sizes_clocks.log     profiles/${tag}_riccati_phase_clocks.log
 cp_if gpurun_out/batched_quadrotor_kernel_stats.csv profiles/${tag}_batched_quadrotor_kernel_stats.csv

@@ -56,6 +56,9 @@ timeout 300 python tools/bench_riccati_sizes.py 4096 2>/dev/null | grep nx | tee
 bash tools/gpu_batched_sqp_profile.sh 4096 2>&1 | tail -30
 echo "== shooting assembly kernel: wavefront-specialised sections against the generic ones (bits, wall clock, kernel split, section clocks)"
 bash tools/gpu_assemble_ab.sh 2>&1 | grep -vE "^iteration [12] instance" | tail -40 | tee gpurun_out/assemble_ab.log | cut -c1-300
+echo "== one-wavefront assembly kernel: three nodes per SIMD against the previous tree's kernel (wall clock, section clocks, kernel split, SQ counters)"
+bash tools/gpu_assemble_occupancy.sh 2>&1 | tee gpurun_out/assemble_occupancy.log | cut -c1-300
+bash tools/gpu_pmc_assemble_wave.sh > /dev/null 2>&1; cat gpurun_out/assemble_wave_sq_counters.log
 echo "== rocprofv3 kernel trace + HBM counters (separate passes)"
 rm -rf gpurun_out/prof gpurun_out/pmc1 gpurun_out/pmc2
 B="python bench.py --no-cpu-baseline --no-sub-results"

@@ -20,3 +20,12 @@ variant eu3_k4 -DUNGAR_ASSEMBLE_WAVES_PER_EU=3 -DUNGAR_ASSEMBLE_K_GROUP=4
 variant eu4_k4 -DUNGAR_ASSEMBLE_WAVES_PER_EU=4 -DUNGAR_ASSEMBLE_K_GROUP=4
 variant eu3_k2 -DUNGAR_ASSEMBLE_WAVES_PER_EU=3 -DUNGAR_ASSEMBLE_K_GROUP=2
 variant wave_eu2 -DUNGAR_ASSEMBLE_WAVE_EU=2  # the one-wavefront kernel held at two nodes per SIMD (its code at three: 10.9 KB of LDS, <= 168 registers)
+# The kernel of an earlier tree for the A/B of tools/gpu_assemble_occupancy.sh / gpu_pmc_assemble_wave.sh: build/variants/shooting_old/libungar_amd.so = this tree's
+# objects with ocp_shooting.hip compiled (measurement flavour) from the sources of commit $1 (default a164aea: the one-wavefront assembly kernel at two nodes per SIMD).
+old_commit=${1:-a164aea}
+rm -rf build/exp/old && mkdir -p build/exp/old build/variants/shooting_old
+git archive "$old_commit" ungar_amd/csrc include | tar -x -C build/exp/old
+hipcc --offload-arch=gfx950 -O3 -std=c++20 -fPIC -Wno-unused-result -DUNGAR_AMD_MEASUREMENT -c build/exp/old/ungar_amd/csrc/kernels/ocp_shooting.hip -o build/exp/ocp_shooting_old.o
+objs=$( (ls build/measurement/*.o | grep -v /ocp_shooting.o; for o in build/*.o; do [ -f build/measurement/$(basename $o) ] || echo $o; done) )
+hipcc --offload-arch=gfx950 -shared -fPIC -o build/variants/shooting_old/libungar_amd.so $objs build/exp/ocp_shooting_old.o
+echo built build/variants/shooting_old/libungar_amd.so from $old_commit
