@@ -337,10 +337,11 @@ def test_one_wavefront_assembly_of_problems_without_equality_rows_on_random_patt
 
 # (stage sizes nx, nu, carried, equality rows, inequality rows; expected ungar_shooting_assemble_route): the reference's quadruped shape is compiled into the
 # library (1); every other shape the kernel template fits is instantiated by the kernel factory on first use (2)
-WAVE_SHAPES = [(13, 24, 12, 16, 12, 1), (8, 9, 12, 4, 5, 2), (10, 3, 0, 2, 0, 2), (30, 12, 5, 7, 9, 2)]
+# the last shape: two states, 20 inputs, 16 rows -- the tableau [E | e] (16 x 23) is the largest of the images that share the kernel's one LDS region (packed W_e: 276)
+WAVE_SHAPES = [(13, 24, 12, 16, 12, 1), (8, 9, 12, 4, 5, 2), (10, 3, 0, 2, 0, 2), (30, 12, 5, 7, 9, 2), (2, 20, 0, 16, 3, 2)]
 
 
-@pytest.mark.parametrize("seed,shape", [(1, WAVE_SHAPES[0]), (2, WAVE_SHAPES[0]), (3, WAVE_SHAPES[0]), (4, WAVE_SHAPES[1]), (5, WAVE_SHAPES[2]), (6, WAVE_SHAPES[3])])
+@pytest.mark.parametrize("seed,shape", [(1, WAVE_SHAPES[0]), (2, WAVE_SHAPES[0]), (3, WAVE_SHAPES[0]), (4, WAVE_SHAPES[1]), (5, WAVE_SHAPES[2]), (6, WAVE_SHAPES[3]), (7, WAVE_SHAPES[4])])
 def test_one_wavefront_assembly_with_equality_rows_on_random_patterns(seed, shape, monkeypatch, measurement_library):
     """ShootingAssembleWaveKernel<NZ, NU, NE> -- compiled in for quadruped-shaped stage nodes (12 carried + 13 states, 24 inputs, 16 equality rows eliminated per
     node), instantiated at run time by the kernel factory for the other shapes (20 + 9 with 4 rows, 10 + 3 with 2 rows and no inequality, 35 + 12 with 7 rows) -- against the
